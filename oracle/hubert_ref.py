@@ -1,0 +1,234 @@
+"""fp32 torch-CPU restatement of the HuBERT speech encoder as the reference runs it.
+
+ORACLE / TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows, in structure, the two monkey-patched functions of the reference
+(avssl/module/speech_encoder_plus.py:29-64 ``extract_features`` and :67-107
+``customHubertForward``) and the wrapper forward (:506-518, :520-634).  The arithmetic below
+those call sites lives in fairseq @ b5a039c292facba9c73f59ff34621ec131d82341
+(requirements.txt:6), which is NOT in /root/reference nor installed in this image; it is
+restated from its published algorithm:
+
+* ConvFeatureExtractionModel: 7x Conv1d(512, k, s) (k=(10,3,3,3,3,2,2), s=(5,2,2,2,2,2,2)),
+  mode "default": GroupNorm(512 groups, 512 ch, eps 1e-5, affine) after conv 0 only, no conv bias;
+  mode "layer_norm": LayerNorm(512) after every conv, conv bias.  GELU(erf) after each.
+* HubertModel: LayerNorm(512) -> forward_padding_mask (chunk .all()) -> Linear 512->D.
+* TransformerEncoder: zero padded frames; pos_conv = Conv1d(D, D, 128, padding 64, groups 16)
+  (weight-norm folded into a plain weight), SamePad drops the last frame, GELU; x += pos;
+  LayerNorm (post-LN variant only); NL x TransformerSentenceEncoderLayer.
+* MultiheadAttention: q = (x Wq + bq) * dh^-0.5 ; k, v ; softmax in fp32 with -inf key mask.
+
+State-dict key names are fairseq's (with ``encoder.pos_conv.0.weight`` already folded).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .lengths import fairseq_valid_frames, feat_len_rule
+
+
+@dataclass
+class HubertArch:
+    embed_dim: int = 768
+    ffn_dim: int = 3072
+    layers: int = 12
+    heads: int = 12
+    conv_dim: int = 512
+    conv_kernels: Tuple[int, ...] = (10, 3, 3, 3, 3, 2, 2)
+    conv_strides: Tuple[int, ...] = (5, 2, 2, 2, 2, 2, 2)
+    extractor_mode: str = "default"      # "default" (base) | "layer_norm" (large)
+    conv_bias: bool = False
+    layer_norm_first: bool = False       # False = post-LN (base), True = pre-LN (large)
+    pos_conv_kernel: int = 128
+    pos_conv_groups: int = 16
+    normalize_wav: bool = False          # fairseq task cfg.normalize (False base, True large)
+    downsample_rate: int = 320
+
+    @staticmethod
+    def base() -> "HubertArch":
+        return HubertArch()
+
+    @staticmethod
+    def large() -> "HubertArch":
+        return HubertArch(embed_dim=1024, ffn_dim=4096, layers=24, heads=16,
+                          extractor_mode="layer_norm", conv_bias=True,
+                          layer_norm_first=True, normalize_wav=True)
+
+
+def init_hubert_weights(arch: HubertArch, seed: int = 7122, std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights (no checkpoints exist offline).  Conv / linear ~ N(0, s),
+    norms ~ (1 + N(0, .1), N(0, .1)) so that every affine term is exercised."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    W: Dict[str, torch.Tensor] = {}
+
+    def randn(*shape, s=std):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * s
+
+    def norm(prefix, n):
+        W[prefix + ".weight"] = 1.0 + randn(n, s=0.1)
+        W[prefix + ".bias"] = randn(n, s=0.1)
+
+    cin = 1
+    for i, k in enumerate(arch.conv_kernels):
+        fan_in = cin * k
+        W[f"feature_extractor.conv_layers.{i}.0.weight"] = randn(arch.conv_dim, cin, k, s=(2.0 / fan_in) ** 0.5)
+        if arch.conv_bias:
+            W[f"feature_extractor.conv_layers.{i}.0.bias"] = randn(arch.conv_dim, s=0.05)
+        if arch.extractor_mode == "default" and i == 0:
+            norm(f"feature_extractor.conv_layers.{i}.2", arch.conv_dim)
+        if arch.extractor_mode == "layer_norm":
+            norm(f"feature_extractor.conv_layers.{i}.2.1", arch.conv_dim)
+        cin = arch.conv_dim
+    norm("layer_norm", arch.conv_dim)
+    D = arch.embed_dim
+    W["post_extract_proj.weight"] = randn(D, arch.conv_dim, s=arch.conv_dim ** -0.5)
+    W["post_extract_proj.bias"] = randn(D, s=0.05)
+    gsz = D // arch.pos_conv_groups
+    W["encoder.pos_conv.0.weight"] = randn(D, gsz, arch.pos_conv_kernel, s=(gsz * arch.pos_conv_kernel) ** -0.5)
+    W["encoder.pos_conv.0.bias"] = randn(D, s=0.05)
+    norm("encoder.layer_norm", D)
+    for i in range(arch.layers):
+        p = f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            W[p + f"self_attn.{n}.weight"] = randn(D, D, s=D ** -0.5)
+            W[p + f"self_attn.{n}.bias"] = randn(D, s=0.05)
+        norm(p + "self_attn_layer_norm", D)
+        W[p + "fc1.weight"] = randn(arch.ffn_dim, D, s=D ** -0.5)
+        W[p + "fc1.bias"] = randn(arch.ffn_dim, s=0.05)
+        W[p + "fc2.weight"] = randn(D, arch.ffn_dim, s=arch.ffn_dim ** -0.5)
+        W[p + "fc2.bias"] = randn(D, s=0.05)
+        norm(p + "final_layer_norm", D)
+    return W
+
+
+def fold_weight_norm(weight_g: torch.Tensor, weight_v: torch.Tensor) -> torch.Tensor:
+    """nn.utils.weight_norm(conv, dim=2): w = g * v / ||v|| with the norm over dims (0, 1)."""
+    n = weight_v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    return weight_g * weight_v / n
+
+
+def preprocess_input(wavs: Sequence[torch.Tensor], normalize: bool):
+    """speech_encoder_plus.py:506-518."""
+    if normalize:
+        wavs = [F.layer_norm(w, w.shape) for w in wavs]
+    lens = torch.tensor([len(w) for w in wavs], dtype=torch.long)
+    L = int(lens.max())
+    padded = torch.zeros(len(wavs), L, dtype=torch.float32)
+    for b, w in enumerate(wavs):
+        padded[b, : len(w)] = w
+    mask = torch.arange(L).unsqueeze(0) >= lens.unsqueeze(1)
+    return padded, mask
+
+
+def conv_feature_extractor(W, arch: HubertArch, x: torch.Tensor, collect: Optional[list] = None) -> torch.Tensor:
+    """fairseq ConvFeatureExtractionModel.forward: (B, L) -> (B, C, T)."""
+    x = x.unsqueeze(1)
+    for i, (k, s) in enumerate(zip(arch.conv_kernels, arch.conv_strides)):
+        w = W[f"feature_extractor.conv_layers.{i}.0.weight"]
+        b = W.get(f"feature_extractor.conv_layers.{i}.0.bias")
+        x = F.conv1d(x, w, b, stride=s)
+        if arch.extractor_mode == "default" and i == 0:
+            x = F.group_norm(x.float(), arch.conv_dim,
+                             W[f"feature_extractor.conv_layers.{i}.2.weight"],
+                             W[f"feature_extractor.conv_layers.{i}.2.bias"], 1e-5)
+        elif arch.extractor_mode == "layer_norm":
+            x = F.layer_norm(x.transpose(1, 2), (arch.conv_dim,),
+                             W[f"feature_extractor.conv_layers.{i}.2.1.weight"],
+                             W[f"feature_extractor.conv_layers.{i}.2.1.bias"], 1e-5).transpose(1, 2)
+        x = F.gelu(x)
+        if collect is not None:
+            collect.append(x)
+    return x
+
+
+def forward_padding_mask(T: int, padding_mask: torch.Tensor) -> torch.Tensor:
+    """fairseq HubertModel.forward_padding_mask."""
+    extra = padding_mask.size(1) % T
+    if extra > 0:
+        padding_mask = padding_mask[:, :-extra]
+    padding_mask = padding_mask.view(padding_mask.size(0), T, -1)
+    return padding_mask.all(-1)
+
+
+def self_attention(W, p: str, x: torch.Tensor, key_padding_mask: Optional[torch.Tensor], heads: int) -> torch.Tensor:
+    """fairseq MultiheadAttention (self-attention, no dropout).  x: (B, T, D)."""
+    B, T, D = x.shape
+    dh = D // heads
+    q = F.linear(x, W[p + "q_proj.weight"], W[p + "q_proj.bias"]) * dh ** -0.5
+    k = F.linear(x, W[p + "k_proj.weight"], W[p + "k_proj.bias"])
+    v = F.linear(x, W[p + "v_proj.weight"], W[p + "v_proj.bias"])
+    q = q.view(B, T, heads, dh).transpose(1, 2)
+    k = k.view(B, T, heads, dh).transpose(1, 2)
+    v = v.view(B, T, heads, dh).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    a = torch.softmax(s.float(), dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, T, D)
+    return F.linear(o, W[p + "out_proj.weight"], W[p + "out_proj.bias"])
+
+
+def encoder_layer(W, arch: HubertArch, i: int, x: torch.Tensor, kpm: Optional[torch.Tensor]) -> torch.Tensor:
+    """fairseq TransformerSentenceEncoderLayer.forward (eval mode)."""
+    p = f"encoder.layers.{i}."
+    D = arch.embed_dim
+
+    def ln(name, t):
+        return F.layer_norm(t, (D,), W[p + name + ".weight"], W[p + name + ".bias"], 1e-5)
+
+    if not arch.layer_norm_first:
+        x = ln("self_attn_layer_norm", x + self_attention(W, p + "self_attn.", x, kpm, arch.heads))
+        h = F.linear(F.gelu(F.linear(x, W[p + "fc1.weight"], W[p + "fc1.bias"])), W[p + "fc2.weight"], W[p + "fc2.bias"])
+        x = ln("final_layer_norm", x + h)
+    else:
+        x = x + self_attention(W, p + "self_attn.", ln("self_attn_layer_norm", x), kpm, arch.heads)
+        y = ln("final_layer_norm", x)
+        x = x + F.linear(F.gelu(F.linear(y, W[p + "fc1.weight"], W[p + "fc1.bias"])), W[p + "fc2.weight"], W[p + "fc2.bias"])
+    return x
+
+
+def hubert_forward(W, arch: HubertArch, padded_wav: torch.Tensor, wav_padding_mask: Optional[torch.Tensor],
+                   debug: Optional[dict] = None) -> List[torch.Tensor]:
+    """customHubertForward (speech_encoder_plus.py:67-107) + patched extract_features (:29-64).
+
+    Returns layer_results = [encoder input, out_1 .. out_NL], each (B, T, D)."""
+    conv_outs = [] if debug is not None else None
+    feats = conv_feature_extractor(W, arch, padded_wav, conv_outs)          # :75
+    feats = feats.transpose(1, 2)                                            # :77
+    feats = F.layer_norm(feats, (arch.conv_dim,), W["layer_norm.weight"], W["layer_norm.bias"], 1e-5)  # :78
+    T = feats.shape[1]
+    pm = forward_padding_mask(T, wav_padding_mask) if wav_padding_mask is not None else None        # :81-82
+    x = F.linear(feats, W["post_extract_proj.weight"], W["post_extract_proj.bias"])                 # :84-85
+    if debug is not None:
+        debug["conv"] = conv_outs
+        debug["proj"] = x.clone()
+        debug["padding_mask"] = pm
+    # mask=None is falsy -> no time masking (:90-94)
+    if pm is not None:
+        x = x.masked_fill(pm.unsqueeze(-1), 0.0)                             # :32-33 index_put(x, mask, 0)
+    k = arch.pos_conv_kernel
+    xc = F.conv1d(x.transpose(1, 2), W["encoder.pos_conv.0.weight"], W["encoder.pos_conv.0.bias"],
+                  padding=k // 2, groups=arch.pos_conv_groups)
+    if k % 2 == 0:
+        xc = xc[:, :, :-1]                                                   # SamePad
+    xc = F.gelu(xc).transpose(1, 2)                                          # :35-36
+    x = x + xc                                                               # :37
+    if not arch.layer_norm_first:
+        x = F.layer_norm(x, (arch.embed_dim,), W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], 1e-5)  # :39-40
+    layer_results = [x]                                                      # :47
+    for i in range(arch.layers):                                             # :49-53 (layerdrop 0, eval)
+        x = encoder_layer(W, arch, i, x, pm)
+        layer_results.append(x)
+    return layer_results
+
+
+def speech_encoder_forward(W, arch: HubertArch, wavs: Sequence[torch.Tensor]):
+    """FairseqSpeechEncoder_Hubert.forward (eval, no crop): returns (hidden_states tuple, feat_len).
+    speech_encoder_plus.py:554-611."""
+    padded, mask = preprocess_input(wavs, arch.normalize_wav)
+    hs = hubert_forward(W, arch, padded, mask)
+    T = hs[-1].shape[1]
+    feat_len = torch.tensor(feat_len_rule([len(w) for w in wavs], T, arch.downsample_rate), dtype=torch.long)
+    return tuple(hs), feat_len

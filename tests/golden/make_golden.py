@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz.
+
+Runs ONLY in the build container (needs /root/reference, which does not travel to the GPU box).
+It imports the reference's *leaf* files by path (their packages' __init__ pull in clip /
+pytorch_lightning / fairseq, which are absent - SURVEY F5/F6), runs them on CPU on small seeded
+inputs and stores inputs + weights + expected outputs.  No reference source is copied: the .npz
+files hold data only.
+
+    python tests/golden/make_golden.py
+
+Fixtures:
+  loss_*.npz       MaskedContrastiveLoss (avssl/module/losses.py) fwd + grads
+  head_*.npz       KW_ParallelBranch computation composed exactly as kw_branches.py:266-280 from
+                   TransformerModels.TransformerEncoder ; MultiheadAttentionAndNorm
+  wsum.npz         WeightedSumLayer (avssl/module/weighted_sum.py)
+  masks.npz        get_keypadding_mask (avssl/util/data_utils.py) + the three length rules
+  retrieval.npz    mutualRetrieval (avssl/module/retrieval.py)
+  hubert_small.npz transformers.HubertModel (independent implementation, local config) outputs for a
+                   tiny HuBERT: the only available cross-check at the fairseq boundary
+"""
+import importlib.util
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+
+
+def load_leaf(rel, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, len(out), "arrays")
+
+
+def unit(x):
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+# --------------------------------------------------------------------------- loss
+def make_loss():
+    ref = load_leaf("avssl/module/losses.py", "ref_losses")
+    cases = [
+        ("loss_b8", 8, 16, False, False),
+        ("loss_b32_dup", 32, 32, True, False),
+        ("loss_b32_dup_trainT", 32, 32, True, True),
+        ("loss_b256_dup", 256, 32, True, False),
+    ]
+    for name, B, E, dup, trainT in cases:
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 2**31)
+        A = unit(torch.randn(B, E, generator=g)).requires_grad_(True)
+        Bm = unit(torch.randn(B, E, generator=g) + 0.5 * A.detach()).requires_grad_(True)
+        ids = torch.arange(B) // 5 if dup else torch.arange(B)
+        crit = ref.MaskedContrastiveLoss(temperature=0.07, temperature_trainable=trainT)
+        loss = crit(A, Bm, ids)
+        loss.backward()
+        extra = {}
+        if trainT:
+            extra["dtemp_param"] = crit.temperature.grad
+            extra["temp_param"] = crit.temperature.detach()
+        loss_noidx = crit(A.detach(), Bm.detach(), None)
+        npz(name + ".npz", A=A, B=Bm, ids=ids, loss=loss, dA=A.grad, dB=Bm.grad, loss_noindex=loss_noidx, **extra)
+    # lifted cap (F8): B = 512 has no runnable reference unless MAX_EYE is raised before constructing
+    ref.MAX_EYE = 512
+    g = torch.Generator().manual_seed(512)
+    B, E = 512, 16
+    A = unit(torch.randn(B, E, generator=g)).requires_grad_(True)
+    Bm = unit(torch.randn(B, E, generator=g) + 0.5 * A.detach())
+    ids = torch.arange(B) // 5
+    crit = ref.MaskedContrastiveLoss(temperature=0.07)
+    loss = crit(A, Bm, ids)
+    loss.backward()
+    npz("loss_b512_cap_lifted.npz", A=A, B=Bm, ids=ids, loss=loss, dA=A.grad)
+
+
+# --------------------------------------------------------------------------- head
+def make_head():
+    TM = load_leaf("avssl/module/kw_modules/TransformerModels.py", "ref_tm")
+    du = load_leaf("avssl/util/data_utils.py", "ref_du")
+    for name, D, nhead, F_, T, lens in [
+        ("head_d64_h8", 64, 8, 128, 16, [16, 0, 7, 11]),
+        ("head_d64_h1", 64, 1, 128, 16, [16, 1, 9, 3]),
+    ]:
+        torch.manual_seed(zlib.crc32(name.encode()) % 2**31)
+        enc = TM.TransformerEncoder(n_layers=1, d_model=D, nhead=nhead, dim_feedforward=F_, dropout=0.1,
+                                    activation="gelu", layer_norm_eps=1e-5, batch_first=True, norm_first=False)
+        # make every affine / bias term non-trivial
+        with torch.no_grad():
+            for n, p in enc.named_parameters():
+                if "norm" in n or "bias" in n:
+                    p.add_(0.1 * torch.randn_like(p))
+        enc.eval()
+        cls = torch.nn.Parameter(torch.randn(1, 1, D))
+        proj = torch.nn.Linear(D, 24)
+        B = len(lens)
+        feat = torch.randn(B, T, D, requires_grad=True)
+        audio_len = torch.tensor(lens, dtype=torch.long)
+        # kw_branches.py:266-280
+        src = torch.cat([torch.cat([cls] * B, dim=0), feat], dim=1)
+        kpm = du.get_keypadding_mask(max_length=T + 1, data_lens=audio_len + 1)
+        # grad mode on => stock (non-fused) TransformerEncoderLayer path
+        out_full = enc(src=src, key_padding_mask=kpm)
+        out = proj(out_full[:, :1].reshape(-1, D))
+        gout = torch.randn(out.shape)
+        (out * gout).sum().backward()
+        W = {"cls": cls}
+        W.update({"self_att." + k: v for k, v in enc.state_dict().items()})
+        W["linear_proj.weight"] = proj.weight
+        W["linear_proj.bias"] = proj.bias
+        G = {"g_cls": cls.grad, "g_feat": feat.grad, "g_linear_proj.weight": proj.weight.grad}
+        for n, p in enc.named_parameters():
+            G["g_self_att." + n] = p.grad
+        hid = enc.extract_hidden_states(src=src, key_padding_mask=kpm)
+        npz(name + ".npz", feat=feat, audio_len=audio_len, kpm=kpm, out=out, out_full=out_full.detach(), gout=gout,
+            hidden_last=hid[-1].detach(), nhead=np.int64(nhead),
+            **{"W_" + k: v for k, v in W.items()}, **G)
+    # MultiheadAttentionAndNorm (cascaded+/hybrid+ block)
+    torch.manual_seed(77)
+    D, nhead, T = 64, 8, 12
+    blk = TM.MultiheadAttentionAndNorm(d_model=D, nhead=nhead, dropout=0.1, layer_norm_eps=1e-5, batch_first=True)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if "Norm" in n or "bias" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    blk.eval()
+    src = torch.randn(3, T, D)
+    lens = torch.tensor([12, 5, 1])
+    kpm = du.get_keypadding_mask(T, lens)
+    with torch.no_grad():
+        out = blk(src, kpm)
+    npz("mha_norm_d64_h8.npz", src=src, lens=lens, out=out, nhead=np.int64(nhead),
+        **{"W_" + k: v for k, v in blk.state_dict().items()})
+
+
+# --------------------------------------------------------------------------- weighted sum
+def make_wsum():
+    ws = load_leaf("avssl/module/weighted_sum.py", "ref_ws")
+    torch.manual_seed(5)
+    layer = ws.WeightedSumLayer(n_weights=13)
+    with torch.no_grad():
+        layer.weights.copy_(torch.randn(13))
+    hs = [torch.randn(2, 9, 32) for _ in range(13)]
+    out = layer(hs)
+    gout = torch.randn_like(out)
+    (out * gout).sum().backward()
+    layer_n = ws.WeightedSumLayer(n_weights=13, normalize_features=True)
+    with torch.no_grad():
+        layer_n.weights.copy_(layer.weights)
+        out_n = layer_n(hs)
+    npz("wsum.npz", weights=layer.weights, hs=torch.stack(hs), out=out, gout=gout, dweights=layer.weights.grad, out_norm=out_n)
+
+
+# --------------------------------------------------------------------------- masks / lengths
+def make_masks():
+    du = load_leaf("avssl/util/data_utils.py", "ref_du")
+    import torch.nn.functional as F
+    from transformers import HubertConfig, HubertModel
+    lens = torch.tensor([0, 1, 5, 16, 17])
+    m = du.get_keypadding_mask(17, lens)
+    # conv length formula vs real conv stack output sizes and vs HF's formula
+    Ls = [400, 401, 799, 800, 1000, 16000, 32000, 102400, 159999, 160000, 160001, 163840]
+    hf = HubertModel(HubertConfig(num_hidden_layers=1, hidden_size=32, intermediate_size=32, num_attention_heads=2,
+                                  conv_dim=(2,) * 7))
+    T_hf = [int(hf._get_feat_extract_output_lengths(torch.tensor(L))) for L in Ls]
+    T_conv = []
+    for L in Ls:
+        x = torch.zeros(1, 1, L)
+        for k, s in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
+            x = F.conv1d(x, torch.zeros(1, 1, k), stride=s)
+        T_conv.append(x.shape[-1])
+    assert T_hf == T_conv, (T_hf, T_conv)
+    # fairseq forward_padding_mask executed literally on bool masks (its 5 published lines)
+    Lmax_cases, valid = [], []
+    for Lmax, wl in [(160000, [160000, 159681, 159680, 320, 1, 80000, 321, 640, 641]),
+                     (102400, [102400, 102000, 96400, 321, 322, 642, 643, 51200]),
+                     (16000, [16000, 15680, 15681, 3200, 323, 324])]:
+        T = T_conv[Ls.index(Lmax)]
+        pm = torch.arange(Lmax).unsqueeze(0) >= torch.tensor(wl).unsqueeze(1)
+        extra = pm.size(1) % T
+        if extra > 0:
+            pm = pm[:, :-extra]
+        fm = pm.view(pm.size(0), T, -1).all(-1)
+        Lmax_cases.append(Lmax)
+        valid.append(np.array([wl, (~fm).sum(1).tolist()]))
+    npz("masks.npz", kpm_lens=lens, kpm=m, Ls=np.array(Ls), T=np.array(T_conv),
+        fm_L0=valid[0], fm_L1=valid[1], fm_L2=valid[2], fm_Lmax=np.array(Lmax_cases),
+        round_in=np.array([160, 480, 800, 1120, 159, 161, 479, 481, 160000, 102400, 102000]),
+        round_out=np.array([round(l / 320) for l in [160, 480, 800, 1120, 159, 161, 479, 481, 160000, 102400, 102000]]))
+
+
+# --------------------------------------------------------------------------- retrieval
+def make_retrieval():
+    rt = load_leaf("avssl/module/retrieval.py", "ref_rt")
+    g = torch.Generator().manual_seed(11)
+    nA, nB = 40, 8
+    a_ids = torch.arange(nA) // 5
+    b_ids = torch.arange(nB)
+    img = unit(torch.randn(nB, 16, generator=g))
+    aud = unit(img[a_ids] + 0.9 * torch.randn(nA, 16, generator=g))
+    score = aud @ img.T
+    AB, BA, mean = rt.mutualRetrieval(score_per_A=score, score_per_B=score.T, AB_answers=a_ids, BA_answers=b_ids,
+                                      recall_at=[1, 5, 10])
+    ks = [1, 5, 10]
+    npz("retrieval.npz", aud=aud, img=img, a_ids=a_ids, b_ids=b_ids, score=score,
+        AB=np.array([AB[f"recall@{k}"] for k in ks]), BA=np.array([BA[f"recall@{k}"] for k in ks]),
+        mean=np.array([mean[f"recall@{k}"] for k in ks]))
+
+
+# --------------------------------------------------------------------------- HuBERT (HF cross-check)
+def make_hubert():
+    from transformers import HubertConfig, HubertModel
+    import oracle
+    from oracle.hubert_ref import fold_weight_norm
+    for name, stable in [("hubert_small", False), ("hubert_small_preln", True)]:
+        torch.manual_seed(3 if not stable else 4)
+        cfg = HubertConfig(hidden_size=32, num_hidden_layers=2, num_attention_heads=4, intermediate_size=64,
+                           conv_dim=(16,) * 7, conv_bias=stable, feat_extract_norm="layer" if stable else "group",
+                           do_stable_layer_norm=stable, num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16,
+                           hidden_dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0,
+                           layerdrop=0.0, apply_spec_augment=False, feat_proj_layer_norm=True)
+        hf = HubertModel(cfg).eval()
+        with torch.no_grad():
+            for n, p in hf.named_parameters():
+                if "norm" in n or n.endswith("bias"):
+                    p.add_(0.1 * torch.randn_like(p))
+        sd = hf.state_dict()
+        W = {}
+        for i in range(7):
+            W[f"feature_extractor.conv_layers.{i}.0.weight"] = sd[f"feature_extractor.conv_layers.{i}.conv.weight"]
+            if stable:
+                W[f"feature_extractor.conv_layers.{i}.0.bias"] = sd[f"feature_extractor.conv_layers.{i}.conv.bias"]
+                W[f"feature_extractor.conv_layers.{i}.2.1.weight"] = sd[f"feature_extractor.conv_layers.{i}.layer_norm.weight"]
+                W[f"feature_extractor.conv_layers.{i}.2.1.bias"] = sd[f"feature_extractor.conv_layers.{i}.layer_norm.bias"]
+            elif i == 0:
+                W["feature_extractor.conv_layers.0.2.weight"] = sd["feature_extractor.conv_layers.0.layer_norm.weight"]
+                W["feature_extractor.conv_layers.0.2.bias"] = sd["feature_extractor.conv_layers.0.layer_norm.bias"]
+        W["layer_norm.weight"] = sd["feature_projection.layer_norm.weight"]
+        W["layer_norm.bias"] = sd["feature_projection.layer_norm.bias"]
+        W["post_extract_proj.weight"] = sd["feature_projection.projection.weight"]
+        W["post_extract_proj.bias"] = sd["feature_projection.projection.bias"]
+        gk = [k for k in sd if "pos_conv_embed" in k]
+        g_key = [k for k in gk if k.endswith("original0") or k.endswith("weight_g")][0]
+        v_key = [k for k in gk if k.endswith("original1") or k.endswith("weight_v")][0]
+        W["encoder.pos_conv.0.weight"] = fold_weight_norm(sd[g_key], sd[v_key])
+        W["encoder.pos_conv.0.bias"] = sd["encoder.pos_conv_embed.conv.bias"]
+        W["encoder.layer_norm.weight"] = sd["encoder.layer_norm.weight"]
+        W["encoder.layer_norm.bias"] = sd["encoder.layer_norm.bias"]
+        for i in range(2):
+            p, q = f"encoder.layers.{i}.", f"encoder.layers.{i}."
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                W[p + f"self_attn.{n}.weight"] = sd[q + f"attention.{n}.weight"]
+                W[p + f"self_attn.{n}.bias"] = sd[q + f"attention.{n}.bias"]
+            W[p + "self_attn_layer_norm.weight"] = sd[q + "layer_norm.weight"]
+            W[p + "self_attn_layer_norm.bias"] = sd[q + "layer_norm.bias"]
+            W[p + "fc1.weight"] = sd[q + "feed_forward.intermediate_dense.weight"]
+            W[p + "fc1.bias"] = sd[q + "feed_forward.intermediate_dense.bias"]
+            W[p + "fc2.weight"] = sd[q + "feed_forward.output_dense.weight"]
+            W[p + "fc2.bias"] = sd[q + "feed_forward.output_dense.bias"]
+            W[p + "final_layer_norm.weight"] = sd[q + "final_layer_norm.weight"]
+            W[p + "final_layer_norm.bias"] = sd[q + "final_layer_norm.bias"]
+        B, L = 3, 8000
+        wav = torch.randn(B, L)
+        with torch.no_grad():
+            out = hf(wav, output_hidden_states=True)
+        hs = torch.stack(out.hidden_states)                       # (3, B, T, D); [0] = encoder input (post-LN variant)
+        # padded batch where HF's conv-formula mask and fairseq's chunk-all() mask agree on the valid count
+        # for every utterance (lens chosen so) -> comparable on valid frames
+        lens = [8000, 4980, 2320]   # both mask rules give the same valid-frame count for these
+        am = (torch.arange(L).unsqueeze(0) < torch.tensor(lens).unsqueeze(1)).long()
+        wav_p = wav * am
+        with torch.no_grad():
+            out_p = hf(wav_p, attention_mask=am, output_hidden_states=True)
+        hf_valid = hf._get_feature_vector_attention_mask(out_p.last_hidden_state.shape[1], am).sum(1)
+        arch = oracle.HubertArch(embed_dim=32, ffn_dim=64, layers=2, heads=4, conv_dim=16,
+                                 extractor_mode="layer_norm" if stable else "default", conv_bias=stable,
+                                 layer_norm_first=stable)
+        # sanity: oracle reproduces HF on the un-padded batch (this is the cross-check itself)
+        mine = oracle.hubert_forward(W, arch, wav, None)
+        if not stable:
+            err = max(float((m - h).abs().max()) for m, h in zip(mine, hs))
+        else:
+            # HF pre-LN: hidden_states[i] are the same pre-final-LN layer outputs except the last, which gets encoder.layer_norm
+            err = max(float((m - h).abs().max()) for m, h in zip(mine[:-1], hs[:-1]))
+        print(name, "oracle vs HF un-padded max abs err", err)
+        assert err < 2e-4, err
+        npz(name + ".npz", wav=wav, hf_hidden=hs, lens=np.array(lens), hf_hidden_padded=torch.stack(out_p.hidden_states),
+            hf_valid=hf_valid, stable=np.int64(stable), **{"W_" + k: v for k, v in W.items()})
+
+
+if __name__ == "__main__":
+    make_loss()
+    make_head()
+    make_wsum()
+    make_masks()
+    make_retrieval()
+    make_hubert()

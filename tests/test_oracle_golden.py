@@ -1,0 +1,125 @@
+"""CPU: the oracle (torch fp32 restatement) against the golden vectors produced by the reference's own
+leaf files (tests/golden/make_golden.py) and against the independent HF HuBERT implementation."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.lengths import conv_out_lengths, fairseq_valid_frames, feat_len_rule, get_keypadding_mask
+from conftest import weights_from
+
+T = torch.from_numpy
+
+
+@pytest.mark.parametrize("name", ["loss_b8", "loss_b32_dup", "loss_b32_dup_trainT", "loss_b256_dup", "loss_b512_cap_lifted"])
+def test_loss(golden, name):
+    fx = golden(name + ".npz")
+    A = T(fx["A"]).requires_grad_(True)
+    B = T(fx["B"]).requires_grad_(True)
+    if "temp_param" in fx:
+        p = T(fx["temp_param"]).clone().requires_grad_(True)
+        inv_t = p.exp()
+    else:
+        p, inv_t = None, 1 / 0.07
+    loss = oracle.masked_contrastive_loss(A, B, T(fx["ids"]), inv_temperature=inv_t)
+    loss.backward()
+    assert abs(loss.item() - fx["loss"].item()) < 1e-5
+    np.testing.assert_allclose(A.grad.numpy(), fx["dA"], rtol=1e-4, atol=1e-6)
+    if "dB" in fx:
+        np.testing.assert_allclose(B.grad.numpy(), fx["dB"], rtol=1e-4, atol=1e-6)
+    if p is not None:
+        np.testing.assert_allclose(p.grad.numpy(), fx["dtemp_param"], rtol=1e-4)
+    if "loss_noindex" in fx:
+        l2 = oracle.masked_contrastive_loss(A.detach(), B.detach(), None, inv_temperature=float(inv_t))
+        assert abs(l2.item() - fx["loss_noindex"].item()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["head_d64_h8", "head_d64_h1"])
+def test_parallel_head(golden, name):
+    fx = golden(name + ".npz")
+    W = {k: v.clone().requires_grad_(True) for k, v in weights_from(fx).items()}
+    feat = T(fx["feat"]).requires_grad_(True)
+    out = oracle.parallel_branch_forward(W, feat, T(fx["audio_len"]), nhead=int(fx["nhead"]))
+    np.testing.assert_allclose(out.detach().numpy(), fx["out"], rtol=1e-4, atol=2e-5)
+    (out * T(fx["gout"])).sum().backward()
+    np.testing.assert_allclose(feat.grad.numpy(), fx["g_feat"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(W["cls"].grad.numpy(), fx["g_cls"], rtol=1e-3, atol=2e-5)
+    for k in W:
+        if k == "cls":
+            continue
+        g = fx["g_" + k] if "g_" + k in fx else None
+        if g is not None:
+            np.testing.assert_allclose(W[k].grad.numpy(), g, rtol=1e-3, atol=3e-5, err_msg=k)
+    m = get_keypadding_mask(feat.shape[1] + 1, T(fx["audio_len"]) + 1)
+    assert (m.numpy() == fx["kpm"]).all()
+
+
+def test_mha_and_norm(golden):
+    fx = golden("mha_norm_d64_h8.npz")
+    W = weights_from(fx)
+    kpm = get_keypadding_mask(fx["src"].shape[1], T(fx["lens"]))
+    out = oracle.mha_and_norm_forward(W, "", T(fx["src"]), kpm, int(fx["nhead"]))
+    np.testing.assert_allclose(out.numpy(), fx["out"], rtol=1e-4, atol=2e-5)
+
+
+def test_weighted_sum(golden):
+    fx = golden("wsum.npz")
+    w = T(fx["weights"]).requires_grad_(True)
+    hs = list(T(fx["hs"]))
+    out = oracle.weighted_sum(w, hs)
+    np.testing.assert_allclose(out.detach().numpy(), fx["out"], rtol=1e-5, atol=1e-6)
+    (out * T(fx["gout"])).sum().backward()
+    np.testing.assert_allclose(w.grad.numpy(), fx["dweights"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(oracle.weighted_sum(w.detach(), hs, True).numpy(), fx["out_norm"], rtol=1e-4, atol=1e-5)
+
+
+def test_masks_and_lengths(golden):
+    fx = golden("masks.npz")
+    assert (get_keypadding_mask(17, T(fx["kpm_lens"])).numpy() == fx["kpm"]).all()
+    for L, t in zip(fx["Ls"], fx["T"]):
+        assert conv_out_lengths(int(L))[-1] == int(t)
+    assert conv_out_lengths(160000)[-1] == 499 and conv_out_lengths(102400)[-1] == 319
+    for i, Lmax in enumerate(fx["fm_Lmax"]):
+        wl, valid = fx[f"fm_L{i}"]
+        Tn = conv_out_lengths(int(Lmax))[-1]
+        assert fairseq_valid_frames(wl.tolist(), int(Lmax), Tn) == valid.tolist()
+    assert feat_len_rule(fx["round_in"].tolist(), 10**9) == fx["round_out"].tolist()
+    # half-to-even cases the survey calls out: 160/320 = .5 -> 0, 480/320 = 1.5 -> 2, 800/320 = 2.5 -> 2
+    assert feat_len_rule([160, 480, 800], 499) == [0, 2, 2]
+
+
+def test_retrieval(golden):
+    fx = golden("retrieval.npz")
+    s = T(fx["score"])
+    AB, BA, mean = oracle.mutual_retrieval(s, s.T, T(fx["a_ids"]), T(fx["b_ids"]), [1, 5, 10])
+    for i, k in enumerate([1, 5, 10]):
+        assert abs(AB[f"recall@{k}"] - fx["AB"][i]) < 1e-4
+        assert abs(BA[f"recall@{k}"] - fx["BA"][i]) < 1e-4
+        assert abs(mean[f"recall@{k}"] - fx["mean"][i]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["hubert_small", "hubert_small_preln"])
+def test_hubert_vs_hf(golden, name):
+    fx = golden(name + ".npz")
+    W = weights_from(fx)
+    stable = bool(fx["stable"])
+    arch = oracle.HubertArch(embed_dim=32, ffn_dim=64, layers=2, heads=4, conv_dim=16,
+                             extractor_mode="layer_norm" if stable else "default", conv_bias=stable,
+                             layer_norm_first=stable)
+    wav = T(fx["wav"])
+    hs = oracle.hubert_forward(W, arch, wav, None)
+    n = len(hs) - 1 if stable else len(hs)      # HF applies encoder.layer_norm to its last pre-LN state
+    for i in range(n):
+        np.testing.assert_allclose(hs[i].numpy(), fx["hf_hidden"][i], rtol=1e-3, atol=2e-5)
+    # padded batch: the two mask rules agree on these lengths -> valid frames must match HF
+    lens = fx["lens"].tolist()
+    L = wav.shape[1]
+    wavs = [wav[b, :l] for b, l in enumerate(lens)]
+    hs_p, feat_len = oracle.speech_encoder_forward(W, arch, wavs)
+    Tn = hs_p[0].shape[1]
+    valid = fairseq_valid_frames(lens, L, Tn)
+    assert valid == fx["hf_valid"].tolist()
+    for i in range(n):
+        for b, v in enumerate(valid):
+            np.testing.assert_allclose(hs_p[i][b, :v].numpy(), fx["hf_hidden_padded"][i][b, :v], rtol=1e-3, atol=5e-5)
+    assert feat_len.tolist() == feat_len_rule(lens, Tn)
