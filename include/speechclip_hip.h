@@ -1,0 +1,177 @@
+/*
+ * speechclip_hip.h - C ABI of libspeechclip_hip.so (gfx950 / MI355X).
+ *
+ * The reference (ShampooWang/SpeechCLIP_plus) is 100 % Python and has no FFI / operator layer of its own
+ * (SURVEY.md F1); its seams are nn.Module.forward signatures.  This header is therefore the boundary a
+ * maintainer would bind *under* those modules (ctypes stub: INTEGRATION.md).  Every entry point names the
+ * reference computation it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all buffers
+ *     (outputs and workspaces are allocated by the caller and passed in).
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, never synchronise, keep no
+ *     global state.  Re-entrant per stream.
+ *   - return 0 on success, <0 on error; sc_last_error() gives a thread-local message.
+ *   - bf16 tensors are raw uint16 storage (`sc_bf16`); "rows" of activations live in the padded layout
+ *     described in DESIGN.md: utterance b, frame t  ->  row  b*R + t,  R % 128 == 0.
+ */
+#ifndef SPEECHCLIP_HIP_H
+#define SPEECHCLIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t sc_bf16;
+
+const char* sc_last_error(void);
+int sc_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM with fused epilogue:  C = epi(A . W^T)      (every Linear / Conv1d on the path)
+ *   replaces: fairseq Linear/Conv1d calls reached from avssl/module/speech_encoder_plus.py:75-105
+ *             (conv feature extractor layers 1-6 as strided-row GEMMs, post_extract_proj, q/k/v/out_proj,
+ *             fc1, fc2, pos_conv per group).
+ *   A   [M, K] bf16, row stride lda (elements; rows may overlap - this is how a channels-last strided
+ *       Conv1d becomes a GEMM: lda = stride*C_in, K = k*C_in)
+ *   W   [N, K] bf16, row stride ldw   (torch Linear layout [out, in])
+ *   C   [M, N] bf16 (or fp32 if out_f32), row stride ldc
+ *   epilogue order:  acc -> +bias[n] -> act (0 none, 1 GELU-erf) -> +residual[m, n] -> store
+ *   columns n >= n_split (if n_split >= 0) are stored TRANSPOSED per head into Ct:
+ *       Ct[(((m / R) * H + (n-n_split)/dh) * dh + (n-n_split)%dh) * R + m % R]     (V^T for attention)
+ *   batch: grid.z = nb1*nb2 ; operand pointers advance by  (z / nb2) * s?1 + (z % nb2) * s?2  elements.
+ *   Requirements: K % 64 == 0, lda/ldw % 8 == 0, pointers 16-byte aligned, ldc % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const sc_bf16* A; int64_t lda;
+    const sc_bf16* W; int64_t ldw;
+    void* C; int64_t ldc;
+    int32_t M, N, K;
+    const float* bias;            /* [N] fp32 or NULL */
+    const sc_bf16* residual; int64_t ldr;   /* [M, N] bf16 or NULL */
+    int32_t act;                  /* 0 none, 1 gelu(erf) */
+    int32_t out_f32;              /* 0: C is bf16, 1: C is fp32 */
+    sc_bf16* Ct; int32_t n_split; int32_t R; int32_t dh;   /* transposed-store region; n_split < 0 disables */
+    int32_t nb1, nb2;             /* batch = nb1*nb2 (>= 1 each) */
+    int64_t sA1, sA2, sW1, sW2, sC1, sC2, sBias1, sBias2, sR1, sR2;
+} sc_gemm_args;
+int sc_gemm_bf16(const sc_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Self-attention forward (flash style, key-padding by length), head_dim 64.
+ *   replaces: fairseq MultiheadAttention inside TransformerSentenceEncoderLayer, invoked at
+ *             avssl/module/speech_encoder_plus.py:52  (softmax((q*dh^-.5) k^T + kpm(-inf)) v)
+ *   qk   [B*R, ldqk] bf16 : columns [0, D) = q (unscaled), [D, 2D) = k ; head h owns 64 columns
+ *   vt   [B, H, 64, R] bf16 : v transposed per head (written by sc_gemm_bf16's Ct path)
+ *   valid_len [B] int32 : keys t >= valid_len[b] are masked (-inf)
+ *   out  [B*R, ldo] bf16, columns h*64..h*64+63
+ * ---------------------------------------------------------------------------------------------- */
+int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len,
+                     sc_bf16* out, int64_t ldo, int32_t B, int32_t R, int32_t H, int32_t D, float scale,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row LayerNorm, bf16 in/out, fp32 statistics:  y = (x - mean) * rstd * gamma + beta  [-> GELU]
+ *   replaces: fairseq LayerNorm calls (speech_encoder_plus.py:40,78 and inside each encoder layer),
+ *             conv-extractor LayerNorm in "layer_norm" mode.
+ *   D % 4 == 0, D <= 1024.  act: 0 none, 1 GELU(erf).
+ * ---------------------------------------------------------------------------------------------- */
+int sc_layernorm_bf16(const sc_bf16* x, int64_t ldx, const float* gamma, const float* beta, sc_bf16* y,
+                      int64_t ldy, int64_t rows, int32_t D, float eps, int32_t act, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Waveform front end.
+ *   sc_wav_prep: speech_encoder_plus.py:506-518 (optional per-utterance layer_norm over the whole
+ *     waveform, zero padding) -> padded fp32 [B, ldw_out], samples >= wav_len[b] are 0.
+ *   sc_conv0_stats + sc_conv0_finalize: GroupNorm(512,512) statistics of conv layer 0 over the padded
+ *     time axis T0 (fairseq Fp32GroupNorm, "default" extractor mode) computed analytically from the
+ *     10x10 Gram matrix of the strided waveform (fp64 accumulation) -> scale/shift [B, C] fp32.
+ *   sc_conv0_gn_gelu: conv0 (C_in=1, k=10, s=5, no bias) + GroupNorm affine + GELU, channels-last bf16
+ *     out[b*R0 + t, c].
+ * ---------------------------------------------------------------------------------------------- */
+int sc_wav_prep(const float* wav, int64_t ldw_in, const int64_t* wav_len, float* out, int64_t ldw_out,
+                int32_t B, int32_t L, int32_t normalize, void* stream);
+#define SC_CONV0_NSTAT 66   /* 55 Gram entries + 10 sums + pad */
+int sc_conv0_stats(const float* wav, int64_t ldw, int32_t B, int32_t T0, int32_t nchunk, double* partial,
+                   void* stream);
+int sc_conv0_finalize(const double* partial, int32_t nchunk, const float* w0 /*[C,10]*/, const float* gamma,
+                      const float* beta, int32_t B, int32_t C, int32_t T0, float eps, float* scale,
+                      float* shift, void* stream);
+int sc_conv0_gn_gelu(const float* wav, int64_t ldw, const float* w0, const float* scale, const float* shift,
+                     sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pos_conv input: zero padded frames (speech_encoder_plus.py:32-33 index_put(x, padding_mask, 0)) and
+ * regroup channels-last [B*R, D] into the group-major, halo-padded slab layout the grouped conv GEMM reads:
+ *   xz  [B*R, D]              : masked copy (residual operand of the pos_conv epilogue)
+ *   xg  [G, B, R + 2*halo, D/G] : rows [halo, halo+R) hold the masked frames, everything else 0
+ * ---------------------------------------------------------------------------------------------- */
+int sc_posconv_prep(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_bf16* xg, int32_t B, int32_t R,
+                    int32_t D, int32_t G, int32_t halo, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weighted sum over hidden states (avssl/module/weighted_sum.py:26-45).
+ *   h    [NL, B*R, D] bf16 ; w [NL] fp32 = softmax(weights) (host computes the 13-element softmax)
+ *   out  [B, R, D] bf16, written at row offset `row_off` inside each utterance (row_off = 1 leaves row 0
+ *        for the CLS token of kw_branches.py:266-267), rows t in [0, R - row_off)
+ *   bwd: dw[n] = sum_{b,t,d} g[b, t + row_off, d] * h[n, b, t, d]   (g fp32 [B, R, D])
+ * ---------------------------------------------------------------------------------------------- */
+int sc_wsum_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, int32_t B, int32_t R, int32_t D,
+                int32_t row_off, void* stream);
+int sc_wsum_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial /*[nblk, NL]*/, int32_t nblk,
+                int32_t B, int32_t R, int32_t D, int32_t row_off, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CLS attention pooling (the query row 0 of the parallel branch's TransformerEncoder layer;
+ * avssl/model/kw_branches.py:266-280 -> nn.MultiheadAttention inside TransformerModels.py:48-97).
+ * Only the CLS query is consumed by the branch, so K/V are never materialised:
+ *   scores[b,h,s] = a[h] . X[b,s]            a[h] = Wk_h^T q_h * dh^-.5  (host side, tiny)
+ *   p = softmax_s(scores | s < len[b]) ;  m[b,h,:] = sum_s p[b,h,s] X[b,s,:]
+ *   X [B, R, D] bf16 ; a [H, D] fp32 ; len [B] int32 (valid keys incl. CLS) ; H <= 16
+ * backward (dm [B,H,D] fp32 given):
+ *   dp = dm . X ; ds = p (dp - sum p dp) ; dX = sum_h p dm + ds a ; da_partial[b,h,:] = sum_s ds X
+ * ---------------------------------------------------------------------------------------------- */
+int sc_cls_scores(const sc_bf16* X, const float* vec, int64_t vec_bstride, float* scores, int32_t B, int32_t R,
+                  int32_t D, int32_t H, void* stream);
+int sc_cls_pool_fwd(const sc_bf16* X, const float* scores, const int32_t* len, float* p, float* m, int32_t B,
+                    int32_t R, int32_t D, int32_t H, void* stream);
+int sc_cls_pool_bwd(const sc_bf16* X, const float* p, const float* dp, const float* dm, const float* a,
+                    const int32_t* len, float* dX, float* da_partial, int32_t B, int32_t R, int32_t D, int32_t H,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32 strided GEMM  C[i,j] = alpha * sum_k A[i*sai + k*sak] * Bm[j*sbj + k*sbk]  (+ bias[j])
+ *   small fp32 products of the loss and of the CLS-row tail (logits = A.B^T / tau, dA = G.B, ...)
+ * ---------------------------------------------------------------------------------------------- */
+int sc_sgemm_f32(const float* A, int64_t sai, int64_t sak, const float* Bm, int64_t sbj, int64_t sbk, float* C,
+                 int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, const float* bias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Masked symmetric InfoNCE (avssl/module/losses.py:185-245), logits [Bg,Bg] fp32 = A.B^T * inv_temp
+ *   neg[i,j] = ids[i] != ids[j] or i == j ;  loss = 1/(2Bg) sum_i (-2 l_ii + LSE_row_i + LSE_col_i)
+ *   sc_infonce_lse : row/col masked log-sum-exp (stable), per-sample terms, loss scalar
+ *   sc_infonce_grad: G = dloss/dlogits * gscale (in place into G), dinv_temp partials
+ * ---------------------------------------------------------------------------------------------- */
+int sc_infonce_lse(const float* logits, const int64_t* ids, int32_t Bg, float* lse_row, float* lse_col,
+                   float* loss, void* stream);
+int sc_infonce_grad(const float* logits, const int64_t* ids, const float* lse_row, const float* lse_col,
+                    int32_t Bg, const float* gscale /*device scalar*/, float* G, float* dlogit_dot /*[Bg]*/,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser step on a flat fp32 parameter buffer: torch.optim.Adam semantics (L2 weight decay added to
+ * the gradient), gradient clipping by global norm folded in (avssl/model/kwClip.py:646-674 +
+ * trainer.gradient_clip_val).  sumsq: partial sums of squares for the global norm.
+ * ---------------------------------------------------------------------------------------------- */
+int sc_sumsq_f32(const float* x, int64_t n, float* partial, int32_t nblk, void* stream);
+int sc_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, int32_t step, const float* gnorm_sq_partial, int32_t nblk,
+                float max_norm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+"""ctypes binding of libspeechclip_hip.so (the C ABI declared in include/speechclip_hip.h).
+
+There is NO fallback: if the library is missing or a symbol cannot be resolved this module raises, and
+every op in ``speechclip_plus_amd.ops`` fails loudly.  Build with ``python -m speechclip_plus_amd.build``
+(or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libspeechclip_hip.so")
+
+c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+
+class GemmArgs(ctypes.Structure):
+    """Mirror of ``sc_gemm_args`` (include/speechclip_hip.h)."""
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_i64),
+        ("W", c_void_p), ("ldw", c_i64),
+        ("C", c_void_p), ("ldc", c_i64),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("bias", c_void_p),
+        ("residual", c_void_p), ("ldr", c_i64),
+        ("act", c_int), ("out_f32", c_int),
+        ("Ct", c_void_p), ("n_split", c_int), ("R", c_int), ("dh", c_int),
+        ("nb1", c_int), ("nb2", c_int),
+        ("sA1", c_i64), ("sA2", c_i64), ("sW1", c_i64), ("sW2", c_i64), ("sC1", c_i64), ("sC2", c_i64),
+        ("sBias1", c_i64), ("sBias2", c_i64), ("sR1", c_i64), ("sR2", c_i64),
+    ]
+
+
+# name -> argtypes (all return int except sc_last_error); kept in one table so tests can check that the
+# library exports every symbol the header declares.
+SIGNATURES = {
+    "sc_abi_version": [],
+    "sc_gemm_bf16": [ctypes.POINTER(GemmArgs), c_void_p],
+    "sc_attn_fwd_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "sc_layernorm_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_float, c_int, c_void_p],
+    "sc_wav_prep": [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p],
+    "sc_conv0_stats": [c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sc_conv0_finalize": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "sc_conv0_gn_gelu": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "sc_posconv_prep": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_wsum_fwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_wsum_bwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_cls_scores": [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_cls_pool_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_cls_pool_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_sgemm_f32": [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
+    "sc_infonce_lse": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sc_infonce_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sc_sumsq_f32": [c_void_p, c_i64, c_void_p, c_int, c_void_p],
+    "sc_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p, c_int, c_float, c_void_p],
+}
+
+_LIB = None
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built (python -m speechclip_plus_amd.build). "
+                "speechclip_plus_amd has no CPU / eager fallback.")
+        cdll = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(cdll, name)            # AttributeError if the symbol is missing: loud
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        cdll.sc_last_error.argtypes = []
+        cdll.sc_last_error.restype = ctypes.c_char_p
+        _LIB = cdll
+    return _LIB
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"libspeechclip_hip {what} failed ({rc}): {lib().sc_last_error().decode()}")

@@ -1,0 +1,178 @@
+// Flash-style self-attention forward for gfx950, head_dim 64, key padding by per-utterance length.
+//
+// One workgroup = 4 waves = 128 query rows of one (utterance, head); each wave owns 32 queries.
+// Scores are computed TRANSPOSED, S^T = K . Q^T with v_mfma_f32_32x32x16_bf16 (A = K rows from LDS,
+// B = Q rows held in registers), so a lane holds one query column and its 16 (of 32) keys in registers:
+// the row max / row sum are in-lane reductions plus one exchange with lane^32.  The S^T accumulator is then,
+// converted to bf16, directly the B operand of  O^T += V^T . P^T  (no LDS round trip, no lane movement);
+// V arrives already transposed per head (written by the QKV GEMM's epilogue), so the A operand V^T[d][keys]
+// is two 8-byte LDS reads.  K and V^T tiles (64 keys) are staged through LDS with register prefetch
+// (global loads for tile t+1 are issued before tile t's MFMAs, written to LDS after them).
+// LDS images are XOR-swizzled so the b128 (K) and b64 (V^T) fragment reads are bank-conflict free.
+#include "sc_common.h"
+
+namespace {
+
+constexpr int KT = 64;   // keys per LDS tile
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qk, int64_t ldqk,
+                                                        const uint16_t* __restrict__ vt,
+                                                        const int32_t* __restrict__ valid_len,
+                                                        uint16_t* __restrict__ out, int64_t ldo, int R, int H, int D,
+                                                        float c /* scale * log2(e) */) {
+    __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
+    __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    int n_valid = valid_len[b];
+    n_valid = max(1, min(n_valid, R));
+
+    // Q fragments (B operand): Q[q0 + l31][ks*16 + 8*half + j]
+    bf16x8 qf[4];
+    {
+        const uint16_t* qp = qk + ((int64_t)b * R + q0 + l31) * ldqk + h * 64 + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+
+    // loader mapping: 512 16-B chunks per tile, two per thread
+    const uint16_t* kg[2];
+    const uint16_t* vg[2];
+    int k_lds[2], v_lds0[2], v_lds1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 256, row = id >> 3, ch = id & 7;
+        kg[i] = qk + ((int64_t)b * R + row) * ldqk + D + h * 64 + ch * 8;
+        vg[i] = vt + (((int64_t)b * H + h) * 64 + row) * R + ch * 8;
+        k_lds[i] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+        v_lds0[i] = row * 128 + (((2 * ch) ^ ((row >> 1) & 15)) << 3);
+        v_lds1[i] = row * 128 + (((2 * ch + 1) ^ ((row >> 1) & 15)) << 3);
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (n_valid + KT - 1) / KT;
+    uint4 kreg[2], vreg[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        kreg[i] = *(const uint4*)(kg[i]);
+        vreg[i] = *(const uint4*)(vg[i]);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KT;
+        // write the prefetched tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(uint4*)(Ks + k_lds[i]) = kreg[i];
+            *(uint2*)(Vs + v_lds0[i]) = make_uint2(vreg[i].x, vreg[i].y);
+            *(uint2*)(Vs + v_lds1[i]) = make_uint2(vreg[i].z, vreg[i].w);
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                kreg[i] = *(const uint4*)(kg[i] + (int64_t)(key0 + KT) * ldqk);
+                vreg[i] = *(const uint4*)(vg[i] + key0 + KT);
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int kbase = key0 + kb * 32;
+            if (kbase < n_valid) {   // wave-uniform
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                const int krow = kb * 32 + l31;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((2 * ks + half) ^ ((krow >> 1) & 7)) << 4));
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                }
+                if (kbase + 32 > n_valid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kidx = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (kidx >= n_valid) s[r] = -INFINITY;
+                    }
+                }
+                float mloc = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+                const float m_new = fmaxf(m_run, mloc);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+                const float mc = m_new * c;
+                float psum = 0.f;
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));
+                    psum += pv[r];
+                }
+                l_run = l_run * alpha + psum;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                bf16x8 pf[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[s2][j] = (__bf16)pv[8 * s2 + j];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int u0 = kb * 8 + 4 * s2 + half;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int vrow = dt * 32 + l31;
+                        const int sw = (vrow >> 1) & 15;
+                        const uint2 lo = *(const uint2*)(Vs + vrow * 128 + ((u0 ^ sw) << 3));
+                        const uint2 hi = *(const uint2*)(Vs + vrow * 128 + (((u0 + 2) ^ sw) << 3));
+                        const uint4 v4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        const bf16x8 vf = __builtin_bit_cast(bf16x8, v4);
+                        if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o0, 0, 0, 0);
+                        else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    uint16_t* op = out + ((int64_t)b * R + q0 + l31) * ldo + h * 64 + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint2 w0, w1;
+        w0.x = pack2bf(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv);
+        w0.y = pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        w1.x = pack2bf(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv);
+        w1.y = pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        *(uint2*)(op + 8 * g) = w0;
+        *(uint2*)(op + 32 + 8 * g) = w1;
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len,
+                                sc_bf16* out, int64_t ldo, int32_t B, int32_t R, int32_t H, int32_t D, float scale,
+                                void* stream) {
+    SC_CHECK(qk && vt && valid_len && out, "sc_attn_fwd_bf16: null pointer");
+    SC_CHECK(B > 0 && H > 0 && R > 0 && R % 128 == 0, "sc_attn_fwd_bf16: R=%d must be a positive multiple of 128", R);
+    SC_CHECK(D == H * 64, "sc_attn_fwd_bf16: head_dim must be 64 (D=%d, H=%d)", D, H);
+    SC_CHECK(ldqk % 8 == 0 && ldo % 4 == 0 && ldqk >= 2 * D && ldo >= D, "sc_attn_fwd_bf16: bad leading dims");
+    SC_CHECK(((uintptr_t)qk % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0,
+             "sc_attn_fwd_bf16: alignment");
+    dim3 grid(R / 128, H, B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R,
+                       H, D, scale * 1.4426950408889634f);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,209 @@
+// Waveform front end: padding / optional utterance layer-norm, conv layer 0 (C_in = 1, k = 10, s = 5) with
+// GroupNorm(512 groups) + GELU fused, channels-last bf16 output.
+//
+// GroupNorm with one channel per group needs mean/var over time of every conv-0 output channel.  Because
+// conv 0 is linear in a 10-sample window, those statistics follow exactly from the 10x10 Gram matrix of the
+// strided waveform:   sum_t y_c[t]   = w_c . s,        s[j]    = sum_t x[5t + j]
+//                     sum_t y_c[t]^2 = w_c^T G w_c,    G[j,j'] = sum_t x[5t + j] x[5t + j']
+// accumulated in fp64 (deterministic two-stage reduction).  The 2.1 GB (B=64, 10 s) conv-0 activation is
+// therefore written exactly once, already normalised and activated; the waveform is read from L2.
+#include "sc_common.h"
+
+namespace {
+
+// one block per utterance: optional layer_norm over the utterance's own samples, zero padding to ldw_out
+__global__ __launch_bounds__(256) void wav_prep_kernel(const float* __restrict__ wav, int64_t ldw_in,
+                                                       const int64_t* __restrict__ wav_len, float* __restrict__ out,
+                                                       int64_t ldw_out, int L, int normalize) {
+    __shared__ double red[2][4];
+    const int b = blockIdx.x;
+    int len = (int)wav_len[b];
+    len = max(0, min(len, L));
+    const float* x = wav + (int64_t)b * ldw_in;
+    float* o = out + (int64_t)b * ldw_out;
+    float mean = 0.f, rstd = 1.f;
+    if (normalize) {
+        double s = 0.0, s2 = 0.0;
+        for (int i = threadIdx.x; i < len; i += blockDim.x) {
+            const double v = x[i];
+            s += v;
+            s2 += v * v;
+        }
+        s = wave_sum_d(s);
+        s2 = wave_sum_d(s2);
+        if ((threadIdx.x & 63) == 0) {
+            red[0][threadIdx.x >> 6] = s;
+            red[1][threadIdx.x >> 6] = s2;
+        }
+        __syncthreads();
+        const double S = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const double S2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double mu = S / (double)max(len, 1);
+        const double var = fmax(S2 / (double)max(len, 1) - mu * mu, 0.0);
+        mean = (float)mu;
+        rstd = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    for (int64_t i = threadIdx.x; i < ldw_out; i += blockDim.x) {
+        float v = 0.f;
+        if (i < len) v = normalize ? (x[i] - mean) * rstd : x[i];
+        o[i] = v;
+    }
+}
+
+// partial[(b*nchunk + chunk)*66 + e]: e < 55 Gram (j <= j'), 55..64 sums
+__global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ wav, int64_t ldw, int T0,
+                                                          int nchunk, double* __restrict__ partial) {
+    __shared__ double red[4][SC_CONV0_NSTAT];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int per = (T0 + nchunk - 1) / nchunk;
+    const int t_begin = chunk * per, t_end = min(T0, t_begin + per);
+    const float* x = wav + (int64_t)b * ldw;
+    double acc[65];
+#pragma unroll
+    for (int e = 0; e < 65; ++e) acc[e] = 0.0;
+    for (int t = t_begin + threadIdx.x; t < t_end; t += blockDim.x) {
+        float v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 10; ++j)
+#pragma unroll
+            for (int k = j; k < 10; ++k) acc[e++] += (double)v[j] * (double)v[k];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) acc[55 + j] += (double)v[j];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < 65; ++e) {
+        const double s = wave_sum_d(acc[e]);
+        if (lane == 0) red[wave][e] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 65)
+        partial[((int64_t)b * nchunk + chunk) * SC_CONV0_NSTAT + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// one block per utterance: reduce partials in fixed order, then per-channel scale / shift
+__global__ __launch_bounds__(256) void conv0_finalize_kernel(const double* __restrict__ partial, int nchunk,
+                                                             const float* __restrict__ w0,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int C, int T0, float eps,
+                                                             float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double st[SC_CONV0_NSTAT];
+    const int b = blockIdx.x;
+    if (threadIdx.x < 65) {
+        double s = 0.0;
+        for (int c = 0; c < nchunk; ++c) s += partial[((int64_t)b * nchunk + c) * SC_CONV0_NSTAT + threadIdx.x];
+        st[threadIdx.x] = s;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double w[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[j] = (double)w0[c * 10 + j];
+        double s1 = 0.0, s2 = 0.0;
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            s1 += w[j] * st[55 + j];
+#pragma unroll
+            for (int k = j; k < 10; ++k) {
+                const double term = w[j] * w[k] * st[e++];
+                s2 += (k == j) ? term : 2.0 * term;
+            }
+        }
+        const double mu = s1 / (double)T0;
+        const double var = fmax(s2 / (double)T0 - mu * mu, 0.0);
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double g = (double)gamma[c];
+        scale[(int64_t)b * C + c] = (float)(g * rstd);
+        shift[(int64_t)b * C + c] = (float)((double)beta[c] - mu * g * rstd);
+    }
+}
+
+// out[b*R0 + t, c] = gelu(conv0(x)[t, c] * scale[b, c] + shift[b, c]); one wave = one output row per step
+// (64 lanes x 8 channels = 512 channels = 1 KiB contiguous store).
+__global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int64_t ldw,
+                                                            const float* __restrict__ w0,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            uint16_t* __restrict__ out, int R0, int C,
+                                                            int rows_per_block) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cgroups = C / 512;   // C is a multiple of 512 (checked on the host)
+    const float* x = wav + (int64_t)b * ldw;
+    const int t_begin = blockIdx.x * rows_per_block;
+    const int t_end = min(R0, t_begin + rows_per_block);
+    for (int cg = 0; cg < cgroups; ++cg) {
+        const int c0 = cg * 512 + lane * 8;
+        float w[8][10], sc[8], sh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) w[i][j] = w0[(c0 + i) * 10 + j];
+            sc[i] = scale[(int64_t)b * C + c0 + i];
+            sh[i] = shift[(int64_t)b * C + c0 + i];
+        }
+        for (int t = t_begin + wave; t < t_end; t += 4) {
+            float v[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];   // wave-uniform address: broadcast load
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) a = fmaf(w[i][j], v[j], a);
+                o[i] = gelu_erf(fmaf(a, sc[i], sh[i]));
+            }
+            uint4 u;
+            u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
+            u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+            *(uint4*)(out + ((int64_t)b * R0 + t) * C + c0) = u;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_wav_prep(const float* wav, int64_t ldw_in, const int64_t* wav_len, float* out, int64_t ldw_out,
+                           int32_t B, int32_t L, int32_t normalize, void* stream) {
+    SC_CHECK(wav && wav_len && out, "sc_wav_prep: null pointer");
+    SC_CHECK(B > 0 && L > 0 && ldw_out >= L && ldw_in >= L, "sc_wav_prep: bad sizes");
+    hipLaunchKernelGGL(wav_prep_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, wav, ldw_in, wav_len, out, ldw_out, L, normalize);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_stats(const float* wav, int64_t ldw, int32_t B, int32_t T0, int32_t nchunk, double* partial,
+                              void* stream) {
+    SC_CHECK(wav && partial, "sc_conv0_stats: null pointer");
+    SC_CHECK(B > 0 && T0 > 0 && nchunk > 0 && ldw >= 5 * (int64_t)(T0 - 1) + 10, "sc_conv0_stats: bad sizes");
+    hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, wav, ldw, T0, nchunk, partial);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_finalize(const double* partial, int32_t nchunk, const float* w0, const float* gamma,
+                                 const float* beta, int32_t B, int32_t C, int32_t T0, float eps, float* scale,
+                                 float* shift, void* stream) {
+    SC_CHECK(partial && w0 && gamma && beta && scale && shift, "sc_conv0_finalize: null pointer");
+    hipLaunchKernelGGL(conv0_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, nchunk, w0, gamma, beta, C, T0, eps, scale, shift);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_gn_gelu(const float* wav, int64_t ldw, const float* w0, const float* scale, const float* shift,
+                                sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream) {
+    SC_CHECK(wav && w0 && scale && shift && out, "sc_conv0_gn_gelu: null pointer");
+    SC_CHECK(C % 512 == 0 && ldw >= 5 * (int64_t)(R0 - 1) + 10, "sc_conv0_gn_gelu: C=%d must be a multiple of 512; ldw too small", C);
+    SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_gn_gelu: alignment");
+    const int rows_per_block = 128;
+    dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
+    hipLaunchKernelGGL(conv0_gn_gelu_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, scale, shift, out, R0, C, rows_per_block);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,273 @@
+// bf16 MFMA GEMM  C = epi(A . W^T)  for gfx950.
+//
+// Tile BM x BN x 64, 256 threads = 4 waves (2 x 2), v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+// Staging: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction = 8 tile rows of 128 B), two LDS
+// buffers; the next K-tile's DMA is issued before the current tile's MFMAs, one barrier per K-tile.
+// LDS image: row-major 128-B rows, 16-B chunk index XOR ((row >> 1) & 7): with two rows per 256-B bank row
+// every ds_read_b128 lane group of the 16x16x32 fragment read touches 16 distinct 16-B slots (conflict
+// free); the DMA writes LDS linearly, so the swizzle is applied on the per-lane GLOBAL source address.
+// Epilogue: fp32 accumulators (+bias, GELU) -> LDS tile -> coalesced 16-B rows (+residual) -> HBM;
+// column blocks >= n_split are written transposed per head (V^T for the attention kernel).
+// Block -> tile map: XCD-aware (blocks b, b+8, ... share an XCD and therefore an L2) and banded
+// (8 M-tiles x all N-tiles per band) so that co-resident blocks share A rows and W rows in L2.
+#include "sc_common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int ROWB = BK * 2;   // bytes per LDS tile row
+
+template <int BM, int BN>
+struct GemmCfg {
+    static constexpr int WM = 2, WN = 2;
+    static constexpr int TM = BM / WM, TN = BN / WN;
+    static constexpr int FM = TM / 16, FN = TN / 16;
+    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    static constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES);
+    static constexpr int EPI_BYTES = BM * BN * 4;
+    static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+};
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
+    using Cfg = GemmCfg<BM, BN>;
+    constexpr int FM = Cfg::FM, FN = Cfg::FN, TM = Cfg::TM, TN = Cfg::TN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- block -> (m_tile, n_tile): XCD remap (bijective) then banded order --------------------------
+    const int nM = (p.M + BM - 1) / BM, nN = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int L;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GM = 8;
+    const int band = L / (GM * nN);
+    const int first_m = band * GM;
+    const int gm = min(GM, nM - first_m);
+    const int within = L - band * GM * nN;
+    const int n_tile = within / gm, m_tile = first_m + within % gm;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    // ---- batch offsets ----------------------------------------------------------------------------------
+    const int z = blockIdx.z, z1 = z / p.nb2, z2 = z % p.nb2;
+    const uint16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
+    const uint16_t* W = p.W + z1 * p.sW1 + z2 * p.sW2;
+    const float* bias = p.bias ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
+    const uint16_t* Rs = p.residual ? p.residual + z1 * p.sR1 + z2 * p.sR2 : nullptr;
+    const int64_t coff = z1 * p.sC1 + z2 * p.sC2;
+
+    // ---- DMA source pointers (per lane; swizzle lives in the source address) ----------------------------
+    constexpr int A_INST = BM / 32, B_INST = BN / 32;   // wave-instructions per wave per K-tile
+    const uint16_t* a_src[A_INST];
+    const uint16_t* b_src[B_INST];
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int gm_row = min(m0 + row, p.M - 1);
+        a_src[i] = A + (int64_t)gm_row * p.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int gn_row = min(n0 + row, p.N - 1);
+        b_src[i] = W + (int64_t)gn_row * p.ldw + c * 8;
+    }
+    char* const As = smem;
+    char* const Bs = smem + 2 * Cfg::A_BYTES;
+
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i)
+            glds16(a_src[i] + k0, As + buf * Cfg::A_BYTES + (i * 4 + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < B_INST; ++i)
+            glds16(b_src[i] + k0, Bs + buf * Cfg::B_BYTES + (i * 4 + wave) * 1024);
+    };
+
+    // ---- fragment read offsets (bytes inside a tile) ----------------------------------------------------
+    int a_off[FM][2], b_off[FN][2];
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi) {
+        const int row = wm * TM + mi * 16 + (lane & 15);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) a_off[mi][kk] = row * ROWB + (((kk * 4 + (lane >> 4)) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ni = 0; ni < FN; ++ni) {
+        const int row = wn * TN + ni * 16 + (lane & 15);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) b_off[ni][kk] = row * ROWB + (((kk * 4 + (lane >> 4)) ^ ((row >> 1) & 7)) << 4);
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    __syncthreads();   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+        const char* as = As + buf * Cfg::A_BYTES;
+        const char* bs = Bs + buf * Cfg::B_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[FM], bfr[FN];
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi) af[mi] = *(const bf16x8*)(as + a_off[mi][kk]);
+#pragma unroll
+            for (int ni = 0; ni < FN; ++ni) bfr[ni] = *(const bf16x8*)(bs + b_off[ni][kk]);
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < FN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------------
+    float* Cs = (float*)smem;
+    const bool transposed = (p.n_split >= 0) && (n0 >= p.n_split);
+#pragma unroll
+    for (int ni = 0; ni < FN; ++ni) {
+        const int nl = wn * TN + ni * 16 + (lane & 15);
+        const int n = n0 + nl;
+        const float bv = (bias && n < p.N) ? bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+            const int ml = wm * TM + mi * 16 + 4 * (lane >> 4);
+            f32x4 v = acc[mi][ni];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = v[r] + bv;
+                if (p.act == 1) x = gelu_erf(x);
+                v[r] = x;
+            }
+            if (transposed) {
+                *(f32x4*)(Cs + nl * BM + ml) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cs[(ml + r) * BN + nl] = v[r];
+            }
+        }
+    }
+    __syncthreads();
+    if (!transposed) {
+        constexpr int CPR = BN / 8;   // 8-element chunks per row
+#pragma unroll
+        for (int it = 0; it < BM * CPR / 256; ++it) {
+            const int q = it * 256 + tid;
+            const int row = q / CPR, cc = q % CPR;
+            const int m = m0 + row, n = n0 + cc * 8;
+            if (m < p.M && n + 8 <= p.N) {
+                const f32x4 lo = *(const f32x4*)(Cs + row * BN + cc * 8);
+                const f32x4 hi = *(const f32x4*)(Cs + row * BN + cc * 8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (Rs) {
+                    const uint4 rv = *(const uint4*)(Rs + (int64_t)m * p.ldr + n);
+                    v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
+                    v[4] += bflo(rv.z); v[5] += bfhi(rv.z); v[6] += bflo(rv.w); v[7] += bfhi(rv.w);
+                }
+                if (p.out_f32) {
+                    float* C = (float*)p.C + coff + (int64_t)m * p.ldc + n;
+                    *(f32x4*)C = f32x4{v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(C + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    uint16_t* C = (uint16_t*)p.C + coff + (int64_t)m * p.ldc + n;
+                    uint4 o;
+                    o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                    o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+                    *(uint4*)C = o;
+                }
+            }
+        }
+    } else {
+        constexpr int CPR = BM / 8;
+        const int H = (p.N - p.n_split) / p.dh;
+#pragma unroll
+        for (int it = 0; it < BN * CPR / 256; ++it) {
+            const int q = it * 256 + tid;
+            const int nrow = q / CPR, mc = q % CPR;
+            const int m = m0 + mc * 8, n = n0 + nrow;
+            if (m < p.M && n < p.N) {
+                const f32x4 lo = *(const f32x4*)(Cs + nrow * BM + mc * 8);
+                const f32x4 hi = *(const f32x4*)(Cs + nrow * BM + mc * 8 + 4);
+                const int nn = n - p.n_split, hh = nn / p.dh, d = nn % p.dh;
+                const int b = m / p.R, t = m % p.R;
+                uint16_t* dst = p.Ct + (((int64_t)b * H + hh) * p.dh + d) * p.R + t;
+                uint4 o;
+                o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]);
+                o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
+                *(uint4*)dst = o;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch(const sc_gemm_args& a, hipStream_t s) {
+    using Cfg = GemmCfg<BM, BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) {
+            sc_set_error("hipFuncSetAttribute(gemm %dx%d): %s", BM, BN, hipGetErrorString(e));
+            return -3;
+        }
+        attr_set = true;
+    }
+    const int nM = (a.M + BM - 1) / BM, nN = (a.N + BN - 1) / BN;
+    dim3 grid(nM * nN, 1, a.nb1 * a.nb2);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
+    SC_CHECK(args != nullptr, "sc_gemm_bf16: null args");
+    sc_gemm_args a = *args;
+    SC_CHECK(a.A && a.W && a.C, "sc_gemm_bf16: null operand");
+    SC_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "sc_gemm_bf16: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    SC_CHECK(a.K % BK == 0, "sc_gemm_bf16: K=%d must be a multiple of %d", a.K, BK);
+    SC_CHECK(a.N % 8 == 0, "sc_gemm_bf16: N=%d must be a multiple of 8", a.N);
+    SC_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0, "sc_gemm_bf16: leading dims must be multiples of 8");
+    SC_CHECK(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0 && ((uintptr_t)a.C % 16) == 0,
+             "sc_gemm_bf16: operands must be 16-byte aligned");
+    SC_CHECK(a.act == 0 || a.act == 1, "sc_gemm_bf16: act=%d", a.act);
+    if (a.nb1 < 1) a.nb1 = 1;
+    if (a.nb2 < 1) a.nb2 = 1;
+    if (a.residual) SC_CHECK(a.ldr % 8 == 0 && ((uintptr_t)a.residual % 16) == 0, "sc_gemm_bf16: residual alignment");
+    if (a.n_split >= 0) {
+        SC_CHECK(a.Ct != nullptr && a.dh > 0 && a.R > 0, "sc_gemm_bf16: transposed store needs Ct, dh, R");
+        SC_CHECK(a.n_split % 128 == 0 && a.R % 128 == 0 && (a.N - a.n_split) % a.dh == 0 && a.M % a.R == 0,
+                 "sc_gemm_bf16: transposed store needs n_split %% 128 == 0, R %% 128 == 0, M %% R == 0");
+        SC_CHECK(a.out_f32 == 0, "sc_gemm_bf16: transposed store is bf16 only");
+    } else {
+        a.n_split = -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // narrow outputs (grouped pos_conv, N = 48) waste less of a 64-wide tile
+    if (a.N <= 64 && a.n_split < 0) return launch<128, 64>(a, s);
+    return launch<128, 128>(a, s);
+}

@@ -1,0 +1,209 @@
+// HBM-bound row kernels: LayerNorm, weighted sum over hidden states (fwd/bwd), pos_conv input regroup.
+// One wave per row, 8-byte (4 x bf16) vector accesses, wavefront reductions (no LDS).
+#include "sc_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------- LayerNorm
+template <int NCH>   // 4-element chunks per lane: D = 256 * NCH at most
+__global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, uint16_t* __restrict__ y,
+                                                        int64_t ldy, int64_t rows, int D, float eps, int act) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunks = D >> 2;
+    float v[NCH][4];
+    float sum = 0.f;
+    const uint16_t* xr = x + row * ldx;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+            const uint2 u = *(const uint2*)(xr + ch * 4);
+            v[i][0] = bflo(u.x); v[i][1] = bfhi(u.x); v[i][2] = bflo(u.y); v[i][3] = bfhi(u.y);
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    uint16_t* yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+            const f32x4 g = *(const f32x4*)(gamma + ch * 4);
+            const f32x4 bt = *(const f32x4*)(beta + ch * 4);
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (v[i][j] - mean) * rstd * g[j] + bt[j];
+                if (act == 1) o[j] = gelu_erf(o[j]);
+            }
+            uint2 w;
+            w.x = pack2bf(o[0], o[1]);
+            w.y = pack2bf(o[2], o[3]);
+            *(uint2*)(yr + ch * 4) = w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- weighted sum
+// out[b, t + row_off, :] = sum_n w[n] * h[n, b, t, :]   (t + row_off < R)
+__global__ __launch_bounds__(256) void wsum_fwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w,
+                                                       int NL, uint16_t* __restrict__ out, int B, int R, int D,
+                                                       int row_off) {
+    const int64_t chunks_per_row = D >> 3;
+    const int64_t total = (int64_t)B * R * chunks_per_row;
+    const int64_t plane = (int64_t)B * R * D;
+    float wl[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) wl[n] = n < NL ? w[n] : 0.f;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = q / chunks_per_row;
+        const int cc = (int)(q % chunks_per_row);
+        const int t = (int)(row % R);
+        if (t + row_off >= R) continue;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint16_t* src = h + row * D + cc * 8;
+#pragma unroll 4
+        for (int n = 0; n < NL; ++n) {
+            const uint4 u = *(const uint4*)(src + n * plane);
+            const float wn = wl[n];
+            acc[0] += wn * bflo(u.x); acc[1] += wn * bfhi(u.x); acc[2] += wn * bflo(u.y); acc[3] += wn * bfhi(u.y);
+            acc[4] += wn * bflo(u.z); acc[5] += wn * bfhi(u.z); acc[6] += wn * bflo(u.w); acc[7] += wn * bfhi(u.w);
+        }
+        uint4 o;
+        o.x = pack2bf(acc[0], acc[1]); o.y = pack2bf(acc[2], acc[3]);
+        o.z = pack2bf(acc[4], acc[5]); o.w = pack2bf(acc[6], acc[7]);
+        *(uint4*)(out + (row + row_off) * D + cc * 8) = o;
+    }
+}
+
+// dw_partial[blk, n] = sum over this block's elements of g[b, t + row_off, d] * h[n, b, t, d]
+__global__ __launch_bounds__(256) void wsum_bwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ g,
+                                                       int NL, float* __restrict__ dw_partial, int B, int R, int D,
+                                                       int row_off) {
+    __shared__ float red[4][32];
+    const int64_t chunks_per_row = D >> 3;
+    const int64_t total = (int64_t)B * R * chunks_per_row;
+    const int64_t plane = (int64_t)B * R * D;
+    float acc[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) acc[n] = 0.f;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = q / chunks_per_row;
+        const int cc = (int)(q % chunks_per_row);
+        const int t = (int)(row % R);
+        if (t + row_off >= R) continue;
+        const float* gp = g + (row + row_off) * D + cc * 8;
+        const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+        const uint16_t* src = h + row * D + cc * 8;
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            if (n < NL) {
+                const uint4 u = *(const uint4*)(src + n * plane);
+                acc[n] += g0[0] * bflo(u.x) + g0[1] * bfhi(u.x) + g0[2] * bflo(u.y) + g0[3] * bfhi(u.y) +
+                          g1[0] * bflo(u.z) + g1[1] * bfhi(u.z) + g1[2] * bflo(u.w) + g1[3] * bfhi(u.w);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        const float s = wave_sum(acc[n]);
+        if (lane == 0) red[wave][n] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NL)
+        dw_partial[(int64_t)blockIdx.x * NL + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------- pos_conv prep
+// xz[b*R + t, :] = t < valid[b] ? x : 0 ;  xg[g][b][halo + t][0:Dg] = same, group-major with zero halos.
+__global__ __launch_bounds__(256) void posconv_prep_kernel(const uint16_t* __restrict__ x,
+                                                           const int32_t* __restrict__ valid_len,
+                                                           uint16_t* __restrict__ xz, uint16_t* __restrict__ xg,
+                                                           int B, int R, int D, int G, int halo) {
+    const int Dg = D / G;
+    const int cpg = Dg >> 3;               // 16-B chunks per group slice (Dg % 8 == 0)
+    const int64_t chunks_per_row = D >> 3;
+    const int64_t total = (int64_t)B * R * chunks_per_row;
+    const int Rp = R + 2 * halo;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = q / chunks_per_row;
+        const int cc = (int)(q % chunks_per_row);
+        const int b = (int)(row / R), t = (int)(row % R);
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (t < valid_len[b]) u = *(const uint4*)(x + row * D + cc * 8);
+        *(uint4*)(xz + row * D + cc * 8) = u;
+        const int g = cc / cpg, cg = cc % cpg;
+        *(uint4*)(xg + (((int64_t)g * B + b) * Rp + halo + t) * Dg + cg * 8) = u;
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_layernorm_bf16(const sc_bf16* x, int64_t ldx, const float* gamma, const float* beta, sc_bf16* y,
+                                 int64_t ldy, int64_t rows, int32_t D, float eps, int32_t act, void* stream) {
+    SC_CHECK(x && gamma && beta && y, "sc_layernorm_bf16: null pointer");
+    SC_CHECK(D > 0 && D % 4 == 0 && D <= 1024, "sc_layernorm_bf16: D=%d must be a multiple of 4, <= 1024", D);
+    SC_CHECK(ldx % 4 == 0 && ldy % 4 == 0 && rows > 0, "sc_layernorm_bf16: bad ld/rows");
+    SC_CHECK(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+                 ((uintptr_t)beta % 16) == 0, "sc_layernorm_bf16: alignment");
+    dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (D / 4 + 63) / 64;
+    if (nch <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
+    else if (nch == 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
+    else hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_wsum_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, int32_t B, int32_t R, int32_t D,
+                           int32_t row_off, void* stream) {
+    SC_CHECK(h && w && out, "sc_wsum_fwd: null pointer");
+    SC_CHECK(NL >= 1 && NL <= 32 && D % 8 == 0 && row_off >= 0 && row_off < R, "sc_wsum_fwd: bad NL/D/row_off");
+    const int64_t total = (int64_t)B * R * (D / 8);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wsum_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, w, NL, out, B, R, D, row_off);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_wsum_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial, int32_t nblk, int32_t B,
+                           int32_t R, int32_t D, int32_t row_off, void* stream) {
+    SC_CHECK(h && g && dw_partial, "sc_wsum_bwd: null pointer");
+    SC_CHECK(NL >= 1 && NL <= 32 && D % 8 == 0 && nblk >= 1 && row_off >= 0 && row_off < R, "sc_wsum_bwd: bad args");
+    hipLaunchKernelGGL(wsum_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, h, g, NL, dw_partial, B, R, D, row_off);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_posconv_prep(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_bf16* xg, int32_t B,
+                               int32_t R, int32_t D, int32_t G, int32_t halo, void* stream) {
+    SC_CHECK(x && valid_len && xz && xg, "sc_posconv_prep: null pointer");
+    SC_CHECK(G > 0 && D % G == 0 && (D / G) % 8 == 0, "sc_posconv_prep: D/G=%d must be a multiple of 8", D / G);
+    const int64_t total = (int64_t)B * R * (D / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(posconv_prep_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, valid_len, xz, xg, B, R, D, G, halo);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,60 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA bf16, LDS 160 KiB/CU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "speechclip_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define SC_WAVE 64
+
+__device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+// exact (erf) GELU: fairseq nn.GELU() / torch "gelu"
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// host side
+void sc_set_error(const char* fmt, ...);
+#define SC_CHECK(cond, ...)                 \
+    do {                                    \
+        if (!(cond)) {                      \
+            sc_set_error(__VA_ARGS__);      \
+            return -1;                      \
+        }                                   \
+    } while (0)
+#define SC_LAUNCH_CHECK()                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = hipGetLastError();                                                       \
+        if (e_ != hipSuccess) {                                                                  \
+            sc_set_error("%s:%d kernel launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return -2;                                                                           \
+        }                                                                                        \
+    } while (0)

@@ -1,0 +1,192 @@
+"""Tensor-level wrappers over the C ABI (raw device pointers, current HIP stream).
+
+torch is used here only for device memory and streams.  Every function requires device tensors and the
+built extension; nothing falls back to eager PyTorch or the CPU.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from ._lib import GemmArgs, check, lib
+
+
+def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("speechclip_plus_amd ops need device (HIP) tensors; there is no CPU path")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tensor, ldc: int, M: int, N: int, K: int,
+             bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ldr: int = 0, act: int = 0,
+             out_f32: bool = False, Ct: Optional[torch.Tensor] = None, n_split: int = -1, R: int = 0, dh: int = 0,
+             nb1: int = 1, nb2: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sBias=(0, 0), sR=(0, 0)) -> None:
+    """C = epi(A . W^T); see sc_gemm_args in include/speechclip_hip.h.  Pointers are the tensors' data_ptr()
+    (pass a sliced view to offset)."""
+    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16
+    assert C.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+    if bias is not None:
+        assert bias.dtype == torch.float32
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16
+    a = GemmArgs()
+    a.A, a.lda, a.W, a.ldw, a.C, a.ldc = _p(A), lda, _p(W), ldw, _p(C), ldc
+    a.M, a.N, a.K = M, N, K
+    a.bias, a.residual, a.ldr = _p(bias), _p(residual), ldr
+    a.act, a.out_f32 = act, int(out_f32)
+    a.Ct, a.n_split, a.R, a.dh = _p(Ct), n_split, R, dh
+    a.nb1, a.nb2 = nb1, nb2
+    a.sA1, a.sA2 = sA
+    a.sW1, a.sW2 = sW
+    a.sC1, a.sC2 = sC
+    a.sBias1, a.sBias2 = sBias
+    a.sR1, a.sR2 = sR
+    check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
+
+
+def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None, act: int = 0, out_f32: bool = False) -> torch.Tensor:
+    """y[M, N] = epi(x[M, K] . w[N, K]^T) for contiguous 2-D operands."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    gemm_raw(x, x.stride(0), w, w.stride(0), out, out.stride(0), M, N, K, bias=bias, residual=residual,
+             ldr=residual.stride(0) if residual is not None else 0, act=act, out_f32=out_f32)
+    return out
+
+
+def attn_fwd(qk: torch.Tensor, vt: torch.Tensor, valid_len: torch.Tensor, out: torch.Tensor, B: int, R: int, H: int,
+             D: int, scale: float) -> None:
+    assert qk.dtype == torch.bfloat16 and vt.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+    assert valid_len.dtype == torch.int32
+    check(lib().sc_attn_fwd_bf16(_p(qk), qk.stride(0), _p(vt), _p(valid_len), _p(out), out.stride(0), B, R, H, D,
+                                 float(scale), _stream()), "sc_attn_fwd_bf16")
+
+
+def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Optional[torch.Tensor] = None,
+                   eps: float = 1e-5, act: int = 0) -> torch.Tensor:
+    assert x.dim() == 2 and x.dtype == torch.bfloat16 and x.stride(1) == 1
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().sc_layernorm_bf16(_p(x), x.stride(0), _p(gamma), _p(beta), _p(out), out.stride(0), x.shape[0],
+                                  x.shape[1], float(eps), act, _stream()), "sc_layernorm_bf16")
+    return out
+
+
+def wav_prep(wav: torch.Tensor, wav_len: torch.Tensor, out: torch.Tensor, normalize: bool) -> None:
+    assert wav.dtype == torch.float32 and wav_len.dtype == torch.int64 and out.dtype == torch.float32
+    B, L = wav.shape
+    check(lib().sc_wav_prep(_p(wav), wav.stride(0), _p(wav_len), _p(out), out.stride(0), B, L, int(normalize), _stream()),
+          "sc_wav_prep")
+
+
+def conv0_groupnorm_gelu(wav_pad: torch.Tensor, w0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, T0: int,
+                         R0: int, out: torch.Tensor, eps: float = 1e-5, nchunk: int = 32) -> None:
+    """conv layer 0 + GroupNorm(C groups) over t < T0 + GELU -> out[B*R0, C] bf16 (channels-last)."""
+    B = wav_pad.shape[0]
+    C = w0.shape[0]
+    partial = torch.empty(B * nchunk * 66, device=wav_pad.device, dtype=torch.float64)
+    scale = torch.empty(B, C, device=wav_pad.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    L = lib()
+    check(L.sc_conv0_stats(_p(wav_pad), wav_pad.stride(0), B, T0, nchunk, _p(partial), _stream()), "sc_conv0_stats")
+    check(L.sc_conv0_finalize(_p(partial), nchunk, _p(w0), _p(gamma), _p(beta), B, C, T0, float(eps), _p(scale),
+                              _p(shift), _stream()), "sc_conv0_finalize")
+    check(L.sc_conv0_gn_gelu(_p(wav_pad), wav_pad.stride(0), _p(w0), _p(scale), _p(shift), _p(out), B, R0, C, _stream()),
+          "sc_conv0_gn_gelu")
+
+
+def posconv_prep(x: torch.Tensor, valid_len: torch.Tensor, xz: torch.Tensor, xg: torch.Tensor, B: int, R: int, D: int,
+                 G: int, halo: int) -> None:
+    check(lib().sc_posconv_prep(_p(x), _p(valid_len), _p(xz), _p(xg), B, R, D, G, halo, _stream()), "sc_posconv_prep")
+
+
+def wsum_fwd(h: torch.Tensor, w_softmax: torch.Tensor, out: torch.Tensor, B: int, R: int, D: int, row_off: int) -> None:
+    NL = h.shape[0]
+    assert h.dtype == torch.bfloat16 and w_softmax.dtype == torch.float32 and out.dtype == torch.bfloat16
+    check(lib().sc_wsum_fwd(_p(h), _p(w_softmax), NL, _p(out), B, R, D, row_off, _stream()), "sc_wsum_fwd")
+
+
+def wsum_bwd(h: torch.Tensor, g: torch.Tensor, B: int, R: int, D: int, row_off: int, nblk: int = 1024) -> torch.Tensor:
+    """returns d(softmaxed weights)[NL] = <g, h_n>."""
+    NL = h.shape[0]
+    assert g.dtype == torch.float32
+    part = torch.empty(nblk, NL, device=h.device, dtype=torch.float32)
+    check(lib().sc_wsum_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, _stream()), "sc_wsum_bwd")
+    return part.sum(0)
+
+
+def cls_scores(X: torch.Tensor, vec: torch.Tensor, per_batch: bool, B: int, R: int, D: int, H: int) -> torch.Tensor:
+    scores = torch.empty(B, H, R, device=X.device, dtype=torch.float32)
+    assert vec.dtype == torch.float32 and vec.is_contiguous()
+    check(lib().sc_cls_scores(_p(X), _p(vec), H * D if per_batch else 0, _p(scores), B, R, D, H, _stream()), "sc_cls_scores")
+    return scores
+
+
+def cls_pool_fwd(X: torch.Tensor, scores: torch.Tensor, lens: torch.Tensor, B: int, R: int, D: int, H: int):
+    p = torch.empty(B, H, R, device=X.device, dtype=torch.float32)
+    m = torch.empty(B, H, D, device=X.device, dtype=torch.float32)
+    check(lib().sc_cls_pool_fwd(_p(X), _p(scores), _p(lens), _p(p), _p(m), B, R, D, H, _stream()), "sc_cls_pool_fwd")
+    return p, m
+
+
+def cls_pool_bwd(X: torch.Tensor, p: torch.Tensor, dp: torch.Tensor, dm: torch.Tensor, a: torch.Tensor, lens: torch.Tensor,
+                 B: int, R: int, D: int, H: int):
+    dX = torch.empty(B, R, D, device=X.device, dtype=torch.float32)
+    da_part = torch.empty(B, H, D, device=X.device, dtype=torch.float32)
+    check(lib().sc_cls_pool_bwd(_p(X), _p(p), _p(dp), _p(dm), _p(a), _p(lens), _p(dX), _p(da_part), B, R, D, H, _stream()),
+          "sc_cls_pool_bwd")
+    return dX, da_part
+
+
+def sgemm(A: torch.Tensor, sai: int, sak: int, Bm: torch.Tensor, sbj: int, sbk: int, M: int, N: int, K: int,
+          alpha: float = 1.0, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert A.dtype == torch.float32 and Bm.dtype == torch.float32
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    check(lib().sc_sgemm_f32(_p(A), sai, sak, _p(Bm), sbj, sbk, _p(out), out.stride(0), M, N, K, float(alpha), _p(bias),
+                             _stream()), "sc_sgemm_f32")
+    return out
+
+
+def infonce_lse(logits: torch.Tensor, ids: Optional[torch.Tensor]):
+    Bg = logits.shape[0]
+    lse_row = torch.empty(Bg, device=logits.device, dtype=torch.float32)
+    lse_col = torch.empty_like(lse_row)
+    loss = torch.empty(Bg + 1, device=logits.device, dtype=torch.float32)
+    if ids is not None:
+        assert ids.dtype == torch.int64
+    check(lib().sc_infonce_lse(_p(logits), _p(ids), Bg, _p(lse_row), _p(lse_col), _p(loss), _stream()), "sc_infonce_lse")
+    return loss, lse_row, lse_col
+
+
+def infonce_grad(logits: torch.Tensor, ids: Optional[torch.Tensor], lse_row: torch.Tensor, lse_col: torch.Tensor,
+                 gscale: torch.Tensor):
+    Bg = logits.shape[0]
+    G = torch.empty_like(logits)
+    dot = torch.empty(Bg, device=logits.device, dtype=torch.float32)
+    check(lib().sc_infonce_grad(_p(logits), _p(ids), _p(lse_row), _p(lse_col), Bg, _p(gscale), _p(G), _p(dot), _stream()),
+          "sc_infonce_grad")
+    return G, dot
+
+
+def sumsq(x: torch.Tensor, nblk: int = 256) -> torch.Tensor:
+    part = torch.empty(nblk, device=x.device, dtype=torch.float32)
+    check(lib().sc_sumsq_f32(_p(x), x.numel(), _p(part), nblk, _stream()), "sc_sumsq_f32")
+    return part
+
+
+def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float,
+              eps: float, weight_decay: float, step: int, gn_partial: Optional[torch.Tensor], max_norm: float) -> None:
+    nblk = gn_partial.numel() if gn_partial is not None else 0
+    check(lib().sc_adam_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                            _p(gn_partial), nblk, max_norm, _stream()), "sc_adam_f32")

@@ -1,0 +1,70 @@
+"""Optimiser side of the train step: flat fp32 parameter / gradient buffers, fused clip + Adam kernel,
+and the reference's LambdaLR schedules (avssl/optim/scheduler.py:1-47).
+
+Flattening is the MI355X-first choice for data parallelism: one contiguous gradient buffer means ONE RCCL
+all-reduce per step (~30 MB for the parallel-base recipe) and one optimiser launch, instead of one
+collective / kernel per tensor.
+"""
+from typing import Iterable, List, Optional
+
+import torch
+
+from . import ops
+
+
+def linear_warmup_decay(step: int, warmup: int, max_step: int, lr: float, final_lr: float) -> float:
+    """LR multiplier of the reference's linear_warmup_decay schedule (avssl/optim/scheduler.py:22-38):
+    ramps (step+1)/warmup, then falls linearly from 1 towards final_lr/lr at max_step (not clamped past it)."""
+    n = step + 1
+    if step < warmup:
+        return n / warmup
+    r = final_lr / lr
+    return 1.0 - (1.0 - r) * (n - warmup) / (max_step - warmup)
+
+
+def noam(step: int, warmup: int = 4000) -> float:
+    """avssl/optim/scheduler.py:10-19."""
+    n = step + 1
+    return n / warmup if step < warmup else (warmup / n) ** 0.5
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (L2 weight decay folded into the gradient, bias correction) over one flat
+    buffer; gradient clipping by global norm (trainer.gradient_clip_val) fused into the same launch."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, max_grad_norm: float = 0.0):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        assert len(self.params) > 0
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.n = n
+        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat_p[off: off + k].copy_(p.data.reshape(-1).float())
+            p.data = self.flat_p[off: off + k].view_as(p.data)        # parameters now alias the flat buffer
+            p.grad = self.flat_g[off: off + k].view_as(p.data)        # autograd accumulates in place
+            off += k
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.step_count = 0
+
+    def zero_grad(self) -> None:
+        self.flat_g.zero_()
+        off = 0
+        for p in self.params:                                          # re-attach if something replaced .grad
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self.flat_g[off: off + k].view_as(p.data)
+            off += k
+
+    def step(self, lr: Optional[float] = None) -> None:
+        self.step_count += 1
+        gn = ops.sumsq(self.flat_g) if self.max_grad_norm > 0 else None
+        ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr if lr is None else lr, self.betas[0],
+                      self.betas[1], self.eps, self.weight_decay, self.step_count, gn, float(self.max_grad_norm))

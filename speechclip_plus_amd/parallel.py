@@ -1,0 +1,75 @@
+"""Data parallelism for the contrastive step: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference trains with nn.DataParallel (``strategy: dp``): per step it broadcasts all weights,
+scatters the batch, gathers the per-replica feature dicts to GPU 0 and computes the loss there on the full
+batch (avssl/model/kwClip.py:149-189).  Here parameters stay resident on every rank and the step needs two
+collectives only:
+
+* ONE all-gather of a packed row per sample  [audio_feat (E) | image_feat (E) | id (int64 as 2 x f32)]
+  (global 512 x (2*512+2) x 4 B ~= 2 MB: latency bound, so it is a single call), after which every rank
+  evaluates the full (Bg x Bg) loss; autograd hands each rank the gradient of ITS rows only.
+* ONE all-reduce (SUM - the loss is already the global-batch mean) of the flat gradient buffer
+  (speechclip_plus_amd.optim.FlatAdam.flat_g), issued on a side stream so it overlaps the tail of the backward.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """all_gather along dim 0 (equal per-rank row counts); backward = this rank's slice of the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        world = dist.get_world_size(group)
+        ctx.rank = dist.get_rank(group)
+        ctx.n = x.shape[0]
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.rank * ctx.n: (ctx.rank + 1) * ctx.n], None
+
+
+def gather_loss_feats(audio_feat: torch.Tensor, image_feat: torch.Tensor, ids: torch.Tensor,
+                      group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Pack, all-gather once, unpack -> (audio_all, image_all, ids_all) with autograd through audio/image."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return audio_feat, image_feat, ids
+    B, E = audio_feat.shape
+    id_bits = ids.to(torch.int64).contiguous().view(torch.float32).view(B, 2)
+    packed = torch.cat([audio_feat.float(), image_feat.float(), id_bits], dim=1)       # (B, 2E + 2) fp32
+    allp = _AllGatherRows.apply(packed, group)
+    ids_all = allp[:, 2 * E:].detach().contiguous().view(torch.int64).view(-1)
+    return allp[:, :E], allp[:, E: 2 * E], ids_all
+
+
+class GradAllReduce:
+    """Sum the flat gradient buffer across ranks on a side HIP stream."""
+
+    def __init__(self, flat_grad: torch.Tensor, group: Optional[dist.ProcessGroup] = None):
+        self.flat_grad, self.group = flat_grad, group
+        self.stream = torch.cuda.Stream() if flat_grad.is_cuda else None
+        self.work = None
+
+    def launch(self) -> None:
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self.work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self) -> None:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)

@@ -1,0 +1,355 @@
+"""HuBERT speech encoder on MI355X: host-side mirror of the reference wrapper
+``FairseqSpeechEncoder_Hubert`` (avssl/module/speech_encoder_plus.py:319-634), driving the HIP kernels of
+libspeechclip_hip.so.  Same constructor keywords, ``forward(wav, wav_len, feat_select_idx,
+return_hidden_states) -> (feat, feat_len[, hidden_states])``, ``out_dim``, ``downsample_rate``,
+``trainable_params()``.
+
+Data layout in HBM: channels-last bf16 activations in a padded row layout, utterance b / frame t
+-> row b*R_l + t with R_6 = R = roundup(T + 2, 128) and R_{l-1} = 2 R_l down the conv stack (R_wav = 5 R_0).
+With that layout every strided Conv1d of the feature extractor is ONE flat GEMM whose A rows overlap
+(lda = stride*C, K = k*C), the transformer GEMMs see M = B*R rows, and attention / pooling index utterances
+by b*R.  Rows t >= T_l are scratch: finite, never read as keys, never returned.
+
+There is no pretrained checkpoint offline (the reference downloads hubert_base_ls960.pt,
+speech_encoder_plus.py:327-331,382): weights come from ``state_dict`` (fairseq key names, pos_conv weight-norm
+already folded or given as weight_g / weight_v) or are seeded random.
+"""
+import logging
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .weighted_sum import WeightedSumLayer
+
+logger = logging.getLogger(__name__)
+
+FEAT_SELECT_IDX_WEIGHTED_SUM_MODE = "weighted_sum"
+
+
+@dataclass
+class HubertArch:
+    embed_dim: int = 768
+    ffn_dim: int = 3072
+    layers: int = 12
+    heads: int = 12
+    conv_dim: int = 512
+    conv_kernels: Tuple[int, ...] = (10, 3, 3, 3, 3, 2, 2)
+    conv_strides: Tuple[int, ...] = (5, 2, 2, 2, 2, 2, 2)
+    extractor_mode: str = "default"
+    conv_bias: bool = False
+    layer_norm_first: bool = False
+    pos_conv_kernel: int = 128
+    pos_conv_groups: int = 16
+    normalize_wav: bool = False
+    downsample_rate: int = 320
+
+
+ARCHS = {
+    "hubert": HubertArch(),
+    "hubert_base": HubertArch(),
+    "hubert_large_ll60k": HubertArch(embed_dim=1024, ffn_dim=4096, layers=24, heads=16, extractor_mode="layer_norm",
+                                     conv_bias=True, layer_norm_first=True, normalize_wav=True),
+}
+
+
+def conv_out_lengths(L: int, arch: HubertArch) -> List[int]:
+    out, t = [], int(L)
+    for k, s in zip(arch.conv_kernels, arch.conv_strides):
+        t = (t - k) // s + 1
+        out.append(t)
+    return out
+
+
+def random_crop_max_length(audio: torch.Tensor, max_len: int, orig_len: int = 1000000000) -> torch.Tensor:
+    """avssl/data/audio_transforms.py:5-23 (called at speech_encoder_plus.py:548-552)."""
+    audio_len = min(len(audio), orig_len)
+    if audio_len <= max_len or max_len < 0:
+        return audio[:audio_len]
+    offset = np.random.randint(audio_len - max_len)
+    return audio[offset: offset + max_len]
+
+
+def random_hubert_state_dict(arch: HubertArch, seed: int = 7122) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights with fairseq key names (fan-in scaled so activations stay O(1))."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+
+    def randn(*shape, s):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * s
+
+    W: Dict[str, torch.Tensor] = {}
+
+    def norm(prefix, n):
+        W[prefix + ".weight"] = 1.0 + randn(n, s=0.1)
+        W[prefix + ".bias"] = randn(n, s=0.1)
+
+    cin = 1
+    for i, k in enumerate(arch.conv_kernels):
+        W[f"feature_extractor.conv_layers.{i}.0.weight"] = randn(arch.conv_dim, cin, k, s=(2.0 / (cin * k)) ** 0.5)
+        if arch.conv_bias:
+            W[f"feature_extractor.conv_layers.{i}.0.bias"] = randn(arch.conv_dim, s=0.05)
+        if arch.extractor_mode == "default" and i == 0:
+            norm(f"feature_extractor.conv_layers.{i}.2", arch.conv_dim)
+        if arch.extractor_mode == "layer_norm":
+            norm(f"feature_extractor.conv_layers.{i}.2.1", arch.conv_dim)
+        cin = arch.conv_dim
+    norm("layer_norm", arch.conv_dim)
+    D = arch.embed_dim
+    W["post_extract_proj.weight"] = randn(D, arch.conv_dim, s=arch.conv_dim ** -0.5)
+    W["post_extract_proj.bias"] = randn(D, s=0.05)
+    gsz = D // arch.pos_conv_groups
+    W["encoder.pos_conv.0.weight"] = randn(D, gsz, arch.pos_conv_kernel, s=(gsz * arch.pos_conv_kernel) ** -0.5)
+    W["encoder.pos_conv.0.bias"] = randn(D, s=0.05)
+    norm("encoder.layer_norm", D)
+    for i in range(arch.layers):
+        p = f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            W[p + f"self_attn.{n}.weight"] = randn(D, D, s=D ** -0.5)
+            W[p + f"self_attn.{n}.bias"] = randn(D, s=0.05)
+        norm(p + "self_attn_layer_norm", D)
+        W[p + "fc1.weight"] = randn(arch.ffn_dim, D, s=D ** -0.5)
+        W[p + "fc1.bias"] = randn(arch.ffn_dim, s=0.05)
+        W[p + "fc2.weight"] = randn(D, arch.ffn_dim, s=arch.ffn_dim ** -0.5)
+        W[p + "fc2.bias"] = randn(D, s=0.05)
+        norm(p + "final_layer_norm", D)
+    return W
+
+
+def _roundup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class _Plan:
+    """Shapes + resident workspaces for one (B, L) batch geometry."""
+
+    def __init__(self, arch: HubertArch, B: int, L: int, device):
+        self.B, self.L = B, L
+        self.T_l = conv_out_lengths(L, arch)
+        self.T = self.T_l[-1]
+        if self.T < 1:
+            raise ValueError(f"waveform too short for the conv stack: L={L}")
+        self.R = _roundup(self.T + 2, 128)
+        nl = len(arch.conv_kernels)
+        self.R_l = [self.R * (2 ** (nl - 1 - i)) for i in range(nl)]
+        assert all(r >= t for r, t in zip(self.R_l, self.T_l))
+        self.ldw = _roundup(max(L, arch.conv_strides[0] * self.R_l[0] + 16), 64)
+        C, D, F = arch.conv_dim, arch.embed_dim, arch.ffn_dim
+        bf, dev = torch.bfloat16, device
+        z = lambda *s, dtype=bf: torch.zeros(*s, device=dev, dtype=dtype)
+        self.wav_pad = z(B, self.ldw, dtype=torch.float32)
+        # conv activations, channels-last, +8 slack rows (the last GEMM row's window runs one row past the end)
+        self.conv = [z(B * r + 8, C) for r in self.R_l]
+        M = B * self.R
+        self.M = M
+        self.feat_ln = z(M, C)
+        self.x_proj = z(M, D)
+        self.xz = z(M, D)
+        G, halo = arch.pos_conv_groups, arch.pos_conv_kernel // 2
+        self.halo = halo
+        self.xg = z(G, B, self.R + 2 * halo, D // G)
+        self.pre = z(M, D)           # pre-LayerNorm / residual scratch
+        self.x1 = z(M, D)
+        self.qk = z(M, 2 * D)
+        self.vt = z(B, arch.heads, D // arch.heads, self.R)
+        self.ctx = z(M, D)
+        self.ffn = z(M, F)
+        self.hidden = z(arch.layers + 1, M, D)
+        self.valid = torch.zeros(B, device=dev, dtype=torch.int32)
+
+
+class FairseqSpeechEncoder_Hubert(nn.Module):
+    MODEL_DOWNSAMPLE_RATE = {"hubert": 320, "hubert_base": 320, "hubert_large_ll60k": 320}
+
+    def __init__(self, name: str = "hubert", pretrained: bool = False, trainable: bool = False, device: str = "cuda",
+                 feat_select_idx: Union[str, list] = "all", layer_drop: Union[str, float] = 0.0, max_audio_len: int = -1,
+                 reinit_layers: List[int] = [], unfreeze_layers: List[int] = [], normalize_hiddenstates: bool = False,
+                 normalize_type: str = "s3prl", state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 arch: Optional[HubertArch] = None, seed: int = 7122, **kwargs):
+        super().__init__()
+        assert name in ARCHS, "Model name({}) should be in {}".format(name, ARCHS.keys())
+        self.name = name
+        self.arch = arch if arch is not None else ARCHS[name]
+        self.pretrained = pretrained
+        self.trainable = trainable
+        if trainable or len(reinit_layers) > 0 or len(unfreeze_layers) > 0:
+            raise NotImplementedError(
+                "HuBERT backward (audio_encoder.trainable / reinit_layers / unfreeze_layers) is not built yet: every "
+                "shipped recipe freezes HuBERT (SURVEY F3); this is scope row f2")
+        if self.arch.extractor_mode != "default" or self.arch.layer_norm_first:
+            raise NotImplementedError("HuBERT-large kernels (layer_norm extractor, pre-LN layers) are not wired yet")
+        if not (isinstance(layer_drop, float) and layer_drop == 0.0) and layer_drop != "original":
+            raise ValueError(f"layer_drop = {layer_drop} is not supported.")
+        self.feat_select_idx = feat_select_idx
+        self.max_audio_len = max_audio_len
+        self.reinit_layers = reinit_layers
+        self.unfreeze_layers = unfreeze_layers
+        self.normalize_hiddenstates = normalize_hiddenstates
+        assert normalize_type in ["s3prl", "method1", "method2"], normalize_type
+        if normalize_hiddenstates:
+            raise NotImplementedError("normalize_hiddenstates=True is not used by any shipped config")
+        self.normalize_type = normalize_type
+        self.downsample_rate = self.MODEL_DOWNSAMPLE_RATE[name]
+        self.out_dim = self.arch.embed_dim
+        self.upstream_model_hiddenstates_len = self.arch.layers + 1
+        self._dev = torch.device(device)
+        if state_dict is None:
+            if pretrained:
+                logger.warning("no checkpoint available offline: HuBERT weights are seeded random (seed %d)", seed)
+            state_dict = random_hubert_state_dict(self.arch, seed)
+        self._load_weights(state_dict)
+        self._plans: Dict[Tuple[int, int], _Plan] = {}
+        if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
+            self.weightedsum_layer = WeightedSumLayer(n_weights=self.upstream_model_hiddenstates_len,
+                                                      normalize_features=False).to(self._dev)
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _load_weights(self, sd: Dict[str, torch.Tensor]) -> None:
+        a, dev = self.arch, self._dev
+        bf = lambda t: t.detach().to(device=dev, dtype=torch.bfloat16).contiguous()
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if "encoder.pos_conv.0.weight" not in sd:
+            g, v = sd["encoder.pos_conv.0.weight_g"], sd["encoder.pos_conv.0.weight_v"]
+            pos_w = g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()     # weight_norm(dim=2)
+        else:
+            pos_w = sd["encoder.pos_conv.0.weight"]
+        w = {}
+        w["conv0_w"] = f32(sd["feature_extractor.conv_layers.0.0.weight"].reshape(a.conv_dim, a.conv_kernels[0]))
+        w["gn_g"] = f32(sd["feature_extractor.conv_layers.0.2.weight"])
+        w["gn_b"] = f32(sd["feature_extractor.conv_layers.0.2.bias"])
+        for i in range(1, len(a.conv_kernels)):
+            cw = sd[f"feature_extractor.conv_layers.{i}.0.weight"]              # [C_out, C_in, k]
+            w[f"conv{i}_w"] = bf(cw.permute(0, 2, 1).reshape(cw.shape[0], -1))  # [C_out, k*C_in]  (tap-major)
+        w["ln_feat_g"], w["ln_feat_b"] = f32(sd["layer_norm.weight"]), f32(sd["layer_norm.bias"])
+        w["proj_w"], w["proj_b"] = bf(sd["post_extract_proj.weight"]), f32(sd["post_extract_proj.bias"])
+        D, G, Kp = a.embed_dim, a.pos_conv_groups, a.pos_conv_kernel
+        Dg = D // G
+        # [D, Dg, K] -> per group [Dg_out, K*Dg_in] (tap-major), groups stacked
+        w["pos_w"] = bf(pos_w.reshape(G, Dg, Dg, Kp).permute(0, 1, 3, 2).reshape(G, Dg, Kp * Dg))
+        w["pos_b"] = f32(sd["encoder.pos_conv.0.bias"])
+        w["ln_enc_g"], w["ln_enc_b"] = f32(sd["encoder.layer_norm.weight"]), f32(sd["encoder.layer_norm.bias"])
+        for i in range(a.layers):
+            p = f"encoder.layers.{i}."
+            w[f"l{i}_qkv_w"] = bf(torch.cat([sd[p + f"self_attn.{n}.weight"] for n in ("q_proj", "k_proj", "v_proj")], 0))
+            w[f"l{i}_qkv_b"] = f32(torch.cat([sd[p + f"self_attn.{n}.bias"] for n in ("q_proj", "k_proj", "v_proj")], 0))
+            w[f"l{i}_o_w"], w[f"l{i}_o_b"] = bf(sd[p + "self_attn.out_proj.weight"]), f32(sd[p + "self_attn.out_proj.bias"])
+            w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"] = f32(sd[p + "self_attn_layer_norm.weight"]), f32(sd[p + "self_attn_layer_norm.bias"])
+            w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"] = bf(sd[p + "fc1.weight"]), f32(sd[p + "fc1.bias"])
+            w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"] = bf(sd[p + "fc2.weight"]), f32(sd[p + "fc2.bias"])
+            w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"] = f32(sd[p + "final_layer_norm.weight"]), f32(sd[p + "final_layer_norm.bias"])
+        self._w = w          # frozen device tensors (not nn.Parameters: no grads, no optimizer state)
+
+    def trainable_params(self) -> list:
+        """speech_encoder_plus.py:478-494 (frozen encoder: only the weighted-sum weights train)."""
+        if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
+            return list(self.weightedsum_layer.parameters())
+        return []
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _plan(self, B: int, L: int) -> _Plan:
+        key = (B, L)
+        if key not in self._plans:
+            if len(self._plans) >= 4:          # keep HBM bounded when lengths vary
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = _Plan(self.arch, B, L, self._dev)
+        return self._plans[key]
+
+    @torch.no_grad()
+    def _encode(self, padded: torch.Tensor, wav_len: List[int]) -> _Plan:
+        """customHubertForward + patched extract_features (speech_encoder_plus.py:29-107) on the device."""
+        a, w = self.arch, self._w
+        B, L = padded.shape
+        pl = self._plan(B, L)
+        C, D, F, H = a.conv_dim, a.embed_dim, a.ffn_dim, a.heads
+        R, M, T = pl.R, pl.M, pl.T
+        len_dev = torch.tensor(wav_len, dtype=torch.int64, device=self._dev)
+        # a1: (optional) utterance layer-norm + zero pad                                (:506-518)
+        ops.wav_prep(padded, len_dev, pl.wav_pad, a.normalize_wav)
+        # fairseq forward_padding_mask: frame t valid iff t*(L//T) < len                (:81-82)
+        chunk = L // T
+        valid = [min(T, -(-int(l) // chunk)) for l in wav_len]
+        pl.valid.copy_(torch.tensor(valid, dtype=torch.int32), non_blocking=True)
+        # a2: conv feature extractor                                                    (:75)
+        ops.conv0_groupnorm_gelu(pl.wav_pad, w["conv0_w"], w["gn_g"], w["gn_b"], pl.T_l[0], pl.R_l[0], pl.conv[0])
+        for i in range(1, len(a.conv_kernels)):
+            k, s = a.conv_kernels[i], a.conv_strides[i]
+            ops.gemm_raw(pl.conv[i - 1], s * C, w[f"conv{i}_w"], k * C, pl.conv[i], C, B * pl.R_l[i], C, k * C, act=1)
+        # a3: LayerNorm(512) -> post_extract_proj                                       (:78, :84-85)
+        ops.layernorm_bf16(pl.conv[-1][:M], w["ln_feat_g"], w["ln_feat_b"], out=pl.feat_ln)
+        ops.linear_bf16(pl.feat_ln, w["proj_w"], w["proj_b"], out=pl.x_proj)
+        # a4: zero padded frames, grouped pos_conv + GELU, residual, LayerNorm          (:32-40)
+        G, Kp = a.pos_conv_groups, a.pos_conv_kernel
+        Dg, Rp = D // G, R + 2 * pl.halo
+        ops.posconv_prep(pl.x_proj, pl.valid, pl.xz, pl.xg, B, R, D, G, pl.halo)
+        ops.gemm_raw(pl.xg, Dg, w["pos_w"], Kp * Dg, pl.pre, D, R, Dg, Kp * Dg, bias=w["pos_b"], residual=pl.xz, ldr=D,
+                     act=1, nb1=G, nb2=B, sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, R * D),
+                     sBias=(Dg, 0), sR=(Dg, R * D))
+        ops.layernorm_bf16(pl.pre, w["ln_enc_g"], w["ln_enc_b"], out=pl.hidden[0])
+        # a5: transformer layers (post-LN)                                              (:49-53)
+        scale = (D // H) ** -0.5
+        for i in range(a.layers):
+            x = pl.hidden[i]
+            ops.gemm_raw(x, D, w[f"l{i}_qkv_w"], D, pl.qk, 2 * D, M, 3 * D, D, bias=w[f"l{i}_qkv_b"], Ct=pl.vt,
+                         n_split=2 * D, R=R, dh=D // H)
+            ops.attn_fwd(pl.qk, pl.vt, pl.valid, pl.ctx, B, R, H, D, scale)
+            ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x)
+            ops.layernorm_bf16(pl.pre, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
+            ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1)
+            ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.pre, residual=pl.x1)
+            ops.layernorm_bf16(pl.pre, w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"], out=pl.hidden[i + 1])
+        return pl
+
+    def forward(self, wav: Union[torch.Tensor, list], wav_len: Union[torch.Tensor, list] = [],
+                feat_select_idx: Union[str, list] = None, return_hidden_states: bool = False) -> Tuple:
+        # :539-554.  Fast path: an already padded (B, L) device batch that needs no crop goes to the kernels as is
+        # (sc_wav_prep re-applies the zero padding from wav_len); otherwise un-pad / crop / re-pad like the reference.
+        crop = self.training and self.max_audio_len >= 0
+        if isinstance(wav, torch.Tensor) and wav.dim() == 2 and not (crop and wav.shape[1] > self.max_audio_len):
+            if len(wav_len) > 0:
+                lens = [int(l) for l in (wav_len.tolist() if isinstance(wav_len, torch.Tensor) else wav_len)]
+            else:
+                lens = [wav.shape[1]] * wav.shape[0]
+            L = max(lens)
+            padded = wav[:, :L].to(self._dev, torch.float32).contiguous()
+        else:
+            if isinstance(wav, torch.Tensor):
+                if wav.dim() == 2:
+                    if len(wav_len) > 0:
+                        lens = wav_len.tolist() if isinstance(wav_len, torch.Tensor) else list(wav_len)
+                        wav = [wav[b, : lens[b]] for b in range(len(wav))]
+                    else:
+                        wav = [wav[b] for b in range(len(wav))]
+                elif wav.dim() == 1:
+                    wav = [wav]
+            if crop:                                                                   # :548-552
+                wav = [random_crop_max_length(wav[b], self.max_audio_len, len(wav[b])) for b in range(len(wav))]
+            lens = [len(w) for w in wav]
+            L = max(lens)
+            padded = torch.zeros(len(wav), L, device=self._dev, dtype=torch.float32)
+            for b, x in enumerate(wav):
+                padded[b, : lens[b]] = x.to(self._dev, torch.float32)
+        pl = self._encode(padded, lens)
+        B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
+        hidden_states = tuple(pl.hidden[n].view(B, R, D)[:, :T] for n in range(self.arch.layers + 1))
+        feat = {"last_hidden_state": hidden_states[-1], "hidden_states": hidden_states}
+        # :604-611  python round (half to even), clamp to T
+        feat_len = torch.tensor([min(round(l / self.downsample_rate), T) for l in lens], dtype=torch.long, device=self._dev)
+        if feat_select_idx is None:
+            feat_select_idx = self.feat_select_idx
+        return_list = []
+        if feat_select_idx == "all":
+            return_list.extend([feat, feat_len])
+        elif feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
+            return_list.extend([self.weightedsum_layer.forward_padded(pl.hidden, B, R, T, D), feat_len])
+        elif isinstance(feat_select_idx, list):
+            return_list.extend([[feat["hidden_states"][i] for i in feat_select_idx], feat_len])
+        elif feat_select_idx in feat:
+            return_list.extend([feat[feat_select_idx], feat_len])
+        else:
+            raise KeyError(feat_select_idx)
+        if return_hidden_states:
+            return_list.append(feat["hidden_states"])
+        return tuple(return_list)

@@ -1,0 +1,71 @@
+"""WeightedSumLayer (avssl/module/weighted_sum.py:9-45) over the HIP weighted-sum kernel.
+
+Two entry points:
+* ``forward(list_of_tensors)``  - the reference signature; stacks into the kernel layout.
+* ``forward_padded(hidden, B, R, T, D)`` - zero-copy path used by the speech encoder: ``hidden`` is the
+  resident [NL, B*R, D] bf16 buffer the transformer layers wrote; the sum lands in a fresh [B, R, D] buffer
+  at row offset 1 (row 0 is left for the CLS token of the parallel branch) and the returned ``feat`` view
+  carries a handle so the branch can run its pooled backward straight into d(weights) without
+  materialising a bf16 gradient of the features.
+"""
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class PaddedFeatHandle:
+    """Side-channel from the encoder to the branch head (same process, same step)."""
+
+    def __init__(self, src, hidden, ws_layer, w_soft, B, R, T, D):
+        self.src, self.hidden, self.ws_layer, self.w_soft = src, hidden, ws_layer, w_soft
+        self.B, self.R, self.T, self.D = B, R, T, D
+
+
+class _WeightedSumFn(torch.autograd.Function):
+    """Generic autograd path: out[M, D] = sum_n softmax(w)_n h[n]; grads to w only (h is a constant)."""
+
+    @staticmethod
+    def forward(ctx, weights, h, B, R, D):
+        w_soft = torch.softmax(weights.float(), dim=0).contiguous()
+        out = torch.zeros(B, R, D, device=h.device, dtype=torch.bfloat16)
+        ops.wsum_fwd(h, w_soft, out, B, R, D, 0)
+        ctx.save_for_backward(h, w_soft)
+        ctx.dims = (B, R, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w_soft = ctx.saved_tensors
+        B, R, D = ctx.dims
+        d_soft = ops.wsum_bwd(h, g.float().contiguous(), B, R, D, 0)
+        dw = w_soft * (d_soft - (w_soft * d_soft).sum())
+        return dw, None, None, None, None
+
+
+class WeightedSumLayer(nn.Module):
+    def __init__(self, n_weights: int, normalize_features: bool = False):
+        super().__init__()
+        self.n_weights = n_weights
+        self.weights = nn.Parameter(torch.zeros((n_weights,), dtype=torch.float))
+        self.normalize_features = normalize_features
+        if normalize_features:
+            raise NotImplementedError("normalize_features=True (per-layer layer_norm) is not used by any shipped config")
+
+    def forward(self, x: List[torch.Tensor]) -> torch.Tensor:
+        assert len(x) == self.n_weights, len(x)
+        shape = x[0].shape
+        D = shape[-1]
+        h = torch.stack([t.reshape(-1, D).to(torch.bfloat16) for t in x], dim=0).contiguous()
+        out = _WeightedSumFn.apply(self.weights, h, 1, h.shape[1], D)
+        return out.view(*shape)
+
+    def forward_padded(self, hidden: torch.Tensor, B: int, R: int, T: int, D: int) -> torch.Tensor:
+        w_soft = torch.softmax(self.weights.detach().float(), dim=0).contiguous()
+        src = torch.zeros(B, R, D, device=hidden.device, dtype=torch.bfloat16)
+        ops.wsum_fwd(hidden, w_soft, src, B, R, D, 1)
+        feat = src[:, 1: T + 1]
+        feat._sc_handle = PaddedFeatHandle(src, hidden, self, w_soft, B, R, T, D)
+        return feat

@@ -1,0 +1,69 @@
+"""world_size-2 gloo test of the data-parallel pieces (speechclip_plus_amd.parallel): the packed all-gather
+with autograd and the flat gradient all-reduce reproduce the single-process global-batch gradients.
+The loss here is the CPU oracle (the HIP loss needs a GPU); what is under test is the collective plumbing."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from speechclip_plus_amd.parallel import GradAllReduce, gather_loss_feats
+    torch.manual_seed(0)
+    Bg, E, D = 8, 16, 12
+    X = torch.randn(Bg, D)
+    img = torch.nn.functional.normalize(torch.randn(Bg, E), dim=-1)
+    ids = torch.tensor([0, 0, 1, 2, 3, 3, 4, 5])
+    W = torch.nn.Parameter(torch.randn(E, D) * 0.3)
+    # single-process reference on the global batch
+    a = torch.nn.functional.normalize(X @ W.t(), dim=-1)
+    ref_loss = oracle.masked_contrastive_loss(a, img, ids)
+    ref_grad, = torch.autograd.grad(ref_loss, W)
+    # data parallel: each rank owns Bg / world rows
+    n = Bg // world
+    sl = slice(rank * n, (rank + 1) * n)
+    a_loc = torch.nn.functional.normalize(X[sl] @ W.t(), dim=-1)
+    a_all, i_all, id_all = gather_loss_feats(a_loc, img[sl], ids[sl])
+    assert torch.equal(id_all, ids) and torch.allclose(i_all, img)
+    loss = oracle.masked_contrastive_loss(a_all, i_all, id_all)
+    loss.backward()
+    flat = W.grad.reshape(-1).clone()
+    ar = GradAllReduce(flat)
+    ar.launch()
+    ar.wait()
+    ok = abs(loss.item() - ref_loss.item()) < 1e-6 and torch.allclose(flat.view_as(W), ref_grad, atol=1e-6)
+    q.put((rank, bool(ok), float((flat.view_as(W) - ref_grad).abs().max())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gather_and_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(ok for _, ok, _ in res), res

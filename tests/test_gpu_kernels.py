@@ -1,0 +1,316 @@
+"""GPU parity, kernel by kernel, through the C ABI (speechclip_plus_amd.ops -> libspeechclip_hip.so).
+
+Reference for each kernel = the same op in plain fp32 torch on the same (bf16-rounded) inputs.
+Tolerances are stated per test: bf16 outputs carry 2^-8 relative rounding; accumulation is fp32."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from speechclip_plus_amd import ops
+    return ops
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K,act,use_bias,use_res,out_f32", [
+    (256, 768, 768, 0, True, False, False),
+    (384, 3072, 768, 1, True, False, False),
+    (300, 768, 3072, 0, True, True, False),      # M tail
+    (128, 512, 1536, 1, False, False, False),
+    (130, 200, 64, 0, True, True, True),         # M and N tails, fp32 out
+    (1024, 128, 128, 0, False, False, False),
+])
+def test_gemm(dev, M, N, K, act, use_bias, use_res, out_f32):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    A = bf(torch.randn(M, K, generator=g)).to(dev)
+    W = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    bias = torch.randn(N, generator=g).to(dev) if use_bias else None
+    res = bf(torch.randn(M, N, generator=g)).to(dev) if use_res else None
+    out = ops.linear_bf16(A, W, bias, residual=res, act=act, out_f32=out_f32)
+    ref = A.float() @ W.float().T
+    if use_bias:
+        ref = ref + bias
+    if act:
+        ref = F.gelu(ref)
+    if use_res:
+        ref = ref + res.float()
+    tol = 1e-4 if out_f32 else 6e-3
+    err = rel_l2(out, ref)
+    assert err < tol, err
+    assert float((out.float() - ref).abs().max()) < (1e-3 if out_f32 else 0.06) * (1 + float(ref.abs().max()))
+
+
+def test_gemm_identity_asymmetric(dev):
+    """A = I against an asymmetric W catches a transposed C write or a wrong fragment map exactly."""
+    ops = _ops()
+    K = N = 256
+    A = bf(torch.eye(K)).to(dev)
+    W = bf(torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125).to(dev)
+    out = ops.linear_bf16(A, W, out_f32=True)
+    assert torch.equal(out, W.float().T.contiguous())
+
+
+def test_gemm_strided_rows_conv(dev):
+    """Overlapping A rows (lda < K): a channels-last Conv1d(k=3, s=2) as one GEMM."""
+    ops = _ops()
+    C, Tin = 512, 301
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = bf(torch.randn(Tin + 8, C, generator=g)).to(dev)
+    w = bf(torch.randn(C, C, 3, generator=g) * (3 * C) ** -0.5).to(dev)
+    wk = w.permute(0, 2, 1).reshape(C, 3 * C).contiguous()
+    Tout = (Tin - 3) // 2 + 1
+    out = torch.zeros(Tout, C, device=dev, dtype=torch.bfloat16)
+    ops.gemm_raw(x, 2 * C, wk, 3 * C, out, C, Tout, C, 3 * C, act=1)
+    ref = F.gelu(F.conv1d(x[:Tin].float().T.unsqueeze(0), w.float(), stride=2))[0].T
+    assert rel_l2(out, ref) < 6e-3
+
+
+def test_gemm_transposed_store_and_batch(dev):
+    ops = _ops()
+    B, R, D, H = 2, 128, 768, 12
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = bf(torch.randn(B * R, D, generator=g)).to(dev)
+    W = bf(torch.randn(3 * D, D, generator=g) * D ** -0.5).to(dev)
+    bias = torch.randn(3 * D, generator=g).to(dev)
+    qk = torch.zeros(B * R, 2 * D, device=dev, dtype=torch.bfloat16)
+    vt = torch.zeros(B, H, 64, R, device=dev, dtype=torch.bfloat16)
+    ops.gemm_raw(x, D, W, D, qk, 2 * D, B * R, 3 * D, D, bias=bias, Ct=vt, n_split=2 * D, R=R, dh=64)
+    ref = x.float() @ W.float().T + bias
+    assert rel_l2(qk, ref[:, : 2 * D]) < 6e-3
+    v_ref = ref[:, 2 * D:].view(B, R, H, 64).permute(0, 2, 3, 1)
+    assert rel_l2(vt, v_ref) < 6e-3
+    # grouped / batched narrow GEMM (pos_conv shape): N = 48 per group
+    G, Dg, Kp, Rr = 4, 48, 128, 128
+    Rp = Rr + Kp
+    xg = bf(torch.randn(G, B, Rp, Dg, generator=g)).to(dev)
+    wg = bf(torch.randn(G, Dg, Kp * Dg, generator=g) * (Kp * Dg) ** -0.5).to(dev)
+    bg = torch.randn(G * Dg, generator=g).to(dev)
+    resid = bf(torch.randn(B * Rr, G * Dg, generator=g)).to(dev)
+    out = torch.zeros(B * Rr, G * Dg, device=dev, dtype=torch.bfloat16)
+    ops.gemm_raw(xg, Dg, wg, Kp * Dg, out, G * Dg, Rr, Dg, Kp * Dg, bias=bg, residual=resid, ldr=G * Dg, act=1,
+                 nb1=G, nb2=B, sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, Rr * G * Dg), sBias=(Dg, 0),
+                 sR=(Dg, Rr * G * Dg))
+    ref = torch.zeros(B, Rr, G * Dg, device=dev)
+    for gi in range(G):
+        for b in range(B):
+            a = xg[gi, b].float().reshape(-1)
+            rows = torch.stack([a[t * Dg: t * Dg + Kp * Dg] for t in range(Rr)])
+            ref[b, :, gi * Dg:(gi + 1) * Dg] = F.gelu(rows @ wg[gi].float().T + bg[gi * Dg:(gi + 1) * Dg])
+    ref = ref.reshape(B * Rr, G * Dg) + resid.float()
+    assert rel_l2(out, ref) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("R,lens", [(128, [128, 1, 37]), (256, [200, 256, 65]), (512, [499, 300, 33])])
+def test_attention(dev, R, lens):
+    ops = _ops()
+    B, H, D = len(lens), 12, 768
+    g = torch.Generator(device="cpu").manual_seed(R)
+    q = bf(torch.randn(B, R, D, generator=g)).to(dev)
+    k = bf(torch.randn(B, R, D, generator=g)).to(dev)
+    v = bf(torch.randn(B, R, D, generator=g)).to(dev)
+    # force one online-softmax rescale late in the sequence (rule 26: exercise the rescale branch)
+    k[0, min(lens[0], R) - 1, :64] = 6.0 * q[0, 5, :64]
+    qk = torch.cat([q, k], dim=-1).reshape(B * R, 2 * D).contiguous()
+    vt = v.view(B, R, H, 64).permute(0, 2, 3, 1).contiguous()
+    valid = torch.tensor(lens, dtype=torch.int32, device=dev)
+    out = torch.zeros(B * R, D, device=dev, dtype=torch.bfloat16)
+    scale = 64 ** -0.5
+    ops.attn_fwd(qk, vt, valid, out, B, R, H, D, scale)
+    qf = q.float().view(B, R, H, 64).transpose(1, 2) * scale
+    kf = k.float().view(B, R, H, 64).transpose(1, 2)
+    vf = v.float().view(B, R, H, 64).transpose(1, 2)
+    s = qf @ kf.transpose(-1, -2)
+    mask = torch.arange(R, device=dev)[None, :] >= valid[:, None]
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B * R, D)
+    err = rel_l2(out, ref)
+    assert err < 1.5e-2, err
+    assert float((out.float() - ref).abs().max()) < 0.08
+
+
+# ------------------------------------------------------------------------------------------------ row ops
+@pytest.mark.parametrize("D", [512, 768, 1024])
+def test_layernorm(dev, D):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(D)
+    x = bf(torch.randn(301, D, generator=g) * 3 + 0.5).to(dev)
+    gam = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    bet = (0.1 * torch.randn(D, generator=g)).to(dev)
+    y = ops.layernorm_bf16(x, gam, bet)
+    ref = F.layer_norm(x.float(), (D,), gam, bet, 1e-5)
+    assert rel_l2(y, ref) < 4e-3
+    y2 = ops.layernorm_bf16(x, gam, bet, act=1)
+    assert rel_l2(y2, F.gelu(ref)) < 5e-3
+
+
+def test_weighted_sum_golden(dev, golden):
+    """WeightedSumLayer against the reference leaf's output + grad (tests/golden/wsum.npz)."""
+    from speechclip_plus_amd.weighted_sum import WeightedSumLayer
+    fx = golden("wsum.npz")
+    layer = WeightedSumLayer(13).to(dev)
+    with torch.no_grad():
+        layer.weights.copy_(torch.from_numpy(fx["weights"]))
+    hs = [torch.from_numpy(h).to(dev) for h in fx["hs"]]
+    out = layer(hs)
+    assert rel_l2(out, torch.from_numpy(fx["out"]).to(dev)) < 8e-3          # bf16 inputs + output
+    (out.float() * torch.from_numpy(fx["gout"]).to(dev)).sum().backward()
+    np.testing.assert_allclose(layer.weights.grad.cpu().numpy(), fx["dweights"], rtol=0.05, atol=0.02)
+
+
+def test_frontend_conv0(dev):
+    ops = _ops()
+    B, L, C = 3, 4000, 512
+    g = torch.Generator(device="cpu").manual_seed(1)
+    wav = torch.randn(B, L, generator=g)
+    lens = torch.tensor([4000, 2500, 801])
+    wav = wav * (torch.arange(L)[None] < lens[:, None])
+    w0 = torch.randn(C, 10, generator=g) * 0.3
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    T0 = (L - 10) // 5 + 1
+    R0 = 1024
+    ldw = 5 * R0 + 64
+    wav_pad = torch.zeros(B, ldw, device=dev)
+    ops.wav_prep(wav.to(dev), lens.to(dev), wav_pad, False)
+    assert torch.equal(wav_pad[:, :L].cpu(), wav)
+    out = torch.zeros(B * R0, C, device=dev, dtype=torch.bfloat16)
+    ops.conv0_groupnorm_gelu(wav_pad, w0.to(dev), gam.to(dev), bet.to(dev), T0, R0, out)
+    y = F.conv1d(wav.unsqueeze(1), w0.unsqueeze(1), stride=5)
+    ref = F.gelu(F.group_norm(y, C, gam, bet, 1e-5)).transpose(1, 2)           # (B, T0, C)
+    got = out.view(B, R0, C)[:, :T0].float().cpu()
+    assert rel_l2(got, ref) < 5e-3
+    # utterance layer-norm variant of wav_prep (fairseq task.cfg.normalize)
+    ops.wav_prep(wav.to(dev), lens.to(dev), wav_pad, True)
+    for b in range(B):
+        n = int(lens[b])
+        ref_n = F.layer_norm(wav[b, :n], (n,))
+        np.testing.assert_allclose(wav_pad[b, :n].cpu().numpy(), ref_n.numpy(), rtol=1e-4, atol=1e-5)
+        assert float(wav_pad[b, n:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("name", ["loss_b8", "loss_b32_dup", "loss_b32_dup_trainT", "loss_b256_dup", "loss_b512_cap_lifted"])
+def test_loss_golden(dev, golden, name):
+    """MaskedContrastiveLoss (HIP) against the reference leaf's loss / dA / dB / dtemperature."""
+    from speechclip_plus_amd.losses import MaskedContrastiveLoss
+    fx = golden(name + ".npz")
+    trainT = "temp_param" in fx
+    crit = MaskedContrastiveLoss(temperature=0.07, temperature_trainable=trainT).to(dev)
+    A = torch.from_numpy(fx["A"]).to(dev).requires_grad_(True)
+    Bm = torch.from_numpy(fx["B"]).to(dev).requires_grad_(True)
+    ids = torch.from_numpy(fx["ids"]).to(dev)
+    loss = crit(A, Bm, ids)
+    loss.backward()
+    assert abs(loss.item() - float(fx["loss"])) < 2e-5 * max(1.0, abs(float(fx["loss"])))
+    np.testing.assert_allclose(A.grad.cpu().numpy(), fx["dA"], rtol=2e-4, atol=2e-6)
+    if "dB" in fx:
+        np.testing.assert_allclose(Bm.grad.cpu().numpy(), fx["dB"], rtol=2e-4, atol=2e-6)
+    if trainT:
+        np.testing.assert_allclose(crit.temperature.grad.cpu().numpy(), fx["dtemp_param"], rtol=2e-4)
+    if "loss_noindex" in fx:
+        l2 = crit(A.detach(), Bm.detach(), None)
+        assert abs(l2.item() - float(fx["loss_noindex"])) < 2e-5 * max(1.0, abs(float(fx["loss_noindex"])))
+
+
+# ------------------------------------------------------------------------------------------------ head
+@pytest.mark.parametrize("name", ["head_d64_h8", "head_d64_h1"])
+def test_parallel_branch_golden(dev, golden, name):
+    """KW_ParallelBranch (CLS pooling kernels + fp32 tail) against the reference leaf composition
+    (tests/golden/head_*.npz): output, grad wrt features, grads of every parameter."""
+    from speechclip_plus_amd import Config, KW_ParallelBranch
+    fx = golden(name + ".npz")
+    nhead = int(fx["nhead"])
+    D, Fd, E = 64, 128, 24
+    cfg = Config({"model_settings": {"parallel_branch": {
+        "transformer_type": "TransformerEncoder",
+        "transformer_args": {"n_layers": 1, "d_model": D, "nhead": nhead, "dim_feedforward": Fd, "dropout": 0.1,
+                             "activation": "gelu", "layer_norm_eps": 1e-5, "batch_first": True, "norm_first": False},
+        "need_projection": True}}})
+    br = KW_ParallelBranch(cfg, audio_dim=D, text_dim=E).to(dev).eval()
+    sd = {k[2:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("W_")}
+    missing = br.load_state_dict(sd, strict=True)
+    feat = torch.from_numpy(fx["feat"]).to(dev).requires_grad_(True)
+    out = br(audio_feat=feat, audio_feat_len=torch.from_numpy(fx["audio_len"]).to(dev))["parallel_audio_feat"]
+    # features enter the kernels as bf16 -> 2^-8 relative input rounding
+    assert rel_l2(out, torch.from_numpy(fx["out"]).to(dev)) < 1e-2
+    (out * torch.from_numpy(fx["gout"]).to(dev)).sum().backward()
+    assert rel_l2(feat.grad, torch.from_numpy(fx["g_feat"]).to(dev)) < 3e-2
+    assert rel_l2(br.cls.grad, torch.from_numpy(fx["g_cls"]).to(dev)) < 3e-2
+    for n, p in br.named_parameters():
+        key = "g_" + n
+        if key in fx and n != "cls":
+            ref = torch.from_numpy(fx[key]).to(dev)
+            if float(ref.norm()) < 1e-6:          # in_proj_bias k-part: exactly zero gradient
+                assert float(p.grad.norm()) < 1e-4, n
+            else:
+                assert rel_l2(p.grad, ref) < 3e-2, (n, rel_l2(p.grad, ref))
+
+
+def test_cls_pool_vs_torch(dev):
+    """CLS pooling kernels at the shipped width (D=768, H=8, R=512) vs the same math in fp32 torch."""
+    ops = _ops()
+    B, R, D, H = 3, 512, 768, 8
+    g = torch.Generator(device="cpu").manual_seed(3)
+    X = bf(torch.randn(B, R, D, generator=g)).to(dev)
+    a = (torch.randn(H, D, generator=g) * 0.05).to(dev)
+    lens = torch.tensor([500, 1, 77], dtype=torch.int32, device=dev)
+    scores = ops.cls_scores(X, a, False, B, R, D, H)
+    p, m = ops.cls_pool_fwd(X, scores, lens, B, R, D, H)
+    Xf = X.float().requires_grad_(True)
+    af = a.clone().requires_grad_(True)
+    s = torch.einsum("brd,hd->bhr", Xf, af)
+    mask = torch.arange(R, device=dev)[None] >= lens[:, None]
+    s = s.masked_fill(mask[:, None], float("-inf"))
+    pr = torch.softmax(s, -1)
+    mr = torch.einsum("bhr,brd->bhd", pr, Xf)
+    assert rel_l2(p, pr) < 1e-4 and rel_l2(m, mr) < 1e-4
+    dm = torch.randn(B, H, D, generator=g).to(dev)
+    (mr * dm).sum().backward()
+    dp = ops.cls_scores(X, dm.contiguous(), True, B, R, D, H)
+    dX, da_part = ops.cls_pool_bwd(X, p, dp, dm, a, lens, B, R, D, H)
+    assert rel_l2(dX, Xf.grad) < 1e-4
+    assert rel_l2(da_part.sum(0), af.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def test_flat_adam_vs_torch(dev):
+    from speechclip_plus_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(300, 70, device=dev)), torch.nn.Parameter(torch.randn(513, device=dev))]
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref = torch.optim.Adam(rs, lr=1e-3, weight_decay=1e-2)
+    opt = FlatAdam(ps, lr=1e-3, weight_decay=1e-2, max_grad_norm=4.0)
+    for step in range(5):
+        opt.zero_grad()
+        ref.zero_grad()
+        gs = [torch.randn_like(p) * (3.0 if step % 2 else 0.01) for p in ps]
+        for p, r, g in zip(ps, rs, gs):
+            p.grad.copy_(g)
+            r.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(rs, 4.0)
+        ref.step()
+        opt.step()
+        for p, r in zip(ps, rs):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)

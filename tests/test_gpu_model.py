@@ -1,0 +1,144 @@
+"""GPU parity of the assembled path against the CPU oracle on identical seeded weights and inputs:
+HuBERT-base encoder hidden states, weighted sum, parallel head, loss, gradients, recall@k.
+
+Stated tolerances (bf16 storage + fp32 accumulate vs the fp32 oracle):
+  hidden states rel-L2 <= 2e-2 per layer; pooled unit-norm embeddings cosine >= 0.999;
+  loss |diff| <= 5e-3 at T = 0.07; recall@k identical."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import oracle
+    from speechclip_plus_amd import KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict, HubertArch
+    assert torch.cuda.is_available()
+    arch = HubertArch()
+    sd = random_hubert_state_dict(arch, seed=7122)
+    torch.manual_seed(7122)
+    cfg = base_parallel_config()
+    cfg.audio_encoder.max_audio_len = -1
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd).eval()
+    with torch.no_grad():
+        model.audio_encoder.weightedsum_layer.weights.copy_(torch.linspace(-1, 1, 13))
+    o_arch = oracle.HubertArch.base()
+    head_W = {k: v.detach().cpu().float() for k, v in model.parallel_branch.state_dict().items()}
+    return model, sd, o_arch, head_W, oracle
+
+
+def test_encoder_hidden_states(setup):
+    model, sd, o_arch, head_W, oracle = setup
+    g = torch.Generator().manual_seed(11)
+    lens = [16000, 9000, 3300]
+    wavs = [torch.randn(l, generator=g) for l in lens]
+    with torch.no_grad():
+        feat, feat_len, hs = model.audio_encoder([w.cuda() for w in wavs], return_hidden_states=True)
+        hs_o, feat_len_o = oracle.speech_encoder_forward(sd, o_arch, wavs)
+    assert feat_len.cpu().tolist() == feat_len_o.tolist()
+    T = hs_o[0].shape[1]
+    assert hs[0].shape == (3, T, 768) and len(hs) == 13
+    valid = oracle.fairseq_valid_frames(lens, max(lens), T)
+    worst = 0.0
+    for n in range(13):
+        # every frame < T exists in the reference (padded frames carry deterministic values the head may read)
+        e_all = rel_l2(hs[n], hs_o[n])
+        e_valid = max(rel_l2(hs[n][b, :v], hs_o[n][b, :v]) for b, v in enumerate(valid))
+        worst = max(worst, e_all, e_valid)
+        assert e_all < 2e-2 and e_valid < 2e-2, (n, e_all, e_valid)
+    w = model.audio_encoder.weightedsum_layer.weights.detach().cpu()
+    ws_o = oracle.weighted_sum(w, hs_o)
+    assert rel_l2(feat, ws_o) < 1.5e-2
+    print("worst hidden-state rel-L2", worst)
+
+
+def _oracle_step(oracle, sd, o_arch, head_W, ws_w, wavs, img, ids):
+    hs_o, fl = oracle.speech_encoder_forward(sd, o_arch, wavs)
+    W = {k: v.clone().requires_grad_(True) for k, v in head_W.items()}
+    w = ws_w.clone().requires_grad_(True)
+    feat = oracle.weighted_sum(w, [h.detach() for h in hs_o])
+    e = oracle.parallel_branch_forward(W, feat, fl, nhead=8)
+    a = e / e.norm(dim=-1, keepdim=True)
+    i = img / img.norm(dim=-1, keepdim=True)
+    loss = oracle.masked_contrastive_loss(a, i, ids)
+    loss.backward()
+    return loss.detach(), a.detach(), W, w
+
+
+def test_train_step_parity(setup):
+    model, sd, o_arch, head_W, oracle = setup
+    g = torch.Generator().manual_seed(5)
+    lens = [12000, 8000, 12000, 5000, 12000, 10300]
+    wavs = [torch.randn(l, generator=g) for l in lens]
+    B = len(lens)
+    img = torch.randn(B, 512, generator=g)
+    ids = torch.tensor([0, 0, 1, 2, 2, 3])
+    L = max(lens)
+    wav = torch.zeros(B, L)
+    for b, x in enumerate(wavs):
+        wav[b, : len(x)] = x
+    batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": img.cuda(), "id": ids.cuda()}
+    model.zero_grad(set_to_none=True)
+    losses_, log_metrics, others = model(batch)
+    out = model.compute_loss(losses_)
+    out["loss"].backward()
+    ws_w = model.audio_encoder.weightedsum_layer.weights.detach().cpu()
+    loss_o, a_o, W_o, w_o = _oracle_step(oracle, sd, o_arch, head_W, ws_w, wavs, img, ids)
+    cos = F.cosine_similarity(others["parallel_audio_feat"].detach().float().cpu(), a_o, dim=-1)
+    assert float(cos.min()) > 0.999, cos
+    assert abs(out["loss"].item() - loss_o.item()) < 5e-3, (out["loss"].item(), loss_o.item())
+    assert abs(out["p_cl_loss"].item() - loss_o.item()) < 5e-3
+    # gradients of the trainable part (bf16 features -> a few 1e-2 relative)
+    errs = {}
+    for n, p in model.parallel_branch.named_parameters():
+        ref = W_o[n].grad
+        if ref is None or float(ref.norm()) < 1e-7:
+            continue
+        errs[n] = rel_l2(p.grad, ref)
+    errs["weightedsum"] = rel_l2(model.audio_encoder.weightedsum_layer.weights.grad, w_o.grad)
+    bad = {k: v for k, v in errs.items() if v > 6e-2}
+    assert not bad, bad
+    print("max grad rel-L2", max(errs.values()))
+
+
+def test_encode_speech_api_and_recall(setup):
+    """encode_speech on a synthetic Flickr8k-shaped eval set (5 utterances per image): recall@k from the HIP
+    embeddings must equal recall@k from the oracle embeddings."""
+    model, sd, o_arch, head_W, oracle = setup
+    from speechclip_plus_amd import mutualRetrieval
+    g = torch.Generator().manual_seed(21)
+    n_img, per = 8, 5
+    lens = [int(x) for x in torch.randint(4000, 9000, (n_img * per,), generator=g)]
+    wavs = [torch.randn(l, generator=g) for l in lens]
+    ids = torch.arange(n_img).repeat_interleave(per)
+    ws_w = model.audio_encoder.weightedsum_layer.weights.detach().cpu()
+    with torch.no_grad():
+        emb = torch.cat([model.encode_speech([w.cuda() for w in wavs[i:i + 8]])["parallel_audio_feat"]
+                         for i in range(0, len(wavs), 8)]).float().cpu()
+        emb_o = []
+        for i in range(0, len(wavs), 8):
+            hs_o, fl = oracle.speech_encoder_forward(sd, o_arch, wavs[i:i + 8])
+            emb_o.append(oracle.parallel_branch_forward(head_W, oracle.weighted_sum(ws_w, hs_o), fl, nhead=8))
+        emb_o = torch.cat(emb_o)
+    assert emb.shape == (n_img * per, 512)
+    assert float(F.cosine_similarity(emb, emb_o, dim=-1).min()) > 0.999
+    # images: noisy mean of their captions' oracle embeddings -> recall neither 0 nor 100
+    a_o = emb_o / emb_o.norm(dim=-1, keepdim=True)
+    img = torch.stack([a_o[ids == k].mean(0) for k in range(n_img)]) + 0.12 * torch.randn(n_img, 512, generator=g)
+    img = img / img.norm(dim=-1, keepdim=True)
+    a = emb / emb.norm(dim=-1, keepdim=True)
+    r_hip = mutualRetrieval(a @ img.T, (a @ img.T).T, ids, torch.arange(n_img), [1, 5, 10])
+    r_ora = oracle.mutual_retrieval(a_o @ img.T, (a_o @ img.T).T, ids, torch.arange(n_img), [1, 5, 10])
+    for d_hip, d_ora in zip(r_hip, r_ora):
+        for k in d_ora:
+            assert abs(d_hip[k] - d_ora[k]) < 1e-6, (k, d_hip[k], d_ora[k])
+    h13 = model.feature_extractor_s3prl([w.cuda() for w in wavs[:2]])
+    assert len(h13[1]) == 13 and h13[0].shape[-1] == 768
