@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py - utterances/s of one contrastive train step (frozen-HuBERT parallel-base recipe) on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+Workload (BASELINE.json configs[1]): Parallel SpeechCLIP base, bf16, batch 64 per GPU x 10 s synthetic audio
+(L = 160000 -> T = 499 frames), frozen HuBERT-base forward + weighted sum + CLS attention-pooling head
+forward/backward + global-batch InfoNCE forward/backward + clip + Adam; weak scaling (per-GPU batch fixed),
+RCCL all-gather of the pooled embeddings + all-reduce of the flat gradient for N > 1.
+Prints ONE JSON line on rank 0 with the contract fields plus
+  "roofline":     the dominant kernel (bf16 MFMA GEMM, 128x128 tile): algorithmic TFLOP/s from HIP events
+                  recorded around each launch inside the timed region, against the 2.5 PFLOP/s dense bf16 peak
+  "cpu_baseline": the CPU oracle (torch fp32 restatement of the reference maths) timed on the host cores of
+                  rank 0 on a bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-utts", type=int, default=2, help="utterances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    dev = torch.device("cuda", local_rank)
+
+    from speechclip_plus_amd import (HubertArch, KWClip_GeneralTransformer, base_parallel_config, ops,
+                                     random_hubert_state_dict)
+    from speechclip_plus_amd.train import ContrastiveTrainer
+
+    B, L = args.batch, int(round(args.seconds * 16000))
+    torch.manual_seed(7122)
+    sd = random_hubert_state_dict(HubertArch(), seed=7122)
+    cfg = base_parallel_config()
+    cfg.audio_encoder.max_audio_len = -1          # 10 s utterances, no 6.4 s training crop (BASELINE configs[1])
+    model = KWClip_GeneralTransformer(cfg, device=str(dev), hubert_state_dict=sd)
+    model.train()
+    trainer = ContrastiveTrainer(model)
+
+    g = torch.Generator(device="cpu").manual_seed(7122 + rank)
+    wav = torch.randn(B, L, generator=g).to(dev)
+    wav_len = torch.full((B,), L, dtype=torch.long)
+    img = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=-1).to(dev)
+    ids = (torch.arange(B) + rank * B) // 5            # Flickr8k shape: 5 captions per image id
+    batch = {"wav": wav, "wav_len": wav_len, "image": img, "id": ids.to(dev)}
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(batch)
+    # ---- timed region: exactly K steps, un-instrumented (timing events would put a marker packet between
+    # back-to-back kernels and cost ~20 % of the step) ------------------------------------------------------
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    # ---- the same K steps again with a HIP-event pair around every GEMM / attention launch (recorded on the
+    # launch stream): per-launch durations of the dominant kernel for the roofline object -------------------
+    timer = None
+    if not args.no_kernel_timer and rank == 0:
+        timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    for _ in range(args.steps):
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    ops.set_timer(None)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    result = None
+    if rank == 0:
+        T = model.audio_encoder._plan(B, L).T
+        roof = None
+        extra = {}
+        if timer is not None:
+            summ = timer.summary()
+            dom = summ["gemm_bf16_128x128"]
+            tflops = dom["work"] / (dom["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<128,128>", "achieved": round(tflops, 2),
+                    "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": dom["launches"] // args.steps,
+                    "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+                    "alg_gflop_per_launch": round(dom["work"] / dom["launches"] / 1e9, 3)}
+            for k, v in summ.items():
+                extra[k] = {"ms_per_step": round(v["ms"] / args.steps, 3),
+                            "alg_tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None}
+        cpu = None
+        if world == 1 and args.cpu_utts > 0:
+            cpu = cpu_baseline(sd, model, args.cpu_utts, L, args.cpu_iters)
+        result = {
+            "metric": "utterances/sec (train step)", "value": round(B * world * args.steps / elapsed, 2),
+            "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Parallel SpeechCLIP base train step (HuBERT-base frozen fwd + weighted sum + CLS "
+                                   f"attention-pool head fwd/bwd + InfoNCE fwd/bwd + Adam), {B} utt/GPU x {args.seconds:g} s "
+                                   f"(L={L}, T={T}), CLIP image embeddings given",
+                       "global_batch": B * world, "per_gpu_batch": B, "audio_samples": L, "frames": T,
+                       "parallelism": f"dp{world}", "dropout": "off (deterministic head; reference trains with p=0.1)"},
+            "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, model, n_utts, L, iters):
+    """The oracle (kind "port": torch-CPU fp32 restatement of the reference maths) on the host cores:
+    same train step (HuBERT fwd no-grad, weighted sum, parallel head fwd/bwd, loss fwd/bwd) on n_utts utterances."""
+    import oracle
+    torch.manual_seed(0)
+    head_W = {k: v.detach().cpu().float().clone().requires_grad_(True) for k, v in model.parallel_branch.state_dict().items()}
+    ws = torch.zeros(13, requires_grad=True)
+    wavs = [torch.randn(L) for _ in range(n_utts)]
+    img = torch.nn.functional.normalize(torch.randn(n_utts, 512), dim=-1)
+    ids = torch.arange(n_utts)
+    arch = oracle.HubertArch.base()
+
+    def step():
+        with torch.no_grad():
+            hs, fl = oracle.speech_encoder_forward(sd, arch, wavs)
+        feat = oracle.weighted_sum(ws, hs)
+        e = oracle.parallel_branch_forward(head_W, feat, fl, nhead=8)
+        loss = oracle.masked_contrastive_loss(e / e.norm(dim=-1, keepdim=True), img, ids)
+        loss.backward()
+        return loss
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(n_utts / dt, 4), "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_utts} utterances x {L} samples, {iters} timed train steps after 1 warm-up, torch fp32 "
+                      f"({torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs)",
+            "s_per_step": round(dt, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void wav_prep_kernel(const float* __restrict__
         mean = (float)mu;
         rstd = (float)(1.0 / sqrt(var + 1e-5));
     }
-    for (int64_t i = threadIdx.x; i < ldw_out; i += blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < ldw_out; i += (int64_t)gridDim.y * blockDim.x) {
         float v = 0.f;
         if (i < len) v = normalize ? (x[i] - mean) * rstd : x[i];
         o[i] = v;
@@ -173,7 +173,8 @@ extern "C" int sc_wav_prep(const float* wav, int64_t ldw_in, const int64_t* wav_
                            int32_t B, int32_t L, int32_t normalize, void* stream) {
     SC_CHECK(wav && wav_len && out, "sc_wav_prep: null pointer");
     SC_CHECK(B > 0 && L > 0 && ldw_out >= L && ldw_in >= L, "sc_wav_prep: bad sizes");
-    hipLaunchKernelGGL(wav_prep_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, wav, ldw_in, wav_len, out, ldw_out, L, normalize);
+    // without normalisation the kernel is a pure copy: spread each utterance over 32 blocks
+    hipLaunchKernelGGL(wav_prep_kernel, dim3(B, normalize ? 4 : 32), dim3(256), 0, (hipStream_t)stream, wav, ldw_in, wav_len, out, ldw_out, L, normalize);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -23,12 +23,40 @@ def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing (bench.py): events are recorded on the stream the kernel is
+    launched on; ``work`` is the ALGORITHMIC flop (or byte) count the caller attributes to the launch."""
+
+    def __init__(self):
+        self.records = {}
+
+    def add(self, name, start, end, work):
+        self.records.setdefault(name, []).append((start, end, work))
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            out[name] = {"launches": len(recs), "ms": ms, "work": float(sum(w for _, _, w in recs))}
+        return out
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_timer(t: Optional[KernelTimer]) -> None:
+    global _timer
+    _timer = t
+
+
 def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tensor, ldc: int, M: int, N: int, K: int,
              bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ldr: int = 0, act: int = 0,
              out_f32: bool = False, Ct: Optional[torch.Tensor] = None, n_split: int = -1, R: int = 0, dh: int = 0,
-             nb1: int = 1, nb2: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sBias=(0, 0), sR=(0, 0)) -> None:
+             nb1: int = 1, nb2: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sBias=(0, 0), sR=(0, 0),
+             alg_rows: Optional[int] = None) -> None:
     """C = epi(A . W^T); see sc_gemm_args in include/speechclip_hip.h.  Pointers are the tensors' data_ptr()
-    (pass a sliced view to offset)."""
+    (pass a sliced view to offset).  ``alg_rows``: rows that are algorithmic work (excludes layout padding),
+    used only by the optional KernelTimer."""
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16
     assert C.dtype == (torch.float32 if out_f32 else torch.bfloat16)
     if bias is not None:
@@ -47,11 +75,21 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     a.sC1, a.sC2 = sC
     a.sBias1, a.sBias2 = sBias
     a.sR1, a.sR2 = sR
+    if _timer is None:
+        check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
+        return
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
     check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
+    ev1.record()
+    rows = (M if alg_rows is None else alg_rows) * nb1 * nb2
+    tile = "128x64" if (N <= 64 and n_split < 0) else "128x128"
+    _timer.add("gemm_bf16_" + tile, ev0, ev1, 2.0 * rows * N * K)
 
 
 def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None, act: int = 0, out_f32: bool = False) -> torch.Tensor:
+                residual: Optional[torch.Tensor] = None, act: int = 0, out_f32: bool = False,
+                alg_rows: Optional[int] = None) -> torch.Tensor:
     """y[M, N] = epi(x[M, K] . w[N, K]^T) for contiguous 2-D operands."""
     M, K = x.shape
     N = w.shape[0]
@@ -59,16 +97,22 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     gemm_raw(x, x.stride(0), w, w.stride(0), out, out.stride(0), M, N, K, bias=bias, residual=residual,
-             ldr=residual.stride(0) if residual is not None else 0, act=act, out_f32=out_f32)
+             ldr=residual.stride(0) if residual is not None else 0, act=act, out_f32=out_f32, alg_rows=alg_rows)
     return out
 
 
 def attn_fwd(qk: torch.Tensor, vt: torch.Tensor, valid_len: torch.Tensor, out: torch.Tensor, B: int, R: int, H: int,
-             D: int, scale: float) -> None:
+             D: int, scale: float, alg_flops: float = 0.0) -> None:
     assert qk.dtype == torch.bfloat16 and vt.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
     assert valid_len.dtype == torch.int32
+    if _timer is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib().sc_attn_fwd_bf16(_p(qk), qk.stride(0), _p(vt), _p(valid_len), _p(out), out.stride(0), B, R, H, D,
                                  float(scale), _stream()), "sc_attn_fwd_bf16")
+    if _timer is not None:
+        ev1.record()
+        _timer.add("attn_fwd", ev0, ev1, float(alg_flops))
 
 
 def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Optional[torch.Tensor] = None,

@@ -276,29 +276,30 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         ops.conv0_groupnorm_gelu(pl.wav_pad, w["conv0_w"], w["gn_g"], w["gn_b"], pl.T_l[0], pl.R_l[0], pl.conv[0])
         for i in range(1, len(a.conv_kernels)):
             k, s = a.conv_kernels[i], a.conv_strides[i]
-            ops.gemm_raw(pl.conv[i - 1], s * C, w[f"conv{i}_w"], k * C, pl.conv[i], C, B * pl.R_l[i], C, k * C, act=1)
+            ops.gemm_raw(pl.conv[i - 1], s * C, w[f"conv{i}_w"], k * C, pl.conv[i], C, B * pl.R_l[i], C, k * C, act=1,
+                         alg_rows=B * pl.T_l[i])
         # a3: LayerNorm(512) -> post_extract_proj                                       (:78, :84-85)
         ops.layernorm_bf16(pl.conv[-1][:M], w["ln_feat_g"], w["ln_feat_b"], out=pl.feat_ln)
-        ops.linear_bf16(pl.feat_ln, w["proj_w"], w["proj_b"], out=pl.x_proj)
+        ops.linear_bf16(pl.feat_ln, w["proj_w"], w["proj_b"], out=pl.x_proj, alg_rows=B * T)
         # a4: zero padded frames, grouped pos_conv + GELU, residual, LayerNorm          (:32-40)
         G, Kp = a.pos_conv_groups, a.pos_conv_kernel
         Dg, Rp = D // G, R + 2 * pl.halo
         ops.posconv_prep(pl.x_proj, pl.valid, pl.xz, pl.xg, B, R, D, G, pl.halo)
         ops.gemm_raw(pl.xg, Dg, w["pos_w"], Kp * Dg, pl.pre, D, R, Dg, Kp * Dg, bias=w["pos_b"], residual=pl.xz, ldr=D,
                      act=1, nb1=G, nb2=B, sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, R * D),
-                     sBias=(Dg, 0), sR=(Dg, R * D))
+                     sBias=(Dg, 0), sR=(Dg, R * D), alg_rows=T)
         ops.layernorm_bf16(pl.pre, w["ln_enc_g"], w["ln_enc_b"], out=pl.hidden[0])
         # a5: transformer layers (post-LN)                                              (:49-53)
         scale = (D // H) ** -0.5
         for i in range(a.layers):
             x = pl.hidden[i]
             ops.gemm_raw(x, D, w[f"l{i}_qkv_w"], D, pl.qk, 2 * D, M, 3 * D, D, bias=w[f"l{i}_qkv_b"], Ct=pl.vt,
-                         n_split=2 * D, R=R, dh=D // H)
-            ops.attn_fwd(pl.qk, pl.vt, pl.valid, pl.ctx, B, R, H, D, scale)
-            ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x)
+                         n_split=2 * D, R=R, dh=D // H, alg_rows=B * T)
+            ops.attn_fwd(pl.qk, pl.vt, pl.valid, pl.ctx, B, R, H, D, scale, alg_flops=4.0 * B * T * T * D)
+            ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T)
             ops.layernorm_bf16(pl.pre, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
-            ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1)
-            ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.pre, residual=pl.x1)
+            ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1, alg_rows=B * T)
+            ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.pre, residual=pl.x1, alg_rows=B * T)
             ops.layernorm_bf16(pl.pre, w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"], out=pl.hidden[i + 1])
         return pl
 
