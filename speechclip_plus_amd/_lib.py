@@ -27,6 +27,7 @@ class GemmArgs(ctypes.Structure):
         ("nb1", c_int), ("nb2", c_int),
         ("sA1", c_i64), ("sA2", c_i64), ("sW1", c_i64), ("sW2", c_i64), ("sC1", c_i64), ("sC2", c_i64),
         ("sBias1", c_i64), ("sBias2", c_i64), ("sR1", c_i64), ("sR2", c_i64),
+        ("tile", c_int), ("reserved", c_int),
     ]
 
 

@@ -1,0 +1,301 @@
+// 256 x 256 x 64 bf16 MFMA GEMM for gfx950: deep-pipelined variant of gemm_bf16.hip for the large GEMMs.
+//
+// 512 threads = 8 waves as 2 (M) x 4 (N); each wave owns a 128 x 64 output block = 8 x 4 fragments of
+// v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  One workgroup per CU (128 KiB LDS), so two waves share
+// each SIMD: waves 0-3 (wm = 0) and 4-7 (wm = 1) run STAGGERED by one barrier interval - while one group is
+// in its MFMA segment the other issues LDS reads / LDS-DMA - which keeps the matrix pipe fed by one wave at a time
+// (MI355X_MICROARCH "Two waves per SIMD").
+//
+// LDS: 2 K-tile buffers x {A, B} x 2 half-tiles of 128 rows x 64 k (16 KiB each), same XOR-swizzled 128-B row
+// image as gemm_bf16.hip.  Staging is LDS-DMA (global_load_lds_dwordx4) that stays in flight across barriers:
+// raw s_barrier (no implicit vmcnt(0)), one counted `s_waitcnt vmcnt(4)` per K-tile.
+//
+// K-tile kt = 4 phases, each [L segment | barrier | C segment: 16 MFMA | barrier]:
+//   P0  L: read A(m-sub 0) 8 x b128 + B(n-sub 0) 4 x b128            C: quadrant (m0, n0)
+//   P1  L: read B(n-sub 1) 4 ; DMA A(kt+1) -> other buffer            C: (m0, n1)
+//   P2  L: read A(m-sub 1) 8                                          C: (m1, n1)
+//   P3  L: DMA B(kt+2) -> this buffer ; s_waitcnt vmcnt(4)            C: (m1, n0)   (B(n0) kept in registers)
+// Hazards (phase p spans barrier intervals 2p, 2p+1 for wm = 0 and 2p+1, 2p+2 for wm = 1):
+//   WAR  a slot is re-staged >= 2 phases after its last ds_read (A: read P0/P2, staged P1 of the next tile;
+//        B: read P0/P1, staged P3), so the staggered group's reads have retired (lgkmcnt) a barrier earlier;
+//   RAW  tile kt+1 (A issued P1(kt), B issued P3(kt-1)) is retired by every wave's vmcnt(4) in L(P3(kt)) and first
+//        read in L(P0(kt+1)), one barrier later for either group.
+#include "sc_common.h"
+
+namespace {
+
+constexpr int BK = 64, ROWB = 128;
+constexpr int HALF_BYTES = 128 * ROWB;           // 16 KiB
+constexpr int BUF_BYTES = 4 * HALF_BYTES;        // A0 A1 B0 B1
+constexpr int LDS_BYTES = 2 * BUF_BYTES;         // 128 KiB
+
+#define SC_BAR()                               \
+    do {                                       \
+        asm volatile("" ::: "memory");         \
+        __builtin_amdgcn_s_barrier();          \
+        asm volatile("" ::: "memory");         \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// DIAG (timing-only diagnostic builds, results are wrong): 1 = no DMA inside the K loop, 2 = DMA but no vmcnt waits
+template <int DIAG>
+__global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // ---- block -> tile (XCD-aware, banded; see gemm_bf16.hip) ---------------------------------------------
+    const int nM = (p.M + 255) >> 8, nN = (p.N + 255) >> 8;
+    int L;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GM = 8;
+    const int band = L / (GM * nN), first_m = band * GM;
+    const int gm = min(GM, nM - first_m);
+    const int within = L - band * GM * nN;
+    const int n_tile = within / gm, m_tile = first_m + within % gm;
+    const int m0 = m_tile << 8, n0 = n_tile << 8;
+
+    const int z = blockIdx.z, z1 = z / p.nb2, z2 = z % p.nb2;
+    const uint16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
+    const uint16_t* W = p.W + z1 * p.sW1 + z2 * p.sW2;
+    const float* bias = p.bias ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
+    const uint16_t* Rs = p.residual ? p.residual + z1 * p.sR1 + z2 * p.sR2 : nullptr;
+    const int64_t coff = z1 * p.sC1 + z2 * p.sC2;
+
+    // ---- DMA sources: half-tile = 16 wave-instructions of 8 rows; wave w issues instr {w, w + 8} -----------
+    const uint16_t* a_src[2][2];
+    const uint16_t* b_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 8 + wave) * 8 + (lane >> 3);          // row inside the half-tile
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            a_src[h][i] = A + (int64_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + c * 8;
+            b_src[h][i] = W + (int64_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw + c * 8;
+        }
+    auto dma_A = [&](int par, int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                glds16(a_src[h][i] + k0, smem + par * BUF_BYTES + h * HALF_BYTES + (i * 8 + wave) * 1024);
+    };
+    auto dma_B = [&](int par, int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                glds16(b_src[h][i] + k0, smem + par * BUF_BYTES + (2 + h) * HALF_BYTES + (i * 8 + wave) * 1024);
+    };
+
+    // ---- fragment read offsets: row = 16*f + (lane & 15)  =>  swizzle term depends on the lane only ----------
+    const int sw = (lane >> 1) & 7;
+    const int frag_off0 = (lane & 15) * ROWB + (((lane >> 4)) ^ sw) * 16;          // kk = 0
+    const int frag_off1 = (lane & 15) * ROWB + ((4 + (lane >> 4)) ^ sw) * 16;      // kk = 1
+    const int a_base = wm * HALF_BYTES;                                             // wave's A half
+    const int b_base = (2 + (wn >> 1)) * HALF_BYTES + (wn & 1) * 64 * ROWB;         // wave's 64 B rows
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], b0[2][2], b1[2][2];
+
+    const int nk = p.K / BK;
+    // ---- prologue ----------------------------------------------------------------------------------------------
+    dma_B(0, 0);
+    dma_A(0, 0);
+    if (nk > 1) {
+        dma_B(1, BK);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    SC_BAR();
+    if (wm == 1) SC_BAR();                       // stagger the second wave group by one barrier interval
+
+#define SC_MFMA_QUAD(MS, NS, BF)                                                                         \
+    do {                                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                   \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                 \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                         \
+                    acc[(MS) * 4 + mi][(NS) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(         \
+                        af[mi][kk], BF[ni][kk], acc[(MS) * 4 + mi][(NS) * 2 + ni], 0, 0, 0);             \
+        __builtin_amdgcn_s_setprio(0);                                                                   \
+    } while (0)
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int par = kt & 1;
+        const char* as = smem + par * BUF_BYTES + a_base;
+        const char* bs = smem + par * BUF_BYTES + b_base;
+        // ---------------- P0
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            b0[ni][0] = *(const bf16x8*)(bs + ni * 16 * ROWB + frag_off0);
+            b0[ni][1] = *(const bf16x8*)(bs + ni * 16 * ROWB + frag_off1);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            af[mi][0] = *(const bf16x8*)(as + mi * 16 * ROWB + frag_off0);
+            af[mi][1] = *(const bf16x8*)(as + mi * 16 * ROWB + frag_off1);
+        }
+        SC_BAR();
+        SC_MFMA_QUAD(0, 0, b0);
+        SC_BAR();
+        // ---------------- P1
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            b1[ni][0] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off0);
+            b1[ni][1] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off1);
+        }
+        if (DIAG != 1 && kt + 1 < nk) dma_A(par ^ 1, (kt + 1) * BK);
+        SC_BAR();
+        SC_MFMA_QUAD(0, 1, b1);
+        SC_BAR();
+        // ---------------- P2
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            af[mi][0] = *(const bf16x8*)(as + (4 + mi) * 16 * ROWB + frag_off0);
+            af[mi][1] = *(const bf16x8*)(as + (4 + mi) * 16 * ROWB + frag_off1);
+        }
+        SC_BAR();
+        SC_MFMA_QUAD(1, 1, b1);
+        SC_BAR();
+        // ---------------- P3
+        if (DIAG == 0) {
+            if (kt + 2 < nk) {
+                dma_B(par, (kt + 2) * BK);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else if (DIAG == 2) {
+            if (kt + 2 < nk) dma_B(par, (kt + 2) * BK);
+        }
+        SC_BAR();
+        SC_MFMA_QUAD(1, 0, b0);
+        SC_BAR();
+    }
+    if (wm == 0) SC_BAR();                       // pairs the staggered group's last barrier
+    if (DIAG != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: each wave streams its 128 x 64 block through a private 16 KiB LDS region, 64 rows a pass ---
+    float* Cw = (float*)(smem + wave * 16384);
+    const bool transposed = (p.n_split >= 0) && (n0 >= p.n_split);
+    const int wn0 = n0 + wn * 64;                // wave's first column
+    float bv[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = wn0 + ni * 16 + (lane & 15);
+        bv[ni] = (bias && n < p.N) ? bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int wm0 = m0 + wm * 128 + ms * 64;   // first row of this pass
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 v = acc[ms * 4 + mi][ni];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = v[r] + bv[ni];
+                    if (p.act == 1) x = gelu_erf(x);
+                    v[r] = x;
+                }
+                const int ml = mi * 16 + 4 * (lane >> 4), nl = ni * 16 + (lane & 15);
+                if (transposed) {
+                    *(f32x4*)(Cw + nl * 64 + ml) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cw[(ml + r) * 64 + nl] = v[r];
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!transposed) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane >> 3), cc = lane & 7;
+                const int m = wm0 + row, n = wn0 + cc * 8;
+                if (m < p.M && n + 8 <= p.N) {
+                    const f32x4 lo = *(const f32x4*)(Cw + row * 64 + cc * 8);
+                    const f32x4 hi = *(const f32x4*)(Cw + row * 64 + cc * 8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (Rs) {
+                        const uint4 rv = *(const uint4*)(Rs + (int64_t)m * p.ldr + n);
+                        v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
+                        v[4] += bflo(rv.z); v[5] += bfhi(rv.z); v[6] += bflo(rv.w); v[7] += bfhi(rv.w);
+                    }
+                    if (p.out_f32) {
+                        float* C = (float*)p.C + coff + (int64_t)m * p.ldc + n;
+                        *(f32x4*)C = f32x4{v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(C + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else {
+                        uint16_t* C = (uint16_t*)p.C + coff + (int64_t)m * p.ldc + n;
+                        uint4 o;
+                        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                        o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+                        *(uint4*)C = o;
+                    }
+                }
+            }
+        } else {
+            const int H = (p.N - p.n_split) / p.dh;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int nrow = it * 8 + (lane >> 3), mc = lane & 7;
+                const int m = wm0 + mc * 8, n = wn0 + nrow;
+                if (m < p.M && n < p.N) {
+                    const f32x4 lo = *(const f32x4*)(Cw + nrow * 64 + mc * 8);
+                    const f32x4 hi = *(const f32x4*)(Cw + nrow * 64 + mc * 8 + 4);
+                    const int nn = n - p.n_split, hh = nn / p.dh, d = nn % p.dh;
+                    const int b = m / p.R, t = m % p.R;
+                    uint16_t* dst = p.Ct + (((int64_t)b * H + hh) * p.dh + d) * p.R + t;
+                    uint4 o;
+                    o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]);
+                    o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
+                    *(uint4*)dst = o;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+}  // namespace
+
+template <int DIAG>
+static int launch256(const sc_gemm_args& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) {
+            sc_set_error("hipFuncSetAttribute(gemm256): %s", hipGetErrorString(e));
+            return -3;
+        }
+        attr_set = true;
+    }
+    const int nM = (a.M + 255) / 256, nN = (a.N + 255) / 256;
+    dim3 grid(nM * nN, 1, a.nb1 * a.nb2);
+    hipLaunchKernelGGL(gemm256_kernel<DIAG>, grid, dim3(512), LDS_BYTES, s, a);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s) {
+    if (a.tile == 12) return launch256<1>(a, s);   // diagnostics only (tools/bench_gemm.py)
+    if (a.tile == 22) return launch256<2>(a, s);
+    return launch256<0>(a, s);
+}

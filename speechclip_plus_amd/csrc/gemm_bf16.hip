@@ -244,6 +244,8 @@ int launch(const sc_gemm_args& a, hipStream_t s) {
 
 }  // namespace
 
+int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s);   // gemm256_bf16.hip
+
 extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     SC_CHECK(args != nullptr, "sc_gemm_bf16: null args");
     sc_gemm_args a = *args;
@@ -267,7 +269,21 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
         a.n_split = -1;
     }
     hipStream_t s = (hipStream_t)stream;
-    // narrow outputs (grouped pos_conv, N = 48) waste less of a 64-wide tile
-    if (a.N <= 64 && a.n_split < 0) return launch<128, 64>(a, s);
-    return launch<128, 128>(a, s);
+    int tile = a.tile;
+    if (tile == 0) {
+        const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.nb1 * a.nb2;
+        if (a.N <= 64 && a.n_split < 0) tile = 3;            // narrow outputs (grouped pos_conv, N = 48)
+        else if (a.M >= 512 && a.N >= 256 && tiles256 >= 192 && (a.n_split < 0 || a.n_split % 256 == 0)) tile = 2;
+        else tile = 1;
+    }
+    switch (tile) {
+        case 1: return launch<128, 128>(a, s);
+        case 2: case 12: case 22:
+            SC_CHECK(a.n_split < 0 || a.n_split % 256 == 0, "sc_gemm_bf16: 256x256 tile needs n_split %% 256 == 0");
+            return sc_gemm256_launch(a, s);
+        case 3:
+            SC_CHECK(a.n_split < 0, "sc_gemm_bf16: 128x64 tile has no transposed store");
+            return launch<128, 64>(a, s);
+        default: sc_set_error("sc_gemm_bf16: tile=%d", a.tile); return -1;
+    }
 }

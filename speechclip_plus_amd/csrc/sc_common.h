@@ -22,8 +22,23 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ float bflo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
-// exact (erf) GELU: fairseq nn.GELU() / torch "gelu"
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (fairseq nn.GELU() / torch "gelu"):  x * Phi(x),  Phi(x) = 0.5 (1 + erf(x / sqrt 2)).
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off level): one v_rcp, one v_exp and a
+// degree-5 Horner chain instead of libm erff's ~40 instructions - the GELU epilogue of FC1 / the conv stack and the
+// conv-0 kernel are VALU-bound on it.  The lower tail is formed without cancellation (Phi(x<0) = 0.5 poly e).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float half_tail = 0.5f * poly * e;                 // = Phi(-|x|)
+    const float phi = x >= 0.f ? 1.0f - half_tail : half_tail;
+    return x * phi;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

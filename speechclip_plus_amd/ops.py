@@ -49,11 +49,23 @@ def set_timer(t: Optional[KernelTimer]) -> None:
     _timer = t
 
 
+def gemm_tile_name(M: int, N: int, K: int, n_split: int, batch: int, tile: int = 0) -> str:
+    """Mirror of the tile selection in sc_gemm_bf16 (csrc/gemm_bf16.hip), for reporting only."""
+    if tile == 0:
+        if N <= 64 and n_split < 0:
+            tile = 3
+        elif M >= 512 and N >= 256 and ((M + 255) // 256) * ((N + 255) // 256) * batch >= 192 and (n_split < 0 or n_split % 256 == 0):
+            tile = 2
+        else:
+            tile = 1
+    return {1: "128x128", 2: "256x256", 3: "128x64"}.get(tile, "diag")
+
+
 def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tensor, ldc: int, M: int, N: int, K: int,
              bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ldr: int = 0, act: int = 0,
              out_f32: bool = False, Ct: Optional[torch.Tensor] = None, n_split: int = -1, R: int = 0, dh: int = 0,
              nb1: int = 1, nb2: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sBias=(0, 0), sR=(0, 0),
-             alg_rows: Optional[int] = None) -> None:
+             alg_rows: Optional[int] = None, tile: int = 0) -> None:
     """C = epi(A . W^T); see sc_gemm_args in include/speechclip_hip.h.  Pointers are the tensors' data_ptr()
     (pass a sliced view to offset).  ``alg_rows``: rows that are algorithmic work (excludes layout padding),
     used only by the optional KernelTimer."""
@@ -75,6 +87,7 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     a.sC1, a.sC2 = sC
     a.sBias1, a.sBias2 = sBias
     a.sR1, a.sR2 = sR
+    a.tile = tile
     if _timer is None:
         check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
         return
@@ -83,13 +96,12 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
     ev1.record()
     rows = (M if alg_rows is None else alg_rows) * nb1 * nb2
-    tile = "128x64" if (N <= 64 and n_split < 0) else "128x128"
-    _timer.add("gemm_bf16_" + tile, ev0, ev1, 2.0 * rows * N * K)
+    _timer.add("gemm_bf16_" + gemm_tile_name(M, N, K, n_split, nb1 * nb2, tile), ev0, ev1, 2.0 * rows * N * K)
 
 
 def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, act: int = 0, out_f32: bool = False,
-                alg_rows: Optional[int] = None) -> torch.Tensor:
+                alg_rows: Optional[int] = None, tile: int = 0) -> torch.Tensor:
     """y[M, N] = epi(x[M, K] . w[N, K]^T) for contiguous 2-D operands."""
     M, K = x.shape
     N = w.shape[0]
@@ -97,7 +109,7 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     gemm_raw(x, x.stride(0), w, w.stride(0), out, out.stride(0), M, N, K, bias=bias, residual=residual,
-             ldr=residual.stride(0) if residual is not None else 0, act=act, out_f32=out_f32, alg_rows=alg_rows)
+             ldr=residual.stride(0) if residual is not None else 0, act=act, out_f32=out_f32, alg_rows=alg_rows, tile=tile)
     return out
 
 

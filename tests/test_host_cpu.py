@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) | {"sc_last_error"} == declared
     assert lib.sc_abi_version() == 1
     # the ctypes mirror of sc_gemm_args must have the C struct's size (8-byte fields, natural alignment)
-    assert ctypes.sizeof(_lib.GemmArgs) == 6 * 8 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 6 * 4 + 10 * 8
+    assert ctypes.sizeof(_lib.GemmArgs) == 6 * 8 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 6 * 4 + 10 * 8 + 8
 
 
 def test_ops_fail_loudly_on_cpu_tensors():
