@@ -46,8 +46,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if int(os.environ.get("SC_SHARE_GPU", "0")):               # rehearsal: all ranks on one device
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SC_DIST_BACKEND", "nccl")      # "nccl" = RCCL; "gloo" only to rehearse on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         dist = None
         torch.cuda.set_device(local_rank)
@@ -124,6 +130,7 @@ def main():
                     "launches_per_step": dom["launches"] // args.steps,
                     "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                     "alg_gflop_per_launch": round(dom["work"] / dom["launches"] / 1e9, 3)}
+            roof.update(pmc_traffic("gemm256_kernel<0>" if dom_name == "gemm_bf16_256x256" else "gemm_bf16_kernel<128, 128>"))
             for k, v in summ.items():
                 extra[k] = {"ms_per_step": round(v["ms"] / args.steps, 3),
                             "alg_tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None}
@@ -146,6 +153,22 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH x2 gfx950 correction; tools/summarize_pmc.py).  bench.py
+    cannot collect hardware counters itself, so it reports the newest profiles/*_traffic.json (or null)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return {"traffic": None}
+    data = json.load(open(files[-1]))
+    for name, v in data.items():
+        if kernel_substr in name:
+            return {"traffic": v["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch (PMC, avg over launches)",
+                    "traffic_source": os.path.relpath(files[-1], ROOT)}
+    return {"traffic": None}
 
 
 def cpu_baseline(sd, model, n_utts, L, iters):
