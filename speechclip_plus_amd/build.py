@@ -28,7 +28,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-I", INCLUDE, "-I", CSRC,
+            # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has a unified register file); otherwise every VALU touch
+            # of an accumulator (softmax, epilogues) pays v_accvgpr_read/write moves
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-x", "hip",
+                   "-I", INCLUDE, "-I", CSRC,
                    "-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

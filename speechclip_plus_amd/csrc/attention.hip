@@ -25,8 +25,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // 1-D grid, XCD-aware decode: blocks bid, bid + 8, ... share an XCD (and its L2); give each XCD a contiguous
+    // range of (utterance, head, q-block) triples with the q-block fastest, so the R/128 workgroups that re-read the
+    // same K / V^T of one (utterance, head) hit in that XCD's L2 instead of fetching it once per XCD.
+    const int nqb = R >> 7;
+    int logical;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int qblk = logical % nqb, bh = logical / nqb;
+    const int h = bh % H, b = bh / H;
+    const int q0 = qblk * 128 + wave * 32;
     int n_valid = valid_len[b];
     n_valid = max(1, min(n_valid, R));
 
@@ -58,93 +68,113 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (n_valid + KT - 1) / KT;
-    uint4 kreg[2], vreg[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        kreg[i] = *(const uint4*)(kg[i]);
-        vreg[i] = *(const uint4*)(vg[i]);
-    }
+    // prefetch registers as named scalars: arrays indexed across the tile loop were being placed in scratch
+    uint4 kreg0 = *(const uint4*)(kg[0]), kreg1 = *(const uint4*)(kg[1]);
+    uint4 vreg0 = *(const uint4*)(vg[0]), vreg1 = *(const uint4*)(vg[1]);
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
         // write the prefetched tile
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *(uint4*)(Ks + k_lds[i]) = kreg[i];
-            *(uint2*)(Vs + v_lds0[i]) = make_uint2(vreg[i].x, vreg[i].y);
-            *(uint2*)(Vs + v_lds1[i]) = make_uint2(vreg[i].z, vreg[i].w);
-        }
+        *(uint4*)(Ks + k_lds[0]) = kreg0;
+        *(uint4*)(Ks + k_lds[1]) = kreg1;
+        *(uint2*)(Vs + v_lds0[0]) = make_uint2(vreg0.x, vreg0.y);
+        *(uint2*)(Vs + v_lds1[0]) = make_uint2(vreg0.z, vreg0.w);
+        *(uint2*)(Vs + v_lds0[1]) = make_uint2(vreg1.x, vreg1.y);
+        *(uint2*)(Vs + v_lds1[1]) = make_uint2(vreg1.z, vreg1.w);
         __syncthreads();
         if (t + 1 < ntiles) {
+            kreg0 = *(const uint4*)(kg[0] + (int64_t)(key0 + KT) * ldqk);
+            kreg1 = *(const uint4*)(kg[1] + (int64_t)(key0 + KT) * ldqk);
+            vreg0 = *(const uint4*)(vg[0] + key0 + KT);
+            vreg1 = *(const uint4*)(vg[1] + key0 + KT);
+        }
+        // Two 32-key blocks per tile, software-pipelined inside the wave: both S^T blocks are issued first, so the
+        // matrix pipe works on block 1 while the VALU runs block 0's softmax, and on P.V of block 0 during block 1's.
+        const bool blk1 = key0 + 32 < n_valid;                       // wave-uniform
+        f32x16 s0, s1;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                kreg[i] = *(const uint4*)(kg[i] + (int64_t)(key0 + KT) * ldqk);
-                vreg[i] = *(const uint4*)(vg[i] + key0 + KT);
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(Ks + l31 * 128 + (((2 * ks + half) ^ ((l31 >> 1) & 7)) << 4));
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s0, 0, 0, 0);
+        }
+        if (blk1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int krow = 32 + l31;
+                const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((2 * ks + half) ^ ((krow >> 1) & 7)) << 4));
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s1, 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int kbase = key0 + kb * 32;
-            if (kbase < n_valid) {   // wave-uniform
-                f32x16 s;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = 0.f;
-                const int krow = kb * 32 + l31;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((2 * ks + half) ^ ((krow >> 1) & 7)) << 4));
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-                }
-                if (kbase + 32 > n_valid) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kidx = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (kidx >= n_valid) s[r] = -INFINITY;
-                    }
-                }
-                float mloc = s[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-                const float m_new = fmaxf(m_run, mloc);
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-                const float mc = m_new * c;
-                float psum = 0.f;
-                float pv[16];
+        auto softmax_block = [&](f32x16& sv, int kbase, bf16x8 (&pf)[2]) {
+            if (kbase + 32 > n_valid) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));
-                    psum += pv[r];
-                }
-                l_run = l_run * alpha + psum;
-                m_run = m_new;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-                bf16x8 pf[2];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[s2][j] = (__bf16)pv[8 * s2 + j];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int u0 = kb * 8 + 4 * s2 + half;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const int vrow = dt * 32 + l31;
-                        const int sw = (vrow >> 1) & 15;
-                        const uint2 lo = *(const uint2*)(Vs + vrow * 128 + ((u0 ^ sw) << 3));
-                        const uint2 hi = *(const uint2*)(Vs + vrow * 128 + (((u0 + 2) ^ sw) << 3));
-                        const uint4 v4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        const bf16x8 vf = __builtin_bit_cast(bf16x8, v4);
-                        if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o0, 0, 0, 0);
-                        else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o1, 0, 0, 0);
-                    }
+                    const int kidx = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (kidx >= n_valid) sv[r] = -INFINITY;
                 }
             }
+            float mloc = sv[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sv[r]);
+            {   // exchange with lane ^ 32 on the VALU (v_permlane32_swap) instead of ds_bpermute
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+                mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            // deferred rescale: keep the running max stale while it would grow by < 2^6 in the exponent domain
+            // (p stays <= 64, harmless for the fp32 sums and the bf16 P operand); when any lane of the wave needs
+            // it, O, l and the max are brought to the new scale together, before this block's P is formed
+            const float m_cand = fmaxf(m_run, mloc);
+            if (__any((m_cand - m_run) * c > 6.0f)) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * c);
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                m_run = m_cand;
+            }
+            const float mc = m_run * c;
+            float psum = 0.f;
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pv[r] = __builtin_amdgcn_exp2f(fmaf(sv[r], c, -mc));
+                psum += pv[r];
+            }
+            l_run += psum;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[s2][j] = (__bf16)pv[8 * s2 + j];
+        };
+        auto pv_block = [&](int kb, const bf16x8 (&pf)[2]) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int u0 = kb * 8 + 4 * s2 + half;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int vrow = dt * 32 + l31;
+                    const int sw = (vrow >> 1) & 15;
+                    const uint2 lo = *(const uint2*)(Vs + vrow * 128 + ((u0 ^ sw) << 3));
+                    const uint2 hi = *(const uint2*)(Vs + vrow * 128 + (((u0 + 2) ^ sw) << 3));
+                    const uint4 v4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    const bf16x8 vf = __builtin_bit_cast(bf16x8, v4);
+                    if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o0, 0, 0, 0);
+                    else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o1, 0, 0, 0);
+                }
+            }
+        };
+        bf16x8 pf0[2], pf1[2];
+        softmax_block(s0, key0, pf0);
+        pv_block(0, pf0);
+        if (blk1) {
+            softmax_block(s1, key0 + 32, pf1);
+            pv_block(1, pf1);
         }
         __syncthreads();
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
     const float inv = 1.0f / l_tot;
     uint16_t* op = out + ((int64_t)b * R + q0 + l31) * ldo + h * 64 + 4 * half;
 #pragma unroll
@@ -170,7 +200,7 @@ extern "C" int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* 
     SC_CHECK(ldqk % 8 == 0 && ldo % 4 == 0 && ldqk >= 2 * D && ldo >= D, "sc_attn_fwd_bf16: bad leading dims");
     SC_CHECK(((uintptr_t)qk % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0,
              "sc_attn_fwd_bf16: alignment");
-    dim3 grid(R / 128, H, B);
+    dim3 grid((R / 128) * H * B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R,
                        H, D, scale * 1.4426950408889634f);
     SC_LAUNCH_CHECK();

@@ -244,7 +244,7 @@ int launch(const sc_gemm_args& a, hipStream_t s) {
 
 }  // namespace
 
-int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s);   // gemm256_bf16.hip
+int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s);    // gemm256_bf16.hip
 
 extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     SC_CHECK(args != nullptr, "sc_gemm_bf16: null args");

@@ -27,6 +27,7 @@ __device__ __forceinline__ float bfhi(uint32_t u) { return __uint_as_float(u & 0
 // degree-5 Horner chain instead of libm erff's ~40 instructions - the GELU epilogue of FC1 / the conv stack and the
 // conv-0 kernel are VALU-bound on it.  The lower tail is formed without cancellation (Phi(x<0) = 0.5 poly e).
 __device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)   // identical rounding in every kernel that inlines it
     const float z = fabsf(x) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
     float poly = fmaf(t, 1.061405429f, -1.453152027f);

@@ -62,17 +62,18 @@ def test_gemm(dev, M, N, K, act, use_bias, use_res, out_f32):
     assert float((out.float() - ref).abs().max()) < (1e-3 if out_f32 else 0.06) * (1 + float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("M,N,K,act,use_res", [(512, 768, 768, 0, True), (1024, 512, 1536, 1, False), (700, 300 * 8 // 8 * 8 + 8, 128, 0, True),
-                                                (2048, 3072, 768, 1, False), (512, 256, 64, 0, False)])
-def test_gemm_tile256(dev, M, N, K, act, use_res):
-    """The pipelined 256x256 variant (forced with tile=2) against fp32 torch, incl. M / N tails and short K."""
+@pytest.mark.parametrize("tile", [2])
+@pytest.mark.parametrize("M,N,K,act,use_res", [(512, 768, 768, 0, True), (1024, 512, 1536, 1, False), (700, 2408, 128, 0, True),
+                                                (2048, 3072, 768, 1, False), (512, 256, 64, 0, False), (6000, 512, 1024, 1, False)])
+def test_gemm_tile256(dev, M, N, K, act, use_res, tile):
+    """The 256x256 variant (tile=2) against fp32 torch and against the 128x128 variant, incl. M / N tails, short K."""
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g)).to(dev)
     W = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
     bias = torch.randn(N, generator=g).to(dev)
     res = bf(torch.randn(M, N, generator=g)).to(dev) if use_res else None
-    out = ops.linear_bf16(A, W, bias, residual=res, act=act, tile=2)
+    out = ops.linear_bf16(A, W, bias, residual=res, act=act, tile=tile)
     ref = A.float() @ W.float().T + bias
     if act:
         ref = F.gelu(ref)
@@ -80,10 +81,11 @@ def test_gemm_tile256(dev, M, N, K, act, use_res):
         ref = ref + res.float()
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
     out1 = ops.linear_bf16(A, W, bias, residual=res, act=act, tile=1)
-    assert torch.equal(out, out1), "both tile variants accumulate k in the same order -> bitwise equal"
+    assert torch.equal(out, out1), "both tile variants accumulate k in the same order and share the epilogue maths"
 
 
-def test_gemm_tile256_transposed_store(dev):
+@pytest.mark.parametrize("tile", [2])
+def test_gemm_tile256_transposed_store(dev, tile):
     ops = _ops()
     B, R, D, H = 2, 384, 768, 12
     g = torch.Generator(device="cpu").manual_seed(19)
@@ -92,7 +94,7 @@ def test_gemm_tile256_transposed_store(dev):
     bias = torch.randn(3 * D, generator=g).to(dev)
     qk = torch.zeros(B * R, 2 * D, device=dev, dtype=torch.bfloat16)
     vt = torch.zeros(B, H, 64, R, device=dev, dtype=torch.bfloat16)
-    ops.gemm_raw(x, D, W, D, qk, 2 * D, B * R, 3 * D, D, bias=bias, Ct=vt, n_split=2 * D, R=R, dh=64, tile=2)
+    ops.gemm_raw(x, D, W, D, qk, 2 * D, B * R, 3 * D, D, bias=bias, Ct=vt, n_split=2 * D, R=R, dh=64, tile=tile)
     ref = x.float() @ W.float().T + bias
     assert rel_l2(qk, ref[:, : 2 * D]) < 6e-3
     assert rel_l2(vt, ref[:, 2 * D:].view(B, R, H, 64).permute(0, 2, 3, 1)) < 6e-3
