@@ -139,13 +139,14 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
     const int t_end = min(R0, t_begin + rows_per_block);
     for (int cg = 0; cg < cgroups; ++cg) {
         const int c0 = cg * 512 + lane * 8;
-        float w[8][10], sc[8], sh[8];
+        // channel pairs in packed fp32 (v_pk_fma_f32): 4 pairs x 10 taps per output row
+        f32x2 w[4][10], sc[4], sh[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int j = 0; j < 10; ++j) w[i][j] = w0[(c0 + i) * 10 + j];
-            sc[i] = scale[(int64_t)b * C + c0 + i];
-            sh[i] = shift[(int64_t)b * C + c0 + i];
+            for (int j = 0; j < 10; ++j) w[i][j] = f32x2{w0[(c0 + 2 * i) * 10 + j], w0[(c0 + 2 * i + 1) * 10 + j]};
+            sc[i] = *(const f32x2*)(scale + (int64_t)b * C + c0 + 2 * i);
+            sh[i] = *(const f32x2*)(shift + (int64_t)b * C + c0 + 2 * i);
         }
         for (int t = t_begin + wave; t < t_end; t += 4) {
             float v[10];
@@ -153,11 +154,13 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
             for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];   // wave-uniform address: broadcast load
             float o[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float a = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                f32x2 a = f32x2{0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 10; ++j) a = fmaf(w[i][j], v[j], a);
-                o[i] = gelu_erf(fmaf(a, sc[i], sh[i]));
+                for (int j = 0; j < 10; ++j) a = __builtin_elementwise_fma(w[i][j], f32x2{v[j], v[j]}, a);
+                const f32x2 g = gelu_erf2(__builtin_elementwise_fma(a, sc[i], sh[i]));
+                o[2 * i] = g.x;
+                o[2 * i + 1] = g.y;
             }
             uint4 u;
             u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);

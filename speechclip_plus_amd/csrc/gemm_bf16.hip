@@ -156,10 +156,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
             const int ml = wm * TM + mi * 16 + 4 * (lane >> 4);
             f32x4 v = acc[mi][ni];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = v[r] + bv;
-                if (p.act == 1) x = gelu_erf(x);
-                v[r] = x;
+            for (int r = 0; r < 4; ++r) v[r] += bv;
+            if (p.act == 1) {
+                const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+                v = f32x4{g0.x, g0.y, g1.x, g1.y};
             }
             if (transposed) {
                 *(f32x4*)(Cs + nl * BM + ml) = v;

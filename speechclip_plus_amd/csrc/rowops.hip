@@ -51,9 +51,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
             const f32x4 bt = *(const f32x4*)(beta + ch * 4);
             float o[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = (v[i][j] - mean) * rstd * g[j] + bt[j];
-                if (act == 1) o[j] = gelu_erf(o[j]);
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bt[j];
+            if (act == 1) {
+                const f32x2 g0 = gelu_erf2(f32x2{o[0], o[1]}), g1 = gelu_erf2(f32x2{o[2], o[3]});
+                o[0] = g0.x; o[1] = g0.y; o[2] = g1.x; o[3] = g1.y;
             }
             uint2 w;
             w.x = pack2bf(o[0], o[1]);

@@ -41,6 +41,32 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return x * phi;
 }
 
+// two elements at a time: the polynomial and the scalings become packed fp32 ops (v_pk_fma_f32 / v_pk_mul_f32, two
+// lanes' worth of work per issue slot); rcp / exp2 stay scalar (transcendental unit).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+#pragma clang fp contract(off)
+    f32x2 ax;
+    ax.x = fabsf(x.x); ax.y = fabsf(x.y);
+    const f32x2 z = ax * 0.70710678118654752f;
+    const f32x2 den = __builtin_elementwise_fma(z, f32x2{0.3275911f, 0.3275911f}, f32x2{1.0f, 1.0f});
+    f32x2 t;
+    t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+    f32x2 poly = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{0.254829592f, 0.254829592f});
+    poly = poly * t;
+    const f32x2 ex = z * z * -1.4426950408889634f;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(ex.x); e.y = __builtin_amdgcn_exp2f(ex.y);
+    const f32x2 half_tail = poly * e * 0.5f;
+    f32x2 phi;
+    phi.x = x.x >= 0.f ? 1.0f - half_tail.x : half_tail.x;
+    phi.y = x.y >= 0.f ? 1.0f - half_tail.y : half_tail.y;
+    return x * phi;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
