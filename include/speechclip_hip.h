@@ -104,6 +104,9 @@ int sc_conv0_finalize(const double* partial, int32_t nchunk, const float* w0 /*[
                       float* shift, void* stream);
 int sc_conv0_gn_gelu(const float* wav, int64_t ldw, const float* w0, const float* scale, const float* shift,
                      sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream);
+/* "layer_norm" extractor mode (HuBERT-large): conv0 (+bias) -> LayerNorm over the 512 channels -> GELU */
+int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma,
+                     const float* beta, float eps, sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pos_conv input: zero padded frames (speech_encoder_plus.py:32-33 index_put(x, padding_mask, 0)) and

@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
                                                             uint16_t* __restrict__ out, int R0, int C,
                                                             int rows_per_block) {
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // wave id made provably uniform: the 10-sample window x[5t .. 5t+9] is then fetched with scalar loads (SMEM,
+    // scalar cache) instead of 10 broadcast vector loads per output row
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cgroups = C / 512;   // C is a multiple of 512 (checked on the host)
     const float* x = wav + (int64_t)b * ldw;
     const int t_begin = blockIdx.x * rows_per_block;
@@ -167,6 +170,63 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
             u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
             *(uint4*)(out + ((int64_t)b * R0 + t) * C + c0) = u;
         }
+    }
+}
+
+// "layer_norm" extractor mode (HuBERT-large): out[b*R0 + t, :] = gelu(LayerNorm_c(conv0(x)[t, :] + bias)), C = 512:
+// one wave per output row, 8 channels per lane, wavefront reductions for the channel statistics.
+__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ wav, int64_t ldw,
+                                                            const float* __restrict__ w0,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            uint16_t* __restrict__ out, int R0, int rows_per_block) {
+    constexpr int C = 512;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* x = wav + (int64_t)b * ldw;
+    const int t_begin = blockIdx.x * rows_per_block;
+    const int t_end = min(R0, t_begin + rows_per_block);
+    const int c0 = lane * 8;
+    float w[8][10], bs[8], gm[8], bt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[i][j] = w0[(c0 + i) * 10 + j];
+        bs[i] = bias ? bias[c0 + i] : 0.f;
+        gm[i] = gamma[c0 + i];
+        bt[i] = beta[c0 + i];
+    }
+    for (int t = t_begin + wave; t < t_end; t += 4) {
+        float v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];
+        float a[8], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float acc = bs[i];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc = fmaf(w[i][j], v[j], acc);
+            a[i] = acc;
+            s += acc;
+        }
+        const float mean = wave_sum(s) * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sq += (a[i] - mean) * (a[i] - mean);
+        const float rstd = rsqrtf(wave_sum(sq) * (1.0f / C) + eps);
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const f32x2 g = gelu_erf2(f32x2{(a[i] - mean) * rstd * gm[i] + bt[i], (a[i + 1] - mean) * rstd * gm[i + 1] + bt[i + 1]});
+            o[i] = g.x;
+            o[i + 1] = g.y;
+        }
+        uint4 u;
+        u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
+        u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+        *(uint4*)(out + ((int64_t)b * R0 + t) * C + c0) = u;
     }
 }
 
@@ -208,6 +268,18 @@ extern "C" int sc_conv0_gn_gelu(const float* wav, int64_t ldw, const float* w0, 
     const int rows_per_block = 128;
     dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
     hipLaunchKernelGGL(conv0_gn_gelu_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, scale, shift, out, R0, C, rows_per_block);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma,
+                                const float* beta, float eps, sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream) {
+    SC_CHECK(wav && w0 && gamma && beta && out, "sc_conv0_ln_gelu: null pointer");
+    SC_CHECK(C == 512 && ldw >= 5 * (int64_t)(R0 - 1) + 10, "sc_conv0_ln_gelu: C must be 512 (got %d); ldw too small", C);
+    SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_ln_gelu: alignment");
+    const int rows_per_block = 128;
+    dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
+    hipLaunchKernelGGL(conv0_ln_gelu_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, out, R0, rows_per_block);
     SC_LAUNCH_CHECK();
     return 0;
 }

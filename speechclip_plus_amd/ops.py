@@ -161,6 +161,14 @@ def conv0_groupnorm_gelu(wav_pad: torch.Tensor, w0: torch.Tensor, gamma: torch.T
           "sc_conv0_gn_gelu")
 
 
+def conv0_layernorm_gelu(wav_pad: torch.Tensor, w0: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
+                         beta: torch.Tensor, R0: int, out: torch.Tensor, eps: float = 1e-5) -> None:
+    """conv layer 0 (+bias) + LayerNorm over channels + GELU ("layer_norm" extractor mode) -> out[B*R0, 512] bf16."""
+    B, C = wav_pad.shape[0], w0.shape[0]
+    check(lib().sc_conv0_ln_gelu(_p(wav_pad), wav_pad.stride(0), _p(w0), _p(bias), _p(gamma), _p(beta), float(eps), _p(out),
+                                 B, R0, C, _stream()), "sc_conv0_ln_gelu")
+
+
 def posconv_prep(x: torch.Tensor, valid_len: torch.Tensor, xz: torch.Tensor, xg: torch.Tensor, B: int, R: int, D: int,
                  G: int, halo: int) -> None:
     check(lib().sc_posconv_prep(_p(x), _p(valid_len), _p(xz), _p(xg), B, R, D, G, halo, _stream()), "sc_posconv_prep")

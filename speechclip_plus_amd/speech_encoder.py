@@ -179,8 +179,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             raise NotImplementedError(
                 "HuBERT backward (audio_encoder.trainable / reinit_layers / unfreeze_layers) is not built yet: every "
                 "shipped recipe freezes HuBERT (SURVEY F3); this is scope row f2")
-        if self.arch.extractor_mode != "default" or self.arch.layer_norm_first:
-            raise NotImplementedError("HuBERT-large kernels (layer_norm extractor, pre-LN layers) are not wired yet")
+        assert self.arch.extractor_mode in ("default", "layer_norm"), self.arch.extractor_mode
+        assert self.arch.embed_dim == self.arch.heads * 64, "the attention kernel is built for head_dim 64"
         if not (isinstance(layer_drop, float) and layer_drop == 0.0) and layer_drop != "original":
             raise ValueError(f"layer_drop = {layer_drop} is not supported.")
         self.feat_select_idx = feat_select_idx
@@ -218,11 +218,21 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             pos_w = sd["encoder.pos_conv.0.weight"]
         w = {}
         w["conv0_w"] = f32(sd["feature_extractor.conv_layers.0.0.weight"].reshape(a.conv_dim, a.conv_kernels[0]))
-        w["gn_g"] = f32(sd["feature_extractor.conv_layers.0.2.weight"])
-        w["gn_b"] = f32(sd["feature_extractor.conv_layers.0.2.bias"])
+        ln_mode = a.extractor_mode == "layer_norm"
+        if ln_mode:
+            w["conv0_ln_g"] = f32(sd["feature_extractor.conv_layers.0.2.1.weight"])
+            w["conv0_ln_b"] = f32(sd["feature_extractor.conv_layers.0.2.1.bias"])
+        else:
+            w["gn_g"] = f32(sd["feature_extractor.conv_layers.0.2.weight"])
+            w["gn_b"] = f32(sd["feature_extractor.conv_layers.0.2.bias"])
+        w["conv0_bias"] = f32(sd["feature_extractor.conv_layers.0.0.bias"]) if a.conv_bias else None
         for i in range(1, len(a.conv_kernels)):
             cw = sd[f"feature_extractor.conv_layers.{i}.0.weight"]              # [C_out, C_in, k]
             w[f"conv{i}_w"] = bf(cw.permute(0, 2, 1).reshape(cw.shape[0], -1))  # [C_out, k*C_in]  (tap-major)
+            w[f"conv{i}_bias"] = f32(sd[f"feature_extractor.conv_layers.{i}.0.bias"]) if a.conv_bias else None
+            if ln_mode:
+                w[f"conv{i}_ln_g"] = f32(sd[f"feature_extractor.conv_layers.{i}.2.1.weight"])
+                w[f"conv{i}_ln_b"] = f32(sd[f"feature_extractor.conv_layers.{i}.2.1.bias"])
         w["ln_feat_g"], w["ln_feat_b"] = f32(sd["layer_norm.weight"]), f32(sd["layer_norm.bias"])
         w["proj_w"], w["proj_b"] = bf(sd["post_extract_proj.weight"]), f32(sd["post_extract_proj.bias"])
         D, G, Kp = a.embed_dim, a.pos_conv_groups, a.pos_conv_kernel
@@ -273,11 +283,19 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         valid = [min(T, -(-int(l) // chunk)) for l in wav_len]
         pl.valid.copy_(torch.tensor(valid, dtype=torch.int32), non_blocking=True)
         # a2: conv feature extractor                                                    (:75)
-        ops.conv0_groupnorm_gelu(pl.wav_pad, w["conv0_w"], w["gn_g"], w["gn_b"], pl.T_l[0], pl.R_l[0], pl.conv[0])
+        ln_mode = a.extractor_mode == "layer_norm"
+        if ln_mode:       # large: conv (+bias) -> LayerNorm(512) -> GELU after every layer
+            ops.conv0_layernorm_gelu(pl.wav_pad, w["conv0_w"], w["conv0_bias"], w["conv0_ln_g"], w["conv0_ln_b"],
+                                     pl.R_l[0], pl.conv[0])
+        else:             # base: GroupNorm(512, 512) over time after conv 0 only, no conv bias
+            ops.conv0_groupnorm_gelu(pl.wav_pad, w["conv0_w"], w["gn_g"], w["gn_b"], pl.T_l[0], pl.R_l[0], pl.conv[0])
         for i in range(1, len(a.conv_kernels)):
             k, s = a.conv_kernels[i], a.conv_strides[i]
-            ops.gemm_raw(pl.conv[i - 1], s * C, w[f"conv{i}_w"], k * C, pl.conv[i], C, B * pl.R_l[i], C, k * C, act=1,
-                         alg_rows=B * pl.T_l[i])
+            rows = B * pl.R_l[i]
+            ops.gemm_raw(pl.conv[i - 1], s * C, w[f"conv{i}_w"], k * C, pl.conv[i], C, rows, C, k * C,
+                         bias=w[f"conv{i}_bias"], act=0 if ln_mode else 1, alg_rows=B * pl.T_l[i])
+            if ln_mode:
+                ops.layernorm_bf16(pl.conv[i][:rows], w[f"conv{i}_ln_g"], w[f"conv{i}_ln_b"], out=pl.conv[i][:rows], act=1)
         # a3: LayerNorm(512) -> post_extract_proj                                       (:78, :84-85)
         ops.layernorm_bf16(pl.conv[-1][:M], w["ln_feat_g"], w["ln_feat_b"], out=pl.feat_ln)
         ops.linear_bf16(pl.feat_ln, w["proj_w"], w["proj_b"], out=pl.x_proj, alg_rows=B * T)
@@ -288,19 +306,37 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         ops.gemm_raw(pl.xg, Dg, w["pos_w"], Kp * Dg, pl.pre, D, R, Dg, Kp * Dg, bias=w["pos_b"], residual=pl.xz, ldr=D,
                      act=1, nb1=G, nb2=B, sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, R * D),
                      sBias=(Dg, 0), sR=(Dg, R * D), alg_rows=T)
-        ops.layernorm_bf16(pl.pre, w["ln_enc_g"], w["ln_enc_b"], out=pl.hidden[0])
-        # a5: transformer layers (post-LN)                                              (:49-53)
         scale = (D // H) ** -0.5
-        for i in range(a.layers):
-            x = pl.hidden[i]
+
+        def qkv_attn(x, i):
             ops.gemm_raw(x, D, w[f"l{i}_qkv_w"], D, pl.qk, 2 * D, M, 3 * D, D, bias=w[f"l{i}_qkv_b"], Ct=pl.vt,
                          n_split=2 * D, R=R, dh=D // H, alg_rows=B * T)
             ops.attn_fwd(pl.qk, pl.vt, pl.valid, pl.ctx, B, R, H, D, scale, alg_flops=4.0 * B * T * T * D)
-            ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T)
-            ops.layernorm_bf16(pl.pre, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
-            ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1, alg_rows=B * T)
-            ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.pre, residual=pl.x1, alg_rows=B * T)
-            ops.layernorm_bf16(pl.pre, w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"], out=pl.hidden[i + 1])
+
+        if not a.layer_norm_first:
+            # a5: post-LN layers (base): x = LN1(x + attn(x)); x = LN2(x + ffn(x))       (:39-40, :49-53)
+            ops.layernorm_bf16(pl.pre, w["ln_enc_g"], w["ln_enc_b"], out=pl.hidden[0])
+            for i in range(a.layers):
+                x = pl.hidden[i]
+                qkv_attn(x, i)
+                ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T)
+                ops.layernorm_bf16(pl.pre, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
+                ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1, alg_rows=B * T)
+                ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.pre, residual=pl.x1, alg_rows=B * T)
+                ops.layernorm_bf16(pl.pre, w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"], out=pl.hidden[i + 1])
+        else:
+            # pre-LN layers (large): x = x + attn(LN1(x)); x = x + ffn(LN2(x)); layer_results are NOT passed through
+            # the encoder's final LayerNorm (fairseq applies it to `x` only, which the reference never reads)
+            pl.hidden[0].copy_(pl.pre)
+            for i in range(a.layers):
+                x = pl.hidden[i]
+                ops.layernorm_bf16(x, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
+                qkv_attn(pl.x1, i)
+                ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T)
+                ops.layernorm_bf16(pl.pre, w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"], out=pl.x1)
+                ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1, alg_rows=B * T)
+                ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.hidden[i + 1], residual=pl.pre,
+                                alg_rows=B * T)
         return pl
 
     def forward(self, wav: Union[torch.Tensor, list], wav_len: Union[torch.Tensor, list] = [],

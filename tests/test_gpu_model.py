@@ -60,6 +60,32 @@ def test_encoder_hidden_states(setup):
     print("worst hidden-state rel-L2", worst)
 
 
+def test_encoder_large_arch():
+    """HuBERT-large wiring (layer_norm extractor with conv bias, utterance-normalised waveform, pre-LN layers,
+    D = 1024 / 16 heads / F = 4096) at reduced depth (3 layers) against the oracle."""
+    import dataclasses
+    import oracle
+    from speechclip_plus_amd import FairseqSpeechEncoder_Hubert, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    arch = dataclasses.replace(ARCHS["hubert_large_ll60k"], layers=3)
+    sd = random_hubert_state_dict(arch, seed=99)
+    enc = FairseqSpeechEncoder_Hubert(name="hubert_large_ll60k", device="cuda:0", feat_select_idx="all", state_dict=sd,
+                                      arch=arch).eval()
+    o_arch = oracle.HubertArch.large()
+    o_arch.layers = 3
+    g = torch.Generator().manual_seed(3)
+    lens = [12000, 7000]
+    wavs = [torch.randn(l, generator=g) * 0.3 + 0.05 for l in lens]
+    with torch.no_grad():
+        feat, feat_len = enc([w.cuda() for w in wavs])
+        hs_o, fl_o = oracle.speech_encoder_forward(sd, o_arch, wavs)
+    assert feat_len.cpu().tolist() == fl_o.tolist()
+    assert len(feat["hidden_states"]) == 4 and feat["hidden_states"][0].shape[-1] == 1024
+    for n in range(4):
+        e = rel_l2(feat["hidden_states"][n], hs_o[n])
+        assert e < 2e-2, (n, e)
+
+
 def _oracle_step(oracle, sd, o_arch, head_W, ws_w, wavs, img, ids):
     hs_o, fl = oracle.speech_encoder_forward(sd, o_arch, wavs)
     W = {k: v.clone().requires_grad_(True) for k, v in head_W.items()}
