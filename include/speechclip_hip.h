@@ -123,11 +123,13 @@ int sc_posconv_prep(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_
  *   out  [B, R, D] bf16, written at row offset `row_off` inside each utterance (row_off = 1 leaves row 0
  *        for the CLS token of kw_branches.py:266-267), rows t in [0, R - row_off)
  *   bwd: dw[n] = sum_{b,t,d} g[b, t + row_off, d] * h[n, b, t, d]   (g fp32 [B, R, D])
+ *   normalize != 0: every h[n, row, :] passes through a non-affine LayerNorm(D, eps 1e-5) first
+ *        (normalize_features=True, weighted_sum.py:41-42; used by the HuBERT-large recipes), D <= 1024
  * ---------------------------------------------------------------------------------------------- */
 int sc_wsum_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, int32_t B, int32_t R, int32_t D,
-                int32_t row_off, void* stream);
+                int32_t row_off, int32_t normalize, void* stream);
 int sc_wsum_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial /*[nblk, NL]*/, int32_t nblk,
-                int32_t B, int32_t R, int32_t D, int32_t row_off, void* stream);
+                int32_t B, int32_t R, int32_t D, int32_t row_off, int32_t normalize, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CLS attention pooling (the query row 0 of the parallel branch's TransformerEncoder layer;

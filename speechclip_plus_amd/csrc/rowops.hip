@@ -136,6 +136,135 @@ __global__ __launch_bounds__(256) void wsum_bwd_kernel(const uint16_t* __restric
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------- weighted sum, normalised
+// normalize_features = True (HuBERT-large recipes): out = sum_n w[n] * LayerNorm_noaffine(h[n, row, :]).
+// One wave per row (D <= 1024 -> <= 16 elements per lane held in registers), wavefront reductions per layer.
+template <int NE>   // 8-element chunks per lane
+__device__ __forceinline__ void load_row_norm(const uint16_t* __restrict__ src, int lane, int nchunks, int D, float eps,
+                                              float (&xh)[NE][8]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+            const uint4 u = *(const uint4*)(src + ch * 8);
+            xh[i][0] = bflo(u.x); xh[i][1] = bfhi(u.x); xh[i][2] = bflo(u.y); xh[i][3] = bfhi(u.y);
+            xh[i][4] = bflo(u.z); xh[i][5] = bfhi(u.z); xh[i][6] = bflo(u.w); xh[i][7] = bfhi(u.w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += xh[i][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xh[i][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xh[i][j] -= mean;
+                sq += xh[i][j] * xh[i][j];
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xh[i][j] *= rstd;
+}
+
+template <int NE>
+__global__ __launch_bounds__(256) void wsum_norm_fwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w,
+                                                            int NL, uint16_t* __restrict__ out, int B, int R, int D,
+                                                            int row_off) {
+    const int lane = threadIdx.x & 63;
+    const int nchunks = D >> 3;
+    const int64_t rows = (int64_t)B * R, plane = rows * D;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        if ((int)(row % R) + row_off >= R) continue;
+        float acc[NE][8];
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+        for (int n = 0; n < NL; ++n) {
+            float xh[NE][8];
+            load_row_norm<NE>(h + n * plane + row * D, lane, nchunks, D, 1e-5f, xh);
+            const float wn = w[n];
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] += wn * xh[i][j];
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunks) {
+                uint4 o;
+                o.x = pack2bf(acc[i][0], acc[i][1]); o.y = pack2bf(acc[i][2], acc[i][3]);
+                o.z = pack2bf(acc[i][4], acc[i][5]); o.w = pack2bf(acc[i][6], acc[i][7]);
+                *(uint4*)(out + (row + row_off) * D + ch * 8) = o;
+            }
+        }
+    }
+}
+
+template <int NE>
+__global__ __launch_bounds__(256) void wsum_norm_bwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ g,
+                                                            int NL, float* __restrict__ dw_partial, int B, int R, int D,
+                                                            int row_off) {
+    __shared__ float red[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = D >> 3;
+    const int64_t rows = (int64_t)B * R, plane = rows * D;
+    float accn[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) accn[n] = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        if ((int)(row % R) + row_off >= R) continue;
+        float gv[NE][8];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunks) {
+                const float* gp = g + (row + row_off) * D + ch * 8;
+                const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+                gv[i][0] = g0[0]; gv[i][1] = g0[1]; gv[i][2] = g0[2]; gv[i][3] = g0[3];
+                gv[i][4] = g1[0]; gv[i][5] = g1[1]; gv[i][6] = g1[2]; gv[i][7] = g1[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gv[i][j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            if (n < NL) {
+                float xh[NE][8];
+                load_row_norm<NE>(h + n * plane + row * D, lane, nchunks, D, 1e-5f, xh);
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < NE; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d += gv[i][j] * xh[i][j];
+                accn[n] += d;        // per-lane partial; reduced over the wave once at the end
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        const float s = wave_sum(accn[n]);
+        if (lane == 0) red[wave][n] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NL)
+        dw_partial[(int64_t)blockIdx.x * NL + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // ---------------------------------------------------------------------------------------- pos_conv prep
 // xz[b*R + t, :] = t < valid[b] ? x : 0 ;  xg[g][b][halo + t][0:Dg] = same, group-major with zero halos.
 __global__ __launch_bounds__(256) void posconv_prep_kernel(const uint16_t* __restrict__ x,
@@ -179,9 +308,18 @@ extern "C" int sc_layernorm_bf16(const sc_bf16* x, int64_t ldx, const float* gam
 }
 
 extern "C" int sc_wsum_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, int32_t B, int32_t R, int32_t D,
-                           int32_t row_off, void* stream) {
+                           int32_t row_off, int32_t normalize, void* stream) {
     SC_CHECK(h && w && out, "sc_wsum_fwd: null pointer");
     SC_CHECK(NL >= 1 && NL <= 32 && D % 8 == 0 && row_off >= 0 && row_off < R, "sc_wsum_fwd: bad NL/D/row_off");
+    if (normalize) {
+        SC_CHECK(D <= 1024, "sc_wsum_fwd: normalised variant needs D <= 1024 (got %d)", D);
+        const int64_t rows = (int64_t)B * R;
+        const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+        if (D <= 512) hipLaunchKernelGGL(wsum_norm_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, w, NL, out, B, R, D, row_off);
+        else hipLaunchKernelGGL(wsum_norm_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, w, NL, out, B, R, D, row_off);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     const int64_t total = (int64_t)B * R * (D / 8);
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(wsum_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, w, NL, out, B, R, D, row_off);
@@ -190,9 +328,16 @@ extern "C" int sc_wsum_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16
 }
 
 extern "C" int sc_wsum_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial, int32_t nblk, int32_t B,
-                           int32_t R, int32_t D, int32_t row_off, void* stream) {
+                           int32_t R, int32_t D, int32_t row_off, int32_t normalize, void* stream) {
     SC_CHECK(h && g && dw_partial, "sc_wsum_bwd: null pointer");
     SC_CHECK(NL >= 1 && NL <= 32 && D % 8 == 0 && nblk >= 1 && row_off >= 0 && row_off < R, "sc_wsum_bwd: bad args");
+    if (normalize) {
+        SC_CHECK(D <= 1024, "sc_wsum_bwd: normalised variant needs D <= 1024 (got %d)", D);
+        if (D <= 512) hipLaunchKernelGGL(wsum_norm_bwd_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, h, g, NL, dw_partial, B, R, D, row_off);
+        else hipLaunchKernelGGL(wsum_norm_bwd_kernel<2>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, h, g, NL, dw_partial, B, R, D, row_off);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(wsum_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, h, g, NL, dw_partial, B, R, D, row_off);
     SC_LAUNCH_CHECK();
     return 0;

@@ -41,6 +41,20 @@ class Config(dict):
         self[k] = v
 
 
+def large_parallel_config(**overrides) -> Config:
+    """config/speechCLIP/model_large/flickr/spchclp_p.yaml restricted to the keys the hot path reads
+    (HuBERT-large ll60k, normalised hidden states, 1024-wide head, CLIP ViT-L/14 joint width 768)."""
+    cfg = base_parallel_config()
+    cfg.model_settings.parallel_branch.transformer_args.d_model = 1024
+    cfg.model_settings.parallel_branch.transformer_args.dim_feedforward = 4096
+    cfg.clip = Config({"name": "ViT-L/14", "embed_dim": 768})
+    cfg.audio_encoder.name = "hubert_large_ll60k"
+    cfg.audio_encoder.normalize_hiddenstates = True
+    for k, v in overrides.items():
+        cfg[k] = v
+    return cfg
+
+
 def base_parallel_config(**overrides) -> Config:
     """config/speechCLIP/model_base/spchclp_p.yaml restricted to the keys the hot path reads."""
     cfg = Config({
@@ -74,7 +88,8 @@ def base_parallel_config(**overrides) -> Config:
 
 
 class KWClip_GeneralTransformer(nn.Module):
-    def __init__(self, config, image_encoder: Optional[Callable] = None, device: str = "cuda", hubert_state_dict=None):
+    def __init__(self, config, image_encoder: Optional[Callable] = None, device: str = "cuda", hubert_state_dict=None,
+                 hubert_arch=None):
         super().__init__()
         self.config = config if isinstance(config, Config) else Config(config)
         config = self.config
@@ -84,7 +99,8 @@ class KWClip_GeneralTransformer(nn.Module):
             raise NotImplementedError(f"audio_encoder.type = {self.audio_encoder_type}: only FairseqHubert is built "
                                       "(every shipped config uses it)")
         enc_args = {k: v for k, v in config.audio_encoder.items() if k not in ("type", "optim", "scheduler", "device")}
-        self.audio_encoder = FairseqSpeechEncoder_Hubert(device=device, state_dict=hubert_state_dict, **enc_args)
+        self.audio_encoder = FairseqSpeechEncoder_Hubert(device=device, state_dict=hubert_state_dict, arch=hubert_arch,
+                                                         **enc_args)
         self.audio_embd_dim = self.audio_encoder.out_dim
         self.image_encoder = image_encoder
         # CLIP joint embedding width (512 ViT-B/32, 768 ViT-L/14): width of image_feat and of the branch projection

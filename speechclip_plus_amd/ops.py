@@ -174,18 +174,20 @@ def posconv_prep(x: torch.Tensor, valid_len: torch.Tensor, xz: torch.Tensor, xg:
     check(lib().sc_posconv_prep(_p(x), _p(valid_len), _p(xz), _p(xg), B, R, D, G, halo, _stream()), "sc_posconv_prep")
 
 
-def wsum_fwd(h: torch.Tensor, w_softmax: torch.Tensor, out: torch.Tensor, B: int, R: int, D: int, row_off: int) -> None:
+def wsum_fwd(h: torch.Tensor, w_softmax: torch.Tensor, out: torch.Tensor, B: int, R: int, D: int, row_off: int,
+             normalize: bool = False) -> None:
     NL = h.shape[0]
     assert h.dtype == torch.bfloat16 and w_softmax.dtype == torch.float32 and out.dtype == torch.bfloat16
-    check(lib().sc_wsum_fwd(_p(h), _p(w_softmax), NL, _p(out), B, R, D, row_off, _stream()), "sc_wsum_fwd")
+    check(lib().sc_wsum_fwd(_p(h), _p(w_softmax), NL, _p(out), B, R, D, row_off, int(normalize), _stream()), "sc_wsum_fwd")
 
 
-def wsum_bwd(h: torch.Tensor, g: torch.Tensor, B: int, R: int, D: int, row_off: int, nblk: int = 1024) -> torch.Tensor:
+def wsum_bwd(h: torch.Tensor, g: torch.Tensor, B: int, R: int, D: int, row_off: int, nblk: int = 1024,
+             normalize: bool = False) -> torch.Tensor:
     """returns d(softmaxed weights)[NL] = <g, h_n>."""
     NL = h.shape[0]
     assert g.dtype == torch.float32
     part = torch.empty(nblk, NL, device=h.device, dtype=torch.float32)
-    check(lib().sc_wsum_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, _stream()), "sc_wsum_bwd")
+    check(lib().sc_wsum_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, int(normalize), _stream()), "sc_wsum_bwd")
     return part.sum(0)
 
 

@@ -189,8 +189,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self.unfreeze_layers = unfreeze_layers
         self.normalize_hiddenstates = normalize_hiddenstates
         assert normalize_type in ["s3prl", "method1", "method2"], normalize_type
-        if normalize_hiddenstates:
-            raise NotImplementedError("normalize_hiddenstates=True is not used by any shipped config")
+        if normalize_hiddenstates and normalize_type != "s3prl":
+            raise NotImplementedError("normalize_type method1 / method2 is not used by any shipped config")
         self.normalize_type = normalize_type
         self.downsample_rate = self.MODEL_DOWNSAMPLE_RATE[name]
         self.out_dim = self.arch.embed_dim
@@ -203,8 +203,9 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self._load_weights(state_dict)
         self._plans: Dict[Tuple[int, int], _Plan] = {}
         if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
-            self.weightedsum_layer = WeightedSumLayer(n_weights=self.upstream_model_hiddenstates_len,
-                                                      normalize_features=False).to(self._dev)
+            self.weightedsum_layer = WeightedSumLayer(
+                n_weights=self.upstream_model_hiddenstates_len,
+                normalize_features=self.normalize_hiddenstates and self.normalize_type == "s3prl").to(self._dev)
 
     # ------------------------------------------------------------------------------------------ weights
     def _load_weights(self, sd: Dict[str, torch.Tensor]) -> None:

@@ -54,7 +54,7 @@ class _ClsAttnPoolFn(torch.autograd.Function):
         d_ws, d_feat = None, None
         hd = ctx.handle
         if hd is not None and ctx.needs_input_grad[2]:
-            d_soft = ops.wsum_bwd(hd.hidden, dX, B, R, D, 1)
+            d_soft = ops.wsum_bwd(hd.hidden, dX, B, R, D, 1, normalize=hd.normalize)
             d_ws = hd.w_soft * (d_soft - (hd.w_soft * d_soft).sum())
         if ctx.feat_meta is not None and ctx.needs_input_grad[3]:
             shape, dtype = ctx.feat_meta

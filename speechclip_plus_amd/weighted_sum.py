@@ -19,8 +19,9 @@ from . import ops
 class PaddedFeatHandle:
     """Side-channel from the encoder to the branch head (same process, same step)."""
 
-    def __init__(self, src, hidden, ws_layer, w_soft, B, R, T, D):
+    def __init__(self, src, hidden, ws_layer, w_soft, B, R, T, D, normalize=False):
         self.src, self.hidden, self.ws_layer, self.w_soft = src, hidden, ws_layer, w_soft
+        self.normalize = normalize
         self.B, self.R, self.T, self.D = B, R, T, D
 
 
@@ -28,21 +29,21 @@ class _WeightedSumFn(torch.autograd.Function):
     """Generic autograd path: out[M, D] = sum_n softmax(w)_n h[n]; grads to w only (h is a constant)."""
 
     @staticmethod
-    def forward(ctx, weights, h, B, R, D):
+    def forward(ctx, weights, h, B, R, D, normalize):
         w_soft = torch.softmax(weights.float(), dim=0).contiguous()
         out = torch.zeros(B, R, D, device=h.device, dtype=torch.bfloat16)
-        ops.wsum_fwd(h, w_soft, out, B, R, D, 0)
+        ops.wsum_fwd(h, w_soft, out, B, R, D, 0, normalize)
         ctx.save_for_backward(h, w_soft)
-        ctx.dims = (B, R, D)
+        ctx.dims = (B, R, D, normalize)
         return out
 
     @staticmethod
     def backward(ctx, g):
         h, w_soft = ctx.saved_tensors
-        B, R, D = ctx.dims
-        d_soft = ops.wsum_bwd(h, g.float().contiguous(), B, R, D, 0)
+        B, R, D, normalize = ctx.dims
+        d_soft = ops.wsum_bwd(h, g.float().contiguous(), B, R, D, 0, normalize=normalize)
         dw = w_soft * (d_soft - (w_soft * d_soft).sum())
-        return dw, None, None, None, None
+        return dw, None, None, None, None, None
 
 
 class WeightedSumLayer(nn.Module):
@@ -50,22 +51,20 @@ class WeightedSumLayer(nn.Module):
         super().__init__()
         self.n_weights = n_weights
         self.weights = nn.Parameter(torch.zeros((n_weights,), dtype=torch.float))
-        self.normalize_features = normalize_features
-        if normalize_features:
-            raise NotImplementedError("normalize_features=True (per-layer layer_norm) is not used by any shipped config")
+        self.normalize_features = normalize_features      # per-layer non-affine layer_norm (HuBERT-large recipes)
 
     def forward(self, x: List[torch.Tensor]) -> torch.Tensor:
         assert len(x) == self.n_weights, len(x)
         shape = x[0].shape
         D = shape[-1]
         h = torch.stack([t.reshape(-1, D).to(torch.bfloat16) for t in x], dim=0).contiguous()
-        out = _WeightedSumFn.apply(self.weights, h, 1, h.shape[1], D)
+        out = _WeightedSumFn.apply(self.weights, h, 1, h.shape[1], D, self.normalize_features)
         return out.view(*shape)
 
     def forward_padded(self, hidden: torch.Tensor, B: int, R: int, T: int, D: int) -> torch.Tensor:
         w_soft = torch.softmax(self.weights.detach().float(), dim=0).contiguous()
         src = torch.zeros(B, R, D, device=hidden.device, dtype=torch.bfloat16)
-        ops.wsum_fwd(hidden, w_soft, src, B, R, D, 1)
+        ops.wsum_fwd(hidden, w_soft, src, B, R, D, 1, self.normalize_features)
         feat = src[:, 1: T + 1]
-        feat._sc_handle = PaddedFeatHandle(src, hidden, self, w_soft, B, R, T, D)
+        feat._sc_handle = PaddedFeatHandle(src, hidden, self, w_soft, B, R, T, D, self.normalize_features)
         return feat

@@ -218,6 +218,33 @@ def test_weighted_sum_golden(dev, golden):
     np.testing.assert_allclose(layer.weights.grad.cpu().numpy(), fx["dweights"], rtol=0.05, atol=0.02)
 
 
+def test_weighted_sum_normalized(dev, golden):
+    """normalize_features=True (HuBERT-large recipes): forward against the reference leaf (wsum.npz out_norm), weight
+    gradient against fp32 torch autograd on the same bf16-rounded inputs; also at D = 1024."""
+    from speechclip_plus_amd.weighted_sum import WeightedSumLayer
+    fx = golden("wsum.npz")
+    layer = WeightedSumLayer(13, normalize_features=True).to(dev)
+    with torch.no_grad():
+        layer.weights.copy_(torch.from_numpy(fx["weights"]))
+    hs = [torch.from_numpy(h).to(dev) for h in fx["hs"]]
+    out = layer(hs)
+    assert rel_l2(out, torch.from_numpy(fx["out_norm"]).to(dev)) < 1e-2
+    g = torch.Generator(device="cpu").manual_seed(4)
+    NL, M, D = 25, 200, 1024
+    h = bf(torch.randn(NL, M, D, generator=g) * 2 + 0.3).to(dev)
+    layer2 = WeightedSumLayer(NL, normalize_features=True).to(dev)
+    with torch.no_grad():
+        layer2.weights.copy_(torch.randn(NL, generator=g))
+    out2 = layer2([h[n].view(2, 100, D) for n in range(NL)])
+    gout = torch.randn(2, 100, D, generator=g).to(dev)
+    (out2.float() * gout).sum().backward()
+    w_ref = layer2.weights.detach().clone().requires_grad_(True)
+    ref = (torch.softmax(w_ref, 0).view(-1, 1, 1) * F.layer_norm(h.float(), (D,))).sum(0).view(2, 100, D)
+    (ref * gout).sum().backward()
+    assert rel_l2(out2, ref) < 6e-3
+    assert rel_l2(layer2.weights.grad, w_ref.grad) < 2e-3
+
+
 def test_frontend_conv0(dev):
     ops = _ops()
     B, L, C = 3, 4000, 512

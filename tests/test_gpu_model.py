@@ -86,11 +86,52 @@ def test_encoder_large_arch():
         assert e < 2e-2, (n, e)
 
 
-def _oracle_step(oracle, sd, o_arch, head_W, ws_w, wavs, img, ids):
+def test_large_parallel_train_step():
+    """Parallel-large recipe (HuBERT-large at reduced depth, normalised hidden states, 1024-wide head, E = 768):
+    loss and gradients of one step against the oracle."""
+    import dataclasses
+    import oracle
+    from speechclip_plus_amd import KWClip_GeneralTransformer, large_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    arch = dataclasses.replace(ARCHS["hubert_large_ll60k"], layers=2)
+    sd = random_hubert_state_dict(arch, seed=5)
+    torch.manual_seed(5)
+    cfg = large_parallel_config()
+    cfg.audio_encoder.max_audio_len = -1
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).eval()
+    with torch.no_grad():
+        model.audio_encoder.weightedsum_layer.weights.copy_(torch.tensor([0.3, -0.2, 0.5]))
+    head_W = {k: v.detach().cpu().float() for k, v in model.parallel_branch.state_dict().items()}
+    o_arch = oracle.HubertArch.large()
+    o_arch.layers = 2
+    g = torch.Generator().manual_seed(8)
+    lens = [9000, 6000, 9000, 4100]
+    wavs = [torch.randn(l, generator=g) * 0.5 for l in lens]
+    img = torch.randn(4, 768, generator=g)
+    ids = torch.tensor([0, 1, 1, 2])
+    wav = torch.zeros(4, max(lens))
+    for b, x in enumerate(wavs):
+        wav[b, : len(x)] = x
+    batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": img.cuda(), "id": ids.cuda()}
+    losses_, _, others = model(batch)
+    out = model.compute_loss(losses_)
+    out["loss"].backward()
+    ws_w = model.audio_encoder.weightedsum_layer.weights.detach().cpu()
+    loss_o, a_o, W_o, w_o = _oracle_step(oracle, sd, o_arch, head_W, ws_w, wavs, img, ids, normalize=True)
+    cos = F.cosine_similarity(others["parallel_audio_feat"].detach().float().cpu(), a_o, dim=-1)
+    assert float(cos.min()) > 0.999, cos
+    assert abs(out["loss"].item() - loss_o.item()) < 5e-3, (out["loss"].item(), loss_o.item())
+    errs = {n: rel_l2(p.grad, W_o[n].grad) for n, p in model.parallel_branch.named_parameters()
+            if W_o[n].grad is not None and float(W_o[n].grad.norm()) > 1e-7}
+    errs["weightedsum"] = rel_l2(model.audio_encoder.weightedsum_layer.weights.grad, w_o.grad)
+    assert not {k: v for k, v in errs.items() if v > 6e-2}, errs
+
+
+def _oracle_step(oracle, sd, o_arch, head_W, ws_w, wavs, img, ids, normalize=False):
     hs_o, fl = oracle.speech_encoder_forward(sd, o_arch, wavs)
     W = {k: v.clone().requires_grad_(True) for k, v in head_W.items()}
     w = ws_w.clone().requires_grad_(True)
-    feat = oracle.weighted_sum(w, [h.detach() for h in hs_o])
+    feat = oracle.weighted_sum(w, [h.detach() for h in hs_o], normalize)
     e = oracle.parallel_branch_forward(W, feat, fl, nhead=8)
     a = e / e.norm(dim=-1, keepdim=True)
     i = img / img.norm(dim=-1, keepdim=True)
