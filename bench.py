@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=2, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--model", choices=["base", "large"], default="base",
+                    help="base = BASELINE configs[1] (headline); large = Parallel large (HuBERT-large + ViT-L/14 width)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -60,14 +62,17 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     dev = torch.device("cuda", local_rank)
 
-    from speechclip_plus_amd import (HubertArch, KWClip_GeneralTransformer, base_parallel_config, ops,
+    from speechclip_plus_amd import (KWClip_GeneralTransformer, base_parallel_config, large_parallel_config, ops,
                                      random_hubert_state_dict)
+    from speechclip_plus_amd.speech_encoder import ARCHS
     from speechclip_plus_amd.train import ContrastiveTrainer
 
     B, L = args.batch, int(round(args.seconds * 16000))
     torch.manual_seed(7122)
-    sd = random_hubert_state_dict(HubertArch(), seed=7122)
-    cfg = base_parallel_config()
+    large = args.model == "large"
+    sd = random_hubert_state_dict(ARCHS["hubert_large_ll60k" if large else "hubert"], seed=7122)
+    cfg = large_parallel_config() if large else base_parallel_config()
+    E = int(cfg.clip.embed_dim)
     cfg.audio_encoder.max_audio_len = -1          # 10 s utterances, no 6.4 s training crop (BASELINE configs[1])
     model = KWClip_GeneralTransformer(cfg, device=str(dev), hubert_state_dict=sd)
     model.train()
@@ -76,7 +81,7 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(7122 + rank)
     wav = torch.randn(B, L, generator=g).to(dev)
     wav_len = torch.full((B,), L, dtype=torch.long)
-    img = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=-1).to(dev)
+    img = torch.nn.functional.normalize(torch.randn(B, E, generator=g), dim=-1).to(dev)
     ids = (torch.arange(B) + rank * B) // 5            # Flickr8k shape: 5 captions per image id
     batch = {"wav": wav, "wav_len": wav_len, "image": img, "id": ids.to(dev)}
 
@@ -137,14 +142,14 @@ def main():
                 extra[k] = {"ms_per_step": round(v["ms"] / args.steps, 3),
                             "alg_tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None}
         cpu = None
-        if world == 1 and args.cpu_utts > 0:
+        if world == 1 and args.cpu_utts > 0 and not large:
             cpu = cpu_baseline(sd, model, args.cpu_utts, L, args.cpu_iters)
         result = {
             "metric": "utterances/sec (train step)", "value": round(B * world * args.steps / elapsed, 2),
             "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Parallel SpeechCLIP base train step (HuBERT-base frozen fwd + weighted sum + CLS "
+            "config": {"workload": f"Parallel SpeechCLIP {args.model} train step (HuBERT-{args.model} frozen fwd + weighted sum + CLS "
                                    f"attention-pool head fwd/bwd + InfoNCE fwd/bwd + Adam), {B} utt/GPU x {args.seconds:g} s "
                                    f"(L={L}, T={T}), CLIP image embeddings given",
                        "global_batch": B * world, "per_gpu_batch": B, "audio_samples": L, "frames": T,
