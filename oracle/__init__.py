@@ -29,3 +29,4 @@ from .head_ref import (weighted_sum, parallel_branch_forward, init_parallel_bran
                        transformer_encoder_forward, mha_and_norm_forward)
 from .loss_ref import masked_contrastive_loss
 from .retrieval_ref import mutual_retrieval
+from .cascaded_ref import cascaded_plus_forward, hybrid_plus_forward, cif_forward, vq_forward, clip_encode_keywords

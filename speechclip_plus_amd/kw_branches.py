@@ -12,9 +12,20 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
+from torch.nn import functional as F
+
 from . import transformer_models as TransformerModels
+from . import vector_quantizers
+from .cif import CIF
+from .projections import MLPLayers
+from .vector_quantizers import Kw_BatchNorm_dynamic
 
 logger = logging.getLogger(__name__)
+
+
+def get_keypadding_mask(max_length: int, data_lens: torch.Tensor) -> torch.Tensor:
+    """avssl/util/data_utils.py:6-22 (True = padding), built on the device of the lengths."""
+    return torch.arange(max_length, device=data_lens.device).unsqueeze(0) >= data_lens.unsqueeze(1)
 
 
 def _get(cfg, key, default=None):
@@ -42,6 +53,45 @@ class GeneralBranch(nn.Module):
     def _create_cls(self, length: int, cls_dim: int) -> nn.Parameter:
         return torch.nn.Parameter(torch.randn([1, length, cls_dim]))
 
+    def _create_kw_proj_layer(self):
+        """kw_branches.py:44-73: Linear d_model -> text_dim, or an MLP when ``keyword.kw_projection`` is given."""
+        cb = _get(_get(self.config, "model_settings"), "cascaded_branch")
+        d_model = _get(_get(cb, "transformer_args"), "d_model")
+        self.kw_projection_config = _get(_get(cb, "keyword"), "kw_projection", None)
+        if self.kw_projection_config is None:
+            self.linear_proj = nn.Linear(d_model, self.text_dim)
+        else:
+            dims = list(_get(self.kw_projection_config, "dimensions"))
+            assert dims[0] == d_model, f"first dim({dims[0]}) should match the audio encoder dim({d_model})"
+            assert dims[-1] == self.text_dim, f"last dim({dims[-1]}) should match the text encoder dim({self.text_dim})"
+            self.linear_proj = MLPLayers(units=dims, dropout=_get(self.kw_projection_config, "dropout"))
+
+    def _create_vector_quantizer(self):
+        vq = _get(_get(_get(self.config, "model_settings"), "cascaded_branch"), "vq")
+        self.vq_type = _get(vq, "type")
+        if not hasattr(vector_quantizers, self.vq_type):
+            raise NotImplementedError("Vq ({}) not implemented".format(self.vq_type))
+        self.vector_quantizer = getattr(vector_quantizers, self.vq_type)(**dict(_get(vq, "args")))
+
+    def project_feats_to_CLIPspace(self, features: torch.Tensor) -> torch.Tensor:
+        features = self.linear_proj(features)
+        if hasattr(self, "bn_layer"):
+            features = self.bn_layer(features)
+        return features
+
+    def get_keyword_cosine_score(self, keywords: torch.Tensor) -> torch.Tensor:
+        """kw_branches.py:158-179: cosine of every keyword against every (reduced-vocabulary) token embedding."""
+        emb = self.clip.model.token_embedding.weight                       # (V, Et), frozen
+        return F.normalize(keywords, dim=-1, eps=1e-8) @ F.normalize(emb, dim=-1, eps=1e-8).t()
+
+    def vq_audio_features(self, audio_feat: torch.Tensor):
+        audio_feat = self.project_feats_to_CLIPspace(audio_feat)
+        cos_score = self.get_keyword_cosine_score(audio_feat)
+        vq_results = self.vector_quantizer(x=cos_score)
+        assert self.clip.model.token_embedding.weight.requires_grad == False
+        keywords = vq_results["subword_prob"] @ self.clip.model.token_embedding.weight
+        return vq_results, keywords
+
 
 class KW_ParallelBranch(GeneralBranch):
     def __init__(self, config, audio_dim: int, text_dim: int) -> None:
@@ -54,7 +104,12 @@ class KW_ParallelBranch(GeneralBranch):
             self.linear_proj = nn.Linear(self.audio_dim, self.text_dim)
 
     def extract_hidden_states(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> Tuple:
-        raise NotImplementedError("parallel-branch hidden states need the full-sequence layer (scope row f3)")
+        """kw_branches.py:223-249: hidden states of the branch layer over [CLS ; frames], CLS position dropped
+        (full-sequence path: stock torch ops)."""
+        bsz, T = audio_feat.shape[:2]
+        src = torch.cat([self.cls.expand(bsz, -1, -1).to(audio_feat.dtype), audio_feat], dim=1)
+        pad = get_keypadding_mask(T + 1, audio_len.to(audio_feat.device) + 1)
+        return tuple(x[:, 1:, ...] for x in self.self_att.extract_hidden_states(src=src, key_padding_mask=pad))
 
     def forward(self, audio_feat: torch.Tensor, audio_len: Optional[torch.Tensor] = None, otherInputs: dict = None,
                 audio_feat_len: Optional[torch.Tensor] = None) -> dict:
@@ -67,3 +122,97 @@ class KW_ParallelBranch(GeneralBranch):
             out = self.linear_proj(out)
         output["parallel_audio_feat"] = out
         return output
+
+
+class KW_CascadedBranchPlus(GeneralBranch):
+    """kw_branches.py:580-777: self-attention over the frames -> CIF downsampling -> keyword projection + BatchNorm ->
+    cosine VQ against the CLIP token table -> frozen CLIP text encoder.  Scope row a11 (stock torch ops)."""
+
+    def __init__(self, config, audio_dim: int, text_dim: int, clip) -> None:
+        super().__init__(config, audio_dim, text_dim)
+        self.clip = clip
+        cb = _get(_get(config, "model_settings"), "cascaded_branch")
+        self._create_self_attn_layer(cb)
+        self._create_kw_proj_layer()
+        self._create_vector_quantizer()
+        bn = _get(_get(cb, "keyword"), "batchnorms", None)
+        if bn is not None:
+            emb = self.clip.model.token_embedding.weight
+            self.bn_layer = Kw_BatchNorm_dynamic(kw_dim=self.text_dim, init_bias=torch.mean(emb, dim=0),
+                                                 init_scale=torch.std(emb, dim=0), std_scale=_get(bn, "std_scale"),
+                                                 learnable=_get(bn, "learnable", True))
+        ds = _get(cb, "downsampling")
+        self.downsampling_type = _get(ds, "type")
+        if self.downsampling_type != "cif":
+            raise NotImplementedError("Unknown type:{}".format(self.downsampling_type))
+        cif_cfg = dict(_get(ds, "cif"))
+        self.using_gt_len = cif_cfg.get("using_gt_len", False)
+        self.downsampling = CIF(**cif_cfg)
+
+    def downsampling_audio_feat(self, audio_feat, audio_feat_len, audio_feat_pad_mask, global_step: int = 0,
+                                target_len: Optional[torch.Tensor] = None) -> dict:
+        """kw_branches.py:644-699: the CIF target length is used only in training (round(len / 20) if not given)."""
+        inputs = {"audio_feat": audio_feat, "audio_feat_len": audio_feat_len, "audio_feat_pad_mask": audio_feat_pad_mask,
+                  "global_step": global_step}
+        if not self.training:
+            input_target_len = None
+        elif target_len is None:
+            input_target_len = (audio_feat_len / 20).round().long()
+        else:
+            input_target_len = target_len
+        res = self.downsampling(inputs, input_target_len)
+        if target_len is not None:
+            res["target_len"] = target_len
+            res["dsample_len_diff"] = (res["dsample_feats_length"] - target_len).abs().float().mean()
+        return res
+
+    def _tail(self, output, feats, feat_len, pad_mask, otherInputs):
+        otherInputs = otherInputs or {}
+        ds = self.downsampling_audio_feat(audio_feat=feats, audio_feat_len=feat_len, audio_feat_pad_mask=pad_mask,
+                                          target_len=otherInputs.get("target_len", None),
+                                          global_step=otherInputs.get("global_step", 0))
+        output["dsample_results"] = ds
+        vq_results, keywords = self.vq_audio_features(ds["dsample_feats"])
+        output["vq_results"] = vq_results
+        output["keywords"] = keywords
+        output["cascaded_audio_feat"] = self.clip.encode_keywords(keywords, ds["dsample_feats_length"])
+        return output
+
+    def forward(self, audio_feat: torch.Tensor, audio_feat_len: torch.Tensor, otherInputs: dict = {}) -> dict:
+        output = defaultdict(lambda: None)
+        pad = get_keypadding_mask(audio_feat.shape[1], audio_feat_len.to(audio_feat.device))
+        feats = self.self_att(src=audio_feat, key_padding_mask=pad)
+        return self._tail(output, feats, audio_feat_len.to(audio_feat.device), pad, otherInputs)
+
+    def extract_hidden_states(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> Tuple:
+        pad = get_keypadding_mask(audio_feat.shape[1], audio_len.to(audio_feat.device))
+        return tuple(self.self_att.extract_hidden_states(src=audio_feat, key_padding_mask=pad))
+
+
+class KW_HybridBranchPlus(KW_CascadedBranchPlus):
+    """kw_branches.py:780-891: one shared self-attention block over [CLS ; frames]; the CLS row is the parallel
+    embedding, the frame rows feed the cascaded tail."""
+
+    def __init__(self, config, audio_dim: int, text_dim: int, out_dim: int, clip) -> None:
+        super().__init__(config, audio_dim, text_dim, clip)
+        self.out_dim = out_dim
+        cb = _get(_get(config, "model_settings"), "cascaded_branch")
+        self.cls = self._create_cls(length=1, cls_dim=_get(_get(cb, "transformer_args"), "d_model"))
+        self._create_self_attn_layer(cb)
+        self.parallel_proj = nn.Linear(self.audio_dim, self.out_dim)
+
+    def forward(self, audio_feat: torch.Tensor, audio_feat_len: torch.Tensor, otherInputs: dict = {}) -> dict:
+        output = defaultdict(lambda: None)
+        bsz, T = audio_feat.shape[:2]
+        lens = audio_feat_len.to(audio_feat.device)
+        pad = get_keypadding_mask(T + 1, lens + 1)
+        src = torch.cat([self.cls.expand(bsz, -1, -1).to(audio_feat.dtype), audio_feat], dim=1)
+        post = self.self_att(src=src, key_padding_mask=pad)
+        output["parallel_audio_feat"] = self.parallel_proj(post[:, :1].reshape(-1, self.audio_dim))
+        return self._tail(output, post[:, 1:].reshape(-1, T, self.audio_dim), lens, pad[:, 1:], otherInputs)
+
+    def extract_hidden_states(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> Tuple:
+        bsz, T = audio_feat.shape[:2]
+        pad = get_keypadding_mask(T + 1, audio_len.to(audio_feat.device) + 1)
+        src = torch.cat([self.cls.expand(bsz, -1, -1).to(audio_feat.dtype), audio_feat], dim=1)
+        return tuple(x[:, 1:, ...] for x in self.self_att.extract_hidden_states(src=src, key_padding_mask=pad))

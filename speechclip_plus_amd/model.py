@@ -17,7 +17,8 @@ import torch
 from torch import nn
 
 from . import losses
-from .kw_branches import KW_ParallelBranch
+from .clip_text import ClipModel
+from .kw_branches import KW_CascadedBranchPlus, KW_HybridBranchPlus, KW_ParallelBranch
 from .speech_encoder import FairseqSpeechEncoder_Hubert
 
 logger = logging.getLogger(__name__)
@@ -39,6 +40,67 @@ class Config(dict):
 
     def __setattr__(self, k, v):
         self[k] = v
+
+
+def _cif_args(d: int) -> dict:
+    return {"quantity_loss_weight": 0.25, "using_gt_len": False, "cif_output_dim": d, "encoder_embed_dim": d,
+            "produce_weight_type": "conv", "cif_threshold": 1.0, "conv_cif_layer_num": 1, "conv_cif_width": 3,
+            "conv_cif_dropout": 0.1, "apply_scaling": True, "scaling_step": 5000, "apply_tail_handling": True,
+            "tail_handling_firing_threshold": 0.5, "add_cif_ctxt_layers": False}
+
+
+def synthetic_reduced_vocab(n: int = 8112, seed: int = 0) -> torch.Tensor:
+    """Stand-in for avssl/data/flickr_stat/text_clip_vocab_usage_byfreq.npy (8112 sub-words; 19787 for coco), which
+    does not travel to the GPU box: n distinct CLIP token ids that contain <|startoftext|> and <|endoftext|>."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ids = torch.randperm(49406, generator=g)[: n - 2]
+    return torch.cat([ids, torch.tensor([49406, 49407])])
+
+
+def cascaded_plus_base_config(**overrides) -> Config:
+    """config/speechCLIP+/model_base/spchclip_c+.yaml (BASELINE configs[2]) restricted to the keys the path reads."""
+    cfg = base_parallel_config()
+    ms = cfg.model_settings
+    ms.cascaded_objective_weight, ms.parallel_objective_weight = 1.0, 0.0
+    ms.cascaded_branch = Config({
+        "type": "CascadedBranch_dynamic",
+        "vq": {"activation": "gelu", "type": "SimpleVectorQuantizer",
+               "args": {"temp": "fixed=0.1", "time_first": True, "use_gumbel": False, "hard": True}},
+        "downsampling": {"type": "cif", "cif": _cif_args(768)},
+        "keyword": {"detokenized_K_neighbors": 5, "retrieve_method": "cosine",
+                    "batchnorms": {"type": "eachKw", "std_scale": 1.0, "learnable": True, "parallel": True}},
+        "transformer_args": {"type": "MultiheadAttentionAndNorm", "n_layers": 1, "d_model": 768, "nhead": 1,
+                             "dim_feedforward": 3072, "dropout": 0.1, "activation": "gelu", "layer_norm_eps": 1.0e-5,
+                             "batch_first": True, "norm_first": False}})
+    cfg.cl_loss.args.temperature_trainable = True
+    cfg.retrieval.audio_feat_src = "cascaded"
+    cfg.clip = Config({"name": "ViT-B/32", "embed_dim": 512, "reduce_subword_embbedding": synthetic_reduced_vocab(8112)})
+    for k, v in overrides.items():
+        cfg[k] = v
+    return cfg
+
+
+def hybrid_plus_large_config(**overrides) -> Config:
+    """config/speechCLIP+/model_large/coco/spchclip_h+.yaml (BASELINE configs[4]) restricted to the keys the path reads."""
+    cfg = large_parallel_config()
+    ms = cfg.model_settings
+    ms.cascaded_objective_weight, ms.parallel_objective_weight = 1.0, 1.0
+    ms.cascaded_branch = Config({
+        "type": "HybridBranch_dynamic",
+        "vq": {"activation": "gelu", "type": "SimpleVectorQuantizer",
+               "args": {"temp": "fixed=0.1", "time_first": True, "use_gumbel": False, "hard": True}},
+        "downsampling": {"type": "cif", "cif": _cif_args(1024)},
+        "keyword": {"detokenized_K_neighbors": 5, "retrieve_method": "cosine",
+                    "batchnorms": {"type": "eachKw", "std_scale": 1.0, "learnable": True, "parallel": True},
+                    "kw_projection": {"dropout": 0.1, "dimensions": [1024, 1024, 768]}},
+        "transformer_args": {"type": "MultiheadAttentionAndNorm", "n_layers": 1, "d_model": 1024, "nhead": 8,
+                             "dim_feedforward": 4096, "dropout": 0.1, "activation": "gelu", "layer_norm_eps": 1.0e-5,
+                             "batch_first": True, "norm_first": False}})
+    cfg.cl_loss.args.temperature_trainable = True
+    cfg.clip = Config({"name": "ViT-L/14", "embed_dim": 768, "reduce_subword_embbedding": synthetic_reduced_vocab(19787)})
+    for k, v in overrides.items():
+        cfg[k] = v
+    return cfg
 
 
 def large_parallel_config(**overrides) -> Config:
@@ -111,9 +173,30 @@ class KWClip_GeneralTransformer(nn.Module):
         self.cascaded_branch = None
         self.parallel_branch = None
         ms = config.model_settings
+        self.clip = None
         if ms.cascaded_objective_weight > 0:
-            raise NotImplementedError("cascaded / hybrid(+) branches are scope row f3: not built yet")
-        if ms.parallel_objective_weight > 0:
+            # kwClip.py:684-745.  The CLIP text tower is frozen; without a checkpoint offline it is seeded random
+            # (load real weights with self.clip.load_state_dict).
+            clip_args = {k: v for k, v in config.clip.items() if k not in ("embed_dim", "device")}
+            self.clip = ClipModel(device=device, **clip_args)
+            text_dim = self.clip.model.token_embedding.weight.size(-1)
+            cBranchType = ms.cascaded_branch.type.replace("KW_", "").replace("dynamic", "plus")
+            if cBranchType == "CascadedBranch_plus":
+                self.cascaded_branch = KW_CascadedBranchPlus(config=config, audio_dim=self.audio_embd_dim,
+                                                             text_dim=text_dim, clip=self.clip)
+            elif cBranchType == "HybridBranch_plus":
+                assert ms.parallel_objective_weight > 0, ms.parallel_objective_weight
+                self.cascaded_branch = KW_HybridBranchPlus(config=config, audio_dim=self.audio_embd_dim,
+                                                           text_dim=text_dim, out_dim=self.subword_embd_dim,
+                                                           clip=self.clip)
+            else:
+                raise NotImplementedError(f"{cBranchType}: the non-plus cascaded / hybrid branches are out of scope "
+                                          "(not in BASELINE configs; SURVEY section 2)")
+            ds = ms.cascaded_branch.get("downsampling", None)
+            if ds is not None and ds.type == "cif":
+                self.quantity_loss_weight = ds.cif.get("quantity_loss_weight", 1.0)
+                self.quantity_loss_criteria = nn.L1Loss()
+        if ms.parallel_objective_weight > 0 and self.cascaded_branch is None:
             logger.info("Create Parallel Branch")
             self.parallel_branch = KW_ParallelBranch(config=config, audio_dim=self.audio_embd_dim,
                                                      text_dim=self.subword_embd_dim)
@@ -133,6 +216,8 @@ class KWClip_GeneralTransformer(nn.Module):
         _params = []
         _params += self.audio_encoder.trainable_params()
         _params += list(self.criterion.parameters())
+        if self.cascaded_branch is not None:
+            _params += [p for p in self.cascaded_branch.parameters() if p.requires_grad]
         if self.parallel_branch is not None:
             _params += list(self.parallel_branch.parameters())
         return _params
@@ -162,17 +247,40 @@ class KWClip_GeneralTransformer(nn.Module):
         audio_feat, audio_feat_len = self.forward_audio(wav, wav_len, return_hidden_states=False)
         image_feat = self.forward_image(image)
         image_feat = image_feat / image_feat.norm(dim=-1, keepdim=True)
-        output = self.parallel_branch(audio_feat=audio_feat, audio_feat_len=audio_feat_len)
+        if self.cascaded_branch is not None:                                       # kwClip.py:859-880
+            otherInputs = {"global_step": self.global_step}
+            if getattr(self.cascaded_branch, "using_gt_len", False):
+                assert "text" in batch, f"Text captions are required, {batch.keys()}"
+                target_len = torch.LongTensor([(t.squeeze().tolist().index(49407) - 1) for t in batch["text"]]).to(self._device)
+            else:
+                target_len = (audio_feat_len / 20).round().long()
+            otherInputs["target_len"] = target_len
+            output = self.cascaded_branch(audio_feat=audio_feat, audio_feat_len=audio_feat_len, otherInputs=otherInputs)
+        if self.parallel_branch is not None:
+            output = self.parallel_branch(audio_feat=audio_feat, audio_feat_len=audio_feat_len)
         parallel_audio_feat = output["parallel_audio_feat"]
         cascaded_audio_feat = output["cascaded_audio_feat"]
         vq_results, keywords, dsample_results = output["vq_results"], output["keywords"], output["dsample_results"]
-        keywords_len = None
+        keywords_len = dsample_results["dsample_feats_length"] if dsample_results is not None else None
         id = id.to(self._device)
         losses_ = {"id": id, "image_feat": image_feat}
+        if cascaded_audio_feat is not None:
+            cascaded_audio_feat = cascaded_audio_feat / cascaded_audio_feat.norm(dim=-1, keepdim=True)
+            losses_["cascaded_audio_feat"] = cascaded_audio_feat
         if parallel_audio_feat is not None:
             parallel_audio_feat = parallel_audio_feat / parallel_audio_feat.norm(dim=-1, keepdim=True)
             losses_["parallel_audio_feat"] = parallel_audio_feat
+        if self.cascaded_branch is not None and getattr(self.cascaded_branch, "downsampling_type", None) == "cif":
+            assert "target_len" in dsample_results and "quantity_out" in dsample_results, f"{dsample_results.keys()}"
+            losses_["cif_quantity_out"] = dsample_results["quantity_out"]
+            losses_["cif_target_len"] = dsample_results["target_len"]
         log_metrics = {"cl_temp": self.criterion.current_temperature}
+        if vq_results is not None:
+            log_metrics["softmax_temp"] = vq_results["temp"]
+        if self.cascaded_branch is not None:
+            if dsample_results is not None and "dsample_len_diff" in dsample_results:
+                log_metrics["dsample_len_diff"] = dsample_results["dsample_len_diff"]
+            log_metrics.update({k: vq_results[k] for k in ["temp", "code_perplexity", "prob_perplexity", "ent_per_t"]})
         return (losses_, log_metrics,
                 {"id": id, "image_feat": image_feat, "parallel_audio_feat": parallel_audio_feat,
                  "cascaded_audio_feat": cascaded_audio_feat, "vq_results": vq_results, "keywords": keywords,
@@ -194,6 +302,9 @@ class KWClip_GeneralTransformer(nn.Module):
                 losses_[f"{branchType[0]}_cl_loss"] = self.criterion(feat_A=inputDict[feats_key].float(),
                                                                      feat_B=image_feat, index=id)
                 losses_["loss"] += loss_weight * losses_[f"{branchType[0]}_cl_loss"]
+        if "cif_quantity_out" in inputDict and "cif_target_len" in inputDict and hasattr(self, "quantity_loss_criteria"):
+            losses_["quantity_loss"] = self.quantity_loss_criteria(inputDict["cif_quantity_out"], inputDict["cif_target_len"])
+            losses_["loss"] += self.quantity_loss_weight * losses_["quantity_loss"]
         return losses_
 
     def training_step(self, batch: dict) -> dict:
@@ -212,15 +323,23 @@ class KWClip_GeneralTransformer(nn.Module):
         """kwClip.py:1042-1091 (un-normalised branch output)."""
         wav, wav_len = self.processWavs(wav)
         audio_feat, audio_feat_len = self.forward_audio(wav, wav_len)
-        output = self.parallel_branch(audio_feat=audio_feat, audio_feat_len=audio_feat_len)
+        if self.cascaded_branch is not None:
+            output = self.cascaded_branch(audio_feat=audio_feat, audio_feat_len=audio_feat_len)
+        if self.parallel_branch is not None:
+            output = self.parallel_branch(audio_feat=audio_feat, audio_feat_len=audio_feat_len)
         return {"cascaded_audio_feat": output["cascaded_audio_feat"], "parallel_audio_feat": output["parallel_audio_feat"],
                 "vq_results": output["vq_results"], "keywords": output["keywords"]}
 
     def feature_extractor_s3prl(self, wav) -> Tuple[torch.Tensor, Tuple]:
-        """kwClip.py:965-997.  The parallel branch's own hidden states need the full-sequence head layer
-        (scope row f3); the 13 HuBERT states are returned (cloned: they live in a reused workspace)."""
+        """kwClip.py:965-997: the HuBERT states (cloned: they live in a reused workspace) followed by the branch
+        layer's hidden states (full-sequence head path, stock torch ops)."""
         wav, wav_len = self.processWavs(wav)
         audio_feat, audio_len, hidden_states = self.forward_audio(wav, wav_len, return_hidden_states=True)
         assert isinstance(hidden_states, tuple)
         hidden_states = tuple(h.clone() for h in hidden_states)
+        with torch.no_grad():
+            if self.cascaded_branch is not None:
+                hidden_states = hidden_states + tuple(self.cascaded_branch.extract_hidden_states(audio_feat, audio_len)[1:])
+            if self.parallel_branch is not None:
+                hidden_states = hidden_states + tuple(self.parallel_branch.extract_hidden_states(audio_feat, audio_len)[1:])
         return hidden_states[-1], hidden_states

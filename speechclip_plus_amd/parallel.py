@@ -36,17 +36,23 @@ class _AllGatherRows(torch.autograd.Function):
         return g[ctx.rank * ctx.n: (ctx.rank + 1) * ctx.n], None
 
 
-def gather_loss_feats(audio_feat: torch.Tensor, image_feat: torch.Tensor, ids: torch.Tensor,
-                      group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Pack, all-gather once, unpack -> (audio_all, image_all, ids_all) with autograd through audio/image."""
+def gather_loss_feats(audio_feat, image_feat: torch.Tensor, ids: torch.Tensor,
+                      group: Optional[dist.ProcessGroup] = None):
+    """Pack, all-gather once, unpack -> (audio_all, image_all, ids_all) with autograd through audio/image.
+    ``audio_feat`` may be one (B, E) tensor or a list of them (parallel + cascaded embeddings of the hybrid recipes):
+    all of them travel in the same packed row, still ONE collective."""
+    single = isinstance(audio_feat, torch.Tensor)
+    feats = [audio_feat] if single else list(audio_feat)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return audio_feat, image_feat, ids
-    B, E = audio_feat.shape
+    B, E = image_feat.shape
     id_bits = ids.to(torch.int64).contiguous().view(torch.float32).view(B, 2)
-    packed = torch.cat([audio_feat.float(), image_feat.float(), id_bits], dim=1)       # (B, 2E + 2) fp32
+    packed = torch.cat([f.float() for f in feats] + [image_feat.float(), id_bits], dim=1)   # (B, (n+1)E + 2) fp32
     allp = _AllGatherRows.apply(packed, group)
-    ids_all = allp[:, 2 * E:].detach().contiguous().view(torch.int64).view(-1)
-    return allp[:, :E], allp[:, E: 2 * E], ids_all
+    n = len(feats)
+    ids_all = allp[:, (n + 1) * E:].detach().contiguous().view(torch.int64).view(-1)
+    outs = [allp[:, i * E: (i + 1) * E] for i in range(n)]
+    return (outs[0] if single else outs), allp[:, n * E: (n + 1) * E], ids_all
 
 
 class GradAllReduce:

@@ -33,10 +33,19 @@ class ContrastiveTrainer:
         model = self.model
         self.opt.zero_grad()
         loss_feats = model.training_step(batch)["loss_feats"]
-        a, i, ids = gather_loss_feats(loss_feats["parallel_audio_feat"], loss_feats["image_feat"], loss_feats["id"],
-                                      self.group)
-        loss = model.training_step_end({"loss_feats": {"parallel_audio_feat": a, "image_feat": i, "id": ids},
-                                        "log_metrics": {}})["loss"]
+        keys = [k for k in ("parallel_audio_feat", "cascaded_audio_feat") if k in loss_feats]
+        feats, i, ids = gather_loss_feats([loss_feats[k] for k in keys], loss_feats["image_feat"], loss_feats["id"], self.group)
+        gathered = {"image_feat": i, "id": ids, **dict(zip(keys, feats))}
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        if "cif_quantity_out" in loss_feats:
+            # the L1 quantity loss is a per-sample mean: each rank contributes its local mean / world so that the
+            # SUM all-reduce of the gradients yields the global-batch mean (kwClip.py:1030-1038 runs on the gathered batch)
+            gathered["cif_quantity_out"] = loss_feats["cif_quantity_out"]
+            gathered["cif_target_len"] = loss_feats["cif_target_len"]
+        losses = model.compute_loss(gathered)
+        loss = losses["loss"]
+        if world > 1 and "quantity_loss" in losses:
+            loss = loss - model.quantity_loss_weight * losses["quantity_loss"] * (1.0 - 1.0 / world)
         loss.backward()
         self.allreduce.launch()
         self.allreduce.wait()

@@ -33,6 +33,7 @@ class _ClsAttnPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cls, a, ws_weights, feat, handle, src, lens, B, R, D, H):
+        src = src.detach()                                          # shares storage with the encoder's buffer
         src[:, 0] = cls.detach().reshape(1, D).to(torch.bfloat16)
         a_c = a.detach().float().contiguous()
         scores = ops.cls_scores(src, a_c, False, B, R, D, H)
@@ -78,12 +79,18 @@ class TransformerEncoder(nn.Module):
         self.norm_first, self.layer_norm_eps, self.dropout = norm_first, layer_norm_eps, dropout
 
     def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
-        raise NotImplementedError(
-            "full-sequence TransformerEncoder.forward (head_dim 96/128 attention) is not built yet; the parallel branch "
-            "uses cls_forward().  Needed by the cascaded+/hybrid+ branches (scope row f3).")
+        """Full-sequence path (every row is needed by the cascaded+/hybrid+ branches that feed CIF; scope row a11:
+        stock device-side torch ops until the head_dim 96/128 attention kernel of row f3 exists)."""
+        return self.model(src=src.float(), src_key_padding_mask=key_padding_mask)
 
     def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
-        raise NotImplementedError("extract_hidden_states needs the full-sequence layer (scope row f3)")
+        """TransformerModels.py:16-45,85-97: inputs of every layer + output of the last, before the final norm."""
+        output, hidden = src.float(), []
+        for mod in self.model.layers:
+            hidden.append(output)
+            output = mod(output, src_key_padding_mask=key_padding_mask)
+        hidden.append(output)
+        return tuple(hidden)
 
     # ------------------------------------------------------------------------------------------------
     def cls_forward(self, cls: torch.Tensor, feat: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
@@ -100,7 +107,7 @@ class TransformerEncoder(nn.Module):
         dh = D // H
         handle = getattr(feat, "_sc_handle", None)
         if handle is not None:
-            src, B, R = handle.src, handle.B, handle.R
+            src, B, R = handle.src.detach(), handle.B, handle.R
             ws_w = handle.ws_layer.weights
             feat_in = None
         else:
@@ -132,4 +139,10 @@ class MultiheadAttentionAndNorm(nn.Module):
         self.attentionBlock_Norm = nn.LayerNorm(d_model, eps=layer_norm_eps)
 
     def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
-        raise NotImplementedError("MultiheadAttentionAndNorm (cascaded+/hybrid+ branches) is scope row f3: not built yet")
+        """LN(MHA(x, x, x) + x) (TransformerModels.py:120-126); scope row a11: stock device-side torch ops."""
+        src = src.float()
+        return self.attentionBlock_Norm(
+            self.multihead_attn_layer(src, src, src, key_padding_mask=key_padding_mask)[0] + src)
+
+    def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
+        return tuple([src, self.forward(src, key_padding_mask)])

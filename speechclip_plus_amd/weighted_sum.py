@@ -46,6 +46,28 @@ class _WeightedSumFn(torch.autograd.Function):
         return dw, None, None, None, None, None
 
 
+class _WeightedSumSrcFn(torch.autograd.Function):
+    """Encoder fast path with autograd: the sum lands at row offset 1 of a fresh [B, R, D] buffer.  The parallel
+    branch never differentiates through this node (it gets d(weights) from the pooled backward via the handle); the
+    cascaded+/hybrid+ branches consume ``feat`` with ordinary torch ops, and their gradient arrives here."""
+
+    @staticmethod
+    def forward(ctx, weights, hidden, B, R, D, normalize):
+        w_soft = torch.softmax(weights.detach().float(), dim=0).contiguous()
+        src = torch.zeros(B, R, D, device=hidden.device, dtype=torch.bfloat16)
+        ops.wsum_fwd(hidden, w_soft, src, B, R, D, 1, normalize)
+        ctx.save_for_backward(hidden, w_soft)
+        ctx.dims = (B, R, D, normalize)
+        return src
+
+    @staticmethod
+    def backward(ctx, g):
+        hidden, w_soft = ctx.saved_tensors
+        B, R, D, normalize = ctx.dims
+        d_soft = ops.wsum_bwd(hidden, g.float().contiguous(), B, R, D, 1, normalize=normalize)
+        return w_soft * (d_soft - (w_soft * d_soft).sum()), None, None, None, None, None
+
+
 class WeightedSumLayer(nn.Module):
     def __init__(self, n_weights: int, normalize_features: bool = False):
         super().__init__()
@@ -63,8 +85,7 @@ class WeightedSumLayer(nn.Module):
 
     def forward_padded(self, hidden: torch.Tensor, B: int, R: int, T: int, D: int) -> torch.Tensor:
         w_soft = torch.softmax(self.weights.detach().float(), dim=0).contiguous()
-        src = torch.zeros(B, R, D, device=hidden.device, dtype=torch.bfloat16)
-        ops.wsum_fwd(hidden, w_soft, src, B, R, D, 1, self.normalize_features)
+        src = _WeightedSumSrcFn.apply(self.weights, hidden, B, R, D, self.normalize_features)
         feat = src[:, 1: T + 1]
         feat._sc_handle = PaddedFeatHandle(src, hidden, self, w_soft, B, R, T, D, self.normalize_features)
         return feat

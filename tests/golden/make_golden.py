@@ -303,6 +303,71 @@ def make_hubert():
             hf_valid=hf_valid, stable=np.int64(stable), **{"W_" + k: v for k, v in W.items()})
 
 
+# --------------------------------------------------------------------------- cascaded+/hybrid+ pieces (row a11)
+def make_cascaded():
+    cif = load_leaf("avssl/module/cif.py", "ref_cif")
+    vqm = load_leaf("avssl/module/speechclip_c_modules/my_vector_quantizer.py", "ref_vq")
+    bnm = load_leaf("avssl/module/speechclip_c_modules/kw_bn.py", "ref_bn")
+    torch.manual_seed(31)
+    D, B, T = 32, 4, 60
+    m = cif.CIF(cif_threshold=1.0, cif_output_dim=D, encoder_embed_dim=D, produce_weight_type="conv", num_layer=1,
+                conv_cif_width=3, apply_scaling=True, apply_tail_handling=True, tail_handling_firing_threshold=0.5,
+                scaling_step=5000).eval()          # eval(): the p=0.5 dropouts of the weight generator are off
+    with torch.no_grad():
+        m.weight_proj[1].bias.add_(-0.5)           # alphas around 0.3-0.6 -> several fires per utterance
+    feat = torch.randn(B, T, D, requires_grad=True)
+    lens = torch.tensor([60, 41, 23, 7])
+    pad = torch.arange(T).unsqueeze(0) >= lens.unsqueeze(1)
+    out = {}
+    # training path: target lengths given (scaling on, tail dropped)
+    tgt = (lens / 20).round().long().clamp(min=1)
+    r = m({"audio_feat": feat, "audio_feat_pad_mask": pad, "global_step": 0}, tgt)
+    g = torch.randn_like(r["dsample_feats"])
+    (r["dsample_feats"] * g).sum().backward()
+    out.update(tr_feats=r["dsample_feats"], tr_len=r["dsample_feats_length"], tr_quantity=r["quantity_out"],
+               tr_alpha=r["alpha"], tr_gout=g, tr_gfeat=feat.grad.clone(), tr_target=tgt,
+               tr_gconvw=m.conv[0].weight.grad.clone())
+    # inference path: no target (no scaling, tail firing)
+    with torch.no_grad():
+        r = m({"audio_feat": feat.detach(), "audio_feat_pad_mask": pad, "global_step": 0}, None)
+    out.update(ev_feats=r["dsample_feats"], ev_len=r["dsample_feats_length"], ev_quantity=r["quantity_out"],
+               ev_pad=r["dsample_feats_pad_mask"], ev_fired=r["fired_marks"])
+    # after the scaling step: apply_scaling switches off for good
+    with torch.no_grad():
+        r = m({"audio_feat": feat.detach(), "audio_feat_pad_mask": pad, "global_step": 6000}, tgt)
+    out.update(ns_feats=r["dsample_feats"], ns_len=r["dsample_feats_length"])
+    npz("cif_d32.npz", feat=feat, lens=lens, **out, **{"W_" + k: v for k, v in m.state_dict().items()})
+
+    # vector quantizer: eval (hard one-hot) and train (straight-through softmax / 0.1)
+    torch.manual_seed(32)
+    V = 50
+    x = torch.randn(3, 5, V) * 0.3
+    vq = vqm.SimpleVectorQuantizer(temp="fixed=0.1", time_first=True, use_gumbel=False, hard=True)
+    vq.eval()
+    re = vq(x=x.clone())
+    vq.train()
+    xt = x.clone().requires_grad_(True)
+    rt = vq(x=xt * 1.0)
+    emb = torch.randn(V, 8)
+    gk = torch.randn(3, 5, 8)
+    ((rt["subword_prob"] @ emb) * gk).sum().backward()
+    npz("vq_v50.npz", x=x, emb=emb, gk=gk, ev_prob=re["subword_prob"], ev_targets=re["targets"],
+        ev_code_ppl=re["code_perplexity"], ev_prob_ppl=re["prob_perplexity"], ev_ent=re["ent_per_t"],
+        ev_div=re["diversity_loss"], tr_prob=rt["subword_prob"], tr_gx=xt.grad)
+
+    # keyword BatchNorm (dynamic): train-mode batch statistics and eval-mode running statistics
+    torch.manual_seed(33)
+    E = 16
+    bn = bnm.Kw_BatchNorm_dynamic(kw_dim=E, init_bias=torch.randn(E) * 0.1, init_scale=torch.rand(E) + 0.5, std_scale=1.0)
+    kw = torch.randn(4, 6, E)
+    bn.train()
+    y_tr = bn(kw)
+    bn.eval()
+    y_ev = bn(kw)
+    npz("kwbn_e16.npz", kw=kw, y_train=y_tr, y_eval=y_ev, **{"W_" + k: v for k, v in bn.state_dict().items()},
+        init_weight=bn.bn_layer.weight, init_bias=bn.bn_layer.bias)
+
+
 if __name__ == "__main__":
     make_loss()
     make_head()
@@ -310,3 +375,4 @@ if __name__ == "__main__":
     make_masks()
     make_retrieval()
     make_hubert()
+    make_cascaded()

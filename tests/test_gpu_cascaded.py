@@ -1,0 +1,125 @@
+"""GPU: scope row a11 (cascaded+/hybrid+ tails; stock device-side torch ops fed by the HIP encoder).
+The golden-vector / oracle checks of tests/test_cascaded_cpu.py are repeated on the device, then the
+Cascaded+ base (BASELINE configs[2]) and Hybrid+ large (configs[4], reduced depth) recipes run end to end."""
+import dataclasses
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import test_cascaded_cpu as cc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_leaf_modules_on_device(golden):
+    cc.check_cif(golden, "cuda")
+    cc.check_vq(golden, "cuda")
+    cc.check_bn(golden, "cuda")
+
+
+@pytest.mark.parametrize("kind", ["cascaded", "hybrid"])
+def test_plus_branch_vs_oracle_on_device(kind):
+    cc.check_branch_vs_oracle(kind, "cuda")
+
+
+def _batch(lens, E, seed):
+    g = torch.Generator().manual_seed(seed)
+    B = len(lens)
+    wav = torch.zeros(B, max(lens))
+    wavs = []
+    for b, l in enumerate(lens):
+        w = torch.randn(l, generator=g) * 0.5
+        wav[b, :l] = w
+        wavs.append(w)
+    img = torch.randn(B, E, generator=g)
+    ids = torch.arange(B) // 2
+    return {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": img.cuda(), "id": ids.cuda()}, wavs
+
+
+def test_cascaded_plus_base_end_to_end():
+    """Cascaded+ base: eval-mode embeddings against the oracle chain (encoder -> weighted sum -> cascaded+ tail) and
+    two train steps (contrastive + CIF quantity loss, trainable temperature) through the flat-Adam trainer."""
+    import oracle
+    from speechclip_plus_amd import KWClip_GeneralTransformer, cascaded_plus_base_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    arch = dataclasses.replace(ARCHS["hubert"], layers=2)
+    sd = random_hubert_state_dict(arch, seed=21)
+    torch.manual_seed(21)
+    cfg = cascaded_plus_base_config()
+    cfg.audio_encoder.max_audio_len = -1
+    cfg.clip.layers = 2
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch)
+    with torch.no_grad():
+        model.cascaded_branch.downsampling.weight_proj[1].bias.add_(-0.5)
+    lens = [24000, 17000, 24000, 9000]
+    batch, wavs = _batch(lens, 512, 1)
+    model.eval()
+    with torch.no_grad():
+        out = model.encode_speech([w.cuda() for w in wavs])
+    emb = out["cascaded_audio_feat"].float().cpu()
+    assert emb.shape == (4, 512) and torch.isfinite(emb).all()
+    # oracle chain on the same weights
+    o_arch = oracle.HubertArch.base()
+    o_arch.layers = 2
+    hs, fl = oracle.speech_encoder_forward(sd, o_arch, wavs)
+    feat = oracle.weighted_sum(model.audio_encoder.weightedsum_layer.weights.detach().cpu(), hs)
+    W = {k: v.detach().cpu().float() for k, v in model.cascaded_branch.state_dict().items()}
+    ref, kw_ref, n_ref, _ = oracle.cascaded_plus_forward(W, feat, fl, nhead=1, training=False, nhead_clip=8,
+                                                         sot=model.clip.startOfTxt_reduced, eot=model.clip.endOfTxt_reduced)
+    assert out["vq_results"]["targets"].shape[0] == 4
+    same_len = out["keywords"].shape[1] == kw_ref.shape[1]
+    if same_len:   # hard VQ choices may flip under bf16 feature noise; where they agree the embeddings must too
+        tok = out["vq_results"]["targets"].squeeze(-1).cpu()
+        tok_ref = (kw_ref @ W["clip.model.token_embedding.weight"].t()).argmax(-1)
+        agree = (tok == tok_ref).all(dim=1)
+        assert float((tok == tok_ref).float().mean()) > 0.8
+        if agree.any():
+            assert float(F.cosine_similarity(emb[agree], ref[agree], dim=-1).min()) > 0.995
+    # training
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    trainer = ContrastiveTrainer(model)
+    l1 = trainer.step(batch).item()
+    l2 = trainer.step(batch).item()
+    assert l1 == l1 and l2 == l2 and l2 < l1 + 0.05, (l1, l2)
+    n_trainable = sum(p.numel() for p in model.getTrainableParams())
+    assert n_trainable == trainer.opt.n and float(trainer.opt.flat_g.abs().sum()) > 0
+    names = {n for n, p in model.named_parameters() if p.requires_grad and p.grad is not None and float(p.grad.abs().sum()) > 0}
+    for must in ["cascaded_branch.downsampling.conv.0.weight", "cascaded_branch.linear_proj.weight",
+                 "cascaded_branch.self_att.multihead_attn_layer.in_proj_weight", "criterion.temperature",
+                 "audio_encoder.weightedsum_layer.weights"]:
+        assert must in names, must
+    assert all(not p.requires_grad for p in model.clip.parameters())
+
+
+def test_hybrid_plus_large_end_to_end():
+    """Hybrid+ large (HuBERT-large at reduced depth, MLP keyword projection, 8-head shared attention block):
+    forward dict keys of kwClip.py:898-963, both contrastive losses + quantity loss, one optimiser step."""
+    from speechclip_plus_amd import KWClip_GeneralTransformer, hybrid_plus_large_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    arch = dataclasses.replace(ARCHS["hubert_large_ll60k"], layers=2)
+    sd = random_hubert_state_dict(arch, seed=22)
+    torch.manual_seed(22)
+    cfg = hybrid_plus_large_config()
+    cfg.audio_encoder.max_audio_len = -1
+    cfg.clip.layers = 2
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train()
+    with torch.no_grad():
+        model.cascaded_branch.downsampling.weight_proj[1].bias.add_(-0.5)
+    batch, _ = _batch([20000, 14000, 20000, 8000], 768, 2)
+    losses_, log_metrics, others = model(batch)
+    assert {"id", "image_feat", "parallel_audio_feat", "cascaded_audio_feat", "cif_quantity_out", "cif_target_len"} <= set(losses_)
+    assert {"cl_temp", "softmax_temp", "temp", "code_perplexity", "prob_perplexity", "ent_per_t", "dsample_len_diff"} <= set(log_metrics)
+    assert others["keywords"].shape[-1] == 768 and others["keywords_len"].shape == (4,)
+    out = model.compute_loss(losses_)
+    assert {"loss", "c_cl_loss", "p_cl_loss", "quantity_loss"} <= set(out)
+    total = out["c_cl_loss"] + out["p_cl_loss"] + 0.25 * out["quantity_loss"]
+    assert abs(out["loss"].item() - total.item()) < 1e-5
+    trainer = ContrastiveTrainer(model)
+    l1 = trainer.step(batch).item()
+    assert l1 == l1

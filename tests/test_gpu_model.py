@@ -208,4 +208,5 @@ def test_encode_speech_api_and_recall(setup):
         for k in d_ora:
             assert abs(d_hip[k] - d_ora[k]) < 1e-6, (k, d_hip[k], d_ora[k])
     h13 = model.feature_extractor_s3prl([w.cuda() for w in wavs[:2]])
-    assert len(h13[1]) == 13 and h13[0].shape[-1] == 768
+    # kwClip.py:965-997: 13 HuBERT states + the parallel branch layer's output (CLS position dropped)
+    assert len(h13[1]) == 14 and h13[0].shape[-1] == 768 and h13[1][-1].shape == h13[1][0].shape
