@@ -38,8 +38,9 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=2, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--model", choices=["base", "large"], default="base",
-                    help="base = BASELINE configs[1] (headline); large = Parallel large (HuBERT-large + ViT-L/14 width)")
+    ap.add_argument("--model", choices=["base", "large", "cascaded_plus", "hybrid_plus_large"], default="base",
+                    help="base = BASELINE configs[1] (headline); large = Parallel large; cascaded_plus = configs[2]; "
+                         "hybrid_plus_large = configs[4] recipe on one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -62,16 +63,17 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     dev = torch.device("cuda", local_rank)
 
-    from speechclip_plus_amd import (KWClip_GeneralTransformer, base_parallel_config, large_parallel_config, ops,
-                                     random_hubert_state_dict)
+    from speechclip_plus_amd import (KWClip_GeneralTransformer, base_parallel_config, cascaded_plus_base_config,
+                                     hybrid_plus_large_config, large_parallel_config, ops, random_hubert_state_dict)
     from speechclip_plus_amd.speech_encoder import ARCHS
     from speechclip_plus_amd.train import ContrastiveTrainer
 
     B, L = args.batch, int(round(args.seconds * 16000))
     torch.manual_seed(7122)
-    large = args.model == "large"
+    large = args.model in ("large", "hybrid_plus_large")
     sd = random_hubert_state_dict(ARCHS["hubert_large_ll60k" if large else "hubert"], seed=7122)
-    cfg = large_parallel_config() if large else base_parallel_config()
+    cfg = {"base": base_parallel_config, "large": large_parallel_config, "cascaded_plus": cascaded_plus_base_config,
+           "hybrid_plus_large": hybrid_plus_large_config}[args.model]()
     E = int(cfg.clip.embed_dim)
     cfg.audio_encoder.max_audio_len = -1          # 10 s utterances, no 6.4 s training crop (BASELINE configs[1])
     model = KWClip_GeneralTransformer(cfg, device=str(dev), hubert_state_dict=sd)
@@ -111,6 +113,17 @@ def main():
         trainer.step(batch)
     torch.cuda.synchronize()
     ops.set_timer(None)
+    # ---- forward only (north_star: fraction of the MFMA bf16 peak on the HuBERT + attention-pool forward) ---------
+    fwd_ms = None
+    if rank == 0 and args.model == "base":
+        with torch.no_grad():
+            model(batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                model(batch)
+            torch.cuda.synchronize()
+            fwd_ms = (time.perf_counter() - t1) / args.steps * 1e3
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -142,7 +155,7 @@ def main():
                 extra[k] = {"ms_per_step": round(v["ms"] / args.steps, 3),
                             "alg_tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None}
         cpu = None
-        if world == 1 and args.cpu_utts > 0 and not large:
+        if world == 1 and args.cpu_utts > 0 and args.model == "base":
             cpu = cpu_baseline(sd, model, args.cpu_utts, L, args.cpu_iters)
         result = {
             "metric": "utterances/sec (train step)", "value": round(B * world * args.steps / elapsed, 2),
@@ -155,11 +168,33 @@ def main():
                        "global_batch": B * world, "per_gpu_batch": B, "audio_samples": L, "frames": T,
                        "parallelism": f"dp{world}", "dropout": "off (deterministic head; reference trains with p=0.1)"},
             "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,
+            "forward": None if fwd_ms is None else forward_summary(fwd_ms, B, L, T),
         }
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def forward_summary(fwd_ms, B, L, T):
+    """Algorithmic flops of the HuBERT-base + CLS-pool forward (SURVEY 8d formulae, conv extractor included; the
+    collapsed CLS head is ~0.013 GFLOP/utt) over the measured forward time."""
+    conv_T, t, cin = [], L, 1
+    ks, ss = (10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)
+    flop = 0.0
+    for k, s_ in zip(ks, ss):
+        t = (t - k) // s_ + 1
+        flop += 2.0 * t * 512 * cin * k
+        cin = 512
+    D, F, NL = 768, 3072, 12
+    flop += 2.0 * T * 512 * D                                  # post_extract_proj
+    flop += 2.0 * T * D * (D // 16) * 128                      # pos_conv
+    flop += NL * T * 2.0 * (4 * D * D + 2 * D * F)             # linear layers
+    flop += NL * 4.0 * T * T * D                               # attention
+    flop += 0.013e9
+    tfl = flop * B / (fwd_ms * 1e-3) / 1e12
+    return {"ms": round(fwd_ms, 3), "utterances_per_s": round(B / fwd_ms * 1e3, 1), "alg_gflop_per_utt": round(flop / 1e9, 2),
+            "alg_tflops": round(tfl, 1), "frac_of_mfma_bf16_peak": round(tfl / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
 
 
 def pmc_traffic(kernel_substr):

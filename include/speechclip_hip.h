@@ -57,7 +57,8 @@ typedef struct {
     sc_bf16* Ct; int32_t n_split; int32_t R; int32_t dh;   /* transposed-store region; n_split < 0 disables */
     int32_t nb1, nb2;             /* batch = nb1*nb2 (>= 1 each) */
     int64_t sA1, sA2, sW1, sW2, sC1, sC2, sBias1, sBias2, sR1, sR2;
-    int32_t tile;                 /* 0 auto | 1: 128x128 (4 waves) | 2: 256x256 (8 waves, persistent) | 3: 128x64 */
+    int32_t tile;                 /* 0 auto | 1: 128x128 (4 waves) | 2: 256-row tile, 8 waves, width 256 or 192 by wave quantisation
+                                     (7 / 8 force 192 / 256) | 3: 128x64 */
     int32_t reserved;
 } sc_gemm_args;
 int sc_gemm_bf16(const sc_gemm_args* args, void* stream);

@@ -43,15 +43,20 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 }
 
 // DIAG (timing-only diagnostic builds, results are wrong): 1 = no DMA inside the K loop, 2 = DMA but no vmcnt waits
-template <int DIAG>
+// BN = 256 or 192 output columns per tile (wave block 128 x 64 or 128 x 48).  The narrower tile exists for wave
+// quantisation: with M = 32768, N = 768 / 2304 give 384 / 1152 tiles of 256 x 256 (1.5 / 4.5 rounds over 256 CUs) but
+// 512 / 1536 tiles of 256 x 192 (exactly 2 / 6 rounds).
+template <int DIAG, int BN>
 __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
+    constexpr int TN = BN / 4, FN = TN / 16, NB1 = FN - 2;   // per-wave columns, fragments, fragments of n-sub 1
+    constexpr int NBI = BN / 64;                             // B-tile DMA instructions per wave and K-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
     // ---- block -> tile (XCD-aware, banded; see gemm_bf16.hip) ---------------------------------------------
-    const int nM = (p.M + 255) >> 8, nN = (p.N + 255) >> 8;
+    const int nM = (p.M + 255) >> 8, nN = (p.N + BN - 1) / BN;
     int L;
     {
         const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     const int gm = min(GM, nM - first_m);
     const int within = L - band * GM * nN;
     const int n_tile = within / gm, m_tile = first_m + within % gm;
-    const int m0 = m_tile << 8, n0 = n_tile << 8;
+    const int m0 = m_tile << 8, n0 = n_tile * BN;
 
     const int z = blockIdx.z, z1 = z / p.nb2, z2 = z % p.nb2;
     const uint16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
@@ -71,9 +76,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     const uint16_t* Rs = p.residual ? p.residual + z1 * p.sR1 + z2 * p.sR2 : nullptr;
     const int64_t coff = z1 * p.sC1 + z2 * p.sC2;
 
-    // ---- DMA sources: half-tile = 16 wave-instructions of 8 rows; wave w issues instr {w, w + 8} -----------
+    // ---- DMA sources: one wave-instruction = 8 rows; A: 2 halves x 16 instr (wave w issues {w, w + 8} of each half),
+    //      B: BN / 8 instr over the BN-row B region (wave w issues {w, w + 8, ...}) --------------------------------
     const uint16_t* a_src[2][2];
-    const uint16_t* b_src[2][2];
+    const uint16_t* b_src[NBI];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -81,8 +87,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             const int row = (i * 8 + wave) * 8 + (lane >> 3);          // row inside the half-tile
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             a_src[h][i] = A + (int64_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + c * 8;
-            b_src[h][i] = W + (int64_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw + c * 8;
         }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);              // row inside the B region
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        b_src[i] = W + (int64_t)min(n0 + row, p.N - 1) * p.ldw + c * 8;
+    }
     auto dma_A = [&](int par, int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -92,10 +103,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     };
     auto dma_B = [&](int par, int k0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                glds16(b_src[h][i] + k0, smem + par * BUF_BYTES + (2 + h) * HALF_BYTES + (i * 8 + wave) * 1024);
+        for (int i = 0; i < NBI; ++i)
+            glds16(b_src[i] + k0, smem + par * BUF_BYTES + 2 * HALF_BYTES + (i * 8 + wave) * 1024);
     };
 
     // ---- fragment read offsets: row = 16*f + (lane & 15)  =>  swizzle term depends on the lane only ----------
@@ -103,14 +112,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     const int frag_off0 = (lane & 15) * ROWB + (((lane >> 4)) ^ sw) * 16;          // kk = 0
     const int frag_off1 = (lane & 15) * ROWB + ((4 + (lane >> 4)) ^ sw) * 16;      // kk = 1
     const int a_base = wm * HALF_BYTES;                                             // wave's A half
-    const int b_base = (2 + (wn >> 1)) * HALF_BYTES + (wn & 1) * 64 * ROWB;         // wave's 64 B rows
+    const int b_base = 2 * HALF_BYTES + wn * TN * ROWB;                             // wave's TN rows of the B region
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][FN];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4][2], b0[2][2], b1[2][2];
+        for (int ni = 0; ni < FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], b0[2][2], b1[NB1][2];
 
     const int nk = p.K / BK;
     // ---- prologue ----------------------------------------------------------------------------------------------
@@ -118,7 +127,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     dma_A(0, 0);
     if (nk > 1) {
         dma_B(1, BK);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (NBI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         __builtin_amdgcn_s_setprio(1);                                                                   \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                 \
             _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
-                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                         \
+                _Pragma("unroll") for (int ni = 0; ni < ((NS) == 0 ? 2 : NB1); ++ni)                     \
                     acc[(MS) * 4 + mi][(NS) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(         \
                         af[mi][kk], BF[ni][kk], acc[(MS) * 4 + mi][(NS) * 2 + ni], 0, 0, 0);             \
         __builtin_amdgcn_s_setprio(0);                                                                   \
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         SC_BAR();
         // ---------------- P1
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NB1; ++ni) {
             b1[ni][0] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off0);
             b1[ni][1] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off1);
         }
@@ -177,7 +187,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         if (DIAG == 0) {
             if (kt + 2 < nk) {
                 dma_B(par, (kt + 2) * BK);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (NBI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -191,13 +202,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     if (wm == 0) SC_BAR();                       // pairs the staggered group's last barrier
     if (DIAG != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue: each wave streams its 128 x 64 block through a private 16 KiB LDS region, 64 rows a pass ---
+    // ---- epilogue: each wave streams its 128 x TN block through a private 16 KiB LDS region, 64 rows a pass --------
     float* Cw = (float*)(smem + wave * 16384);
     const bool transposed = (p.n_split >= 0) && (n0 >= p.n_split);
-    const int wn0 = n0 + wn * 64;                // wave's first column
-    float bv[4];
+    const int wn0 = n0 + wn * TN;                // wave's first column
+    constexpr int CPR = TN / 8;                  // 8-column chunks per row
+    float bv[FN];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < FN; ++ni) {
         const int n = wn0 + ni * 16 + (lane & 15);
         bv[ni] = (bias && n < p.N) ? bias[n] : 0.f;
     }
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < FN; ++ni) {
                 f32x4 v = acc[ms * 4 + mi][ni];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += bv[ni];
@@ -220,18 +232,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                     *(f32x4*)(Cw + nl * 64 + ml) = v;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Cw[(ml + r) * 64 + nl] = v[r];
+                    for (int r = 0; r < 4; ++r) Cw[(ml + r) * TN + nl] = v[r];
                 }
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!transposed) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 8 + (lane >> 3), cc = lane & 7;
+            for (int it = 0; it < CPR; ++it) {
+                const int q = it * 64 + lane;
+                const int row = q / CPR, cc = q % CPR;
                 const int m = wm0 + row, n = wn0 + cc * 8;
                 if (m < p.M && n + 8 <= p.N) {
-                    const f32x4 lo = *(const f32x4*)(Cw + row * 64 + cc * 8);
-                    const f32x4 hi = *(const f32x4*)(Cw + row * 64 + cc * 8 + 4);
+                    const f32x4 lo = *(const f32x4*)(Cw + row * TN + cc * 8);
+                    const f32x4 hi = *(const f32x4*)(Cw + row * TN + cc * 8 + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     if (Rs) {
                         const uint4 rv = *(const uint4*)(Rs + (int64_t)m * p.ldr + n);
@@ -254,8 +267,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         } else {
             const int H = (p.N - p.n_split) / p.dh;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int nrow = it * 8 + (lane >> 3), mc = lane & 7;
+            for (int it = 0; it < CPR; ++it) {
+                const int q = it * 64 + lane;
+                const int nrow = q >> 3, mc = q & 7;
                 const int m = wm0 + mc * 8, n = wn0 + nrow;
                 if (m < p.M && n < p.N) {
                     const f32x4 lo = *(const f32x4*)(Cw + nrow * 64 + mc * 8);
@@ -276,26 +290,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
 
 }  // namespace
 
-template <int DIAG>
+template <int DIAG, int BN>
 static int launch256(const sc_gemm_args& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DIAG, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) {
             sc_set_error("hipFuncSetAttribute(gemm256): %s", hipGetErrorString(e));
             return -3;
         }
         attr_set = true;
     }
-    const int nM = (a.M + 255) / 256, nN = (a.N + 255) / 256;
+    const int nM = (a.M + 255) / 256, nN = (a.N + BN - 1) / BN;
     dim3 grid(nM * nN, 1, a.nb1 * a.nb2);
-    hipLaunchKernelGGL(gemm256_kernel<DIAG>, grid, dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm256_kernel<DIAG, BN>), grid, dim3(512), LDS_BYTES, s, a);
     SC_LAUNCH_CHECK();
     return 0;
 }
 
+// rounds of 256 workgroups the grid needs with BN-wide tiles, times a per-tile efficiency factor
+static double tile_cost(const sc_gemm_args& a, int BN) {
+    const double tiles = (double)((a.M + 255) / 256) * ((a.N + BN - 1) / BN) * a.nb1 * a.nb2;
+    const double rounds = (double)(((long)tiles + 255) / 256);
+    return rounds * BN * (BN == 192 ? 1.06 : 1.0);       // the 128 x 48 wave block reads ~20 % more LDS per MFMA
+}
+
 int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s) {
-    if (a.tile == 12) return launch256<1>(a, s);   // diagnostics only (tools/bench_gemm.py)
-    if (a.tile == 22) return launch256<2>(a, s);
-    return launch256<0>(a, s);
+    if (a.tile == 12) return launch256<1, 256>(a, s);   // diagnostics only (tools/bench_gemm.py)
+    if (a.tile == 22) return launch256<2, 256>(a, s);
+    if (a.tile == 7) return launch256<0, 192>(a, s);
+    if (a.tile == 8) return launch256<0, 256>(a, s);
+    const bool ok192 = (a.n_split < 0 || a.n_split % 192 == 0);
+    const bool ok256 = (a.n_split < 0 || a.n_split % 256 == 0);
+    if (ok192 && (!ok256 || tile_cost(a, 192) < tile_cost(a, 256))) return launch256<0, 192>(a, s);
+    return launch256<0, 256>(a, s);
 }

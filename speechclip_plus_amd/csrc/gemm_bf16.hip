@@ -273,13 +273,14 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     if (tile == 0) {
         const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.nb1 * a.nb2;
         if (a.N <= 64 && a.n_split < 0) tile = 3;            // narrow outputs (grouped pos_conv, N = 48)
-        else if (a.M >= 512 && a.N >= 256 && tiles256 >= 192 && (a.n_split < 0 || a.n_split % 256 == 0)) tile = 2;
+        else if (a.M >= 512 && a.N >= 192 && tiles256 >= 192 && (a.n_split < 0 || a.n_split % 64 == 0)) tile = 2;
         else tile = 1;
     }
     switch (tile) {
         case 1: return launch<128, 128>(a, s);
-        case 2: case 12: case 22:
-            SC_CHECK(a.n_split < 0 || a.n_split % 256 == 0, "sc_gemm_bf16: 256x256 tile needs n_split %% 256 == 0");
+        case 2: case 12: case 22: case 7: case 8:   // 2 = 256-row tile, width (256 / 192) chosen by wave quantisation; 7 / 8 force it
+            SC_CHECK(a.n_split < 0 || a.n_split % 192 == 0 || a.n_split % 256 == 0,
+                     "sc_gemm_bf16: 256-row tiles need n_split %% 192 == 0 or %% 256 == 0");
             return sc_gemm256_launch(a, s);
         case 3:
             SC_CHECK(a.n_split < 0, "sc_gemm_bf16: 128x64 tile has no transposed store");

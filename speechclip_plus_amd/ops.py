@@ -54,11 +54,11 @@ def gemm_tile_name(M: int, N: int, K: int, n_split: int, batch: int, tile: int =
     if tile == 0:
         if N <= 64 and n_split < 0:
             tile = 3
-        elif M >= 512 and N >= 256 and ((M + 255) // 256) * ((N + 255) // 256) * batch >= 192 and (n_split < 0 or n_split % 256 == 0):
+        elif M >= 512 and N >= 192 and ((M + 255) // 256) * ((N + 255) // 256) * batch >= 192 and (n_split < 0 or n_split % 64 == 0):
             tile = 2
         else:
             tile = 1
-    return {1: "128x128", 2: "256x256", 3: "128x64"}.get(tile, "diag")
+    return {1: "128x128", 2: "256x256", 3: "128x64", 7: "256x256", 8: "256x256"}.get(tile, "diag")
 
 
 def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tensor, ldc: int, M: int, N: int, K: int,

@@ -62,7 +62,7 @@ def test_gemm(dev, M, N, K, act, use_bias, use_res, out_f32):
     assert float((out.float() - ref).abs().max()) < (1e-3 if out_f32 else 0.06) * (1 + float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("tile", [2])
+@pytest.mark.parametrize("tile", [2, 7, 8])
 @pytest.mark.parametrize("M,N,K,act,use_res", [(512, 768, 768, 0, True), (1024, 512, 1536, 1, False), (700, 2408, 128, 0, True),
                                                 (2048, 3072, 768, 1, False), (512, 256, 64, 0, False), (6000, 512, 1024, 1, False)])
 def test_gemm_tile256(dev, M, N, K, act, use_res, tile):
@@ -84,7 +84,7 @@ def test_gemm_tile256(dev, M, N, K, act, use_res, tile):
     assert torch.equal(out, out1), "both tile variants accumulate k in the same order and share the epilogue maths"
 
 
-@pytest.mark.parametrize("tile", [2])
+@pytest.mark.parametrize("tile", [2, 7, 8])
 def test_gemm_tile256_transposed_store(dev, tile):
     ops = _ops()
     B, R, D, H = 2, 384, 768, 12
