@@ -140,7 +140,7 @@ def main():
             dom_name = max((k for k in summ if k.startswith("gemm_bf16_")), key=lambda k: summ[k]["ms"])
             dom = summ[dom_name]
             tflops = dom["work"] / (dom["ms"] * 1e-3) / 1e12
-            kname = {"gemm_bf16_256x256": "gemm256_kernel<0> (256x256x64 tile)", "gemm_bf16_128x128": "gemm_bf16_kernel<128,128>",
+            kname = {"gemm_bf16_256x256": "gemm256_kernel<0,BN> (256 x {256|192} x 64 tiles)", "gemm_bf16_128x128": "gemm_bf16_kernel<128,128>",
                      "gemm_bf16_128x64": "gemm_bf16_kernel<128,64>"}[dom_name]
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(tflops, 2),
                     "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -148,7 +148,7 @@ def main():
                     "launches_per_step": dom["launches"] // args.steps,
                     "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                     "alg_gflop_per_launch": round(dom["work"] / dom["launches"] / 1e9, 3)}
-            roof.update(pmc_traffic("gemm256_kernel<0>" if dom_name == "gemm_bf16_256x256" else "gemm_bf16_kernel<128, 128>"))
+            roof.update(pmc_traffic("gemm256_kernel<0," if dom_name == "gemm_bf16_256x256" else "gemm_bf16_kernel<128, 128>"))
             for k, v in summ.items():
                 if not k.startswith("gemm_bf16_"):
                     continue          # event brackets are validated against rocprofv3 for the GEMM launches only
@@ -206,11 +206,13 @@ def pmc_traffic(kernel_substr):
     if not files:
         return {"traffic": None}
     data = json.load(open(files[-1]))
-    for name, v in data.items():
-        if kernel_substr in name:
-            return {"traffic": v["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch (PMC, avg over launches)",
-                    "traffic_source": os.path.relpath(files[-1], ROOT)}
-    return {"traffic": None}
+    hits = [v for name, v in data.items() if kernel_substr in name]
+    if not hits:
+        return {"traffic": None}
+    n = sum(v["launches_sampled"] for v in hits)
+    avg = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hits) / n
+    return {"traffic": round(avg), "traffic_unit": "bytes/launch (PMC, avg over launches of all instantiations)",
+            "traffic_source": os.path.relpath(files[-1], ROOT)}
 
 
 def cpu_baseline(sd, model, n_utts, L, iters):

@@ -312,7 +312,7 @@ static int launch256(const sc_gemm_args& a, hipStream_t s) {
 static double tile_cost(const sc_gemm_args& a, int BN) {
     const double tiles = (double)((a.M + 255) / 256) * ((a.N + BN - 1) / BN) * a.nb1 * a.nb2;
     const double rounds = (double)(((long)tiles + 255) / 256);
-    return rounds * BN * (BN == 192 ? 1.06 : 1.0);       // the 128 x 48 wave block reads ~20 % more LDS per MFMA
+    return rounds * BN * (BN == 192 ? 1.12 : 1.0);       // measured: a 256 x 192 tile runs ~12 % below the 256 x 256 rate
 }
 
 int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s) {
