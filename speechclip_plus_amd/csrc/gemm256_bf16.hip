@@ -1,25 +1,33 @@
-// 256 x 256 x 64 bf16 MFMA GEMM for gfx950: deep-pipelined variant of gemm_bf16.hip for the large GEMMs.
+// 256 x {256,192} x 64 bf16 MFMA GEMM for gfx950: persistent, deep-pipelined variant of gemm_bf16.hip for the large GEMMs.
 //
-// 512 threads = 8 waves as 2 (M) x 4 (N); each wave owns a 128 x 64 output block = 8 x 4 fragments of
-// v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  One workgroup per CU (128 KiB LDS), so two waves share
-// each SIMD: waves 0-3 (wm = 0) and 4-7 (wm = 1) run STAGGERED by one barrier interval - while one group is
-// in its MFMA segment the other issues LDS reads / LDS-DMA - which keeps the matrix pipe fed by one wave at a time
-// (MI355X_MICROARCH "Two waves per SIMD").
+// 512 threads = 8 waves as 2 (M) x 4 (N); each wave owns a 128 x 64 (or 128 x 48) output block = 8 x 4 (8 x 3) fragments
+// of v_mfma_f32_16x16x32_bf16.  One workgroup per CU (128 KiB LDS), so two waves share each SIMD: waves 0-3 (wm = 0)
+// and 4-7 (wm = 1) run STAGGERED by one barrier interval - while one group is in its MFMA segment the other issues
+// LDS reads / LDS-DMA - which keeps the matrix pipe fed by one wave at a time (MI355X_MICROARCH "Two waves per SIMD").
 //
 // LDS: 2 K-tile buffers x {A, B} x 2 half-tiles of 128 rows x 64 k (16 KiB each), same XOR-swizzled 128-B row
 // image as gemm_bf16.hip.  Staging is LDS-DMA (global_load_lds_dwordx4) that stays in flight across barriers:
-// raw s_barrier (no implicit vmcnt(0)), one counted `s_waitcnt vmcnt(4)` per K-tile.
+// raw s_barrier (no implicit vmcnt(0)), one counted `s_waitcnt vmcnt(NBI)` per K-tile.
 //
-// K-tile kt = 4 phases, each [L segment | barrier | C segment: 16 MFMA | barrier]:
+// K-tile kt (buffer par = (kt + base) & 1) = 4 phases, each [L segment | barrier | C segment: 16 MFMA | barrier]:
 //   P0  L: read A(m-sub 0) 8 x b128 + B(n-sub 0) 4 x b128            C: quadrant (m0, n0)
 //   P1  L: read B(n-sub 1) 4 ; DMA A(kt+1) -> other buffer            C: (m0, n1)
 //   P2  L: read A(m-sub 1) 8                                          C: (m1, n1)
-//   P3  L: DMA B(kt+2) -> this buffer ; s_waitcnt vmcnt(4)            C: (m1, n0)   (B(n0) kept in registers)
+//   P3  L: DMA B(kt+2) -> this buffer ; s_waitcnt vmcnt(NBI)          C: (m1, n0)   (B(n0) kept in registers)
 // Hazards (phase p spans barrier intervals 2p, 2p+1 for wm = 0 and 2p+1, 2p+2 for wm = 1):
 //   WAR  a slot is re-staged >= 2 phases after its last ds_read (A: read P0/P2, staged P1 of the next tile;
 //        B: read P0/P1, staged P3), so the staggered group's reads have retired (lgkmcnt) a barrier earlier;
-//   RAW  tile kt+1 (A issued P1(kt), B issued P3(kt-1)) is retired by every wave's vmcnt(4) in L(P3(kt)) and first
+//   RAW  tile kt+1 (A issued P1(kt), B issued P3(kt-1)) is retired by every wave's vmcnt(NBI) in L(P3(kt)) and first
 //        read in L(P0(kt+1)), one barrier later for either group.
+//
+// PERSISTENT: min(tiles, CUs) workgroups walk the tile list (virtual block id = i * gridDim.x + blockIdx.x through the
+// same XCD-aware banded map as a plain launch).  When a tile's K loop ends, K-tile 0 of the NEXT tile is DMA'd into the
+// ring buffer that the last K-tile did not use, and only then the epilogue runs - in the other buffer (8 KiB per wave,
+// four 32-row passes) - so the next tile's first-load latency (3-4 us, measured with in-kernel stamps:
+// tools/epi_stamps.py) hides under the GELU / store work instead of following it.  B(1) of the next tile is issued
+// after the epilogue's closing barrier (it lands in the epilogue's buffer).  `base` carries the buffer parity across tiles.
+#include <algorithm>
+
 #include "sc_common.h"
 
 namespace {
@@ -28,6 +36,7 @@ constexpr int BK = 64, ROWB = 128;
 constexpr int HALF_BYTES = 128 * ROWB;           // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;        // A0 A1 B0 B1
 constexpr int LDS_BYTES = 2 * BUF_BYTES;         // 128 KiB
+constexpr int EPI_BYTES = BUF_BYTES / 8;         // per-wave epilogue staging inside ONE ring buffer: 8 KiB
 
 #define SC_BAR()                               \
     do {                                       \
@@ -42,11 +51,13 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// DIAG (timing-only diagnostic builds, results are wrong): 1 = no DMA inside the K loop, 2 = DMA but no vmcnt waits
+// DIAG (diagnostic builds): 3 = no epilogue (timing only, results wrong), 4 = wall-clock stamps of each tile's sections
+// written to p.Ct (results right; tools/epi_stamps.py).  ACT = 1: erf-GELU in the epilogue (compile-time so the 128
+// evaluations per lane form straight-line code).
 // BN = 256 or 192 output columns per tile (wave block 128 x 64 or 128 x 48).  The narrower tile exists for wave
 // quantisation: with M = 32768, N = 768 / 2304 give 384 / 1152 tiles of 256 x 256 (1.5 / 4.5 rounds over 256 CUs) but
 // 512 / 1536 tiles of 256 x 192 (exactly 2 / 6 rounds).
-template <int DIAG, int BN>
+template <int DIAG, int BN, int ACT>
 __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     constexpr int TN = BN / 4, FN = TN / 16, NB1 = FN - 2;   // per-wave columns, fragments, fragments of n-sub 1
     constexpr int NBI = BN / 64;                             // B-tile DMA instructions per wave and K-tile
@@ -55,19 +66,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    // ---- block -> tile (XCD-aware, banded; see gemm_bf16.hip) ---------------------------------------------
     const int nM = (p.M + 255) >> 8, nN = (p.N + BN - 1) / BN;
-    int L;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    constexpr int GM = 8;
-    const int band = L / (GM * nN), first_m = band * GM;
-    const int gm = min(GM, nM - first_m);
-    const int within = L - band * GM * nN;
-    const int n_tile = within / gm, m_tile = first_m + within % gm;
-    const int m0 = m_tile << 8, n0 = n_tile * BN;
+    const int n_tiles = nM * nN;
+    // ---- virtual block -> tile (XCD-aware, banded; see gemm_bf16.hip) --------------------------------------
+    auto tile_of = [&](int vb, int& m0, int& n0) {
+        const int xcd = vb & 7, q = n_tiles >> 3, r = n_tiles & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+        constexpr int GM = 8;
+        const int band = L / (GM * nN), first_m = band * GM;
+        const int gm = min(GM, nM - first_m);
+        const int within = L - band * GM * nN;
+        m0 = (first_m + within % gm) << 8;
+        n0 = (within / gm) * BN;
+    };
 
     const int z = blockIdx.z, z1 = z / p.nb2, z2 = z % p.nb2;
     const uint16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
@@ -80,20 +91,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     //      B: BN / 8 instr over the BN-row B region (wave w issues {w, w + 8, ...}) --------------------------------
     const uint16_t* a_src[2][2];
     const uint16_t* b_src[NBI];
+    auto set_sources = [&](int m0, int n0) {
+        int sl = lane;                           // opaque copy: keeps the lane-only terms from being hoisted out of the
+        asm volatile("" : "+v"(sl));             // tile loop and living across the K loop
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (i * 8 + wave) * 8 + (lane >> 3);          // row inside the half-tile
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            a_src[h][i] = A + (int64_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + c * 8;
+            for (int i = 0; i < 2; ++i) {
+                const int row = (i * 8 + wave) * 8 + (sl >> 3);            // row inside the half-tile
+                const int c = (sl & 7) ^ ((row >> 1) & 7);
+                a_src[h][i] = A + (int64_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + c * 8;
+            }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int row = (i * 8 + wave) * 8 + (sl >> 3);                // row inside the B region
+            const int c = (sl & 7) ^ ((row >> 1) & 7);
+            b_src[i] = W + (int64_t)min(n0 + row, p.N - 1) * p.ldw + c * 8;
         }
-#pragma unroll
-    for (int i = 0; i < NBI; ++i) {
-        const int row = (i * 8 + wave) * 8 + (lane >> 3);              // row inside the B region
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        b_src[i] = W + (int64_t)min(n0 + row, p.N - 1) * p.ldw + c * 8;
-    }
+    };
     auto dma_A = [&](int par, int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -106,6 +121,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         for (int i = 0; i < NBI; ++i)
             glds16(b_src[i] + k0, smem + par * BUF_BYTES + 2 * HALF_BYTES + (i * 8 + wave) * 1024);
     };
+#define SC_WAIT_NBI()                                                      \
+    do {                                                                   \
+        if (NBI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     \
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");              \
+    } while (0)
 
     // ---- fragment read offsets: row = 16*f + (lane & 15)  =>  swizzle term depends on the lane only ----------
     const int sw = (lane >> 1) & 7;
@@ -113,27 +133,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     const int frag_off1 = (lane & 15) * ROWB + ((4 + (lane >> 4)) ^ sw) * 16;      // kk = 1
     const int a_base = wm * HALF_BYTES;                                             // wave's A half
     const int b_base = 2 * HALF_BYTES + wn * TN * ROWB;                             // wave's TN rows of the B region
-
-    f32x4 acc[8][FN];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4][2], b0[2][2], b1[NB1][2];
-
     const int nk = p.K / BK;
-    // ---- prologue ----------------------------------------------------------------------------------------------
-    dma_B(0, 0);
-    dma_A(0, 0);
-    if (nk > 1) {
-        dma_B(1, BK);
-        if (NBI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    SC_BAR();
-    if (wm == 1) SC_BAR();                       // stagger the second wave group by one barrier interval
+
+    int iter_ = 0;
+#define SC_STAMP(K)                                                                                          \
+    do {                                                                                                     \
+        if (DIAG == 4 && (blockIdx.x & 63) == 0 && lane == 0 && iter_ < 8)                                   \
+            ((long long*)p.Ct)[(((blockIdx.x >> 6) * 8 + iter_) * 8 + wave) * 8 + (K)] = wall_clock64();     \
+    } while (0)
 
 #define SC_MFMA_QUAD(MS, NS, BF)                                                                         \
     do {                                                                                                 \
@@ -146,155 +153,218 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         __builtin_amdgcn_s_setprio(0);                                                                   \
     } while (0)
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int par = kt & 1;
-        const char* as = smem + par * BUF_BYTES + a_base;
-        const char* bs = smem + par * BUF_BYTES + b_base;
-        // ---------------- P0
+    // ---- first tile: K-tile 0 into buffer 0 -------------------------------------------------------------------
+    int vb = blockIdx.x, m0, n0, base = 0;
+    tile_of(vb, m0, n0);
+    set_sources(m0, n0);
+    dma_B(0, 0);
+    dma_A(0, 0);
+
+    while (true) {
+        SC_STAMP(0);
+        // accumulators start from the bias (a lane's fragment column is fixed: n = wave's first column + 16 ni + lane % 16),
+        // so the epilogue neither waits on a bias load nor spends an add per element
+        f32x4 acc[8][FN];
+        int bl = lane & 15;
+        asm volatile("" : "+v"(bl));
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            b0[ni][0] = *(const bf16x8*)(bs + ni * 16 * ROWB + frag_off0);
-            b0[ni][1] = *(const bf16x8*)(bs + ni * 16 * ROWB + frag_off1);
-        }
+        for (int ni = 0; ni < FN; ++ni) {
+            const int n = n0 + wn * TN + ni * 16 + bl;
+            const float bvn = (bias && n < p.N) ? bias[n] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            af[mi][0] = *(const bf16x8*)(as + mi * 16 * ROWB + frag_off0);
-            af[mi][1] = *(const bf16x8*)(as + mi * 16 * ROWB + frag_off1);
+            for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = f32x4{bvn, bvn, bvn, bvn};
         }
+        bf16x8 af[4][2], b0[2][2], b1[NB1][2];
+
+        // ---- prologue: A(0), B(0) are in flight (issued before the previous epilogue); B(1) goes to the other buffer ----
+        if (nk > 1) {
+            dma_B(base ^ 1, BK);
+            SC_WAIT_NBI();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        SC_STAMP(1);
         SC_BAR();
-        SC_MFMA_QUAD(0, 0, b0);
-        SC_BAR();
-        // ---------------- P1
+        if (wm == 1) SC_BAR();                       // stagger the second wave group by one barrier interval
+
+        int kt = 0;
+        do {                                         // nk >= 1 (checked by the launcher): no zero-trip path to carry acc through
+            const int par = (kt + base) & 1;
+            const char* as = smem + par * BUF_BYTES + a_base;
+            const char* bs = smem + par * BUF_BYTES + b_base;
+            // ---------------- P0
 #pragma unroll
-        for (int ni = 0; ni < NB1; ++ni) {
-            b1[ni][0] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off0);
-            b1[ni][1] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off1);
-        }
-        if (DIAG != 1 && kt + 1 < nk) dma_A(par ^ 1, (kt + 1) * BK);
-        SC_BAR();
-        SC_MFMA_QUAD(0, 1, b1);
-        SC_BAR();
-        // ---------------- P2
+            for (int ni = 0; ni < 2; ++ni) {
+                b0[ni][0] = *(const bf16x8*)(bs + ni * 16 * ROWB + frag_off0);
+                b0[ni][1] = *(const bf16x8*)(bs + ni * 16 * ROWB + frag_off1);
+            }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            af[mi][0] = *(const bf16x8*)(as + (4 + mi) * 16 * ROWB + frag_off0);
-            af[mi][1] = *(const bf16x8*)(as + (4 + mi) * 16 * ROWB + frag_off1);
-        }
-        SC_BAR();
-        SC_MFMA_QUAD(1, 1, b1);
-        SC_BAR();
-        // ---------------- P3
-        if (DIAG == 0) {
+            for (int mi = 0; mi < 4; ++mi) {
+                af[mi][0] = *(const bf16x8*)(as + mi * 16 * ROWB + frag_off0);
+                af[mi][1] = *(const bf16x8*)(as + mi * 16 * ROWB + frag_off1);
+            }
+            SC_BAR();
+            SC_MFMA_QUAD(0, 0, b0);
+            SC_BAR();
+            // ---------------- P1
+#pragma unroll
+            for (int ni = 0; ni < NB1; ++ni) {
+                b1[ni][0] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off0);
+                b1[ni][1] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off1);
+            }
+            if (kt + 1 < nk) dma_A(par ^ 1, (kt + 1) * BK);
+            SC_BAR();
+            SC_MFMA_QUAD(0, 1, b1);
+            SC_BAR();
+            // ---------------- P2
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                af[mi][0] = *(const bf16x8*)(as + (4 + mi) * 16 * ROWB + frag_off0);
+                af[mi][1] = *(const bf16x8*)(as + (4 + mi) * 16 * ROWB + frag_off1);
+            }
+            SC_BAR();
+            SC_MFMA_QUAD(1, 1, b1);
+            SC_BAR();
+            // ---------------- P3
             if (kt + 2 < nk) {
                 dma_B(par, (kt + 2) * BK);
-                if (NBI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                SC_WAIT_NBI();
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-        } else if (DIAG == 2) {
-            if (kt + 2 < nk) dma_B(par, (kt + 2) * BK);
-        }
-        SC_BAR();
-        SC_MFMA_QUAD(1, 0, b0);
-        SC_BAR();
-    }
-    if (wm == 0) SC_BAR();                       // pairs the staggered group's last barrier
-    if (DIAG != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SC_BAR();
+            SC_MFMA_QUAD(1, 0, b0);
+            SC_BAR();
+        } while (++kt < nk);
+        if (wm == 0) SC_BAR();                       // pairs the staggered group's last barrier
+        SC_STAMP(2);
 
-    // ---- epilogue: each wave streams its 128 x TN block through a private 16 KiB LDS region, 64 rows a pass --------
-    float* Cw = (float*)(smem + wave * 16384);
-    const bool transposed = (p.n_split >= 0) && (n0 >= p.n_split);
-    const int wn0 = n0 + wn * TN;                // wave's first column
-    constexpr int CPR = TN / 8;                  // 8-column chunks per row
-    float bv[FN];
+        // ---- next tile's K-tile 0 into the buffer the last K-tile did not use (its last reads are a K-tile old) ---------
+        const int last_par = (nk - 1 + base) & 1;
+        const int cm0 = m0, cn0 = n0;
+        vb += gridDim.x;
+        const bool has_next = vb < n_tiles;
+        if (has_next) {
+            tile_of(vb, m0, n0);
+            set_sources(m0, n0);
+            base = last_par ^ 1;
+            dma_B(base, 0);
+            dma_A(base, 0);
+        }
+
+        if (DIAG == 3) {                             // timing-only: consume the accumulators without an epilogue
+            float t = 0.f;
 #pragma unroll
-    for (int ni = 0; ni < FN; ++ni) {
-        const int n = wn0 + ni * 16 + (lane & 15);
-        bv[ni] = (bias && n < p.N) ? bias[n] : 0.f;
-    }
+            for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-        const int wm0 = m0 + wm * 128 + ms * 64;   // first row of this pass
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < FN; ++ni) {
-                f32x4 v = acc[ms * 4 + mi][ni];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bv[ni];
-                if (p.act == 1) {
-                    const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
-                    v = f32x4{g0.x, g0.y, g1.x, g1.y};
-                }
-                const int ml = mi * 16 + 4 * (lane >> 4), nl = ni * 16 + (lane & 15);
-                if (transposed) {
-                    *(f32x4*)(Cw + nl * 64 + ml) = v;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Cw[(ml + r) * TN + nl] = v[r];
-                }
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!transposed) {
-#pragma unroll
-            for (int it = 0; it < CPR; ++it) {
-                const int q = it * 64 + lane;
-                const int row = q / CPR, cc = q % CPR;
-                const int m = wm0 + row, n = wn0 + cc * 8;
-                if (m < p.M && n + 8 <= p.N) {
-                    const f32x4 lo = *(const f32x4*)(Cw + row * TN + cc * 8);
-                    const f32x4 hi = *(const f32x4*)(Cw + row * TN + cc * 8 + 4);
-                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    if (Rs) {
-                        const uint4 rv = *(const uint4*)(Rs + (int64_t)m * p.ldr + n);
-                        v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
-                        v[4] += bflo(rv.z); v[5] += bfhi(rv.z); v[6] += bflo(rv.w); v[7] += bfhi(rv.w);
-                    }
-                    if (p.out_f32) {
-                        float* C = (float*)p.C + coff + (int64_t)m * p.ldc + n;
-                        *(f32x4*)C = f32x4{v[0], v[1], v[2], v[3]};
-                        *(f32x4*)(C + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                    } else {
-                        uint16_t* C = (uint16_t*)p.C + coff + (int64_t)m * p.ldc + n;
-                        uint4 o;
-                        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                        o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-                        *(uint4*)C = o;
-                    }
-                }
-            }
+                for (int ni = 0; ni < FN; ++ni) t += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+            if (t == 123.456f) ((float*)p.C)[tid] = t;
         } else {
-            const int H = (p.N - p.n_split) / p.dh;
+            // ---- epilogue: each wave streams its 128 x TN block through a private 8 KiB region of buffer last_par,
+            //      32 rows a pass: fragments -> LDS (fp32) -> full 16-B row chunks -> +residual -> bf16 stores ----------
+            // lane id re-materialised through an opaque asm: everything below that depends only on the lane would otherwise be
+            // hoisted out of the tile loop as loop-invariant and stay live across the K loop (VGPR budget: 256)
+            int el = lane;
+            asm volatile("" : "+v"(el));
+            float* Cw = (float*)(smem + last_par * BUF_BYTES + wave * EPI_BYTES);
+            const bool transposed = (p.n_split >= 0) && (cn0 >= p.n_split);
+            const int wn0 = cn0 + wn * TN;                // wave's first column
+            constexpr int CPR = TN / 8;                   // 8-column chunks per row
+            constexpr int TNP = TN == 48 ? 52 : TN;       // LDS row pitch in floats (48: padded against bank conflicts)
 #pragma unroll
-            for (int it = 0; it < CPR; ++it) {
-                const int q = it * 64 + lane;
-                const int nrow = q >> 3, mc = q & 7;
-                const int m = wm0 + mc * 8, n = wn0 + nrow;
-                if (m < p.M && n < p.N) {
-                    const f32x4 lo = *(const f32x4*)(Cw + nrow * 64 + mc * 8);
-                    const f32x4 hi = *(const f32x4*)(Cw + nrow * 64 + mc * 8 + 4);
-                    const int nn = n - p.n_split, hh = nn / p.dh, d = nn % p.dh;
-                    const int b = m / p.R, t = m % p.R;
-                    uint16_t* dst = p.Ct + (((int64_t)b * H + hh) * p.dh + d) * p.R + t;
-                    uint4 o;
-                    o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]);
-                    o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
-                    *(uint4*)dst = o;
+            for (int ms = 0; ms < 4; ++ms) {
+                const int wm0 = cm0 + wm * 128 + ms * 32;   // first row of this pass
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < FN; ++ni) {
+                        f32x4 v = acc[ms * 2 + mi][ni];
+                        if (ACT == 1) {
+                            const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+                            v = f32x4{g0.x, g0.y, g1.x, g1.y};
+                        }
+                        const int ml = mi * 16 + 4 * (el >> 4), nl = ni * 16 + (el & 15);
+                        if (transposed) {
+                            *(f32x4*)(Cw + nl * 32 + ml) = v;
+                        } else {
+                            // the four el groups hold rows 4 apart: with a 64-float pitch they would share banks, so
+                            // 16-column blocks are XOR-swizzled by (row >> 2) & 3 = el >> 4 (TN = 64) / rows padded (TN = 48)
+                            const int ns = TN == 64 ? (nl ^ ((el >> 4) << 4)) : nl;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) Cw[(ml + r) * TNP + ns] = v[r];
+                        }
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);   // keep each pass's address arithmetic inside the pass (VGPR budget)
+                if (ms == 0) SC_STAMP(3);
+                if (!transposed) {
+#pragma unroll
+                    for (int it = 0; it < CPR / 2; ++it) {
+                        const int q = it * 64 + el;
+                        const int row = q / CPR, cc = q % CPR;
+                        const int m = wm0 + row, n = wn0 + cc * 8;
+                        if (m < p.M && n + 8 <= p.N) {
+                            const int cs = TN == 64 ? ((cc * 8) ^ (((row >> 2) & 3) << 4)) : cc * 8;
+                            const f32x4 lo = *(const f32x4*)(Cw + row * TNP + cs);
+                            const f32x4 hi = *(const f32x4*)(Cw + row * TNP + cs + 4);
+                            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            if (Rs) {
+                                const uint4 rv = *(const uint4*)(Rs + (int64_t)m * p.ldr + n);
+                                v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
+                                v[4] += bflo(rv.z); v[5] += bfhi(rv.z); v[6] += bflo(rv.w); v[7] += bfhi(rv.w);
+                            }
+                            if (p.out_f32) {
+                                float* C = (float*)p.C + coff + (int64_t)m * p.ldc + n;
+                                *(f32x4*)C = f32x4{v[0], v[1], v[2], v[3]};
+                                *(f32x4*)(C + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                            } else {
+                                uint16_t* C = (uint16_t*)p.C + coff + (int64_t)m * p.ldc + n;
+                                uint4 o;
+                                o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                                o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+                                *(uint4*)C = o;
+                            }
+                        }
+                    }
+                } else {
+                    const int H = (p.N - p.n_split) / p.dh;
+#pragma unroll
+                    for (int it = 0; it < TN / 16; ++it) {
+                        const int q = it * 64 + el;
+                        const int nrow = q >> 2, mc = q & 3;
+                        const int m = wm0 + mc * 8, n = wn0 + nrow;
+                        if (m < p.M && n < p.N) {
+                            const f32x4 lo = *(const f32x4*)(Cw + nrow * 32 + mc * 8);
+                            const f32x4 hi = *(const f32x4*)(Cw + nrow * 32 + mc * 8 + 4);
+                            const int nn = n - p.n_split, hh = nn / p.dh, d = nn % p.dh;
+                            const int b = m / p.R, t = m % p.R;
+                            uint16_t* dst = p.Ct + (((int64_t)b * H + hh) * p.dh + d) * p.R + t;
+                            uint4 o;
+                            o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]);
+                            o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
+                            *(uint4*)dst = o;
+                        }
+                    }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (ms == 0) SC_STAMP(4);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SC_STAMP(5);
+        ++iter_;
+        if (!has_next) break;
+        SC_BAR();                                    // every wave is done with its staging region before B(1) lands in it
     }
 }
 
 }  // namespace
 
-template <int DIAG, int BN>
-static int launch256(const sc_gemm_args& a, hipStream_t s) {
+template <int DIAG, int BN, int ACT>
+static int launch256_(const sc_gemm_args& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DIAG, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DIAG, BN, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) {
             sc_set_error("hipFuncSetAttribute(gemm256): %s", hipGetErrorString(e));
             return -3;
@@ -302,22 +372,28 @@ static int launch256(const sc_gemm_args& a, hipStream_t s) {
         attr_set = true;
     }
     const int nM = (a.M + 255) / 256, nN = (a.N + BN - 1) / BN;
-    dim3 grid(nM * nN, 1, a.nb1 * a.nb2);
-    hipLaunchKernelGGL((gemm256_kernel<DIAG, BN>), grid, dim3(512), LDS_BYTES, s, a);
+    dim3 grid(std::min(nM * nN, sc_num_cus()), 1, a.nb1 * a.nb2);
+    hipLaunchKernelGGL((gemm256_kernel<DIAG, BN, ACT>), grid, dim3(512), LDS_BYTES, s, a);
     SC_LAUNCH_CHECK();
     return 0;
 }
 
-// rounds of 256 workgroups the grid needs with BN-wide tiles, times a per-tile efficiency factor
+template <int DIAG, int BN>
+static int launch256(const sc_gemm_args& a, hipStream_t s) {
+    return a.act == 1 ? launch256_<DIAG, BN, 1>(a, s) : launch256_<DIAG, BN, 0>(a, s);
+}
+
+// rounds of workgroups the grid needs with BN-wide tiles, times a per-tile efficiency factor
 static double tile_cost(const sc_gemm_args& a, int BN) {
     const double tiles = (double)((a.M + 255) / 256) * ((a.N + BN - 1) / BN) * a.nb1 * a.nb2;
-    const double rounds = (double)(((long)tiles + 255) / 256);
+    const int cus = sc_num_cus();
+    const double rounds = (double)(((long)tiles + cus - 1) / cus);
     return rounds * BN * (BN == 192 ? 1.12 : 1.0);       // measured: a 256 x 192 tile runs ~12 % below the 256 x 256 rate
 }
 
 int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s) {
-    if (a.tile == 12) return launch256<1, 256>(a, s);   // diagnostics only (tools/bench_gemm.py)
-    if (a.tile == 22) return launch256<2, 256>(a, s);
+    if (a.tile == 32) return launch256<3, 256>(a, s);   // diagnostics only (tools/epi_probe.py, tools/epi_stamps.py)
+    if (a.tile == 34) return launch256<4, 256>(a, s);
     if (a.tile == 7) return launch256<0, 192>(a, s);
     if (a.tile == 8) return launch256<0, 256>(a, s);
     const bool ok192 = (a.n_split < 0 || a.n_split % 192 == 0);

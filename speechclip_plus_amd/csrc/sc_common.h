@@ -85,6 +85,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // host side
 void sc_set_error(const char* fmt, ...);
+int sc_num_cus();   // compute units of the current device (immutable cache; 256 on MI355X)
 #define SC_CHECK(cond, ...)                 \
     do {                                    \
         if (!(cond)) {                      \
