@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=2, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape GEMM timing table to stderr")
     ap.add_argument("--model", choices=["base", "large", "cascaded_plus", "hybrid_plus_large"], default="base",
                     help="base = BASELINE configs[1] (headline); large = Parallel large; cascaded_plus = configs[2]; "
                          "hybrid_plus_large = configs[4] recipe on one GPU")
@@ -137,6 +138,11 @@ def main():
         extra = {}
         if timer is not None:
             summ = timer.summary()
+            if args.gemm_shapes:                                 # per-shape table on stderr (diagnostics; not part of the JSON line)
+                import sys as _sys
+                for tag, r in sorted(timer.summary_by_tag().items(), key=lambda kv: -kv[1]["ms"]):
+                    print(f"[gemm] {tag:58s} {r['launches'] // args.steps:3d}/step  {r['ms'] * 1e3 / r['launches']:8.1f} us  "
+                          f"{r['work'] / (r['ms'] * 1e-3) / 1e12:7.1f} TF/s  {r['ms'] / args.steps:6.3f} ms/step", file=_sys.stderr)
             dom_name = max((k for k in summ if k.startswith("gemm_bf16_")), key=lambda k: summ[k]["ms"])
             dom = summ[dom_name]
             tflops = dom["work"] / (dom["ms"] * 1e-3) / 1e12

@@ -113,11 +113,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
         for (int kk = 0; kk < 2; ++kk) b_off[ni][kk] = row * ROWB + (((kk * 4 + (lane >> 4)) ^ ((row >> 1) & 7)) << 4);
     }
 
+    // accumulators start from the bias (same summation order as gemm256_bf16.hip: the tile variants agree bitwise)
     f32x4 acc[FM][FN];
 #pragma unroll
-    for (int mi = 0; mi < FM; ++mi)
+    for (int ni = 0; ni < FN; ++ni) {
+        const int n = n0 + wn * TN + ni * 16 + (lane & 15);
+        const float bv = (bias && n < p.N) ? bias[n] : 0.f;
 #pragma unroll
-        for (int ni = 0; ni < FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < FM; ++mi) acc[mi][ni] = f32x4{bv, bv, bv, bv};
+    }
 
     const int nk = p.K / BK;
     stage(0, 0);
@@ -155,8 +159,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
         for (int mi = 0; mi < FM; ++mi) {
             const int ml = wm * TM + mi * 16 + 4 * (lane >> 4);
             f32x4 v = acc[mi][ni];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bv;
             if (p.act == 1) {
                 const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
                 v = f32x4{g0.x, g0.y, g1.x, g1.y};
@@ -278,7 +280,7 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     }
     switch (tile) {
         case 1: return launch<128, 128>(a, s);
-        case 2: case 32: case 34: case 7: case 8:   // 2 = 256-row tile, width (256 / 192) chosen by wave quantisation; 7 / 8 force it
+        case 2: case 32: case 34: case 35: case 7: case 8:   // 2 = 256-row tile, width (256 / 192) chosen by wave quantisation; 7 / 8 force it
             SC_CHECK(a.n_split < 0 || a.n_split % 192 == 0 || a.n_split % 256 == 0,
                      "sc_gemm_bf16: 256-row tiles need n_split %% 192 == 0 or %% 256 == 0");
             return sc_gemm256_launch(a, s);

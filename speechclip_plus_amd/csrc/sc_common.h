@@ -23,48 +23,53 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 __device__ __forceinline__ float bflo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 // erf-GELU (fairseq nn.GELU() / torch "gelu"):  x * Phi(x),  Phi(x) = 0.5 (1 + erf(x / sqrt 2)).
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off level): one v_rcp, one v_exp and a
-// degree-5 Horner chain instead of libm erff's ~40 instructions - the GELU epilogue of FC1 / the conv stack and the
-// conv-0 kernel are VALU-bound on it.  The lower tail is formed without cancellation (Phi(x<0) = 0.5 poly e).
+// erfc by Abramowitz-Stegun 7.1.28: erfc(z) = (1 + a1 z + ... + a6 z^6)^-16, |err| <= 3e-7 (7e-7 measured in fp32 incl.
+// the four squarings) - ONE transcendental (v_rcp) and packed-fp32 FMAs instead of libm erff's ~40 instructions or the
+// rcp + exp of 7.1.26: the GELU epilogues of FC1 / the conv stack and the conv-0 kernel are VALU-bound on it.
+// gelu(x) = 0.5 x (1 + sign(x) (1 - erfc|z|)) = (h + |h|) - |h| erfc(|z|),  h = x / 2: no select, no cancellation in the
+// lower tail.  Overflow of the 16th power gives rcp(inf) = 0 = the right limit.
 __device__ __forceinline__ float gelu_erf(float x) {
 #pragma clang fp contract(off)   // identical rounding in every kernel that inlines it
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(t, 1.061405429f, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float half_tail = 0.5f * poly * e;                 // = Phi(-|x|)
-    const float phi = x >= 0.f ? 1.0f - half_tail : half_tail;
-    return x * phi;
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752f;
+    float p = fmaf(0.0000430638f, z, 0.0002765672f);
+    p = fmaf(p, z, 0.0001520143f);
+    p = fmaf(p, z, 0.0092705272f);
+    p = fmaf(p, z, 0.0422820123f);
+    p = fmaf(p, z, 0.0705230784f);
+    p = fmaf(p, z, 1.0f);
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    const float r = __builtin_amdgcn_rcpf(p);                // erfc(|z|)
+    const float h = x * 0.5f, ah = ax * 0.5f;
+    return fmaf(-ah, r, h + ah);
 }
 
-// two elements at a time: the polynomial and the scalings become packed fp32 ops (v_pk_fma_f32 / v_pk_mul_f32, two
-// lanes' worth of work per issue slot); rcp / exp2 stay scalar (transcendental unit).
+// two elements at a time: the polynomial, squarings and scalings become packed fp32 ops (v_pk_fma_f32 / v_pk_mul_f32,
+// two lanes' worth of work per issue slot); only the rcp stays scalar (transcendental unit).  Same operation order as
+// gelu_erf => bitwise identical results.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 #pragma clang fp contract(off)
     f32x2 ax;
     ax.x = fabsf(x.x); ax.y = fabsf(x.y);
     const f32x2 z = ax * 0.70710678118654752f;
-    const f32x2 den = __builtin_elementwise_fma(z, f32x2{0.3275911f, 0.3275911f}, f32x2{1.0f, 1.0f});
-    f32x2 t;
-    t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
-    f32x2 poly = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
-    poly = __builtin_elementwise_fma(poly, t, f32x2{1.421413741f, 1.421413741f});
-    poly = __builtin_elementwise_fma(poly, t, f32x2{-0.284496736f, -0.284496736f});
-    poly = __builtin_elementwise_fma(poly, t, f32x2{0.254829592f, 0.254829592f});
-    poly = poly * t;
-    const f32x2 ex = z * z * -1.4426950408889634f;
-    f32x2 e;
-    e.x = __builtin_amdgcn_exp2f(ex.x); e.y = __builtin_amdgcn_exp2f(ex.y);
-    const f32x2 half_tail = poly * e * 0.5f;
-    f32x2 phi;
-    phi.x = x.x >= 0.f ? 1.0f - half_tail.x : half_tail.x;
-    phi.y = x.y >= 0.f ? 1.0f - half_tail.y : half_tail.y;
-    return x * phi;
+    f32x2 p = __builtin_elementwise_fma(f32x2{0.0000430638f, 0.0000430638f}, z, f32x2{0.0002765672f, 0.0002765672f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0001520143f, 0.0001520143f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0092705272f, 0.0092705272f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0422820123f, 0.0422820123f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0705230784f, 0.0705230784f});
+    p = __builtin_elementwise_fma(p, z, f32x2{1.0f, 1.0f});
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(p.x); r.y = __builtin_amdgcn_rcpf(p.y);
+    const f32x2 h = x * 0.5f, ah = ax * 0.5f;
+    return __builtin_elementwise_fma(-ah, r, h + ah);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

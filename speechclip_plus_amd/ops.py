@@ -29,9 +29,16 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}
+        self.tagged = {}
 
-    def add(self, name, start, end, work):
+    def add(self, name, start, end, work, tag=None):
         self.records.setdefault(name, []).append((start, end, work))
+        if tag is not None:
+            self.tagged.setdefault(tag, []).append((start, end, work))
+
+    def summary_by_tag(self):
+        return {tag: {"launches": len(r), "ms": sum(s.elapsed_time(e) for s, e, _ in r), "work": float(sum(w for _, _, w in r))}
+                for tag, r in self.tagged.items()}
 
     def summary(self):
         out = {}
@@ -96,7 +103,8 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
     ev1.record()
     rows = (M if alg_rows is None else alg_rows) * nb1 * nb2
-    _timer.add("gemm_bf16_" + gemm_tile_name(M, N, K, n_split, nb1 * nb2, tile), ev0, ev1, 2.0 * rows * N * K)
+    _timer.add("gemm_bf16_" + gemm_tile_name(M, N, K, n_split, nb1 * nb2, tile), ev0, ev1, 2.0 * rows * N * K,
+               tag=f"M{M} N{N} K{K} lda{lda} act{act} res{int(residual is not None)} z{nb1 * nb2}")
 
 
 def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
