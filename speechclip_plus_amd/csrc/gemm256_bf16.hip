@@ -271,6 +271,53 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             const int wn0 = cn0 + wn * TN;                // wave's first column
             constexpr int CPR = TN / 8;                   // 8-column chunks per row
             constexpr int TNP = TN == 48 ? 52 : TN;       // LDS row pitch in floats (48: padded against bank conflicts)
+            if (transposed) {
+                // V^T store (QKV GEMM, columns >= n_split): passes of 64 rows (m) x 32 columns (n) staged as [n][64 m] so a
+                // column's 64 consecutive frames leave as one full 128-B line; 16-B m-chunks XOR-swizzled by n & 15 (the 16
+                // lanes of a fragment row group write the same m-chunk of 16 different n: 256-B stride otherwise)
+                const int H = (p.N - p.n_split) / p.dh;
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int ng = 0; ng < (FN + 1) / 2; ++ng) {
+                        const int nfr = (FN - 2 * ng) < 2 ? (FN - 2 * ng) : 2;      // fragments (16 n each) in this pass
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                            for (int nj = 0; nj < 2; ++nj) {
+                                if (nj >= nfr) continue;
+                                f32x4 v = acc[mh * 4 + mi][ng * 2 + nj];
+                                if (ACT == 1) {
+                                    const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+                                    v = f32x4{g0.x, g0.y, g1.x, g1.y};
+                                }
+                                const int nl = nj * 16 + (el & 15), mlc = mi * 4 + (el >> 4);
+                                *(f32x4*)(Cw + nl * 64 + ((mlc ^ (nl & 15)) << 2)) = v;
+                            }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            if (it >= 2 * nfr) continue;
+                            const int q = it * 64 + el;
+                            const int nrow = q >> 3, mc = q & 7;
+                            const int m = cm0 + wm * 128 + mh * 64 + mc * 8, n = wn0 + ng * 32 + nrow;
+                            if (m < p.M && n < p.N) {
+                                const f32x4 lo = *(const f32x4*)(Cw + nrow * 64 + (((2 * mc) ^ (nrow & 15)) << 2));
+                                const f32x4 hi = *(const f32x4*)(Cw + nrow * 64 + (((2 * mc + 1) ^ (nrow & 15)) << 2));
+                                const int nn = n - p.n_split, hh = nn / p.dh, d = nn % p.dh;
+                                const int b = m / p.R, t = m % p.R;
+                                uint16_t* dst = p.Ct + (((int64_t)b * H + hh) * p.dh + d) * p.R + t;
+                                uint4 o;
+                                o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]);
+                                o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
+                                *(uint4*)dst = o;
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            } else {
 #pragma unroll
             for (int ms = 0; ms < 4; ++ms) {
                 const int wm0 = cm0 + wm * 128 + ms * 32;   // first row of this pass
@@ -284,20 +331,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                             v = f32x4{g0.x, g0.y, g1.x, g1.y};
                         }
                         const int ml = mi * 16 + 4 * (el >> 4), nl = ni * 16 + (el & 15);
-                        if (transposed) {
-                            *(f32x4*)(Cw + nl * 32 + ml) = v;
-                        } else {
-                            // the four el groups hold rows 4 apart: with a 64-float pitch they would share banks, so
-                            // 16-column blocks are XOR-swizzled by (row >> 2) & 3 = el >> 4 (TN = 64) / rows padded (TN = 48)
-                            const int ns = TN == 64 ? (nl ^ ((el >> 4) << 4)) : nl;
+                        // the four lane groups hold rows 4 apart: with a 64-float pitch they would share banks, so
+                        // 16-column blocks are XOR-swizzled by (row >> 2) & 3 = lane >> 4 (TN = 64) / rows padded (TN = 48)
+                        const int ns = TN == 64 ? (nl ^ ((el >> 4) << 4)) : nl;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) Cw[(ml + r) * TNP + ns] = v[r];
-                        }
+                        for (int r = 0; r < 4; ++r) Cw[(ml + r) * TNP + ns] = v[r];
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);   // keep each pass's address arithmetic inside the pass (VGPR budget)
                 if (ms == 0) SC_STAMP(3);
-                if (!transposed) {
+                {
 #pragma unroll
                     for (int it = 0; it < CPR / 2; ++it) {
                         const int q = it * 64 + el;
@@ -327,29 +370,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                             }
                         }
                     }
-                } else {
-                    const int H = (p.N - p.n_split) / p.dh;
-#pragma unroll
-                    for (int it = 0; it < TN / 16; ++it) {
-                        const int q = it * 64 + el;
-                        const int nrow = q >> 2, mc = q & 3;
-                        const int m = wm0 + mc * 8, n = wn0 + nrow;
-                        if (m < p.M && n < p.N) {
-                            const f32x4 lo = *(const f32x4*)(Cw + nrow * 32 + mc * 8);
-                            const f32x4 hi = *(const f32x4*)(Cw + nrow * 32 + mc * 8 + 4);
-                            const int nn = n - p.n_split, hh = nn / p.dh, d = nn % p.dh;
-                            const int b = m / p.R, t = m % p.R;
-                            uint16_t* dst = p.Ct + (((int64_t)b * H + hh) * p.dh + d) * p.R + t;
-                            uint4 o;
-                            o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]);
-                            o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
-                            *(uint4*)dst = o;
-                        }
-                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 if (ms == 0) SC_STAMP(4);
+            }
             }
         }
         SC_STAMP(5);

@@ -10,7 +10,8 @@ torch.manual_seed(0)
 B, R, D, F, C = 64, 512, 768, 3072, 512
 M = B * R
 shapes = [("conv1", B * 32 * R, C, 3 * C, 2 * C, False), ("conv4", B * 4 * R, C, 3 * C, 2 * C, False),
-          ("fc1", M, F, D, None, False), ("fc2", M, D, F, None, True), ("qkv", M, 3 * D, D, None, False)]
+          ("fc1", M, F, D, None, False), ("fc2", M, D, F, None, True), ("qkv", M, 3 * D, D, None, False),
+          ("qkvT", M, 3 * D, D, None, False), ("oproj", M, D, D, None, True)]
 # variant = tile:act[:lib]   lib 0 = in-tree build, 1 = tools/_ab/lib_base.so (a previous build kept for same-process A/B)
 variants = [tuple(int(x) for x in (v + ":0").split(":")[:3]) for v in (sys.argv[1] if len(sys.argv) > 1 else "8:1,8:1:1,8:0,8:0:1,32:0,32:0:1").split(",")]
 import ctypes
@@ -45,6 +46,10 @@ for name, m, n, k, lda, res in shapes:
             d = (outs[v].float() - outs[ref[0]].float()).abs().max()
             print("  check", v, "vs", ref[0], "equal", bool(torch.equal(outs[v], outs[ref[0]])), "maxdiff", float(d))
     del outs
+    kw = {}
+    if name == "qkvT":                              # production QKV: V columns stored transposed per head
+        Cm = torch.empty(m, 2 * D, device=dev, dtype=torch.bfloat16)
+        kw = dict(Ct=torch.empty(B, 12, 64, R, device=dev, dtype=torch.bfloat16), n_split=2 * D, R=R, dh=64)
     times = {v: [] for v in variants}
     for r in range(rounds + 1):
         for v in variants:
@@ -52,7 +57,7 @@ for name, m, n, k, lda, res in shapes:
             use(v)
             e0.record()
             for _ in range(3):
-                ops.gemm_raw(A, lda, W, k, Cm, n, m, n, k, bias=bias, residual=Rm, ldr=n, act=v[1], tile=v[0])
+                ops.gemm_raw(A, lda, W, k, Cm, Cm.shape[1], m, n, k, bias=bias, residual=Rm, ldr=n, act=v[1], tile=v[0], **kw)
             e1.record()
             torch.cuda.synchronize()
             if r > 0:
