@@ -365,8 +365,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                                 uint4 o;
                                 o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
                                 o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-                                if (DIAG == 5) { typedef __attribute__((ext_vector_type(4))) unsigned u32x4; __builtin_nontemporal_store(u32x4{o.x, o.y, o.z, o.w}, (u32x4*)C); }
-                                else *(uint4*)C = o;
+                                if (p.reserved & 1) {
+                                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                                    __builtin_nontemporal_store(u32x4{o.x, o.y, o.z, o.w}, (u32x4*)C);
+                                } else {
+                                    *(uint4*)C = o;
+                                }
                             }
                         }
                     }
@@ -417,10 +421,11 @@ static double tile_cost(const sc_gemm_args& a, int BN) {
     return rounds * BN * (BN == 192 ? 1.12 : 1.0);       // measured: a 256 x 192 tile runs ~12 % below the 256 x 256 rate
 }
 
-int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s) {
+int sc_gemm256_launch(const sc_gemm_args& a_in, hipStream_t s) {
+    sc_gemm_args a = a_in;
+    a.reserved = a_in.reserved == 1 || (a_in.reserved == 0 && a_in.residual != nullptr);   // bit 0: non-temporal C stores
     if (a.tile == 32) return launch256<3, 256>(a, s);   // diagnostics only (tools/epi_probe.py, tools/epi_stamps.py)
     if (a.tile == 34) return launch256<4, 256>(a, s);
-    if (a.tile == 35) return launch256<5, 256>(a, s);
     if (a.tile == 7) return launch256<0, 192>(a, s);
     if (a.tile == 8) return launch256<0, 256>(a, s);
     const bool ok192 = (a.n_split < 0 || a.n_split % 192 == 0);

@@ -280,7 +280,7 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     }
     switch (tile) {
         case 1: return launch<128, 128>(a, s);
-        case 2: case 32: case 34: case 35: case 7: case 8:   // 2 = 256-row tile, width (256 / 192) chosen by wave quantisation; 7 / 8 force it
+        case 2: case 32: case 34: case 7: case 8:   // 2 = 256-row tile, width (256 / 192) chosen by wave quantisation; 7 / 8 force it
             SC_CHECK(a.n_split < 0 || a.n_split % 192 == 0 || a.n_split % 256 == 0,
                      "sc_gemm_bf16: 256-row tiles need n_split %% 192 == 0 or %% 256 == 0");
             return sc_gemm256_launch(a, s);
