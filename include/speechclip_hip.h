@@ -160,6 +160,31 @@ int sc_sgemm_f32(const float* A, int64_t sai, int64_t sak, const float* Bm, int6
                  int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, const float* bias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * One-row-per-utterance tail of the parallel head in fp32 on the master weights:
+ *   nn.TransformerEncoderLayer (post-LN, GELU) row 0 + final LayerNorm + Linear, as instantiated by
+ *   avssl/module/kw_modules/TransformerModels.py:48-97 and consumed at avssl/model/kw_branches.py:266-280.
+ *   sc_sgemm_f32_ex : C[z][i,j] = alpha sum_k A[z][i*sai + k*sak] B[z][j*sbj + k*sbk] (+ bias[z][j]) + beta C[z][i,j]
+ *                     (beta = 1 accumulates weight gradients straight into the flat gradient buffer; with a workspace,
+ *                     few-tile products are split along K and the slices reduced in order)
+ *   sc_rowln_f32_fwd: y = LayerNorm(x + res) gamma + beta ; res_stride 0 broadcasts one residual row (the CLS token)
+ *   sc_rowln_f32_bwd: dx ; dgamma += sum_rows dy xhat ; dbeta += sum_rows dy   (fixed row order, no atomics)
+ *   sc_gelu_f32     : df == NULL: out = gelu(u) (erf form) ; else out = df * gelu'(u)
+ *   sc_colsum_f32   : out[j] = beta out[j] + alpha sum_i x[i*ld + j]
+ *   sc_headmask_f32 : dir 0: Qm[h,j] = q[j] if j / dh == h else 0 ; dir 1: q[j] = Qm[j / dh, j]
+ * ---------------------------------------------------------------------------------------------- */
+int sc_sgemm_f32_ex(const float* A, int64_t sai, int64_t sak, int64_t saz, const float* Bm, int64_t sbj, int64_t sbk,
+                    int64_t sbz, float* C, int64_t ldc, int64_t scz, int32_t M, int32_t N, int32_t K, int32_t nbatch,
+                    float alpha, float beta, const float* bias, int64_t sbiasz, float* workspace, int64_t workspace_floats,
+                    void* stream);
+int sc_rowln_f32_fwd(const float* x, const float* res, int64_t res_stride, const float* gamma, const float* beta, float* y,
+                     float* xhat, float* rstd, int32_t rows, int32_t D, float eps, void* stream);
+int sc_rowln_f32_bwd(const float* dy, const float* xhat, const float* gamma, const float* rstd, float* dx, float* dgamma_acc,
+                     float* dbeta_acc, int32_t rows, int32_t D, void* stream);
+int sc_gelu_f32(const float* u, const float* df, float* out, int64_t n, void* stream);
+int sc_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float* out, float alpha, float beta, void* stream);
+int sc_headmask_f32(float* q, float* Qm, int32_t H, int32_t D, int32_t dh, int32_t dir, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Masked symmetric InfoNCE (avssl/module/losses.py:185-245), logits [Bg,Bg] fp32 = A.B^T * inv_temp
  *   neg[i,j] = ids[i] != ids[j] or i == j ;  loss = 1/(2Bg) sum_i (-2 l_ii + LSE_row_i + LSE_col_i)
  *   sc_infonce_lse : row/col masked log-sum-exp (stable), per-sample terms, loss scalar

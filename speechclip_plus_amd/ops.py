@@ -264,3 +264,57 @@ def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
     nblk = gn_partial.numel() if gn_partial is not None else 0
     check(lib().sc_adam_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                             _p(gn_partial), nblk, max_norm, _stream()), "sc_adam_f32")
+
+
+# ---- fp32 one-row-per-utterance head tail (csrc/headtail.hip) ------------------------------------------------------
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(device) -> torch.Tensor:
+    """Per-device scratch for split-K partial sums (8 Mi floats; calls on one stream are serialised, so one buffer serves)."""
+    ws = _SPLITK_WS.get(device)
+    if ws is None:
+        ws = _SPLITK_WS[device] = torch.empty(8 << 20, device=device, dtype=torch.float32)
+    return ws
+
+
+def sgemm_ex(A: torch.Tensor, sa, Bm: torch.Tensor, sb, C: torch.Tensor, ldc: int, M: int, N: int, K: int, nbatch: int = 1,
+             scz: int = 0, alpha: float = 1.0, beta: float = 0.0, bias: Optional[torch.Tensor] = None, sbiasz: int = 0) -> None:
+    """C[z][i,j] = alpha sum_k A[z][i*sa0 + k*sa1] Bm[z][j*sb0 + k*sb1] (+ bias[z][j]) + beta C[z][i,j];
+    sa / sb = (row stride, k stride, batch stride) in elements; pointers are the tensors' data_ptr()."""
+    assert A.dtype == torch.float32 and Bm.dtype == torch.float32 and C.dtype == torch.float32
+    ws = _splitk_workspace(A.device)
+    check(lib().sc_sgemm_f32_ex(_p(A), sa[0], sa[1], sa[2], _p(Bm), sb[0], sb[1], sb[2], _p(C), ldc, scz, M, N, K, nbatch,
+                                float(alpha), float(beta), _p(bias), sbiasz, _p(ws), ws.numel(), _stream()), "sc_sgemm_f32_ex")
+
+
+def rowln_fwd(x: torch.Tensor, res: Optional[torch.Tensor], res_stride: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    rows, D = x.shape
+    y, xhat = torch.empty_like(x), torch.empty_like(x)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(lib().sc_rowln_f32_fwd(_p(x), _p(res), res_stride, _p(gamma), _p(beta), _p(y), _p(xhat), _p(rstd), rows, D, float(eps),
+                                 _stream()), "sc_rowln_f32_fwd")
+    return y, xhat, rstd
+
+
+def rowln_bwd(dy: torch.Tensor, xhat: torch.Tensor, gamma: torch.Tensor, rstd: torch.Tensor, dgamma_acc: torch.Tensor,
+              dbeta_acc: torch.Tensor) -> torch.Tensor:
+    rows, D = dy.shape
+    dx = torch.empty_like(dy)
+    check(lib().sc_rowln_f32_bwd(_p(dy), _p(xhat), _p(gamma), _p(rstd), _p(dx), _p(dgamma_acc), _p(dbeta_acc), rows, D, _stream()),
+          "sc_rowln_f32_bwd")
+    return dx
+
+
+def gelu_f32(u: torch.Tensor, df: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(u)
+    check(lib().sc_gelu_f32(_p(u), _p(df), _p(out), u.numel(), _stream()), "sc_gelu_f32")
+    return out
+
+
+def colsum(x: torch.Tensor, ld: int, rows: int, cols: int, out: torch.Tensor, alpha: float = 1.0, beta: float = 0.0) -> None:
+    check(lib().sc_colsum_f32(_p(x), ld, rows, cols, _p(out), float(alpha), float(beta), _stream()), "sc_colsum_f32")
+
+
+def headmask(q: torch.Tensor, Qm: torch.Tensor, H: int, D: int, dh: int, gather: bool) -> None:
+    check(lib().sc_headmask_f32(_p(q), _p(Qm), H, D, dh, int(gather), _stream()), "sc_headmask_f32")

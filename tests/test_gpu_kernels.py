@@ -379,3 +379,83 @@ def test_flat_adam_vs_torch(dev):
         opt.step()
         for p, r in zip(ps, rs):
             np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+# ---- fp32 head-tail kernels (csrc/headtail.hip) against plain torch fp32 ---------------------------------------------------
+def test_sgemm_ex_batched_strided_accumulate(dev):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    Bn, H, D, dh = 37, 8, 96, 12
+    m = torch.randn(Bn, H, D, generator=g).to(dev)
+    Wv = torch.randn(D, D, generator=g).to(dev)
+    bv = torch.randn(D, generator=g).to(dev)
+    cx = torch.empty(Bn, D, device=dev)
+    ops.sgemm_ex(m, (H * D, 1, D), Wv, (D, 1, dh * D), cx, D, Bn, dh, D, nbatch=H, scz=dh, bias=bv, sbiasz=dh)
+    ref = torch.einsum("bhk,hdk->bhd", m, Wv.view(H, dh, D)).reshape(Bn, D) + bv
+    assert torch.allclose(cx, ref, rtol=1e-4, atol=1e-4)
+    # weight gradient with accumulate: gW[h*dh+d, k] = 0.5 gW + 2 sum_b dcx[b, h*dh+d] m[b, h, k]
+    dcx = torch.randn(Bn, D, generator=g).to(dev)
+    gW0 = torch.randn(D, D, generator=g).to(dev)
+    gW = gW0.clone()
+    ops.sgemm_ex(dcx, (1, D, dh), m, (1, H * D, D), gW, D, dh, D, Bn, nbatch=H, scz=dh * D, alpha=2.0, beta=0.5)
+    ref = 0.5 * gW0 + 2.0 * torch.einsum("bhd,bhk->hdk", dcx.view(Bn, H, dh), m).reshape(D, D)
+    assert torch.allclose(gW, ref, rtol=1e-4, atol=1e-3)
+    # few tiles + long K: the split-K path (partials through the workspace, ordered reduction), with bias / alpha / beta
+    x, W2, b2 = torch.randn(Bn, 3000, generator=g).to(dev), torch.randn(70, 3000, generator=g).to(dev), torch.randn(70, generator=g).to(dev)
+    y0 = torch.randn(Bn, 70, generator=g).to(dev)
+    y = y0.clone()
+    ops.sgemm_ex(x, (3000, 1, 0), W2, (3000, 1, 0), y, 70, Bn, 70, 3000, alpha=0.5, beta=2.0, bias=b2)
+    assert torch.allclose(y, 2.0 * y0 + 0.5 * (x @ W2.T) + b2, rtol=1e-4, atol=1e-3)
+    cx2 = torch.empty(Bn, D, device=dev)
+    m2, Wv2 = torch.randn(Bn, H, 768, generator=g).to(dev), torch.randn(D, 768, generator=g).to(dev)
+    ops.sgemm_ex(m2, (H * 768, 1, 768), Wv2, (768, 1, dh * 768), cx2, D, Bn, dh, 768, nbatch=H, scz=dh, bias=bv, sbiasz=dh)
+    assert torch.allclose(cx2, torch.einsum("bhk,hdk->bhd", m2, Wv2.view(H, dh, 768)).reshape(Bn, D) + bv, rtol=1e-4, atol=1e-3)
+    # transposed operand: dx = dy W
+    dy, W = torch.randn(Bn, 50, generator=g).to(dev), torch.randn(50, 70, generator=g).to(dev)
+    dx = torch.empty(Bn, 70, device=dev)
+    ops.sgemm_ex(dy, (50, 1, 0), W, (1, 70, 0), dx, 70, Bn, 70, 50)
+    assert torch.allclose(dx, dy @ W, rtol=1e-4, atol=1e-4)
+
+
+def test_rowln_gelu_colsum_headmask(dev):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    rows, D = 29, 200
+    x = torch.randn(rows, D, generator=g).to(dev).requires_grad_()
+    res = torch.randn(1, D, generator=g).to(dev)
+    gam, bet = (torch.randn(D, generator=g).to(dev) + 1.0).requires_grad_(), torch.randn(D, generator=g).to(dev).requires_grad_()
+    y, xhat, rstd = ops.rowln_fwd(x.detach(), res, 0, gam.detach(), bet.detach(), 1e-5)
+    ref = F.layer_norm(x + res, (D,), gam, bet, 1e-5)
+    assert torch.allclose(y, ref, rtol=1e-4, atol=1e-5)
+    dy = torch.randn(rows, D, generator=g).to(dev)
+    ref.backward(dy)
+    dg, db = torch.ones(D, device=dev), torch.full((D,), 2.0, device=dev)        # accumulate on top of existing values
+    dx = ops.rowln_bwd(dy, xhat, gam.detach(), rstd, dg, db)
+    assert torch.allclose(dx, x.grad, rtol=1e-3, atol=1e-5)
+    assert torch.allclose(dg - 1.0, gam.grad, rtol=1e-4, atol=1e-4) and torch.allclose(db - 2.0, bet.grad, rtol=1e-4, atol=1e-4)
+    # per-row residual
+    res2 = torch.randn(rows, D, generator=g).to(dev)
+    y2, _, _ = ops.rowln_fwd(x.detach(), res2, D, gam.detach(), bet.detach(), 1e-5)
+    assert torch.allclose(y2, F.layer_norm(x.detach() + res2, (D,), gam.detach(), bet.detach(), 1e-5), rtol=1e-4, atol=1e-5)
+    # gelu fwd / bwd
+    u = (torch.randn(rows, D, generator=g) * 2).to(dev).requires_grad_()
+    f = ops.gelu_f32(u.detach())
+    fr = F.gelu(u)
+    assert torch.allclose(f, fr, rtol=1e-5, atol=1e-6)
+    fr.backward(dy)
+    assert torch.allclose(ops.gelu_f32(u.detach(), dy), u.grad, rtol=1e-4, atol=1e-6)
+    # column sums with scale / accumulate, head mask scatter / gather
+    out = torch.ones(D, device=dev)
+    ops.colsum(dy, D, rows, D, out, alpha=0.5, beta=2.0)
+    assert torch.allclose(out, 2.0 + 0.5 * dy.sum(0), rtol=1e-5, atol=1e-5)
+    H, dh = 8, 25
+    q = torch.randn(1, D, generator=g).to(dev)
+    Qm = torch.empty(H, D, device=dev)
+    ops.headmask(q, Qm, H, D, dh, gather=False)
+    ref = torch.zeros(H, D, device=dev)
+    for h in range(H):
+        ref[h, h * dh: (h + 1) * dh] = q[0, h * dh: (h + 1) * dh]
+    assert torch.equal(Qm, ref)
+    back = torch.empty(1, D, device=dev)
+    ops.headmask(back, torch.arange(H * D, device=dev, dtype=torch.float32).view(H, D), H, D, dh, gather=True)
+    assert torch.equal(back[0], torch.tensor([float((j // dh) * D + j) for j in range(D)], device=dev))
