@@ -65,6 +65,14 @@ class MaskedContrastiveLoss(nn.Module):
             temp = self.temperature
         return float(temp)
 
+    @property
+    def temperature_for_logging(self):
+        """``current_temperature`` without the device -> host synchronisation of ``.item()``: a 0-dim device tensor when the
+        temperature is trainable (loggers accept tensors), the python float otherwise."""
+        if self.temperature_trainable:
+            return self.temperature.detach().float().exp()
+        return float(self.temperature)
+
     def forward(self, feat_A: torch.Tensor, feat_B: torch.Tensor, index: torch.LongTensor = None) -> torch.Tensor:
         assert feat_A.shape == feat_B.shape, (feat_A.shape, feat_B.shape)
         if index is not None:

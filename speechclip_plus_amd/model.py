@@ -274,7 +274,7 @@ class KWClip_GeneralTransformer(nn.Module):
             assert "target_len" in dsample_results and "quantity_out" in dsample_results, f"{dsample_results.keys()}"
             losses_["cif_quantity_out"] = dsample_results["quantity_out"]
             losses_["cif_target_len"] = dsample_results["target_len"]
-        log_metrics = {"cl_temp": self.criterion.current_temperature}
+        log_metrics = {"cl_temp": self.criterion.temperature_for_logging}   # kwClip.py: .item() per step; here no host sync
         if vq_results is not None:
             log_metrics["softmax_temp"] = vq_results["temp"]
         if self.cascaded_branch is not None:

@@ -276,13 +276,20 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         pl = self._plan(B, L)
         C, D, F, H = a.conv_dim, a.embed_dim, a.ffn_dim, a.heads
         R, M, T = pl.R, pl.M, pl.T
-        len_dev = torch.tensor(wav_len, dtype=torch.int64, device=self._dev)
-        # a1: (optional) utterance layer-norm + zero pad                                (:506-518)
-        ops.wav_prep(padded, len_dev, pl.wav_pad, a.normalize_wav)
+        # every length-derived integer of the step goes up in ONE asynchronous copy from pinned memory BEFORE the kernels are
+        # enqueued (a pageable host -> device copy later in the stream would block the host until the GPU got there and
+        # leave the head / loss / optimiser launch-bound):  [wav_len | valid frames | feat_len]
         # fairseq forward_padding_mask: frame t valid iff t*(L//T) < len                (:81-82)
+        # feat_len = min(round(len / 320), T), python round = half to even              (:604-611)
         chunk = L // T
         valid = [min(T, -(-int(l) // chunk)) for l in wav_len]
-        pl.valid.copy_(torch.tensor(valid, dtype=torch.int32), non_blocking=True)
+        feat_len = [min(round(int(l) / self.downsample_rate), T) for l in wav_len]
+        host = torch.tensor([list(map(int, wav_len)), valid, feat_len], dtype=torch.int64).pin_memory()
+        ints = host.to(self._dev, non_blocking=True)
+        len_dev, pl.feat_len = ints[0], ints[2]
+        pl.valid.copy_(ints[1])
+        # a1: (optional) utterance layer-norm + zero pad                                (:506-518)
+        ops.wav_prep(padded, len_dev, pl.wav_pad, a.normalize_wav)
         # a2: conv feature extractor                                                    (:75)
         ln_mode = a.extractor_mode == "layer_norm"
         if ln_mode:       # large: conv (+bias) -> LayerNorm(512) -> GELU after every layer
@@ -373,8 +380,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
         hidden_states = tuple(pl.hidden[n].view(B, R, D)[:, :T] for n in range(self.arch.layers + 1))
         feat = {"last_hidden_state": hidden_states[-1], "hidden_states": hidden_states}
-        # :604-611  python round (half to even), clamp to T
-        feat_len = torch.tensor([min(round(l / self.downsample_rate), T) for l in lens], dtype=torch.long, device=self._dev)
+        feat_len = pl.feat_len                                                          # :604-611 (uploaded in _encode)
         if feat_select_idx is None:
             feat_select_idx = self.feat_select_idx
         return_list = []
