@@ -55,6 +55,20 @@ def gather_loss_feats(audio_feat, image_feat: torch.Tensor, ids: torch.Tensor,
     return (outs[0] if single else outs), allp[:, n * E: (n + 1) * E], ids_all
 
 
+def scale_replicated_grads(params, group: Optional[dist.ProcessGroup] = None) -> None:
+    """Parameters of the loss itself (the trainable temperature) see the WHOLE global-batch loss on every rank, so each rank
+    already holds their full gradient: divide by the world size before the SUM all-reduce (every other parameter only
+    receives the gradient that flows through this rank's own rows, whose sum over ranks is the global gradient)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    for p in params:
+        if p.grad is not None:
+            p.grad.mul_(1.0 / world)
+
+
 class GradAllReduce:
     """Sum the flat gradient buffer across ranks on a side HIP stream."""
 

@@ -184,6 +184,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if not (isinstance(layer_drop, float) and layer_drop == 0.0) and layer_drop != "original":
             raise ValueError(f"layer_drop = {layer_drop} is not supported.")
         self.feat_select_idx = feat_select_idx
+        self.before_trainable = None            # optional callable invoked right before the first trainable module (train.py)
         self.max_audio_len = max_audio_len
         self.reinit_layers = reinit_layers
         self.unfreeze_layers = unfreeze_layers
@@ -387,6 +388,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if feat_select_idx == "all":
             return_list.extend([feat, feat_len])
         elif feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
+            if self.before_trainable is not None:
+                self.before_trainable()                 # train.ContrastiveTrainer: join the optimiser's side stream here
             return_list.extend([self.weightedsum_layer.forward_padded(pl.hidden, B, R, T, D), feat_len])
         elif isinstance(feat_select_idx, list):
             return_list.extend([[feat["hidden_states"][i] for i in feat_select_idx], feat_len])

@@ -1,14 +1,20 @@
 """One contrastive train step (frozen-HuBERT recipe of every shipped config):
 forward -> packed all-gather -> global-batch InfoNCE -> backward (head + weighted-sum weights [+ temperature])
 -> flat gradient all-reduce -> clip + Adam.  Mirrors training_step / training_step_end / configure_optimizers
-of avssl/model/kwClip.py:145-193,646-674 without PyTorch-Lightning."""
+of avssl/model/kwClip.py:145-193,646-674 without PyTorch-Lightning.
+
+Stream schedule: the gradient all-reduce, the clip + Adam launch and the zeroing of the gradient buffer are enqueued on a
+SIDE stream after the backward.  HuBERT is frozen in every shipped recipe, so the next step's encoder forward (12 of the
+13 ms) touches no trainable parameter: the main stream joins the side stream only right before the first trainable module
+of the next step (the weighted sum at the end of the encoder).  The collective and the optimiser therefore run under the next
+encoder forward instead of extending the step."""
 from typing import Optional
 
 import torch
 import torch.distributed as dist
 
 from .optim import FlatAdam, linear_warmup_decay
-from .parallel import GradAllReduce, gather_loss_feats
+from .parallel import GradAllReduce, gather_loss_feats, scale_replicated_grads
 
 
 class ContrastiveTrainer:
@@ -22,6 +28,22 @@ class ContrastiveTrainer:
         self.opt = FlatAdam(model.getTrainableParams(), lr=self.base_lr, weight_decay=float(oc.args.get("weight_decay", 0.0)),
                             max_grad_norm=float(cfg.trainer.get("gradient_clip_val", 0.0)))
         self.allreduce = GradAllReduce(self.opt.flat_g, group)
+        self.replicated = [p for p in model.criterion.parameters() if p.requires_grad]   # evaluated on the full batch by every rank
+        self.side = torch.cuda.Stream() if self.opt.flat_g.is_cuda else None
+        self._pending = False
+        # join point: first use of a trainable parameter in a step
+        model.audio_encoder.before_trainable = self.join
+        for m in (model.parallel_branch, model.cascaded_branch, model.criterion):
+            if m is not None:
+                m.register_forward_pre_hook(lambda *_: self.join())
+
+    def join(self) -> None:
+        """Make the current stream wait for the optimiser work of the previous step (no host synchronisation)."""
+        if self._pending:
+            if self.side is not None:
+                torch.cuda.current_stream().wait_stream(self.side)
+            self.opt.zero_grad()                      # gradients of the finished step stay readable until the next step needs the buffer
+        self._pending = False
 
     def lr_at(self, step: int) -> float:
         s = self.sched
@@ -31,7 +53,6 @@ class ContrastiveTrainer:
 
     def step(self, batch: dict) -> torch.Tensor:
         model = self.model
-        self.opt.zero_grad()
         loss_feats = model.training_step(batch)["loss_feats"]
         keys = [k for k in ("parallel_audio_feat", "cascaded_audio_feat") if k in loss_feats]
         feats, i, ids = gather_loss_feats([loss_feats[k] for k in keys], loss_feats["image_feat"], loss_feats["id"], self.group)
@@ -47,8 +68,19 @@ class ContrastiveTrainer:
         if world > 1 and "quantity_loss" in losses:
             loss = loss - model.quantity_loss_weight * losses["quantity_loss"] * (1.0 - 1.0 / world)
         loss.backward()
-        self.allreduce.launch()
-        self.allreduce.wait()
-        self.opt.step(lr=self.lr_at(model.global_step))
+        lr = self.lr_at(model.global_step)
+        if self.side is None:
+            self._finish(lr)
+        else:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self._finish(lr)
+        self._pending = True
         model.global_step += 1
         return loss.detach()
+
+    def _finish(self, lr: float) -> None:
+        scale_replicated_grads(self.replicated, self.group)
+        self.allreduce.launch()
+        self.allreduce.wait()
+        self.opt.step(lr=lr)

@@ -27,31 +27,35 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
-    from speechclip_plus_amd.parallel import GradAllReduce, gather_loss_feats
+    from speechclip_plus_amd.parallel import GradAllReduce, gather_loss_feats, scale_replicated_grads
     torch.manual_seed(0)
     Bg, E, D = 8, 16, 12
     X = torch.randn(Bg, D)
     img = torch.nn.functional.normalize(torch.randn(Bg, E), dim=-1)
     ids = torch.tensor([0, 0, 1, 2, 3, 3, 4, 5])
     W = torch.nn.Parameter(torch.randn(E, D) * 0.3)
+    logt = torch.nn.Parameter(torch.tensor(2.0))              # trainable log(1 / temperature): a parameter of the loss itself
     # single-process reference on the global batch
     a = torch.nn.functional.normalize(X @ W.t(), dim=-1)
-    ref_loss = oracle.masked_contrastive_loss(a, img, ids)
-    ref_grad, = torch.autograd.grad(ref_loss, W)
+    ref_loss = oracle.masked_contrastive_loss(a, img, ids, inv_temperature=logt.exp())
+    ref_grad, ref_gt = torch.autograd.grad(ref_loss, [W, logt])
     # data parallel: each rank owns Bg / world rows
     n = Bg // world
     sl = slice(rank * n, (rank + 1) * n)
     a_loc = torch.nn.functional.normalize(X[sl] @ W.t(), dim=-1)
     a_all, i_all, id_all = gather_loss_feats(a_loc, img[sl], ids[sl])
     assert torch.equal(id_all, ids) and torch.allclose(i_all, img)
-    loss = oracle.masked_contrastive_loss(a_all, i_all, id_all)
+    loss = oracle.masked_contrastive_loss(a_all, i_all, id_all, inv_temperature=logt.exp())
     loss.backward()
-    flat = W.grad.reshape(-1).clone()
+    scale_replicated_grads([logt])                            # every rank holds the full temperature gradient
+    flat = torch.cat([W.grad.reshape(-1), logt.grad.reshape(1)]).clone()
     ar = GradAllReduce(flat)
     ar.launch()
     ar.wait()
-    ok = abs(loss.item() - ref_loss.item()) < 1e-6 and torch.allclose(flat.view_as(W), ref_grad, atol=1e-6)
-    q.put((rank, bool(ok), float((flat.view_as(W) - ref_grad).abs().max())))
+    gW, gt = flat[:-1].view_as(W), flat[-1]
+    ok = (abs(loss.item() - ref_loss.item()) < 1e-6 and torch.allclose(gW, ref_grad, atol=1e-6)
+          and abs(float(gt) - float(ref_gt)) < 1e-6)
+    q.put((rank, bool(ok), float((gW - ref_grad).abs().max()), float(gt), float(ref_gt)))
     dist.destroy_process_group()
 
 
@@ -66,4 +70,4 @@ def test_gather_and_allreduce_world2():
     res = [q.get(timeout=100) for _ in procs]
     for p in procs:
         p.join(timeout=30)
-    assert all(ok for _, ok, _ in res), res
+    assert all(r[1] for r in res), res

@@ -221,3 +221,36 @@ def test_encode_speech_api_and_recall(setup):
     h13 = model.feature_extractor_s3prl([w.cuda() for w in wavs[:2]])
     # kwClip.py:965-997: 13 HuBERT states + the parallel branch layer's output (CLS position dropped)
     assert len(h13[1]) == 14 and h13[0].shape[-1] == 768 and h13[1][-1].shape == h13[1][0].shape
+
+
+def test_trainer_side_stream_schedule_matches_synchronous():
+    """train.ContrastiveTrainer enqueues all-reduce + Adam on a side stream and joins it before the first trainable module of
+    the next step: three steps must leave exactly the parameters of the same steps run on one stream, and the gradients of the
+    last step must still be readable."""
+    import dataclasses
+    from speechclip_plus_amd import KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    arch = dataclasses.replace(ARCHS["hubert"], layers=2)
+    sd = random_hubert_state_dict(arch, seed=3)
+    g = torch.Generator().manual_seed(11)
+    B, L = 6, 9000
+    batch = {"wav": torch.randn(B, L, generator=g).cuda(), "wav_len": torch.tensor([9000, 7000, 9000, 5000, 8000, 9000]),
+             "image": torch.randn(B, 512, generator=g).cuda(), "id": torch.tensor([0, 1, 1, 2, 3, 4]).cuda()}
+    finals = []
+    for sync in (False, True):
+        torch.manual_seed(3)
+        cfg = base_parallel_config()
+        cfg.audio_encoder.max_audio_len = -1
+        cfg.cl_loss.args.temperature_trainable = True
+        model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train()
+        trainer = ContrastiveTrainer(model)
+        if sync:
+            trainer.side = None
+        losses = [float(trainer.step(batch)) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert float(trainer.opt.flat_g.abs().sum()) > 0
+        finals.append((losses, trainer.opt.flat_p.clone(), trainer.opt.flat_g.clone()))
+    assert finals[0][0] == finals[1][0], (finals[0][0], finals[1][0])
+    assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
+    assert finals[0][0][2] < finals[0][0][0]
