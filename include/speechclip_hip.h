@@ -76,7 +76,24 @@ int sc_gemm_bf16(const sc_gemm_args* args, void* stream);
  * ---------------------------------------------------------------------------------------------- */
 int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len,
                      sc_bf16* out, int64_t ldo, int32_t B, int32_t R, int32_t H, int32_t D, float scale,
-                     void* stream);
+                     float* lse2 /* [B,H,R] log2-domain log-sum-exp for the backward, or NULL */,
+                     int32_t causal /* 1: key t' > query t masked too (CLIP text tower) */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Self-attention backward, head_dim 64 (fairseq MultiheadAttention / nn.MultiheadAttention / CLIP ResidualAttentionBlock
+ * with dh = 64): dq, dk, dv from q, k, v, out, dout and the forward's lse2.  Two kernels (dq ; dk + dv), no atomics.
+ *   q, k, v, out, dout : row-major [B*R, ld] bf16, head h at columns h*64..h*64+63 of the given base pointers
+ *   qT, kT, doT        : per-head transposed copies [B, H, 64, R] (sc_head_transpose_bf16)
+ *   delta              : [B, H, R] fp32 workspace (rowsum(dout . out), written here)
+ *   rows of padded queries must carry dout = 0; keys t >= valid_len[b] (and t' > t when causal) get zero gradient
+ * sc_head_transpose_bf16: xT[b, h, d, t] = x[b*R + t, h*64 + d]
+ * ---------------------------------------------------------------------------------------------- */
+int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k, int64_t ldk, const sc_bf16* v, int64_t ldv,
+                     const sc_bf16* out, int64_t ldo, const sc_bf16* dout, int64_t lddo, const sc_bf16* qT, const sc_bf16* kT,
+                     const sc_bf16* doT, const float* lse2, float* delta, const int32_t* valid_len, sc_bf16* dq, int64_t lddq,
+                     sc_bf16* dk, int64_t lddk, sc_bf16* dv, int64_t lddv, int32_t B, int32_t R, int32_t H, float scale,
+                     int32_t causal, void* stream);
+int sc_head_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* xT, int32_t B, int32_t R, int32_t H, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row LayerNorm, bf16 in/out, fp32 statistics:  y = (x - mean) * rstd * gamma + beta  [-> GELU]

@@ -36,7 +36,12 @@ class GemmArgs(ctypes.Structure):
 SIGNATURES = {
     "sc_abi_version": [],
     "sc_gemm_bf16": [ctypes.POINTER(GemmArgs), c_void_p],
-    "sc_attn_fwd_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "sc_attn_fwd_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
+                         c_void_p],
+    "sc_attn_bwd_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int,
+                         c_int, c_float, c_int, c_void_p],
+    "sc_head_transpose_bf16": [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p],
     "sc_layernorm_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_float, c_int, c_void_p],
     "sc_wav_prep": [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p],
     "sc_conv0_stats": [c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p],

@@ -55,7 +55,7 @@ class CIF(nn.Module):
         original_length = (~pad).sum(-1).long()
         if self.scaling_step >= 0 and self.apply_scaling and input_dict["global_step"] >= self.scaling_step:
             self.apply_scaling = False                         # cif.py:110-112: permanent once the step is reached
-        logits = self.conv(feats.permute(0, 2, 1)).permute(0, 2, 1)
+        logits = self._weight_conv(feats)
         alpha = self.weight_proj(logits).clip(min=0.0, max=1.0).float().squeeze(-1)
         alpha = alpha.masked_fill(pad, 0.0)
         orig_alpha = alpha
@@ -69,6 +69,21 @@ class CIF(nn.Module):
         out.update(self.integrate_and_fire(feats, alpha, target_lengths=target_lengths))
         out["input_feats_pad_mask"] = pad
         return out
+
+    def _weight_conv(self, feats: torch.Tensor) -> torch.Tensor:
+        """``self.conv(feats^T)^T`` (Conv1d k, stride 1, 'same' padding -> Dropout -> ReLU per layer) evaluated channels-last as
+        one GEMM per layer over the k shifted copies of the input: MIOpen's fp32 NCHW path for this 768 x 768 x 3 conv costs
+        ~7 ms per call at B = 64 (rocprofv3), the GEMM form ~1 ms; same parameters, same arithmetic (fp32)."""
+        x = feats
+        for i in range(0, len(self.conv), 3):
+            conv, drop, act = self.conv[i], self.conv[i + 1], self.conv[i + 2]
+            k, pad = conv.kernel_size[0], conv.padding[0]
+            B, T, C = x.shape
+            xp = torch.nn.functional.pad(x, (0, 0, pad, pad))                       # (B, T + 2 pad, C)
+            cols = torch.cat([xp[:, j: j + T + 2 * pad - k + 1] for j in range(k)], dim=-1)   # (B, T', k C), tap-major
+            w = conv.weight.permute(0, 2, 1).reshape(conv.out_channels, k * C)    # [C_out, k, C_in] flattened tap-major
+            x = act(drop(torch.nn.functional.linear(cols, w, conv.bias)))
+        return x
 
     def integrate_and_fire(self, input: torch.Tensor, alpha: torch.Tensor,
                            target_lengths: Optional[torch.Tensor] = None) -> dict:

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                                                         const uint16_t* __restrict__ vt,
                                                         const int32_t* __restrict__ valid_len,
                                                         uint16_t* __restrict__ out, int64_t ldo, int R, int H, int D,
-                                                        float c /* scale * log2(e) */) {
+                                                        float c /* scale * log2(e) */, float* __restrict__ lse2, int causal) {
     __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
     __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
 
@@ -67,6 +67,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
+    const int qrow = q0 + l31;                                       // this lane's query
+    if (causal) n_valid = min(n_valid, qblk * 128 + 128);           // keys beyond the block's last query are all masked
     const int ntiles = (n_valid + KT - 1) / KT;
     // prefetch registers as named scalars: arrays indexed across the tile loop were being placed in scratch
     uint4 kreg0 = *(const uint4*)(kg[0]), kreg1 = *(const uint4*)(kg[1]);
@@ -107,11 +109,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
             }
         }
         auto softmax_block = [&](f32x16& sv, int kbase, bf16x8 (&pf)[2]) {
-            if (kbase + 32 > n_valid) {
+            if (kbase + 32 > n_valid || (causal && kbase + 31 > q0)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kidx = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (kidx >= n_valid) sv[r] = -INFINITY;
+                    if (kidx >= n_valid || (causal && kidx > qrow)) sv[r] = -INFINITY;
                 }
             }
             float mloc = sv[0];
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
     const float inv = 1.0f / l_tot;
+    if (lse2 && half == 0) lse2[((int64_t)b * H + h) * R + qrow] = m_run * c + __builtin_amdgcn_logf(l_tot);   // log2 domain
     uint16_t* op = out + ((int64_t)b * R + q0 + l31) * ldo + h * 64 + 4 * half;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 
 extern "C" int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len,
                                 sc_bf16* out, int64_t ldo, int32_t B, int32_t R, int32_t H, int32_t D, float scale,
-                                void* stream) {
+                                float* lse2, int32_t causal, void* stream) {
     SC_CHECK(qk && vt && valid_len && out, "sc_attn_fwd_bf16: null pointer");
     SC_CHECK(B > 0 && H > 0 && R > 0 && R % 128 == 0, "sc_attn_fwd_bf16: R=%d must be a positive multiple of 128", R);
     SC_CHECK(D == H * 64, "sc_attn_fwd_bf16: head_dim must be 64 (D=%d, H=%d)", D, H);
@@ -202,7 +205,7 @@ extern "C" int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* 
              "sc_attn_fwd_bf16: alignment");
     dim3 grid((R / 128) * H * B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R,
-                       H, D, scale * 1.4426950408889634f);
+                       H, D, scale * 1.4426950408889634f, lse2, causal);
     SC_LAUNCH_CHECK();
     return 0;
 }

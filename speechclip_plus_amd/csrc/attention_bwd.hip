@@ -1,0 +1,373 @@
+// Self-attention backward for gfx950, head_dim 64 (flash style, key padding by length, optional causal mask).
+//
+// Same operand discipline as attention.hip: v_mfma_f32_32x32x16_bf16, every product arranged so that the accumulator of
+// one MFMA is, converted to bf16, the B operand of the next (no LDS round trip, no lane movement), which works when the next
+// product sums over the accumulator's ROW index.  With P = exp2(S c - lse2) (lse2 from the forward, log2 domain),
+// delta = rowsum(dO . O) and dS = P (dP - delta):
+//
+//   dq kernel   (workgroup = 128 queries, wave = 32, loop over 64-key tiles; lane = one query column)
+//     S^T  [key][q] = K . Q^T        A = K rows (LDS)      B = Q  fragments (registers)
+//     dP^T [key][q] = V . dO^T       A = V rows (LDS)      B = dO fragments (registers)
+//     dQ^T [d][q]  += K^T . dS^T     A = K^T rows (LDS)    B = dS^T accumulator
+//   dk/dv kernel (workgroup = 128 keys, wave = 32, loop over 64-query tiles; lane = one key column)
+//     S  [q][key]  = Q . K^T         A = Q rows (LDS)      B = K fragments (registers)
+//     dP [q][key]  = dO . V^T        A = dO rows (LDS)     B = V fragments (registers)
+//     dV^T [d][key] += dO^T . P      A = dO^T rows (LDS)   B = P accumulator
+//     dK^T [d][key] += Q^T . dS      A = Q^T rows (LDS)    B = dS accumulator
+// K^T, Q^T, dO^T are per-head transposed copies [B, H, 64, R] made by sc_head_transpose_bf16 (HBM-bound, ~25 us each at
+// B = 64): two kernels and seven products instead of five, but no atomics - every gradient element is written once, in a
+// fixed summation order.  Rows of padded queries carry dO = 0 (the caller's contract) and padded / future keys get P = 0.
+#include "sc_common.h"
+
+namespace {
+
+constexpr int TT = 64;   // rows of the looped dimension per LDS tile
+
+// row-major tile image [64 rows][64 bf16] (128-B rows, 16-B chunk ^ ((row >> 1) & 7)): fragment of rows 32 blk + l31
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int blk, int l31, int half, int ks) {
+    const int row = blk * 32 + l31;
+    return *(const bf16x8*)(tile + row * 128 + (((2 * ks + half) ^ ((row >> 1) & 7)) << 4));
+}
+// transposed tile image [64 d rows][64 x bf16] (8-B unit ^ ((row >> 1) & 15)): A fragment of d rows 32 dt + l31 for k step
+// (blk, s2): positions (half, j) <-> looped index 32 blk + 16 s2 + 4 half + (j & 3) + 8 (j >> 2), matching the accumulator
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int blk, int s2, int dt, int l31, int half) {
+    const int row = dt * 32 + l31, sw = (row >> 1) & 15, u0 = blk * 8 + 4 * s2 + half;
+    const uint2 lo = *(const uint2*)(tile + row * 128 + ((u0 ^ sw) << 3));
+    const uint2 hi = *(const uint2*)(tile + row * 128 + (((u0 + 2) ^ sw) << 3));
+    return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+__device__ __forceinline__ void acc_to_frag(const f32x16& v, bf16x8 (&pf)[2]) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[s2][j] = (__bf16)v[8 * s2 + j];
+}
+__device__ __forceinline__ int xcd_logical() {
+    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+// accumulator [d rows][lane column] -> out[row of the lane][d]  (same store as the forward's O), times s
+__device__ __forceinline__ void store_T(const f32x16& a0, const f32x16& a1, uint16_t* op /* row ptr + 4 half */, float s) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint2 w0, w1;
+        w0.x = pack2bf(a0[4 * g + 0] * s, a0[4 * g + 1] * s);
+        w0.y = pack2bf(a0[4 * g + 2] * s, a0[4 * g + 3] * s);
+        w1.x = pack2bf(a1[4 * g + 0] * s, a1[4 * g + 1] * s);
+        w1.y = pack2bf(a1[4 * g + 2] * s, a1[4 * g + 3] * s);
+        *(uint2*)(op + 8 * g) = w0;
+        *(uint2*)(op + 32 + 8 * g) = w1;
+    }
+}
+
+struct bwd_args {
+    const uint16_t *q, *k, *v, *dout;            // row-major [B R, ld*], head h at column h * 64
+    int64_t ldq, ldk, ldv, lddo;
+    const uint16_t *qT, *kT, *doT;               // [B, H, 64, R]
+    const float *lse2, *delta;                   // [B, H, R]
+    const int32_t* valid_len;                    // [B]
+    uint16_t *dq, *dk, *dv;                      // row-major outputs
+    int64_t lddq, lddk, lddv;
+    int R, H;
+    float scale, c;                              // c = scale * log2(e)
+    int causal;
+};
+
+// ------------------------------------------------------------------------------------------------------------ dQ
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bwd_args p) {
+    __shared__ __attribute__((aligned(16))) char Ks[TT * 128];
+    __shared__ __attribute__((aligned(16))) char Vs[TT * 128];
+    __shared__ __attribute__((aligned(16))) char KTs[64 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int R = p.R, H = p.H, nqb = R >> 7;
+    const int logical = xcd_logical();
+    const int qblk = logical % nqb, bh = logical / nqb, h = bh % H, b = bh / H;
+    const int q0 = qblk * 128 + wave * 32, qrow = q0 + l31;
+    int n_valid = max(1, min(p.valid_len[b], R));
+    if (p.causal) n_valid = min(n_valid, qblk * 128 + 128);
+
+    bf16x8 qf[4], dof[4];
+    {
+        const uint16_t* qp = p.q + ((int64_t)b * R + qrow) * p.ldq + h * 64 + 8 * half;
+        const uint16_t* dp = p.dout + ((int64_t)b * R + qrow) * p.lddo + h * 64 + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *(const bf16x8*)(qp + ks * 16);
+            dof[ks] = *(const bf16x8*)(dp + ks * 16);
+        }
+    }
+    const float lse = p.lse2[((int64_t)b * H + h) * R + qrow], dl = p.delta[((int64_t)b * H + h) * R + qrow];
+
+    const uint16_t *kg[2], *vg[2], *tg[2];
+    int r_lds[2], t_lds0[2], t_lds1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 256, row = id >> 3, ch = id & 7;
+        kg[i] = p.k + ((int64_t)b * R + row) * p.ldk + h * 64 + ch * 8;
+        vg[i] = p.v + ((int64_t)b * R + row) * p.ldv + h * 64 + ch * 8;
+        tg[i] = p.kT + (((int64_t)b * H + h) * 64 + row) * R + ch * 8;
+        r_lds[i] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+        t_lds0[i] = row * 128 + (((2 * ch) ^ ((row >> 1) & 15)) << 3);
+        t_lds1[i] = row * 128 + (((2 * ch + 1) ^ ((row >> 1) & 15)) << 3);
+    }
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+
+    const int ntiles = (n_valid + TT - 1) / TT;
+    uint4 k0 = *(const uint4*)kg[0], k1 = *(const uint4*)kg[1], v0 = *(const uint4*)vg[0], v1 = *(const uint4*)vg[1];
+    uint4 t0 = *(const uint4*)tg[0], t1 = *(const uint4*)tg[1];
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * TT;
+        *(uint4*)(Ks + r_lds[0]) = k0;
+        *(uint4*)(Ks + r_lds[1]) = k1;
+        *(uint4*)(Vs + r_lds[0]) = v0;
+        *(uint4*)(Vs + r_lds[1]) = v1;
+        *(uint2*)(KTs + t_lds0[0]) = make_uint2(t0.x, t0.y);
+        *(uint2*)(KTs + t_lds1[0]) = make_uint2(t0.z, t0.w);
+        *(uint2*)(KTs + t_lds0[1]) = make_uint2(t1.x, t1.y);
+        *(uint2*)(KTs + t_lds1[1]) = make_uint2(t1.z, t1.w);
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            k0 = *(const uint4*)(kg[0] + (int64_t)(key0 + TT) * p.ldk);
+            k1 = *(const uint4*)(kg[1] + (int64_t)(key0 + TT) * p.ldk);
+            v0 = *(const uint4*)(vg[0] + (int64_t)(key0 + TT) * p.ldv);
+            v1 = *(const uint4*)(vg[1] + (int64_t)(key0 + TT) * p.ldv);
+            t0 = *(const uint4*)(tg[0] + key0 + TT);
+            t1 = *(const uint4*)(tg[1] + key0 + TT);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int kbase = key0 + kb * 32;
+            if (kbase >= n_valid) break;                               // wave-uniform
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kb, l31, half, ks), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kb, l31, half, ks), dof[ks], dp, 0, 0, 0);
+            }
+            f32x16 ds;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kidx = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const bool ok = kidx < n_valid && !(p.causal && kidx > qrow);
+                const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse)) : 0.f;
+                ds[r] = pr * (dp[r] - dl);
+            }
+            bf16x8 pf[2];
+            acc_to_frag(ds, pf);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(KTs, kb, s2, 0, l31, half), pf[s2], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(KTs, kb, s2, 1, l31, half), pf[s2], a1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    store_T(a0, a1, p.dq + ((int64_t)b * R + qrow) * p.lddq + h * 64 + 4 * half, p.scale);
+}
+
+// ------------------------------------------------------------------------------------------------------------ dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
+    __shared__ __attribute__((aligned(16))) char Qs[TT * 128];
+    __shared__ __attribute__((aligned(16))) char Os[TT * 128];
+    __shared__ __attribute__((aligned(16))) char QTs[64 * 128];
+    __shared__ __attribute__((aligned(16))) char OTs[64 * 128];
+    __shared__ __attribute__((aligned(16))) float lse_s[TT], dl_s[TT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int R = p.R, H = p.H, nkb = R >> 7;
+    const int logical = xcd_logical();
+    const int kblk = logical % nkb, bh = logical / nkb, h = bh % H, b = bh / H;
+    const int key0w = kblk * 128 + wave * 32, krow = key0w + l31;
+    const int n_valid = max(1, min(p.valid_len[b], R));
+    uint16_t* dkp = p.dk + ((int64_t)b * R + krow) * p.lddk + h * 64 + 4 * half;
+    uint16_t* dvp = p.dv + ((int64_t)b * R + krow) * p.lddv + h * 64 + 4 * half;
+
+    f32x16 ak0, ak1, av0, av1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ak0[r] = 0.f; ak1[r] = 0.f; av0[r] = 0.f; av1[r] = 0.f; }
+    if (kblk * 128 >= n_valid) {                                       // workgroup-uniform: a block of padded keys
+        store_T(ak0, ak1, dkp, 0.f);
+        store_T(av0, av1, dvp, 0.f);
+        return;
+    }
+    bf16x8 kf[4], vf[4];
+    {
+        const uint16_t* kp = p.k + ((int64_t)b * R + krow) * p.ldk + h * 64 + 8 * half;
+        const uint16_t* vp = p.v + ((int64_t)b * R + krow) * p.ldv + h * 64 + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = *(const bf16x8*)(kp + ks * 16);
+            vf[ks] = *(const bf16x8*)(vp + ks * 16);
+        }
+    }
+    const bool key_ok = krow < n_valid;
+
+    const uint16_t *qg[2], *og[2], *qtg[2], *otg[2];
+    int r_lds[2], t_lds0[2], t_lds1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 256, row = id >> 3, ch = id & 7;
+        qg[i] = p.q + ((int64_t)b * R + row) * p.ldq + h * 64 + ch * 8;
+        og[i] = p.dout + ((int64_t)b * R + row) * p.lddo + h * 64 + ch * 8;
+        qtg[i] = p.qT + (((int64_t)b * H + h) * 64 + row) * R + ch * 8;
+        otg[i] = p.doT + (((int64_t)b * H + h) * 64 + row) * R + ch * 8;
+        r_lds[i] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+        t_lds0[i] = row * 128 + (((2 * ch) ^ ((row >> 1) & 15)) << 3);
+        t_lds1[i] = row * 128 + (((2 * ch + 1) ^ ((row >> 1) & 15)) << 3);
+    }
+    const float* lse_g = p.lse2 + ((int64_t)b * H + h) * R;
+    const float* dl_g = p.delta + ((int64_t)b * H + h) * R;
+
+    // queries that can see this key block: all valid ones, or (causal) those from the block's first key on
+    const int q_end = n_valid;                                         // rows beyond carry dO = 0
+    const int t_first = p.causal ? (kblk * 128) / TT : 0;
+    const int t_last = (q_end + TT - 1) / TT;                          // exclusive
+    for (int t = t_first; t < t_last; ++t) {
+        const int qt0 = t * TT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(uint4*)(Qs + r_lds[i]) = *(const uint4*)(qg[i] + (int64_t)qt0 * p.ldq);
+            *(uint4*)(Os + r_lds[i]) = *(const uint4*)(og[i] + (int64_t)qt0 * p.lddo);
+            const uint4 a = *(const uint4*)(qtg[i] + qt0), o = *(const uint4*)(otg[i] + qt0);
+            *(uint2*)(QTs + t_lds0[i]) = make_uint2(a.x, a.y);
+            *(uint2*)(QTs + t_lds1[i]) = make_uint2(a.z, a.w);
+            *(uint2*)(OTs + t_lds0[i]) = make_uint2(o.x, o.y);
+            *(uint2*)(OTs + t_lds1[i]) = make_uint2(o.z, o.w);
+        }
+        if (tid < TT) {
+            lse_s[tid] = lse_g[qt0 + tid];
+            dl_s[tid] = dl_g[qt0 + tid];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qbase = qt0 + qb * 32;
+            if (qbase >= q_end) break;
+            if (p.causal && qbase + 31 < key0w) continue;              // every query of the block precedes every key of the wave
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qs, qb, l31, half, ks), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Os, qb, l31, half, ks), vf[ks], dp, 0, 0, 0);
+            }
+            f32x16 pr, ds;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ql = qb * 32 + 8 * g + 4 * half;               // local query index of registers 4 g .. 4 g + 3
+                const f32x4 l4 = *(const f32x4*)(lse_s + ql), d4 = *(const f32x4*)(dl_s + ql);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e, qidx = qt0 + ql + e;
+                    const bool ok = key_ok && !(p.causal && krow > qidx);
+                    const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e])) : 0.f;
+                    pr[r] = pv;
+                    ds[r] = pv * (dp[r] - d4[e]);
+                }
+            }
+            bf16x8 pf[2], df[2];
+            acc_to_frag(pr, pf);
+            acc_to_frag(ds, df);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                av0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(OTs, qb, s2, 0, l31, half), pf[s2], av0, 0, 0, 0);
+                av1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(OTs, qb, s2, 1, l31, half), pf[s2], av1, 0, 0, 0);
+                ak0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(QTs, qb, s2, 0, l31, half), df[s2], ak0, 0, 0, 0);
+                ak1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(QTs, qb, s2, 1, l31, half), df[s2], ak1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    store_T(ak0, ak1, dkp, p.scale);
+    store_T(av0, av1, dvp, 1.0f);
+}
+
+// delta[b, h, t] = sum_d dO[b R + t, h 64 + d] * O[b R + t, h 64 + d]      one thread per (row, head)
+__global__ void attn_delta_kernel(const uint16_t* __restrict__ dout, int64_t lddo, const uint16_t* __restrict__ out, int64_t ldo,
+                                  float* __restrict__ delta, int R, int H, int64_t total) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int h = (int)(e % H);
+    const int64_t row = e / H;
+    const uint4* a = (const uint4*)(dout + row * lddo + h * 64);
+    const uint4* o = (const uint4*)(out + row * ldo + h * 64);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 x = a[i], y = o[i];
+        s += bflo(x.x) * bflo(y.x) + bfhi(x.x) * bfhi(y.x) + bflo(x.y) * bflo(y.y) + bfhi(x.y) * bfhi(y.y) +
+             bflo(x.z) * bflo(y.z) + bfhi(x.z) * bfhi(y.z) + bflo(x.w) * bflo(y.w) + bfhi(x.w) * bfhi(y.w);
+    }
+    const int64_t b = row / R, t = row % R;
+    delta[(b * H + h) * R + t] = s;
+}
+
+// xT[b, h, d, t] = x[b R + t, h 64 + d]       64 x 64 tile per workgroup through LDS
+__global__ __launch_bounds__(256) void head_transpose_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ xT,
+                                                             int R, int H) {
+    __shared__ uint16_t tile[64][66];
+    const int tb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int t0 = tb * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 256, row = id >> 3, ch = id & 7;
+        const uint4 v = *(const uint4*)(x + ((int64_t)b * R + t0 + row) * ldx + h * 64 + ch * 8);
+        uint16_t* d = &tile[row][ch * 8];
+        d[0] = v.x & 0xffff; d[1] = v.x >> 16; d[2] = v.y & 0xffff; d[3] = v.y >> 16;
+        d[4] = v.z & 0xffff; d[5] = v.z >> 16; d[6] = v.w & 0xffff; d[7] = v.w >> 16;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 256, d = id >> 3, ch = id & 7;
+        uint4 o;
+        o.x = tile[ch * 8 + 0][d] | ((uint32_t)tile[ch * 8 + 1][d] << 16);
+        o.y = tile[ch * 8 + 2][d] | ((uint32_t)tile[ch * 8 + 3][d] << 16);
+        o.z = tile[ch * 8 + 4][d] | ((uint32_t)tile[ch * 8 + 5][d] << 16);
+        o.w = tile[ch * 8 + 6][d] | ((uint32_t)tile[ch * 8 + 7][d] << 16);
+        *(uint4*)(xT + (((int64_t)b * H + h) * 64 + d) * R + t0 + ch * 8) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_head_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* xT, int32_t B, int32_t R, int32_t H, void* stream) {
+    SC_CHECK(x && xT && B > 0 && H > 0 && R > 0 && R % 64 == 0 && ldx % 8 == 0, "sc_head_transpose_bf16: bad args");
+    hipLaunchKernelGGL(head_transpose_kernel, dim3(R / 64, H, B), dim3(256), 0, (hipStream_t)stream, x, ldx, xT, R, H);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k, int64_t ldk, const sc_bf16* v, int64_t ldv,
+                                const sc_bf16* out, int64_t ldo, const sc_bf16* dout, int64_t lddo, const sc_bf16* qT,
+                                const sc_bf16* kT, const sc_bf16* doT, const float* lse2, float* delta,
+                                const int32_t* valid_len, sc_bf16* dq, int64_t lddq, sc_bf16* dk, int64_t lddk, sc_bf16* dv,
+                                int64_t lddv, int32_t B, int32_t R, int32_t H, float scale, int32_t causal, void* stream) {
+    SC_CHECK(q && k && v && out && dout && qT && kT && doT && lse2 && delta && valid_len && dq && dk && dv,
+             "sc_attn_bwd_bf16: null pointer");
+    SC_CHECK(B > 0 && H > 0 && R > 0 && R % 128 == 0, "sc_attn_bwd_bf16: R=%d must be a positive multiple of 128", R);
+    SC_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 &&
+                 lddv % 4 == 0, "sc_attn_bwd_bf16: leading dims");
+    const int64_t total = (int64_t)B * R * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, lddo, out,
+                       ldo, delta, R, H, total);
+    SC_LAUNCH_CHECK();
+    bwd_args a;
+    a.q = q; a.k = k; a.v = v; a.dout = dout;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo;
+    a.qT = qT; a.kT = kT; a.doT = doT;
+    a.lse2 = lse2; a.delta = delta; a.valid_len = valid_len;
+    a.dq = dq; a.dk = dk; a.dv = dv;
+    a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.R = R; a.H = H; a.scale = scale; a.c = scale * 1.4426950408889634f; a.causal = causal;
+    const dim3 grid((R / 128) * H * B);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    SC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

@@ -122,17 +122,43 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 def attn_fwd(qk: torch.Tensor, vt: torch.Tensor, valid_len: torch.Tensor, out: torch.Tensor, B: int, R: int, H: int,
-             D: int, scale: float, alg_flops: float = 0.0) -> None:
+             D: int, scale: float, alg_flops: float = 0.0, lse2: Optional[torch.Tensor] = None, causal: bool = False) -> None:
     assert qk.dtype == torch.bfloat16 and vt.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
     assert valid_len.dtype == torch.int32
     if _timer is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     check(lib().sc_attn_fwd_bf16(_p(qk), qk.stride(0), _p(vt), _p(valid_len), _p(out), out.stride(0), B, R, H, D,
-                                 float(scale), _stream()), "sc_attn_fwd_bf16")
+                                 float(scale), _p(lse2), int(causal), _stream()), "sc_attn_fwd_bf16")
     if _timer is not None:
         ev1.record()
         _timer.add("attn_fwd", ev0, ev1, float(alg_flops))
+
+
+def head_transpose(x: torch.Tensor, B: int, R: int, H: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """xT[b, h, d, t] = x[b R + t, h 64 + d]; ``x`` may be a column slice of a wider row-major buffer."""
+    assert x.dtype == torch.bfloat16 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty(B, H, 64, R, device=x.device, dtype=torch.bfloat16)
+    check(lib().sc_head_transpose_bf16(_p(x), x.stride(0), _p(out), B, R, H, _stream()), "sc_head_transpose_bf16")
+    return out
+
+
+def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse2: torch.Tensor,
+             valid_len: torch.Tensor, dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, B: int, R: int, H: int, scale: float,
+             causal: bool = False, kT: Optional[torch.Tensor] = None) -> None:
+    """q, k, v, out, dout, dq, dk, dv: [B R, H 64] views (column slices of wider buffers allowed)."""
+    for t in (q, k, v, out, dout, dq, dk, dv):
+        assert t.dtype == torch.bfloat16 and t.stride(1) == 1
+    qT = head_transpose(q, B, R, H)
+    if kT is None:
+        kT = head_transpose(k, B, R, H)
+    doT = head_transpose(dout, B, R, H)
+    delta = torch.empty(B, H, R, device=q.device, dtype=torch.float32)
+    check(lib().sc_attn_bwd_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), _p(dout),
+                                 dout.stride(0), _p(qT), _p(kT), _p(doT), _p(lse2), _p(delta), _p(valid_len), _p(dq), dq.stride(0),
+                                 _p(dk), dk.stride(0), _p(dv), dv.stride(0), B, R, H, float(scale), int(causal), _stream()),
+          "sc_attn_bwd_bf16")
 
 
 def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Optional[torch.Tensor] = None,

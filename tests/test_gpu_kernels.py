@@ -459,3 +459,46 @@ def test_rowln_gelu_colsum_headmask(dev):
     back = torch.empty(1, D, device=dev)
     ops.headmask(back, torch.arange(H * D, device=dev, dtype=torch.float32).view(H, D), H, D, dh, gather=True)
     assert torch.equal(back[0], torch.tensor([float((j // dh) * D + j) for j in range(D)], device=dev))
+
+
+# ---- attention forward (LSE, causal) and backward against fp32 torch ----------------------------------------------------------
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_backward(dev, causal):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(21 + causal)
+    B, H, R = 2, 3, 256
+    D = H * 64
+    valid = [200, 256] if not causal else [77, 256]
+    qkv = bf(torch.randn(B * R, 3 * D, generator=g)).to(dev)
+    q, k, v = qkv[:, :D], qkv[:, D: 2 * D], qkv[:, 2 * D:]
+    vl = torch.tensor(valid, dtype=torch.int32, device=dev)
+    vt = ops.head_transpose(v, B, R, H)
+    assert torch.equal(vt, v.view(B, R, H, 64).permute(0, 2, 3, 1).contiguous())
+    out = torch.zeros(B * R, D, device=dev, dtype=torch.bfloat16)
+    lse2 = torch.empty(B, H, R, device=dev, dtype=torch.float32)
+    scale = 64 ** -0.5
+    ops.attn_fwd(qkv[:, : 2 * D], vt, vl, out, B, R, H, D, scale, lse2=lse2, causal=causal)
+    # fp32 reference with autograd
+    qf, kf, vf = (t.float().view(B, R, H, 64).transpose(1, 2).detach().requires_grad_() for t in (q, k, v))
+    s = (qf @ kf.transpose(-1, -2)) * scale
+    key_ok = torch.arange(R, device=dev)[None, :] < vl[:, None]                       # (B, R)
+    mask = key_ok[:, None, None, :].expand(B, H, R, R).clone()
+    if causal:
+        mask &= torch.tril(torch.ones(R, R, dtype=torch.bool, device=dev))[None, None]
+    s = s.masked_fill(~mask, float("-inf"))
+    o_ref = torch.softmax(s, dim=-1) @ vf                                           # (B, H, R, 64)
+    o_ref_rows = o_ref.transpose(1, 2).reshape(B * R, D)
+    qrow_ok = key_ok.reshape(B * R)                                                  # only valid queries matter
+    assert rel_l2(out[qrow_ok], o_ref_rows[qrow_ok]) < 1e-2
+    lse_ref = torch.logsumexp(s, dim=-1) * 1.4426950408889634                        # log2 domain
+    assert torch.allclose(lse2.transpose(0, 1)[:, key_ok], lse_ref.transpose(0, 1)[:, key_ok], rtol=1e-3, atol=2e-2)
+    dout = bf(torch.randn(B * R, D, generator=g)).to(dev)
+    dout[~qrow_ok] = 0                                                               # padded queries carry no gradient
+    o_ref_rows.backward(dout.float())
+    dqkv = torch.full((B * R, 3 * D), 7.0, device=dev, dtype=torch.bfloat16)
+    ops.attn_bwd(q, k, v, out, dout, lse2, vl, dqkv[:, :D], dqkv[:, D: 2 * D], dqkv[:, 2 * D:], B, R, H, scale, causal=causal)
+    ref = [t.grad.transpose(1, 2).reshape(B * R, D) for t in (qf, kf, vf)]
+    errs = [rel_l2(dqkv[qrow_ok, i * D: (i + 1) * D], ref[i][qrow_ok]) for i in range(3)]
+    assert max(errs) < 2e-2, errs
+    # padded keys receive exactly zero
+    assert float(dqkv[~qrow_ok][:, D:].abs().max()) == 0.0
