@@ -177,6 +177,18 @@ int sc_sgemm_f32(const float* A, int64_t sai, int64_t sak, const float* Bm, int6
                  int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, const float* bias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Row kernels of the backward pass over bf16 activations (CLIP text tower input gradient, HuBERT layer backward):
+ *   sc_layernorm_bwd_bf16 : dx = LayerNorm'(x; gamma)(dy) (+ dres), statistics recomputed from the saved LN input x;
+ *                           optional per-wave partial sums [n_partial, D] of dgamma = sum dy xhat and dbeta = sum dy
+ *                           (n_partial = 4 * workgroups; reduce with sc_colsum_f32)
+ *   sc_act_bf16           : df == NULL: out = act(u) ; else out = df * act'(u) ; act 1 = erf-GELU, 2 = QuickGELU
+ * ---------------------------------------------------------------------------------------------- */
+int sc_layernorm_bwd_bf16(const sc_bf16* x, int64_t ldx, const sc_bf16* dy, int64_t lddy, const float* gamma, const sc_bf16* dres,
+                          int64_t lddres, sc_bf16* dx, int64_t lddx, int64_t rows, int32_t D, float eps, float* dgamma_partial,
+                          float* dbeta_partial, int32_t n_partial, void* stream);
+int sc_act_bf16(const sc_bf16* u, const sc_bf16* df, sc_bf16* out, int64_t n, int32_t act, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * One-row-per-utterance tail of the parallel head in fp32 on the master weights:
  *   nn.TransformerEncoderLayer (post-LN, GELU) row 0 + final LayerNorm + Linear, as instantiated by
  *   avssl/module/kw_modules/TransformerModels.py:48-97 and consumed at avssl/model/kw_branches.py:266-280.

@@ -7,8 +7,10 @@ Architecture restated from the published model: token_embedding (V x W), learned
 (x * sigmoid(1.702 x)) -> Linear(4W, W)], ln_final, text_projection (W x E).  ViT-B/32: W = 512, 8 heads, 12 layers,
 E = 512; ViT-L/14: W = 768, 12 heads, 12 layers, E = 768.  Parameter names follow openai/CLIP's state dict
 (``model.token_embedding.weight``, ``model.transformer.resblocks.{i}.attn.in_proj_weight``, ...) so a real
-checkpoint can be loaded with ``load_state_dict``.  Scope row a11: stock device-side torch ops (the gradient flows
-THROUGH the frozen tower to the keyword embeddings).
+checkpoint can be loaded with ``load_state_dict``.  The gradient flows THROUGH the frozen tower to the keyword embeddings:
+on a GPU the transformer blocks run on the library's kernels (clip_text_hip.py: bf16 GEMMs, causal attention forward and
+backward, LayerNorm / QuickGELU forward and backward); the stock-op modules below define the parameters, serve a trainable
+tower and the CPU.
 """
 from collections import OrderedDict
 from typing import Optional, Union
@@ -107,6 +109,19 @@ class ClipModel(nn.Module):
                 p.requires_grad = False
         self.to(device)
 
+    def _transformer(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, 77, W) -> (B, 77, W).  Frozen tower on a GPU with head_dim 64: the library's bf16 kernels, forward and input
+        gradient (clip_text_hip.TextTowerFn); otherwise the stock-op blocks defined above."""
+        core = self.model
+        heads = core.transformer.resblocks[0].attn.num_heads
+        if x.is_cuda and not self.text_encoder_trainable and core.transformer.width == 64 * heads:
+            from .clip_text_hip import TextTowerFn, prepare_weights
+            key = (x.device, tuple((p.data_ptr(), p._version) for p in core.transformer.parameters()))
+            if getattr(self, "_hip_key", None) != key:          # (re)converted when a checkpoint is loaded or the module moves
+                self._hip_weights, self._hip_key = prepare_weights(core.transformer, x.device), key
+            return TextTowerFn.apply(x, self._hip_weights, heads)
+        return core.transformer(x.permute(1, 0, 2), core.attn_mask).permute(1, 0, 2)
+
     def update_device(self, device):
         self.device = device
 
@@ -141,7 +156,7 @@ class ClipModel(nn.Module):
         else:
             x = torch.cat([x[:, :1], keywords, x[:, 1 + keyword_num:]], dim=1)
         x = x + self.model.positional_embedding
-        x = self.model.transformer(x.permute(1, 0, 2), self.model.attn_mask).permute(1, 0, 2)
+        x = self._transformer(x)
         x = self.model.ln_final(x)
         if index is not None:
             return x[torch.arange(bsz, device=dev), index] @ self.model.text_projection

@@ -1,0 +1,182 @@
+// Row kernels of the backward pass (HBM-bound): LayerNorm backward over bf16 activations, activation forward / backward
+// (erf-GELU of fairseq's FFN, QuickGELU of CLIP's MLP).  Used by the frozen CLIP text tower's input gradient
+// (avssl/module/clip_official.py:222-279 under autograd) and by the HuBERT layer backward (audio_encoder.trainable).
+#include "sc_common.h"
+
+namespace {
+
+// dx = rstd (g - mean(g) - xhat mean(g xhat)) (+ dres),  g = dy gamma,  statistics recomputed from the saved LN input x.
+// Persistent over rows (row = wave_global + k * n_waves) so that each lane can also accumulate its columns' dgamma / dbeta
+// partials in registers; partial[wave_global][D] is reduced by the caller (sc_colsum_f32): fixed order, no atomics.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                            const uint16_t* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ gamma, const uint16_t* __restrict__ dres,
+                                                            int64_t lddres, uint16_t* __restrict__ dx, int64_t lddx, int64_t rows,
+                                                            int D, float eps, float* __restrict__ dg_part,
+                                                            float* __restrict__ db_part) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    const int nchunks = D >> 2;
+    float ag[NCH][4], ab[NCH][4], gm[NCH][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ag[i][j] = 0.f;
+            ab[i][j] = 0.f;
+            gm[i][j] = ch < nchunks ? gamma[ch * 4 + j] : 0.f;
+        }
+    }
+    for (int64_t row = wg; row < rows; row += nw) {
+        const uint16_t* xr = x + row * ldx;
+        const uint16_t* dr = dy + row * lddy;
+        float xv[NCH][4], dv[NCH][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunks) {
+                const uint2 u = *(const uint2*)(xr + ch * 4), w = *(const uint2*)(dr + ch * 4);
+                xv[i][0] = bflo(u.x); xv[i][1] = bfhi(u.x); xv[i][2] = bflo(u.y); xv[i][3] = bfhi(u.y);
+                dv[i][0] = bflo(w.x); dv[i][1] = bfhi(w.x); dv[i][2] = bflo(w.y); dv[i][3] = bfhi(w.y);
+                sum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xv[i][j] = 0.f; dv[i][j] = 0.f; }
+            }
+        }
+        const float mean = wave_sum(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (lane + i * 64 < nchunks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = xv[i][j] - mean;
+                    sq += d * d;
+                }
+            }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (lane + i * 64 < nchunks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xv[i][j] - mean) * rstd;
+                    const float g = dv[i][j] * gm[i][j];
+                    xv[i][j] = xh;                       // keep xhat
+                    s1 += g;
+                    s2 += g * xh;
+                    ag[i][j] += dv[i][j] * xh;
+                    ab[i][j] += dv[i][j];
+                }
+            }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunks) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rstd * (dv[i][j] * gm[i][j] - s1 - xv[i][j] * s2);
+                if (dres) {
+                    const uint2 r = *(const uint2*)(dres + row * lddres + ch * 4);
+                    o[0] += bflo(r.x); o[1] += bfhi(r.x); o[2] += bflo(r.y); o[3] += bfhi(r.y);
+                }
+                uint2 w;
+                w.x = pack2bf(o[0], o[1]);
+                w.y = pack2bf(o[2], o[3]);
+                *(uint2*)(dx + row * lddx + ch * 4) = w;
+            }
+        }
+    }
+    if (dg_part) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunks) {
+                *(f32x4*)(dg_part + wg * D + ch * 4) = f32x4{ag[i][0], ag[i][1], ag[i][2], ag[i][3]};
+                *(f32x4*)(db_part + wg * D + ch * 4) = f32x4{ab[i][0], ab[i][1], ab[i][2], ab[i][3]};
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float act_fwd(float u, int act) {
+    if (act == 1) return gelu_erf(u);
+    const float sg = 1.f / (1.f + __expf(-1.702f * u));            // QuickGELU (CLIP): u * sigmoid(1.702 u)
+    return u * sg;
+}
+__device__ __forceinline__ float act_grad(float u, int act) {
+    if (act == 1) {                                                  // Phi(u) + u phi(u)
+        const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+        return cdf + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+    }
+    const float sg = 1.f / (1.f + __expf(-1.702f * u));
+    return sg * (1.f + 1.702f * u * (1.f - sg));
+}
+// out = act(u)  (df == nullptr)   or   out = df * act'(u);   8 bf16 per thread
+__global__ void act_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ df, uint16_t* __restrict__ out, int64_t n8,
+                           int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 a = ((const uint4*)u)[i];
+    float v[8] = {bflo(a.x), bfhi(a.x), bflo(a.y), bfhi(a.y), bflo(a.z), bfhi(a.z), bflo(a.w), bfhi(a.w)};
+    if (df) {
+        const uint4 d = ((const uint4*)df)[i];
+        const float g[8] = {bflo(d.x), bfhi(d.x), bflo(d.y), bfhi(d.y), bflo(d.z), bfhi(d.z), bflo(d.w), bfhi(d.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = g[j] * act_grad(v[j], act);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], act);
+    }
+    uint4 o;
+    o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+    ((uint4*)out)[i] = o;
+}
+
+}  // namespace
+
+extern "C" int sc_layernorm_bwd_bf16(const sc_bf16* x, int64_t ldx, const sc_bf16* dy, int64_t lddy, const float* gamma,
+                                     const sc_bf16* dres, int64_t lddres, sc_bf16* dx, int64_t lddx, int64_t rows, int32_t D,
+                                     float eps, float* dgamma_partial, float* dbeta_partial, int32_t n_partial, void* stream) {
+    SC_CHECK(x && dy && gamma && dx, "sc_layernorm_bwd_bf16: null pointer");
+    SC_CHECK(rows > 0 && D > 0 && D % 4 == 0 && D <= 1024, "sc_layernorm_bwd_bf16: D=%d must be a multiple of 4, <= 1024", D);
+    SC_CHECK(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (dres == nullptr || lddres % 4 == 0), "sc_layernorm_bwd_bf16: leading dims");
+    SC_CHECK((dgamma_partial == nullptr) == (dbeta_partial == nullptr), "sc_layernorm_bwd_bf16: both partial buffers or none");
+    // waves = 4 * grid; with partial sums the caller's buffers fix the wave count (n_partial rows of D floats each)
+    int grid;
+    if (dgamma_partial) {
+        SC_CHECK(n_partial >= 4 && n_partial % 4 == 0, "sc_layernorm_bwd_bf16: n_partial must be a positive multiple of 4");
+        grid = n_partial / 4;
+    } else {
+        grid = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (D / 4 + 63) / 64;
+#define SC_LNB(N) hipLaunchKernelGGL((layernorm_bwd_kernel<N>), dim3(grid), dim3(256), 0, s, x, ldx, dy, lddy, gamma, dres, lddres, dx, \
+                                     lddx, rows, D, eps, dgamma_partial, dbeta_partial)
+    switch (nch) {
+        case 1: SC_LNB(1); break;
+        case 2: SC_LNB(2); break;
+        case 3: SC_LNB(3); break;
+        default: SC_LNB(4); break;
+    }
+#undef SC_LNB
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_act_bf16(const sc_bf16* u, const sc_bf16* df, sc_bf16* out, int64_t n, int32_t act, void* stream) {
+    SC_CHECK(u && out && n > 0 && n % 8 == 0, "sc_act_bf16: n must be a positive multiple of 8");
+    SC_CHECK(act == 1 || act == 2, "sc_act_bf16: act=%d (1 erf-GELU, 2 QuickGELU)", act);
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(act_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, df, out, n8, act);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

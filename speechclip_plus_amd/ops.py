@@ -161,6 +161,39 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
           "sc_attn_bwd_bf16")
 
 
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float, dres: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None, want_param_grads: bool = False):
+    """dx = LN'(x)(dy) (+ dres) for bf16 rows; with ``want_param_grads`` also returns (dgamma, dbeta) fp32."""
+    rows, D = x.shape
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and gamma.dtype == torch.float32
+    if out is None:
+        out = torch.empty(rows, D, device=x.device, dtype=torch.bfloat16)
+    dg = db = None
+    n_part = 0
+    if want_param_grads:
+        n_part = 4 * min(1024, (rows + 3) // 4)
+        dg = torch.empty(n_part, D, device=x.device, dtype=torch.float32)
+        db = torch.empty(n_part, D, device=x.device, dtype=torch.float32)
+    check(lib().sc_layernorm_bwd_bf16(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(dres), 0 if dres is None else dres.stride(0),
+                                      _p(out), out.stride(0), rows, D, float(eps), _p(dg), _p(db), n_part, _stream()),
+          "sc_layernorm_bwd_bf16")
+    if not want_param_grads:
+        return out
+    g, b = torch.empty(D, device=x.device, dtype=torch.float32), torch.empty(D, device=x.device, dtype=torch.float32)
+    colsum(dg, D, n_part, D, g)
+    colsum(db, D, n_part, D, b)
+    return out, g, b
+
+
+def act_bf16(u: torch.Tensor, act: int, df: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act 1 = erf-GELU, 2 = QuickGELU; with ``df``: df * act'(u)."""
+    assert u.dtype == torch.bfloat16 and u.is_contiguous() and (df is None or (df.dtype == torch.bfloat16 and df.is_contiguous()))
+    if out is None:
+        out = torch.empty_like(u)
+    check(lib().sc_act_bf16(_p(u), _p(df), _p(out), u.numel(), act, _stream()), "sc_act_bf16")
+    return out
+
+
 def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Optional[torch.Tensor] = None,
                    eps: float = 1e-5, act: int = 0) -> torch.Tensor:
     assert x.dim() == 2 and x.dtype == torch.bfloat16 and x.stride(1) == 1

@@ -175,7 +175,14 @@ def check_branch_vs_oracle(kind, dev="cpu"):
         assert out["dsample_results"]["dsample_feats_length"].cpu().tolist() == ref[2].tolist()
         np.testing.assert_allclose(out["dsample_results"]["quantity_out"].detach().cpu().numpy(), ref[3].numpy(), rtol=1e-3)
         np.testing.assert_allclose(out["keywords"].detach().cpu().numpy(), ref[1].detach().numpy(), rtol=2e-3, atol=2e-4)
-        np.testing.assert_allclose(out["cascaded_audio_feat"].detach().cpu().numpy(), ref[0].detach().numpy(), rtol=5e-3, atol=5e-4)
+        got, want = out["cascaded_audio_feat"].detach().cpu().float(), ref[0].detach().float()
+        if dev == "cpu":
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=5e-3, atol=5e-4)
+        else:
+            # on the GPU the frozen text tower runs on the bf16 kernels (clip_text_hip): bf16 storage + fp32 accumulate through
+            # every block -> rel-L2 <= 2e-2, cosine >= 0.999 (the tolerances of the HuBERT hidden states)
+            assert float((got - want).norm() / want.norm()) < 2e-2
+            assert float(torch.nn.functional.cosine_similarity(got, want, dim=-1).min()) > 0.999
 
 
 @pytest.mark.parametrize("kind", ["cascaded", "hybrid"])

@@ -123,3 +123,30 @@ def test_hybrid_plus_large_end_to_end():
     trainer = ContrastiveTrainer(model)
     l1 = trainer.step(batch).item()
     assert l1 == l1
+
+
+def test_clip_text_tower_kernels_match_stock_blocks():
+    """clip_text_hip.TextTowerFn (bf16 kernels: GEMMs, causal attention fwd / bwd, LayerNorm and QuickGELU fwd / bwd) against the
+    stock fp32 blocks of the same frozen tower: output and input gradient."""
+    from speechclip_plus_amd.clip_text import ClipModel
+    torch.manual_seed(2)
+    clip = ClipModel("ViT-B/32", device="cuda:0", layers=3).eval()
+    core = clip.model
+    with torch.no_grad():                                        # non-trivial LayerNorm parameters
+        for blk in core.transformer.resblocks:
+            for ln in (blk.ln_1, blk.ln_2):
+                ln.weight.add_(torch.randn_like(ln.weight) * 0.1)
+                ln.bias.add_(torch.randn_like(ln.bias) * 0.1)
+    g = torch.Generator().manual_seed(4)
+    B = 5
+    x = (torch.randn(B, 77, 512, generator=g) * 0.5).cuda().requires_grad_()
+    dy = torch.randn(B, 77, 512, generator=g).cuda()
+    y = clip._transformer(x)
+    y.backward(dy)
+    gx = x.grad.clone()
+    x2 = x.detach().clone().requires_grad_()
+    y_ref = core.transformer(x2.permute(1, 0, 2), core.attn_mask).permute(1, 0, 2)
+    y_ref.backward(dy)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    assert rel(y, y_ref) < 2e-2, rel(y, y_ref)
+    assert rel(gx, x2.grad) < 3e-2, rel(gx, x2.grad)

@@ -502,3 +502,31 @@ def test_attention_backward(dev, causal):
     assert max(errs) < 2e-2, errs
     # padded keys receive exactly zero
     assert float(dqkv[~qrow_ok][:, D:].abs().max()) == 0.0
+
+
+def test_layernorm_bwd_and_act(dev):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    rows, D = 1000, 768
+    x = bf(torch.randn(rows, D, generator=g) * 2 + 0.3).to(dev)
+    dy = bf(torch.randn(rows, D, generator=g)).to(dev)
+    dres = bf(torch.randn(rows, D, generator=g)).to(dev)
+    gam = (torch.randn(D, generator=g) * 0.2 + 1).to(dev)
+    xr = x.float().requires_grad_()
+    gr = gam.clone().requires_grad_()
+    br = torch.zeros(D, device=dev, requires_grad=True)
+    F.layer_norm(xr, (D,), gr, br, 1e-5).backward(dy.float())
+    dx, dg, db = ops.layernorm_bwd(x, dy, gam, 1e-5, dres=dres, want_param_grads=True)
+    assert rel_l2(dx, xr.grad + dres.float()) < 6e-3
+    assert rel_l2(dg, gr.grad) < 1e-4 and rel_l2(db, br.grad) < 1e-4
+    dx2 = ops.layernorm_bwd(x, dy, gam, 1e-5)
+    assert rel_l2(dx2, xr.grad) < 6e-3
+    # activations: erf-GELU (1) and QuickGELU (2), forward and derivative
+    u = bf(torch.randn(512, 2048, generator=g) * 2).to(dev)
+    df = bf(torch.randn(512, 2048, generator=g)).to(dev)
+    for act, fn in ((1, F.gelu), (2, lambda t: t * torch.sigmoid(1.702 * t))):
+        ur = u.float().requires_grad_()
+        fr = fn(ur)
+        assert rel_l2(ops.act_bf16(u, act), fr) < 4e-3
+        fr.backward(df.float())
+        assert rel_l2(ops.act_bf16(u, act, df=df), ur.grad) < 4e-3
