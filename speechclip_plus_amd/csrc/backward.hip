@@ -180,3 +180,69 @@ extern "C" int sc_act_bf16(const sc_bf16* u, const sc_bf16* df, sc_bf16* out, in
     SC_LAUNCH_CHECK();
     return 0;
 }
+
+namespace {
+
+// yT[c, r] = x[r, c]   ([rows, cols] bf16 row-major, ldx >= cols  ->  [cols, ldy >= rows]); 64 x 64 tiles through LDS.
+// Feeds the weight-gradient GEMMs: dW[n, k] = sum_rows dY[row, n] X[row, k] = (dY^T) . (X^T)^T with the row index as the
+// contraction (K) dimension of sc_gemm_bf16.
+__global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
+                                                        int64_t ldy, int rows, int cols) {
+    __shared__ uint16_t tile[64][66];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 256, row = id >> 3, ch = id & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + row < rows && c0 + ch * 8 < cols) v = *(const uint4*)(x + (int64_t)(r0 + row) * ldx + c0 + ch * 8);
+        uint16_t* d = &tile[row][ch * 8];
+        d[0] = v.x & 0xffff; d[1] = v.x >> 16; d[2] = v.y & 0xffff; d[3] = v.y >> 16;
+        d[4] = v.z & 0xffff; d[5] = v.z >> 16; d[6] = v.w & 0xffff; d[7] = v.w >> 16;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 256, c = id >> 3, ch = id & 7;
+        if (c0 + c < cols && r0 + ch * 8 < rows) {
+            uint4 o;
+            o.x = tile[ch * 8 + 0][c] | ((uint32_t)tile[ch * 8 + 1][c] << 16);
+            o.y = tile[ch * 8 + 2][c] | ((uint32_t)tile[ch * 8 + 3][c] << 16);
+            o.z = tile[ch * 8 + 4][c] | ((uint32_t)tile[ch * 8 + 5][c] << 16);
+            o.w = tile[ch * 8 + 6][c] | ((uint32_t)tile[ch * 8 + 7][c] << 16);
+            *(uint4*)(y + (int64_t)(c0 + c) * ldy + r0 + ch * 8) = o;
+        }
+    }
+}
+
+// partial[blk][c] = sum over the block's rows of x[row, c]  (bf16 -> fp32; bias gradients).  Threads own 2 columns each.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, int64_t ldx, int64_t rows, int cols,
+                                                          float* __restrict__ partial) {
+    const int c2 = blockIdx.x * 256 + threadIdx.x;           // column pair
+    if (c2 * 2 >= cols) return;
+    const int64_t per = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const uint32_t u = *(const uint32_t*)(x + r * ldx + c2 * 2);
+        s0 += bflo(u);
+        s1 += bfhi(u);
+    }
+    partial[(int64_t)blockIdx.y * cols + c2 * 2] = s0;
+    partial[(int64_t)blockIdx.y * cols + c2 * 2 + 1] = s1;
+}
+
+}  // namespace
+
+extern "C" int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int64_t ldy, int32_t rows, int32_t cols, void* stream) {
+    SC_CHECK(x && y && rows > 0 && cols > 0, "sc_transpose_bf16: bad args");
+    SC_CHECK(rows % 8 == 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "sc_transpose_bf16: rows, cols and leading dims must be multiples of 8");
+    hipLaunchKernelGGL(transpose_kernel, dim3((rows + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_colsum_bf16(const sc_bf16* x, int64_t ldx, int64_t rows, int32_t cols, float* partial, int32_t nblk, void* stream) {
+    SC_CHECK(x && partial && rows > 0 && cols > 0 && cols % 2 == 0 && nblk > 0 && ldx % 2 == 0, "sc_colsum_bf16: bad args");
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((cols / 2 + 255) / 256, nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, partial);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

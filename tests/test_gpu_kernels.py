@@ -530,3 +530,22 @@ def test_layernorm_bwd_and_act(dev):
         assert rel_l2(ops.act_bf16(u, act), fr) < 4e-3
         fr.backward(df.float())
         assert rel_l2(ops.act_bf16(u, act, df=df), ur.grad) < 4e-3
+
+
+def test_transpose_and_weight_gradient(dev):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(13)
+    rows, N, K = 4096, 776, 520                                          # N, K not multiples of the tile sizes
+    dy = bf(torch.randn(rows, N, generator=g)).to(dev)
+    x = bf(torch.randn(rows, K, generator=g)).to(dev)
+    wide = bf(torch.randn(rows, N + 40, generator=g)).to(dev)
+    assert torch.equal(ops.transpose_bf16(dy), dy.t().contiguous())
+    assert torch.equal(ops.transpose_bf16(wide[:, 8: 8 + N]), wide[:, 8: 8 + N].t().contiguous())      # strided source
+    gW0, gb0 = torch.randn(N, K, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+    gW, gb = gW0.clone(), gb0.clone()
+    ops.wgrad_bf16(dy, x, gW, gb)
+    assert rel_l2(gW - gW0, dy.float().t() @ x.float()) < 1e-3
+    assert rel_l2(gb - gb0, dy.float().sum(0)) < 1e-4
+    gW2 = torch.full_like(gW0, 3.0)
+    ops.wgrad_bf16(dy, x, gW2, beta=0.0)
+    assert rel_l2(gW2, dy.float().t() @ x.float()) < 1e-3
