@@ -85,14 +85,15 @@ int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const i
  *   q, k, v, out, dout : row-major [B*R, ld] bf16, head h at columns h*64..h*64+63 of the given base pointers
  *   qT, kT, doT        : per-head transposed copies [B, H, 64, R] (sc_head_transpose_bf16)
  *   delta              : [B, H, R] fp32 workspace (rowsum(dout . out), written here)
- *   rows of padded queries must carry dout = 0; keys t >= valid_len[b] (and t' > t when causal) get zero gradient
+ *   query rows t >= q_rows must carry dout = 0; keys t >= valid_len[b] (and t' > t when causal) get zero gradient
  * sc_head_transpose_bf16: xT[b, h, d, t] = x[b*R + t, h*64 + d]
  * ---------------------------------------------------------------------------------------------- */
 int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k, int64_t ldk, const sc_bf16* v, int64_t ldv,
                      const sc_bf16* out, int64_t ldo, const sc_bf16* dout, int64_t lddo, const sc_bf16* qT, const sc_bf16* kT,
                      const sc_bf16* doT, const float* lse2, float* delta, const int32_t* valid_len, sc_bf16* dq, int64_t lddq,
-                     sc_bf16* dk, int64_t lddk, sc_bf16* dv, int64_t lddv, int32_t B, int32_t R, int32_t H, float scale,
-                     int32_t causal, void* stream);
+                     sc_bf16* dk, int64_t lddk, sc_bf16* dv, int64_t lddv, int32_t B, int32_t R, int32_t H,
+                     int32_t q_rows /* query rows t >= q_rows carry dout = 0 (layout padding) */, float scale, int32_t causal,
+                     void* stream);
 int sc_head_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* xT, int32_t B, int32_t R, int32_t H, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

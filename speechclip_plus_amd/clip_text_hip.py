@@ -91,7 +91,7 @@ class TextTowerFn(torch.autograd.Function):
             datt = ops.linear_bf16(dX2, w.woT)
             dqkv = torch.empty(M, 3 * W, device=dev, dtype=torch.bfloat16)
             ops.attn_bwd(qkv[:, :W], qkv[:, W: 2 * W], qkv[:, 2 * W:], att, datt, lse2, ctx.valid, dqkv[:, :W], dqkv[:, W: 2 * W],
-                         dqkv[:, 2 * W:], B, ROWS, heads, scale, causal=True)
+                         dqkv[:, 2 * W:], B, ROWS, heads, scale, causal=True, q_rows=T)
             dh1 = ops.linear_bf16(dqkv, w.wqkvT)
             dX = ops.layernorm_bwd(X, dh1, w.g1, w.eps1, dres=dX2)
         ctx.saved = None

@@ -16,7 +16,8 @@
 //     dK^T [d][key] += Q^T . dS      A = Q^T rows (LDS)    B = dS accumulator
 // K^T, Q^T, dO^T are per-head transposed copies [B, H, 64, R] made by sc_head_transpose_bf16 (HBM-bound, ~25 us each at
 // B = 64): two kernels and seven products instead of five, but no atomics - every gradient element is written once, in a
-// fixed summation order.  Rows of padded queries carry dO = 0 (the caller's contract) and padded / future keys get P = 0.
+// fixed summation order.  Query rows >= q_rows carry dO = 0 (the caller's contract: layout padding) and are never visited;
+// padded / future keys get P = 0.
 #include "sc_common.h"
 
 namespace {
@@ -68,7 +69,7 @@ struct bwd_args {
     const int32_t* valid_len;                    // [B]
     uint16_t *dq, *dk, *dv;                      // row-major outputs
     int64_t lddq, lddk, lddv;
-    int R, H;
+    int R, H, q_rows;                            // query rows >= q_rows carry dout = 0 (layout padding): never visited
     float scale, c;                              // c = scale * log2(e)
     int causal;
 };
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
     const float* dl_g = p.delta + ((int64_t)b * H + h) * R;
 
     // queries that can see this key block: all valid ones, or (causal) those from the block's first key on
-    const int q_end = n_valid;                                         // rows beyond carry dO = 0
+    const int q_end = p.q_rows;                                        // rows beyond carry dO = 0
     const int t_first = p.causal ? (kblk * 128) / TT : 0;
     const int t_last = (q_end + TT - 1) / TT;                          // exclusive
     for (int t = t_first; t < t_last; ++t) {
@@ -346,10 +347,12 @@ extern "C" int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k,
                                 const sc_bf16* out, int64_t ldo, const sc_bf16* dout, int64_t lddo, const sc_bf16* qT,
                                 const sc_bf16* kT, const sc_bf16* doT, const float* lse2, float* delta,
                                 const int32_t* valid_len, sc_bf16* dq, int64_t lddq, sc_bf16* dk, int64_t lddk, sc_bf16* dv,
-                                int64_t lddv, int32_t B, int32_t R, int32_t H, float scale, int32_t causal, void* stream) {
+                                int64_t lddv, int32_t B, int32_t R, int32_t H, int32_t q_rows, float scale, int32_t causal,
+                                void* stream) {
     SC_CHECK(q && k && v && out && dout && qT && kT && doT && lse2 && delta && valid_len && dq && dk && dv,
              "sc_attn_bwd_bf16: null pointer");
     SC_CHECK(B > 0 && H > 0 && R > 0 && R % 128 == 0, "sc_attn_bwd_bf16: R=%d must be a positive multiple of 128", R);
+    SC_CHECK(q_rows > 0 && q_rows <= R, "sc_attn_bwd_bf16: q_rows=%d", q_rows);
     SC_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 &&
                  lddv % 4 == 0, "sc_attn_bwd_bf16: leading dims");
     const int64_t total = (int64_t)B * R * H;
@@ -363,7 +366,7 @@ extern "C" int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k,
     a.lse2 = lse2; a.delta = delta; a.valid_len = valid_len;
     a.dq = dq; a.dk = dk; a.dv = dv;
     a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-    a.R = R; a.H = H; a.scale = scale; a.c = scale * 1.4426950408889634f; a.causal = causal;
+    a.R = R; a.H = H; a.q_rows = q_rows; a.scale = scale; a.c = scale * 1.4426950408889634f; a.causal = causal;
     const dim3 grid((R / 128) * H * B);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     SC_LAUNCH_CHECK();

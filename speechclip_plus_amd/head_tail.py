@@ -150,6 +150,8 @@ class ParallelHeadFn(torch.autograd.Function):
         if hd is not None and ctx.needs_input_grad[1]:
             d_soft = ops.wsum_bwd(hd.hidden, dX, B, R, D, 1, normalize=hd.normalize)
             d_ws = hd.w_soft * (d_soft - (hd.w_soft * d_soft).sum())
+        if hd is not None and hd.layers_bwd is not None:           # unfrozen HuBERT layers: continue the chain below the weighted sum
+            hd.layers_bwd(dX, hd.w_soft)
         if ctx.feat_meta is not None and ctx.needs_input_grad[2]:
             shape, dtype = ctx.feat_meta
             d_feat = dX[:, 1: 1 + shape[1]].to(dtype)

@@ -159,6 +159,7 @@ class _Plan:
         self.ffn = z(M, F)
         self.hidden = z(arch.layers + 1, M, D)
         self.valid = torch.zeros(B, device=dev, dtype=torch.int32)
+        self.train = {}              # per unfrozen layer: activations kept for the backward (hubert_train.TrainableLayers)
 
 
 class FairseqSpeechEncoder_Hubert(nn.Module):
@@ -175,10 +176,19 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self.arch = arch if arch is not None else ARCHS[name]
         self.pretrained = pretrained
         self.trainable = trainable
-        if trainable or len(reinit_layers) > 0 or len(unfreeze_layers) > 0:
+        assert not (len(reinit_layers) > 0 and len(unfreeze_layers) > 0)               # speech_encoder_plus.py:416
+        train_ids = sorted(set(int(i) for i in (list(reinit_layers) or list(unfreeze_layers))))
+        if train_ids:
+            assert trainable, "reinit_layers / unfreeze_layers need trainable: true (speech_encoder_plus.py:419,434)"
+            if train_ids != list(range(train_ids[0], self.arch.layers)):
+                raise NotImplementedError("the unfrozen / re-initialised layers must be a contiguous block ending at the top layer "
+                                          f"(got {train_ids}): the backward does not yet pass through frozen layers")
+        elif trainable:
             raise NotImplementedError(
-                "HuBERT backward (audio_encoder.trainable / reinit_layers / unfreeze_layers) is not built yet: every "
-                "shipped recipe freezes HuBERT (SURVEY F3); this is scope row f2")
+                "audio_encoder.trainable without reinit_layers / unfreeze_layers fine-tunes the conv extractor, projection and "
+                "pos_conv too; their backward is not built (scope row f2 covers the transformer layers). No shipped recipe "
+                "trains HuBERT (SURVEY F3)")
+        self._train_ids = train_ids
         assert self.arch.extractor_mode in ("default", "layer_norm"), self.arch.extractor_mode
         assert self.arch.embed_dim == self.arch.heads * 64, "the attention kernel is built for head_dim 64"
         if not (isinstance(layer_drop, float) and layer_drop == 0.0) and layer_drop != "original":
@@ -202,6 +212,10 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 logger.warning("no checkpoint available offline: HuBERT weights are seeded random (seed %d)", seed)
             state_dict = random_hubert_state_dict(self.arch, seed)
         self._load_weights(state_dict)
+        self.train_layers = None
+        if train_ids:
+            from .hubert_train import TrainableLayers
+            self.train_layers = TrainableLayers(self.arch, state_dict, train_ids, self._dev, reinit=len(reinit_layers) > 0, seed=seed)
         self._plans: Dict[Tuple[int, int], _Plan] = {}
         if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             self.weightedsum_layer = WeightedSumLayer(
@@ -255,10 +269,14 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self._w = w          # frozen device tensors (not nn.Parameters: no grads, no optimizer state)
 
     def trainable_params(self) -> list:
-        """speech_encoder_plus.py:478-494 (frozen encoder: only the weighted-sum weights train)."""
-        if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
-            return list(self.weightedsum_layer.parameters())
-        return []
+        """speech_encoder_plus.py:478-494.  Frozen encoder: only the weighted-sum weights train; with ``reinit_layers`` the
+        reference hands the optimiser the re-initialised layers alone (not the weighted-sum weights), with ``unfreeze_layers``
+        every parameter that still requires grad."""
+        ws = list(self.weightedsum_layer.parameters()) if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE else []
+        if self.train_layers is None:
+            return ws
+        layer_params = list(self.train_layers.parameters())
+        return layer_params if len(self.reinit_layers) > 0 else layer_params + ws
 
     # ------------------------------------------------------------------------------------------ forward
     def _plan(self, B: int, L: int) -> _Plan:
@@ -270,7 +288,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         return self._plans[key]
 
     @torch.no_grad()
-    def _encode(self, padded: torch.Tensor, wav_len: List[int]) -> _Plan:
+    def _encode(self, padded: torch.Tensor, wav_len: List[int], save: bool = False) -> _Plan:
         """customHubertForward + patched extract_features (speech_encoder_plus.py:29-107) on the device."""
         a, w = self.arch, self._w
         B, L = padded.shape
@@ -325,8 +343,14 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if not a.layer_norm_first:
             # a5: post-LN layers (base): x = LN1(x + attn(x)); x = LN2(x + ffn(x))       (:39-40, :49-53)
             ops.layernorm_bf16(pl.pre, w["ln_enc_g"], w["ln_enc_b"], out=pl.hidden[0])
+            tl = self.train_layers
+            if tl is not None:
+                tl.refresh()
             for i in range(a.layers):
                 x = pl.hidden[i]
+                if tl is not None and i in tl.ids:          # unfrozen layer: fp32 masters' bf16 copies, activations kept for its backward
+                    tl.layer_forward(i, x, pl.hidden[i + 1], pl, save)
+                    continue
                 qkv_attn(x, i)
                 ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T)
                 ops.layernorm_bf16(pl.pre, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
@@ -377,7 +401,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             padded = torch.zeros(len(wav), L, device=self._dev, dtype=torch.float32)
             for b, x in enumerate(wav):
                 padded[b, : lens[b]] = x.to(self._dev, torch.float32)
-        pl = self._encode(padded, lens)
+        save = self.train_layers is not None and self.training and torch.is_grad_enabled()
+        pl = self._encode(padded, lens, save)
         B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
         hidden_states = tuple(pl.hidden[n].view(B, R, D)[:, :T] for n in range(self.arch.layers + 1))
         feat = {"last_hidden_state": hidden_states[-1], "hidden_states": hidden_states}
@@ -390,7 +415,11 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         elif feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             if self.before_trainable is not None:
                 self.before_trainable()                 # train.ContrastiveTrainer: join the optimiser's side stream here
-            return_list.extend([self.weightedsum_layer.forward_padded(pl.hidden, B, R, T, D), feat_len])
+            ws_feat = self.weightedsum_layer.forward_padded(pl.hidden, B, R, T, D)
+            if save:                                    # the head's backward hands dX to the unfrozen layers (hubert_train.py)
+                tl = self.train_layers
+                ws_feat._sc_handle.layers_bwd = lambda dX, w_soft, _pl=pl: tl.backward(_pl, dX, w_soft)
+            return_list.extend([ws_feat, feat_len])
         elif isinstance(feat_select_idx, list):
             return_list.extend([[feat["hidden_states"][i] for i in feat_select_idx], feat_len])
         elif feat_select_idx in feat:

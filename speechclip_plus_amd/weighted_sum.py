@@ -23,6 +23,7 @@ class PaddedFeatHandle:
         self.src, self.hidden, self.ws_layer, self.w_soft = src, hidden, ws_layer, w_soft
         self.normalize = normalize
         self.B, self.R, self.T, self.D = B, R, T, D
+        self.layers_bwd = None       # set by the encoder when transformer layers are unfrozen: callable(dX, w_soft)
 
 
 class _WeightedSumFn(torch.autograd.Function):

@@ -254,3 +254,63 @@ def test_trainer_side_stream_schedule_matches_synchronous():
     assert finals[0][0] == finals[1][0], (finals[0][0], finals[1][0])
     assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
     assert finals[0][0][2] < finals[0][0][0]
+
+
+def test_unfrozen_hubert_layers_gradients_vs_oracle():
+    """audio_encoder.trainable with unfreeze_layers = top two of a 3-layer HuBERT: loss and the gradients of every parameter of
+    the unfrozen layers (attention backward, LayerNorm / GELU backward, dgrad and weight-gradient GEMMs) against the oracle's
+    autograd through the same layers."""
+    import dataclasses
+    import oracle
+    from speechclip_plus_amd import KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    arch = dataclasses.replace(ARCHS["hubert"], layers=3)
+    sd = random_hubert_state_dict(arch, seed=9)
+    torch.manual_seed(9)
+    cfg = base_parallel_config()
+    cfg.audio_encoder.max_audio_len = -1
+    cfg.audio_encoder.trainable = True
+    cfg.audio_encoder.unfreeze_layers = [1, 2]
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train()
+    with torch.no_grad():
+        model.audio_encoder.weightedsum_layer.weights.copy_(torch.tensor([0.2, -0.1, 0.4, 0.3]))
+    tl = model.audio_encoder.train_layers
+    assert {id(p) for p in tl.parameters()} <= {id(p) for p in model.getTrainableParams()}
+    g = torch.Generator().manual_seed(6)
+    lens = [9000, 6100, 9000, 4100, 8000]
+    wavs = [torch.randn(l, generator=g) * 0.5 for l in lens]
+    B = len(lens)
+    img = torch.randn(B, 512, generator=g)
+    ids = torch.tensor([0, 1, 1, 2, 3])
+    wav = torch.zeros(B, max(lens))
+    for b, x in enumerate(wavs):
+        wav[b, : len(x)] = x
+    batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": img.cuda(), "id": ids.cuda()}
+    losses_, _, _ = model(batch)
+    out = model.compute_loss(losses_)
+    out["loss"].backward()
+    # oracle: same weights, layers 1 and 2 require grad
+    o_arch = oracle.HubertArch.base()
+    o_arch.layers = 3
+    W = {k: v.clone().float() for k, v in sd.items()}
+    names = [n for n in W if n.startswith("encoder.layers.1.") or n.startswith("encoder.layers.2.")]
+    for n in names:
+        W[n].requires_grad_(True)
+    hs_o, fl = oracle.speech_encoder_forward(W, o_arch, wavs)
+    head_W = {k: v.detach().cpu().float() for k, v in model.parallel_branch.state_dict().items()}
+    ws_w = model.audio_encoder.weightedsum_layer.weights.detach().cpu()
+    feat = oracle.weighted_sum(ws_w, list(hs_o), False)
+    e = oracle.parallel_branch_forward(head_W, feat, fl, nhead=8)
+    loss_o = oracle.masked_contrastive_loss(e / e.norm(dim=-1, keepdim=True), img / img.norm(dim=-1, keepdim=True), ids)
+    loss_o.backward()
+    assert abs(out["loss"].item() - loss_o.item()) < 5e-3
+    errs = {}
+    for key, fname in tl.fairseq_names.items():
+        ref = W[fname].grad
+        got = tl.p[key].grad
+        assert got is not None and ref is not None, fname
+        if float(ref.norm()) > 1e-8:
+            errs[fname] = rel_l2(got, ref)
+    bad = {k: v for k, v in errs.items() if v > 8e-2}
+    assert not bad, bad
+    print("unfrozen-layer grads: max rel-L2 %.3g" % max(errs.values()))
