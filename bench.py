@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape GEMM timing table to stderr")
+    ap.add_argument("--unfreeze", type=int, default=0, help="train the top K HuBERT transformer layers too (audio_encoder.trainable "
+                    "+ unfreeze_layers; NOT the headline configuration, which freezes HuBERT like every shipped recipe)")
     ap.add_argument("--model", choices=["base", "large", "cascaded_plus", "hybrid_plus_large"], default="base",
                     help="base = BASELINE configs[1] (headline); large = Parallel large; cascaded_plus = configs[2]; "
                          "hybrid_plus_large = configs[4] recipe on one GPU")
@@ -77,6 +79,10 @@ def main():
            "hybrid_plus_large": hybrid_plus_large_config}[args.model]()
     E = int(cfg.clip.embed_dim)
     cfg.audio_encoder.max_audio_len = -1          # 10 s utterances, no 6.4 s training crop (BASELINE configs[1])
+    if args.unfreeze > 0:
+        nl = 24 if large else 12
+        cfg.audio_encoder.trainable = True
+        cfg.audio_encoder.unfreeze_layers = list(range(nl - args.unfreeze, nl))
     model = KWClip_GeneralTransformer(cfg, device=str(dev), hubert_state_dict=sd)
     model.train()
     trainer = ContrastiveTrainer(model)
@@ -168,7 +174,8 @@ def main():
             "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Parallel SpeechCLIP {args.model} train step (HuBERT-{args.model} frozen fwd + weighted sum + CLS "
+            "config": {"workload": (f"[top {args.unfreeze} HuBERT layers unfrozen: fwd + bwd + Adam] " if args.unfreeze else "") +
+                                   f"Parallel SpeechCLIP {args.model} train step (HuBERT-{args.model} frozen fwd + weighted sum + CLS "
                                    f"attention-pool head fwd/bwd + InfoNCE fwd/bwd + Adam), {B} utt/GPU x {args.seconds:g} s "
                                    f"(L={L}, T={T}), CLIP image embeddings given",
                        "global_batch": B * world, "per_gpu_batch": B, "audio_samples": L, "frames": T,

@@ -184,14 +184,22 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ u, const float* __rest
     }
 }
 
-// out[j] = beta * out[j] + alpha * sum_i x[i * ld + j]      (bias gradients, the broadcast-residual gradient)
-__global__ void colsum_kernel(const float* __restrict__ x, int64_t ld, int rows, int cols, float* __restrict__ out,
-                              float alpha, float beta) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cols) return;
+// out[j] = beta * out[j] + alpha * sum_i x[i * ld + j]      (bias gradients, split-K slices, LayerNorm parameter partials)
+// block = 64 columns x 4 row groups: group g adds rows g, g + 4, ... in order, the four group sums are added in order.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int rows, int cols,
+                                                     float* __restrict__ out, float alpha, float beta) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[(int64_t)r * ld + j];
-    out[j] = (beta != 0.f ? beta * out[j] : 0.f) + alpha * s;
+    if (j < cols)
+        for (int r = g; r < rows; r += 4) s += x[(int64_t)r * ld + j];
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0 && j < cols) {
+        const float t = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+        out[j] = (beta != 0.f ? beta * out[j] : 0.f) + alpha * t;
+    }
 }
 
 // dir 0: Qm[h, j] = q[j] if j / dh == h else 0  ([H, D] from [D]);  dir 1: q[j] = Qm[j / dh, j]
@@ -275,7 +283,7 @@ extern "C" int sc_gelu_f32(const float* u, const float* df, float* out, int64_t 
 extern "C" int sc_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float* out, float alpha, float beta,
                              void* stream) {
     SC_CHECK(x && out && rows > 0 && cols > 0, "sc_colsum_f32: bad args");
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out, alpha, beta);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out, alpha, beta);
     SC_LAUNCH_CHECK();
     return 0;
 }

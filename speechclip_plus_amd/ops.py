@@ -173,7 +173,7 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
     dg = db = None
     n_part = 0
     if want_param_grads:
-        n_part = 4 * min(1024, (rows + 3) // 4)
+        n_part = 4 * min(256, (rows + 3) // 4)          # 256 workgroups x 4 waves of partial sums, reduced by colsum
         dg = torch.empty(n_part, D, device=x.device, dtype=torch.float32)
         db = torch.empty(n_part, D, device=x.device, dtype=torch.float32)
     check(lib().sc_layernorm_bwd_bf16(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(dres), 0 if dres is None else dres.stride(0),
@@ -215,7 +215,7 @@ def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional
     gemm_raw(dyT, rows, xT, rows, part, K, N, K, Kc, out_f32=True, nb1=S, sA=(Kc, 0), sW=(Kc, 0), sC=(N * K, 0))
     colsum(part, N * K, S, N * K, gW, beta=beta)
     if gb is not None:
-        nblk = 64
+        nblk = 256
         pb = torch.empty(nblk, N, device=dy.device, dtype=torch.float32)
         check(lib().sc_colsum_bf16(_p(dy), dy.stride(0), rows, N, _p(pb), nblk, _stream()), "sc_colsum_bf16")
         colsum(pb, N, nblk, N, gb, beta=beta)
