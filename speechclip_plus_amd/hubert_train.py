@@ -61,6 +61,10 @@ class TrainableLayers(nn.Module):
                 self.p[_key(i, name)] = nn.Parameter(t.to(device))
                 self.fairseq_names[_key(i, name)] = f"encoder.layers.{i}.{name}"
         self._copies, self._versions = {}, None
+        self.grad_ready_hook = None              # callable(layer_id): every gradient of that layer has been enqueued (train.py)
+
+    def layer_parameters(self, i: int) -> List[nn.Parameter]:
+        return [self.p[_key(i, name)] for name in _PARAMS]
 
     def get(self, i: int, name: str) -> nn.Parameter:
         return self.p[_key(i, name)]
@@ -131,6 +135,8 @@ class TrainableLayers(nn.Module):
             d_out = g if d_out is None else d_out + g
             if i in self._copies and i in pl.train:
                 d_out = self._layer_backward(i, pl, d_out, need_dx=i > lo)
+                if self.grad_ready_hook is not None:
+                    self.grad_ready_hook(i)
             else:
                 raise NotImplementedError("a frozen layer above an unfrozen one needs the input-gradient-only backward; "
                                           "unfreeze a contiguous top block (the reference recipes unfreeze / reinit top layers)")

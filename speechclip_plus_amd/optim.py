@@ -54,6 +54,19 @@ class FlatAdam:
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
 
+    def span(self, params) -> tuple:
+        """(start, end) of the smallest range of the flat buffers covering ``params`` (registered consecutively for one module)."""
+        ids = {id(p) for p in params}
+        off, lo, hi = 0, None, None
+        for p in self.params:
+            k = p.numel()
+            if id(p) in ids:
+                lo = off if lo is None else lo
+                hi = off + k
+            off += k
+        assert lo is not None, "parameters are not managed by this optimiser"
+        return lo, hi
+
     def zero_grad(self) -> None:
         self.flat_g.zero_()
         off = 0

@@ -31,11 +31,33 @@ class ContrastiveTrainer:
         self.replicated = [p for p in model.criterion.parameters() if p.requires_grad]   # evaluated on the full batch by every rank
         self.side = torch.cuda.Stream() if self.opt.flat_g.is_cuda else None
         self._pending = False
+        # unfrozen HuBERT layers (hubert_train.py): the slice of the flat gradient buffer that belongs to a layer is all-reduced
+        # on the side stream as soon as that layer's backward has been enqueued, i.e. under the backward of the layers below it
+        self._reduced = []                         # [start, end) ranges already summed across ranks in this step
+        tl = getattr(model.audio_encoder, "train_layers", None)
+        if tl is not None:
+            self._layer_span = {i: self.opt.span(tl.layer_parameters(i)) for i in tl.ids}
+            tl.grad_ready_hook = self._layer_ready
         # join point: first use of a trainable parameter in a step
         model.audio_encoder.before_trainable = self.join
         for m in (model.parallel_branch, model.cascaded_branch, model.criterion):
             if m is not None:
                 m.register_forward_pre_hook(lambda *_: self.join())
+
+    def _world(self) -> int:
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _layer_ready(self, i: int) -> None:
+        if self._world() == 1:
+            return
+        lo, hi = self._layer_span[i]
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                dist.all_reduce(self.opt.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(self.opt.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        self._reduced.append((lo, hi))
 
     def join(self) -> None:
         """Make the current stream wait for the optimiser work of the previous step (no host synchronisation)."""
@@ -81,6 +103,14 @@ class ContrastiveTrainer:
 
     def _finish(self, lr: float) -> None:
         scale_replicated_grads(self.replicated, self.group)
-        self.allreduce.launch()
-        self.allreduce.wait()
+        if not self._reduced:
+            self.allreduce.launch()
+            self.allreduce.wait()
+        else:                                          # everything the per-layer collectives have not covered yet
+            pos = 0
+            for lo, hi in sorted(self._reduced) + [(self.opt.n, self.opt.n)]:
+                if lo > pos and self._world() > 1:
+                    dist.all_reduce(self.opt.flat_g[pos:lo], op=dist.ReduceOp.SUM, group=self.group)
+                pos = max(pos, hi)
+            self._reduced = []
         self.opt.step(lr=lr)
