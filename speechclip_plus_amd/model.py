@@ -318,6 +318,66 @@ class KWClip_GeneralTransformer(nn.Module):
         losses_ = self.compute_loss(outputs["loss_feats"])
         return {"loss": losses_["loss"], **{f"train_{k}": v for k, v in losses_.items()}}
 
+    # --------------------------------------------------------------------------------------------- validation (f4)
+    def validation_step(self, batch: dict, batch_idx: int = 0) -> dict:
+        """kwClip.py:195-228: the features the epoch-end retrieval needs (source branch by ``retrieval.audio_feat_src``)."""
+        with torch.no_grad():
+            losses_, log_metrics, others = self.forward(batch)
+        src = self.config.retrieval.get("audio_feat_src", "parallel")
+        audio_feat = others["cascaded_audio_feat"] if src == "cascaded" else others["parallel_audio_feat"]
+        return {"id": others["id"], "audio_feat": audio_feat, "image_feat": others.get("image_feat", None),
+                "loss_feats": losses_, "log_metrics": log_metrics}
+
+    def validation_epoch_end(self, outputs: list) -> dict:
+        """kwClip.py:447-482: one image embedding per id (the last seen, as the reference's dict does), audio x image scores
+        and recall@k in both directions - everything stays on the device (retrieval.mutualRetrieval)."""
+        from .retrieval import mutualRetrieval
+        ids = torch.cat([o["id"] for o in outputs], dim=0)
+        audio = torch.cat([o["audio_feat"] for o in outputs], dim=0).float()
+        imgs = torch.cat([o["image_feat"] for o in outputs], dim=0).float()
+        # last occurrence of every id, ids kept in first-seen order (python dict semantics of the reference)
+        uniq, inv = torch.unique(ids, return_inverse=True)
+        n = ids.shape[0]
+        pos = torch.arange(n, device=ids.device)
+        last = torch.zeros(uniq.shape[0], dtype=torch.long, device=ids.device).scatter_reduce(0, inv, pos, "amax", include_self=False)
+        first = torch.full((uniq.shape[0],), n, dtype=torch.long, device=ids.device).scatter_reduce(0, inv, pos, "amin", include_self=False)
+        order = torch.argsort(first)
+        img_ids, img_feats = uniq[order], imgs[last[order]]
+        score_per_audio = audio @ img_feats.t()
+        return mutualRetrieval(score_per_A=score_per_audio, score_per_B=score_per_audio.t(), AB_answers=ids, BA_answers=img_ids,
+                               recall_at=self.recall_at)
+
+    # --------------------------------------------------------------------------------------------- checkpoints (f4)
+    @staticmethod
+    def split_reference_state_dict(sd: dict):
+        """A PyTorch-Lightning checkpoint of the reference (``ckpt["state_dict"]``) -> (hubert_state_dict in fairseq naming,
+        rest).  Reference keys: ``audio_encoder.encoder.<fairseq HubertModel key>``, ``audio_encoder.weightedsum_layer.weights``,
+        ``parallel_branch.* / cascaded_branch.*`` (same module names here), ``criterion.temperature``, ``clip.model.*`` (the text
+        side is kept, ``clip.model.visual.*`` is dropped: image embeddings are inputs)."""
+        hubert, rest = {}, {}
+        for k, v in sd.items():
+            if k.startswith("audio_encoder.encoder."):
+                hubert[k[len("audio_encoder.encoder."):]] = v
+            elif k.startswith("clip.model.visual.") or k in ("clip.model.logit_scale",):
+                continue
+            else:
+                rest[k] = v
+        return hubert, rest
+
+    @classmethod
+    def from_reference_checkpoint(cls, config, state_dict: dict, **kw):
+        """Build the model on the reference's weights: the HuBERT part is converted by the encoder's loader (fairseq key names,
+        weight-normed pos_conv accepted), everything else loads by name (non-strict for keys this build does not hold)."""
+        hubert, rest = cls.split_reference_state_dict(state_dict)
+        model = cls(config, hubert_state_dict=hubert if hubert else None, **kw)
+        own = model.state_dict()
+        loadable = {k: v for k, v in rest.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
+        missing = [k for k in own if k not in loadable and not k.startswith("audio_encoder.train_layers.")]
+        model.load_state_dict(loadable, strict=False)
+        model._reference_load_report = {"loaded": sorted(loadable), "not_in_checkpoint": missing,
+                                        "ignored": sorted(k for k in rest if k not in loadable)}
+        return model
+
     # ---------------------------------------------------------------------------------------------
     def encode_speech(self, wav) -> dict:
         """kwClip.py:1042-1091 (un-normalised branch output)."""

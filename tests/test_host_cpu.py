@@ -74,3 +74,31 @@ def test_config_and_model_surface():
     for m in ["forward", "compute_loss", "encode_speech", "feature_extractor_s3prl", "processWavs",
               "getTrainableParams", "training_step", "training_step_end", "forward_audio", "forward_image"]:
         assert callable(getattr(KWClip_GeneralTransformer, m))
+
+
+def test_collate_general_matches_reference_format():
+    """data.collate_general against the batch dict of avssl/data/collate_function.py:7-36 (semantics restated in the test:
+    wav zero-padded batch-first + wav_len from the raw lengths, tensors stacked, scalars -> int64)."""
+    from speechclip_plus_amd.data import collate_general
+    g = torch.Generator().manual_seed(0)
+    rows = [{"wav": torch.randn(n, generator=g), "image": torch.randn(3, 4, 4, generator=g), "id": i * 7}
+            for i, n in enumerate([50, 120, 33])]
+    out = collate_general(rows)
+    assert set(out) == {"wav", "image", "id", "wav_len"}
+    assert out["wav"].shape == (3, 120) and out["wav_len"].tolist() == [50, 120, 33] and out["wav_len"].dtype == torch.long
+    for i, r in enumerate(rows):
+        assert torch.equal(out["wav"][i, : len(r["wav"])], r["wav"]) and float(out["wav"][i, len(r["wav"]):].abs().sum()) == 0
+    assert torch.equal(out["image"], torch.stack([r["image"] for r in rows])) and out["id"].tolist() == [0, 7, 14]
+
+
+def test_split_reference_state_dict_key_map():
+    from speechclip_plus_amd.model import KWClip_GeneralTransformer
+    sd = {"audio_encoder.encoder.encoder.layers.3.fc1.weight": 1, "audio_encoder.encoder.feature_extractor.conv_layers.0.0.weight": 2,
+          "audio_encoder.weightedsum_layer.weights": 3, "parallel_branch.cls": 4, "parallel_branch.self_att.model.layers.0.linear1.bias": 5,
+          "criterion.temperature": 6, "clip.model.visual.conv1.weight": 7, "clip.model.token_embedding.weight": 8,
+          "clip.model.logit_scale": 9}
+    hubert, rest = KWClip_GeneralTransformer.split_reference_state_dict(sd)
+    assert hubert == {"encoder.layers.3.fc1.weight": 1, "feature_extractor.conv_layers.0.0.weight": 2}
+    assert set(rest) == {"audio_encoder.weightedsum_layer.weights", "parallel_branch.cls",
+                         "parallel_branch.self_att.model.layers.0.linear1.bias", "criterion.temperature",
+                         "clip.model.token_embedding.weight"}
