@@ -169,12 +169,19 @@ def check_branch_vs_oracle(kind, dev="cpu"):
         out = br(audio_feat=feat.to(dev), audio_feat_len=lens.to(dev),
                  otherInputs={"global_step": 0, "target_len": tgt.to(dev)} if training else {})
         ref = fn(W, feat, lens, nhead, training=training, target_len=tgt if training else None, nhead_clip=8, sot=sot, eot=eot)
+        def close(got, want, rtol, atol):
+            got, want = got.detach().cpu().float(), want.detach().float()
+            if dev == "cpu":
+                np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=rtol, atol=atol)
+            else:       # bf16 projections / text tower on the GPU: rel-L2 <= 2e-2 (SURVEY 8d tolerances)
+                assert float((got - want).norm() / want.norm()) < 2e-2
+
         if kind == "hybrid":
-            np.testing.assert_allclose(out["parallel_audio_feat"].detach().cpu().numpy(), ref[0].numpy(), rtol=2e-3, atol=2e-4)
+            close(out["parallel_audio_feat"], ref[0], 2e-3, 2e-4)
             ref = ref[1:]
         assert out["dsample_results"]["dsample_feats_length"].cpu().tolist() == ref[2].tolist()
         np.testing.assert_allclose(out["dsample_results"]["quantity_out"].detach().cpu().numpy(), ref[3].numpy(), rtol=1e-3)
-        np.testing.assert_allclose(out["keywords"].detach().cpu().numpy(), ref[1].detach().numpy(), rtol=2e-3, atol=2e-4)
+        close(out["keywords"], ref[1], 2e-3, 2e-4)
         got, want = out["cascaded_audio_feat"].detach().cpu().float(), ref[0].detach().float()
         if dev == "cpu":
             np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=5e-3, atol=5e-4)
