@@ -64,6 +64,80 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
     }
 }
 
+// Half a wave per row, 16-byte accesses (8 x bf16 per lane per chunk): half the load / store instructions of the kernel above
+// and one shuffle step less per reduction.  D % 8 == 0, D <= 1024, rows 16-byte aligned.  Same arithmetic order per element
+// (fp32 two-pass mean / variance); the reduction tree differs, so results match the kernel above to fp32 round-off, not bitwise.
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int NCH8>   // 8-element chunks per lane: D <= 256 * NCH8
+__global__ __launch_bounds__(256) void layernorm16_kernel(const uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, uint16_t* __restrict__ y, int64_t ldy,
+                                                          int64_t rows, int D, float eps, int act) {
+    const int l = threadIdx.x & 31;
+    int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = row < rows;
+    if (!live) row = rows - 1;                    // keep the half-wave in the shuffles; its stores are skipped
+    const int nchunks = D >> 3;
+    float v[NCH8][8];
+    float sum = 0.f;
+    const uint16_t* xr = x + row * ldx;
+#pragma unroll
+    for (int i = 0; i < NCH8; ++i) {
+        const int ch = l + i * 32;
+        if (ch < nchunks) {
+            const uint4 u = *(const uint4*)(xr + ch * 8);
+            v[i][0] = bflo(u.x); v[i][1] = bfhi(u.x); v[i][2] = bflo(u.y); v[i][3] = bfhi(u.y);
+            v[i][4] = bflo(u.z); v[i][5] = bfhi(u.z); v[i][6] = bflo(u.w); v[i][7] = bfhi(u.w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[i][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    const float mean = half_wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH8; ++i)
+        if (l + i * 32 < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[i][j] - mean;
+                sq += d * d;
+            }
+        }
+    const float rstd = rsqrtf(half_wave_sum(sq) / (float)D + eps);
+    if (!live) return;
+    uint16_t* yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < NCH8; ++i) {
+        const int ch = l + i * 32;
+        if (ch < nchunks) {
+            float o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 g = *(const f32x4*)(gamma + ch * 8 + 4 * h);
+                const f32x4 bt = *(const f32x4*)(beta + ch * 8 + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[4 * h + j] = (v[i][4 * h + j] - mean) * rstd * g[j] + bt[j];
+            }
+            if (act == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const f32x2 gg = gelu_erf2(f32x2{o[j], o[j + 1]});
+                    o[j] = gg.x; o[j + 1] = gg.y;
+                }
+            }
+            uint4 w;
+            w.x = pack2bf(o[0], o[1]); w.y = pack2bf(o[2], o[3]); w.z = pack2bf(o[4], o[5]); w.w = pack2bf(o[6], o[7]);
+            *(uint4*)(yr + ch * 8) = w;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- weighted sum
 // out[b, t + row_off, :] = sum_n w[n] * h[n, b, t, :]   (t + row_off < R)
 __global__ __launch_bounds__(256) void wsum_fwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w,
@@ -297,8 +371,18 @@ extern "C" int sc_layernorm_bf16(const sc_bf16* x, int64_t ldx, const float* gam
     SC_CHECK(ldx % 4 == 0 && ldy % 4 == 0 && rows > 0, "sc_layernorm_bf16: bad ld/rows");
     SC_CHECK(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)gamma % 16) == 0 &&
                  ((uintptr_t)beta % 16) == 0, "sc_layernorm_bf16: alignment");
-    dim3 grid((unsigned)((rows + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
+    if (D % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0) {
+        // 16-byte path: half a wave per row, 8 rows per workgroup
+        dim3 grid8((unsigned)((rows + 7) / 8));
+        const int nch8 = (D / 8 + 31) / 32;
+        if (nch8 <= 2) hipLaunchKernelGGL(layernorm16_kernel<2>, grid8, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
+        else if (nch8 == 3) hipLaunchKernelGGL(layernorm16_kernel<3>, grid8, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
+        else hipLaunchKernelGGL(layernorm16_kernel<4>, grid8, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
+    dim3 grid((unsigned)((rows + 3) / 4));
     const int nch = (D / 4 + 63) / 64;
     if (nch <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
     else if (nch == 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
