@@ -1,0 +1,98 @@
+"""Data-parallel train steps on the GPU: two ranks (gloo rendezvous, both on cuda:0 - a 1-GPU box cannot host an RCCL world) each
+take half of a batch through train.ContrastiveTrainer; the parameters after two steps must equal those of one process that
+takes the whole batch.  Exercises the packed all-gather with autograd, the replicated-parameter scaling (trainable
+temperature), the side-stream all-reduce + Adam schedule and, in the second case, unfrozen HuBERT layers with their per-layer
+gradient all-reduce."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(unfreeze):
+    import dataclasses
+    sys.path.insert(0, ROOT)
+    from speechclip_plus_amd import KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    arch = dataclasses.replace(ARCHS["hubert"], layers=3)
+    sd = random_hubert_state_dict(arch, seed=4)
+    torch.manual_seed(4)
+    cfg = base_parallel_config()
+    cfg.audio_encoder.max_audio_len = -1
+    cfg.cl_loss.args.temperature_trainable = True
+    cfg.audio_encoder.optim.args.lr = 1e-2                      # large steps so that a wrong gradient scale shows
+    cfg.audio_encoder.scheduler.warmup = 1
+    if unfreeze:
+        cfg.audio_encoder.trainable = True
+        cfg.audio_encoder.unfreeze_layers = [1, 2]
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train()
+    return model, ContrastiveTrainer(model)
+
+
+def _batch(lo, hi):
+    g = torch.Generator().manual_seed(31)
+    B, L = 8, 9000
+    wav = torch.randn(B, L, generator=g) * 0.4
+    lens = torch.tensor([9000, 7000, 9000, 5200, 8000, 9000, 6100, 9000])
+    img = torch.randn(B, 512, generator=g)
+    ids = torch.tensor([0, 1, 1, 2, 3, 4, 4, 5])
+    return {"wav": wav[lo:hi].cuda(), "wav_len": lens[lo:hi], "image": img[lo:hi].cuda(), "id": ids[lo:hi].cuda()}
+
+
+def _worker(rank, world, port, unfreeze, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, trainer = _make(unfreeze)
+    n = 8 // world
+    batch = _batch(rank * n, (rank + 1) * n)
+    losses = [float(trainer.step(batch)) for _ in range(2)]
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put((losses, trainer.opt.flat_p.detach().cpu().numpy()))      # by value: torch tensors travel as fds the exiting rank may close
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("unfreeze", [False, True])
+def test_two_ranks_equal_one_process(unfreeze):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, unfreeze, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    losses2, flat2 = q.get(timeout=240)
+    flat2 = torch.from_numpy(flat2)
+    for p in procs:
+        p.join(timeout=60)
+    model, trainer = _make(unfreeze)
+    batch = _batch(0, 8)
+    losses1 = [float(trainer.step(batch)) for _ in range(2)]
+    torch.cuda.synchronize()
+    flat1 = trainer.opt.flat_p.detach().cpu()
+    assert abs(losses1[0] - losses2[0]) < 1e-4 and abs(losses1[1] - losses2[1]) < 2e-3, (losses1, losses2)
+    rel = float((flat1 - flat2).norm() / flat1.norm())
+    moved = float((flat1 - _initial_flat(unfreeze)).norm() / flat1.norm())
+    assert rel < 0.05 * moved + 1e-7, (rel, moved)
+
+
+def _initial_flat(unfreeze):
+    _, trainer = _make(unfreeze)
+    return trainer.opt.flat_p.detach().cpu()
