@@ -185,21 +185,40 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ u, const float* __rest
 }
 
 // out[j] = beta * out[j] + alpha * sum_i x[i * ld + j]      (bias gradients, split-K slices, LayerNorm parameter partials)
-// block = 64 columns x 4 row groups: group g adds rows g, g + 4, ... in order, the four group sums are added in order.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int rows, int cols,
-                                                     float* __restrict__ out, float alpha, float beta) {
-    __shared__ float part[4][64];
+// Many rows: block = 64 columns x 16 row groups; group g adds rows g, g + 16, ... in order, the group sums are added in order.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int64_t ld, int rows, int cols,
+                                                      float* __restrict__ out, float alpha, float beta) {
+    __shared__ float part[16][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 64 + c;
     float s = 0.f;
     if (j < cols)
-        for (int r = g; r < rows; r += 4) s += x[(int64_t)r * ld + j];
+        for (int r = g; r < rows; r += 16) s += x[(int64_t)r * ld + j];
     part[g][c] = s;
     __syncthreads();
     if (g == 0 && j < cols) {
-        const float t = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+        float t = part[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += part[k][c];
         out[j] = (beta != 0.f ? beta * out[j] : 0.f) + alpha * t;
     }
+}
+// Few rows (split-K slices over millions of columns): one thread per 4 consecutive columns, rows added in order.
+__global__ __launch_bounds__(256) void colsum_few_rows_kernel(const float* __restrict__ x, int64_t ld, int rows, int64_t cols4,
+                                                              float* __restrict__ out, float alpha, float beta) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols4) return;
+    f32x4 s = *(const f32x4*)(x + j * 4);
+    for (int r = 1; r < rows; ++r) {
+        const f32x4 v = *(const f32x4*)(x + (int64_t)r * ld + j * 4);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    f32x4 o = f32x4{alpha * s[0], alpha * s[1], alpha * s[2], alpha * s[3]};
+    if (beta != 0.f) {
+        const f32x4 p = *(const f32x4*)(out + j * 4);
+        o[0] += beta * p[0]; o[1] += beta * p[1]; o[2] += beta * p[2]; o[3] += beta * p[3];
+    }
+    *(f32x4*)(out + j * 4) = o;
 }
 
 // dir 0: Qm[h, j] = q[j] if j / dh == h else 0  ([H, D] from [D]);  dir 1: q[j] = Qm[j / dh, j]
@@ -283,7 +302,13 @@ extern "C" int sc_gelu_f32(const float* u, const float* df, float* out, int64_t 
 extern "C" int sc_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float* out, float alpha, float beta,
                              void* stream) {
     SC_CHECK(x && out && rows > 0 && cols > 0, "sc_colsum_f32: bad args");
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out, alpha, beta);
+    if (rows <= 16 && cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+        const int64_t cols4 = cols / 4;
+        hipLaunchKernelGGL(colsum_few_rows_kernel, dim3((unsigned)((cols4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, rows,
+                           cols4, out, alpha, beta);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, rows, cols, out, alpha, beta);
+    }
     SC_LAUNCH_CHECK();
     return 0;
 }
