@@ -9,6 +9,8 @@ from the head's backward (head_tail.ParallelHeadFn) with the gradient of the wei
     d hidden[n] = softmax(w)[n] * dX[:, 1 : T + 1]                     (the weighted sum reads every hidden state)
     per layer (post-LN):  LayerNorm' -> fc2 wgrad / dgrad -> GELU' -> fc1 wgrad / dgrad (+ residual) -> LayerNorm'
                           -> out_proj wgrad / dgrad -> attention backward -> qkv wgrad / dgrad (+ residual)
+    pre-LN (large) order: the two LayerNorms sit in front of the attention and of the FFN; their backward is fused with the
+                          residual add.  Frozen layers above the lowest unfrozen one run the same chain without weight gradients.
 
 Weight gradients are written in fp32 straight into the parameters' ``.grad`` (views of the optimiser's flat buffer), so the
 single flat all-reduce of parallel.GradAllReduce covers them.  Dropout / layerdrop inside the unfrozen layers
@@ -40,11 +42,14 @@ def _gacc(p: torch.Tensor) -> torch.Tensor:
 class TrainableLayers(nn.Module):
     def __init__(self, arch, sd: Dict[str, torch.Tensor], layer_ids: List[int], device, reinit: bool = False, seed: int = 0):
         super().__init__()
-        if arch.layer_norm_first:
-            raise NotImplementedError("trainable layers are built for the post-LN (HuBERT-base) layer order only")
         self.arch = arch
         self.ids = sorted(int(i) for i in layer_ids)
         assert all(0 <= i < arch.layers for i in self.ids), layer_ids
+        # frozen layers ABOVE the lowest unfrozen one still carry the gradient down: they keep their activations and run the
+        # input-gradient half of the backward (no weight gradients)
+        self.pass_ids = [i for i in range(self.ids[0], arch.layers) if i not in self.ids]
+        self._frozen = {i: {name: sd[f"encoder.layers.{i}.{name}"].detach().float().to(device) for name in _PARAMS}
+                        for i in self.pass_ids}
         self.p = nn.ParameterDict()
         self.fairseq_names = {}                      # parameter key -> "encoder.layers.{i}.{name}" (checkpoint mapping)
         g = torch.Generator(device="cpu").manual_seed(seed)
@@ -66,8 +71,8 @@ class TrainableLayers(nn.Module):
     def layer_parameters(self, i: int) -> List[nn.Parameter]:
         return [self.p[_key(i, name)] for name in _PARAMS]
 
-    def get(self, i: int, name: str) -> nn.Parameter:
-        return self.p[_key(i, name)]
+    def get(self, i: int, name: str) -> torch.Tensor:
+        return self.p[_key(i, name)] if i in self.ids else self._frozen[i][name]
 
     def refresh(self) -> None:
         """bf16 working copies (+ transposed ones for the dgrad products) of the fp32 masters, rebuilt after an optimiser step."""
@@ -75,7 +80,7 @@ class TrainableLayers(nn.Module):
         if ver == self._versions:
             return
         bf = lambda t: t.detach().to(torch.bfloat16).contiguous()
-        for i in self.ids:
+        for i in self.ids + [j for j in self.pass_ids if j not in self._copies]:
             c = {}
             qkv = torch.cat([self.get(i, f"self_attn.{n}.weight").detach() for n in ("q_proj", "k_proj", "v_proj")], 0)
             c["qkv_w"], c["qkv_wT"] = bf(qkv), bf(qkv.t())
@@ -90,88 +95,128 @@ class TrainableLayers(nn.Module):
 
     # -------------------------------------------------------------------------------------------------- forward
     def layer_forward(self, i: int, x: torch.Tensor, out: torch.Tensor, pl, save: bool) -> None:
-        """hidden[i] -> hidden[i + 1] (post-LN).  ``save``: keep the activations the backward needs in ``pl.train[i]``."""
+        """hidden[i] -> hidden[i + 1].  ``save``: keep the activations the backward needs in ``pl.train[i]``.
+        post-LN (base):  pre1 = x + attn(x) ; x1 = LN1(pre1) ; pre2 = x1 + ffn(x1) ; out = LN2(pre2)
+        pre-LN (large):  x1 = LN1(x) ; pre1 = x + attn(x1) ; x2 = LN2(pre1) ; out = pre1 + ffn(x2)"""
         a, c = self.arch, self._copies[i]
         B, R, M, T = pl.B, pl.R, pl.M, pl.T
         D, F, H = a.embed_dim, a.ffn_dim, a.heads
         dev = x.device
+        pre_ln = a.layer_norm_first
         if save:
             s = pl.train.get(i)
             if s is None:
                 z = lambda *sh, dtype=torch.bfloat16: torch.zeros(*sh, device=dev, dtype=dtype)
                 s = pl.train[i] = dict(qkv=z(M, 3 * D), ctx=z(M, D), lse2=z(B, H, R, dtype=torch.float32), pre1=z(M, D), x1=z(M, D),
-                                       u=z(M, F), f=z(M, F), pre2=z(M, D))
+                                       u=z(M, F), f=z(M, F), pre2=z(M, D))       # pre-LN: x1 = LN1(x), pre2 = LN2(pre1)
         else:
-            s = dict(qkv=torch.empty(M, 3 * D, device=dev, dtype=torch.bfloat16), ctx=pl.ctx, lse2=None, pre1=pl.pre, x1=pl.x1,
-                     u=pl.ffn, f=pl.ffn, pre2=pl.pre)
-        ops.linear_bf16(x, c["qkv_w"], c["qkv_b"], out=s["qkv"], alg_rows=B * T)
+            s = dict(qkv=torch.empty(M, 3 * D, device=dev, dtype=torch.bfloat16), ctx=pl.ctx, lse2=None,
+                     pre1=torch.empty(M, D, device=dev, dtype=torch.bfloat16) if pre_ln else pl.pre, x1=pl.x1, u=pl.ffn, f=pl.ffn,
+                     pre2=pl.pre)
+        attn_in = x
+        if pre_ln:
+            ops.layernorm_bf16(x, c["ln1_g"], c["ln1_b"], out=s["x1"])
+            attn_in = s["x1"]
+        ops.linear_bf16(attn_in, c["qkv_w"], c["qkv_b"], out=s["qkv"], alg_rows=B * T)
         ops.head_transpose(s["qkv"][:, 2 * D:], B, R, H, out=pl.vt)
         ops.attn_fwd(s["qkv"][:, : 2 * D], pl.vt, pl.valid, s["ctx"], B, R, H, D, (D // H) ** -0.5, lse2=s["lse2"],
                      alg_flops=4.0 * B * T * T * D)
         ops.linear_bf16(s["ctx"], c["o_w"], c["o_b"], out=s["pre1"], residual=x, alg_rows=B * T)
-        ops.layernorm_bf16(s["pre1"], c["ln1_g"], c["ln1_b"], out=s["x1"])
+        ffn_in = s["pre2"] if pre_ln else s["x1"]
+        if pre_ln:
+            ops.layernorm_bf16(s["pre1"], c["ln2_g"], c["ln2_b"], out=s["pre2"])
+        else:
+            ops.layernorm_bf16(s["pre1"], c["ln1_g"], c["ln1_b"], out=s["x1"])
         if save:
-            ops.linear_bf16(s["x1"], c["fc1_w"], c["fc1_b"], out=s["u"], alg_rows=B * T)
+            ops.linear_bf16(ffn_in, c["fc1_w"], c["fc1_b"], out=s["u"], alg_rows=B * T)
             ops.act_bf16(s["u"], 1, out=s["f"])
         else:
-            ops.linear_bf16(s["x1"], c["fc1_w"], c["fc1_b"], out=s["f"], act=1, alg_rows=B * T)
-        ops.linear_bf16(s["f"], c["fc2_w"], c["fc2_b"], out=s["pre2"], residual=s["x1"], alg_rows=B * T)
-        ops.layernorm_bf16(s["pre2"], c["ln2_g"], c["ln2_b"], out=out)
+            ops.linear_bf16(ffn_in, c["fc1_w"], c["fc1_b"], out=s["f"], act=1, alg_rows=B * T)
+        if pre_ln:
+            ops.linear_bf16(s["f"], c["fc2_w"], c["fc2_b"], out=out, residual=s["pre1"], alg_rows=B * T)
+        else:
+            ops.linear_bf16(s["f"], c["fc2_w"], c["fc2_b"], out=s["pre2"], residual=s["x1"], alg_rows=B * T)
+            ops.layernorm_bf16(s["pre2"], c["ln2_g"], c["ln2_b"], out=out)
 
     # -------------------------------------------------------------------------------------------------- backward
-    def backward(self, pl, dX: torch.Tensor, w_soft: torch.Tensor) -> None:
-        """dX [B, R, D] fp32: gradient of the weighted-sum output (row 0 = CLS slot, rows 1..T = frames 0..T-1)."""
+    def backward(self, pl, dX: torch.Tensor, w_soft: torch.Tensor, normalize: bool = False) -> None:
+        """dX [B, R, D] fp32: gradient of the weighted-sum output (row 0 = CLS slot, rows 1..T = frames 0..T-1).
+        ``normalize``: the weighted sum reads layer_norm(hidden[n]) without affine (weighted_sum.py:41-42)."""
         a = self.arch
         B, R, M, T = pl.B, pl.R, pl.M, pl.T
-        D, F, H = a.embed_dim, a.ffn_dim, a.heads
+        D = a.embed_dim
         lo = self.ids[0]
-        assert self.ids == list(range(lo, lo + len(self.ids))) or True     # gaps are fine: frozen layers in between still propagate
         dfeat = torch.zeros(B, R, D, device=dX.device, dtype=torch.float32)
         dfeat[:, :T] = dX[:, 1: T + 1]
         dfeat = dfeat.view(M, D)
+        ones = torch.ones(D, device=dX.device, dtype=torch.float32) if normalize else None
         d_out = None
         for i in range(a.layers - 1, lo - 1, -1):
             g = (dfeat * w_soft[i + 1]).to(torch.bfloat16)                 # d hidden[i + 1] from the weighted sum
+            if normalize:
+                g = ops.layernorm_bwd(pl.hidden[i + 1], g, ones, 1e-5)
             d_out = g if d_out is None else d_out + g
-            if i in self._copies and i in pl.train:
-                d_out = self._layer_backward(i, pl, d_out, need_dx=i > lo)
-                if self.grad_ready_hook is not None:
-                    self.grad_ready_hook(i)
-            else:
-                raise NotImplementedError("a frozen layer above an unfrozen one needs the input-gradient-only backward; "
-                                          "unfreeze a contiguous top block (the reference recipes unfreeze / reinit top layers)")
+            assert i in pl.train, "unfrozen layers ran without saved activations (forward in eval / no_grad mode?)"
+            d_out = self._layer_backward(i, pl, d_out, need_dx=i > lo, train=i in self.ids)
+            if self.grad_ready_hook is not None and i in self.ids:
+                self.grad_ready_hook(i)
 
-    def _layer_backward(self, i: int, pl, d_out: torch.Tensor, need_dx: bool):
+    def _layer_backward(self, i: int, pl, d_out: torch.Tensor, need_dx: bool, train: bool = True):
         a, c, s = self.arch, self._copies[i], pl.train[i]
         B, R, M, T = pl.B, pl.R, pl.M, pl.T
         D, F, H = a.embed_dim, a.ffn_dim, a.heads
         x = pl.hidden[i]
+        pre_ln = a.layer_norm_first
         P = lambda name: _gacc(self.get(i, name))
-        # LN2 -> fc2 -> GELU -> fc1 (+ residual)
-        dpre2, dg, db = ops.layernorm_bwd(s["pre2"], d_out, c["ln2_g"], 1e-5, want_param_grads=True)
-        P("final_layer_norm.weight").add_(dg)
-        P("final_layer_norm.bias").add_(db)
-        ops.wgrad_bf16(dpre2, s["f"], P("fc2.weight"), P("fc2.bias"))
-        df = ops.linear_bf16(dpre2, c["fc2_wT"])
+
+        def ln_bwd(xin, dy, which, dres=None):                             # LayerNorm backward (+ its parameter gradients)
+            gname = "self_attn_layer_norm" if which == 1 else "final_layer_norm"
+            if not train:
+                return ops.layernorm_bwd(xin, dy, c[f"ln{which}_g"], 1e-5, dres=dres)
+            dx, dg, db = ops.layernorm_bwd(xin, dy, c[f"ln{which}_g"], 1e-5, dres=dres, want_param_grads=True)
+            P(gname + ".weight").add_(dg)
+            P(gname + ".bias").add_(db)
+            return dx
+
+        def wgrad(dy, xin, name):
+            if train:
+                ops.wgrad_bf16(dy, xin, P(name + ".weight"), P(name + ".bias"))
+
+        # ---- FFN half
+        if pre_ln:                                                          # out = pre1 + fc2(gelu(fc1(LN2(pre1))))
+            dffn_out, ffn_in = d_out, s["pre2"]
+        else:                                                               # out = LN2(pre2), pre2 = x1 + fc2(gelu(fc1(x1)))
+            dffn_out, ffn_in = ln_bwd(s["pre2"], d_out, 2), s["x1"]
+        wgrad(dffn_out, s["f"], "fc2")
+        df = ops.linear_bf16(dffn_out, c["fc2_wT"])
         du = ops.act_bf16(s["u"], 1, df=df, out=df)
-        ops.wgrad_bf16(du, s["x1"], P("fc1.weight"), P("fc1.bias"))
-        dx1 = ops.linear_bf16(du, c["fc1_wT"], residual=dpre2)
-        # LN1 -> out_proj -> attention -> qkv (+ residual)
-        dpre1, dg, db = ops.layernorm_bwd(s["pre1"], dx1, c["ln1_g"], 1e-5, want_param_grads=True)
-        P("self_attn_layer_norm.weight").add_(dg)
-        P("self_attn_layer_norm.bias").add_(db)
-        ops.wgrad_bf16(dpre1, s["ctx"], P("self_attn.out_proj.weight"), P("self_attn.out_proj.bias"))
+        wgrad(du, ffn_in, "fc1")
+        if pre_ln:
+            dx2n = ops.linear_bf16(du, c["fc1_wT"])
+            dpre1 = ln_bwd(s["pre1"], dx2n, 2, dres=d_out)                  # through LN2 + the residual
+        else:
+            dx1 = ops.linear_bf16(du, c["fc1_wT"], residual=dffn_out)
+            dpre1 = ln_bwd(s["pre1"], dx1, 1)
+        # ---- attention half:  pre1 = x + out_proj(attn(qkv(attn_in)))
+        wgrad(dpre1, s["ctx"], "self_attn.out_proj")
         dctx = ops.linear_bf16(dpre1, c["o_wT"])
         dqkv = torch.empty(M, 3 * D, device=x.device, dtype=torch.bfloat16)
         qkv = s["qkv"]
         ops.attn_bwd(qkv[:, :D], qkv[:, D: 2 * D], qkv[:, 2 * D:], s["ctx"], dctx, s["lse2"], pl.valid, dqkv[:, :D], dqkv[:, D: 2 * D],
                      dqkv[:, 2 * D:], B, R, H, (D // H) ** -0.5, q_rows=T)
-        gW = torch.empty(3 * D, D, device=x.device, dtype=torch.float32)
-        gb = torch.empty(3 * D, device=x.device, dtype=torch.float32)
-        ops.wgrad_bf16(dqkv, x, gW, gb, beta=0.0)
-        for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
-            P(f"self_attn.{n}.weight").add_(gW[j * D: (j + 1) * D])
-            P(f"self_attn.{n}.bias").add_(gb[j * D: (j + 1) * D])
+        attn_in = s["x1"] if pre_ln else x
+        if train:
+            gW = torch.empty(3 * D, D, device=x.device, dtype=torch.float32)
+            gb = torch.empty(3 * D, device=x.device, dtype=torch.float32)
+            ops.wgrad_bf16(dqkv, attn_in, gW, gb, beta=0.0)
+            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                P(f"self_attn.{n}.weight").add_(gW[j * D: (j + 1) * D])
+                P(f"self_attn.{n}.bias").add_(gb[j * D: (j + 1) * D])
+        if pre_ln:                       # LN1 sits in front of the attention: its parameters need the gradient even at the lowest layer
+            if not (need_dx or train):
+                return None
+            dx1n = ops.linear_bf16(dqkv, c["qkv_wT"])
+            return ln_bwd(x, dx1n, 1, dres=dpre1)
         if not need_dx:
             return None
         return ops.linear_bf16(dqkv, c["qkv_wT"], residual=dpre1)

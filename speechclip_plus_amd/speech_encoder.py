@@ -187,9 +187,6 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         train_ids = sorted(set(int(i) for i in (list(reinit_layers) or list(unfreeze_layers))))
         if train_ids:
             assert trainable, "reinit_layers / unfreeze_layers need trainable: true (speech_encoder_plus.py:419,434)"
-            if train_ids != list(range(train_ids[0], self.arch.layers)):
-                raise NotImplementedError("the unfrozen / re-initialised layers must be a contiguous block ending at the top layer "
-                                          f"(got {train_ids}): the backward does not yet pass through frozen layers")
         elif trainable:
             raise NotImplementedError(
                 "audio_encoder.trainable without reinit_layers / unfreeze_layers fine-tunes the conv extractor, projection and "
@@ -385,7 +382,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 tl.refresh()
             for i in range(a.layers):
                 x = pl.hidden[i]
-                if tl is not None and i in tl.ids:          # unfrozen layer: fp32 masters' bf16 copies, activations kept for its backward
+                if tl is not None and (i in tl.ids or i in tl.pass_ids):   # unfrozen (or frozen above an unfrozen one): activations kept
                     tl.layer_forward(i, x, pl.hidden[i + 1], pl, save)
                     continue
                 qkv_attn(x, i)
@@ -398,8 +395,14 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             # pre-LN layers (large): x = x + attn(LN1(x)); x = x + ffn(LN2(x)); layer_results are NOT passed through
             # the encoder's final LayerNorm (fairseq applies it to `x` only, which the reference never reads)
             pl.hidden[0].copy_(pl.pre)
+            tl = self.train_layers
+            if tl is not None:
+                tl.refresh()
             for i in range(a.layers):
                 x = pl.hidden[i]
+                if tl is not None and (i in tl.ids or i in tl.pass_ids):
+                    tl.layer_forward(i, x, pl.hidden[i + 1], pl, save)
+                    continue
                 ops.layernorm_bf16(x, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
                 qkv_attn(pl.x1, i)
                 ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T)
@@ -454,7 +457,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             ws_feat = self.weightedsum_layer.forward_padded(pl.hidden, B, R, T, D)
             if save:                                    # the head's backward hands dX to the unfrozen layers (hubert_train.py)
                 tl = self.train_layers
-                ws_feat._sc_handle.layers_bwd = lambda dX, w_soft, _pl=pl: tl.backward(_pl, dX, w_soft)
+                ws_feat._sc_handle.layers_bwd = lambda dX, w_soft, _pl=pl: tl.backward(
+                    _pl, dX, w_soft, normalize=self.weightedsum_layer.normalize_features)
             return_list.extend([ws_feat, feat_len])
         elif isinstance(feat_select_idx, list):
             return_list.extend([[feat["hidden_states"][i] for i in feat_select_idx], feat_len])

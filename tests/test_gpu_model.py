@@ -355,3 +355,60 @@ def test_reference_checkpoint_round_trip_and_validation_epoch(setup):
     ref = oracle.mutual_retrieval(score, score.t(), ids, img_ids, model.recall_at)
     for got, want in zip(rec, ref):
         assert {k: round(float(v), 4) for k, v in got.items()} == {k: round(float(v), 4) for k, v in want.items()}
+
+
+def test_unfrozen_layer_prelN_large_with_frozen_layer_above():
+    """HuBERT-large layer order (pre-LN), normalised weighted sum, unfreeze_layers = [1] of 3 layers: layer 2 stays frozen but must
+    carry the gradient down (input-gradient half of its backward).  Gradients of layer 1 against the oracle's autograd."""
+    import dataclasses
+    import oracle
+    from speechclip_plus_amd import KWClip_GeneralTransformer, large_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    arch = dataclasses.replace(ARCHS["hubert_large_ll60k"], layers=3)
+    sd = random_hubert_state_dict(arch, seed=12)
+    torch.manual_seed(12)
+    cfg = large_parallel_config()
+    cfg.audio_encoder.max_audio_len = -1
+    cfg.audio_encoder.trainable = True
+    cfg.audio_encoder.unfreeze_layers = [1]
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train()
+    with torch.no_grad():
+        model.audio_encoder.weightedsum_layer.weights.copy_(torch.tensor([0.2, -0.1, 0.4, 0.3]))
+    tl = model.audio_encoder.train_layers
+    assert tl.ids == [1] and tl.pass_ids == [2]
+    g = torch.Generator().manual_seed(16)
+    lens = [9000, 6100, 9000, 4100]
+    wavs = [torch.randn(l, generator=g) * 0.5 for l in lens]
+    B = len(lens)
+    img = torch.randn(B, 768, generator=g)
+    ids = torch.tensor([0, 1, 1, 2])
+    wav = torch.zeros(B, max(lens))
+    for b, x in enumerate(wavs):
+        wav[b, : len(x)] = x
+    batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": img.cuda(), "id": ids.cuda()}
+    losses_, _, _ = model(batch)
+    out = model.compute_loss(losses_)
+    out["loss"].backward()
+    o_arch = oracle.HubertArch.large()
+    o_arch.layers = 3
+    W = {k: v.clone().float() for k, v in sd.items()}
+    names = [n for n in W if n.startswith("encoder.layers.1.")]
+    for n in names:
+        W[n].requires_grad_(True)
+    hs_o, fl = oracle.speech_encoder_forward(W, o_arch, wavs)
+    head_W = {k: v.detach().cpu().float() for k, v in model.parallel_branch.state_dict().items()}
+    ws_w = model.audio_encoder.weightedsum_layer.weights.detach().cpu()
+    feat = oracle.weighted_sum(ws_w, list(hs_o), True)
+    e = oracle.parallel_branch_forward(head_W, feat, fl, nhead=8)
+    loss_o = oracle.masked_contrastive_loss(e / e.norm(dim=-1, keepdim=True), img / img.norm(dim=-1, keepdim=True), ids)
+    loss_o.backward()
+    assert abs(out["loss"].item() - loss_o.item()) < 5e-3
+    errs = {}
+    for key, fname in tl.fairseq_names.items():
+        ref, got = W[fname].grad, tl.p[key].grad
+        assert got is not None and ref is not None, fname
+        if float(ref.norm()) > 1e-8:
+            errs[fname] = rel_l2(got, ref)
+    bad = {k: v for k, v in errs.items() if v > 8e-2}
+    assert not bad, bad
+    print("pre-LN unfrozen layer below a frozen one: max rel-L2 %.3g" % max(errs.values()))
