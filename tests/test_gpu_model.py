@@ -412,3 +412,24 @@ def test_unfrozen_layer_prelN_large_with_frozen_layer_above():
     bad = {k: v for k, v in errs.items() if v > 8e-2}
     assert not bad, bad
     print("pre-LN unfrozen layer below a frozen one: max rel-L2 %.3g" % max(errs.values()))
+
+
+def test_edge_batches_single_utterance_and_very_short_utterance(setup):
+    """Edge cases of the reference's inputs: a batch of one utterance, and a ragged batch whose shortest utterance (400 samples,
+    one conv frame, feat_len = round(400 / 320) = 1) sits next to full-length ones.  Encoder states of every valid frame and
+    the pooled embedding against the oracle."""
+    model, sd, o_arch, head_W, oracle = setup
+    g = torch.Generator().manual_seed(40)
+    for lens in ([7000], [12000, 400, 3999, 12000]):
+        wavs = [torch.randn(l, generator=g) * 0.5 for l in lens]
+        with torch.no_grad():
+            out = model.encode_speech(wavs)["parallel_audio_feat"].float().cpu()
+            _, fl_m, hs_m = model.forward_audio(*model.processWavs(wavs), return_hidden_states=True)
+        hs_o, fl = oracle.speech_encoder_forward(sd, o_arch, wavs)
+        assert fl_m.cpu().tolist() == fl.tolist()
+        for b, n in enumerate(fl.tolist()):
+            assert rel_l2(hs_m[-1][b, :n], hs_o[-1][b, :n]) < 2e-2, (lens, b)
+        ws_w = model.audio_encoder.weightedsum_layer.weights.detach().cpu()
+        feat = oracle.weighted_sum(ws_w, list(hs_o), False)
+        e = oracle.parallel_branch_forward(head_W, feat, fl, nhead=8)
+        assert float(F.cosine_similarity(out, e, dim=-1).min()) > 0.999, lens
