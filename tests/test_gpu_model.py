@@ -433,3 +433,31 @@ def test_edge_batches_single_utterance_and_very_short_utterance(setup):
         feat = oracle.weighted_sum(ws_w, list(hs_o), False)
         e = oracle.parallel_branch_forward(head_W, feat, fl, nhead=8)
         assert float(F.cosine_similarity(out, e, dim=-1).min()) > 0.999, lens
+
+
+def test_speech_encoder_api_like_the_reference_test():
+    """The call patterns and properties of the reference's own encoder test (test/test_speech_encoder.py:15-45, try_model):
+    list-of-waveforms input with descending lengths, feat_select_idx "all" / "hidden_states" / index list, out_dim,
+    downsample_rate == 320, frame count within 2 of max(feat_len)."""
+    import dataclasses
+    from speechclip_plus_amd import random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS, FairseqSpeechEncoder_Hubert
+    arch = dataclasses.replace(ARCHS["hubert"], layers=3)
+    model = FairseqSpeechEncoder_Hubert(name="hubert", pretrained=False, trainable=False, device="cuda:0", feat_select_idx="all",
+                                        state_dict=random_hubert_state_dict(arch, seed=1), arch=arch).eval()
+    with torch.no_grad():
+        wav_len = [80000 - 97 * i for i in range(8)]
+        wav = [torch.randn(l, dtype=torch.float).cuda() for l in wav_len]
+        feat_all, feat_len = model(wav, wav_len)
+        feat_hid, _ = model(wav, wav_len, "hidden_states")
+        feat_hid = tuple(h.clone() for h in feat_hid)                  # the encoder's states live in a reused workspace
+        max_hidden = len(feat_hid)
+        feat_layers_2, _ = model(wav, wav_len, [2, max_hidden - 1])
+        assert isinstance(feat_all, dict)
+        assert isinstance(feat_hid, (tuple, list)) and isinstance(feat_hid[0], torch.Tensor)
+        assert feat_hid[0].shape[0] == 8 and feat_hid[0].shape[-1] == model.out_dim
+        assert (feat_layers_2[0].float() - feat_hid[2].float()).abs().mean() < 1e-5
+        assert (feat_layers_2[1].float() - feat_hid[max_hidden - 1].float()).abs().mean() < 1e-5
+        assert model.downsample_rate == 320
+        for h in range(len(feat_hid)):
+            assert abs(feat_hid[h].shape[1] - feat_len.max().item()) <= 2
