@@ -102,3 +102,15 @@ def test_split_reference_state_dict_key_map():
     assert set(rest) == {"audio_encoder.weightedsum_layer.weights", "parallel_branch.cls",
                          "parallel_branch.self_att.model.layers.0.linear1.bias", "criterion.temperature",
                          "clip.model.token_embedding.weight"}
+
+
+def test_audio_transform_like_the_reference_test():
+    """test/test_audio_transform.py of the reference, on this build's random_crop_max_length (audio_transforms.py:5-23)."""
+    from speechclip_plus_amd.speech_encoder import random_crop_max_length
+    wav = torch.randn((10000,), dtype=torch.float)
+    out_1 = random_crop_max_length(wav, 1000)
+    out_2 = random_crop_max_length(wav, 1000, 100)
+    assert out_1.shape == (1000,)
+    assert out_2.shape == (100,)
+    short = torch.randn(300)
+    assert torch.equal(random_crop_max_length(short, 1000), short)                    # shorter than the cap: returned as is
