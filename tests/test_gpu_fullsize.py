@@ -58,3 +58,38 @@ def test_full_size_properties(model):
         a = torch.nn.functional.normalize(e1.float(), dim=-1)
         r = mutualRetrieval(a @ a.T, a @ a.T, torch.arange(B), torch.arange(B), [1, 5])
         assert r[0]["recall@1"] == 100.0 and r[1]["recall@1"] == 100.0
+
+
+def test_ten_second_utterances_vs_oracle():
+    """Full-length utterances (10 s -> T = 499 frames, and a ragged 7.7 s one) through all 12 layers against the oracle: the
+    13 hidden states over the valid frames (rel-L2 <= 2e-2) and the pooled embedding (cosine >= 0.999).  Two utterances keep
+    the CPU oracle at a few seconds; the B = 64 geometry is covered by the invariants above."""
+    import oracle
+    from speechclip_plus_amd import KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict, HubertArch
+    sd = random_hubert_state_dict(HubertArch(), seed=7122)
+    torch.manual_seed(7122)
+    cfg = base_parallel_config()
+    cfg.audio_encoder.max_audio_len = -1
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd).eval()
+    with torch.no_grad():
+        model.audio_encoder.weightedsum_layer.weights.copy_(torch.linspace(-1, 1, 13))
+    g = torch.Generator().manual_seed(3)
+    wavs = [torch.randn(160000, generator=g) * 0.5, torch.randn(123456, generator=g) * 0.5]
+    with torch.no_grad():
+        out = model.encode_speech(wavs)["parallel_audio_feat"].float().cpu()
+        _, fl_m, hs_m = model.forward_audio(*model.processWavs(wavs), return_hidden_states=True)
+        hs_m = [h.float().cpu() for h in hs_m]
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    hs_o, fl = oracle.speech_encoder_forward(sd, oracle.HubertArch.base(), wavs)
+    assert fl_m.cpu().tolist() == fl.tolist() == [499, 386]
+    worst = 0.0
+    for n in range(13):
+        for b, nv in enumerate(fl.tolist()):
+            e = float((hs_m[n][b, :nv] - hs_o[n][b, :nv]).norm() / hs_o[n][b, :nv].norm())
+            worst = max(worst, e)
+    assert worst < 2e-2, worst
+    head_W = {k: v.detach().cpu().float() for k, v in model.parallel_branch.state_dict().items()}
+    feat = oracle.weighted_sum(model.audio_encoder.weightedsum_layer.weights.detach().cpu(), list(hs_o), False)
+    e = oracle.parallel_branch_forward(head_W, feat, fl, nhead=8)
+    assert float(torch.nn.functional.cosine_similarity(out, e, dim=-1).min()) > 0.999
+    print("10 s utterances: worst hidden-state rel-L2 %.3g" % worst)
