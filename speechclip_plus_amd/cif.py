@@ -82,7 +82,16 @@ class CIF(nn.Module):
             xp = torch.nn.functional.pad(x, (0, 0, pad, pad))                       # (B, T + 2 pad, C)
             cols = torch.cat([xp[:, j: j + T + 2 * pad - k + 1] for j in range(k)], dim=-1)   # (B, T', k C), tap-major
             w = conv.weight.permute(0, 2, 1).reshape(conv.out_channels, k * C)    # [C_out, k, C_in] flattened tap-major
-            x = act(drop(torch.nn.functional.linear(cols, w, conv.bias)))
+            if self.training and cols.is_cuda:
+                # training: bf16 operands / fp32 accumulation on the library's GEMM with its dgrad + weight-gradient products
+                # (the reference trains under precision-16 autocast; the keyword COUNT is pinned by the target-length scaling
+                # of alpha, so the discrete part of CIF does not depend on this rounding).  Inference stays fp32: there the
+                # count is floor(sum alpha), which must be the fp32 oracle's.
+                from .linear_fn import linear_bf16_autograd
+                y = linear_bf16_autograd(cols, w, conv.bias)
+            else:
+                y = torch.nn.functional.linear(cols, w, conv.bias)
+            x = act(drop(y))
         return x
 
     def integrate_and_fire(self, input: torch.Tensor, alpha: torch.Tensor,
