@@ -191,7 +191,8 @@ int sc_act_bf16(const sc_bf16* u, const sc_bf16* df, sc_bf16* out, int64_t n, in
 /*   sc_transpose_bf16 : y[c, r] = x[r, c]  - operands of the weight-gradient GEMMs (dW = dY^T X: the row index becomes the
  *                       contraction dimension of sc_gemm_bf16, split along K over the batch dimension, partials in fp32)
  *   sc_colsum_bf16    : partial[blk, c] = sum of the block's rows of x[:, c] in fp32 (bias gradients; reduce with sc_colsum_f32) */
-int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int64_t ldy, int32_t rows, int32_t cols, void* stream);
+int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int64_t ldy, int32_t rows, int32_t cols,
+                      float* colsum_partial /* NULL, or [ceil(rows / 64), cols] fp32: per-64-row-block column sums of x */, void* stream);
 int sc_colsum_bf16(const sc_bf16* x, int64_t ldx, int64_t rows, int32_t cols, float* partial, int32_t nblk, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

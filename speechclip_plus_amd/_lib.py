@@ -59,7 +59,7 @@ SIGNATURES = {
     "sc_infonce_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "sc_layernorm_bwd_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_float,
                               c_void_p, c_void_p, c_int, c_void_p],
-    "sc_transpose_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p],
+    "sc_transpose_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p],
     "sc_colsum_bf16": [c_void_p, c_i64, c_i64, c_int, c_void_p, c_int, c_void_p],
     "sc_act_bf16": [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p],
     "sc_sgemm_f32_ex": [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int,

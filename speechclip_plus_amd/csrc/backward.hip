@@ -186,8 +186,10 @@ namespace {
 // yT[c, r] = x[r, c]   ([rows, cols] bf16 row-major, ldx >= cols  ->  [cols, ldy >= rows]); 64 x 64 tiles through LDS.
 // Feeds the weight-gradient GEMMs: dW[n, k] = sum_rows dY[row, n] X[row, k] = (dY^T) . (X^T)^T with the row index as the
 // contraction (K) dimension of sc_gemm_bf16.
+// colpart (optional): colpart[row block][c] = sum of the block's 64 rows of column c in fp32 - the bias gradient's first stage
+// comes for free with the pass that already reads dY.
 __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
-                                                        int64_t ldy, int rows, int cols) {
+                                                        int64_t ldy, int rows, int cols, float* __restrict__ colpart) {
     __shared__ uint16_t tile[64][66];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
 #pragma unroll
@@ -200,6 +202,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restri
         d[4] = v.z & 0xffff; d[5] = v.z >> 16; d[6] = v.w & 0xffff; d[7] = v.w >> 16;
     }
     __syncthreads();
+    if (colpart && tid < 64 && c0 + tid < cols) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) s += bf2f(tile[r][tid]);       // rows past the end were loaded as zeros
+        colpart[(int64_t)blockIdx.x * cols + c0 + tid] = s;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int id = tid + i * 256, c = id >> 3, ch = id & 7;
@@ -232,10 +240,12 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
 
 }  // namespace
 
-extern "C" int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int64_t ldy, int32_t rows, int32_t cols, void* stream) {
+extern "C" int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int64_t ldy, int32_t rows, int32_t cols,
+                                 float* colsum_partial, void* stream) {
     SC_CHECK(x && y && rows > 0 && cols > 0, "sc_transpose_bf16: bad args");
     SC_CHECK(rows % 8 == 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "sc_transpose_bf16: rows, cols and leading dims must be multiples of 8");
-    hipLaunchKernelGGL(transpose_kernel, dim3((rows + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols);
+    hipLaunchKernelGGL(transpose_kernel, dim3((rows + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols,
+                       colsum_partial);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -187,13 +187,15 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
     return out, g, b
 
 
-def transpose_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """[rows, cols] (row stride >= cols) -> contiguous [cols, rows]; rows and cols multiples of 8."""
+def transpose_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None, colsum_partial: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[rows, cols] (row stride >= cols) -> contiguous [cols, rows]; rows and cols multiples of 8.  ``colsum_partial``
+    ([ceil(rows / 64), cols] fp32) receives the per-64-row-block column sums of x (first stage of a bias gradient)."""
     rows, cols = x.shape
     assert x.dtype == torch.bfloat16 and x.stride(1) == 1
     if out is None:
         out = torch.empty(cols, rows, device=x.device, dtype=torch.bfloat16)
-    check(lib().sc_transpose_bf16(_p(x), x.stride(0), _p(out), out.stride(0), rows, cols, _stream()), "sc_transpose_bf16")
+    check(lib().sc_transpose_bf16(_p(x), x.stride(0), _p(out), out.stride(0), rows, cols, _p(colsum_partial), _stream()),
+          "sc_transpose_bf16")
     return out
 
 
@@ -205,7 +207,8 @@ def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional
     rows, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == rows and rows % 64 == 0 and gW.dtype == torch.float32 and gW.is_contiguous() and tuple(gW.shape) == (N, K)
-    dyT, xT = transpose_bf16(dy), transpose_bf16(x)
+    pb = torch.empty((rows + 63) // 64, N, device=dy.device, dtype=torch.float32) if gb is not None else None
+    dyT, xT = transpose_bf16(dy, colsum_partial=pb), transpose_bf16(x)
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     S = max(1, min(256 // max(tiles, 1), rows // 512))
     while rows % (64 * S):
@@ -214,11 +217,8 @@ def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional
     part = torch.empty(S, N, K, device=dy.device, dtype=torch.float32)
     gemm_raw(dyT, rows, xT, rows, part, K, N, K, Kc, out_f32=True, nb1=S, sA=(Kc, 0), sW=(Kc, 0), sC=(N * K, 0))
     colsum(part, N * K, S, N * K, gW, beta=beta)
-    if gb is not None:
-        nblk = 256
-        pb = torch.empty(nblk, N, device=dy.device, dtype=torch.float32)
-        check(lib().sc_colsum_bf16(_p(dy), dy.stride(0), rows, N, _p(pb), nblk, _stream()), "sc_colsum_bf16")
-        colsum(pb, N, nblk, N, gb, beta=beta)
+    if gb is not None:                      # second stage of the bias gradient (first stage: the transpose of dy above)
+        colsum(pb, N, pb.shape[0], N, gb, beta=beta)
 
 
 def act_bf16(u: torch.Tensor, act: int, df: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
