@@ -180,8 +180,8 @@ int sc_sgemm_f32(const float* A, int64_t sai, int64_t sak, const float* Bm, int6
 /* ------------------------------------------------------------------------------------------------
  * Row kernels of the backward pass over bf16 activations (CLIP text tower input gradient, HuBERT layer backward):
  *   sc_layernorm_bwd_bf16 : dx = LayerNorm'(x; gamma)(dy) (+ dres), statistics recomputed from the saved LN input x;
- *                           optional per-wave partial sums [n_partial, D] of dgamma = sum dy xhat and dbeta = sum dy
- *                           (n_partial = 4 * workgroups; reduce with sc_colsum_f32)
+ *                           optional per-workgroup partial sums [n_partial, D] of dgamma = sum dy xhat and dbeta = sum dy
+ *                           (n_partial = workgroups launched; reduce with sc_colsum_f32)
  *   sc_act_bf16           : df == NULL: out = act(u) ; else out = df * act'(u) ; act 1 = erf-GELU, 2 = QuickGELU
  * ---------------------------------------------------------------------------------------------- */
 int sc_layernorm_bwd_bf16(const sc_bf16* x, int64_t ldx, const sc_bf16* dy, int64_t lddy, const float* gamma, const sc_bf16* dres,

@@ -7,7 +7,8 @@ namespace {
 
 // dx = rstd (g - mean(g) - xhat mean(g xhat)) (+ dres),  g = dy gamma,  statistics recomputed from the saved LN input x.
 // Persistent over rows (row = wave_global + k * n_waves) so that each lane can also accumulate its columns' dgamma / dbeta
-// partials in registers; partial[wave_global][D] is reduced by the caller (sc_colsum_f32): fixed order, no atomics.
+// partials in registers; partial[workgroup][D] (the four waves added through LDS) is reduced by the caller (sc_colsum_f32):
+// fixed order, no atomics.
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                             const uint16_t* __restrict__ dy, int64_t lddy,
@@ -94,14 +95,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
             }
         }
     }
-    if (dg_part) {
+    if (dg_part) {                                   // the four waves' column partials are added through LDS: one row per workgroup
+        __shared__ float red[2][4][NCH * 256];
+        const int w = threadIdx.x >> 6;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int ch = lane + i * 64;
-            if (ch < nchunks) {
-                *(f32x4*)(dg_part + wg * D + ch * 4) = f32x4{ag[i][0], ag[i][1], ag[i][2], ag[i][3]};
-                *(f32x4*)(db_part + wg * D + ch * 4) = f32x4{ab[i][0], ab[i][1], ab[i][2], ab[i][3]};
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[0][w][(i * 64 + lane) * 4 + j] = ag[i][j];
+                red[1][w][(i * 64 + lane) * 4 + j] = ab[i][j];
             }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) {
+            dg_part[(int64_t)blockIdx.x * D + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+            db_part[(int64_t)blockIdx.x * D + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
         }
     }
 }
@@ -149,11 +156,11 @@ extern "C" int sc_layernorm_bwd_bf16(const sc_bf16* x, int64_t ldx, const sc_bf1
     SC_CHECK(rows > 0 && D > 0 && D % 4 == 0 && D <= 1024, "sc_layernorm_bwd_bf16: D=%d must be a multiple of 4, <= 1024", D);
     SC_CHECK(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (dres == nullptr || lddres % 4 == 0), "sc_layernorm_bwd_bf16: leading dims");
     SC_CHECK((dgamma_partial == nullptr) == (dbeta_partial == nullptr), "sc_layernorm_bwd_bf16: both partial buffers or none");
-    // waves = 4 * grid; with partial sums the caller's buffers fix the wave count (n_partial rows of D floats each)
+    // with partial sums the caller's buffers fix the workgroup count (n_partial rows of D floats each)
     int grid;
     if (dgamma_partial) {
-        SC_CHECK(n_partial >= 4 && n_partial % 4 == 0, "sc_layernorm_bwd_bf16: n_partial must be a positive multiple of 4");
-        grid = n_partial / 4;
+        SC_CHECK(n_partial >= 1, "sc_layernorm_bwd_bf16: n_partial must be positive");
+        grid = n_partial;
     } else {
         grid = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
     }

@@ -173,7 +173,7 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
     dg = db = None
     n_part = 0
     if want_param_grads:
-        n_part = 4 * min(1024, (rows + 3) // 4)         # up to 1024 workgroups x 4 waves of partial sums, reduced by colsum
+        n_part = min(1024, (rows + 3) // 4)             # one partial row per workgroup (its four waves are added in LDS)
         dg = torch.empty(n_part, D, device=x.device, dtype=torch.float32)
         db = torch.empty(n_part, D, device=x.device, dtype=torch.float32)
     check(lib().sc_layernorm_bwd_bf16(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(dres), 0 if dres is None else dres.stride(0),
