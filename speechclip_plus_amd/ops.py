@@ -319,11 +319,12 @@ def cls_pool_bwd(X: torch.Tensor, p: torch.Tensor, dp: torch.Tensor, dm: torch.T
 
 def sgemm(A: torch.Tensor, sai: int, sak: int, Bm: torch.Tensor, sbj: int, sbk: int, M: int, N: int, K: int,
           alpha: float = 1.0, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C[i, j] = alpha sum_k A[i sai + k sak] Bm[j sbj + k sbk] (+ bias[j]): the loss's logits / gradient products.  Routed through
+    sc_sgemm_f32_ex so that the few-tile case (Bg = 64 per GPU: one 64 x 64 tile) is split along K over the chip."""
     assert A.dtype == torch.float32 and Bm.dtype == torch.float32
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    check(lib().sc_sgemm_f32(_p(A), sai, sak, _p(Bm), sbj, sbk, _p(out), out.stride(0), M, N, K, float(alpha), _p(bias),
-                             _stream()), "sc_sgemm_f32")
+    sgemm_ex(A, (sai, sak, 0), Bm, (sbj, sbk, 0), out, out.stride(0), M, N, K, alpha=alpha, bias=bias)
     return out
 
 
