@@ -549,3 +549,41 @@ def test_transpose_and_weight_gradient(dev):
     gW2 = torch.full_like(gW0, 3.0)
     ops.wgrad_bf16(dy, x, gW2, beta=0.0)
     assert rel_l2(gW2, dy.float().t() @ x.float()) < 1e-3
+
+
+def test_gemm_random_shape_fuzz(dev):
+    """Seeded fuzz of sc_gemm_bf16 over every tile variant: M from 1 row to a few thousand (tails in every tile size, fewer tiles
+    than CUs and more), N any multiple of 8, K any multiple of 64, random epilogue (bias / GELU / residual / fp32 output), strided
+    A and C.  The persistent 256-row kernel walks several tiles per workgroup only when tiles > CUs: forced with small grids is not
+    possible, so large-M cases are included."""
+    import random
+    ops = _ops()
+    rng = random.Random(1234)
+    g = torch.Generator(device="cpu").manual_seed(99)
+    cases = []
+    for _ in range(28):
+        M = rng.choice([1, 7, 63, 64, 129, 255, 256, 257, 511, 700, 1000, 2048, 3001, 8192, 70000])
+        N = 8 * rng.randint(1, 130)
+        K = 64 * rng.randint(1, 20)
+        cases.append((M, N, K, rng.random() < 0.5, rng.random() < 0.4, rng.random() < 0.4, rng.random() < 0.25, rng.choice([0, 1, 2, 3, 7, 8])))
+    for M, N, K, use_bias, act, use_res, out_f32, tile in cases:
+        if tile == 3 and N > 64:
+            tile = 0
+        pad_a, pad_c = 8 * rng.randint(0, 2), 8 * rng.randint(0, 2)
+        A = bf(torch.randn(M, K + pad_a, generator=g)).to(dev)
+        W = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+        bias = torch.randn(N, generator=g).to(dev) if use_bias else None
+        res = bf(torch.randn(M, N, generator=g)).to(dev) if use_res else None
+        C = torch.full((M, N + pad_c), 3.0, device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        ops.gemm_raw(A, K + pad_a, W, K, C, N + pad_c, M, N, K, bias=bias, residual=res, ldr=N, act=int(act), out_f32=out_f32, tile=tile)
+        ref = A[:, :K].float() @ W.float().T
+        if use_bias:
+            ref = ref + bias
+        if act:
+            ref = F.gelu(ref)
+        if use_res:
+            ref = ref + res.float()
+        tag = (M, N, K, use_bias, act, use_res, out_f32, tile)
+        assert rel_l2(C[:, :N], ref) < (2e-4 if out_f32 else 6e-3), tag
+        if pad_c:
+            assert float((C[:, N:].float() - 3.0).abs().max()) == 0.0, tag          # nothing written past column N
