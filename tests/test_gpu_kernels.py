@@ -587,3 +587,46 @@ def test_gemm_random_shape_fuzz(dev):
         assert rel_l2(C[:, :N], ref) < (2e-4 if out_f32 else 6e-3), tag
         if pad_c:
             assert float((C[:, N:].float() - 3.0).abs().max()) == 0.0, tag          # nothing written past column N
+
+
+def test_attention_fwd_bwd_fuzz(dev):
+    """Seeded fuzz of the attention forward / backward kernels over batch, heads, padded length, key lengths (incl. 1 and R) and
+    the causal flag, against fp32 torch."""
+    import random
+    ops = _ops()
+    rng = random.Random(77)
+    g = torch.Generator(device="cpu").manual_seed(78)
+    for _ in range(10):
+        B, H, R = rng.choice([1, 2, 3]), rng.choice([1, 2, 4, 12]), rng.choice([128, 256, 384, 512])
+        D = 64 * H
+        causal = rng.random() < 0.4
+        valid = [rng.choice([1, 2, 63, 64, 65, R // 2, R - 1, R]) for _ in range(B)]
+        qkv = bf(torch.randn(B * R, 3 * D, generator=g)).to(dev)
+        q, k, v = qkv[:, :D], qkv[:, D: 2 * D], qkv[:, 2 * D:]
+        vl = torch.tensor(valid, dtype=torch.int32, device=dev)
+        vt = ops.head_transpose(v, B, R, H)
+        out = torch.zeros(B * R, D, device=dev, dtype=torch.bfloat16)
+        lse2 = torch.empty(B, H, R, device=dev, dtype=torch.float32)
+        scale = 64 ** -0.5
+        ops.attn_fwd(qkv[:, : 2 * D], vt, vl, out, B, R, H, D, scale, lse2=lse2, causal=causal)
+        qf, kf, vf = (t.float().view(B, R, H, 64).transpose(1, 2).detach().requires_grad_() for t in (q, k, v))
+        s = (qf @ kf.transpose(-1, -2)) * scale
+        key_ok = torch.arange(R, device=dev)[None, :] < vl[:, None]
+        mask = key_ok[:, None, None, :].expand(B, H, R, R).clone()
+        if causal:
+            mask &= torch.tril(torch.ones(R, R, dtype=torch.bool, device=dev))[None, None]
+        o_ref = (torch.softmax(s.masked_fill(~mask, float("-inf")), dim=-1) @ vf).transpose(1, 2).reshape(B * R, D)
+        rows_ok = key_ok.reshape(B * R)                                  # queries inside the utterance
+        tag = (B, H, R, valid, causal)
+        assert rel_l2(out[rows_ok], o_ref[rows_ok]) < 1e-2, tag
+        dout = bf(torch.randn(B * R, D, generator=g)).to(dev)
+        dout[~rows_ok] = 0
+        o_ref.backward(dout.float())
+        dqkv = torch.full((B * R, 3 * D), 5.0, device=dev, dtype=torch.bfloat16)
+        ops.attn_bwd(q, k, v, out, dout, lse2, vl, dqkv[:, :D], dqkv[:, D: 2 * D], dqkv[:, 2 * D:], B, R, H, scale, causal=causal)
+        ref = [t.grad.transpose(1, 2).reshape(B * R, D) for t in (qf, kf, vf)]
+        for i in range(3):
+            gi = dqkv[rows_ok, i * D: (i + 1) * D]
+            if float(ref[i][rows_ok].norm()) > 1e-6:
+                assert rel_l2(gi, ref[i][rows_ok]) < 2.5e-2, (tag, i)
+        assert float(dqkv[~rows_ok][:, D:].abs().max() if (~rows_ok).any() else 0.0) == 0.0, tag
