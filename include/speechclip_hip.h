@@ -39,7 +39,10 @@ int sc_abi_version(void);
  *       Conv1d becomes a GEMM: lda = stride*C_in, K = k*C_in)
  *   W   [N, K] bf16, row stride ldw   (torch Linear layout [out, in])
  *   C   [M, N] bf16 (or fp32 if out_f32), row stride ldc
- *   epilogue order:  acc -> +bias[n] -> act (0 none, 1 GELU-erf) -> +residual[m, n] -> store
+ *   epilogue order:  acc -> +bias[n] -> act (0 none, 1 GELU-erf) -> dropout (train mode) -> +residual[m, n] -> store
+ *   dropout (fairseq dropout_input / the layers' residual dropouts, F.dropout semantics: keep with probability 1 - p, scale the
+ *       kept values by 1 / (1 - p)): stateless counter-based mask - element (m, n) is kept iff the 16-bit lane of
+ *       sc_hash32((m*N + n) / 2 ^ drop_seed) selected by (m*N + n) & 1 is >= round(p * 65536); not applied to Ct columns
  *   columns n >= n_split (if n_split >= 0) are stored TRANSPOSED per head into Ct:
  *       Ct[(((m / R) * H + (n-n_split)/dh) * dh + (n-n_split)%dh) * R + m % R]     (V^T for attention)
  *   batch: grid.z = nb1*nb2 ; operand pointers advance by  (z / nb2) * s?1 + (z % nb2) * s?2  elements.
@@ -62,8 +65,11 @@ typedef struct {
     int32_t reserved;             /* store policy of the bf16 C tile (256-row kernels): 0 auto = non-temporal stores when a residual
                                      is given (the output is the next residual stream, not re-read by this kernel; measured
                                      -3.5 % GEMM time per step), 1 always non-temporal, 2 never */
+    float drop_p;                 /* 0 = no dropout */
+    uint32_t drop_seed;
 } sc_gemm_args;
 int sc_gemm_bf16(const sc_gemm_args* args, void* stream);
+uint32_t sc_hash32(uint32_t x);   /* host twin of the kernels' dropout hash (lowbias32): reconstructs a mask exactly */
 
 /* ------------------------------------------------------------------------------------------------
  * Self-attention forward (flash style, key-padding by length), head_dim 64.
@@ -77,7 +83,9 @@ int sc_gemm_bf16(const sc_gemm_args* args, void* stream);
 int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len,
                      sc_bf16* out, int64_t ldo, int32_t B, int32_t R, int32_t H, int32_t D, float scale,
                      float* lse2 /* [B,H,R] log2-domain log-sum-exp for the backward, or NULL */,
-                     int32_t causal /* 1: key t' > query t masked too (CLIP text tower) */, void* stream);
+                     int32_t causal /* 1: key t' > query t masked too (CLIP text tower) */,
+                     float drop_p, uint32_t drop_seed /* attention-probability dropout (train mode): P' = mask . P / (1 - p), element
+                     ((b*H + h)*R + q)*R + k hashed as in sc_gemm_args; 0 = off */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Self-attention backward, head_dim 64 (fairseq MultiheadAttention / nn.MultiheadAttention / CLIP ResidualAttentionBlock
@@ -191,6 +199,10 @@ int sc_act_bf16(const sc_bf16* u, const sc_bf16* df, sc_bf16* out, int64_t n, in
 /*   sc_transpose_bf16 : y[c, r] = x[r, c]  - operands of the weight-gradient GEMMs (dW = dY^T X: the row index becomes the
  *                       contraction dimension of sc_gemm_bf16, split along K over the batch dimension, partials in fp32)
  *   sc_colsum_bf16    : partial[blk, c] = sum of the block's rows of x[:, c] in fp32 (bias gradients; reduce with sc_colsum_f32) */
+/*   sc_dropout_bf16   : out = dropout(x) (F.dropout semantics, the stateless mask of sc_gemm_args over element row*D + col):
+ *                       fairseq's encoder dropout after pos_conv + LayerNorm (speech_encoder_plus.py:41), train mode only */
+int sc_dropout_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* out, int64_t ldo, int64_t rows, int32_t D, float p, uint32_t seed,
+                    void* stream);
 int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int64_t ldy, int32_t rows, int32_t cols,
                       float* colsum_partial /* NULL, or [ceil(rows / 64), cols] fp32: per-64-row-block column sums of x */, void* stream);
 int sc_colsum_bf16(const sc_bf16* x, int64_t ldx, int64_t rows, int32_t cols, float* partial, int32_t nblk, void* stream);

@@ -28,6 +28,7 @@ class GemmArgs(ctypes.Structure):
         ("sA1", c_i64), ("sA2", c_i64), ("sW1", c_i64), ("sW2", c_i64), ("sC1", c_i64), ("sC2", c_i64),
         ("sBias1", c_i64), ("sBias2", c_i64), ("sR1", c_i64), ("sR2", c_i64),
         ("tile", c_int), ("reserved", c_int),
+        ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32),
     ]
 
 
@@ -37,7 +38,7 @@ SIGNATURES = {
     "sc_abi_version": [],
     "sc_gemm_bf16": [ctypes.POINTER(GemmArgs), c_void_p],
     "sc_attn_fwd_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
-                         c_void_p],
+                         c_float, ctypes.c_uint32, c_void_p],
     "sc_attn_bwd_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int,
                          c_int, c_int, c_float, c_int, c_void_p],
@@ -61,6 +62,7 @@ SIGNATURES = {
                               c_void_p, c_void_p, c_int, c_void_p],
     "sc_transpose_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p],
     "sc_colsum_bf16": [c_void_p, c_i64, c_i64, c_int, c_void_p, c_int, c_void_p],
+    "sc_dropout_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_float, ctypes.c_uint32, c_void_p],
     "sc_act_bf16": [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p],
     "sc_sgemm_f32_ex": [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int,
                         c_float, c_float, c_void_p, c_i64, c_void_p, c_i64, c_void_p],
@@ -90,6 +92,8 @@ def lib() -> ctypes.CDLL:
             fn.restype = ctypes.c_int
         cdll.sc_last_error.argtypes = []
         cdll.sc_last_error.restype = ctypes.c_char_p
+        cdll.sc_hash32.argtypes = [ctypes.c_uint32]
+        cdll.sc_hash32.restype = ctypes.c_uint32
         _LIB = cdll
     return _LIB
 

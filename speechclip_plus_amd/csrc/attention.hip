@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                                                         const uint16_t* __restrict__ vt,
                                                         const int32_t* __restrict__ valid_len,
                                                         uint16_t* __restrict__ out, int64_t ldo, int R, int H, int D,
-                                                        float c /* scale * log2(e) */, float* __restrict__ lse2, int causal) {
+                                                        float c /* scale * log2(e) */, float* __restrict__ lse2, int causal,
+                                                        float drop_p, uint32_t drop_seed) {
     __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
     __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
 
@@ -68,6 +69,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     float m_run = -INFINITY, l_run = 0.f;
 
     const int qrow = q0 + l31;                                       // this lane's query
+    // attention-probability dropout (fairseq attention_dropout, train mode): P' = mask . P / (1 - p) with the row sum taken
+    // over the un-masked P; element (b, h, q, k) -> sc_hash32 lane as in sc_common.h
+    const uint32_t drop_thr = drop_p > 0.f ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
+    const uint32_t drop_row = (uint32_t)(((b * H + h) * R + qrow)) * (uint32_t)R;
     if (causal) n_valid = min(n_valid, qblk * 128 + 128);           // keys beyond the block's last query are all masked
     const int ntiles = (n_valid + KT - 1) / KT;
     // prefetch registers as named scalars: arrays indexed across the tile loop were being placed in scratch
@@ -143,6 +148,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                 psum += pv[r];
             }
             l_run += psum;
+            if (drop_thr) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const uint32_t kidx = (uint32_t)(kbase + (r & 3) + 8 * (r >> 2) + 4 * half);
+                    const uint32_t hsh = sc_hash32(((drop_row + kidx) >> 1) ^ drop_seed);
+                    if ((hsh & 0xffffu) < drop_thr) pv[r] = 0.f;
+                    if ((hsh >> 16) < drop_thr) pv[r + 1] = 0.f;
+                }
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 
     const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
-    const float inv = 1.0f / l_tot;
+    const float inv = 1.0f / (l_tot * (1.0f - drop_p));
     if (lse2 && half == 0) lse2[((int64_t)b * H + h) * R + qrow] = m_run * c + __builtin_amdgcn_logf(l_tot);   // log2 domain
     uint16_t* op = out + ((int64_t)b * R + q0 + l31) * ldo + h * 64 + 4 * half;
 #pragma unroll
@@ -196,16 +210,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 
 extern "C" int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len,
                                 sc_bf16* out, int64_t ldo, int32_t B, int32_t R, int32_t H, int32_t D, float scale,
-                                float* lse2, int32_t causal, void* stream) {
+                                float* lse2, int32_t causal, float drop_p, uint32_t drop_seed, void* stream) {
     SC_CHECK(qk && vt && valid_len && out, "sc_attn_fwd_bf16: null pointer");
     SC_CHECK(B > 0 && H > 0 && R > 0 && R % 128 == 0, "sc_attn_fwd_bf16: R=%d must be a positive multiple of 128", R);
     SC_CHECK(D == H * 64, "sc_attn_fwd_bf16: head_dim must be 64 (D=%d, H=%d)", D, H);
+    SC_CHECK(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || (int64_t)B * H * R * R < ((int64_t)1 << 32)),
+             "sc_attn_fwd_bf16: drop_p=%f (needs B*H*R*R < 2^32)", (double)drop_p);
     SC_CHECK(ldqk % 8 == 0 && ldo % 4 == 0 && ldqk >= 2 * D && ldo >= D, "sc_attn_fwd_bf16: bad leading dims");
     SC_CHECK(((uintptr_t)qk % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0,
              "sc_attn_fwd_bf16: alignment");
     dim3 grid((R / 128) * H * B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R,
-                       H, D, scale * 1.4426950408889634f, lse2, causal);
+                       H, D, scale * 1.4426950408889634f, lse2, causal, drop_p, drop_seed);
     SC_LAUNCH_CHECK();
     return 0;
 }

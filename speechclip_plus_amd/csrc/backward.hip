@@ -147,7 +147,36 @@ __global__ void act_kernel(const uint16_t* __restrict__ u, const uint16_t* __res
     ((uint4*)out)[i] = o;
 }
 
+// out = dropout(x): keep with probability 1 - p, scale by 1 / (1 - p); the mask of element i is that of sc_gemm_args (sc_keep8);
+// rows of ld elements, D of them used.  8 bf16 per thread.
+__global__ void dropout_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out, int64_t ldo, int64_t rows,
+                               int D, uint32_t thr, float scale, uint32_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, per_row = D >> 3;
+    if (i >= rows * per_row) return;
+    const int64_t row = i / per_row;
+    const int c = (int)(i - row * per_row) * 8;
+    const uint4 a = *(const uint4*)(x + row * ldx + c);
+    float v[8] = {bflo(a.x), bfhi(a.x), bflo(a.y), bfhi(a.y), bflo(a.z), bfhi(a.z), bflo(a.w), bfhi(a.w)};
+    const uint32_t keep = sc_keep8((uint32_t)(row * D + c), seed, thr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * scale : 0.f;
+    uint4 o;
+    o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+    *(uint4*)(out + row * ldo + c) = o;
+}
+
 }  // namespace
+
+extern "C" int sc_dropout_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* out, int64_t ldo, int64_t rows, int32_t D, float p, uint32_t seed,
+                               void* stream) {
+    SC_CHECK(x && out && rows > 0 && D > 0 && D % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "sc_dropout_bf16: bad args");
+    SC_CHECK(p >= 0.f && p < 1.f && rows * D < ((int64_t)1 << 32), "sc_dropout_bf16: p=%f, rows*D must be < 2^32", (double)p);
+    const int64_t n8 = rows * (D / 8);
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, rows, D,
+                       (uint32_t)(p * 65536.f + 0.5f), 1.f / (1.f - p), seed);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int sc_layernorm_bwd_bf16(const sc_bf16* x, int64_t ldx, const sc_bf16* dy, int64_t lddy, const float* gamma,
                                      const sc_bf16* dres, int64_t lddres, sc_bf16* dx, int64_t lddx, int64_t rows, int32_t D,

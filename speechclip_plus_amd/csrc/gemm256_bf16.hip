@@ -134,6 +134,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     const int a_base = wm * HALF_BYTES;                                             // wave's A half
     const int b_base = 2 * HALF_BYTES + wn * TN * ROWB;                             // wave's TN rows of the B region
     const int nk = p.K / BK;
+    const uint32_t drop_thr = p.drop_p > 0.f ? (uint32_t)(p.drop_p * 65536.f + 0.5f) : 0u;
+    const float drop_scale = 1.f / (1.f - p.drop_p);
 
     int iter_ = 0;
 #define SC_STAMP(K)                                                                                          \
@@ -351,6 +353,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                             const f32x4 lo = *(const f32x4*)(Cw + row * TNP + cs);
                             const f32x4 hi = *(const f32x4*)(Cw + row * TNP + cs + 4);
                             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            if (drop_thr) {                  // train-mode dropout before the residual add (F.dropout semantics)
+                                const uint32_t keep = sc_keep8((uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_seed, drop_thr);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * drop_scale : 0.f;
+                            }
                             if (Rs) {
                                 const uint4 rv = *(const uint4*)(Rs + (int64_t)m * p.ldr + n);
                                 v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);

@@ -183,6 +183,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
                 const f32x4 lo = *(const f32x4*)(Cs + row * BN + cc * 8);
                 const f32x4 hi = *(const f32x4*)(Cs + row * BN + cc * 8 + 4);
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (p.drop_p > 0.f) {                    // train-mode dropout before the residual add (same mask as gemm256_bf16.hip)
+                    const uint32_t thr = (uint32_t)(p.drop_p * 65536.f + 0.5f);
+                    const float sc = 1.f / (1.f - p.drop_p);
+                    const uint32_t keep = sc_keep8((uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_seed, thr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * sc : 0.f;
+                }
                 if (Rs) {
                     const uint4 rv = *(const uint4*)(Rs + (int64_t)m * p.ldr + n);
                     v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
@@ -259,6 +266,9 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     SC_CHECK(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0 && ((uintptr_t)a.C % 16) == 0,
              "sc_gemm_bf16: operands must be 16-byte aligned");
     SC_CHECK(a.act == 0 || a.act == 1, "sc_gemm_bf16: act=%d", a.act);
+    SC_CHECK(a.drop_p >= 0.f && a.drop_p < 1.f, "sc_gemm_bf16: drop_p=%f", (double)a.drop_p);
+    SC_CHECK(a.drop_p == 0.f || ((int64_t)a.M * a.N < (int64_t)1 << 32 && a.nb1 * a.nb2 == 1),
+             "sc_gemm_bf16: dropout needs M*N < 2^32 and no batch");
     if (a.nb1 < 1) a.nb1 = 1;
     if (a.nb2 < 1) a.nb2 = 1;
     if (a.residual) SC_CHECK(a.ldr % 8 == 0 && ((uintptr_t)a.residual % 16) == 0, "sc_gemm_bf16: residual alignment");

@@ -72,6 +72,29 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     return __builtin_elementwise_fma(-ah, r, h + ah);
 }
 
+// Stateless dropout masks (train mode): lowbias32 integer hash of (element-pair index ^ seed); the low / high 16 bits decide
+// the even / odd element of the pair: keep iff bits >= thr16 = round(p * 65536).  The same function is evaluated on the host
+// (tests/, numpy uint32) to reconstruct a mask exactly.
+__device__ __forceinline__ uint32_t sc_hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+// keep flags of the 8 consecutive elements idx .. idx + 7 (idx even) as a bit mask
+__device__ __forceinline__ uint32_t sc_keep8(uint32_t idx, uint32_t seed, uint32_t thr16) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t h = sc_hash32(((idx >> 1) + i) ^ seed);
+        m |= ((h & 0xffffu) >= thr16 ? 1u : 0u) << (2 * i);
+        m |= ((h >> 16) >= thr16 ? 1u : 0u) << (2 * i + 1);
+    }
+    return m;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

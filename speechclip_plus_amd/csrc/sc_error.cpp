@@ -1,6 +1,7 @@
 // Thread-local last-error string of the C ABI and the immutable device-property cache.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 
 #include "speechclip_hip.h"
@@ -25,6 +26,16 @@ int sc_num_cus() {
             cus = 256;
     }
     return cus;
+}
+
+// host twin of the device-side dropout hash (csrc/sc_common.h): lets a caller or a test reconstruct a mask exactly
+extern "C" uint32_t sc_hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
 }
 
 extern "C" const char* sc_last_error(void) { return g_err; }

@@ -72,7 +72,7 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
              bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ldr: int = 0, act: int = 0,
              out_f32: bool = False, Ct: Optional[torch.Tensor] = None, n_split: int = -1, R: int = 0, dh: int = 0,
              nb1: int = 1, nb2: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sBias=(0, 0), sR=(0, 0),
-             alg_rows: Optional[int] = None, tile: int = 0) -> None:
+             alg_rows: Optional[int] = None, tile: int = 0, drop_p: float = 0.0, drop_seed: int = 0) -> None:
     """C = epi(A . W^T); see sc_gemm_args in include/speechclip_hip.h.  Pointers are the tensors' data_ptr()
     (pass a sliced view to offset).  ``alg_rows``: rows that are algorithmic work (excludes layout padding),
     used only by the optional KernelTimer."""
@@ -95,6 +95,7 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     a.sBias1, a.sBias2 = sBias
     a.sR1, a.sR2 = sR
     a.tile = tile
+    a.drop_p, a.drop_seed = float(drop_p), int(drop_seed) & 0xffffffff
     if _timer is None:
         check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
         return
@@ -109,7 +110,7 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
 
 def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, act: int = 0, out_f32: bool = False,
-                alg_rows: Optional[int] = None, tile: int = 0) -> torch.Tensor:
+                alg_rows: Optional[int] = None, tile: int = 0, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
     """y[M, N] = epi(x[M, K] . w[N, K]^T) for contiguous 2-D operands."""
     M, K = x.shape
     N = w.shape[0]
@@ -117,19 +118,22 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     gemm_raw(x, x.stride(0), w, w.stride(0), out, out.stride(0), M, N, K, bias=bias, residual=residual,
-             ldr=residual.stride(0) if residual is not None else 0, act=act, out_f32=out_f32, alg_rows=alg_rows, tile=tile)
+             ldr=residual.stride(0) if residual is not None else 0, act=act, out_f32=out_f32, alg_rows=alg_rows, tile=tile,
+             drop_p=drop_p, drop_seed=drop_seed)
     return out
 
 
 def attn_fwd(qk: torch.Tensor, vt: torch.Tensor, valid_len: torch.Tensor, out: torch.Tensor, B: int, R: int, H: int,
-             D: int, scale: float, alg_flops: float = 0.0, lse2: Optional[torch.Tensor] = None, causal: bool = False) -> None:
+             D: int, scale: float, alg_flops: float = 0.0, lse2: Optional[torch.Tensor] = None, causal: bool = False,
+             drop_p: float = 0.0, drop_seed: int = 0) -> None:
     assert qk.dtype == torch.bfloat16 and vt.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
     assert valid_len.dtype == torch.int32
     if _timer is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     check(lib().sc_attn_fwd_bf16(_p(qk), qk.stride(0), _p(vt), _p(valid_len), _p(out), out.stride(0), B, R, H, D,
-                                 float(scale), _p(lse2), int(causal), _stream()), "sc_attn_fwd_bf16")
+                                 float(scale), _p(lse2), int(causal), float(drop_p), int(drop_seed) & 0xffffffff, _stream()),
+          "sc_attn_fwd_bf16")
     if _timer is not None:
         ev1.record()
         _timer.add("attn_fwd", ev0, ev1, float(alg_flops))
@@ -219,6 +223,17 @@ def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional
     colsum(part, N * K, S, N * K, gW, beta=beta)
     if gb is not None:                      # second stage of the bias gradient (first stage: the transpose of dy above)
         colsum(pb, N, pb.shape[0], N, gb, beta=beta)
+
+
+def dropout_bf16(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.dropout(x, p) on bf16 rows with the stateless hash mask (element row * D + col); in place when out is x."""
+    rows, D = x.shape
+    assert x.dtype == torch.bfloat16 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().sc_dropout_bf16(_p(x), x.stride(0), _p(out), out.stride(0), rows, D, float(p), int(seed) & 0xffffffff, _stream()),
+          "sc_dropout_bf16")
+    return out
 
 
 def act_bf16(u: torch.Tensor, act: int, df: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -630,3 +630,66 @@ def test_attention_fwd_bwd_fuzz(dev):
             if float(ref[i][rows_ok].norm()) > 1e-6:
                 assert rel_l2(gi, ref[i][rows_ok]) < 2.5e-2, (tag, i)
         assert float(dqkv[~rows_ok][:, D:].abs().max() if (~rows_ok).any() else 0.0) == 0.0, tag
+
+
+# ---- train-mode dropout: the stateless hash mask, reconstructed on the host ------------------------------------------------
+def _hash32_np(x):
+    import numpy as np
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7feb352d)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846ca68b)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
+def _keep_mask(idx, seed, p):
+    """idx: int64 numpy array of linear element indices -> bool keep mask (csrc/sc_common.h: sc_keep8)."""
+    import numpy as np
+    h = _hash32_np((idx >> 1).astype(np.uint32) ^ np.uint32(seed))
+    bits = np.where(idx & 1, h >> np.uint32(16), h & np.uint32(0xffff))
+    return bits >= np.uint32(int(p * 65536 + 0.5))
+
+
+def test_dropout_masks_gemm_rows_attention(dev):
+    import numpy as np
+    from speechclip_plus_amd import _lib
+    ops = _ops()
+    assert int(_hash32_np(np.array([12345], dtype=np.uint32))[0]) == _lib.lib().sc_hash32(12345)
+    g = torch.Generator(device="cpu").manual_seed(55)
+    p, seed = 0.25, 0x1234abcd
+    # rows
+    x = bf(torch.randn(200, 768, generator=g)).to(dev)
+    y = ops.dropout_bf16(x, p, seed)
+    keep = torch.from_numpy(_keep_mask(np.arange(200 * 768, dtype=np.int64), seed, p)).view(200, 768).to(dev)
+    assert torch.equal(y, bf(torch.where(keep, x.float() / (1 - p), torch.zeros((), device=dev))))
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+    # GEMM epilogue: dropout after bias / GELU, before the residual; both tile families
+    for M, N, K, tile in ((300, 136, 128, 1), (1000, 512, 192, 2), (700, 776, 64, 7)):
+        A = bf(torch.randn(M, K, generator=g)).to(dev)
+        W = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        res = bf(torch.randn(M, N, generator=g)).to(dev)
+        out = ops.linear_bf16(A, W, bias, residual=res, act=1, tile=tile, drop_p=p, drop_seed=seed)
+        keep = torch.from_numpy(_keep_mask(np.arange(M * N, dtype=np.int64), seed, p)).view(M, N).to(dev)
+        ref = torch.where(keep, F.gelu(A.float() @ W.float().T + bias) / (1 - p), torch.zeros((), device=dev)) + res.float()
+        assert rel_l2(out, ref) < 6e-3, (M, N, K, tile)
+        plain = ops.linear_bf16(A, W, bias, residual=res, act=1, tile=tile)
+        assert torch.equal(ops.linear_bf16(A, W, bias, residual=res, act=1, tile=tile, drop_p=0.0, drop_seed=seed), plain)
+    # attention probabilities: P' = mask . P / (1 - p), row sums over the un-masked P
+    B, H, R = 2, 3, 256
+    D = H * 64
+    qkv = bf(torch.randn(B * R, 3 * D, generator=g)).to(dev)
+    vl = torch.tensor([200, 256], dtype=torch.int32, device=dev)
+    vt = ops.head_transpose(qkv[:, 2 * D:], B, R, H)
+    out = torch.zeros(B * R, D, device=dev, dtype=torch.bfloat16)
+    ops.attn_fwd(qkv[:, : 2 * D], vt, vl, out, B, R, H, D, 64 ** -0.5, drop_p=p, drop_seed=seed)
+    qf, kf, vf = (t.float().view(B, R, H, 64).transpose(1, 2) for t in (qkv[:, :D], qkv[:, D: 2 * D], qkv[:, 2 * D:]))
+    s = (qf @ kf.transpose(-1, -2)) * 64 ** -0.5
+    key_ok = torch.arange(R, device=dev)[None, :] < vl[:, None]
+    P = torch.softmax(s.masked_fill(~key_ok[:, None, None, :], float("-inf")), dim=-1)
+    keep = torch.from_numpy(_keep_mask(np.arange(B * H * R * R, dtype=np.int64), seed, p)).view(B, H, R, R).to(dev)
+    ref = ((P * keep / (1 - p)) @ vf).transpose(1, 2).reshape(B * R, D)
+    rows_ok = key_ok.reshape(B * R)
+    assert rel_l2(out[rows_ok], ref[rows_ok]) < 1.2e-2
