@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=2, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="deterministic train step: every dropout site off (A/B only; the "
+                    "reference's train step runs HuBERT's and the head's dropout, which is the default here)")
     ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape GEMM timing table to stderr")
     ap.add_argument("--unfreeze", type=int, default=0, help="train the top K HuBERT transformer layers too (audio_encoder.trainable "
                     "+ unfreeze_layers; NOT the headline configuration, which freezes HuBERT like every shipped recipe)")
@@ -85,6 +87,9 @@ def main():
         cfg.audio_encoder.unfreeze_layers = list(range(nl - args.unfreeze, nl))
     model = KWClip_GeneralTransformer(cfg, device=str(dev), hubert_state_dict=sd)
     model.train()
+    if args.no_dropout:
+        from speechclip_plus_amd import set_dropout
+        set_dropout(model, False)
     trainer = ContrastiveTrainer(model)
 
     g = torch.Generator(device="cpu").manual_seed(7122 + rank)
@@ -123,6 +128,7 @@ def main():
     # ---- forward only (north_star: fraction of the MFMA bf16 peak on the HuBERT + attention-pool forward) ---------
     fwd_ms = None
     if rank == 0 and args.model == "base":
+        model.eval()                                             # inference forward: no dropout
         with torch.no_grad():
             model(batch)
             torch.cuda.synchronize()
@@ -131,6 +137,7 @@ def main():
                 model(batch)
             torch.cuda.synchronize()
             fwd_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        model.train()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -179,7 +186,9 @@ def main():
                                    f"attention-pool head fwd/bwd + InfoNCE fwd/bwd + Adam), {B} utt/GPU x {args.seconds:g} s "
                                    f"(L={L}, T={T}), CLIP image embeddings given",
                        "global_batch": B * world, "per_gpu_batch": B, "audio_samples": L, "frames": T,
-                       "parallelism": f"dp{world}", "dropout": "off (deterministic head; reference trains with p=0.1)"},
+                       "parallelism": f"dp{world}", "dropout": ("off (--no-dropout)" if args.no_dropout else
+                                   "on, as the reference's train step: frozen HuBERT in train mode (base: input / residual / attention "
+                                   "p=0.1; large: 0) + head p=0.1; masks = stateless hash inside the GEMM / attention kernels")},
             "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,
             "forward": None if fwd_ms is None else forward_summary(fwd_ms, B, L, T),
         }

@@ -169,14 +169,16 @@ int sc_wsum_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial 
  *   X [B, R, D] bf16 ; a [H, D] fp32 ; len [B] int32 (valid keys incl. CLS) ; H <= 16
  * backward (dm [B,H,D] fp32 given):
  *   dp = dm . X ; ds = p (dp - sum p dp) ; dX = sum_h p dm + ds a ; da_partial[b,h,:] = sum_s ds X
+ * train-mode dropout of the attention weights (nn.MultiheadAttention dropout=): mult [B,H,R] fp32 (0 or 1/(1-p_drop),
+ *   NULL = none): m = sum_s p*mult X ; backward takes dp already multiplied by mult and uses p*mult in the dX term.
  * ---------------------------------------------------------------------------------------------- */
 int sc_cls_scores(const sc_bf16* X, const float* vec, int64_t vec_bstride, float* scores, int32_t B, int32_t R,
                   int32_t D, int32_t H, void* stream);
 int sc_cls_pool_fwd(const sc_bf16* X, const float* scores, const int32_t* len, float* p, float* m, int32_t B,
-                    int32_t R, int32_t D, int32_t H, void* stream);
+                    int32_t R, int32_t D, int32_t H, const float* mult, void* stream);
 int sc_cls_pool_bwd(const sc_bf16* X, const float* p, const float* dp, const float* dm, const float* a,
                     const int32_t* len, float* dX, float* da_partial, int32_t B, int32_t R, int32_t D, int32_t H,
-                    void* stream);
+                    const float* mult, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 strided GEMM  C[i,j] = alpha * sum_k A[i*sai + k*sak] * Bm[j*sbj + k*sbk]  (+ bias[j])

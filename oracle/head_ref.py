@@ -30,8 +30,8 @@ def weighted_sum(weights: torch.Tensor, hidden_states: Sequence[torch.Tensor], n
     return (w.view(-1, *([1] * hidden_states[0].dim())) * x).sum(0)
 
 
-def _mha(W, p: str, x: torch.Tensor, kpm: Optional[torch.Tensor], nhead: int) -> torch.Tensor:
-    """nn.MultiheadAttention(batch_first=True) self-attention, eval mode."""
+def _mha(W, p: str, x: torch.Tensor, kpm: Optional[torch.Tensor], nhead: int, drop=None) -> torch.Tensor:
+    """nn.MultiheadAttention(batch_first=True) self-attention; ``drop`` (train mode) acts on the attention probabilities."""
     B, S, D = x.shape
     dh = D // nhead
     qkv = F.linear(x, W[p + "in_proj_weight"], W[p + "in_proj_bias"])
@@ -43,13 +43,18 @@ def _mha(W, p: str, x: torch.Tensor, kpm: Optional[torch.Tensor], nhead: int) ->
     if kpm is not None:
         s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
     a = torch.softmax(s, dim=-1)
+    if drop is not None:
+        a = drop(a)
     o = (a @ v).transpose(1, 2).reshape(B, S, D)
     return F.linear(o, W[p + "out_proj.weight"], W[p + "out_proj.bias"])
 
 
 def transformer_encoder_forward(W, prefix: str, src: torch.Tensor, key_padding_mask: torch.Tensor,
                                 n_layers: int, nhead: int, norm_first: bool = False,
-                                layer_norm_eps: float = 1e-5, return_hidden: bool = False):
+                                layer_norm_eps: float = 1e-5, return_hidden: bool = False, drop=None):
+    """nn.TransformerEncoder of nn.TransformerEncoderLayer(activation=gelu) + final LayerNorm.  ``drop`` = None: eval mode.
+    Train mode: ``drop(site, layer, tensor)`` at the layer's four dropout sites - "attn" (attention probabilities (B,H,S,S)),
+    "dropout1" (attention block output), "dropout" (after the activation), "dropout2" (FFN output); masks are the caller's."""
     D = src.shape[-1]
     x = src
     hidden = []
@@ -60,15 +65,18 @@ def transformer_encoder_forward(W, prefix: str, src: torch.Tensor, key_padding_m
         def ln(name, t):
             return F.layer_norm(t, (D,), W[p + name + ".weight"], W[p + name + ".bias"], layer_norm_eps)
 
-        def ff(t):
-            return F.linear(F.gelu(F.linear(t, W[p + "linear1.weight"], W[p + "linear1.bias"])),
-                            W[p + "linear2.weight"], W[p + "linear2.bias"])
+        dr = (lambda site: (lambda t: drop(site, i, t))) if drop is not None else (lambda site: (lambda t: t))
 
+        def ff(t):
+            return dr("dropout2")(F.linear(dr("dropout")(F.gelu(F.linear(t, W[p + "linear1.weight"], W[p + "linear1.bias"]))),
+                                           W[p + "linear2.weight"], W[p + "linear2.bias"]))
+
+        d_att = dr("attn") if drop is not None else None
         if norm_first:
-            x = x + _mha(W, p + "self_attn.", ln("norm1", x), key_padding_mask, nhead)
+            x = x + dr("dropout1")(_mha(W, p + "self_attn.", ln("norm1", x), key_padding_mask, nhead, d_att))
             x = x + ff(ln("norm2", x))
         else:
-            x = ln("norm1", x + _mha(W, p + "self_attn.", x, key_padding_mask, nhead))
+            x = ln("norm1", x + dr("dropout1")(_mha(W, p + "self_attn.", x, key_padding_mask, nhead, d_att)))
             x = ln("norm2", x + ff(x))
     hidden.append(x)
     out = F.layer_norm(x, (D,), W[prefix + "model.norm.weight"], W[prefix + "model.norm.bias"], 1e-5)
@@ -113,13 +121,13 @@ def init_parallel_branch_weights(d_model: int = 768, ffn: int = 3072, out_dim: i
 
 
 def parallel_branch_forward(W, audio_feat: torch.Tensor, audio_len: torch.Tensor, nhead: int = 8,
-                            n_layers: int = 1, need_projection: bool = True) -> torch.Tensor:
-    """kw_branches.py:266-280 -> (B, E) un-normalised parallel_audio_feat."""
+                            n_layers: int = 1, need_projection: bool = True, drop=None) -> torch.Tensor:
+    """kw_branches.py:266-280 -> (B, E) un-normalised parallel_audio_feat (``drop``: see transformer_encoder_forward)."""
     bsz, T = audio_feat.shape[:2]
     cls = torch.cat([W["cls"]] * bsz, dim=0)
     src = torch.cat([cls, audio_feat], dim=1)
     kpm = get_keypadding_mask(T + 1, audio_len + 1)
-    out = transformer_encoder_forward(W, "self_att.", src, kpm, n_layers, nhead)
+    out = transformer_encoder_forward(W, "self_att.", src, kpm, n_layers, nhead, drop=drop)
     out = out[:, :1].reshape(-1, audio_feat.shape[-1])
     if need_projection:
         out = F.linear(out, W["linear_proj.weight"], W["linear_proj.bias"])

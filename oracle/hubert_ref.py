@@ -152,8 +152,9 @@ def forward_padding_mask(T: int, padding_mask: torch.Tensor) -> torch.Tensor:
     return padding_mask.all(-1)
 
 
-def self_attention(W, p: str, x: torch.Tensor, key_padding_mask: Optional[torch.Tensor], heads: int) -> torch.Tensor:
-    """fairseq MultiheadAttention (self-attention, no dropout).  x: (B, T, D)."""
+def self_attention(W, p: str, x: torch.Tensor, key_padding_mask: Optional[torch.Tensor], heads: int, drop=None) -> torch.Tensor:
+    """fairseq MultiheadAttention (self-attention).  x: (B, T, D).  ``drop`` (train mode): applied to the attention
+    probabilities (B, H, T, T), fairseq's dropout_module(attn_weights)."""
     B, T, D = x.shape
     dh = D // heads
     q = F.linear(x, W[p + "q_proj.weight"], W[p + "q_proj.bias"]) * dh ** -0.5
@@ -166,32 +167,45 @@ def self_attention(W, p: str, x: torch.Tensor, key_padding_mask: Optional[torch.
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
     a = torch.softmax(s.float(), dim=-1)
+    if drop is not None:
+        a = drop(a)
     o = (a @ v).transpose(1, 2).reshape(B, T, D)
     return F.linear(o, W[p + "out_proj.weight"], W[p + "out_proj.bias"])
 
 
-def encoder_layer(W, arch: HubertArch, i: int, x: torch.Tensor, kpm: Optional[torch.Tensor]) -> torch.Tensor:
-    """fairseq TransformerSentenceEncoderLayer.forward (eval mode)."""
+def encoder_layer(W, arch: HubertArch, i: int, x: torch.Tensor, kpm: Optional[torch.Tensor], drop=None) -> torch.Tensor:
+    """fairseq TransformerSentenceEncoderLayer.forward.  ``drop`` = None: eval mode.  Train mode (the reference's training
+    step runs the frozen HuBERT in train mode, see hubert_forward): ``drop(site, layer, tensor)`` is called at the layer's
+    dropout sites - "attn" (attention probabilities), "dropout1" (after out_proj, before the residual), "dropout3" (after
+    fc2, before the residual); dropout2 (activation_dropout) is 0 in the released HuBERT configs."""
     p = f"encoder.layers.{i}."
     D = arch.embed_dim
+    d_att = (lambda t: drop("attn", i, t)) if drop is not None else None
+    d1 = (lambda t: drop("dropout1", i, t)) if drop is not None else (lambda t: t)
+    d3 = (lambda t: drop("dropout3", i, t)) if drop is not None else (lambda t: t)
 
     def ln(name, t):
         return F.layer_norm(t, (D,), W[p + name + ".weight"], W[p + name + ".bias"], 1e-5)
 
     if not arch.layer_norm_first:
-        x = ln("self_attn_layer_norm", x + self_attention(W, p + "self_attn.", x, kpm, arch.heads))
+        x = ln("self_attn_layer_norm", x + d1(self_attention(W, p + "self_attn.", x, kpm, arch.heads, d_att)))
         h = F.linear(F.gelu(F.linear(x, W[p + "fc1.weight"], W[p + "fc1.bias"])), W[p + "fc2.weight"], W[p + "fc2.bias"])
-        x = ln("final_layer_norm", x + h)
+        x = ln("final_layer_norm", x + d3(h))
     else:
-        x = x + self_attention(W, p + "self_attn.", ln("self_attn_layer_norm", x), kpm, arch.heads)
+        x = x + d1(self_attention(W, p + "self_attn.", ln("self_attn_layer_norm", x), kpm, arch.heads, d_att))
         y = ln("final_layer_norm", x)
-        x = x + F.linear(F.gelu(F.linear(y, W[p + "fc1.weight"], W[p + "fc1.bias"])), W[p + "fc2.weight"], W[p + "fc2.bias"])
+        x = x + d3(F.linear(F.gelu(F.linear(y, W[p + "fc1.weight"], W[p + "fc1.bias"])), W[p + "fc2.weight"], W[p + "fc2.bias"]))
     return x
 
 
 def hubert_forward(W, arch: HubertArch, padded_wav: torch.Tensor, wav_padding_mask: Optional[torch.Tensor],
-                   debug: Optional[dict] = None) -> List[torch.Tensor]:
+                   debug: Optional[dict] = None, drop=None) -> List[torch.Tensor]:
     """customHubertForward (speech_encoder_plus.py:67-107) + patched extract_features (:29-64).
+
+    ``drop`` = None is eval mode.  In the reference's TRAINING step the frozen HuBERT is in train mode (the constructor's
+    eval() at :402 is undone by Lightning's model.train(); nothing overrides train()), so its dropout sites are live:
+    ``drop(site, layer, tensor)`` is called with site "input" (dropout_input, :87), "encoder" (F.dropout after the encoder
+    LayerNorm, :42) and the per-layer sites of encoder_layer; the caller supplies the masks (the oracle has no RNG of its own).
 
     Returns layer_results = [encoder input, out_1 .. out_NL], each (B, T, D)."""
     conv_outs = [] if debug is not None else None
@@ -205,6 +219,8 @@ def hubert_forward(W, arch: HubertArch, padded_wav: torch.Tensor, wav_padding_ma
         debug["conv"] = conv_outs
         debug["proj"] = x.clone()
         debug["padding_mask"] = pm
+    if drop is not None:
+        x = drop("input", -1, x)                                             # :87 dropout_input
     # mask=None is falsy -> no time masking (:90-94)
     if pm is not None:
         x = x.masked_fill(pm.unsqueeze(-1), 0.0)                             # :32-33 index_put(x, mask, 0)
@@ -217,18 +233,20 @@ def hubert_forward(W, arch: HubertArch, padded_wav: torch.Tensor, wav_padding_ma
     x = x + xc                                                               # :37
     if not arch.layer_norm_first:
         x = F.layer_norm(x, (arch.embed_dim,), W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], 1e-5)  # :39-40
+    if drop is not None:
+        x = drop("encoder", -1, x)                                           # :42
     layer_results = [x]                                                      # :47
-    for i in range(arch.layers):                                             # :49-53 (layerdrop 0, eval)
-        x = encoder_layer(W, arch, i, x, pm)
+    for i in range(arch.layers):                                             # :49-53 (layerdrop 0)
+        x = encoder_layer(W, arch, i, x, pm, drop)
         layer_results.append(x)
     return layer_results
 
 
-def speech_encoder_forward(W, arch: HubertArch, wavs: Sequence[torch.Tensor]):
-    """FairseqSpeechEncoder_Hubert.forward (eval, no crop): returns (hidden_states tuple, feat_len).
-    speech_encoder_plus.py:554-611."""
+def speech_encoder_forward(W, arch: HubertArch, wavs: Sequence[torch.Tensor], drop=None):
+    """FairseqSpeechEncoder_Hubert.forward (no crop; eval unless ``drop`` is given, see hubert_forward): returns
+    (hidden_states tuple, feat_len).  speech_encoder_plus.py:554-611."""
     padded, mask = preprocess_input(wavs, arch.normalize_wav)
-    hs = hubert_forward(W, arch, padded, mask)
+    hs = hubert_forward(W, arch, padded, mask, drop=drop)
     T = hs[-1].shape[1]
     feat_len = torch.tensor(feat_len_rule([len(w) for w in wavs], T, arch.downsample_rate), dtype=torch.long)
     return tuple(hs), feat_len

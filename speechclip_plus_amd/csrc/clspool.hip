@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void cls_scores_kernel(const uint16_t* __restr
 __global__ __launch_bounds__(256) void cls_pool_fwd_kernel(const uint16_t* __restrict__ X,
                                                            const float* __restrict__ scores,
                                                            const int32_t* __restrict__ len, float* __restrict__ p,
-                                                           float* __restrict__ m, int R, int D, int H) {
+                                                           float* __restrict__ m, int R, int D, int H,
+                                                           const float* __restrict__ mult) {
     extern __shared__ float sm[];            // p[H][R] then red[4][H][64]
     float* ps = sm;
     float* red = sm + H * R;
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256) void cls_pool_fwd_kernel(const uint16_t* __res
         const float inv = 1.0f / sum;
         for (int s = lane; s < R; s += 64) {
             const float v = s < n ? ps[h * R + s] * inv : 0.f;
-            ps[h * R + s] = v;
+            // attention-weight dropout (train mode): the pooling uses p * mult (mult = 0 or 1 / (1 - p_drop)), p itself is kept
+            ps[h * R + s] = mult ? v * mult[((int64_t)b * H + h) * R + s] : v;
             if (blockIdx.x == 0) p[((int64_t)b * H + h) * R + s] = v;
         }
     }
@@ -107,8 +109,9 @@ __global__ __launch_bounds__(256) void cls_pool_bwd_kernel(const uint16_t* __res
                                                            const float* __restrict__ dm,
                                                            const float* __restrict__ a,
                                                            const int32_t* __restrict__ len, float* __restrict__ dX,
-                                                           float* __restrict__ da_partial, int R, int D, int H) {
-    extern __shared__ float sm[];            // ps[H][R], dss[H][R], red[4][H][64]
+                                                           float* __restrict__ da_partial, int R, int D, int H,
+                                                           const float* __restrict__ mult) {
+    extern __shared__ float sm[];            // ps[H][R] (p * mult: the weights the pooling used), dss[H][R], red[4][H][64]
     float* ps = sm;
     float* dss = sm + H * R;
     float* red = sm + 2 * H * R;
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(256) void cls_pool_bwd_kernel(const uint16_t* __res
         dot = wave_sum(dot);
         for (int s = lane; s < R; s += 64) {
             const float pv = s < n ? pr[s] : 0.f;
-            ps[h * R + s] = pv;
-            dss[h * R + s] = s < n ? pv * (dpr[s] - dot) : 0.f;
+            ps[h * R + s] = mult ? pv * mult[((int64_t)b * H + h) * R + s] : pv;
+            dss[h * R + s] = s < n ? pv * (dpr[s] - dot) : 0.f;     // dp arrives already multiplied by mult
         }
     }
     __syncthreads();
@@ -185,24 +188,24 @@ extern "C" int sc_cls_scores(const sc_bf16* X, const float* vec, int64_t vec_bst
 }
 
 extern "C" int sc_cls_pool_fwd(const sc_bf16* X, const float* scores, const int32_t* len, float* p, float* m,
-                               int32_t B, int32_t R, int32_t D, int32_t H, void* stream) {
+                               int32_t B, int32_t R, int32_t D, int32_t H, const float* mult, void* stream) {
     SC_CHECK(X && scores && len && p && m, "sc_cls_pool_fwd: null pointer");
     SC_CHECK(D % 64 == 0 && H >= 1 && H <= MAXH, "sc_cls_pool_fwd: D %% 64, H <= 16 required (D=%d H=%d)", D, H);
     const size_t lds = (size_t)(H * R + 4 * H * 64) * sizeof(float);
     SC_CHECK(lds <= 64 * 1024, "sc_cls_pool_fwd: H*R too large for LDS");
-    hipLaunchKernelGGL(cls_pool_fwd_kernel, dim3(D / 64, B), dim3(256), lds, (hipStream_t)stream, X, scores, len, p, m, R, D, H);
+    hipLaunchKernelGGL(cls_pool_fwd_kernel, dim3(D / 64, B), dim3(256), lds, (hipStream_t)stream, X, scores, len, p, m, R, D, H, mult);
     SC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sc_cls_pool_bwd(const sc_bf16* X, const float* p, const float* dp, const float* dm, const float* a,
                                const int32_t* len, float* dX, float* da_partial, int32_t B, int32_t R, int32_t D,
-                               int32_t H, void* stream) {
+                               int32_t H, const float* mult, void* stream) {
     SC_CHECK(X && p && dp && dm && a && len && dX && da_partial, "sc_cls_pool_bwd: null pointer");
     SC_CHECK(D % 64 == 0 && H >= 1 && H <= MAXH, "sc_cls_pool_bwd: D %% 64, H <= 16 required");
     const size_t lds = (size_t)(2 * H * R + 4 * H * 64) * sizeof(float);
     SC_CHECK(lds <= 64 * 1024, "sc_cls_pool_bwd: H*R too large for LDS");
-    hipLaunchKernelGGL(cls_pool_bwd_kernel, dim3(D / 64, B), dim3(256), lds, (hipStream_t)stream, X, p, dp, dm, a, len, dX, da_partial, R, D, H);
+    hipLaunchKernelGGL(cls_pool_bwd_kernel, dim3(D / 64, B), dim3(256), lds, (hipStream_t)stream, X, p, dp, dm, a, len, dX, da_partial, R, D, H, mult);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -13,6 +13,11 @@ One autograd node: parameter gradients are ACCUMULATED IN PLACE into ``p.grad`` 
 buffer, optim.FlatAdam) by the weight-gradient products themselves (beta = 1), so the backward adds no per-parameter
 accumulate kernels; only ``cls`` (which guarantees the node is reached), the weighted-sum logits and a generic ``feat``
 input receive their gradient through autograd's return values.
+
+Train mode (``module.training`` and dropout p > 0; nn.TransformerEncoderLayer's four dropout sites, p = 0.1 in every
+recipe): attention weights (a [B,H,R] multiplier consumed by the pooling kernel), dropout1 on the attention output,
+dropout on the activation, dropout2 on the FFN output.  The masks come from torch's device generator (so
+``torch.manual_seed`` makes a step reproducible) as 0 / (1/(1-p)) multipliers and are kept for the backward.
 """
 from typing import Optional
 
@@ -78,21 +83,32 @@ class ParallelHeadFn(torch.autograd.Function):
         a = torch.empty(H, D, device=dev, dtype=torch.float32)
         ops.sgemm_ex(Qm, (D, 1, 0), Wk, (1, D, 0), a, D, H, D, D, alpha=dh ** -0.5)
         scores = ops.cls_scores(src, a, False, B, R, D, H)
-        p, m = ops.cls_pool_fwd(src, scores, lens, B, R, D, H)   # m [B, H, D]
+        pd = float(module.dropout) if module.training else 0.0
+        mk = (lambda *shape: (torch.rand(*shape, device=dev) >= pd).float().mul_(1.0 / (1.0 - pd))) if pd > 0 else None
+        mult = mk(B, H, R) if mk else None
+        p, m = ops.cls_pool_fwd(src, scores, lens, B, R, D, H, mult)   # m [B, H, D]
         # ---- value projection per head (softmax sums to 1 => + bv), out_proj, post-LN layer on B rows
         cx = torch.empty(B, D, device=dev, dtype=torch.float32)
         ops.sgemm_ex(m, (H * D, 1, D), Wv, (D, 1, dh * D), cx, D, B, dh, D, nbatch=H, scz=dh, bias=bi[2 * D:], sbiasz=dh)
         attn = _lin(cx, att.out_proj.weight.detach(), att.out_proj.bias.detach())
+        k1, kf, k2 = (mk(B, D), mk(B, layer.linear1.out_features), mk(B, D)) if mk else (None, None, None)
+        if mk:
+            attn *= k1
         x1, xh1, rs1 = ops.rowln_fwd(attn, x0, 0, layer.norm1.weight.detach(), layer.norm1.bias.detach(), module.layer_norm_eps)
         u = _lin(x1, layer.linear1.weight.detach(), layer.linear1.bias.detach())
         f = ops.gelu_f32(u)
+        if mk:
+            f *= kf
         y2 = _lin(f, layer.linear2.weight.detach(), layer.linear2.bias.detach())
+        if mk:
+            y2 *= k2
         x2, xh2, rs2 = ops.rowln_fwd(y2, x1, D, layer.norm2.weight.detach(), layer.norm2.bias.detach(), module.layer_norm_eps)
         fin = module.model.norm
         x3, xh3, rs3 = ops.rowln_fwd(x2, None, 0, fin.weight.detach(), fin.bias.detach(), fin.eps)
         out = _lin(x3, proj.weight.detach(), proj.bias.detach()) if proj is not None else x3
         ctx.mod, ctx.proj, ctx.handle, ctx.dims = module, proj, handle, (B, R, D, H)
         ctx.feat_meta = None if feat is None else (feat.shape, feat.dtype)
+        ctx.masks = (mult, k1, kf, k2)
         ctx.save_for_backward(src, lens, x0, q, Qm, a, p, m, cx, xh1, rs1, x1, u, f, xh2, rs2, xh3, rs3, x3)
         return out
 
@@ -101,6 +117,7 @@ class ParallelHeadFn(torch.autograd.Function):
         src, lens, x0, q, Qm, a, p, m, cx, xh1, rs1, x1, u, f, xh2, rs2, xh3, rs3, x3 = ctx.saved_tensors
         module, proj = ctx.mod, ctx.proj
         B, R, D, H = ctx.dims
+        mult, k1, kf, k2 = ctx.masks
         dh = D // H
         dev = src.device
         layer, fin = module.model.layers[0], module.model.norm
@@ -113,8 +130,11 @@ class ParallelHeadFn(torch.autograd.Function):
         dx3 = _lin_bwd(d_out, x3, proj.weight.detach(), _gacc(proj.weight), _gacc(proj.bias)) if proj is not None else d_out
         dx2 = ops.rowln_bwd(dx3, xh3, fin.weight.detach(), rs3, _gacc(fin.weight), _gacc(fin.bias))
         dy2 = ops.rowln_bwd(dx2, xh2, layer.norm2.weight.detach(), rs2, _gacc(layer.norm2.weight), _gacc(layer.norm2.bias))
-        # ---- FFN:  y2 = x1 + W2 gelu(W1 x1 + b1) + b2
-        df = _lin_bwd(dy2, f, layer.linear2.weight.detach(), _gacc(layer.linear2.weight), _gacc(layer.linear2.bias))
+        # ---- FFN:  y2 = x1 + k2 * (W2 (kf * gelu(W1 x1 + b1)) + b2)      (k* = dropout multipliers, 1 in eval; f is saved masked)
+        dl2 = dy2 * k2 if k2 is not None else dy2
+        df = _lin_bwd(dl2, f, layer.linear2.weight.detach(), _gacc(layer.linear2.weight), _gacc(layer.linear2.bias))
+        if kf is not None:
+            df *= kf
         du = ops.gelu_f32(u, df)
         dx1 = _lin_bwd(du, x1, layer.linear1.weight.detach(), _gacc(layer.linear1.weight), _gacc(layer.linear1.bias))
         dx1 += dy2
@@ -122,6 +142,8 @@ class ParallelHeadFn(torch.autograd.Function):
         dy1 = ops.rowln_bwd(dx1, xh1, layer.norm1.weight.detach(), rs1, _gacc(layer.norm1.weight), _gacc(layer.norm1.bias))
         d_x0 = torch.empty(1, D, device=dev, dtype=torch.float32)
         ops.colsum(dy1, D, B, D, d_x0)
+        if k1 is not None:
+            dy1 = dy1 * k1
         dcx = _lin_bwd(dy1, cx, att.out_proj.weight.detach(), _gacc(att.out_proj.weight), _gacc(att.out_proj.bias))
         # ---- value projection: bv, Wv_h += dcx_h^T m_h, dm_h = dcx_h Wv_h
         ops.colsum(dcx, D, B, D, gbi[2 * D:], beta=1.0)
@@ -130,7 +152,9 @@ class ParallelHeadFn(torch.autograd.Function):
         ops.sgemm_ex(dcx, (D, 1, dh), Wv, (1, D, dh * D), dm, H * D, B, D, dh, nbatch=H, scz=D)
         # ---- attention pooling backward (two sweeps over X), gradient of the CLS slot and of a
         dp = ops.cls_scores(src, dm, True, B, R, D, H)
-        dX, da_part = ops.cls_pool_bwd(src, p, dp, dm, a, lens, B, R, D, H)
+        if mult is not None:
+            dp *= mult
+        dX, da_part = ops.cls_pool_bwd(src, p, dp, dm, a, lens, B, R, D, H, mult)
         ops.colsum(dX, R * D, B, D, d_x0, beta=1.0)              # row 0 of every utterance is the CLS token
         d_a = torch.empty(H, D, device=dev, dtype=torch.float32)
         ops.colsum(da_part, H * D, B, H * D, d_a)

@@ -13,8 +13,10 @@ from the head's backward (head_tail.ParallelHeadFn) with the gradient of the wei
                           residual add.  Frozen layers above the lowest unfrozen one run the same chain without weight gradients.
 
 Weight gradients are written in fp32 straight into the parameters' ``.grad`` (views of the optimiser's flat buffer), so the
-single flat all-reduce of parallel.GradAllReduce covers them.  Dropout / layerdrop inside the unfrozen layers
-(fairseq trains them with p = 0.1) is not applied: the path is deterministic, as the rest of this build.
+single flat all-reduce of parallel.GradAllReduce covers them.  Dropout inside the UNFROZEN layers (and the frozen
+pass-through layers above them; fairseq: p = 0.1 base, 0 large) is not applied - their backward would have to re-apply the
+masks; the frozen layers below them, the encoder input sites and the head do run their train-mode dropout
+(speech_encoder._encode_kernels).  No shipped recipe unfreezes HuBERT layers.
 """
 from typing import Dict, List
 

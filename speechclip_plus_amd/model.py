@@ -149,6 +149,26 @@ def base_parallel_config(**overrides) -> Config:
     return cfg
 
 
+def set_dropout(model: nn.Module, enabled: bool) -> nn.Module:
+    """Switch every train-mode dropout site of ``model`` off (or back on): the frozen HuBERT's (speech_encoder.HubertArch), the
+    parallel head's four sites (head_tail.ParallelHeadFn), nn.MultiheadAttention's and every nn.Dropout.  The reference has no
+    such switch (its train step always runs them); the deterministic form is what the parity tests compare with the oracle.
+    The original probabilities are remembered on the modules, so ``set_dropout(model, True)`` restores them."""
+    from .transformer_models import TransformerEncoder
+    for m in model.modules():
+        if isinstance(m, FairseqSpeechEncoder_Hubert):
+            m.hubert_dropout = bool(enabled)
+        elif isinstance(m, nn.Dropout):
+            if not hasattr(m, "_sc_p"):
+                m._sc_p = m.p
+            m.p = m._sc_p if enabled else 0.0
+        elif isinstance(m, (nn.MultiheadAttention, TransformerEncoder)):
+            if not hasattr(m, "_sc_p"):
+                m._sc_p = m.dropout
+            m.dropout = m._sc_p if enabled else 0.0
+    return model
+
+
 class KWClip_GeneralTransformer(nn.Module):
     def __init__(self, config, image_encoder: Optional[Callable] = None, device: str = "cuda", hubert_state_dict=None,
                  hubert_arch=None):

@@ -316,19 +316,25 @@ def cls_scores(X: torch.Tensor, vec: torch.Tensor, per_batch: bool, B: int, R: i
     return scores
 
 
-def cls_pool_fwd(X: torch.Tensor, scores: torch.Tensor, lens: torch.Tensor, B: int, R: int, D: int, H: int):
+def cls_pool_fwd(X: torch.Tensor, scores: torch.Tensor, lens: torch.Tensor, B: int, R: int, D: int, H: int,
+                 mult: Optional[torch.Tensor] = None):
+    """``mult`` [B,H,R] fp32 = dropout multipliers of the attention weights (0 or 1/(1-p)); p is returned un-masked."""
     p = torch.empty(B, H, R, device=X.device, dtype=torch.float32)
     m = torch.empty(B, H, D, device=X.device, dtype=torch.float32)
-    check(lib().sc_cls_pool_fwd(_p(X), _p(scores), _p(lens), _p(p), _p(m), B, R, D, H, _stream()), "sc_cls_pool_fwd")
+    if mult is not None:
+        assert mult.shape == (B, H, R) and mult.dtype == torch.float32 and mult.is_contiguous()
+    check(lib().sc_cls_pool_fwd(_p(X), _p(scores), _p(lens), _p(p), _p(m), B, R, D, H, _p(mult) if mult is not None else None,
+                                _stream()), "sc_cls_pool_fwd")
     return p, m
 
 
 def cls_pool_bwd(X: torch.Tensor, p: torch.Tensor, dp: torch.Tensor, dm: torch.Tensor, a: torch.Tensor, lens: torch.Tensor,
-                 B: int, R: int, D: int, H: int):
+                 B: int, R: int, D: int, H: int, mult: Optional[torch.Tensor] = None):
+    """with ``mult`` (see cls_pool_fwd) ``dp`` must already be multiplied by it."""
     dX = torch.empty(B, R, D, device=X.device, dtype=torch.float32)
     da_part = torch.empty(B, H, D, device=X.device, dtype=torch.float32)
-    check(lib().sc_cls_pool_bwd(_p(X), _p(p), _p(dp), _p(dm), _p(a), _p(lens), _p(dX), _p(da_part), B, R, D, H, _stream()),
-          "sc_cls_pool_bwd")
+    check(lib().sc_cls_pool_bwd(_p(X), _p(p), _p(dp), _p(dm), _p(a), _p(lens), _p(dX), _p(da_part), B, R, D, H,
+                                _p(mult) if mult is not None else None, _stream()), "sc_cls_pool_bwd")
     return dX, da_part
 
 

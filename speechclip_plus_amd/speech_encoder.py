@@ -48,13 +48,21 @@ class HubertArch:
     pos_conv_groups: int = 16
     normalize_wav: bool = False
     downsample_rate: int = 320
+    # fairseq HubertConfig dropouts of the released checkpoints (hubert_base_librispeech.yaml; hubert_large_librivox.yaml has
+    # all of them 0).  They act in the reference's TRAIN step although HuBERT is frozen: Lightning's model.train() flips the
+    # eval() of speech_encoder_plus.py:402 back.  encoder_layerdrop is overwritten by layer_drop (:404-411, 0.0 in every recipe).
+    dropout: float = 0.1               # after the encoder LayerNorm, after out_proj and after fc2
+    attention_dropout: float = 0.1     # on the attention probabilities
+    activation_dropout: float = 0.0    # after the FFN activation
+    dropout_input: float = 0.1         # on post_extract_proj's output
 
 
 ARCHS = {
     "hubert": HubertArch(),
     "hubert_base": HubertArch(),
     "hubert_large_ll60k": HubertArch(embed_dim=1024, ffn_dim=4096, layers=24, heads=16, extractor_mode="layer_norm",
-                                     conv_bias=True, layer_norm_first=True, normalize_wav=True),
+                                     conv_bias=True, layer_norm_first=True, normalize_wav=True, dropout=0.0,
+                                     attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0),
 }
 
 
@@ -121,6 +129,16 @@ def random_hubert_state_dict(arch: HubertArch, seed: int = 7122) -> Dict[str, to
 
 
 _USE_GRAPH = os.environ.get("SC_ENCODER_GRAPH", "0") == "1"      # opt-in: measured +-0 on one GPU
+
+
+def _mix32(x: int) -> int:
+    """lowbias32 (the kernels' sc_hash32) on the host: decorrelates the per-site dropout seeds."""
+    x &= 0xffffffff
+    x ^= x >> 16
+    x = (x * 0x7feb352d) & 0xffffffff
+    x ^= x >> 15
+    x = (x * 0x846ca68b) & 0xffffffff
+    return x ^ (x >> 16)
 
 
 def _roundup(x: int, m: int) -> int:
@@ -198,6 +216,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if not (isinstance(layer_drop, float) and layer_drop == 0.0) and layer_drop != "original":
             raise ValueError(f"layer_drop = {layer_drop} is not supported.")
         self.feat_select_idx = feat_select_idx
+        self.hubert_dropout = True              # False: keep the frozen encoder deterministic in train mode (not the reference)
+        self._drop_calls = 0
         self.before_trainable = None            # optional callable invoked right before the first trainable module (train.py)
         self.max_audio_len = max_audio_len
         self.reinit_layers = reinit_layers
@@ -317,7 +337,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # launch instead of ~130.  Measured +-0 on one GPU (the host already runs a full step ahead of the device and the ~3 us
         # gaps between kernels are the hardware's dispatch, not the host's), so it stays off by default; not used with
         # unfrozen layers nor while bench.py's per-kernel event timer is attached.
-        use_graph = (_USE_GRAPH and self._dev.type == "cuda" and self.train_layers is None and ops._timer is None)
+        use_graph = (_USE_GRAPH and self._dev.type == "cuda" and self.train_layers is None and ops._timer is None
+                     and not self._dropout_active())
         if not use_graph:
             self._encode_kernels(pl, padded, save)
             return pl
@@ -334,9 +355,30 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         pl.graph.replay()
         return pl
 
+    def _dropout_active(self) -> bool:
+        a = self.arch
+        return bool(self.training and self.hubert_dropout
+                    and max(a.dropout, a.attention_dropout, a.activation_dropout, a.dropout_input) > 0.0)
+
+    def _dropout_seeds(self):
+        """Per-forward dropout seeds, one per site: a function of torch's seed (torch.manual_seed / seed_everything make a run
+        reproducible), the rank and the number of train-mode forwards so far.  The masks themselves are stateless hashes of
+        (element index, seed) evaluated inside the kernels (csrc/sc_common.h sc_keep8) - nothing is stored."""
+        if not self._dropout_active():
+            return None
+        self._drop_calls += 1
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        base = _mix32(_mix32(torch.initial_seed() & 0xffffffff) ^ _mix32(0x9E3779B9 * (rank + 1)) ^ self._drop_calls)
+        return lambda site: _mix32(base + 0x85EBCA6B * (site + 1))
+
     @torch.no_grad()
     def _encode_kernels(self, pl: _Plan, padded: torch.Tensor, save: bool) -> None:
         a, w = self.arch, self._w
+        seeds = self._dropout_seeds()           # None in eval mode: every drop_p below is 0
+        p_in, p_res, p_att = ((a.dropout_input, a.dropout, a.attention_dropout) if seeds else (0.0, 0.0, 0.0))
+        if seeds and a.activation_dropout > 0.0:
+            raise NotImplementedError("activation_dropout > 0 (0.0 in both released HuBERT configs)")
+        sd = seeds if seeds else (lambda site: 0)
         B, L = pl.B, pl.L
         C, D, F, H = a.conv_dim, a.embed_dim, a.ffn_dim, a.heads
         R, M, T = pl.R, pl.M, pl.T
@@ -359,7 +401,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 ops.layernorm_bf16(pl.conv[i][:rows], w[f"conv{i}_ln_g"], w[f"conv{i}_ln_b"], out=pl.conv[i][:rows], act=1)
         # a3: LayerNorm(512) -> post_extract_proj                                       (:78, :84-85)
         ops.layernorm_bf16(pl.conv[-1][:M], w["ln_feat_g"], w["ln_feat_b"], out=pl.feat_ln)
-        ops.linear_bf16(pl.feat_ln, w["proj_w"], w["proj_b"], out=pl.x_proj, alg_rows=B * T)
+        ops.linear_bf16(pl.feat_ln, w["proj_w"], w["proj_b"], out=pl.x_proj, alg_rows=B * T, drop_p=p_in, drop_seed=sd(0))   # dropout_input (:87)
         # a4: zero padded frames, grouped pos_conv + GELU, residual, LayerNorm          (:32-40)
         G, Kp = a.pos_conv_groups, a.pos_conv_kernel
         Dg, Rp = D // G, R + 2 * pl.halo
@@ -372,11 +414,14 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         def qkv_attn(x, i):
             ops.gemm_raw(x, D, w[f"l{i}_qkv_w"], D, pl.qk, 2 * D, M, 3 * D, D, bias=w[f"l{i}_qkv_b"], Ct=pl.vt,
                          n_split=2 * D, R=R, dh=D // H, alg_rows=B * T)
-            ops.attn_fwd(pl.qk, pl.vt, pl.valid, pl.ctx, B, R, H, D, scale, alg_flops=4.0 * B * T * T * D)
+            ops.attn_fwd(pl.qk, pl.vt, pl.valid, pl.ctx, B, R, H, D, scale, alg_flops=4.0 * B * T * T * D,
+                         drop_p=p_att, drop_seed=sd(3 * i + 2))
 
         if not a.layer_norm_first:
             # a5: post-LN layers (base): x = LN1(x + attn(x)); x = LN2(x + ffn(x))       (:39-40, :49-53)
             ops.layernorm_bf16(pl.pre, w["ln_enc_g"], w["ln_enc_b"], out=pl.hidden[0])
+            if p_res > 0:
+                ops.dropout_bf16(pl.hidden[0], p_res, sd(1), out=pl.hidden[0])                 # F.dropout after the LN (:42)
             tl = self.train_layers
             if tl is not None:
                 tl.refresh()
@@ -386,15 +431,21 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                     tl.layer_forward(i, x, pl.hidden[i + 1], pl, save)
                     continue
                 qkv_attn(x, i)
-                ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T)
+                # train mode: dropout1 / dropout3 of fairseq's TransformerSentenceEncoderLayer in the GEMM epilogues (before the
+                # residual add), attention dropout inside the attention kernel
+                ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T,
+                                drop_p=p_res, drop_seed=sd(3 * i + 3))
                 ops.layernorm_bf16(pl.pre, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
                 ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1, alg_rows=B * T)
-                ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.pre, residual=pl.x1, alg_rows=B * T)
+                ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.pre, residual=pl.x1, alg_rows=B * T,
+                                drop_p=p_res, drop_seed=sd(3 * i + 4))
                 ops.layernorm_bf16(pl.pre, w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"], out=pl.hidden[i + 1])
         else:
             # pre-LN layers (large): x = x + attn(LN1(x)); x = x + ffn(LN2(x)); layer_results are NOT passed through
             # the encoder's final LayerNorm (fairseq applies it to `x` only, which the reference never reads)
             pl.hidden[0].copy_(pl.pre)
+            if p_res > 0:
+                ops.dropout_bf16(pl.hidden[0], p_res, sd(1), out=pl.hidden[0])
             tl = self.train_layers
             if tl is not None:
                 tl.refresh()
@@ -405,11 +456,12 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                     continue
                 ops.layernorm_bf16(x, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
                 qkv_attn(pl.x1, i)
-                ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T)
+                ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T,
+                                drop_p=p_res, drop_seed=sd(3 * i + 3))
                 ops.layernorm_bf16(pl.pre, w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"], out=pl.x1)
                 ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1, alg_rows=B * T)
                 ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.hidden[i + 1], residual=pl.pre,
-                                alg_rows=B * T)
+                                alg_rows=B * T, drop_p=p_res, drop_seed=sd(3 * i + 4))
 
     def forward(self, wav: Union[torch.Tensor, list], wav_len: Union[torch.Tensor, list] = [],
                 feat_select_idx: Union[str, list] = None, return_hidden_states: bool = False) -> Tuple:

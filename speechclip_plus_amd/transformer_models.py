@@ -63,7 +63,7 @@ class TransformerEncoder(nn.Module):
         ``lens`` = number of valid keys per utterance including the CLS slot (audio_len + 1)."""
         if self.n_layers != 1 or self.norm_first:
             raise NotImplementedError("cls_forward covers the shipped parallel-branch recipe: 1 post-LN layer")
-        # the reference applies dropout(p = 0.1) inside the layer in train mode; this build runs the head deterministically
+        # train mode: the layer's four dropout sites (p = self.dropout) are applied inside ParallelHeadFn
         D = self.d_model
         handle = getattr(feat, "_sc_handle", None)
         if handle is not None:
@@ -90,7 +90,8 @@ class MultiheadAttentionAndNorm(nn.Module):
     def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
         """LN(MHA(x, x, x) + x) (TransformerModels.py:120-126).  On a GPU the two projections (B x S rows, the block's FLOPs)
         run on the library's bf16 GEMM with their dgrad / weight-gradient products (linear_fn.LinearBf16Fn); the S x S attention
-        of the branch's head_dim (768 / 96 / 128: the attention kernels are head_dim 64) and the LayerNorm stay stock fp32 ops.  Train-mode attention dropout (p = 0.1 in the reference) is not applied (deterministic build)."""
+        of the branch's head_dim (768 / 96 / 128: the attention kernels are head_dim 64) and the LayerNorm stay stock fp32 ops.
+        Train mode applies nn.MultiheadAttention's dropout to the attention probabilities."""
         src = src.float()
         mha = self.multihead_attn_layer
         if not src.is_cuda:
@@ -107,6 +108,8 @@ class MultiheadAttentionAndNorm(nn.Module):
         scores = torch.bmm(q, k.transpose(1, 2)).view(B, H, S, S) * dh ** -0.5
         scores = scores.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
         p = torch.softmax(scores, dim=-1).view(B * H, S, S)
+        if self.training and mha.dropout > 0:
+            p = torch.nn.functional.dropout(p, mha.dropout)
         ctx = torch.bmm(p, v).view(B, H, S, dh).transpose(1, 2).reshape(B, S, D)
         out = linear_bf16_autograd(ctx, mha.out_proj.weight, mha.out_proj.bias)
         return self.attentionBlock_Norm(out + src)

@@ -41,7 +41,7 @@ def test_cascaded_plus_base_end_to_end():
     """Cascaded+ base: eval-mode embeddings against the oracle chain (encoder -> weighted sum -> cascaded+ tail) and
     two train steps (contrastive + CIF quantity loss, trainable temperature) through the flat-Adam trainer."""
     import oracle
-    from speechclip_plus_amd import KWClip_GeneralTransformer, cascaded_plus_base_config, random_hubert_state_dict
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, cascaded_plus_base_config, random_hubert_state_dict
     from speechclip_plus_amd.speech_encoder import ARCHS
     from speechclip_plus_amd.train import ContrastiveTrainer
     arch = dataclasses.replace(ARCHS["hubert"], layers=2)
@@ -78,10 +78,7 @@ def test_cascaded_plus_base_end_to_end():
         if agree.any():
             assert float(F.cosine_similarity(emb[agree], ref[agree], dim=-1).min()) > 0.995
     # training
-    model.train()
-    for m in model.modules():
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
+    set_dropout(model.train(), False)
     trainer = ContrastiveTrainer(model)
     l1 = trainer.step(batch).item()
     l2 = trainer.step(batch).item()
@@ -99,7 +96,7 @@ def test_cascaded_plus_base_end_to_end():
 def test_hybrid_plus_large_end_to_end():
     """Hybrid+ large (HuBERT-large at reduced depth, MLP keyword projection, 8-head shared attention block):
     forward dict keys of kwClip.py:898-963, both contrastive losses + quantity loss, one optimiser step."""
-    from speechclip_plus_amd import KWClip_GeneralTransformer, hybrid_plus_large_config, random_hubert_state_dict
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, hybrid_plus_large_config, random_hubert_state_dict
     from speechclip_plus_amd.speech_encoder import ARCHS
     from speechclip_plus_amd.train import ContrastiveTrainer
     arch = dataclasses.replace(ARCHS["hubert_large_ll60k"], layers=2)
@@ -108,7 +105,7 @@ def test_hybrid_plus_large_end_to_end():
     cfg = hybrid_plus_large_config()
     cfg.audio_encoder.max_audio_len = -1
     cfg.clip.layers = 2
-    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train()
+    model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
     with torch.no_grad():
         model.cascaded_branch.downsampling.weight_proj[1].bias.add_(-0.5)
     batch, _ = _batch([20000, 14000, 20000, 8000], 768, 2)

@@ -26,7 +26,7 @@ def _free_port():
 def _make(unfreeze):
     import dataclasses
     sys.path.insert(0, ROOT)
-    from speechclip_plus_amd import KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
     from speechclip_plus_amd.speech_encoder import ARCHS
     from speechclip_plus_amd.train import ContrastiveTrainer
     arch = dataclasses.replace(ARCHS["hubert"], layers=3)
@@ -40,7 +40,7 @@ def _make(unfreeze):
     if unfreeze:
         cfg.audio_encoder.trainable = True
         cfg.audio_encoder.unfreeze_layers = [1, 2]
-    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train()
+    model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
     return model, ContrastiveTrainer(model)
 
 

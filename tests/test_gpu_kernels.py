@@ -333,6 +333,68 @@ def test_parallel_branch_golden(dev, golden, name):
                 assert rel_l2(p.grad, ref) < 3e-2, (n, rel_l2(p.grad, ref))
 
 
+def test_parallel_branch_train_mode_dropout_vs_oracle(dev, golden):
+    """Train mode of the CLS head (the four dropout sites of nn.TransformerEncoderLayer, p = 0.1 in the recipes; p = 0.3 here)
+    against the oracle's train-mode restatement fed the SAME masks: they are drawn from torch's device generator in a fixed
+    order (head_tail.ParallelHeadFn), so re-seeding reproduces them.  Output, feature / cls / parameter gradients."""
+    import oracle
+    from conftest import weights_from
+    from speechclip_plus_amd import Config, KW_ParallelBranch
+    fx = golden("head_d64_h8.npz")
+    nhead, D, Fd, E, pd = int(fx["nhead"]), 64, 128, 24, 0.3
+    cfg = Config({"model_settings": {"parallel_branch": {
+        "transformer_type": "TransformerEncoder",
+        "transformer_args": {"n_layers": 1, "d_model": D, "nhead": nhead, "dim_feedforward": Fd, "dropout": pd,
+                             "activation": "gelu", "layer_norm_eps": 1e-5, "batch_first": True, "norm_first": False},
+        "need_projection": True}}})
+    br = KW_ParallelBranch(cfg, audio_dim=D, text_dim=E).to(dev).train()
+    br.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("W_")}, strict=True)
+    feat = torch.from_numpy(fx["feat"]).to(dev).requires_grad_(True)
+    alen = torch.from_numpy(fx["audio_len"])
+    B, T = feat.shape[:2]
+    R = (T + 1 + 127) // 128 * 128
+    torch.manual_seed(77)
+    out = br(audio_feat=feat, audio_feat_len=alen.to(dev))["parallel_audio_feat"]
+    gout = torch.from_numpy(fx["gout"]).to(dev)
+    (out * gout).sum().backward()
+    torch.manual_seed(77)
+    mk = lambda *shape: ((torch.rand(*shape, device=dev) >= pd).float() / (1.0 - pd)).cpu()
+    mult, k1, kf, k2 = mk(B, nhead, R), mk(B, D), mk(B, Fd), mk(B, D)
+    assert 0.5 < float((mult > 0).float().mean()) < 0.9
+    row0 = {"dropout1": k1, "dropout": kf, "dropout2": k2}
+
+    def drop(site, layer, t):
+        m = torch.ones_like(t)
+        if site == "attn":
+            m[:, :, 0, :] = mult[:, :, : t.shape[-1]]
+        else:
+            m[:, 0] = row0[site]
+        return t * m
+
+    W = {k: v.clone().requires_grad_(True) for k, v in weights_from(fx).items()}
+    f_ref = torch.from_numpy(fx["feat"]).bfloat16().float().requires_grad_(True)      # the kernels read the features as bf16
+    ref = oracle.parallel_branch_forward(W, f_ref, alen, nhead=nhead, drop=drop)
+    (ref * gout.cpu()).sum().backward()
+    assert rel_l2(out, ref.to(dev)) < 1e-2
+    eval_out = oracle.parallel_branch_forward(W, f_ref, alen, nhead=nhead)
+    assert rel_l2(ref, eval_out) > 0.1                       # the masks matter: train mode is far from the eval output
+    assert rel_l2(feat.grad, f_ref.grad.to(dev)) < 3e-2
+    assert rel_l2(br.cls.grad, W["cls"].grad.to(dev)) < 3e-2
+    for n, p_ in br.named_parameters():
+        if n == "cls" or W[n].grad is None:
+            continue
+        r = W[n].grad.to(dev)
+        if float(r.norm()) < 1e-6:
+            assert float(p_.grad.norm()) < 1e-4, n
+        else:
+            assert rel_l2(p_.grad, r) < 3e-2, (n, rel_l2(p_.grad, r))
+    # eval mode is untouched by the train-mode path
+    br.eval()
+    with torch.no_grad():
+        o2 = br(audio_feat=feat.detach(), audio_feat_len=alen.to(dev))["parallel_audio_feat"]
+    assert rel_l2(o2, torch.from_numpy(fx["out"]).to(dev)) < 1e-2
+
+
 def test_cls_pool_vs_torch(dev):
     """CLS pooling kernels at the shipped width (D=768, H=8, R=512) vs the same math in fp32 torch."""
     ops = _ops()

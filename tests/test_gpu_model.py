@@ -228,7 +228,7 @@ def test_trainer_side_stream_schedule_matches_synchronous():
     the next step: three steps must leave exactly the parameters of the same steps run on one stream, and the gradients of the
     last step must still be readable."""
     import dataclasses
-    from speechclip_plus_amd import KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
     from speechclip_plus_amd.speech_encoder import ARCHS
     from speechclip_plus_amd.train import ContrastiveTrainer
     arch = dataclasses.replace(ARCHS["hubert"], layers=2)
@@ -243,7 +243,7 @@ def test_trainer_side_stream_schedule_matches_synchronous():
         cfg = base_parallel_config()
         cfg.audio_encoder.max_audio_len = -1
         cfg.cl_loss.args.temperature_trainable = True
-        model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train()
+        model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
         trainer = ContrastiveTrainer(model)
         if sync:
             trainer.side = None
@@ -262,7 +262,7 @@ def test_unfrozen_hubert_layers_gradients_vs_oracle():
     autograd through the same layers."""
     import dataclasses
     import oracle
-    from speechclip_plus_amd import KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
     from speechclip_plus_amd.speech_encoder import ARCHS
     arch = dataclasses.replace(ARCHS["hubert"], layers=3)
     sd = random_hubert_state_dict(arch, seed=9)
@@ -271,7 +271,7 @@ def test_unfrozen_hubert_layers_gradients_vs_oracle():
     cfg.audio_encoder.max_audio_len = -1
     cfg.audio_encoder.trainable = True
     cfg.audio_encoder.unfreeze_layers = [1, 2]
-    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train()
+    model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
     with torch.no_grad():
         model.audio_encoder.weightedsum_layer.weights.copy_(torch.tensor([0.2, -0.1, 0.4, 0.3]))
     tl = model.audio_encoder.train_layers
@@ -362,7 +362,7 @@ def test_unfrozen_layer_prelN_large_with_frozen_layer_above():
     carry the gradient down (input-gradient half of its backward).  Gradients of layer 1 against the oracle's autograd."""
     import dataclasses
     import oracle
-    from speechclip_plus_amd import KWClip_GeneralTransformer, large_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, large_parallel_config, random_hubert_state_dict
     from speechclip_plus_amd.speech_encoder import ARCHS
     arch = dataclasses.replace(ARCHS["hubert_large_ll60k"], layers=3)
     sd = random_hubert_state_dict(arch, seed=12)
@@ -371,7 +371,7 @@ def test_unfrozen_layer_prelN_large_with_frozen_layer_above():
     cfg.audio_encoder.max_audio_len = -1
     cfg.audio_encoder.trainable = True
     cfg.audio_encoder.unfreeze_layers = [1]
-    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train()
+    model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
     with torch.no_grad():
         model.audio_encoder.weightedsum_layer.weights.copy_(torch.tensor([0.2, -0.1, 0.4, 0.3]))
     tl = model.audio_encoder.train_layers
@@ -433,6 +433,64 @@ def test_edge_batches_single_utterance_and_very_short_utterance(setup):
         feat = oracle.weighted_sum(ws_w, list(hs_o), False)
         e = oracle.parallel_branch_forward(head_W, feat, fl, nhead=8)
         assert float(F.cosine_similarity(out, e, dim=-1).min()) > 0.999, lens
+
+
+def test_encoder_train_mode_dropout_vs_oracle(setup):
+    """The reference's TRAINING step runs the frozen HuBERT in train mode (oracle/hubert_ref.py hubert_forward): dropout_input,
+    the dropout after the encoder LayerNorm and, per layer, attention / out_proj / fc2 dropout are live (p = 0.1, base).  The
+    kernels' masks are stateless hashes of (element, seed) (csrc/sc_common.h), so the host rebuilds every mask from the seeds of
+    the call and feeds them to the oracle: all 13 hidden states must agree as in eval mode."""
+    from test_gpu_kernels import _keep_mask
+    model, sd, o_arch, head_W, oracle = setup
+    enc = model.audio_encoder
+    g = torch.Generator().manual_seed(12)
+    lens = [16000, 9000, 3300]
+    wavs = [torch.randn(l, generator=g) for l in lens]
+    with torch.no_grad():
+        hs_eval = [h.clone() for h in enc([w.cuda() for w in wavs], return_hidden_states=True)[2]]
+    try:
+        enc.train()
+        torch.manual_seed(5)
+        enc._drop_calls = 0
+        with torch.no_grad():
+            hs = [h.clone() for h in enc([w.cuda() for w in wavs], return_hidden_states=True)[2]]
+            hs_again = [h.clone() for h in enc([w.cuda() for w in wavs], return_hidden_states=True)[2]]
+        enc._drop_calls = 0
+        seed_of = enc._dropout_seeds()                     # the site -> seed map of call 1
+        enc._drop_calls = 0
+        with torch.no_grad():
+            hs_same = [h.clone() for h in enc([w.cuda() for w in wavs], return_hidden_states=True)[2]]
+    finally:
+        enc.eval()
+    B, T, D = hs[0].shape
+    H, R = 12, (T + 2 + 127) // 128 * 128
+    a = enc.arch
+    assert (a.dropout, a.attention_dropout, a.dropout_input) == (0.1, 0.1, 0.1)
+    site_of = {"input": lambda i: 0, "encoder": lambda i: 1, "attn": lambda i: 3 * i + 2, "dropout1": lambda i: 3 * i + 3,
+               "dropout3": lambda i: 3 * i + 4}
+    b_, t_, d_ = np.meshgrid(np.arange(B), np.arange(T), np.arange(D), indexing="ij")
+    row_idx = ((b_ * R + t_) * D + d_).astype(np.int64)
+    bb, hh, qq, kk = np.meshgrid(np.arange(B), np.arange(H), np.arange(T), np.arange(T), indexing="ij")
+    att_idx = (((bb * H + hh) * R + qq) * R + kk).astype(np.int64)
+
+    def drop(site, layer, t):
+        seed = seed_of(site_of[site](layer))
+        keep = _keep_mask(att_idx if site == "attn" else row_idx, seed, 0.1)
+        return t * torch.from_numpy(keep).float() / 0.9
+
+    hs_o, _ = oracle.speech_encoder_forward(sd, o_arch, wavs, drop=drop)
+    valid = oracle.fairseq_valid_frames(lens, max(lens), T)
+    zero_frac = float((hs[0][0, : valid[0]] == 0).float().mean())
+    assert 0.08 < zero_frac < 0.12, zero_frac              # F.dropout after the encoder LayerNorm leaves exact zeros in layer_results[0]
+    for n in range(13):
+        e_valid = max(rel_l2(hs[n][b, :v], hs_o[n][b, :v]) for b, v in enumerate(valid))
+        assert e_valid < 2.5e-2, (n, e_valid)
+        assert rel_l2(hs[n], hs_eval[n]) > 0.05, n         # and differs from the eval-mode states
+        assert torch.equal(hs[n], hs_same[n])              # same seed, same call index -> same masks
+        assert not torch.equal(hs[n], hs_again[n])         # next call: new masks
+    with torch.no_grad():                                  # eval mode afterwards: deterministic again
+        hs_e2 = enc([w.cuda() for w in wavs], return_hidden_states=True)[2]
+    assert all(torch.equal(x, y) for x, y in zip(hs_e2, hs_eval))
 
 
 def test_speech_encoder_api_like_the_reference_test():

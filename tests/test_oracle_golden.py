@@ -123,3 +123,39 @@ def test_hubert_vs_hf(golden, name):
         for b, v in enumerate(valid):
             np.testing.assert_allclose(hs_p[i][b, :v].numpy(), fx["hf_hidden_padded"][i][b, :v], rtol=1e-3, atol=5e-5)
     assert feat_len.tolist() == feat_len_rule(lens, Tn)
+
+
+def test_head_train_mode_dropout_sites_vs_torch_layer():
+    """Train mode of the oracle head (drop hook) against torch's own nn.TransformerEncoderLayer - the module the reference
+    instantiates (avssl/module/kw_modules/TransformerModels.py:62-73) - in train mode, with its three nn.Dropout modules
+    replaced by recorded-mask multipliers (the attention-probability site lives inside scaled_dot_product_attention and
+    cannot be intercepted: it is set to p = 0 here and covered by the kernel-level mask tests)."""
+    from torch import nn
+    D, H, Fd, B, S = 32, 4, 48, 3, 9
+    g = torch.Generator().manual_seed(3)
+    layer = nn.TransformerEncoderLayer(D, H, Fd, dropout=0.1, activation="gelu", batch_first=True, norm_first=False)
+    enc = nn.TransformerEncoder(layer, 1, nn.LayerNorm(D), enable_nested_tensor=False).train()
+    masks = {}
+
+    class Rec(nn.Module):
+        def __init__(self, name):
+            super().__init__()
+            self.name = name
+
+        def forward(self, x):
+            m = (torch.rand(x.shape, generator=g) >= 0.3).float() / 0.7
+            masks[self.name] = m
+            return x * m
+
+    L = enc.layers[0]
+    L.self_attn.dropout = 0.0
+    L.dropout1, L.dropout, L.dropout2 = Rec("dropout1"), Rec("dropout"), Rec("dropout2")
+    x = torch.randn(B, S, D, generator=g)
+    lens = torch.tensor([9, 5, 7])
+    kpm = get_keypadding_mask(S, lens)
+    ref = enc(x, src_key_padding_mask=kpm)
+    W = {"enc.model." + k: v.detach() for k, v in enc.state_dict().items()}
+    out = oracle.head_ref.transformer_encoder_forward(
+        W, "enc.", x, kpm, 1, H, drop=lambda site, i, t: t if site == "attn" else t * masks[site])
+    valid = ~kpm
+    np.testing.assert_allclose(out[valid].detach().numpy(), ref[valid].detach().numpy(), rtol=1e-4, atol=2e-5)
