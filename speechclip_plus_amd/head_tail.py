@@ -89,7 +89,13 @@ class ParallelHeadFn(torch.autograd.Function):
         p, m = ops.cls_pool_fwd(src, scores, lens, B, R, D, H, mult)   # m [B, H, D]
         # ---- value projection per head (softmax sums to 1 => + bv), out_proj, post-LN layer on B rows
         cx = torch.empty(B, D, device=dev, dtype=torch.float32)
-        ops.sgemm_ex(m, (H * D, 1, D), Wv, (D, 1, dh * D), cx, D, B, dh, D, nbatch=H, scz=dh, bias=bi[2 * D:], sbiasz=dh)
+        if mult is None:
+            ops.sgemm_ex(m, (H * D, 1, D), Wv, (D, 1, dh * D), cx, D, B, dh, D, nbatch=H, scz=dh, bias=bi[2 * D:], sbiasz=dh)
+            psum = None
+        else:       # dropped attention weights no longer sum to 1: ctx_h = Wv_h m_h + bv_h * sum_s(p mult)
+            ops.sgemm_ex(m, (H * D, 1, D), Wv, (D, 1, dh * D), cx, D, B, dh, D, nbatch=H, scz=dh)
+            psum = (p * mult).sum(-1)                               # [B, H]
+            cx.view(B, H, dh).addcmul_(psum[:, :, None], bi[2 * D:].view(1, H, dh))
         attn = _lin(cx, att.out_proj.weight.detach(), att.out_proj.bias.detach())
         k1, kf, k2 = (mk(B, D), mk(B, layer.linear1.out_features), mk(B, D)) if mk else (None, None, None)
         if mk:
@@ -108,7 +114,7 @@ class ParallelHeadFn(torch.autograd.Function):
         out = _lin(x3, proj.weight.detach(), proj.bias.detach()) if proj is not None else x3
         ctx.mod, ctx.proj, ctx.handle, ctx.dims = module, proj, handle, (B, R, D, H)
         ctx.feat_meta = None if feat is None else (feat.shape, feat.dtype)
-        ctx.masks = (mult, k1, kf, k2)
+        ctx.masks = (mult, k1, kf, k2, psum)
         ctx.save_for_backward(src, lens, x0, q, Qm, a, p, m, cx, xh1, rs1, x1, u, f, xh2, rs2, xh3, rs3, x3)
         return out
 
@@ -117,7 +123,7 @@ class ParallelHeadFn(torch.autograd.Function):
         src, lens, x0, q, Qm, a, p, m, cx, xh1, rs1, x1, u, f, xh2, rs2, xh3, rs3, x3 = ctx.saved_tensors
         module, proj = ctx.mod, ctx.proj
         B, R, D, H = ctx.dims
-        mult, k1, kf, k2 = ctx.masks
+        mult, k1, kf, k2, psum = ctx.masks
         dh = D // H
         dev = src.device
         layer, fin = module.model.layers[0], module.model.norm
@@ -146,13 +152,17 @@ class ParallelHeadFn(torch.autograd.Function):
             dy1 = dy1 * k1
         dcx = _lin_bwd(dy1, cx, att.out_proj.weight.detach(), _gacc(att.out_proj.weight), _gacc(att.out_proj.bias))
         # ---- value projection: bv, Wv_h += dcx_h^T m_h, dm_h = dcx_h Wv_h
-        ops.colsum(dcx, D, B, D, gbi[2 * D:], beta=1.0)
+        if psum is None:
+            ops.colsum(dcx, D, B, D, gbi[2 * D:], beta=1.0)
+        else:
+            gbi[2 * D:].view(H, dh).add_((dcx.view(B, H, dh) * psum[:, :, None]).sum(0))
         ops.sgemm_ex(dcx, (1, D, dh), m, (1, H * D, D), gWi[2 * D:], D, dh, D, B, nbatch=H, scz=dh * D, beta=1.0)
         dm = torch.empty(B, H, D, device=dev, dtype=torch.float32)
         ops.sgemm_ex(dcx, (D, 1, dh), Wv, (1, D, dh * D), dm, H * D, B, D, dh, nbatch=H, scz=D)
         # ---- attention pooling backward (two sweeps over X), gradient of the CLS slot and of a
         dp = ops.cls_scores(src, dm, True, B, R, D, H)
-        if mult is not None:
+        if mult is not None:                                        # + the bias path through sum_s(p mult), then the mask itself
+            dp += (dcx.view(B, H, dh) * att.in_proj_bias.detach()[2 * D:].view(1, H, dh)).sum(-1)[:, :, None]
             dp *= mult
         dX, da_part = ops.cls_pool_bwd(src, p, dp, dm, a, lens, B, R, D, H, mult)
         ops.colsum(dX, R * D, B, D, d_x0, beta=1.0)              # row 0 of every utterance is the CLS token
