@@ -51,9 +51,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("SC_FORCE_COLLECTIVES", "0") == "1":   # the latter: one-rank RCCL rehearsal (parallel.dp_world)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if int(os.environ.get("SC_SHARE_GPU", "0")):               # rehearsal: all ranks on one device
             local_rank = 0
         torch.cuda.set_device(local_rank)

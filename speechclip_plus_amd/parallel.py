@@ -12,10 +12,23 @@ collectives only:
 * ONE all-reduce (SUM - the loss is already the global-batch mean) of the flat gradient buffer
   (speechclip_plus_amd.optim.FlatAdam.flat_g), issued on a side stream so it overlaps the tail of the backward.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def dp_world(group: Optional[dist.ProcessGroup] = None) -> int:
+    """World size as the data-parallel code sees it: 1 without an initialised process group.  With SC_FORCE_COLLECTIVES=1 a
+    one-rank group reports 2 to the callers' "is there anything to exchange" checks, so every collective of the step is
+    issued through the backend (RCCL rehearsal on a one-GPU box; the results are unchanged by one-rank collectives)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    w = dist.get_world_size(group)
+    if w == 1 and os.environ.get("SC_FORCE_COLLECTIVES", "0") == "1":
+        return 2
+    return w
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -43,7 +56,7 @@ def gather_loss_feats(audio_feat, image_feat: torch.Tensor, ids: torch.Tensor,
     all of them travel in the same packed row, still ONE collective."""
     single = isinstance(audio_feat, torch.Tensor)
     feats = [audio_feat] if single else list(audio_feat)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if dp_world(group) == 1:
         return audio_feat, image_feat, ids
     B, E = image_feat.shape
     id_bits = ids.to(torch.int64).contiguous().view(torch.float32).view(B, 2)
@@ -59,11 +72,9 @@ def scale_replicated_grads(params, group: Optional[dist.ProcessGroup] = None) ->
     """Parameters of the loss itself (the trainable temperature) see the WHOLE global-batch loss on every rank, so each rank
     already holds their full gradient: divide by the world size before the SUM all-reduce (every other parameter only
     receives the gradient that flows through this rank's own rows, whose sum over ranks is the global gradient)."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if dp_world(group) == 1:
         return
     world = dist.get_world_size(group)
-    if world == 1:
-        return
     for p in params:
         if p.grad is not None:
             p.grad.mul_(1.0 / world)
@@ -78,7 +89,7 @@ class GradAllReduce:
         self.work = None
 
     def launch(self) -> None:
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if dp_world(self.group) == 1:
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from .optim import FlatAdam, linear_warmup_decay
-from .parallel import GradAllReduce, gather_loss_feats, scale_replicated_grads
+from .parallel import GradAllReduce, dp_world, gather_loss_feats, scale_replicated_grads
 
 
 class ContrastiveTrainer:
@@ -45,7 +45,7 @@ class ContrastiveTrainer:
                 m.register_forward_pre_hook(lambda *_: self.join())
 
     def _world(self) -> int:
-        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        return dp_world(self.group)
 
     def _layer_ready(self, i: int) -> None:
         if self._world() == 1:

@@ -54,10 +54,15 @@ def _batch(lo, hi):
     return {"wav": wav[lo:hi].cuda(), "wav_len": lens[lo:hi], "image": img[lo:hi].cuda(), "id": ids[lo:hi].cuda()}
 
 
-def _worker(rank, world, port, unfreeze, q):
+def _worker(rank, world, port, unfreeze, q, backend="gloo"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                                        # RCCL rehearsal: one rank, every collective forced through the backend
+        os.environ["SC_FORCE_COLLECTIVES"] = "1"
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     model, trainer = _make(unfreeze)
     n = 8 // world
     batch = _batch(rank * n, (rank + 1) * n)
@@ -92,6 +97,29 @@ def test_two_ranks_equal_one_process(unfreeze):
     moved = float((flat1 - _initial_flat(unfreeze)).norm() / flat1.norm())
     print("two ranks vs one process: |dp - single| / |single| = %.3g, parameter movement %.3g" % (rel, moved))
     assert rel < 0.05 * moved + 1e-7, (rel, moved)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("unfreeze", [False, True])
+def test_rccl_backend_one_rank_rehearsal(unfreeze):
+    """The collectives of the step through the backend the multi-GPU runs use ("nccl" = RCCL), as far as a one-GPU box allows:
+    a one-rank RCCL group with SC_FORCE_COLLECTIVES=1 issues the packed all-gather (with autograd), the side-stream flat
+    all-reduce and the per-layer slice all-reduces; one-rank collectives are identities, so the result must equal the plain
+    single-process run bit for bit in the loss and closely in the parameters."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_worker, args=(0, 1, _free_port(), unfreeze, q, "nccl"))
+    proc.start()
+    losses_r, flat_r = q.get(timeout=240)
+    proc.join(timeout=60)
+    assert proc.exitcode == 0
+    model, trainer = _make(unfreeze)
+    batch = _batch(0, 8)
+    losses1 = [float(trainer.step(batch)) for _ in range(2)]
+    torch.cuda.synchronize()
+    flat1 = trainer.opt.flat_p.detach().cpu()
+    assert abs(losses1[0] - losses_r[0]) < 1e-5 and abs(losses1[1] - losses_r[1]) < 1e-3, (losses1, losses_r)
+    assert float((flat1 - torch.from_numpy(flat_r)).norm() / flat1.norm()) < 1e-5
 
 
 def _initial_flat(unfreeze):
