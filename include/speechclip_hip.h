@@ -67,6 +67,12 @@ typedef struct {
                                      -3.5 % GEMM time per step), 1 always non-temporal, 2 never */
     float drop_p;                 /* 0 = no dropout */
     uint32_t drop_seed;
+    int32_t tap_c;                /* K-tile visiting-order hint for conv-shaped A (rows overlap: lda = 2*tap_c, K = 3*tap_c, i.e. a
+                                     channels-last Conv1d with k = 3, stride 2): 0 = ascending k; tap_c = C_in visits, per 64-channel
+                                     block, tap 0, tap 2, tap 1 - tap 2 of output row r is tap 0 of row r + 1, so its tile is
+                                     re-read while still in the L2 instead of 16 K-tiles later from the fabric. Only the
+                                     fp32 summation order over k changes. Kernels without the reordering ignore it. */
+    int32_t pad_;
 } sc_gemm_args;
 int sc_gemm_bf16(const sc_gemm_args* args, void* stream);
 uint32_t sc_hash32(uint32_t x);   /* host twin of the kernels' dropout hash (lowbias32): reconstructs a mask exactly */

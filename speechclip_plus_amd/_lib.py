@@ -29,6 +29,7 @@ class GemmArgs(ctypes.Structure):
         ("sBias1", c_i64), ("sBias2", c_i64), ("sR1", c_i64), ("sR2", c_i64),
         ("tile", c_int), ("reserved", c_int),
         ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32),
+        ("tap_c", c_int), ("pad_", c_int),
     ]
 
 

@@ -134,6 +134,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     const int a_base = wm * HALF_BYTES;                                             // wave's A half
     const int b_base = 2 * HALF_BYTES + wn * TN * ROWB;                             // wave's TN rows of the B region
     const int nk = p.K / BK;
+    // K-tile kt -> first k of the tile.  Conv-shaped A (tap_c = C_in, K = 3 C_in, lda = 2 C_in): per 64-channel block visit tap 0,
+    // tap 2, tap 1 - tap 2 of row r is tap 0 of row r + 1, so that tile is fetched again while the L2 still holds it.
+    const int tap_c = p.tap_c;
+    auto koff = [&](int kt) -> int {
+        if (tap_c == 0) return kt * BK;
+        const int c = kt / 3, j = kt - 3 * c;
+        return (j == 0 ? 0 : (3 - j) * tap_c) + c * BK;
+    };
     const uint32_t drop_thr = p.drop_p > 0.f ? (uint32_t)(p.drop_p * 65536.f + 0.5f) : 0u;
     const float drop_scale = 1.f / (1.f - p.drop_p);
 
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
 
         // ---- prologue: A(0), B(0) are in flight (issued before the previous epilogue); B(1) goes to the other buffer ----
         if (nk > 1) {
-            dma_B(base ^ 1, BK);
+            dma_B(base ^ 1, koff(1));
             SC_WAIT_NBI();
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                 b1[ni][0] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off0);
                 b1[ni][1] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off1);
             }
-            if (kt + 1 < nk) dma_A(par ^ 1, (kt + 1) * BK);
+            if (kt + 1 < nk) dma_A(par ^ 1, koff(kt + 1));
             SC_BAR();
             SC_MFMA_QUAD(0, 1, b1);
             SC_BAR();
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             SC_BAR();
             // ---------------- P3
             if (kt + 2 < nk) {
-                dma_B(par, (kt + 2) * BK);
+                dma_B(par, koff(kt + 2));
                 SC_WAIT_NBI();
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -431,6 +439,10 @@ static double tile_cost(const sc_gemm_args& a, int BN) {
 int sc_gemm256_launch(const sc_gemm_args& a_in, hipStream_t s) {
     sc_gemm_args a = a_in;
     a.reserved = a_in.reserved == 1 || (a_in.reserved == 0 && a_in.residual != nullptr);   // bit 0: non-temporal C stores
+    if (a.tap_c != 0 && !(a.tap_c > 0 && a.tap_c % 64 == 0 && a.K == 3 * a.tap_c)) {
+        sc_set_error("sc_gemm_bf16: tap_c=%d needs tap_c %% 64 == 0 and K == 3 * tap_c (K=%d)", a.tap_c, a.K);
+        return -1;
+    }
     if (a.tile == 32) return launch256<3, 256>(a, s);   // diagnostics only (tools/epi_probe.py, tools/epi_stamps.py)
     if (a.tile == 34) return launch256<4, 256>(a, s);
     if (a.tile == 7) return launch256<0, 192>(a, s);

@@ -72,7 +72,7 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
              bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ldr: int = 0, act: int = 0,
              out_f32: bool = False, Ct: Optional[torch.Tensor] = None, n_split: int = -1, R: int = 0, dh: int = 0,
              nb1: int = 1, nb2: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sBias=(0, 0), sR=(0, 0),
-             alg_rows: Optional[int] = None, tile: int = 0, drop_p: float = 0.0, drop_seed: int = 0) -> None:
+             alg_rows: Optional[int] = None, tile: int = 0, drop_p: float = 0.0, drop_seed: int = 0, tap_c: int = 0) -> None:
     """C = epi(A . W^T); see sc_gemm_args in include/speechclip_hip.h.  Pointers are the tensors' data_ptr()
     (pass a sliced view to offset).  ``alg_rows``: rows that are algorithmic work (excludes layout padding),
     used only by the optional KernelTimer."""
@@ -96,6 +96,7 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     a.sR1, a.sR2 = sR
     a.tile = tile
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed) & 0xffffffff
+    a.tap_c = int(tap_c)
     if _timer is None:
         check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
         return

@@ -396,7 +396,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             k, s = a.conv_kernels[i], a.conv_strides[i]
             rows = B * pl.R_l[i]
             ops.gemm_raw(pl.conv[i - 1], s * C, w[f"conv{i}_w"], k * C, pl.conv[i], C, rows, C, k * C,
-                         bias=w[f"conv{i}_bias"], act=0 if ln_mode else 1, alg_rows=B * pl.T_l[i])
+                         bias=w[f"conv{i}_bias"], act=0 if ln_mode else 1, alg_rows=B * pl.T_l[i],
+                         tap_c=C if (k == 3 and s == 2) else 0)      # shared-tap K order: see sc_gemm_args.tap_c
             if ln_mode:
                 ops.layernorm_bf16(pl.conv[i][:rows], w[f"conv{i}_ln_g"], w[f"conv{i}_ln_b"], out=pl.conv[i][:rows], act=1)
         # a3: LayerNorm(512) -> post_extract_proj                                       (:78, :84-85)

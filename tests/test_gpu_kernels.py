@@ -123,6 +123,21 @@ def test_gemm_strided_rows_conv(dev):
     ops.gemm_raw(x, 2 * C, wk, 3 * C, out, C, Tout, C, 3 * C, act=1)
     ref = F.gelu(F.conv1d(x[:Tin].float().T.unsqueeze(0), w.float(), stride=2))[0].T
     assert rel_l2(out, ref) < 6e-3
+    # shared-tap K order (sc_gemm_args.tap_c: per channel block tap 0, tap 2, tap 1) on both 256-row tile widths, more rows than
+    # one tile: only the fp32 summation order over k changes
+    Tin2 = 2 * 1500 + 1
+    x2 = bf(torch.randn(Tin2 + 8, C, generator=g)).to(dev)
+    Tout2 = (Tin2 - 3) // 2 + 1
+    ref2 = F.gelu(F.conv1d(x2[:Tin2].float().T.unsqueeze(0), w.float(), stride=2))[0].T
+    for tile in (7, 8):
+        o0 = torch.zeros(Tout2, C, device=dev, dtype=torch.bfloat16)
+        o1 = torch.zeros(Tout2, C, device=dev, dtype=torch.bfloat16)
+        ops.gemm_raw(x2, 2 * C, wk, 3 * C, o0, C, Tout2, C, 3 * C, act=1, tile=tile)
+        ops.gemm_raw(x2, 2 * C, wk, 3 * C, o1, C, Tout2, C, 3 * C, act=1, tile=tile, tap_c=C)
+        assert rel_l2(o1, ref2) < 6e-3 and rel_l2(o0, ref2) < 6e-3
+        assert rel_l2(o1, o0) < 3e-3 and not torch.equal(o1, torch.zeros_like(o1))
+    with pytest.raises(RuntimeError, match="tap_c"):
+        ops.gemm_raw(x2, 2 * C, wk, 3 * C, o1, C, Tout2, C, 2 * C, tile=8, tap_c=C)
 
 
 def test_gemm_transposed_store_and_batch(dev):

@@ -23,8 +23,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/speechclip_hip.h but not exported"
     assert set(_lib.SIGNATURES) | {"sc_last_error", "sc_hash32"} == declared
     assert lib.sc_abi_version() == 1
-    # the ctypes mirror of sc_gemm_args must have the C struct's size (8-byte fields, natural alignment; + drop_p, drop_seed)
-    assert ctypes.sizeof(_lib.GemmArgs) == 6 * 8 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 6 * 4 + 10 * 8 + 8 + 8
+    # the ctypes mirror of sc_gemm_args must have the C struct's size (8-byte fields, natural alignment; + drop_p, drop_seed; + tap_c, pad)
+    assert ctypes.sizeof(_lib.GemmArgs) == 6 * 8 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 6 * 4 + 10 * 8 + 8 + 8 + 8
     # host twin of the kernels' dropout hash (lowbias32): known answers
     assert lib.sc_hash32(0) == 0 and lib.sc_hash32(1) == 0x688990C0
     ref = lambda x: ((((x ^ (x >> 16)) * 0x7feb352d & 0xffffffff) ^ ((((x ^ (x >> 16)) * 0x7feb352d & 0xffffffff)) >> 15)) * 0x846ca68b) & 0xffffffff
