@@ -213,14 +213,22 @@ def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional
     K = x.shape[1]
     assert x.shape[0] == rows and rows % 64 == 0 and gW.dtype == torch.float32 and gW.is_contiguous() and tuple(gW.shape) == (N, K)
     pb = torch.empty((rows + 63) // 64, N, device=dy.device, dtype=torch.float32) if gb is not None else None
-    dyT, xT = transpose_bf16(dy, colsum_partial=pb), transpose_bf16(x)
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     S = max(1, min(256 // max(tiles, 1), rows // 512))
-    while rows % (64 * S):
-        S -= 1
-    Kc = rows // S
+    # the slices must be equal and multiples of 64 rows: the transposed operands are laid out with the row count padded up to
+    # 64 * S and the pad columns zeroed (rows = B * 499 has no useful divisor; one un-split GEMM over 32k rows would leave most
+    # of the chip idle)
+    rows_pad = -(-rows // (64 * S)) * (64 * S)
+    dyT = torch.empty(N, rows_pad, device=dy.device, dtype=torch.bfloat16)
+    xT = torch.empty(K, rows_pad, device=dy.device, dtype=torch.bfloat16)
+    if rows_pad != rows:
+        dyT[:, rows:].zero_()
+        xT[:, rows:].zero_()
+    transpose_bf16(dy, out=dyT, colsum_partial=pb)
+    transpose_bf16(x, out=xT)
+    Kc = rows_pad // S
     part = torch.empty(S, N, K, device=dy.device, dtype=torch.float32)
-    gemm_raw(dyT, rows, xT, rows, part, K, N, K, Kc, out_f32=True, nb1=S, sA=(Kc, 0), sW=(Kc, 0), sC=(N * K, 0))
+    gemm_raw(dyT, rows_pad, xT, rows_pad, part, K, N, K, Kc, out_f32=True, nb1=S, sA=(Kc, 0), sW=(Kc, 0), sC=(N * K, 0))
     colsum(part, N * K, S, N * K, gW, beta=beta)
     if gb is not None:                      # second stage of the bias gradient (first stage: the transpose of dy above)
         colsum(pb, N, pb.shape[0], N, gb, beta=beta)

@@ -88,22 +88,28 @@ class MultiheadAttentionAndNorm(nn.Module):
         self.attentionBlock_Norm = nn.LayerNorm(d_model, eps=layer_norm_eps)
 
     def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
-        """LN(MHA(x, x, x) + x) (TransformerModels.py:120-126).  On a GPU the two projections (B x S rows, the block's FLOPs)
-        run on the library's bf16 GEMM with their dgrad / weight-gradient products (linear_fn.LinearBf16Fn); the S x S attention
-        of the branch's head_dim (768 / 96 / 128: the attention kernels are head_dim 64) and the LayerNorm stay stock fp32 ops.
-        Train mode applies nn.MultiheadAttention's dropout to the attention probabilities."""
+        """LN(MHA(x, x, x) + x) (TransformerModels.py:120-126).  On a GPU the whole block - projections, S x S core as batched bf16
+        GEMMs (any head_dim that is a multiple of 64: 768 / 128 in the shipped recipes), residual, LayerNorm, and their backward -
+        runs on the library's kernels (mha_block.MhaNormFn).  Train mode applies nn.MultiheadAttention's dropout to the attention
+        probabilities."""
         src = src.float()
         mha = self.multihead_attn_layer
         if not src.is_cuda:
             return self.attentionBlock_Norm(mha(src, src, src, key_padding_mask=key_padding_mask)[0] + src)
+        D, H = src.shape[-1], mha.num_heads
+        if D % 64 == 0 and D % H == 0 and (D // H) % 64 == 0:
+            from .mha_block import mha_norm                  # whole block (projections, S x S core, residual, LayerNorm) on own kernels
+            return mha_norm(src, mha, self.attentionBlock_Norm, key_padding_mask, self.training)
+        return self._forward_stock_core(src, key_padding_mask)
+
+    def _forward_stock_core(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
+        """head_dim not a multiple of 64: projections on the library's GEMM, fp32 torch bmm core."""
+        mha = self.multihead_attn_layer
         from .linear_fn import linear_bf16_autograd
         B, S, D = src.shape
         H = mha.num_heads
         dh = D // H
         qkv = linear_bf16_autograd(src, mha.in_proj_weight, mha.in_proj_bias)                  # (B, S, 3D)
-        # S x S core in fp32 on CONTIGUOUS (B H, S, dh) operands, as nn.MultiheadAttention lays them out.  (A bf16 torch.matmul
-        # on the strided q / k views of the fused projection faults inside the stock batched-GEMM kernel at B = 64, S = 499,
-        # dh = 768 - "Memory access fault by GPU" in torch's own op, reproduced in isolation - so that form is not used.)
         q, k, v = (t.reshape(B, S, H, dh).transpose(1, 2).reshape(B * H, S, dh).contiguous() for t in qkv.split(D, dim=-1))
         scores = torch.bmm(q, k.transpose(1, 2)).view(B, H, S, S) * dh ** -0.5
         scores = scores.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))

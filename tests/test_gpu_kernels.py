@@ -626,6 +626,13 @@ def test_transpose_and_weight_gradient(dev):
     gW2 = torch.full_like(gW0, 3.0)
     ops.wgrad_bf16(dy, x, gW2, beta=0.0)
     assert rel_l2(gW2, dy.float().t() @ x.float()) < 1e-3
+    # a row count without a useful divisor (B x 499 frames): the split slices are padded, the pad must contribute nothing
+    rows3 = 64 * 37
+    dy3, x3 = bf(torch.randn(rows3, 2304, generator=g)).to(dev), bf(torch.randn(rows3, 768, generator=g)).to(dev)
+    gW3, gb3 = torch.zeros(2304, 768, device=dev), torch.zeros(2304, device=dev)
+    torch.empty(64 << 20, device=dev).fill_(float("nan"))               # poison the allocator's free blocks
+    ops.wgrad_bf16(dy3, x3, gW3, gb3, beta=0.0)
+    assert rel_l2(gW3, dy3.float().t() @ x3.float()) < 1e-3 and rel_l2(gb3, dy3.float().sum(0)) < 1e-4
 
 
 def test_gemm_random_shape_fuzz(dev):
@@ -770,3 +777,57 @@ def test_dropout_masks_gemm_rows_attention(dev):
     ref = ((P * keep / (1 - p)) @ vf).transpose(1, 2).reshape(B * R, D)
     rows_ok = key_ok.reshape(B * R)
     assert rel_l2(out[rows_ok], ref[rows_ok]) < 1.2e-2
+
+
+@pytest.mark.parametrize("D,H,S,p_drop", [(768, 1, 37, 0.0), (256, 2, 150, 0.0), (256, 2, 70, 0.25)])
+def test_mha_norm_block_vs_torch(dev, D, H, S, p_drop):
+    """mha_block.MhaNormFn (attention block of the cascaded+/hybrid+ branches on own kernels, head_dim 768 / 128) against
+    nn.MultiheadAttention + residual + LayerNorm in fp32: output, input gradient and every parameter gradient; with dropout the
+    reference is the manual fp32 composition fed the same keep mask (drawn from torch's device generator: re-seeding
+    reproduces it)."""
+    from speechclip_plus_amd.mha_block import mha_norm
+    B = 3
+    torch.manual_seed(21)
+    mha = torch.nn.MultiheadAttention(D, H, dropout=p_drop, batch_first=True).to(dev)
+    norm = torch.nn.LayerNorm(D).to(dev)
+    with torch.no_grad():
+        mha.in_proj_bias.normal_(0, 0.1)
+        mha.out_proj.bias.normal_(0, 0.1)
+        norm.weight.normal_(1, 0.1)
+        norm.bias.normal_(0, 0.1)
+    g = torch.Generator(device="cpu").manual_seed(8)
+    x0 = bf(torch.randn(B, S, D, generator=g)).float().to(dev)
+    lens = torch.tensor([S, S - 11, 5], device=dev)
+    kpm = torch.arange(S, device=dev)[None, :] >= lens[:, None]
+    gout = torch.randn(B, S, D, generator=g).to(dev)
+    gout[kpm] = 0                                                      # padded frames are never read downstream
+    x = x0.clone().requires_grad_()
+    torch.manual_seed(99)
+    out = mha_norm(x, mha, norm, kpm, training=p_drop > 0)
+    (out * gout).sum().backward()
+    got = {"x": x.grad.clone(), **{n: p.grad.clone() for n, p in list(mha.named_parameters()) + [("ln." + n, p) for n, p in norm.named_parameters()]}}
+    for p in list(mha.parameters()) + list(norm.parameters()):
+        p.grad = None
+    # fp32 reference (manual composition so that the dropout mask can be injected)
+    xr = x0.clone().requires_grad_()
+    dh, Sp = D // H, (S + 63) // 64 * 64
+    qkv = F.linear(xr, mha.in_proj_weight, mha.in_proj_bias)
+    q, k, v = (t.view(B, S, H, dh).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    sc = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    P = torch.softmax(sc.masked_fill(kpm[:, None, None, :], float("-inf")), dim=-1)
+    if p_drop > 0:
+        torch.manual_seed(99)
+        keep = (torch.rand(B, H, Sp, Sp, device=dev) >= p_drop)[:, :, :S, :S]
+        P = P * keep / (1 - p_drop)
+    cx = (P @ v).transpose(1, 2).reshape(B, S, D)
+    ref = norm(F.linear(cx, mha.out_proj.weight, mha.out_proj.bias) + xr)
+    (ref * gout).sum().backward()
+    valid = ~kpm
+    assert rel_l2(out[valid], ref[valid]) < 1e-2
+    assert rel_l2(got["x"][valid], xr.grad[valid]) < 3e-2
+    for n, p in list(mha.named_parameters()) + [("ln." + n, p) for n, p in norm.named_parameters()]:
+        assert rel_l2(got[n], p.grad) < 3e-2, (n, rel_l2(got[n], p.grad))
+    if p_drop == 0:                                                    # and against the stock module itself
+        with torch.no_grad():
+            stock = norm(mha(x0, x0, x0, key_padding_mask=kpm)[0] + x0)
+        assert rel_l2(out[valid], stock[valid]) < 1e-2
