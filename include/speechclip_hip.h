@@ -187,6 +187,20 @@ int sc_cls_pool_bwd(const sc_bf16* X, const float* p, const float* dp, const flo
                     const float* mult, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Row softmax of the GEMM-based attention core (attention block of the cascaded+/hybrid+ branches,
+ * avssl/module/kw_modules/TransformerModels.py:101-126 -> nn.MultiheadAttention with head_dim 768 / 128):
+ *   forward   P = softmax(scale * scores | key mask)   scores fp32 [rows, n] contiguous (a batched sc_gemm_bf16 output), P bf16;
+ *             Pd = keep . P / (1 - p) (train mode, drop_p > 0: the hash mask of sc_gemm_args over element row * n + col)
+ *             key_mask uint8 [rows / rows_per_batch, n], non-zero = padded key (probability exactly 0)
+ *   backward  dS = scale * P (dP' - sum_k P dP'),  dP' = keep . dP / (1 - p)         dP fp32, dS bf16
+ *   n % 4 == 0, n <= 1024.
+ * ---------------------------------------------------------------------------------------------- */
+int sc_softmax_fwd(const float* scores, const uint8_t* key_mask, sc_bf16* P, sc_bf16* Pd, int64_t rows, int32_t n,
+                   int32_t rows_per_batch, float scale, float drop_p, uint32_t drop_seed, void* stream);
+int sc_softmax_bwd(const float* dP, const sc_bf16* P, sc_bf16* dS, int64_t rows, int32_t n, float scale, float drop_p,
+                   uint32_t drop_seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * fp32 strided GEMM  C[i,j] = alpha * sum_k A[i*sai + k*sak] * Bm[j*sbj + k*sbk]  (+ bias[j])
  *   small fp32 products of the loss and of the CLS-row tail (logits = A.B^T / tau, dA = G.B, ...)
  * ---------------------------------------------------------------------------------------------- */

@@ -245,6 +245,32 @@ def dropout_bf16(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tenso
     return out
 
 
+def softmax_fwd(scores: torch.Tensor, key_mask: torch.Tensor, rows_per_batch: int, scale: float, drop_p: float = 0.0,
+                drop_seed: int = 0):
+    """P = softmax(scale * scores | key mask) as bf16 (+ the dropped copy in train mode); scores fp32 [..., n] contiguous,
+    key_mask uint8 / bool [batches, n] (non-zero = padded key).  Returns (P, Pd) with Pd = P when drop_p == 0."""
+    n = scores.shape[-1]
+    rows = scores.numel() // n
+    assert scores.dtype == torch.float32 and scores.is_contiguous() and key_mask.is_contiguous() and key_mask.element_size() == 1
+    assert key_mask.shape[-1] == n and rows == key_mask.numel() // n * rows_per_batch
+    P = torch.empty(scores.shape, device=scores.device, dtype=torch.bfloat16)
+    Pd = torch.empty_like(P) if drop_p > 0.0 else None
+    check(lib().sc_softmax_fwd(_p(scores), _p(key_mask), _p(P), _p(Pd), rows, n, rows_per_batch, float(scale), float(drop_p),
+                               int(drop_seed) & 0xffffffff, _stream()), "sc_softmax_fwd")
+    return P, (Pd if Pd is not None else P)
+
+
+def softmax_bwd(dP: torch.Tensor, P: torch.Tensor, scale: float, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
+    """dS = scale * P (dP' - rowsum(P dP')) as bf16, dP' = the dropout backward of dP (same mask as softmax_fwd)."""
+    n = dP.shape[-1]
+    rows = dP.numel() // n
+    assert dP.dtype == torch.float32 and P.dtype == torch.bfloat16 and dP.is_contiguous() and P.is_contiguous() and P.shape == dP.shape
+    dS = torch.empty_like(P)
+    check(lib().sc_softmax_bwd(_p(dP), _p(P), _p(dS), rows, n, float(scale), float(drop_p), int(drop_seed) & 0xffffffff, _stream()),
+          "sc_softmax_bwd")
+    return dS
+
+
 def act_bf16(u: torch.Tensor, act: int, df: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act 1 = erf-GELU, 2 = QuickGELU; with ``df``: df * act'(u)."""
     assert u.dtype == torch.bfloat16 and u.is_contiguous() and (df is None or (df.dtype == torch.bfloat16 and df.is_contiguous()))
