@@ -201,6 +201,19 @@ int sc_softmax_bwd(const float* dP, const sc_bf16* P, sc_bf16* dS, int64_t rows,
                    uint32_t drop_seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Continuous integrate-and-fire accumulation (avssl/module/cif.py:157-240; the downsampler of the cascaded+/hybrid+ branches).
+ *   x [B,S,C] fp32, alpha [B,S] fp32 (weights, 0 on padded frames), csum = cumsum(alpha) [B,S] (computed by the caller so
+ *   that the slot boundaries floor(csum / thr) are the host framework's), out [B,T+1,C] fp32 (slot T collects the tail;
+ *   every slot is written).  Frame s adds lw_s x_s to slot left_s, thr x_s to the slots in between, rw_s x_s to slot right_s.
+ *   backward: g [B,T+1,C] -> dx [B,S,C], pa / pb [ceil(C/256), B, S]: per-channel-block partials of
+ *   d alpha_s (direct) = x_s . g[left_s]  and  d csum_s = fire_s ? x_s . (g[right_s] - g[left_s]) : 0.        C % 4 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int sc_cif_fwd(const float* x, const float* alpha, const float* csum, float* out, int32_t B, int32_t S, int32_t C, int32_t T,
+               float thr, void* stream);
+int sc_cif_bwd(const float* x, const float* alpha, const float* csum, const float* g, float* dx, float* pa, float* pb, int32_t B,
+               int32_t S, int32_t C, int32_t T, float thr, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * fp32 strided GEMM  C[i,j] = alpha * sum_k A[i*sai + k*sak] * Bm[j*sbj + k*sbk]  (+ bias[j])
  *   small fp32 products of the loss and of the CLS-row tail (logits = A.B^T / tau, dA = G.B, ...)
  * ---------------------------------------------------------------------------------------------- */

@@ -54,6 +54,8 @@ SIGNATURES = {
     "sc_wsum_fwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "sc_wsum_bwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "sc_cls_scores": [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_cif_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p],
+    "sc_cif_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p],
     "sc_softmax_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint32, c_void_p],
     "sc_softmax_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint32, c_void_p],
     "sc_cls_pool_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],

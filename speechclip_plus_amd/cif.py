@@ -1,7 +1,8 @@
 """Continuous integrate-and-fire downsampler: mirror of avssl/module/cif.py:24-311 (cascaded+/hybrid+ branches).
 
-Scope row a11, "stock ops first": the arithmetic here is plain device-side torch (cumsum, floor, scatter_add_);
-a segmented-scan HIP kernel is scope row f3.  Same constructor keywords, sub-module names (``conv.0``,
+On a GPU the accumulation itself runs on the library's kernels (csrc/cif.hip through ``CifFireFn``: one deterministic pass over
+the frames instead of the reference's atomically-accumulating scatter_add_ calls, forward and backward); the slot boundaries come
+from torch.cumsum either way, and the tiny (B, S) / (B, T) bookkeeping around it stays device-side torch.  Same constructor keywords, sub-module names (``conv.0``,
 ``weight_proj.1``) and result-dict keys as the reference, including its quirks that change numbers:
 ``nn.Dropout()`` (p = 0.5) in the weight generator, ``MAX_FEAT_LEN = 75``, alpha clipped to [0, 1], the
 quantity output taken BEFORE scaling, train-time tail drop vs inference-time tail firing.
@@ -20,6 +21,27 @@ MAX_FEAT_LEN = 75   # cif.py:11
 def _length_mask(max_length: int, lens: torch.Tensor) -> torch.Tensor:
     """True = padding (cif.py:14-21), built on the lengths' device."""
     return torch.arange(max_length, device=lens.device).unsqueeze(0) >= lens.unsqueeze(1)
+
+
+class CifFireFn(torch.autograd.Function):
+    """out[B, T + 1, C] = integrate-and-fire accumulation of x under (alpha, csum); the slot indices are constants of the graph
+    (computed under no_grad in the reference too), gradients flow to x, alpha and csum."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, csum, T, thr):
+        from . import ops
+        xf, af, cf = x.detach().float().contiguous(), alpha.detach().float().contiguous(), csum.detach().float().contiguous()
+        ctx.save_for_backward(xf, af, cf)
+        ctx.meta = (int(T), float(thr), x.dtype, alpha.dtype)
+        return ops.cif_fwd(xf, af, cf, int(T), float(thr)).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        xf, af, cf = ctx.saved_tensors
+        T, thr, xdt, adt = ctx.meta
+        dx, da, dc = ops.cif_bwd(xf, af, cf, g.float().contiguous(), T, thr)
+        return dx.to(xdt), da.to(adt), dc.to(adt), None, None
 
 
 class CIF(nn.Module):
@@ -111,21 +133,24 @@ class CIF(nn.Module):
             left_idx[:, 0] = 0
             fire_num = right_idx - left_idx
             extra = (fire_num - 1).clip(min=0)
-        output = input.new_zeros((B, T + 1, C))                # slot T collects the tail
         fire_mask = fire_num > 0
         zero = alpha.new_zeros((1,))
         right_w = torch.where(fire_mask, csum - right_idx.type_as(alpha) * thr, zero).type_as(input)
-        output.scatter_add_(1, right_idx.unsqueeze(-1).expand(-1, -1, C), right_w.unsqueeze(-1) * input)
         left_w = (alpha - right_w - extra.type_as(alpha) * thr).type_as(input)
-        output.scatter_add_(1, left_idx.unsqueeze(-1).expand(-1, -1, C), left_w.unsqueeze(-1) * input)
-        if extra.ge(0).any():
-            steps = int(extra.max())
-            tgt = left_idx
-            whole = input * thr
-            for _ in range(steps):
-                tgt = (tgt + 1).clip(max=T)
-                output.scatter_add_(1, tgt.unsqueeze(-1).expand(-1, -1, C), whole * (extra > 0).unsqueeze(2))
-                extra = extra - 1
+        if input.is_cuda and C % 4 == 0 and S <= 2048:
+            output = CifFireFn.apply(input, alpha, csum, T, thr)   # slot T collects the tail
+        else:
+            output = input.new_zeros((B, T + 1, C))
+            output.scatter_add_(1, right_idx.unsqueeze(-1).expand(-1, -1, C), right_w.unsqueeze(-1) * input)
+            output.scatter_add_(1, left_idx.unsqueeze(-1).expand(-1, -1, C), left_w.unsqueeze(-1) * input)
+            if extra.ge(0).any():
+                steps = int(extra.max())
+                tgt = left_idx
+                whole = input * thr
+                for _ in range(steps):
+                    tgt = (tgt + 1).clip(max=T)
+                    output.scatter_add_(1, tgt.unsqueeze(-1).expand(-1, -1, C), whole * (extra > 0).unsqueeze(2))
+                    extra = extra - 1
         if self.apply_tail_handling:
             if target_lengths is not None:
                 output = output[:, :T, :]                      # training: the tail is dropped

@@ -1,0 +1,183 @@
+// Continuous integrate-and-fire accumulation (avssl/module/cif.py:157-240, the scatter_add_ form of the reference's frame loop;
+// cascaded+/hybrid+ branches), forward and backward.
+//
+// Per utterance, frame s with weight alpha_s and cumulative weight c_s = sum_{j<=s} alpha_j (given: torch.cumsum, so the slot
+// boundaries are exactly the host framework's):
+//     right_s = clip(floor(c_s / thr), 0, T) ;  left_s = right_{s-1} (0 for s = 0) ;  fire_s = right_s - left_s
+//     rw_s = fire_s > 0 ? c_s - right_s thr : 0 ;  extra_s = max(fire_s - 1, 0) ;  lw_s = alpha_s - rw_s - extra_s thr
+//     out[left_s] += lw_s x_s ;  out[left_s + j] += thr x_s  (j = 1 .. extra_s) ;  out[right_s] += rw_s x_s          (T + 1 slots)
+// Slots are visited in non-decreasing order, so a thread that owns 4 channels walks the frames once with a running accumulator
+// and writes every slot exactly once, in frame order: deterministic (the reference's scatter_add_ uses float atomics) and one
+// pass over x.  Backward (indices are constants of the graph, as in the reference's no_grad block):
+//     dx_s = lw_s g[left_s] + rw_s g[right_s] + thr sum_j g[left_s + j]
+//     d alpha_s (direct) = x_s . g[left_s]            d c_s = fire_s > 0 ? x_s . (g[right_s] - g[left_s]) : 0
+// (the cumsum's own backward turns d c into the remaining part of d alpha); the two dot products are reduced over the wave and
+// written per channel block: pa / pb [nblk, B, S].
+// HBM-bound: x once forward; x once + dx once backward.  One wave per (utterance, 256-channel block).
+#include "sc_common.h"
+
+namespace {
+
+struct frame_meta {
+    int left, right;
+    float lw, rw;
+};
+constexpr int MAXS = 2048;      // frames per utterance held in LDS (32 KiB)
+
+// every lane derives the metadata of frames lane, lane + 64, ... (each needs only c_s and c_{s-1}); the frame loop then reads
+// one LDS word group per frame instead of two dependent global loads
+__device__ __forceinline__ void stage_meta(frame_meta* sm, const float* __restrict__ alpha, const float* __restrict__ csum, int S,
+                                           float thr, int T) {
+    for (int s = threadIdx.x; s < S; s += 64) {
+        const float c = csum[s];
+        frame_meta m;
+        m.right = min(max((int)floorf(c / thr), 0), T);
+        m.left = s > 0 ? min(max((int)floorf(csum[s - 1] / thr), 0), T) : 0;
+        const int fire = m.right - m.left;
+        m.rw = fire > 0 ? c - (float)m.right * thr : 0.f;
+        m.lw = alpha[s] - m.rw - (float)max(fire - 1, 0) * thr;
+        sm[s] = m;
+    }
+    __syncthreads();
+}
+
+constexpr int UNROLL = 8;
+
+__device__ __forceinline__ void load_batch(float4 (&xv)[UNROLL], const float* __restrict__ xb, int s0, int S, int C, bool active) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+        xv[u] = (active && s0 + u < S) ? *(const float4*)(xb + (int64_t)(s0 + u) * C) : float4{0.f, 0.f, 0.f, 0.f};
+}
+
+// frames are consumed in batches of UNROLL rows; the next batch's loads are issued before the current one is processed
+__global__ __launch_bounds__(64) void cif_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                     const float* __restrict__ csum, float* __restrict__ out, int S, int C, int T,
+                                                     float thr) {
+    const int b = blockIdx.y, c0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const bool active = c0 < C;
+    const float* xb = x + (int64_t)b * S * C + (active ? c0 : 0);
+    float* ob = out + (int64_t)b * (T + 1) * C + (active ? c0 : 0);
+    __shared__ frame_meta sm[MAXS];
+    float4 xv[UNROLL], xn[UNROLL];
+    load_batch(xv, xb, 0, S, C, active);
+    stage_meta(sm, alpha + (int64_t)b * S, csum + (int64_t)b * S, S, thr, T);
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    for (int s0 = 0; s0 < S; s0 += UNROLL) {
+        load_batch(xn, xb, s0 + UNROLL, S, C, active);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (s0 + u < S) {
+                const frame_meta m = sm[s0 + u];
+                const int extra = m.right - m.left - 1;
+                const float4 v = xv[u];
+                acc.x = fmaf(m.lw, v.x, acc.x); acc.y = fmaf(m.lw, v.y, acc.y);
+                acc.z = fmaf(m.lw, v.z, acc.z); acc.w = fmaf(m.lw, v.w, acc.w);
+                if (m.right != m.left) {
+                    if (active) {
+                        *(float4*)(ob + (int64_t)m.left * C) = acc;
+                        const float4 w = {thr * v.x, thr * v.y, thr * v.z, thr * v.w};
+                        for (int j = 1; j <= extra; ++j) *(float4*)(ob + (int64_t)(m.left + j) * C) = w;
+                    }
+                    acc = float4{m.rw * v.x, m.rw * v.y, m.rw * v.z, m.rw * v.w};
+                    cur = m.right;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) xv[u] = xn[u];
+    }
+    if (active) {
+        *(float4*)(ob + (int64_t)cur * C) = acc;
+        const float4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int t = cur + 1; t <= T; ++t) *(float4*)(ob + (int64_t)t * C) = z;
+    }
+}
+
+__global__ __launch_bounds__(64) void cif_bwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                     const float* __restrict__ csum, const float* __restrict__ g,
+                                                     float* __restrict__ dx, float* __restrict__ pa, float* __restrict__ pb, int B, int S,
+                                                     int C, int T, float thr) {
+    const int b = blockIdx.y, lane = threadIdx.x, c0 = (blockIdx.x * 64 + lane) * 4;
+    const bool active = c0 < C;
+    const float* xb = x + (int64_t)b * S * C + (active ? c0 : 0);
+    float* dxb = dx + (int64_t)b * S * C + (active ? c0 : 0);
+    const float* gb = g + (int64_t)b * (T + 1) * C + (active ? c0 : 0);
+    float* pab = pa + ((int64_t)blockIdx.x * B + b) * S;
+    float* pbb = pb + ((int64_t)blockIdx.x * B + b) * S;
+    const float4 zero = {0.f, 0.f, 0.f, 0.f};
+    __shared__ frame_meta sm[MAXS];
+    __shared__ float red[2 * UNROLL][65];        // per-lane partial dot products of a batch (row stride 65: conflict-free column sums)
+    float4 xv[UNROLL], xn[UNROLL];
+    load_batch(xv, xb, 0, S, C, active);
+    stage_meta(sm, alpha + (int64_t)b * S, csum + (int64_t)b * S, S, thr, T);
+    float4 gl = active ? *(const float4*)gb : zero;                               // g[slot 0]
+    float4 gn = active ? *(const float4*)(gb + (int64_t)min(1, T) * C) : zero;    // prefetched g[current slot + 1]
+    for (int s0 = 0; s0 < S; s0 += UNROLL) {
+        load_batch(xn, xb, s0 + UNROLL, S, C, active);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int s = s0 + u;
+            float a = 0.f, bq = 0.f;
+            if (s < S) {
+                const frame_meta m = sm[s];
+                const int extra = m.right - m.left - 1;
+                const float4 v = xv[u];
+                float4 d = {m.lw * gl.x, m.lw * gl.y, m.lw * gl.z, m.lw * gl.w};
+                a = v.x * gl.x + v.y * gl.y + v.z * gl.z + v.w * gl.w;
+                if (m.right != m.left) {
+                    const float4 gr = extra == 0 ? gn : (active ? *(const float4*)(gb + (int64_t)m.right * C) : zero);
+                    float4 mid = zero;
+                    for (int j = 1; j <= extra; ++j) {
+                        const float4 t = active ? *(const float4*)(gb + (int64_t)(m.left + j) * C) : zero;
+                        mid.x += t.x; mid.y += t.y; mid.z += t.z; mid.w += t.w;
+                    }
+                    d.x += m.rw * gr.x + thr * mid.x; d.y += m.rw * gr.y + thr * mid.y;
+                    d.z += m.rw * gr.z + thr * mid.z; d.w += m.rw * gr.w + thr * mid.w;
+                    bq = v.x * (gr.x - gl.x) + v.y * (gr.y - gl.y) + v.z * (gr.z - gl.z) + v.w * (gr.w - gl.w);
+                    gl = gr;
+                    gn = active ? *(const float4*)(gb + (int64_t)min(m.right + 1, T) * C) : zero;
+                }
+                if (active) *(float4*)(dxb + (int64_t)s * C) = d;
+            }
+            red[2 * u][lane] = a;
+            red[2 * u + 1][lane] = bq;
+        }
+        __syncthreads();
+        if (lane < 2 * UNROLL) {                 // lane k sums row k over the 64 lanes: fixed order, no shuffles in the frame loop
+            float t = 0.f;
+#pragma unroll 16
+            for (int j = 0; j < 64; ++j) t += red[lane][j];
+            const int s = s0 + (lane >> 1);
+            if (s < S) ((lane & 1) ? pbb : pab)[s] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) xv[u] = xn[u];
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_cif_fwd(const float* x, const float* alpha, const float* csum, float* out, int32_t B, int32_t S, int32_t C, int32_t T,
+                          float thr, void* stream) {
+    SC_CHECK(x && alpha && csum && out, "sc_cif_fwd: null pointer");
+    SC_CHECK(B > 0 && S > 0 && S <= MAXS && T >= 0 && C > 0 && C % 4 == 0 && thr > 0.f,
+             "sc_cif_fwd: B=%d S=%d (<= 2048) C=%d (C %% 4) T=%d thr=%f", B, S, C, T, (double)thr);
+    SC_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0, "sc_cif_fwd: alignment");
+    hipLaunchKernelGGL(cif_fwd_kernel, dim3((C + 255) / 256, B), dim3(64), 0, (hipStream_t)stream, x, alpha, csum, out, S, C, T, thr);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_cif_bwd(const float* x, const float* alpha, const float* csum, const float* g, float* dx, float* pa, float* pb,
+                          int32_t B, int32_t S, int32_t C, int32_t T, float thr, void* stream) {
+    SC_CHECK(x && alpha && csum && g && dx && pa && pb, "sc_cif_bwd: null pointer");
+    SC_CHECK(B > 0 && S > 0 && S <= MAXS && T >= 0 && C > 0 && C % 4 == 0 && thr > 0.f,
+             "sc_cif_bwd: B=%d S=%d (<= 2048) C=%d (C %% 4) T=%d thr=%f", B, S, C, T, (double)thr);
+    SC_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)dx % 16) == 0, "sc_cif_bwd: alignment");
+    hipLaunchKernelGGL(cif_bwd_kernel, dim3((C + 255) / 256, B), dim3(64), 0, (hipStream_t)stream, x, alpha, csum, g, dx, pa, pb, B, S, C, T,
+                       thr);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

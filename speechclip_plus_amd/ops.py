@@ -245,6 +245,28 @@ def dropout_bf16(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tenso
     return out
 
 
+def cif_fwd(x: torch.Tensor, alpha: torch.Tensor, csum: torch.Tensor, T: int, thr: float) -> torch.Tensor:
+    """integrate-and-fire accumulation: x [B,S,C] fp32, alpha / csum [B,S] fp32 -> out [B,T+1,C] (see sc_cif_fwd)."""
+    B, S, C = x.shape
+    for t in (x, alpha, csum):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    out = torch.empty(B, T + 1, C, device=x.device, dtype=torch.float32)
+    check(lib().sc_cif_fwd(_p(x), _p(alpha), _p(csum), _p(out), B, S, C, T, float(thr), _stream()), "sc_cif_fwd")
+    return out
+
+
+def cif_bwd(x: torch.Tensor, alpha: torch.Tensor, csum: torch.Tensor, g: torch.Tensor, T: int, thr: float):
+    """-> (dx [B,S,C], d alpha (direct part) [B,S], d csum [B,S])"""
+    B, S, C = x.shape
+    assert g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == (B, T + 1, C)
+    nblk = (C + 255) // 256
+    dx = torch.empty_like(x)
+    pa = torch.empty(nblk, B, S, device=x.device, dtype=torch.float32)
+    pb = torch.empty(nblk, B, S, device=x.device, dtype=torch.float32)
+    check(lib().sc_cif_bwd(_p(x), _p(alpha), _p(csum), _p(g), _p(dx), _p(pa), _p(pb), B, S, C, T, float(thr), _stream()), "sc_cif_bwd")
+    return dx, pa.sum(0), pb.sum(0)
+
+
 def softmax_fwd(scores: torch.Tensor, key_mask: torch.Tensor, rows_per_batch: int, scale: float, drop_p: float = 0.0,
                 drop_seed: int = 0):
     """P = softmax(scale * scores | key mask) as bf16 (+ the dropped copy in train mode); scores fp32 [..., n] contiguous,
