@@ -71,7 +71,8 @@ typedef struct {
                                      channels-last Conv1d with k = 3, stride 2): 0 = ascending k; tap_c = C_in visits, per 64-channel
                                      block, tap 0, tap 2, tap 1 - tap 2 of output row r is tap 0 of row r + 1, so its tile is
                                      re-read while still in the L2 instead of 16 K-tiles later from the fabric. Only the
-                                     fp32 summation order over k changes. Kernels without the reordering ignore it. */
+                                     fp32 summation order over k changes; every tile family uses the same order, so results do not depend on
+                                     the dispatcher's choice. */
     int32_t pad_;
 } sc_gemm_args;
 int sc_gemm_bf16(const sc_gemm_args* args, void* stream);

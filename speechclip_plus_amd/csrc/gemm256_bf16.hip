@@ -439,10 +439,6 @@ static double tile_cost(const sc_gemm_args& a, int BN) {
 int sc_gemm256_launch(const sc_gemm_args& a_in, hipStream_t s) {
     sc_gemm_args a = a_in;
     a.reserved = a_in.reserved == 1 || (a_in.reserved == 0 && a_in.residual != nullptr);   // bit 0: non-temporal C stores
-    if (a.tap_c != 0 && !(a.tap_c > 0 && a.tap_c % 64 == 0 && a.K == 3 * a.tap_c)) {
-        sc_set_error("sc_gemm_bf16: tap_c=%d needs tap_c %% 64 == 0 and K == 3 * tap_c (K=%d)", a.tap_c, a.K);
-        return -1;
-    }
     if (a.tile == 32) return launch256<3, 256>(a, s);   // diagnostics only (tools/epi_probe.py, tools/epi_stamps.py)
     if (a.tile == 34) return launch256<4, 256>(a, s);
     if (a.tile == 7) return launch256<0, 192>(a, s);

@@ -124,11 +124,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
     }
 
     const int nk = p.K / BK;
+    // K-tile order of conv-shaped problems (sc_gemm_args.tap_c, see gemm256_bf16.hip): the same order in every kernel, so the
+    // result does not depend on which tile family the dispatcher picks for a given row count
+    const int tap_c = p.tap_c;
+    auto koff = [&](int kt) -> int {
+        if (tap_c == 0) return kt * BK;
+        const int c = kt / 3, j = kt - 3 * c;
+        return (j == 0 ? 0 : (3 - j) * tap_c) + c * BK;
+    };
     stage(0, 0);
     __syncthreads();   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+        if (kt + 1 < nk) stage(buf ^ 1, koff(kt + 1));
         const char* as = As + buf * Cfg::A_BYTES;
         const char* bs = Bs + buf * Cfg::B_BYTES;
 #pragma unroll
@@ -267,6 +275,8 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
              "sc_gemm_bf16: operands must be 16-byte aligned");
     SC_CHECK(a.act == 0 || a.act == 1, "sc_gemm_bf16: act=%d", a.act);
     SC_CHECK(a.drop_p >= 0.f && a.drop_p < 1.f, "sc_gemm_bf16: drop_p=%f", (double)a.drop_p);
+    SC_CHECK(a.tap_c == 0 || (a.tap_c > 0 && a.tap_c % 64 == 0 && a.K == 3 * a.tap_c),
+             "sc_gemm_bf16: tap_c=%d needs tap_c %% 64 == 0 and K == 3 * tap_c (K=%d)", a.tap_c, a.K);
     SC_CHECK(a.drop_p == 0.f || ((int64_t)a.M * a.N < (int64_t)1 << 32 && a.nb1 * a.nb2 == 1),
              "sc_gemm_bf16: dropout needs M*N < 2^32 and no batch");
     if (a.nb1 < 1) a.nb1 = 1;

@@ -136,6 +136,9 @@ def test_gemm_strided_rows_conv(dev):
         ops.gemm_raw(x2, 2 * C, wk, 3 * C, o1, C, Tout2, C, 3 * C, act=1, tile=tile, tap_c=C)
         assert rel_l2(o1, ref2) < 6e-3 and rel_l2(o0, ref2) < 6e-3
         assert rel_l2(o1, o0) < 3e-3 and not torch.equal(o1, torch.zeros_like(o1))
+    o128 = torch.zeros(Tout2, C, device=dev, dtype=torch.bfloat16)
+    ops.gemm_raw(x2, 2 * C, wk, 3 * C, o128, C, Tout2, C, 3 * C, act=1, tile=1, tap_c=C)
+    assert torch.equal(o128, o1)                                     # same K order in every tile family: bitwise equal
     with pytest.raises(RuntimeError, match="tap_c"):
         ops.gemm_raw(x2, 2 * C, wk, 3 * C, o1, C, Tout2, C, 2 * C, tile=8, tap_c=C)
 
