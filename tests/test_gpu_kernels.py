@@ -653,6 +653,9 @@ def test_gemm_random_shape_fuzz(dev):
         N = 8 * rng.randint(1, 130)
         K = 64 * rng.randint(1, 20)
         cases.append((M, N, K, rng.random() < 0.5, rng.random() < 0.4, rng.random() < 0.4, rng.random() < 0.25, rng.choice([0, 1, 2, 3, 7, 8])))
+    # narrow outputs on the 128 x 64 tile (the grouped pos_conv is 48 wide)
+    cases += [(300, 48, 192, True, True, True, False, 3), (129, 40, 64, True, False, False, True, 3), (1000, 8, 128, False, True, False, False, 3),
+              (257, 24, 320, True, False, True, False, 3), (640, 56, 128, True, True, False, False, 3), (512, 64, 256, False, False, True, False, 3)]
     for M, N, K, use_bias, act, use_res, out_f32, tile in cases:
         if tile == 3 and N > 64:
             tile = 0
