@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _make(unfreeze):
+def _make(unfreeze, dropout=False):
     import dataclasses
     sys.path.insert(0, ROOT)
     from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
@@ -40,7 +40,7 @@ def _make(unfreeze):
     if unfreeze:
         cfg.audio_encoder.trainable = True
         cfg.audio_encoder.unfreeze_layers = [1, 2]
-    model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
+    model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), dropout)
     return model, ContrastiveTrainer(model)
 
 
@@ -120,6 +120,46 @@ def test_rccl_backend_one_rank_rehearsal(unfreeze):
     flat1 = trainer.opt.flat_p.detach().cpu()
     assert abs(losses1[0] - losses_r[0]) < 1e-5 and abs(losses1[1] - losses_r[1]) < 1e-3, (losses1, losses_r)
     assert float((flat1 - torch.from_numpy(flat_r)).norm() / flat1.norm()) < 1e-5
+
+
+def _worker_dropout(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(123)                                      # same torch seed on both ranks: the rank enters the mask seeds itself
+    model, trainer = _make(False, dropout=True)
+    n = 8 // world
+    batch = _batch(rank * n, (rank + 1) * n)
+    enc = model.audio_encoder
+    seeds = enc._dropout_seeds()
+    enc._drop_calls = 0
+    losses = [float(trainer.step(batch)) for _ in range(2)]
+    torch.cuda.synchronize()
+    q.put((rank, losses, trainer.opt.flat_p.detach().cpu().numpy(), seeds(0)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_with_train_mode_dropout_stay_in_sync():
+    """The reference's train step has dropout live: each rank draws its OWN masks (the rank enters the seeds), the all-reduced
+    gradient is the same everywhere, so the replicas' parameters must remain bit-identical after the optimiser steps."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dropout, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        rank, losses, flat, seed0 = q.get(timeout=240)
+        got[rank] = (losses, torch.from_numpy(flat), seed0)
+    for p in procs:
+        p.join(timeout=60)
+    assert got[0][2] != got[1][2]                                # different masks per rank
+    assert all(l == l for l in got[0][0] + got[1][0])
+    assert got[0][0] == got[1][0]                                # the loss is evaluated on the gathered global batch by every rank
+    assert torch.equal(got[0][1], got[1][1])
 
 
 def _initial_flat(unfreeze):
