@@ -64,7 +64,7 @@ typedef struct {
                                      (7 / 8 force 192 / 256) | 3: 128x64 */
     int32_t reserved;             /* store policy of the bf16 C tile (256-row kernels): 0 auto = non-temporal stores when a residual
                                      is given (the output is the next residual stream, not re-read by this kernel; measured
-                                     -3.5 % GEMM time per step) or the output is >= 32 MiB, 1 always non-temporal, 2 never */
+                                     -3.5 % GEMM time per step), 1 always non-temporal, 2 never */
     float drop_p;                 /* 0 = no dropout */
     uint32_t drop_seed;
     int32_t tap_c;                /* K-tile visiting-order hint for conv-shaped A (rows overlap: lda = 2*tap_c, K = 3*tap_c, i.e. a

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libspeechclip_hip.so")
+LIB_PATH = os.environ.get("SC_LIB_PATH") or os.path.join(_HERE, "csrc", "libspeechclip_hip.so")   # override: same-box A/B of two builds
 
 c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 

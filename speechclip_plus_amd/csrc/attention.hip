@@ -15,6 +15,7 @@ namespace {
 
 constexpr int KT = 64;   // keys per LDS tile
 
+template <int DROP>   // train-mode probability dropout as a compile-time variant: the eval kernel carries none of its registers
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qk, int64_t ldqk,
                                                         const uint16_t* __restrict__ vt,
                                                         const int32_t* __restrict__ valid_len,
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     const int qrow = q0 + l31;                                       // this lane's query
     // attention-probability dropout (fairseq attention_dropout, train mode): P' = mask . P / (1 - p) with the row sum taken
     // over the un-masked P; element (b, h, q, k) -> sc_hash32 lane as in sc_common.h
-    const uint32_t drop_thr = drop_p > 0.f ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
+    const uint32_t drop_thr = DROP ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
     const uint32_t drop_row = (uint32_t)(((b * H + h) * R + qrow)) * (uint32_t)R;
     if (causal) n_valid = min(n_valid, qblk * 128 + 128);           // keys beyond the block's last query are all masked
     const int ntiles = (n_valid + KT - 1) / KT;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                 psum += pv[r];
             }
             l_run += psum;
-            if (drop_thr) {
+            if (DROP) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const uint32_t kidx = (uint32_t)(kbase + (r & 3) + 8 * (r >> 2) + 4 * half);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 
     const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
-    const float inv = 1.0f / (l_tot * (1.0f - drop_p));
+    const float inv = DROP ? 1.0f / (l_tot * (1.0f - drop_p)) : 1.0f / l_tot;
     if (lse2 && half == 0) lse2[((int64_t)b * H + h) * R + qrow] = m_run * c + __builtin_amdgcn_logf(l_tot);   // log2 domain
     uint16_t* op = out + ((int64_t)b * R + q0 + l31) * ldo + h * 64 + 4 * half;
 #pragma unroll
@@ -220,8 +221,12 @@ extern "C" int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* 
     SC_CHECK(((uintptr_t)qk % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0,
              "sc_attn_fwd_bf16: alignment");
     dim3 grid((R / 128) * H * B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R,
-                       H, D, scale * 1.4426950408889634f, lse2, causal, drop_p, drop_seed);
+    if (drop_p > 0.f)
+        hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R,
+                           H, D, scale * 1.4426950408889634f, lse2, causal, drop_p, drop_seed);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R,
+                           H, D, scale * 1.4426950408889634f, lse2, causal, drop_p, drop_seed);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -57,7 +57,7 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 // BN = 256 or 192 output columns per tile (wave block 128 x 64 or 128 x 48).  The narrower tile exists for wave
 // quantisation: with M = 32768, N = 768 / 2304 give 384 / 1152 tiles of 256 x 256 (1.5 / 4.5 rounds over 256 CUs) but
 // 512 / 1536 tiles of 256 x 192 (exactly 2 / 6 rounds).
-template <int DIAG, int BN, int ACT>
+template <int DIAG, int BN, int ACT, int DROP>
 __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     constexpr int TN = BN / 4, FN = TN / 16, NB1 = FN - 2;   // per-wave columns, fragments, fragments of n-sub 1
     constexpr int NBI = BN / 64;                             // B-tile DMA instructions per wave and K-tile
@@ -142,8 +142,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         const int c = kt / 3, j = kt - 3 * c;
         return (j == 0 ? 0 : (3 - j) * tap_c) + c * BK;
     };
-    const uint32_t drop_thr = p.drop_p > 0.f ? (uint32_t)(p.drop_p * 65536.f + 0.5f) : 0u;
-    const float drop_scale = 1.f / (1.f - p.drop_p);
+    // train-mode dropout is a compile-time variant: in the runtime-switched form its mask / scale registers and the branch in
+    // the store loop cost the plain instantiations 4 % (rocprofv3, r01 v6 -> v7)
+    const uint32_t drop_thr = DROP ? (uint32_t)(p.drop_p * 65536.f + 0.5f) : 0u;
+    const float drop_scale = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
 
     int iter_ = 0;
 #define SC_STAMP(K)                                                                                          \
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                             const f32x4 lo = *(const f32x4*)(Cw + row * TNP + cs);
                             const f32x4 hi = *(const f32x4*)(Cw + row * TNP + cs + 4);
                             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            if (drop_thr) {                  // train-mode dropout before the residual add (F.dropout semantics)
+                            if (DROP) {                      // train-mode dropout before the residual add (F.dropout semantics)
                                 const uint32_t keep = sc_keep8((uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_seed, drop_thr);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * drop_scale : 0.f;
@@ -405,11 +407,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
 
 }  // namespace
 
-template <int DIAG, int BN, int ACT>
+template <int DIAG, int BN, int ACT, int DROP>
 static int launch256_(const sc_gemm_args& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DIAG, BN, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DIAG, BN, ACT, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) {
             sc_set_error("hipFuncSetAttribute(gemm256): %s", hipGetErrorString(e));
             return -3;
@@ -418,14 +420,17 @@ static int launch256_(const sc_gemm_args& a, hipStream_t s) {
     }
     const int nM = (a.M + 255) / 256, nN = (a.N + BN - 1) / BN;
     dim3 grid(std::min(nM * nN, sc_num_cus()), 1, a.nb1 * a.nb2);
-    hipLaunchKernelGGL((gemm256_kernel<DIAG, BN, ACT>), grid, dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm256_kernel<DIAG, BN, ACT, DROP>), grid, dim3(512), LDS_BYTES, s, a);
     SC_LAUNCH_CHECK();
     return 0;
 }
 
 template <int DIAG, int BN>
 static int launch256(const sc_gemm_args& a, hipStream_t s) {
-    return a.act == 1 ? launch256_<DIAG, BN, 1>(a, s) : launch256_<DIAG, BN, 0>(a, s);
+    if constexpr (DIAG == 0) {          // the diagnostic builds have no dropout variant
+        if (a.drop_p > 0.f) return a.act == 1 ? launch256_<DIAG, BN, 1, 1>(a, s) : launch256_<DIAG, BN, 0, 1>(a, s);
+    }
+    return a.act == 1 ? launch256_<DIAG, BN, 1, 0>(a, s) : launch256_<DIAG, BN, 0, 0>(a, s);
 }
 
 // rounds of workgroups the grid needs with BN-wide tiles, times a per-tile efficiency factor
@@ -438,10 +443,10 @@ static double tile_cost(const sc_gemm_args& a, int BN) {
 
 int sc_gemm256_launch(const sc_gemm_args& a_in, hipStream_t s) {
     sc_gemm_args a = a_in;
-    // bit 0: non-temporal C stores.  auto: when a residual is given (the output is the next residual stream) or the output is too
-    // large to stay cache-resident for its consumer anyway (>= 32 MiB per launch: -0.5 % on the encoder forward vs residual-only)
-    const bool big = (int64_t)a_in.M * a_in.N * a_in.nb1 * a_in.nb2 * 2 >= ((int64_t)32 << 20);
-    a.reserved = a_in.reserved == 1 || (a_in.reserved == 0 && (a_in.residual != nullptr || big));
+    // bit 0: non-temporal C stores.  auto = only when a residual is given (the output is the next residual stream and is read
+    // next by a LayerNorm pass).  Extending it to every large output was measured and reverted: FC1 itself gains 2 % but FC2 then
+    // reads its 201 MB A operand from HBM instead of the MALL (145 -> 165 us), encoder forward +2 % (same-box A/B).
+    a.reserved = a_in.reserved == 1 || (a_in.reserved == 0 && a_in.residual != nullptr);
     if (a.tile == 32) return launch256<3, 256>(a, s);   // diagnostics only (tools/epi_probe.py, tools/epi_stamps.py)
     if (a.tile == 34) return launch256<4, 256>(a, s);
     if (a.tile == 7) return launch256<0, 192>(a, s);
