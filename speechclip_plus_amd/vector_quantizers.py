@@ -25,6 +25,7 @@ class SimpleVectorQuantizer(nn.Module):
             elif temp.startswith("fixed="):
                 self.temp_type = "fixed"
                 self.register_buffer("curr_temp", torch.FloatTensor([ast.literal_eval(temp[len("fixed="):])]))
+                self._fixed_temp = float(ast.literal_eval(temp[len("fixed="):]))     # host copy: reporting it needs no device read
             else:
                 self.temp_type = "scheduled"
                 sched = ast.literal_eval(temp)
@@ -58,7 +59,10 @@ class SimpleVectorQuantizer(nn.Module):
         probs_per_t = torch.softmax(x.view(bsz, tsz, -1), dim=-1).permute(1, 0, 2)
         result["ent_per_t"] = (-torch.sum(probs_per_t * torch.log(probs_per_t + 1e-9), dim=-1)).mean(dim=-1)
         result["prob_perplexity"] = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-7), dim=-1)).sum()
-        result["temp"] = self.curr_temp.item() if isinstance(self.curr_temp, torch.Tensor) else float(self.curr_temp)
+        if self.temp_type == "fixed":
+            result["temp"] = self._fixed_temp
+        else:
+            result["temp"] = self.curr_temp.item() if isinstance(self.curr_temp, torch.Tensor) else float(self.curr_temp)
         if self.training:
             if self.use_gumbel:
                 x = F.gumbel_softmax(x.float(), tau=self.curr_temp, hard=self.hard).type_as(x)
