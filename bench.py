@@ -188,7 +188,7 @@ def main():
                                    f"(L={L}, T={T}), CLIP image embeddings given",
                        "global_batch": B * world, "per_gpu_batch": B, "audio_samples": L, "frames": T,
                        "parallelism": f"dp{world}", "dropout": ("off (--no-dropout)" if args.no_dropout else
-                                   "on, as the reference's train step: frozen HuBERT in train mode (base: input / residual / attention "
+                                   "on, as the reference's train step: HuBERT in train mode (base: input / residual / attention "
                                    "p=0.1; large: 0) + head p=0.1; masks = stateless hash inside the GEMM / attention kernels")},
             "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,
             "forward": None if fwd_ms is None else forward_summary(fwd_ms, B, L, T),

@@ -66,6 +66,7 @@ struct bwd_args {
     int64_t ldq, ldk, ldv, lddo;
     const uint16_t *qT, *kT, *doT;               // [B, H, 64, R]
     const float *lse2, *delta;                   // [B, H, R]
+    float drop_p; uint32_t drop_seed;            // attention-probability dropout of the forward (sc_attn_fwd_bf16), 0 = none
     const int32_t* valid_len;                    // [B]
     uint16_t *dq, *dk, *dv;                      // row-major outputs
     int64_t lddq, lddk, lddv;
@@ -75,6 +76,7 @@ struct bwd_args {
 };
 
 // ------------------------------------------------------------------------------------------------------------ dQ
+template <int DROP>   // DROP: the forward dropped its probabilities (same stateless hash mask, regenerated here)
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bwd_args p) {
     __shared__ __attribute__((aligned(16))) char Ks[TT * 128];
     __shared__ __attribute__((aligned(16))) char Vs[TT * 128];
@@ -86,6 +88,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bwd_args p) {
     const int q0 = qblk * 128 + wave * 32, qrow = q0 + l31;
     int n_valid = max(1, min(p.valid_len[b], R));
     if (p.causal) n_valid = min(n_valid, qblk * 128 + 128);
+    const uint32_t drop_thr = DROP ? (uint32_t)(p.drop_p * 65536.f + 0.5f) : 0u;
+    const float drop_scale = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t drop_row = (uint32_t)((b * H + h) * R + qrow) * (uint32_t)R;       // element (b, h, q, k) -> drop_row + k
 
     bf16x8 qf[4], dof[4];
     {
@@ -149,6 +154,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bwd_args p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kb, l31, half, ks), qf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kb, l31, half, ks), dof[ks], dp, 0, 0, 0);
             }
+            if (DROP) {                                                // dP = keep . dP' / (1 - p): the forward's mask (pairs along k)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const uint32_t kidx = (uint32_t)(kbase + (r & 3) + 8 * (r >> 2) + 4 * half);
+                    const uint32_t hsh = sc_hash32(((drop_row + kidx) >> 1) ^ p.drop_seed);
+                    dp[r] = (hsh & 0xffffu) < drop_thr ? 0.f : dp[r] * drop_scale;
+                    dp[r + 1] = (hsh >> 16) < drop_thr ? 0.f : dp[r + 1] * drop_scale;
+                }
+            }
             f32x16 ds;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -171,6 +185,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bwd_args p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------ dK, dV
+template <int DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
     __shared__ __attribute__((aligned(16))) char Qs[TT * 128];
     __shared__ __attribute__((aligned(16))) char Os[TT * 128];
@@ -183,6 +198,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
     const int kblk = logical % nkb, bh = logical / nkb, h = bh % H, b = bh / H;
     const int key0w = kblk * 128 + wave * 32, krow = key0w + l31;
     const int n_valid = max(1, min(p.valid_len[b], R));
+    const uint32_t drop_thr = DROP ? (uint32_t)(p.drop_p * 65536.f + 0.5f) : 0u;
+    const float drop_scale = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
     uint16_t* dkp = p.dk + ((int64_t)b * R + krow) * p.lddk + h * 64 + 4 * half;
     uint16_t* dvp = p.dv + ((int64_t)b * R + krow) * p.lddv + h * 64 + 4 * half;
 
@@ -266,8 +283,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
                     const int r = 4 * g + e, qidx = qt0 + ql + e;
                     const bool ok = key_ok && !(p.causal && krow > qidx);
                     const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e])) : 0.f;
-                    pr[r] = pv;
-                    ds[r] = pv * (dp[r] - d4[e]);
+                    if (DROP) {                                        // this lane's key, query qidx: one hash word per element
+                        const uint32_t idx = (uint32_t)((b * H + h) * R + qidx) * (uint32_t)R + (uint32_t)krow;
+                        const uint32_t hsh = sc_hash32((idx >> 1) ^ p.drop_seed);
+                        const bool keep = ((krow & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= drop_thr;
+                        pr[r] = keep ? pv * drop_scale : 0.f;          // P' (dV = P'^T dO)
+                        ds[r] = pv * ((keep ? dp[r] * drop_scale : 0.f) - d4[e]);
+                    } else {
+                        pr[r] = pv;
+                        ds[r] = pv * (dp[r] - d4[e]);
+                    }
                 }
             }
             bf16x8 pf[2], df[2];
@@ -348,11 +373,13 @@ extern "C" int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k,
                                 const sc_bf16* kT, const sc_bf16* doT, const float* lse2, float* delta,
                                 const int32_t* valid_len, sc_bf16* dq, int64_t lddq, sc_bf16* dk, int64_t lddk, sc_bf16* dv,
                                 int64_t lddv, int32_t B, int32_t R, int32_t H, int32_t q_rows, float scale, int32_t causal,
-                                void* stream) {
+                                float drop_p, uint32_t drop_seed, void* stream) {
     SC_CHECK(q && k && v && out && dout && qT && kT && doT && lse2 && delta && valid_len && dq && dk && dv,
              "sc_attn_bwd_bf16: null pointer");
     SC_CHECK(B > 0 && H > 0 && R > 0 && R % 128 == 0, "sc_attn_bwd_bf16: R=%d must be a positive multiple of 128", R);
     SC_CHECK(q_rows > 0 && q_rows <= R, "sc_attn_bwd_bf16: q_rows=%d", q_rows);
+    SC_CHECK(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || (int64_t)B * H * R * R < ((int64_t)1 << 32)),
+             "sc_attn_bwd_bf16: drop_p=%f (needs B*H*R*R < 2^32)", (double)drop_p);
     SC_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 &&
                  lddv % 4 == 0, "sc_attn_bwd_bf16: leading dims");
     const int64_t total = (int64_t)B * R * H;
@@ -364,13 +391,16 @@ extern "C" int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k,
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo;
     a.qT = qT; a.kT = kT; a.doT = doT;
     a.lse2 = lse2; a.delta = delta; a.valid_len = valid_len;
+    a.drop_p = drop_p; a.drop_seed = drop_seed;
     a.dq = dq; a.dk = dk; a.dv = dv;
     a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.R = R; a.H = H; a.q_rows = q_rows; a.scale = scale; a.c = scale * 1.4426950408889634f; a.causal = causal;
     const dim3 grid((R / 128) * H * B);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
     SC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
     SC_LAUNCH_CHECK();
     return 0;
 }

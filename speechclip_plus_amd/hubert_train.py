@@ -13,10 +13,10 @@ from the head's backward (head_tail.ParallelHeadFn) with the gradient of the wei
                           residual add.  Frozen layers above the lowest unfrozen one run the same chain without weight gradients.
 
 Weight gradients are written in fp32 straight into the parameters' ``.grad`` (views of the optimiser's flat buffer), so the
-single flat all-reduce of parallel.GradAllReduce covers them.  Dropout inside the UNFROZEN layers (and the frozen
-pass-through layers above them; fairseq: p = 0.1 base, 0 large) is not applied - their backward would have to re-apply the
-masks; the frozen layers below them, the encoder input sites and the head do run their train-mode dropout
-(speech_encoder._encode_kernels).  No shipped recipe unfreezes HuBERT layers.
+single flat all-reduce of parallel.GradAllReduce covers them.  Train-mode dropout (fairseq: p = 0.1 base, 0 large) runs in
+these layers too: the forward applies the stateless hash masks in the kernels (attention probabilities, out_proj and fc2
+epilogues) and the backward regenerates them from the same seeds - ops.dropout_bf16 on the two branch gradients, the
+DROP variants of the attention backward kernels.  No shipped recipe unfreezes HuBERT layers.
 """
 from typing import Dict, List
 
@@ -96,8 +96,10 @@ class TrainableLayers(nn.Module):
         self._versions = ver
 
     # -------------------------------------------------------------------------------------------------- forward
-    def layer_forward(self, i: int, x: torch.Tensor, out: torch.Tensor, pl, save: bool) -> None:
+    def layer_forward(self, i: int, x: torch.Tensor, out: torch.Tensor, pl, save: bool, drops=None) -> None:
         """hidden[i] -> hidden[i + 1].  ``save``: keep the activations the backward needs in ``pl.train[i]``.
+        ``drops`` = (p_residual, p_attention, seed_attention, seed_out_proj, seed_fc2) in train mode (fairseq's dropout1 /
+        dropout3 in the GEMM epilogues, attention dropout in the attention kernel; the backward regenerates the same hash masks).
         post-LN (base):  pre1 = x + attn(x) ; x1 = LN1(pre1) ; pre2 = x1 + ffn(x1) ; out = LN2(pre2)
         pre-LN (large):  x1 = LN1(x) ; pre1 = x + attn(x1) ; x2 = LN2(pre1) ; out = pre1 + ffn(x2)"""
         a, c = self.arch, self._copies[i]
@@ -115,6 +117,8 @@ class TrainableLayers(nn.Module):
             s = dict(qkv=torch.empty(M, 3 * D, device=dev, dtype=torch.bfloat16), ctx=pl.ctx, lse2=None,
                      pre1=torch.empty(M, D, device=dev, dtype=torch.bfloat16) if pre_ln else pl.pre, x1=pl.x1, u=pl.ffn, f=pl.ffn,
                      pre2=pl.pre)
+        p_res, p_att, sd_a, sd_o, sd_f = drops if drops is not None else (0.0, 0.0, 0, 0, 0)
+        s["drops"] = (p_res, p_att, sd_a, sd_o, sd_f)
         attn_in = x
         if pre_ln:
             ops.layernorm_bf16(x, c["ln1_g"], c["ln1_b"], out=s["x1"])
@@ -122,8 +126,8 @@ class TrainableLayers(nn.Module):
         ops.linear_bf16(attn_in, c["qkv_w"], c["qkv_b"], out=s["qkv"], alg_rows=B * T)
         ops.head_transpose(s["qkv"][:, 2 * D:], B, R, H, out=pl.vt)
         ops.attn_fwd(s["qkv"][:, : 2 * D], pl.vt, pl.valid, s["ctx"], B, R, H, D, (D // H) ** -0.5, lse2=s["lse2"],
-                     alg_flops=4.0 * B * T * T * D)
-        ops.linear_bf16(s["ctx"], c["o_w"], c["o_b"], out=s["pre1"], residual=x, alg_rows=B * T)
+                     alg_flops=4.0 * B * T * T * D, drop_p=p_att, drop_seed=sd_a)
+        ops.linear_bf16(s["ctx"], c["o_w"], c["o_b"], out=s["pre1"], residual=x, alg_rows=B * T, drop_p=p_res, drop_seed=sd_o)
         ffn_in = s["pre2"] if pre_ln else s["x1"]
         if pre_ln:
             ops.layernorm_bf16(s["pre1"], c["ln2_g"], c["ln2_b"], out=s["pre2"])
@@ -135,9 +139,10 @@ class TrainableLayers(nn.Module):
         else:
             ops.linear_bf16(ffn_in, c["fc1_w"], c["fc1_b"], out=s["f"], act=1, alg_rows=B * T)
         if pre_ln:
-            ops.linear_bf16(s["f"], c["fc2_w"], c["fc2_b"], out=out, residual=s["pre1"], alg_rows=B * T)
+            ops.linear_bf16(s["f"], c["fc2_w"], c["fc2_b"], out=out, residual=s["pre1"], alg_rows=B * T, drop_p=p_res, drop_seed=sd_f)
         else:
-            ops.linear_bf16(s["f"], c["fc2_w"], c["fc2_b"], out=s["pre2"], residual=s["x1"], alg_rows=B * T)
+            ops.linear_bf16(s["f"], c["fc2_w"], c["fc2_b"], out=s["pre2"], residual=s["x1"], alg_rows=B * T, drop_p=p_res,
+                            drop_seed=sd_f)
             ops.layernorm_bf16(s["pre2"], c["ln2_g"], c["ln2_b"], out=out)
 
     # -------------------------------------------------------------------------------------------------- backward
@@ -184,13 +189,16 @@ class TrainableLayers(nn.Module):
             if train:
                 ops.wgrad_bf16(dy, xin, P(name + ".weight"), P(name + ".bias"))
 
+        p_res, p_att, sd_a, sd_o, sd_f = s.get("drops", (0.0, 0.0, 0, 0, 0))
         # ---- FFN half
-        if pre_ln:                                                          # out = pre1 + fc2(gelu(fc1(LN2(pre1))))
+        if pre_ln:                                                          # out = pre1 + drop(fc2(gelu(fc1(LN2(pre1)))))
             dffn_out, ffn_in = d_out, s["pre2"]
-        else:                                                               # out = LN2(pre2), pre2 = x1 + fc2(gelu(fc1(x1)))
+        else:                                                               # out = LN2(pre2), pre2 = x1 + drop(fc2(gelu(fc1(x1))))
             dffn_out, ffn_in = ln_bwd(s["pre2"], d_out, 2), s["x1"]
-        wgrad(dffn_out, s["f"], "fc2")
-        df = ops.linear_bf16(dffn_out, c["fc2_wT"])
+        # gradient of the dropped branch = the same mask on the sum's gradient; the residual path keeps the un-masked one
+        dfc2 = ops.dropout_bf16(dffn_out, p_res, sd_f) if p_res > 0.0 else dffn_out
+        wgrad(dfc2, s["f"], "fc2")
+        df = ops.linear_bf16(dfc2, c["fc2_wT"])
         du = ops.act_bf16(s["u"], 1, df=df, out=df)
         wgrad(du, ffn_in, "fc1")
         if pre_ln:
@@ -200,12 +208,13 @@ class TrainableLayers(nn.Module):
             dx1 = ops.linear_bf16(du, c["fc1_wT"], residual=dffn_out)
             dpre1 = ln_bwd(s["pre1"], dx1, 1)
         # ---- attention half:  pre1 = x + out_proj(attn(qkv(attn_in)))
-        wgrad(dpre1, s["ctx"], "self_attn.out_proj")
-        dctx = ops.linear_bf16(dpre1, c["o_wT"])
+        dop = ops.dropout_bf16(dpre1, p_res, sd_o) if p_res > 0.0 else dpre1
+        wgrad(dop, s["ctx"], "self_attn.out_proj")
+        dctx = ops.linear_bf16(dop, c["o_wT"])
         dqkv = torch.empty(M, 3 * D, device=x.device, dtype=torch.bfloat16)
         qkv = s["qkv"]
         ops.attn_bwd(qkv[:, :D], qkv[:, D: 2 * D], qkv[:, 2 * D:], s["ctx"], dctx, s["lse2"], pl.valid, dqkv[:, :D], dqkv[:, D: 2 * D],
-                     dqkv[:, 2 * D:], B, R, H, (D // H) ** -0.5, q_rows=T)
+                     dqkv[:, 2 * D:], B, R, H, (D // H) ** -0.5, q_rows=T, drop_p=p_att, drop_seed=sd_a)
         attn_in = s["x1"] if pre_ln else x
         if train:
             gW = torch.empty(3 * D, D, device=x.device, dtype=torch.float32)

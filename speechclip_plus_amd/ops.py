@@ -151,9 +151,10 @@ def head_transpose(x: torch.Tensor, B: int, R: int, H: int, out: Optional[torch.
 
 def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse2: torch.Tensor,
              valid_len: torch.Tensor, dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, B: int, R: int, H: int, scale: float,
-             causal: bool = False, kT: Optional[torch.Tensor] = None, q_rows: Optional[int] = None) -> None:
+             causal: bool = False, kT: Optional[torch.Tensor] = None, q_rows: Optional[int] = None, drop_p: float = 0.0,
+             drop_seed: int = 0) -> None:
     """q, k, v, out, dout, dq, dk, dv: [B R, H 64] views (column slices of wider buffers allowed); query rows t >= q_rows
-    (default R) must carry dout = 0."""
+    (default R) must carry dout = 0.  ``drop_p`` / ``drop_seed``: those of the forward (attn_fwd) when it dropped probabilities."""
     for t in (q, k, v, out, dout, dq, dk, dv):
         assert t.dtype == torch.bfloat16 and t.stride(1) == 1
     qT = head_transpose(q, B, R, H)
@@ -164,7 +165,7 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     check(lib().sc_attn_bwd_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), _p(dout),
                                  dout.stride(0), _p(qT), _p(kT), _p(doT), _p(lse2), _p(delta), _p(valid_len), _p(dq), dq.stride(0),
                                  _p(dk), dk.stride(0), _p(dv), dv.stride(0), B, R, H, R if q_rows is None else q_rows, float(scale),
-                                 int(causal), _stream()),
+                                 int(causal), float(drop_p), int(drop_seed) & 0xffffffff, _stream()),
           "sc_attn_bwd_bf16")
 
 

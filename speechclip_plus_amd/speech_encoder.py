@@ -429,7 +429,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             for i in range(a.layers):
                 x = pl.hidden[i]
                 if tl is not None and (i in tl.ids or i in tl.pass_ids):   # unfrozen (or frozen above an unfrozen one): activations kept
-                    tl.layer_forward(i, x, pl.hidden[i + 1], pl, save)
+                    tl.layer_forward(i, x, pl.hidden[i + 1], pl, save,
+                                     drops=(p_res, p_att, sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)) if seeds else None)
                     continue
                 qkv_attn(x, i)
                 # train mode: dropout1 / dropout3 of fairseq's TransformerSentenceEncoderLayer in the GEMM epilogues (before the
@@ -453,7 +454,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             for i in range(a.layers):
                 x = pl.hidden[i]
                 if tl is not None and (i in tl.ids or i in tl.pass_ids):
-                    tl.layer_forward(i, x, pl.hidden[i + 1], pl, save)
+                    tl.layer_forward(i, x, pl.hidden[i + 1], pl, save,
+                                     drops=(p_res, p_att, sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)) if seeds else None)
                     continue
                 ops.layernorm_bf16(x, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
                 qkv_attn(pl.x1, i)

@@ -783,6 +783,21 @@ def test_dropout_masks_gemm_rows_attention(dev):
     ref = ((P * keep / (1 - p)) @ vf).transpose(1, 2).reshape(B * R, D)
     rows_ok = key_ok.reshape(B * R)
     assert rel_l2(out[rows_ok], ref[rows_ok]) < 1.2e-2
+    # backward through the dropped probabilities: the DROP variants of the dq / dkv kernels regenerate the same mask
+    lse2 = torch.empty(B, H, R, device=dev, dtype=torch.float32)
+    ops.attn_fwd(qkv[:, : 2 * D], vt, vl, out, B, R, H, D, 64 ** -0.5, lse2=lse2, drop_p=p, drop_seed=seed)
+    qa, ka, va = (t.detach().clone().requires_grad_() for t in (qf, kf, vf))
+    Pa = torch.softmax(((qa @ ka.transpose(-1, -2)) * 64 ** -0.5).masked_fill(~key_ok[:, None, None, :], float("-inf")), dim=-1)
+    oa = ((Pa * keep / (1 - p)) @ va).transpose(1, 2).reshape(B * R, D)
+    dout = bf(torch.randn(B * R, D, generator=g)).to(dev)
+    dout[~rows_ok] = 0
+    oa.backward(dout.float())
+    dqkv = torch.zeros(B * R, 3 * D, device=dev, dtype=torch.bfloat16)
+    ops.attn_bwd(qkv[:, :D], qkv[:, D: 2 * D], qkv[:, 2 * D:], out, dout, lse2, vl, dqkv[:, :D], dqkv[:, D: 2 * D], dqkv[:, 2 * D:],
+                 B, R, H, 64 ** -0.5, drop_p=p, drop_seed=seed)
+    for i, t in enumerate((qa, ka, va)):
+        gref = t.grad.transpose(1, 2).reshape(B * R, D)
+        assert rel_l2(dqkv[rows_ok, i * D: (i + 1) * D], gref[rows_ok]) < 3e-2, i
 
 
 @pytest.mark.parametrize("D,H,S,p_drop", [(768, 1, 37, 0.0), (256, 2, 150, 0.0), (256, 2, 70, 0.25)])

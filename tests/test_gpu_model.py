@@ -256,7 +256,8 @@ def test_trainer_side_stream_schedule_matches_synchronous():
     assert finals[0][0][2] < finals[0][0][0]
 
 
-def test_unfrozen_hubert_layers_gradients_vs_oracle():
+@pytest.mark.parametrize("hubert_dropout", [False, True])
+def test_unfrozen_hubert_layers_gradients_vs_oracle(hubert_dropout):
     """audio_encoder.trainable with unfreeze_layers = top two of a 3-layer HuBERT: loss and the gradients of every parameter of
     the unfrozen layers (attention backward, LayerNorm / GELU backward, dgrad and weight-gradient GEMMs) against the oracle's
     autograd through the same layers."""
@@ -286,9 +287,20 @@ def test_unfrozen_hubert_layers_gradients_vs_oracle():
     for b, x in enumerate(wavs):
         wav[b, : len(x)] = x
     batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": img.cuda(), "id": ids.cuda()}
+    enc = model.audio_encoder
+    drop = None
+    if hubert_dropout:          # fairseq's train-mode dropout in the frozen AND the unfrozen layers; masks rebuilt on the host
+        enc.hubert_dropout = True
+        torch.manual_seed(31)
+        enc._drop_calls = 0
+        seed_of = enc._dropout_seeds()
+        enc._drop_calls = 0
     losses_, _, _ = model(batch)
     out = model.compute_loss(losses_)
     out["loss"].backward()
+    if hubert_dropout:
+        pl_ = enc._plan(B, max(lens))
+        drop = _encoder_mask_hook(seed_of, B, pl_.T, 768, 12, pl_.R)
     # oracle: same weights, layers 1 and 2 require grad
     o_arch = oracle.HubertArch.base()
     o_arch.layers = 3
@@ -296,7 +308,7 @@ def test_unfrozen_hubert_layers_gradients_vs_oracle():
     names = [n for n in W if n.startswith("encoder.layers.1.") or n.startswith("encoder.layers.2.")]
     for n in names:
         W[n].requires_grad_(True)
-    hs_o, fl = oracle.speech_encoder_forward(W, o_arch, wavs)
+    hs_o, fl = oracle.speech_encoder_forward(W, o_arch, wavs, drop=drop)
     head_W = {k: v.detach().cpu().float() for k, v in model.parallel_branch.state_dict().items()}
     ws_w = model.audio_encoder.weightedsum_layer.weights.detach().cpu()
     feat = oracle.weighted_sum(ws_w, list(hs_o), False)
@@ -435,12 +447,29 @@ def test_edge_batches_single_utterance_and_very_short_utterance(setup):
         assert float(F.cosine_similarity(out, e, dim=-1).min()) > 0.999, lens
 
 
+def _encoder_mask_hook(seed_of, B, T, D, H, R, p=0.1):
+    """oracle ``drop`` hook that rebuilds the kernels' stateless hash masks on the host (site numbering of
+    speech_encoder._encode_kernels: 0 input, 1 encoder, 3 i + 2 attention, 3 i + 3 out_proj, 3 i + 4 fc2 of layer i)."""
+    from test_gpu_kernels import _keep_mask
+    site_of = {"input": lambda i: 0, "encoder": lambda i: 1, "attn": lambda i: 3 * i + 2, "dropout1": lambda i: 3 * i + 3,
+               "dropout3": lambda i: 3 * i + 4}
+    b_, t_, d_ = np.meshgrid(np.arange(B), np.arange(T), np.arange(D), indexing="ij")
+    row_idx = ((b_ * R + t_) * D + d_).astype(np.int64)
+    bb, hh, qq, kk = np.meshgrid(np.arange(B), np.arange(H), np.arange(T), np.arange(T), indexing="ij")
+    att_idx = (((bb * H + hh) * R + qq) * R + kk).astype(np.int64)
+
+    def drop(site, layer, t):
+        keep = _keep_mask(att_idx if site == "attn" else row_idx, seed_of(site_of[site](layer)), p)
+        return t * torch.from_numpy(keep).float() / (1.0 - p)
+
+    return drop
+
+
 def test_encoder_train_mode_dropout_vs_oracle(setup):
     """The reference's TRAINING step runs the frozen HuBERT in train mode (oracle/hubert_ref.py hubert_forward): dropout_input,
     the dropout after the encoder LayerNorm and, per layer, attention / out_proj / fc2 dropout are live (p = 0.1, base).  The
     kernels' masks are stateless hashes of (element, seed) (csrc/sc_common.h), so the host rebuilds every mask from the seeds of
     the call and feeds them to the oracle: all 13 hidden states must agree as in eval mode."""
-    from test_gpu_kernels import _keep_mask
     model, sd, o_arch, head_W, oracle = setup
     enc = model.audio_encoder
     g = torch.Generator().manual_seed(12)
@@ -466,18 +495,7 @@ def test_encoder_train_mode_dropout_vs_oracle(setup):
     H, R = 12, (T + 2 + 127) // 128 * 128
     a = enc.arch
     assert (a.dropout, a.attention_dropout, a.dropout_input) == (0.1, 0.1, 0.1)
-    site_of = {"input": lambda i: 0, "encoder": lambda i: 1, "attn": lambda i: 3 * i + 2, "dropout1": lambda i: 3 * i + 3,
-               "dropout3": lambda i: 3 * i + 4}
-    b_, t_, d_ = np.meshgrid(np.arange(B), np.arange(T), np.arange(D), indexing="ij")
-    row_idx = ((b_ * R + t_) * D + d_).astype(np.int64)
-    bb, hh, qq, kk = np.meshgrid(np.arange(B), np.arange(H), np.arange(T), np.arange(T), indexing="ij")
-    att_idx = (((bb * H + hh) * R + qq) * R + kk).astype(np.int64)
-
-    def drop(site, layer, t):
-        seed = seed_of(site_of[site](layer))
-        keep = _keep_mask(att_idx if site == "attn" else row_idx, seed, 0.1)
-        return t * torch.from_numpy(keep).float() / 0.9
-
+    drop = _encoder_mask_hook(seed_of, B, T, D, H, R)
     hs_o, _ = oracle.speech_encoder_forward(sd, o_arch, wavs, drop=drop)
     valid = oracle.fairseq_valid_frames(lens, max(lens), T)
     zero_frac = float((hs[0][0, : valid[0]] == 0).float().mean())
