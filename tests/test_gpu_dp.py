@@ -122,12 +122,12 @@ def test_rccl_backend_one_rank_rehearsal(unfreeze):
     assert float((flat1 - torch.from_numpy(flat_r)).norm() / flat1.norm()) < 1e-5
 
 
-def _worker_dropout(rank, world, port, q):
+def _worker_dropout(rank, world, port, q, unfreeze=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(123)                                      # same torch seed on both ranks: the rank enters the mask seeds itself
-    model, trainer = _make(False, dropout=True)
+    model, trainer = _make(unfreeze, dropout=True)
     n = 8 // world
     batch = _batch(rank * n, (rank + 1) * n)
     enc = model.audio_encoder
@@ -141,13 +141,14 @@ def _worker_dropout(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_with_train_mode_dropout_stay_in_sync():
+@pytest.mark.parametrize("unfreeze", [False, True])
+def test_two_ranks_with_train_mode_dropout_stay_in_sync(unfreeze):
     """The reference's train step has dropout live: each rank draws its OWN masks (the rank enters the seeds), the all-reduced
     gradient is the same everywhere, so the replicas' parameters must remain bit-identical after the optimiser steps."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_dropout, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_dropout, args=(r, 2, port, q, unfreeze)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict()
