@@ -537,3 +537,30 @@ def test_speech_encoder_api_like_the_reference_test():
         assert model.downsample_rate == 320
         for h in range(len(feat_hid)):
             assert abs(feat_hid[h].shape[1] - feat_len.max().item()) <= 2
+
+
+def test_long_utterance_geometry_vs_oracle():
+    """15 s next to 6.25 s (T = 749 -> R = 768, six 128-row attention blocks, conv rows R_l = 768 * 2^(6-l)): hidden states vs the
+    oracle on a 3-layer encoder; exercises a padded-row geometry other than the benchmark's R = 512."""
+    import dataclasses
+    import oracle
+    from speechclip_plus_amd import random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS, FairseqSpeechEncoder_Hubert
+    arch = dataclasses.replace(ARCHS["hubert"], layers=3)
+    sd = random_hubert_state_dict(arch, seed=3)
+    enc = FairseqSpeechEncoder_Hubert(name="hubert", device="cuda:0", feat_select_idx="all", state_dict=sd, arch=arch).eval()
+    g = torch.Generator().manual_seed(2)
+    lens = [240000, 100000]
+    wavs = [torch.randn(l, generator=g) * 0.3 for l in lens]
+    with torch.no_grad():
+        feat, feat_len = enc([w.cuda() for w in wavs])
+        hs = [h.clone() for h in feat["hidden_states"]]
+    o_arch = oracle.HubertArch.base()
+    o_arch.layers = 3
+    hs_o, fl_o = oracle.speech_encoder_forward(sd, o_arch, wavs)
+    T = hs_o[0].shape[1]
+    assert T == 749 and hs[0].shape == (2, T, 768) and feat_len.cpu().tolist() == fl_o.tolist()
+    valid = oracle.fairseq_valid_frames(lens, max(lens), T)
+    for n in range(4):
+        for b, v in enumerate(valid):
+            assert rel_l2(hs[n][b, :v], hs_o[n][b, :v]) < 2e-2, (n, b)
