@@ -20,8 +20,8 @@ __global__ __launch_bounds__(256) void sgemm_ex_kernel(const float* __restrict__
                                                        float* __restrict__ C, int64_t ldc, int64_t scz, int M, int N, int K,
                                                        float alpha, float beta, const float* __restrict__ bias,
                                                        int64_t sbiasz, int S, int Kc, float* __restrict__ P) {
-    __shared__ float As[TK][TS + 4];
-    __shared__ float Bs[TK][TS + 4];
+    __shared__ __attribute__((aligned(16))) float As[TK][TS + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[TK][TS + 4];
     // split-K: blockIdx.z = z * S + ks ; slice ks reduces k in [ks Kc, min(K, (ks + 1) Kc)) into the workspace P[ks][z][M][N]
     const int z = blockIdx.z / S, ks = blockIdx.z - z * S;
     A += z * saz + (int64_t)ks * Kc * sak;
@@ -38,18 +38,52 @@ __global__ __launch_bounds__(256) void sgemm_ex_kernel(const float* __restrict__
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
     const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);   // make the unit-stride dimension the fast thread index
+    // one 16-byte load per thread and operand when the unit-stride dimension allows it (aligned base, stride and extent multiples
+    // of 4): k-fast -> 4 consecutive k of one row, otherwise 4 consecutive rows of one k
+    const bool a_vec = (K % 4 == 0) && (((uintptr_t)A % 16) == 0) &&
+                       (a_kfast ? (sai % 4 == 0) : (sai == 1 && sak % 4 == 0 && M % 4 == 0));
+    const bool b_vec = (K % 4 == 0) && (((uintptr_t)Bm % 16) == 0) &&
+                       (b_kfast ? (sbj % 4 == 0) : (sbj == 1 && sbk % 4 == 0 && N % 4 == 0));
     for (int k0 = 0; k0 < K; k0 += TK) {
+        if (a_vec) {
+            if (a_kfast) {
+                const int kk = (tid & 3) * 4, ii = tid >> 2, gi = i0 + ii, gk = k0 + kk;
+                const f32x4 v = (gi < M && gk < K) ? *(const f32x4*)(A + gi * sai + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+                As[kk][ii] = v[0]; As[kk + 1][ii] = v[1]; As[kk + 2][ii] = v[2]; As[kk + 3][ii] = v[3];
+            } else {
+                const int ii = (tid & 15) * 4, kk = tid >> 4, gi = i0 + ii, gk = k0 + kk;
+                const f32x4 v = (gi < M && gk < K) ? *(const f32x4*)(A + gi + gk * sak) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *(f32x4*)&As[kk][ii] = v;
+            }
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int id = tid + e * 256;
-            int ii, kk;
-            if (a_kfast) { kk = id & 15; ii = id >> 4; } else { ii = id & 63; kk = id >> 6; }
-            const int gi = i0 + ii, gk = k0 + kk;
-            As[kk][ii] = (gi < M && gk < K) ? A[gi * sai + gk * sak] : 0.f;
-            int jj, kb;
-            if (b_kfast) { kb = id & 15; jj = id >> 4; } else { jj = id & 63; kb = id >> 6; }
-            const int gj = j0 + jj, gkb = k0 + kb;
-            Bs[kb][jj] = (gj < N && gkb < K) ? Bm[gj * sbj + gkb * sbk] : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const int id = tid + e * 256;
+                int ii, kk;
+                if (a_kfast) { kk = id & 15; ii = id >> 4; } else { ii = id & 63; kk = id >> 6; }
+                const int gi = i0 + ii, gk = k0 + kk;
+                As[kk][ii] = (gi < M && gk < K) ? A[gi * sai + gk * sak] : 0.f;
+            }
+        }
+        if (b_vec) {
+            if (b_kfast) {
+                const int kb = (tid & 3) * 4, jj = tid >> 2, gj = j0 + jj, gkb = k0 + kb;
+                const f32x4 v = (gj < N && gkb < K) ? *(const f32x4*)(Bm + gj * sbj + gkb) : f32x4{0.f, 0.f, 0.f, 0.f};
+                Bs[kb][jj] = v[0]; Bs[kb + 1][jj] = v[1]; Bs[kb + 2][jj] = v[2]; Bs[kb + 3][jj] = v[3];
+            } else {
+                const int jj = (tid & 15) * 4, kb = tid >> 4, gj = j0 + jj, gkb = k0 + kb;
+                const f32x4 v = (gj < N && gkb < K) ? *(const f32x4*)(Bm + gj + gkb * sbk) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *(f32x4*)&Bs[kb][jj] = v;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int id = tid + e * 256;
+                int jj, kb;
+                if (b_kfast) { kb = id & 15; jj = id >> 4; } else { jj = id & 63; kb = id >> 6; }
+                const int gj = j0 + jj, gkb = k0 + kb;
+                Bs[kb][jj] = (gj < N && gkb < K) ? Bm[gj * sbj + gkb * sbk] : 0.f;
+            }
         }
         __syncthreads();
 #pragma unroll
