@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void cls_scores_kernel(const uint16_t* __restr
             const int ch = lane + 64 * c;
             vr[h][c] = ch < nchunks ? *(const f32x4*)(vs + (h * nchunks + ch) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    constexpr int ROWS = 32, RPW = ROWS / 4;          // rows per block / per wave
+    constexpr int ROWS = 64, RPW = ROWS / 4;          // rows per block / per wave
     const int s0 = blockIdx.x * ROWS + wave * RPW;
 #pragma unroll
     for (int g = 0; g < RPW; g += 4) {
@@ -254,7 +254,7 @@ extern "C" int sc_cls_scores(const sc_bf16* X, const float* vec, int64_t vec_bst
     SC_CHECK(D % 4 == 0 && ((uintptr_t)X % 8) == 0 && ((uintptr_t)vec % 16) == 0 && vec_bstride % 4 == 0,
              "sc_cls_scores: alignment");
     SC_CHECK(D <= 1024, "sc_cls_scores: D=%d must be <= 1024", D);
-    dim3 grid((R + 31) / 32, B);
+    dim3 grid((R + 63) / 64, B);
     hipStream_t s = (hipStream_t)stream;
     const int nch = (D / 4 + 63) / 64;
 #define SC_CS(NH, NC) hipLaunchKernelGGL((cls_scores_kernel<NH, NC>), grid, dim3(256), 0, s, X, vec, vec_bstride, scores, R, D, H, h0)
