@@ -225,7 +225,12 @@ def pmc_traffic(kernel_substr):
     (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH x2 gfx950 correction; tools/summarize_pmc.py).  bench.py
     cannot collect hardware counters itself, so it reports the newest profiles/*_traffic.json (or null)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    import re
+
+    def version(path):                      # profiles/rNN_vMM_*: numeric order (r01_v10 after r01_v9)
+        m = re.search(r"r(\d+)_v(\d+)", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=version)
     if not files:
         return {"traffic": None}
     data = json.load(open(files[-1]))
