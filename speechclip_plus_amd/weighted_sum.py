@@ -32,7 +32,7 @@ class _WeightedSumFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, h, B, R, D, normalize):
         w_soft = torch.softmax(weights.float(), dim=0).contiguous()
-        out = torch.zeros(B, R, D, device=h.device, dtype=torch.bfloat16)
+        out = torch.empty(B, R, D, device=h.device, dtype=torch.bfloat16)      # every row is written (row offset 0)
         ops.wsum_fwd(h, w_soft, out, B, R, D, 0, normalize)
         ctx.save_for_backward(h, w_soft)
         ctx.dims = (B, R, D, normalize)
@@ -55,7 +55,8 @@ class _WeightedSumSrcFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, hidden, B, R, D, normalize):
         w_soft = torch.softmax(weights.detach().float(), dim=0).contiguous()
-        src = torch.zeros(B, R, D, device=hidden.device, dtype=torch.bfloat16)
+        src = torch.empty(B, R, D, device=hidden.device, dtype=torch.bfloat16)
+        src[:, 0].zero_()                    # rows 1 .. R - 1 are written by the kernel; row 0 is the CLS slot
         ops.wsum_fwd(hidden, w_soft, src, B, R, D, 1, normalize)
         ctx.save_for_backward(hidden, w_soft)
         ctx.dims = (B, R, D, normalize)
