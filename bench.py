@@ -183,9 +183,17 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"[top {args.unfreeze} HuBERT layers unfrozen: fwd + bwd + Adam] " if args.unfreeze else "") +
-                                   f"Parallel SpeechCLIP {args.model} train step (HuBERT-{args.model} frozen fwd + weighted sum + CLS "
-                                   f"attention-pool head fwd/bwd + InfoNCE fwd/bwd + Adam), {B} utt/GPU x {args.seconds:g} s "
-                                   f"(L={L}, T={T}), CLIP image embeddings given",
+                                   {"base": "Parallel SpeechCLIP base train step (HuBERT-base frozen fwd + weighted sum + CLS "
+                                            "attention-pool head fwd/bwd + InfoNCE fwd/bwd + Adam)",
+                                    "large": "Parallel SpeechCLIP large train step (HuBERT-large frozen fwd + normalised weighted sum + "
+                                             "CLS attention-pool head fwd/bwd + InfoNCE fwd/bwd + Adam)",
+                                    "cascaded_plus": "Cascaded+ base train step (HuBERT-base frozen fwd + weighted sum + attention block + "
+                                                     "CIF + keyword projection / BatchNorm / VQ + frozen CLIP text tower, fwd/bwd + InfoNCE "
+                                                     "+ quantity loss + Adam)",
+                                    "hybrid_plus_large": "Hybrid+ large train step (HuBERT-large frozen fwd + weighted sum + shared attention "
+                                                         "block: CLS row -> parallel embedding, frames -> CIF / VQ / frozen CLIP ViT-L/14 text "
+                                                         "tower, fwd/bwd + both InfoNCE losses + quantity loss + Adam)"}[args.model] +
+                                   f", {B} utt/GPU x {args.seconds:g} s (L={L}, T={T}), CLIP image embeddings given",
                        "global_batch": B * world, "per_gpu_batch": B, "audio_samples": L, "frames": T,
                        "parallelism": f"dp{world}", "dropout": ("off (--no-dropout)" if args.no_dropout else
                                    "on, as the reference's train step: HuBERT in train mode (base: input / residual / attention "
