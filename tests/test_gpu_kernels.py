@@ -891,3 +891,36 @@ def test_cif_fire_kernels_vs_scatter_add(dev, C, S, train):
     assert rel_l2(y1, y0) < 1e-5
     if train:
         assert rel_l2(dx1, dx0) < 1e-5 and rel_l2(da1, da0) < 1e-4
+
+
+@pytest.mark.parametrize("n,p_drop", [(72, 0.0), (512, 0.0), (1024, 0.2), (260, 0.5)])
+def test_softmax_rows_fwd_bwd_vs_torch(dev, n, p_drop):
+    """csrc/softmax.hip on its own: masked row softmax (+ hash dropout) and its backward against fp32 torch, row lengths that use
+    1, 2 and 4 chunks per lane, fully masked rows, the host-rebuilt dropout mask."""
+    import numpy as np
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(n)
+    nb, rpb, seed, scale = 3, 40, 0x51f15e, 0.37
+    rows = nb * rpb
+    scores = (torch.randn(rows, n, generator=g) * 3).to(dev)
+    mask = torch.rand(nb, n, generator=g) < 0.3
+    mask[1] = True                                                     # one batch with every key padded: probabilities all 0
+    mask_d = mask.to(dev).to(torch.uint8).contiguous()
+    P, Pd = ops.softmax_fwd(scores, mask_d, rpb, scale, p_drop, seed)
+    mrow = mask.to(dev).repeat_interleave(rpb, dim=0)
+    sr = scores.clone().requires_grad_()
+    ref = torch.softmax((sr * scale).masked_fill(mrow, float("-inf")), dim=-1)
+    ref = torch.nan_to_num(ref, nan=0.0)
+    live = ~mrow.all(dim=1)
+    assert rel_l2(P[live], ref[live]) < 4e-3 and float(P[~live].float().abs().max()) == 0.0
+    keep = torch.ones(rows, n, device=dev)
+    if p_drop > 0:
+        keep = torch.from_numpy(_keep_mask(np.arange(rows * n, dtype=np.int64), seed, p_drop)).view(rows, n).to(dev).float() / (1 - p_drop)
+        assert rel_l2(Pd[live], (ref * keep)[live]) < 4e-3
+    else:
+        assert Pd is P
+    dPd = torch.randn(rows, n, generator=g).to(dev)
+    (ref * keep * dPd)[live].sum().backward()
+    dS = ops.softmax_bwd(dPd, P, scale, p_drop, seed)
+    # the kernel differentiates through the bf16-rounded P it is given: compare against the fp32 gradient at bf16 tolerance
+    assert rel_l2(dS[live], sr.grad[live]) < 1.5e-2
