@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """The C-ABI library is a build artefact (git-ignored).  On a checkout where __graft_entry__.build() has not run yet, build it
+    once (hipcc cross-compiles gfx950 without a GPU); if that is impossible the tests that need it fail loudly on their own."""
+    lib = os.path.join(ROOT, "speechclip_plus_amd", "csrc", "libspeechclip_hip.so")
+    if not os.path.exists(lib):
+        try:
+            from speechclip_plus_amd.build import build
+            build(verbose=False)
+        except Exception as e:       # noqa: BLE001 - reported, not hidden: the symbol-export test will fail with the real cause
+            print(f"[conftest] could not build libspeechclip_hip.so: {e}", file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
