@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py - utterances/s of one contrastive train step (frozen-HuBERT parallel-base recipe) on N MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+environment), or started plainly - then this process, BEFORE any GPU call, starts the N ranks as a child
+`python -m torch.distributed.run` (127.0.0.1 rendezvous), relays rank 0's JSON line and exits with the child's code.
+The parent never touches the GPU.
 
 Workload (BASELINE.json configs[1]): Parallel SpeechCLIP base, bf16, batch 64 per GPU x 10 s synthetic audio
 (L = 160000 -> T = 499 frames), frozen HuBERT-base forward + weighted sum + CLS attention-pooling head
@@ -46,9 +51,16 @@ def main():
     ap.add_argument("--model", choices=["base", "large", "cascaded_plus", "hybrid_plus_large"], default="base",
                     help="base = BASELINE configs[1] (headline); large = Parallel large; cascaded_plus = configs[2]; "
                          "hybrid_plus_large = configs[4] recipe on one GPU")
+    ap.add_argument("--rehearse-launch", action="store_true", help="launch plumbing only, no GPU: the ranks rendezvous, issue the "
+                    "step's two collectives (packed all-gather, flat all-reduce) on CPU tensors and rank 0 prints the JSON line "
+                    "with value null (tests/test_dp_gloo.py runs this with SC_DIST_BACKEND=gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rehearse_launch:
+        return rehearse_launch(args, world)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or os.environ.get("SC_FORCE_COLLECTIVES", "0") == "1":   # the latter: one-rank RCCL rehearsal (parallel.dp_world)
@@ -68,6 +80,7 @@ def main():
         torch.cuda.set_device(local_rank)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = count_ranks(dist, dev)
 
     from speechclip_plus_amd import (KWClip_GeneralTransformer, base_parallel_config, cascaded_plus_base_config,
                                      hybrid_plus_large_config, large_parallel_config, ops, random_hubert_state_dict)
@@ -198,11 +211,69 @@ def main():
                        "parallelism": f"dp{world}", "dropout": ("off (--no-dropout)" if args.no_dropout else
                                    "on, as the reference's train step: HuBERT in train mode (base: input / residual / attention "
                                    "p=0.1; large: 0) + head p=0.1; masks = stateless hash inside the GEMM / attention kernels")},
+            "rccl_ranks": rccl_ranks, "dist_backend": (os.environ.get("SC_DIST_BACKEND", "nccl") if dist is not None else None),
             "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,
             "forward": None if fwd_ms is None else forward_summary(fwd_ms, B, L, T),
         }
         print(json.dumps(result), flush=True)
     if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def launch_ranks(n: int) -> int:
+    """Parent of a plain `bench.py --gpus N` call: start the N ranks as ONE child process tree (torch.distributed.run) and
+    return its exit code.  Nothing here touches the GPU (no HIP call, no torch.cuda.* query): the children initialise it."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: the only mode this pool's driver supports
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def count_ranks(dist, dev) -> int:
+    """Number of ranks that really took part: an all-reduce (SUM) of ones through the backend in use."""
+    if dist is None:
+        return 1
+    one = torch.ones(1, device=dev if os.environ.get("SC_DIST_BACKEND", "nccl") == "nccl" else "cpu")
+    dist.all_reduce(one)
+    return int(round(float(one.item())))
+
+
+def rehearse_launch(args, world: int) -> None:
+    """--rehearse-launch: everything of the N-rank run except the GPU work (this container has no GPU)."""
+    import torch.distributed as dist
+    from speechclip_plus_amd.parallel import GradAllReduce, gather_loss_feats
+    rank = int(os.environ.get("RANK", "0"))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(os.environ.get("SC_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
+    ranks = count_ranks(dist if world > 1 else None, "cpu")
+    B, E = args.batch, 512
+    g = torch.Generator().manual_seed(rank)
+    a = torch.randn(B, E, generator=g, requires_grad=True)
+    a_all, i_all, id_all = gather_loss_feats(a, torch.randn(B, E, generator=g), torch.arange(B) + rank * B)
+    assert a_all.shape[0] == B * world and id_all.tolist() == list(range(B * world))
+    a_all.sum().backward()
+    flat = torch.full((1000,), float(rank + 1))
+    ar = GradAllReduce(flat)
+    ar.launch()
+    ar.wait()
+    assert float(flat[0]) == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"metric": "utterances/sec (train step)", "value": None, "unit": "utterances/s", "n_gpus": world,
+                          "steps": 0, "warmup": 0, "rehearsal": "launch plumbing only (no GPU work)", "rccl_ranks": ranks,
+                          "dist_backend": os.environ.get("SC_DIST_BACKEND", "gloo") if world > 1 else None}), flush=True)
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

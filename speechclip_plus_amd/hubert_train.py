@@ -70,6 +70,9 @@ class TrainableLayers(nn.Module):
         self._copies, self._versions = {}, None
         self.grad_ready_hook = None              # callable(layer_id): every gradient of that layer has been enqueued (train.py)
 
+    def invalidate(self) -> None:
+        self._versions = None
+
     def layer_parameters(self, i: int) -> List[nn.Parameter]:
         return [self.p[_key(i, name)] for name in _PARAMS]
 
@@ -77,8 +80,11 @@ class TrainableLayers(nn.Module):
         return self.p[_key(i, name)] if i in self.ids else self._frozen[i][name]
 
     def refresh(self) -> None:
-        """bf16 working copies (+ transposed ones for the dgrad products) of the fp32 masters, rebuilt after an optimiser step."""
-        ver = tuple((p.data_ptr(), p._version) for p in self.p.values())
+        """bf16 working copies (+ transposed ones for the dgrad products) of the fp32 masters, rebuilt after an optimiser step.
+        The fused Adam kernel writes the masters through a raw pointer (no ``_version`` bump), so the cache key also carries
+        optim.param_generation(); ``invalidate()`` forces a rebuild after any other out-of-band write."""
+        from .optim import param_generation
+        ver = (param_generation(),) + tuple((p.data_ptr(), p._version) for p in self.p.values())
         if ver == self._versions:
             return
         bf = lambda t: t.detach().to(torch.bfloat16).contiguous()

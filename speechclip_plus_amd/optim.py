@@ -28,6 +28,16 @@ def noam(step: int, warmup: int = 4000) -> float:
     return n / warmup if step < warmup else (warmup / n) ** 0.5
 
 
+_GENERATION = [0]
+
+
+def param_generation() -> int:
+    """Counts optimiser steps of every FlatAdam in the process.  ``sc_adam_f32`` updates the parameters through a raw pointer,
+    which bumps no tensor ``_version``: anything that caches a function of the parameters (the bf16 working copies of
+    hubert_train.TrainableLayers) keys on this counter instead."""
+    return _GENERATION[0]
+
+
 class FlatAdam:
     """torch.optim.Adam semantics (L2 weight decay folded into the gradient, bias correction) over one flat
     buffer; gradient clipping by global norm (trainer.gradient_clip_val) fused into the same launch."""
@@ -78,6 +88,7 @@ class FlatAdam:
 
     def step(self, lr: Optional[float] = None) -> None:
         self.step_count += 1
+        _GENERATION[0] += 1
         gn = ops.sumsq(self.flat_g) if self.max_grad_norm > 0 else None
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr if lr is None else lr, self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, self.step_count, gn, float(self.max_grad_norm))

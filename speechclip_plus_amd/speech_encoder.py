@@ -496,6 +496,10 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             for b, x in enumerate(wav):
                 padded[b, : lens[b]] = x.to(self._dev, torch.float32)
         save = self.train_layers is not None and self.training and torch.is_grad_enabled()
+        if self.train_layers is not None and self.before_trainable is not None:
+            # unfrozen layers read their parameters (refresh(): bf16 copies; LayerNorm affine and biases alias the masters) inside
+            # the encoder: join the optimiser's side stream BEFORE the first kernel, not at the weighted sum
+            self.before_trainable()
         pl = self._encode(padded, lens, save)
         B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
         hidden_states = tuple(pl.hidden[n].view(B, R, D)[:, :T] for n in range(self.arch.layers + 1))

@@ -7,7 +7,9 @@ Stream schedule: the gradient all-reduce, the clip + Adam launch and the zeroing
 SIDE stream after the backward.  HuBERT is frozen in every shipped recipe, so the next step's encoder forward (12 of the
 13 ms) touches no trainable parameter: the main stream joins the side stream only right before the first trainable module
 of the next step (the weighted sum at the end of the encoder).  The collective and the optimiser therefore run under the next
-encoder forward instead of extending the step."""
+encoder forward instead of extending the step.  With unfrozen HuBERT layers (hubert_train.py) that premise does not hold - the
+encoder reads trainable parameters from its first unfrozen layer on - so the encoder joins at the top of its forward instead
+(speech_encoder.forward) and only the per-layer gradient all-reduces overlap (with the backward of the layers below)."""
 from typing import Optional
 
 import torch

@@ -71,3 +71,25 @@ def test_gather_and_allreduce_world2():
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] for r in res), res
+
+
+@pytest.mark.timeout(180)
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` as the driver calls it (no WORLD_SIZE in the environment): the parent starts the two ranks
+    itself, they rendezvous on 127.0.0.1, run the step's collectives (here on CPU tensors over gloo: --rehearse-launch, the
+    container has no GPU) and exactly one JSON line with n_gpus = rccl_ranks = 2 comes back with exit code 0."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SC_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch", "--batch", "4"],
+                       env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["dist_backend"] == "gloo"
+    # a failing rank must surface as a non-zero exit code of the parent
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch", "--batch", "-1"],
+                       env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode != 0

@@ -256,6 +256,52 @@ def test_trainer_side_stream_schedule_matches_synchronous():
     assert finals[0][0][2] < finals[0][0][0]
 
 
+def test_unfrozen_layers_follow_the_optimiser_and_side_stream_matches_synchronous():
+    """Unfrozen HuBERT layers over several optimiser steps: (1) the bf16 working copies the forward / dgrad kernels read are the
+    CURRENT fp32 masters after every step (sc_adam_f32 writes through a raw pointer: no tensor version changes, the copies key on
+    optim.param_generation()); (2) the loss keeps falling over 4 steps on one batch (stale forward weights made it stall or
+    diverge); (3) the side-stream schedule (join at the top of the encoder forward when layers are unfrozen) leaves bitwise the
+    parameters of the one-stream schedule."""
+    import dataclasses
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    arch = dataclasses.replace(ARCHS["hubert"], layers=3)
+    sd = random_hubert_state_dict(arch, seed=4)
+    g = torch.Generator().manual_seed(12)
+    B, L = 6, 9000
+    batch = {"wav": torch.randn(B, L, generator=g).cuda(), "wav_len": torch.tensor([9000, 7000, 9000, 5000, 8000, 9000]),
+             "image": torch.randn(B, 512, generator=g).cuda(), "id": torch.tensor([0, 1, 1, 2, 3, 4]).cuda()}
+    finals = []
+    for sync in (False, True):
+        torch.manual_seed(4)
+        cfg = base_parallel_config()
+        cfg.audio_encoder.max_audio_len = -1
+        cfg.audio_encoder.trainable = True
+        cfg.audio_encoder.unfreeze_layers = [1, 2]
+        cfg.audio_encoder.optim.args.lr = 1e-3              # large enough for the bf16 copies to move every step
+        model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
+        trainer = ContrastiveTrainer(model)
+        if sync:
+            trainer.side = None
+        tl = model.audio_encoder.train_layers
+        losses, prev = [], None
+        for step in range(4):
+            losses.append(float(trainer.step(batch)))
+            torch.cuda.synchronize()
+            # the copies used by the step that just ran were built from the masters as they stood BEFORE its Adam update
+            w_now = tl.get(2, "fc1.weight").detach().to(torch.bfloat16)
+            if prev is not None:
+                assert torch.equal(tl._copies[2]["fc1_w"], prev), f"step {step}: forward ran on stale bf16 weights"
+                assert torch.equal(tl._copies[2]["fc1_wT"], prev.t().contiguous())
+            assert not torch.equal(w_now, tl._copies[2]["fc1_w"]), "lr too small for this check"
+            prev = w_now.clone()
+        assert losses[3] < losses[1] < losses[0], losses
+        finals.append((losses, trainer.opt.flat_p.clone()))
+    assert finals[0][0] == finals[1][0], (finals[0][0], finals[1][0])
+    assert torch.equal(finals[0][1], finals[1][1])
+
+
 @pytest.mark.parametrize("hubert_dropout", [False, True])
 def test_unfrozen_hubert_layers_gradients_vs_oracle(hubert_dropout):
     """audio_encoder.trainable with unfreeze_layers = top two of a 3-layer HuBERT: loss and the gradients of every parameter of
