@@ -215,6 +215,68 @@ int sc_cif_fwd(const float* x, const float* alpha, const float* csum, float* out
 int sc_cif_bwd(const float* x, const float* alpha, const float* csum, const float* g, float* dx, float* pa, float* pb, int32_t B,
                int32_t S, int32_t C, int32_t T, float thr, void* stream);
 
+/* CIF bookkeeping on the device (avssl/module/cif.py:106-175, 244-297), one workgroup per utterance, no host round trip.
+ *   sc_cif_prepare: a = clip(alpha_raw, 0, 1), padded frames (pad != 0) zeroed -> a_clip [B,S] ("orig_alpha") ; quantity = sum a ;
+ *     if target && apply_scaling: a *= (thr * target + eps) / quantity (ratio [B] kept for the backward) ; alpha [B,S] ;
+ *     csum = inclusive scan [B,S] ; feat_len = clip(floor(sum alpha / thr), 1, max_feat) ; fired [B,S] = slot index advances at the
+ *     frame (indices clipped at T) ; flags[0] += (quantity > 0) (the reference asserts that not ALL utterances are zero) ;
+ *     flags[1] += (feat_len != clip(target, 1, max_feat)) when scaling (the caller sized the output from target).  fp64 sums.
+ *   sc_cif_prepare_bwd: pa / pb of sc_cif_bwd + d quantity (gq, may be NULL) -> d alpha_raw [B,S] (suffix sum of d csum, scaling).
+ *   sc_cif_tail (inference): tail weight of slot feat_len >= tail_thr -> that row *= thr / weight, feat_len += 1 (clip max_feat),
+ *     rows >= feat_len zeroed in out [B,T+1,C]; factor / extend [B] returned for the caller's backward / diagnostics.    S <= 2048. */
+int sc_cif_prepare(const float* alpha_raw, int64_t lda, const uint8_t* pad, int64_t ldp, const int64_t* target, int32_t apply_scaling,
+                   int32_t B, int32_t S, float thr, float eps, int32_t max_feat, int32_t T, float* a_clip, float* alpha, float* csum,
+                   float* quantity, float* ratio, int64_t* feat_len, uint8_t* fired, int32_t* flags, void* stream);
+int sc_cif_prepare_bwd(const float* pa, const float* pb, int32_t nblk, int32_t B, int32_t S, const float* a_clip, const uint8_t* pad,
+                       int64_t ldp, const float* ratio, const float* quantity, const float* gq, int32_t scaled, float* da, void* stream);
+int sc_cif_tail(const float* alpha, const float* csum, int32_t B, int32_t S, int32_t C, int32_t T, float thr, float tail_thr,
+                int32_t max_feat, int64_t* feat_len, float* out, float* factor, uint8_t* extend, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Keyword -> CLIP sub-word vector quantiser (cascaded+/hybrid+ tails; csrc/vq.hip).
+ *   replaces: GeneralBranch.get_keyword_cosine_score / vq_audio_features (avssl/model/kw_branches.py:158-197) and
+ *             SimpleVectorQuantizer.forward (avssl/module/speechclip_c_modules/my_vector_quantizer.py:64-165).
+ *   sc_vq_prep_f32     kw [Nk, Et] (row stride ldk) -> kwn_T [Et][ldt] = (kw / max(|kw|, eps))^T (columns >= Nk zero; ldt % 64 == 0),
+ *                      rnorm [Nk] = 1 / max(|kw|, eps)                                       (F.normalize, kw_branches.py:170-173)
+ *   sc_sgemm_mfma_f32  C [M, N] = A . B^T (+ bias[n]) in exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32): the cosine scores
+ *                      decide an argmax over the vocabulary and the CIF weights a floor(), so no reduced-precision operand.
+ *                      A: [M][K] row-major (a_kmajor 0) or [K][M] (a_kmajor 1); B: [N][K] (the nn.Linear layout) or [K][N].
+ *                      lda / ldb % 4 == 0, 16-byte aligned operands, row-major operands K % 4 == 0; any M, N
+ *   sc_vq_rowstats     x [Nk, ldx] fp32, V columns: columns listed in mask_cols_host (<= 4, host array: the special tokens 0, 2, 3) are
+ *                      set to -inf IN PLACE (the reference's x[:, i] += -inf), idx = first argmax, lse_t = LSE(x / temp),
+ *                      lse_1 = LSE(x), ent = - sum p log(p + 1e-9) with p = softmax(x)       (my_vector_quantizer.py:80-116)
+ *   sc_vq_perplexity   out2[0] = code_perplexity (histogram of idx), out2[1] = prob_perplexity (column means of softmax(x));
+ *                      workspaces: partial [nchunk, V] fp32, hist [V] int32
+ *   sc_vq_gather_f32   out[n] = table[idx[n]]   (= hard one-hot @ token_embedding)
+ *   sc_vq_onehot_f32   dense hard one-hot [Nk, ldo] (module-level subword_prob)
+ *   sc_vq_soft_bwd     dx = softmax(x / temp) (t - <softmax, t>) / temp, t = d subword_prob [Nk, ldt]; out bf16 (feeds the bf16
+ *                      GEMM dx . normalised table) or fp32; columns V .. Vpad - 1 zero-filled         (straight-through estimator)
+ *   sc_vq_norm_bwd_f32 gradient through x / max(|x|, eps)
+ * ---------------------------------------------------------------------------------------------- */
+int sc_vq_prep_f32(const float* kw, int64_t ldk, int32_t Nk, int32_t Et, float eps, float* kwn_T, int64_t ldt, float* rnorm, void* stream);
+int sc_sgemm_mfma_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc,
+                      int32_t M, int32_t N, int32_t K, const float* bias, void* stream);
+int sc_vq_rowstats(float* x, int64_t ldx, int32_t Nk, int32_t V, float temp, const int32_t* mask_cols_host, int32_t n_mask, int64_t* idx,
+                   float* lse_t, float* lse_1, float* ent, void* stream);
+int sc_vq_perplexity(const float* x, int64_t ldx, int32_t Nk, int32_t V, const int64_t* idx, const float* lse_1, float* partial,
+                     int32_t nchunk, int32_t* hist, float* out2, void* stream);
+int sc_vq_gather_f32(const float* table, int64_t ldt, const int64_t* idx, float* out, int64_t ldo, int32_t Nk, int32_t Et, void* stream);
+int sc_vq_onehot_f32(const int64_t* idx, float* out, int64_t ldo, int32_t Nk, int32_t V, void* stream);
+int sc_vq_soft_bwd(const float* x, int64_t ldx, const float* lse_t, const float* t, int64_t ldt, int32_t Nk, int32_t V, int32_t Vpad,
+                   float temp, void* dx, int64_t ldd, int32_t out_bf16, void* stream);
+int sc_vq_norm_bwd_f32(const float* kw, int64_t ldk, const float* rnorm, const float* dy, int64_t ldy, float eps, float* dx, int64_t ldd,
+                       int32_t Nk, int32_t Et, void* stream);
+
+/* Keyword BatchNorm: nn.BatchNorm1d over the keyword positions (avssl/module/speechclip_c_modules/kw_bn.py:167-228).
+ *   x [N, E] fp32 (N = batch x keyword slots), per-channel statistics.  training: batch statistics (biased variance for the
+ *   normalisation, unbiased for the running estimate; run_mean / run_var updated in place with `momentum`), save_mean / save_rstd
+ *   kept for the backward; inference: the running estimates.  backward (training statistics): dx, dgamma [E], dbeta [E]. */
+int sc_bn_rows_fwd(const float* x, int64_t ldx, int32_t N, int32_t E, const float* gamma, const float* beta, float* run_mean,
+                   float* run_var, int32_t training, float momentum, float eps, float* y, int64_t ldy, float* save_mean,
+                   float* save_rstd, void* stream);
+int sc_bn_rows_bwd(const float* x, int64_t ldx, const float* dy, int64_t ldg, int32_t N, int32_t E, const float* gamma,
+                   const float* save_mean, const float* save_rstd, float* dx, int64_t ldd, float* dgamma, float* dbeta, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * fp32 strided GEMM  C[i,j] = alpha * sum_k A[i*sai + k*sak] * Bm[j*sbj + k*sbk]  (+ bias[j])
  *   small fp32 products of the loss and of the CLS-row tail (logits = A.B^T / tau, dA = G.B, ...)

@@ -56,6 +56,25 @@ SIGNATURES = {
     "sc_cls_scores": [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "sc_cif_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p],
     "sc_cif_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p],
+    "sc_cif_prepare": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_void_p, c_void_p,
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sc_cif_prepare_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int,
+                           c_void_p, c_void_p],
+    "sc_cif_tail": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                    c_void_p],
+    "sc_vq_prep_f32": [c_void_p, c_i64, c_int, c_int, c_float, c_void_p, c_i64, c_void_p, c_void_p],
+    "sc_sgemm_mfma_f32": [c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sc_vq_rowstats": [c_void_p, c_i64, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                       c_void_p],
+    "sc_vq_perplexity": [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "sc_vq_gather_f32": [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p],
+    "sc_vq_onehot_f32": [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p],
+    "sc_vq_soft_bwd": [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_float, c_void_p, c_i64, c_int, c_void_p],
+    "sc_vq_norm_bwd_f32": [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_float, c_void_p, c_i64, c_int, c_int, c_void_p],
+    "sc_bn_rows_fwd": [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_i64,
+                       c_void_p, c_void_p, c_void_p],
+    "sc_bn_rows_bwd": [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p,
+                       c_void_p],
     "sc_softmax_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint32, c_void_p],
     "sc_softmax_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint32, c_void_p],
     "sc_cls_pool_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],

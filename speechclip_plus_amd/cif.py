@@ -1,47 +1,73 @@
-"""Continuous integrate-and-fire downsampler: mirror of avssl/module/cif.py:24-311 (cascaded+/hybrid+ branches).
+"""Continuous integrate-and-fire downsampler of the cascaded+/hybrid+ branches (avssl/module/cif.py:24-311) on the library's
+kernels (csrc/cif.hip).  Same constructor keywords, sub-module names (``conv.0``, ``weight_proj.1``) and result-dict keys as the
+reference, including the quirks that change numbers: ``nn.Dropout()`` (p = 0.5) in the weight generator, ``MAX_FEAT_LEN = 75``,
+alpha clipped to [0, 1], ``quantity_out`` taken before the scaling, train-time tail drop vs inference-time tail firing.
 
-On a GPU the accumulation itself runs on the library's kernels (csrc/cif.hip through ``CifFireFn``: one deterministic pass over
-the frames instead of the reference's atomically-accumulating scatter_add_ calls, forward and backward); the slot boundaries come
-from torch.cumsum either way, and the tiny (B, S) / (B, T) bookkeeping around it stays device-side torch.  Same constructor keywords, sub-module names (``conv.0``,
-``weight_proj.1``) and result-dict keys as the reference, including its quirks that change numbers:
-``nn.Dropout()`` (p = 0.5) in the weight generator, ``MAX_FEAT_LEN = 75``, alpha clipped to [0, 1], the
-quantity output taken BEFORE scaling, train-time tail drop vs inference-time tail firing.
+Everything between the weight generator and the downsampled features is device-side, one workgroup per utterance:
+
+    sc_cif_prepare   clip / zero padded frames / quantity / target-length scaling / inclusive scan / keyword count / fired marks
+    sc_cif_fwd       one deterministic pass over the frames (the reference: three atomically accumulating scatter_add_ rounds)
+    sc_cif_tail      inference: tail firing, rescale, zero the rows past the final count
+    sc_cif_bwd + sc_cif_prepare_bwd   gradients to the features and to the weight generator's output
+
+Host reads: NONE while the target-length scaling is on (training before ``scaling_step``): the scaled weights sum to
+``target + 1e-5`` by construction, so the keyword count equals ``clip(target, 1, 75)``, which the caller already knows on the host
+(``target_lengths_host``); the kernel counts disagreements in ``consistency_flags`` (read them with ``check_flags()`` whenever a
+synchronisation is acceptable).  Otherwise the count is data and the shape of the returned tensor needs ONE read (the batch
+maximum); the reference reads three values per call (count maximum, extra-fire maximum, the all-zero assertion).
+There is no CPU path (the CPU restatement of this maths is oracle/cascaded_ref.py).
 """
 import logging
-from typing import Optional
+from typing import List, Optional
 
 import torch
 from torch import nn
+
+from . import ops
 
 logger = logging.getLogger(__name__)
 
 MAX_FEAT_LEN = 75   # cif.py:11
 
 
-def _length_mask(max_length: int, lens: torch.Tensor) -> torch.Tensor:
-    """True = padding (cif.py:14-21), built on the lengths' device."""
-    return torch.arange(max_length, device=lens.device).unsqueeze(0) >= lens.unsqueeze(1)
-
-
-class CifFireFn(torch.autograd.Function):
-    """out[B, T + 1, C] = integrate-and-fire accumulation of x under (alpha, csum); the slot indices are constants of the graph
-    (computed under no_grad in the reference too), gradients flow to x, alpha and csum."""
+class _CifFn(torch.autograd.Function):
+    """(feats [B,S,C], alpha_raw [B,S]) -> (slots [B,Tc+1,C] fp32, quantity [B]); everything else rides on ``st`` (plain dict)."""
 
     @staticmethod
-    def forward(ctx, x, alpha, csum, T, thr):
-        from . import ops
-        xf, af, cf = x.detach().float().contiguous(), alpha.detach().float().contiguous(), csum.detach().float().contiguous()
-        ctx.save_for_backward(xf, af, cf)
-        ctx.meta = (int(T), float(thr), x.dtype, alpha.dtype)
-        return ops.cif_fwd(xf, af, cf, int(T), float(thr)).to(x.dtype)
+    def forward(ctx, feats, alpha_raw, pad, target, st: dict):
+        x = feats.detach().float().contiguous()
+        a = alpha_raw.detach().float().contiguous()
+        thr, Tc = st["thr"], st["T_clip"]
+        r = ops.cif_prepare(a, pad, target, st["apply_scaling"], thr, st["eps"], MAX_FEAT_LEN, Tc, st["flags"])
+        out = ops.cif_fwd(x, r["alpha"], r["csum"], Tc, thr)
+        st.update(r)
+        if st["tail"]:                                         # inference-time tail handling
+            st["feat_len_pre"] = r["feat_len"].clone()
+            st["factor"], st["extend"] = ops.cif_tail(r["alpha"], r["csum"], r["feat_len"], out, Tc, thr, st["tail_thr"], MAX_FEAT_LEN)
+        ctx.st = st
+        ctx.save_for_backward(x, r["alpha"], r["csum"], r["a_clip"], r["ratio"], r["quantity"], pad)
+        ctx.dtypes = (feats.dtype, alpha_raw.dtype)
+        ctx.mark_non_differentiable(r["feat_len"])
+        return out, r["quantity"], r["feat_len"]
 
     @staticmethod
-    def backward(ctx, g):
-        from . import ops
-        xf, af, cf = ctx.saved_tensors
-        T, thr, xdt, adt = ctx.meta
-        dx, da, dc = ops.cif_bwd(xf, af, cf, g.float().contiguous(), T, thr)
-        return dx.to(xdt), da.to(adt), dc.to(adt), None, None
+    def backward(ctx, g_out, g_q, _):
+        x, alpha, csum, a_clip, ratio, quantity, pad = ctx.saved_tensors
+        st = ctx.st
+        thr, Tc = st["thr"], st["T_clip"]
+        g = g_out.float().contiguous()
+        if st["tail"]:
+            # the rescaled row carries its factor (a constant of the graph: cif.py:262-279 detaches it); rows past the final count
+            # were overwritten with zeros
+            rows = torch.arange(Tc + 1, device=g.device).unsqueeze(0)
+            fl_new, fl_old = st["feat_len"].unsqueeze(1), st["feat_len_pre"].unsqueeze(1)
+            scale = torch.where((rows == fl_old) & st["extend"].bool().unsqueeze(1), st["factor"].unsqueeze(1),
+                                torch.ones((), device=g.device))
+            g = g * (scale * (rows < fl_new)).unsqueeze(-1)
+        dx, pa, pb = ops.cif_bwd(x, alpha, csum, g, Tc, thr)
+        gq = g_q.float().contiguous() if g_q is not None else None
+        da = ops.cif_prepare_bwd(pa, pb, a_clip, pad, ratio, quantity, gq, st["scaled"])
+        return dx.to(ctx.dtypes[0]), da.to(ctx.dtypes[1]), None, None, None
 
 
 class CIF(nn.Module):
@@ -70,108 +96,73 @@ class CIF(nn.Module):
                                  padding=int(conv_cif_width / 2)), nn.Dropout(), nn.ReLU()]
         self.conv = nn.Sequential(*layers)
         self.weight_proj = nn.Sequential(nn.Dropout(), nn.Linear(encoder_embed_dim, 1), nn.Sigmoid())
+        # [0] utterances with a positive weight sum (the reference asserts that there is at least one per call),
+        # [1] keyword counts that differ from clip(target, 1, 75) while the output was sized from the host-side targets, [2] calls
+        self.register_buffer("consistency_flags", torch.zeros(4, dtype=torch.int32), persistent=False)
 
-    def forward(self, input_dict, target_lengths=None, eps=1e-5):
-        feats = input_dict["audio_feat"]                       # B x T x D
-        pad = input_dict["audio_feat_pad_mask"].bool()         # B x T, True = padding
-        original_length = (~pad).sum(-1).long()
+    def check_flags(self) -> dict:
+        """Synchronises.  Raises like the reference's assertion if some call saw only all-zero weights cannot be told apart
+        per call without a read per call, so the counters are cumulative: ``positive`` utterances over ``calls`` calls."""
+        pos, mism, calls, _ = self.consistency_flags.tolist()
+        assert calls == 0 or pos > 0, "alphas are all zero"
+        return {"positive_utterances": pos, "count_mismatches": mism, "calls": calls}
+
+    def forward(self, input_dict, target_lengths=None, eps=1e-5, target_lengths_host: Optional[List[int]] = None):
+        feats = input_dict["audio_feat"]                       # B x S x C
+        if not feats.is_cuda:
+            raise RuntimeError("CIF runs on the HIP kernels: device tensors only (CPU restatement: oracle/cascaded_ref.py)")
+        pad = input_dict["audio_feat_pad_mask"].bool().contiguous()      # B x S, True = padding
+        B, S, C = feats.shape
+        if S > 2048 or C % 4 != 0:
+            raise NotImplementedError(f"CIF kernels: at most 2048 frames per utterance and C % 4 == 0 (got S={S}, C={C})")
         if self.scaling_step >= 0 and self.apply_scaling and input_dict["global_step"] >= self.scaling_step:
             self.apply_scaling = False                         # cif.py:110-112: permanent once the step is reached
         logits = self._weight_conv(feats)
-        alpha = self.weight_proj(logits).clip(min=0.0, max=1.0).float().squeeze(-1)
-        alpha = alpha.masked_fill(pad, 0.0)
-        orig_alpha = alpha
-        alpha_sum = alpha.sum(1)
-        assert (alpha_sum > 0).any(), f"alphas are all zero:\n{alpha_sum}"
-        if self.apply_scaling and target_lengths is not None:
-            desired = self.cif_threshold * target_lengths.type_as(alpha) + eps
-            alpha = alpha * (desired / alpha_sum).unsqueeze(1)
-        out = {"quantity_out": alpha_sum, "orig_alpha": orig_alpha, "original_length": original_length,
-               "target_len": target_lengths}
-        out.update(self.integrate_and_fire(feats, alpha, target_lengths=target_lengths))
-        out["input_feats_pad_mask"] = pad
-        return out
+        alpha_raw = self.weight_proj(logits).float().squeeze(-1)          # sigmoid output; clip / masking: sc_cif_prepare
+        scaled = bool(self.apply_scaling and target_lengths is not None)
+        tail = bool(self.apply_tail_handling and target_lengths is None)
+        target = target_lengths.to(device=feats.device, dtype=torch.int64).contiguous() if target_lengths is not None else None
+        T_known = None
+        if scaled and target_lengths_host is not None:
+            T_known = max(min(max(int(t), 1), MAX_FEAT_LEN) for t in target_lengths_host)
+        st = {"thr": float(self.cif_threshold), "eps": float(eps), "apply_scaling": scaled, "scaled": scaled, "tail": tail,
+              "tail_thr": float(self.tail_handling_firing_threshold), "flags": self.consistency_flags,
+              "T_clip": T_known if T_known is not None else MAX_FEAT_LEN}
+        self.consistency_flags[2:3] += 1
+        slots, quantity, feat_lengths = _CifFn.apply(feats, alpha_raw, pad, target, st)
+        if T_known is not None:
+            T = T_known
+        else:
+            T = int(feat_lengths.max())                        # the one host read: the returned tensor's shape is data
+        output = slots[:, :T].to(feats.dtype)
+        fired = st["fired"].bool()
+        if tail:
+            # cif.py:281-283 marks, for EVERY row, the columns feat_len_j - 1 of the utterances j that fired their tail (diagnostic)
+            ext = st["extend"].bool()
+            cols = (feat_lengths - 1).clamp(min=0)
+            add = torch.zeros(S, dtype=torch.bool, device=feats.device).index_put_((cols[ext],), torch.ones((), dtype=torch.bool,
+                                                                                                       device=feats.device))
+            fired = fired | add.unsqueeze(0)
+        out_pad = torch.arange(T, device=feats.device).unsqueeze(0) >= feat_lengths.unsqueeze(1)
+        return {"quantity_out": quantity, "orig_alpha": st["a_clip"], "original_length": (~pad).sum(-1).long(),
+                "target_len": target_lengths, "dsample_feats_pad_mask": out_pad, "dsample_feats": output,
+                "dsample_feats_length": feat_lengths, "alpha": st["alpha"], "fired_marks": fired, "input_feats_pad_mask": pad}
 
     def _weight_conv(self, feats: torch.Tensor) -> torch.Tensor:
-        """``self.conv(feats^T)^T`` (Conv1d k, stride 1, 'same' padding -> Dropout -> ReLU per layer) evaluated channels-last as
-        one GEMM per layer over the k shifted copies of the input: MIOpen's fp32 NCHW path for this 768 x 768 x 3 conv costs
-        ~7 ms per call at B = 64 (rocprofv3), the GEMM form ~1 ms; same parameters, same arithmetic (fp32)."""
+        """``self.conv(feats^T)^T`` (Conv1d k, stride 1, 'same' padding -> Dropout -> ReLU per layer) evaluated channels-last as ONE
+        GEMM per layer over the k shifted copies of the input.  Training: bf16 operands / fp32 accumulation on the library's MFMA
+        GEMM (the reference trains under precision-16 autocast, and the keyword COUNT is pinned by the target-length scaling, so
+        the discrete part of CIF does not depend on this rounding).  Inference: exact fp32 on the matrix pipe
+        (sc_sgemm_mfma_f32) - there the count is floor(sum alpha) and must be the fp32 reference's."""
+        from .linear_fn import linear_bf16_autograd, linear_f32_autograd
+        linear = linear_bf16_autograd if self.training else linear_f32_autograd
         x = feats
         for i in range(0, len(self.conv), 3):
             conv, drop, act = self.conv[i], self.conv[i + 1], self.conv[i + 2]
-            k, pad = conv.kernel_size[0], conv.padding[0]
+            k, p = conv.kernel_size[0], conv.padding[0]
             B, T, C = x.shape
-            xp = torch.nn.functional.pad(x, (0, 0, pad, pad))                       # (B, T + 2 pad, C)
-            cols = torch.cat([xp[:, j: j + T + 2 * pad - k + 1] for j in range(k)], dim=-1)   # (B, T', k C), tap-major
-            w = conv.weight.permute(0, 2, 1).reshape(conv.out_channels, k * C)    # [C_out, k, C_in] flattened tap-major
-            if self.training and cols.is_cuda:
-                # training: bf16 operands / fp32 accumulation on the library's GEMM with its dgrad + weight-gradient products
-                # (the reference trains under precision-16 autocast; the keyword COUNT is pinned by the target-length scaling
-                # of alpha, so the discrete part of CIF does not depend on this rounding).  Inference stays fp32: there the
-                # count is floor(sum alpha), which must be the fp32 oracle's.
-                from .linear_fn import linear_bf16_autograd
-                y = linear_bf16_autograd(cols, w, conv.bias)
-            else:
-                y = torch.nn.functional.linear(cols, w, conv.bias)
-            x = act(drop(y))
+            xp = torch.nn.functional.pad(x, (0, 0, p, p))                           # (B, T + 2 p, C)
+            cols = torch.cat([xp[:, j: j + T + 2 * p - k + 1] for j in range(k)], dim=-1)   # (B, T', k C), tap-major
+            w = conv.weight.permute(0, 2, 1).reshape(conv.out_channels, k * C)      # [C_out, k, C_in] flattened tap-major
+            x = act(drop(linear(cols, w, conv.bias)))
         return x
-
-    def integrate_and_fire(self, input: torch.Tensor, alpha: torch.Tensor,
-                           target_lengths: Optional[torch.Tensor] = None) -> dict:
-        """cif.py:157-311.  Frame s with cumulative weight c_s contributes to output slots floor(c_{s-1}/thr) ..
-        floor(c_s/thr): the part up to the first boundary goes left, whole thresholds go to the slots in between, the
-        remainder goes right."""
-        B, S, C = input.shape
-        thr = self.cif_threshold
-        assert tuple(alpha.shape) == (B, S), f"{alpha.shape} != {(B, S)}"
-        feat_lengths = (alpha.sum(1) / thr).floor().clip(min=1, max=MAX_FEAT_LEN).long()
-        T = int(feat_lengths.max())
-        csum = alpha.cumsum(-1)
-        with torch.no_grad():
-            right_idx = (csum / thr).floor().long().clip(min=0, max=T)
-            left_idx = right_idx.roll(1, dims=1)
-            left_idx[:, 0] = 0
-            fire_num = right_idx - left_idx
-            extra = (fire_num - 1).clip(min=0)
-        fire_mask = fire_num > 0
-        zero = alpha.new_zeros((1,))
-        right_w = torch.where(fire_mask, csum - right_idx.type_as(alpha) * thr, zero).type_as(input)
-        left_w = (alpha - right_w - extra.type_as(alpha) * thr).type_as(input)
-        if input.is_cuda and C % 4 == 0 and S <= 2048:
-            output = CifFireFn.apply(input, alpha, csum, T, thr)   # slot T collects the tail
-        else:
-            output = input.new_zeros((B, T + 1, C))
-            output.scatter_add_(1, right_idx.unsqueeze(-1).expand(-1, -1, C), right_w.unsqueeze(-1) * input)
-            output.scatter_add_(1, left_idx.unsqueeze(-1).expand(-1, -1, C), left_w.unsqueeze(-1) * input)
-            if extra.ge(0).any():
-                steps = int(extra.max())
-                tgt = left_idx
-                whole = input * thr
-                for _ in range(steps):
-                    tgt = (tgt + 1).clip(max=T)
-                    output.scatter_add_(1, tgt.unsqueeze(-1).expand(-1, -1, C), whole * (extra > 0).unsqueeze(2))
-                    extra = extra - 1
-        if self.apply_tail_handling:
-            if target_lengths is not None:
-                output = output[:, :T, :]                      # training: the tail is dropped
-            else:
-                zero = right_w.new_zeros((1,))
-                tail_w = torch.where(right_idx == feat_lengths.unsqueeze(1), right_w, zero).sum(-1)
-                tail_w = tail_w + torch.where(left_idx == feat_lengths.unsqueeze(1), left_w, zero).sum(-1)
-                extend = tail_w >= self.tail_handling_firing_threshold
-                if extend.any():
-                    factor = (thr / tail_w.masked_fill(~extend, thr)).view(B, 1, 1).expand(-1, -1, C).to(output.dtype)
-                    upscale = torch.ones_like(output).scatter(1, feat_lengths.view(B, 1, 1).expand(-1, -1, C), factor).detach()
-                    output = output * upscale
-                    feat_lengths = feat_lengths + extend.long()
-                    cols = feat_lengths - 1                    # cif.py:281-283 (diagnostic mask only)
-                    fire_mask[:, cols] = fire_mask[:, cols] + extend
-                    feat_lengths = feat_lengths.clip(max=MAX_FEAT_LEN)
-                    T = int(feat_lengths.max())
-                output = output[:, :T, :]
-                tail_mask = torch.arange(T, device=output.device).unsqueeze(0) >= feat_lengths.unsqueeze(1)
-                output = output.masked_fill(tail_mask.unsqueeze(-1), 0)
-        else:
-            output = output[:, :T, :]
-        return {"dsample_feats_pad_mask": _length_mask(output.shape[1], feat_lengths), "dsample_feats": output,
-                "dsample_feats_length": feat_lengths, "alpha": alpha, "fired_marks": fire_mask}

@@ -157,6 +157,167 @@ __global__ __launch_bounds__(64) void cif_bwd_kernel(const float* __restrict__ x
     }
 }
 
+// ------------------------------------------------------------------------------------------ bookkeeping (cif.py:106-175)
+// One workgroup per utterance, no host round trip:  a = clip(alpha_raw, 0, 1) with padded frames zeroed ; quantity = sum a ;
+// (train, apply_scaling) a *= (thr * target + eps) / quantity ; csum = inclusive scan(a) ; feat_len = clip(floor(sum a / thr), 1, 75) ;
+// fired marks.  Sums and the scan run in fp64 and are rounded once: the scaled weights sum to target + 1e-5 by construction, and an
+// fp32 summation error of that size would turn floor() into target - 1.
+constexpr int PREP_PER = MAXS / 256;
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void cif_prepare_kernel(const float* __restrict__ a_raw, int64_t lda, const uint8_t* __restrict__ pad,
+                                                          int64_t ldp, const int64_t* __restrict__ target, int S, float thr, float eps,
+                                                          int scale, int max_feat, int T, float* __restrict__ a_clip,
+                                                          float* __restrict__ alpha, float* __restrict__ csum, float* __restrict__ quantity,
+                                                          float* __restrict__ ratio_out, int64_t* __restrict__ feat_len,
+                                                          uint8_t* __restrict__ fired, int* __restrict__ flags) {
+    __shared__ double red[4];
+    __shared__ double tot[256];
+    const int b = blockIdx.x, s0 = threadIdx.x * PREP_PER;
+    float a[PREP_PER];
+    double loc = 0.0;
+#pragma unroll
+    for (int i = 0; i < PREP_PER; ++i) {
+        const int s = s0 + i;
+        float v = 0.f;
+        if (s < S && !pad[(int64_t)b * ldp + s]) v = fminf(fmaxf(a_raw[(int64_t)b * lda + s], 0.f), 1.f);
+        a[i] = v;
+        loc += (double)v;
+        if (s < S) a_clip[(int64_t)b * S + s] = v;
+    }
+    const float q = (float)block_sum_d(loc, red);
+    float ratio = 1.f;
+    if (scale) ratio = (thr * (float)target[b] + eps) / q;
+    loc = 0.0;
+#pragma unroll
+    for (int i = 0; i < PREP_PER; ++i) {
+        a[i] *= ratio;
+        loc += (double)a[i];
+    }
+    tot[threadIdx.x] = loc;
+    const double total = block_sum_d(loc, red);            // (its barriers also publish tot[])
+    double pre = 0.0;
+    for (int j = 0; j < (int)threadIdx.x; ++j) pre += tot[j];
+    float prev = (float)pre;                                // csum of the frame before this thread's first one
+#pragma unroll
+    for (int i = 0; i < PREP_PER; ++i) {
+        const int s = s0 + i;
+        pre += (double)a[i];
+        const float c = (float)pre;
+        if (s < S) {
+            alpha[(int64_t)b * S + s] = a[i];
+            csum[(int64_t)b * S + s] = c;
+            const int right = min(max((int)floorf(c / thr), 0), T);
+            const int left = s > 0 ? min(max((int)floorf(prev / thr), 0), T) : 0;
+            fired[(int64_t)b * S + s] = right > left;
+        }
+        prev = c;
+    }
+    if (threadIdx.x == 0) {
+        int64_t fl = (int64_t)floorf((float)total / thr);
+        fl = fl < 1 ? 1 : (fl > max_feat ? max_feat : fl);
+        feat_len[b] = fl;
+        quantity[b] = q;
+        ratio_out[b] = ratio;
+        if (q > 0.f) atomicAdd(&flags[0], 1);               // the reference asserts (alpha_sum > 0).any()
+        if (scale) {
+            int64_t t = target[b];
+            t = t < 1 ? 1 : (t > max_feat ? max_feat : t);
+            if (t != fl) atomicAdd(&flags[1], 1);           // the host sized the output from target_len
+        }
+    }
+}
+
+// d a_raw from the fire kernel's per-channel-block partials (pa: direct d alpha, pb: d csum) and d quantity:
+//   g'_i = sum_blk pa_i + sum_{j >= i} sum_blk pb_j ;  scaled: d a_k = r g'_k - r <g', a> / Q ; + d quantity ; padded frames 0
+__global__ __launch_bounds__(256) void cif_prepare_bwd_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nblk, int B,
+                                                              int S, const float* __restrict__ a_clip, const uint8_t* __restrict__ pad,
+                                                              int64_t ldp, const float* __restrict__ ratio, const float* __restrict__ quantity,
+                                                              const float* __restrict__ gq, int scale, float* __restrict__ da) {
+    __shared__ double red[4];
+    __shared__ double tot[256];
+    const int b = blockIdx.x, s0 = threadIdx.x * PREP_PER;
+    float ga[PREP_PER], gc[PREP_PER];
+    double loc = 0.0;
+#pragma unroll
+    for (int i = 0; i < PREP_PER; ++i) {
+        const int s = s0 + i;
+        float x = 0.f, y = 0.f;
+        if (s < S)
+            for (int k = 0; k < nblk; ++k) {
+                x += pa[((int64_t)k * B + b) * S + s];
+                y += pb[((int64_t)k * B + b) * S + s];
+            }
+        ga[i] = x;
+        gc[i] = y;
+        loc += (double)y;
+    }
+    tot[threadIdx.x] = loc;
+    block_sum_d(loc, red);
+    double suf = 0.0;                                       // sum of d csum over the frames AFTER this thread's chunk
+    for (int j = threadIdx.x + 1; j < 256; ++j) suf += tot[j];
+    double dot = 0.0;
+#pragma unroll
+    for (int i = PREP_PER - 1; i >= 0; --i) {
+        suf += (double)gc[i];
+        ga[i] += (float)suf;
+        const int s = s0 + i;
+        if (s < S) dot += (double)ga[i] * (double)a_clip[(int64_t)b * S + s];
+    }
+    const float r = ratio[b];
+    const float corr = scale ? (float)block_sum_d(dot, red) * r / quantity[b] : 0.f;
+    const float g_q = gq ? gq[b] : 0.f;
+#pragma unroll
+    for (int i = 0; i < PREP_PER; ++i) {
+        const int s = s0 + i;
+        if (s < S) da[(int64_t)b * S + s] = pad[(int64_t)b * ldp + s] ? 0.f : (r * ga[i] - corr + g_q);
+    }
+}
+
+// inference-time tail handling (cif.py:244-297): the weight left in slot feat_len fires an extra keyword when it reaches the tail
+// threshold (its row is rescaled to a full threshold); rows >= the final length are zeroed.
+__global__ __launch_bounds__(256) void cif_tail_kernel(const float* __restrict__ alpha, const float* __restrict__ csum, int S, int C, int T,
+                                                       float thr, float tail_thr, int max_feat, int64_t* __restrict__ feat_len,
+                                                       float* __restrict__ out, float* __restrict__ factor, uint8_t* __restrict__ extend) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    const float* al = alpha + (int64_t)b * S;
+    const float* cs = csum + (int64_t)b * S;
+    const int fl = (int)feat_len[b];
+    double w = 0.0;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const float c = cs[s];
+        const int right = min(max((int)floorf(c / thr), 0), T);
+        const int left = s > 0 ? min(max((int)floorf(cs[s - 1] / thr), 0), T) : 0;
+        const int fire = right - left;
+        const float rw = fire > 0 ? c - (float)right * thr : 0.f;
+        const float lw = al[s] - rw - (float)max(fire - 1, 0) * thr;
+        if (right == fl) w += (double)rw;
+        if (left == fl) w += (double)lw;
+    }
+    const float tw = (float)block_sum_d(w, red);
+    const bool ext = tw >= tail_thr;
+    const float f = ext ? thr / tw : 1.f;
+    const int fl_new = min(fl + (ext ? 1 : 0), max_feat);
+    float* ob = out + (int64_t)b * (T + 1) * C;
+    if (ext && fl <= T)
+        for (int c = threadIdx.x; c < C; c += 256) ob[(int64_t)fl * C + c] *= f;
+    __syncthreads();
+    for (int64_t i = (int64_t)fl_new * C + threadIdx.x; i < (int64_t)(T + 1) * C; i += 256) ob[i] = 0.f;
+    if (threadIdx.x == 0) {
+        feat_len[b] = fl_new;
+        factor[b] = f;
+        extend[b] = ext;
+    }
+}
+
 }  // namespace
 
 extern "C" int sc_cif_fwd(const float* x, const float* alpha, const float* csum, float* out, int32_t B, int32_t S, int32_t C, int32_t T,
@@ -178,6 +339,38 @@ extern "C" int sc_cif_bwd(const float* x, const float* alpha, const float* csum,
     SC_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)dx % 16) == 0, "sc_cif_bwd: alignment");
     hipLaunchKernelGGL(cif_bwd_kernel, dim3((C + 255) / 256, B), dim3(64), 0, (hipStream_t)stream, x, alpha, csum, g, dx, pa, pb, B, S, C, T,
                        thr);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_cif_prepare(const float* alpha_raw, int64_t lda, const uint8_t* pad, int64_t ldp, const int64_t* target,
+                              int32_t apply_scaling, int32_t B, int32_t S, float thr, float eps, int32_t max_feat, int32_t T, float* a_clip, float* alpha, float* csum,
+                              float* quantity, float* ratio, int64_t* feat_len, uint8_t* fired, int32_t* flags, void* stream) {
+    SC_CHECK(alpha_raw && pad && a_clip && alpha && csum && quantity && ratio && feat_len && fired && flags, "sc_cif_prepare: null pointer");
+    SC_CHECK(B > 0 && S > 0 && S <= MAXS && thr > 0.f && T >= 0 && max_feat >= 1, "sc_cif_prepare: B=%d S=%d (<= 2048) T=%d", B, S, T);
+    hipLaunchKernelGGL(cif_prepare_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, alpha_raw, lda, pad, ldp, target, S, thr, eps,
+                       (target && apply_scaling) ? 1 : 0, max_feat, T, a_clip, alpha, csum, quantity, ratio, feat_len, fired, flags);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_cif_prepare_bwd(const float* pa, const float* pb, int32_t nblk, int32_t B, int32_t S, const float* a_clip,
+                                  const uint8_t* pad, int64_t ldp, const float* ratio, const float* quantity, const float* gq,
+                                  int32_t scaled, float* da, void* stream) {
+    SC_CHECK(pa && pb && a_clip && pad && ratio && quantity && da, "sc_cif_prepare_bwd: null pointer");
+    SC_CHECK(B > 0 && S > 0 && S <= MAXS && nblk > 0, "sc_cif_prepare_bwd: B=%d S=%d nblk=%d", B, S, nblk);
+    hipLaunchKernelGGL(cif_prepare_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pa, pb, nblk, B, S, a_clip, pad, ldp, ratio,
+                       quantity, gq, scaled, da);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_cif_tail(const float* alpha, const float* csum, int32_t B, int32_t S, int32_t C, int32_t T, float thr, float tail_thr,
+                           int32_t max_feat, int64_t* feat_len, float* out, float* factor, uint8_t* extend, void* stream) {
+    SC_CHECK(alpha && csum && feat_len && out && factor && extend, "sc_cif_tail: null pointer");
+    SC_CHECK(B > 0 && S > 0 && C > 0 && T >= 0 && thr > 0.f, "sc_cif_tail: bad arguments");
+    hipLaunchKernelGGL(cif_tail_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, alpha, csum, S, C, T, thr, tail_thr, max_feat, feat_len,
+                       out, factor, extend);
     SC_LAUNCH_CHECK();
     return 0;
 }

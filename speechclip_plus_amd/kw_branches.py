@@ -12,11 +12,10 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
-from torch.nn import functional as F
-
 from . import transformer_models as TransformerModels
 from . import vector_quantizers
 from .cif import CIF
+from .linear_fn import linear_f32_autograd
 from .projections import MLPLayers
 from .vector_quantizers import Kw_BatchNorm_dynamic
 
@@ -26,6 +25,12 @@ logger = logging.getLogger(__name__)
 def get_keypadding_mask(max_length: int, data_lens: torch.Tensor) -> torch.Tensor:
     """avssl/util/data_utils.py:6-22 (True = padding), built on the device of the lengths."""
     return torch.arange(max_length, device=data_lens.device).unsqueeze(0) >= data_lens.unsqueeze(1)
+
+
+def target_len_host(feat_len_host) -> list:
+    """``(feat_len / 20).round().long()`` (kwClip.py:876) on host integers: float32 division, round half to even."""
+    import numpy as np
+    return [int(v) for v in np.round(np.asarray(feat_len_host, dtype=np.float32) / np.float32(20.0))]
 
 
 def _get(cfg, key, default=None):
@@ -74,23 +79,33 @@ class GeneralBranch(nn.Module):
         self.vector_quantizer = getattr(vector_quantizers, self.vq_type)(**dict(_get(vq, "args")))
 
     def project_feats_to_CLIPspace(self, features: torch.Tensor) -> torch.Tensor:
-        features = self.linear_proj(features)
+        """kw_branches.py:143-156.  Exact fp32 on the matrix pipe (linear_fn.LinearF32Fn): the projected keywords are compared
+        against the whole vocabulary by an argmax, so their operands are not rounded to bf16."""
+        if isinstance(self.linear_proj, nn.Linear):
+            features = linear_f32_autograd(features.float(), self.linear_proj.weight, self.linear_proj.bias)
+        else:
+            features = self.linear_proj(features.float())
         if hasattr(self, "bn_layer"):
             features = self.bn_layer(features)
         return features
 
     def get_keyword_cosine_score(self, keywords: torch.Tensor) -> torch.Tensor:
-        """kw_branches.py:158-179: cosine of every keyword against every (reduced-vocabulary) token embedding."""
-        emb = self.clip.model.token_embedding.weight                       # (V, Et), frozen
-        return F.normalize(keywords, dim=-1, eps=1e-8) @ F.normalize(emb, dim=-1, eps=1e-8).t()
+        """kw_branches.py:158-179: cosine of every keyword against every (reduced-vocabulary) token embedding, in exact fp32 on
+        the matrix pipe (sc_vq_prep_f32 + sc_sgemm_mfma_f32).  Forward only: the training path is ``vq_audio_features``."""
+        from . import ops
+        from .vector_quantizers import VocabTables
+        tb = VocabTables.of(self.clip.model.token_embedding.weight, self.vector_quantizer._tables)
+        bsz, n, Et = keywords.shape
+        kwn_T, _ = ops.vq_prep(keywords.detach().reshape(bsz * n, Et).float().contiguous())
+        cos = ops.sgemm_mfma(kwn_T, tb.norm_T, a_kmajor=True, b_kmajor=True)
+        return cos[: bsz * n, : tb.V].reshape(bsz, n, tb.V)
 
     def vq_audio_features(self, audio_feat: torch.Tensor):
+        """kw_branches.py:181-197 as ONE autograd node (vector_quantizers.SimpleVectorQuantizer.quantize_keywords): cosine scores,
+        special-token mask, argmax / straight-through softmax and the ``@ token_embedding`` product, forward and backward."""
         audio_feat = self.project_feats_to_CLIPspace(audio_feat)
-        cos_score = self.get_keyword_cosine_score(audio_feat)
-        vq_results = self.vector_quantizer(x=cos_score)
         assert self.clip.model.token_embedding.weight.requires_grad == False
-        keywords = vq_results["subword_prob"] @ self.clip.model.token_embedding.weight
-        return vq_results, keywords
+        return self.vector_quantizer.quantize_keywords(audio_feat, self.clip.model.token_embedding.weight)
 
 
 class KW_ParallelBranch(GeneralBranch):
@@ -124,7 +139,8 @@ class KW_ParallelBranch(GeneralBranch):
 
 class KW_CascadedBranchPlus(GeneralBranch):
     """kw_branches.py:580-777: self-attention over the frames -> CIF downsampling -> keyword projection + BatchNorm ->
-    cosine VQ against the CLIP token table -> frozen CLIP text encoder.  Scope row a11 (stock torch ops)."""
+    cosine VQ against the CLIP token table -> frozen CLIP text encoder, every stage on the library's kernels (mha_block, cif,
+    linear_fn, vector_quantizers, clip_text_hip)."""
 
     def __init__(self, config, audio_dim: int, text_dim: int, clip) -> None:
         super().__init__(config, audio_dim, text_dim)
@@ -152,13 +168,18 @@ class KW_CascadedBranchPlus(GeneralBranch):
         """kw_branches.py:644-699: the CIF target length is used only in training (round(len / 20) if not given)."""
         inputs = {"audio_feat": audio_feat, "audio_feat_len": audio_feat_len, "audio_feat_pad_mask": audio_feat_pad_mask,
                   "global_step": global_step}
+        host = None
         if not self.training:
             input_target_len = None
         elif target_len is None:
             input_target_len = (audio_feat_len / 20).round().long()
+            lens_host = getattr(audio_feat_len, "_sc_host", None)      # the encoder's host copy of the frame counts
+            host = target_len_host(lens_host) if lens_host is not None else None
         else:
             input_target_len = target_len
-        res = self.downsampling(inputs, input_target_len)
+            host = getattr(target_len, "_sc_host", None)
+        # with the targets known on the host the CIF output is sized without a device read (cif.CIF.forward)
+        res = self.downsampling(inputs, input_target_len, target_lengths_host=host)
         if target_len is not None:
             res["target_len"] = target_len
             res["dsample_len_diff"] = (res["dsample_feats_length"] - target_len).abs().float().mean()
@@ -206,7 +227,8 @@ class KW_HybridBranchPlus(KW_CascadedBranchPlus):
         pad = get_keypadding_mask(T + 1, lens + 1)
         src = torch.cat([self.cls.expand(bsz, -1, -1).to(audio_feat.dtype), audio_feat], dim=1)
         post = self.self_att(src=src, key_padding_mask=pad)
-        output["parallel_audio_feat"] = self.parallel_proj(post[:, :1].reshape(-1, self.audio_dim))
+        output["parallel_audio_feat"] = linear_f32_autograd(post[:, :1].reshape(-1, self.audio_dim).float(), self.parallel_proj.weight,
+                                                            self.parallel_proj.bias)
         return self._tail(output, post[:, 1:].reshape(-1, T, self.audio_dim), lens, pad[:, 1:], otherInputs)
 
     def extract_hidden_states(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> Tuple:

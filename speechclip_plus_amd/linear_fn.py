@@ -48,8 +48,50 @@ class LinearBf16Fn(torch.autograd.Function):
         return dx, gW, gb
 
 
+class LinearF32Fn(torch.autograd.Function):
+    """``y = x W^T + b`` in exact fp32 on the matrix pipe (sc_sgemm_mfma_f32), forward and backward, no transposed copies: the
+    three products read x, W and dy in place, each either row-major or K-major.  Used where a rounding of the operands would
+    change a DISCRETE result downstream (inference-time CIF: the keyword count is floor(sum alpha))."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        shape = x.shape
+        K, N = shape[-1], weight.shape[0]
+        x2 = x.detach().reshape(-1, K).float().contiguous()
+        w = weight.detach().float().contiguous()
+        y = ops.sgemm_mfma(x2, w, bias=None if bias is None else bias.detach().float().contiguous())
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (shape, x.dtype, bias is not None)
+        return y.reshape(*shape[:-1], N).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        shape, dtype, has_bias = ctx.meta
+        N = w.shape[0]
+        dy2 = dy.reshape(-1, N).float().contiguous()
+        rows = dy2.shape[0]
+        dx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.sgemm_mfma(dy2, w, b_kmajor=True).to(dtype).reshape(shape)        # dx[m, k] = sum_n dy[m, n] W[n, k]
+        if ctx.needs_input_grad[1]:
+            gW = ops.sgemm_mfma(dy2, x2, a_kmajor=True, b_kmajor=True)                 # gW[n, k] = sum_m dy[m, n] x[m, k]
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(N, device=dy.device, dtype=torch.float32)
+            ops.colsum(dy2, N, rows, N, gb)
+        return dx, gW, gb
+
+
+def linear_f32_autograd(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+    if not x.is_cuda:
+        raise RuntimeError("speechclip_plus_amd linear layers run on the HIP kernels: device tensors only")
+    return LinearF32Fn.apply(x, weight, bias)
+
+
 def linear_bf16_autograd(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
-    """Drop-in for ``F.linear`` on a GPU when K and N are multiples of 64 / 8; plain ``F.linear`` otherwise (CPU, odd shapes)."""
-    if x.is_cuda and x.shape[-1] % 64 == 0 and weight.shape[0] % 8 == 0:
-        return LinearBf16Fn.apply(x, weight, bias)
-    return torch.nn.functional.linear(x, weight, bias)
+    """``F.linear`` on the library's bf16 MFMA GEMM (K a multiple of 64, N of 8)."""
+    if not x.is_cuda:
+        raise RuntimeError("speechclip_plus_amd linear layers run on the HIP kernels: device tensors only")
+    if x.shape[-1] % 64 != 0 or weight.shape[0] % 8 != 0:
+        raise NotImplementedError(f"linear_bf16_autograd: K = {x.shape[-1]} must be a multiple of 64 and N = {weight.shape[0]} of 8")
+    return LinearBf16Fn.apply(x, weight, bias)

@@ -1,6 +1,9 @@
 """``LayerNorm(MultiheadAttention(x, x, x, key_padding_mask) + x)`` - the attention block of the cascaded+/hybrid+ branches
 (avssl/module/kw_modules/TransformerModels.py:101-126, one head of 768 in the base recipes, 8 heads of 128 in the large ones) -
-forward and backward on the library's kernels, any head_dim that is a multiple of 64 (scope row f3).
+forward and backward on the library's kernels, any head_dim (scope rows a10 / f3): head dims that are not a multiple of 64
+(96 = 768 / 8 in the hybrid+ base recipe) run with every head zero-padded to the next multiple of 64 inside the projection
+weights, which changes nothing in the results (zero columns of q / k add nothing to the scores, zero columns of v give zero
+context columns that meet zero columns of the output projection).
 
 The flash kernels of the encoder are head_dim 64; here the S x S core runs as batched bf16 GEMMs on ``sc_gemm_bf16`` (batch
 dimensions = utterance x head, operands addressed in place inside the fused projection output):
@@ -47,61 +50,75 @@ class MhaNormFn(torch.autograd.Function):
     LayerNorm weight / bias [D]; constants: key_padding_mask [B, S] bool (True = padding), H, eps, p_drop (0 in eval)."""
 
     @staticmethod
-    def forward(ctx, x, Wi, bi, Wo, bo, g, beta, kpm, H, eps, p_drop, seed):
-        B, S, D = x.shape
-        dh = D // H
-        assert D % H == 0 and dh % 64 == 0 and D % 64 == 0, "head_dim must be a multiple of 64"
+    def forward(ctx, x, Wi, bi, Wo, bo, g, beta, kpm, H, eps, p_drop, seed, p_res=0.0, seed_res=0):
+        B, S, Dm = x.shape
+        dh_true = Dm // H
+        assert Dm % H == 0 and Dm % 64 == 0, "d_model must be a multiple of 64 and of the head count"
         dev, bf = x.device, torch.bfloat16
+        dh = _roundup(dh_true, 64)                       # padded head dim; D = width of q, k, v and of the context
+        D = H * dh
         Sp = _roundup(S, 64)
         M = B * Sp
-        xb = torch.zeros(B, Sp, D, device=dev, dtype=bf)
+        xb = torch.zeros(B, Sp, Dm, device=dev, dtype=bf)
         xb[:, :S] = x.detach()
-        xb = xb.view(M, D)
-        Wi_b, Wo_b = Wi.detach().to(bf).contiguous(), Wo.detach().to(bf).contiguous()
-        qkv = ops.linear_bf16(xb, Wi_b, bi.detach().float().contiguous())                    # [M, 3D]
+        xb = xb.view(M, Dm)
+        if dh == dh_true:
+            Wi_b, Wo_b, bi_f = Wi.detach().to(bf).contiguous(), Wo.detach().to(bf).contiguous(), bi.detach().float().contiguous()
+        else:
+            Wi_b = torch.zeros(3, H, dh, Dm, device=dev, dtype=bf)
+            Wi_b[:, :, :dh_true] = Wi.detach().view(3, H, dh_true, Dm)
+            Wi_b = Wi_b.view(3 * D, Dm)
+            bi_f = torch.zeros(3, H, dh, device=dev, dtype=torch.float32)
+            bi_f[:, :, :dh_true] = bi.detach().view(3, H, dh_true)
+            bi_f = bi_f.view(3 * D)
+            Wo_b = torch.zeros(Dm, H, dh, device=dev, dtype=bf)
+            Wo_b[:, :, :dh_true] = Wo.detach().view(Dm, H, dh_true)
+            Wo_b = Wo_b.view(Dm, D)
+        qkv = ops.linear_bf16(xb, Wi_b, bi_f)                                                # [M, 3D]
         # ---- S x S core
         scores = torch.empty(B, H, Sp, Sp, device=dev, dtype=torch.float32)
         ops.gemm_raw(qkv, 3 * D, qkv[:, D:], 3 * D, scores, Sp, Sp, Sp, dh, out_f32=True, nb1=B, nb2=H,
                      sA=(Sp * 3 * D, dh), sW=(Sp * 3 * D, dh), sC=(H * Sp * Sp, Sp * Sp))
         key_pad = torch.ones(B, Sp, device=dev, dtype=torch.uint8)
         key_pad[:, :S] = kpm
-        P, Pd = ops.softmax_fwd(scores, key_pad, H * Sp, dh ** -0.5, p_drop, seed)               # P un-dropped (softmax backward), Pd dropped
+        P, Pd = ops.softmax_fwd(scores, key_pad, H * Sp, dh_true ** -0.5, p_drop, seed)          # P un-dropped (softmax backward), Pd dropped
         del scores
         vT = ops.transpose_bf16(qkv[:, 2 * D:])                                               # [D, M]: V^T of every utterance
         cx = torch.empty(M, D, device=dev, dtype=bf)
         ops.gemm_raw(Pd, Sp, vT, M, cx, D, Sp, dh, Sp, nb1=B, nb2=H,
                      sA=(H * Sp * Sp, Sp * Sp), sW=(Sp, dh * M), sC=(Sp * D, dh))
-        pre = ops.linear_bf16(cx, Wo_b, bo.detach().float().contiguous(), residual=xb)
+        pre = ops.linear_bf16(cx, Wo_b, bo.detach().float().contiguous(), residual=xb, drop_p=p_res, drop_seed=seed_res)
         # fresh copies: trainable parameters are views into the optimiser's flat buffer (4-byte aligned), the row kernels read
         # gamma / beta with 16-byte loads
         g32, b32 = g.detach().float().clone(), beta.detach().float().clone()
         out = ops.layernorm_bf16(pre, g32, b32, eps=eps)
         ctx.save_for_backward(xb, Wi_b, Wo_b, qkv, P, Pd if p_drop > 0.0 else None, cx, pre, g32)
-        ctx.meta = (B, S, Sp, D, H, dh, eps, p_drop, seed, x.dtype)
-        return out.view(B, Sp, D)[:, :S].to(x.dtype)
+        ctx.meta = (B, S, Sp, D, H, dh, eps, p_drop, seed, x.dtype, Dm, dh_true, p_res, seed_res)
+        return out.view(B, Sp, Dm)[:, :S].to(x.dtype)
 
     @staticmethod
     def backward(ctx, dout):
         xb, Wi_b, Wo_b, qkv, P, Pd, cx, pre, g = ctx.saved_tensors
-        B, S, Sp, D, H, dh, eps, p_drop, seed, xdtype = ctx.meta
+        B, S, Sp, D, H, dh, eps, p_drop, seed, xdtype, Dm, dh_true, p_res, seed_res = ctx.meta
         dev, bf = dout.device, torch.bfloat16
         M = B * Sp
         if Pd is None:
             Pd = P
-        dy = torch.zeros(B, Sp, D, device=dev, dtype=bf)
+        dy = torch.zeros(B, Sp, Dm, device=dev, dtype=bf)
         dy[:, :S] = dout
-        dy = dy.view(M, D)
+        dy = dy.view(M, Dm)
         # ---- LayerNorm, out_proj
         dpre, dg, dbeta = ops.layernorm_bwd(pre, dy, g, eps, want_param_grads=True)
-        gWo = torch.empty(D, D, device=dev, dtype=torch.float32)
-        gbo = torch.empty(D, device=dev, dtype=torch.float32)
-        ops.wgrad_bf16(dpre, cx, gWo, gbo, beta=0.0)
-        dcx = ops.linear_bf16(dpre, Wo_b.t().contiguous())                                    # [M, D]
+        gWo = torch.empty(Dm, D, device=dev, dtype=torch.float32)
+        gbo = torch.empty(Dm, device=dev, dtype=torch.float32)
+        dbr = ops.dropout_bf16(dpre, p_res, seed_res) if p_res > 0.0 else dpre                # the dropped branch's gradient
+        ops.wgrad_bf16(dbr, cx, gWo, gbo, beta=0.0)
+        dcx = ops.linear_bf16(dbr, Wo_b.t().contiguous())                                     # [M, D]
         # ---- core: dP = dctx V^T ; dS = P (dP - rowsum(P dP)) scale
         dP = torch.empty(B, H, Sp, Sp, device=dev, dtype=torch.float32)
         ops.gemm_raw(dcx, D, qkv[:, 2 * D:], 3 * D, dP, Sp, Sp, Sp, dh, out_f32=True, nb1=B, nb2=H,
                      sA=(Sp * D, dh), sW=(Sp * 3 * D, dh), sC=(H * Sp * Sp, Sp * Sp))
-        dS = ops.softmax_bwd(dP, P, dh ** -0.5, p_drop, seed)
+        dS = ops.softmax_bwd(dP, P, dh_true ** -0.5, p_drop, seed)
         del dP
         dqkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
         # dV = Pd^T dctx   (A = Pd^T from one 2-D transpose [Sp, B H Sp]; W = dctx^T [D, M])
@@ -119,16 +136,97 @@ class MhaNormFn(torch.autograd.Function):
         ops.gemm_raw(dST, B * H * Sp, qT, M, dqkv[:, D: 2 * D], 3 * D, Sp, dh, Sp, nb1=B, nb2=H,
                      sA=(H * Sp, Sp), sW=(Sp, dh * M), sC=(Sp * 3 * D, dh))
         # ---- in_proj (+ the residual branch's gradient)
-        gWi = torch.empty(3 * D, D, device=dev, dtype=torch.float32)
+        gWi = torch.empty(3 * D, Dm, device=dev, dtype=torch.float32)
         gbi = torch.empty(3 * D, device=dev, dtype=torch.float32)
         ops.wgrad_bf16(dqkv, xb, gWi, gbi, beta=0.0)
         dx = ops.linear_bf16(dqkv, Wi_b.t().contiguous(), residual=dpre)
-        dx = dx.view(B, Sp, D)[:, :S].to(xdtype)
-        return dx, gWi, gbi, gWo, gbo, dg, dbeta, None, None, None, None, None
+        dx = dx.view(B, Sp, Dm)[:, :S].to(xdtype)
+        if dh != dh_true:                                   # drop the gradients of the zero padding
+            gWi = gWi.view(3, H, dh, Dm)[:, :, :dh_true].reshape(3 * Dm, Dm)
+            gbi = gbi.view(3, H, dh)[:, :, :dh_true].reshape(3 * Dm)
+            gWo = gWo.view(Dm, H, dh)[:, :, :dh_true].reshape(Dm, Dm)
+        return dx, gWi, gbi, gWo, gbo, dg, dbeta, None, None, None, None, None, None, None
 
 
 def mha_norm(x: torch.Tensor, mha: torch.nn.MultiheadAttention, norm: torch.nn.LayerNorm, key_padding_mask: torch.Tensor,
-             training: bool) -> torch.Tensor:
+             training: bool, p_res: float = 0.0) -> torch.Tensor:
+    """``norm(x + dropout_res(MHA(x, x, x, key_padding_mask)))``; ``p_res`` = nn.TransformerEncoderLayer's dropout1 (the bare
+    MultiheadAttentionAndNorm block has none)."""
     p = float(mha.dropout) if training else 0.0
+    p_res = float(p_res) if training else 0.0
     return MhaNormFn.apply(x, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, norm.weight,
-                           norm.bias, key_padding_mask, mha.num_heads, norm.eps, p, _next_seed() if p > 0.0 else 0)
+                           norm.bias, key_padding_mask, mha.num_heads, norm.eps, p, _next_seed() if p > 0.0 else 0,
+                           p_res, _next_seed() if p_res > 0.0 else 0)
+
+
+class FfnNormFn(torch.autograd.Function):
+    """``LayerNorm(x + drop2(W2 drop1(gelu(W1 x + b1)) + b2))``: the feed-forward half of a post-LN nn.TransformerEncoderLayer
+    (avssl/module/kw_modules/TransformerModels.py:60-70) on the library's kernels: bias + GELU / bias + dropout + residual in the
+    GEMM epilogues, hash dropout masks regenerated in the backward, split-K weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, g, beta, eps, p_drop, seed1, seed2):
+        B, S, D = x.shape
+        dev, bf = x.device, torch.bfloat16
+        Sp = _roundup(S, 64)
+        M = B * Sp
+        xb = torch.zeros(B, Sp, D, device=dev, dtype=bf)
+        xb[:, :S] = x.detach()
+        xb = xb.view(M, D)
+        W1b, W2b = W1.detach().to(bf).contiguous(), W2.detach().to(bf).contiguous()
+        u = ops.linear_bf16(xb, W1b, b1.detach().float().contiguous())                        # pre-activation (kept for GELU')
+        f = ops.act_bf16(u, 1)
+        if p_drop > 0.0:
+            ops.dropout_bf16(f, p_drop, seed1, out=f)
+        pre = ops.linear_bf16(f, W2b, b2.detach().float().contiguous(), residual=xb, drop_p=p_drop, drop_seed=seed2)
+        g32, b32 = g.detach().float().clone(), beta.detach().float().clone()
+        out = ops.layernorm_bf16(pre, g32, b32, eps=eps)
+        ctx.save_for_backward(xb, W1b, W2b, u, f, pre, g32)
+        ctx.meta = (B, S, Sp, D, eps, p_drop, seed1, seed2, x.dtype)
+        return out.view(B, Sp, D)[:, :S].to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xb, W1b, W2b, u, f, pre, g = ctx.saved_tensors
+        B, S, Sp, D, eps, p_drop, seed1, seed2, xdtype = ctx.meta
+        dev, bf = dout.device, torch.bfloat16
+        M, F_ = B * Sp, W1b.shape[0]
+        dy = torch.zeros(B, Sp, D, device=dev, dtype=bf)
+        dy[:, :S] = dout
+        dy = dy.view(M, D)
+        dpre, dg, dbeta = ops.layernorm_bwd(pre, dy, g, eps, want_param_grads=True)
+        dbr = ops.dropout_bf16(dpre, p_drop, seed2) if p_drop > 0.0 else dpre
+        gW2 = torch.empty(D, F_, device=dev, dtype=torch.float32)
+        gb2 = torch.empty(D, device=dev, dtype=torch.float32)
+        ops.wgrad_bf16(dbr, f, gW2, gb2, beta=0.0)
+        df = ops.linear_bf16(dbr, W2b.t().contiguous())
+        if p_drop > 0.0:
+            ops.dropout_bf16(df, p_drop, seed1, out=df)
+        du = ops.act_bf16(u, 1, df=df, out=df)
+        gW1 = torch.empty(F_, D, device=dev, dtype=torch.float32)
+        gb1 = torch.empty(F_, device=dev, dtype=torch.float32)
+        ops.wgrad_bf16(du, xb, gW1, gb1, beta=0.0)
+        dx = ops.linear_bf16(du, W1b.t().contiguous(), residual=dpre)
+        return dx.view(B, Sp, D)[:, :S].to(xdtype), gW1, gb1, gW2, gb2, dg, dbeta, None, None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last dimension on the row kernels (bf16 rows, fp32 statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, g, beta, eps):
+        shape = x.shape
+        D = shape[-1]
+        xb = x.detach().reshape(-1, D).to(torch.bfloat16).contiguous()
+        g32, b32 = g.detach().float().clone(), beta.detach().float().clone()
+        ctx.save_for_backward(xb, g32)
+        ctx.meta = (shape, eps, x.dtype)
+        return ops.layernorm_bf16(xb, g32, b32, eps=eps).view(shape).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, g = ctx.saved_tensors
+        shape, eps, dtype = ctx.meta
+        dyb = dy.reshape(-1, shape[-1]).to(torch.bfloat16).contiguous()
+        dx, dg, db = ops.layernorm_bwd(xb, dyb, g, eps, want_param_grads=True)
+        return dx.view(shape).to(dtype), dg, db, None

@@ -19,6 +19,12 @@ def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
     return ctypes.c_void_p(t.data_ptr())
 
 
+def aligned16(t: torch.Tensor) -> torch.Tensor:
+    """``t`` itself when its storage offset is 16-byte aligned, else a fresh copy (trainable parameters are views into the
+    optimiser's flat buffer at 4-byte granularity; kernels that load 16 bytes per lane need aligned bases)."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -257,7 +263,8 @@ def cif_fwd(x: torch.Tensor, alpha: torch.Tensor, csum: torch.Tensor, T: int, th
 
 
 def cif_bwd(x: torch.Tensor, alpha: torch.Tensor, csum: torch.Tensor, g: torch.Tensor, T: int, thr: float):
-    """-> (dx [B,S,C], d alpha (direct part) [B,S], d csum [B,S])"""
+    """-> (dx [B,S,C], pa, pb [nblk,B,S]): per-channel-block partials of d alpha (direct part) and d csum (sc_cif_prepare_bwd adds
+    them up)."""
     B, S, C = x.shape
     assert g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == (B, T + 1, C)
     nblk = (C + 255) // 256
@@ -265,7 +272,172 @@ def cif_bwd(x: torch.Tensor, alpha: torch.Tensor, csum: torch.Tensor, g: torch.T
     pa = torch.empty(nblk, B, S, device=x.device, dtype=torch.float32)
     pb = torch.empty(nblk, B, S, device=x.device, dtype=torch.float32)
     check(lib().sc_cif_bwd(_p(x), _p(alpha), _p(csum), _p(g), _p(dx), _p(pa), _p(pb), B, S, C, T, float(thr), _stream()), "sc_cif_bwd")
-    return dx, pa.sum(0), pb.sum(0)
+    return dx, pa, pb
+
+
+def cif_prepare(alpha_raw: torch.Tensor, pad: torch.Tensor, target: Optional[torch.Tensor], apply_scaling: bool, thr: float, eps: float,
+                max_feat: int, T: int, flags: torch.Tensor) -> dict:
+    """CIF bookkeeping of one batch on the device (sc_cif_prepare): alpha_raw [B,S] fp32 (row stride free), pad [B,S] uint8 / bool."""
+    B, S = alpha_raw.shape
+    assert alpha_raw.dtype == torch.float32 and alpha_raw.stride(1) == 1 and pad.element_size() == 1 and pad.stride(1) == 1
+    assert flags.dtype == torch.int32 and flags.numel() >= 2
+    if target is not None:
+        assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == B
+    dev = alpha_raw.device
+    f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+    r = dict(a_clip=f(B, S), alpha=f(B, S), csum=f(B, S), quantity=f(B), ratio=f(B),
+             feat_len=torch.empty(B, device=dev, dtype=torch.int64), fired=torch.empty(B, S, device=dev, dtype=torch.uint8))
+    check(lib().sc_cif_prepare(_p(alpha_raw), alpha_raw.stride(0), _p(pad), pad.stride(0), _p(target), int(bool(apply_scaling)), B, S,
+                               float(thr), float(eps), int(max_feat), int(T), _p(r["a_clip"]), _p(r["alpha"]), _p(r["csum"]),
+                               _p(r["quantity"]), _p(r["ratio"]), _p(r["feat_len"]), _p(r["fired"]), _p(flags), _stream()),
+          "sc_cif_prepare")
+    return r
+
+
+def cif_prepare_bwd(pa: torch.Tensor, pb: torch.Tensor, a_clip: torch.Tensor, pad: torch.Tensor, ratio: torch.Tensor,
+                    quantity: torch.Tensor, gq: Optional[torch.Tensor], scaled: bool) -> torch.Tensor:
+    nblk, B, S = pa.shape
+    da = torch.empty(B, S, device=pa.device, dtype=torch.float32)
+    if gq is not None:
+        assert gq.dtype == torch.float32 and gq.is_contiguous()
+    check(lib().sc_cif_prepare_bwd(_p(pa), _p(pb), nblk, B, S, _p(a_clip), _p(pad), pad.stride(0), _p(ratio), _p(quantity), _p(gq),
+                                   int(bool(scaled)), _p(da), _stream()), "sc_cif_prepare_bwd")
+    return da
+
+
+def cif_tail(alpha: torch.Tensor, csum: torch.Tensor, feat_len: torch.Tensor, out: torch.Tensor, T: int, thr: float, tail_thr: float,
+             max_feat: int):
+    """in place on ``feat_len`` and ``out`` [B,T+1,C]; returns (factor [B] fp32, extend [B] uint8)."""
+    B, S = alpha.shape
+    C = out.shape[2]
+    assert tuple(out.shape) == (B, T + 1, C) and out.is_contiguous() and feat_len.dtype == torch.int64
+    factor = torch.empty(B, device=alpha.device, dtype=torch.float32)
+    extend = torch.empty(B, device=alpha.device, dtype=torch.uint8)
+    check(lib().sc_cif_tail(_p(alpha), _p(csum), B, S, C, int(T), float(thr), float(tail_thr), int(max_feat), _p(feat_len), _p(out),
+                            _p(factor), _p(extend), _stream()), "sc_cif_tail")
+    return factor, extend
+
+
+# ---- keyword -> sub-word vector quantiser (csrc/vq.hip) ---------------------------------------------------------------
+def vq_prep(kw: torch.Tensor, eps: float = 1e-8):
+    """kw [Nk, Et] fp32 -> (kwn_T [Et, Nkp] fp32 normalised + transposed, Nkp = roundup(Nk, 128); rnorm [Nk])."""
+    Nk, Et = kw.shape
+    assert kw.dtype == torch.float32 and kw.stride(1) == 1
+    Nkp = (Nk + 127) // 128 * 128
+    kwn_T = torch.empty(Et, Nkp, device=kw.device, dtype=torch.float32)
+    rnorm = torch.empty(Nk, device=kw.device, dtype=torch.float32)
+    check(lib().sc_vq_prep_f32(_p(kw), kw.stride(0), Nk, Et, float(eps), _p(kwn_T), Nkp, _p(rnorm), _stream()), "sc_vq_prep_f32")
+    return kwn_T, rnorm
+
+
+def sgemm_mfma(A: torch.Tensor, Bm: torch.Tensor, a_kmajor: bool = False, b_kmajor: bool = False, bias: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C [M, N] = A . B^T (+ bias) in exact fp32 on the matrix pipe.  A: [M, K] (or [K, M] with a_kmajor), B: [N, K] (nn.Linear
+    layout; or [K, N] with b_kmajor); row-major operands need K % 4 == 0."""
+    assert A.dtype == torch.float32 and Bm.dtype == torch.float32 and A.stride(1) == 1 and Bm.stride(1) == 1
+    A, Bm = aligned16(A), aligned16(Bm)
+    K, M = A.shape if a_kmajor else A.shape[::-1]
+    K2, N = Bm.shape if b_kmajor else Bm.shape[::-1]
+    assert K == K2, (A.shape, Bm.shape)
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.stride(1) == 1
+    if _timer is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().sc_sgemm_mfma_f32(_p(A), A.stride(0), int(a_kmajor), _p(Bm), Bm.stride(0), int(b_kmajor), _p(out), out.stride(0), M, N, K,
+                                  _p(bias), _stream()), "sc_sgemm_mfma_f32")
+    if _timer is not None:
+        ev1.record()
+        _timer.add("sgemm_mfma_f32", ev0, ev1, 2.0 * M * N * K)
+    return out
+
+
+def vq_rowstats(x: torch.Tensor, V: int, temp: float, mask_cols=(0, 2, 3)):
+    """x [Nk, >= V] fp32 (masked columns overwritten with -inf) -> idx [Nk] int64, lse_t, lse_1, ent [Nk] fp32."""
+    Nk = x.shape[0]
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] >= V
+    dev = x.device
+    idx = torch.empty(Nk, device=dev, dtype=torch.int64)
+    lse_t, lse_1, ent = (torch.empty(Nk, device=dev, dtype=torch.float32) for _ in range(3))
+    cols = [int(c) for c in mask_cols if 0 <= int(c) < V]
+    assert len(cols) <= 4
+    arr = (ctypes.c_int32 * 4)(*(cols + [-1] * (4 - len(cols))))
+    check(lib().sc_vq_rowstats(_p(x), x.stride(0), Nk, V, float(temp), arr, len(cols), _p(idx), _p(lse_t), _p(lse_1), _p(ent), _stream()),
+          "sc_vq_rowstats")
+    return idx, lse_t, lse_1, ent
+
+
+def vq_perplexity(x: torch.Tensor, V: int, idx: torch.Tensor, lse_1: torch.Tensor, nchunk: int = 16) -> torch.Tensor:
+    """-> [code_perplexity, prob_perplexity] (fp32, device)."""
+    Nk = x.shape[0]
+    nchunk = max(1, min(nchunk, Nk))
+    partial = torch.empty(nchunk, V, device=x.device, dtype=torch.float32)
+    hist = torch.empty(V, device=x.device, dtype=torch.int32)
+    out = torch.empty(2, device=x.device, dtype=torch.float32)
+    check(lib().sc_vq_perplexity(_p(x), x.stride(0), Nk, V, _p(idx), _p(lse_1), _p(partial), nchunk, _p(hist), _p(out), _stream()),
+          "sc_vq_perplexity")
+    return out
+
+
+def vq_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    Nk, Et = idx.numel(), table.shape[1]
+    assert table.dtype == torch.float32 and table.stride(1) == 1 and idx.dtype == torch.int64
+    out = torch.empty(Nk, Et, device=table.device, dtype=torch.float32)
+    check(lib().sc_vq_gather_f32(_p(table), table.stride(0), _p(idx), _p(out), Et, Nk, Et, _stream()), "sc_vq_gather_f32")
+    return out
+
+
+def vq_onehot(idx: torch.Tensor, V: int) -> torch.Tensor:
+    out = torch.empty(idx.numel(), V, device=idx.device, dtype=torch.float32)
+    check(lib().sc_vq_onehot_f32(_p(idx), _p(out), V, idx.numel(), V, _stream()), "sc_vq_onehot_f32")
+    return out
+
+
+def vq_soft_bwd(x: torch.Tensor, lse_t: torch.Tensor, t: torch.Tensor, V: int, temp: float, out_bf16: bool, Vpad: Optional[int] = None):
+    """dx [Nk, Vpad] = softmax(x / temp)(t - <softmax, t>) / temp; x, t [Nk, >= V] fp32."""
+    Nk = x.shape[0]
+    Vpad = V if Vpad is None else Vpad
+    assert x.dtype == torch.float32 and t.dtype == torch.float32 and x.stride(1) == 1 and t.stride(1) == 1
+    dx = torch.empty(Nk, Vpad, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    check(lib().sc_vq_soft_bwd(_p(x), x.stride(0), _p(lse_t), _p(t), t.stride(0), Nk, V, Vpad, float(temp), _p(dx), Vpad,
+                               int(out_bf16), _stream()), "sc_vq_soft_bwd")
+    return dx
+
+
+def vq_norm_bwd(kw: torch.Tensor, rnorm: torch.Tensor, dy: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    Nk, Et = kw.shape
+    assert kw.dtype == torch.float32 and dy.dtype == torch.float32 and kw.stride(1) == 1 and dy.stride(1) == 1
+    dx = torch.empty(Nk, Et, device=kw.device, dtype=torch.float32)
+    check(lib().sc_vq_norm_bwd_f32(_p(kw), kw.stride(0), _p(rnorm), _p(dy), dy.stride(0), float(eps), _p(dx), Et, Nk, Et, _stream()),
+          "sc_vq_norm_bwd_f32")
+    return dx
+
+
+def bn_rows_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, run_mean: torch.Tensor, run_var: torch.Tensor,
+                training: bool, momentum: float, eps: float):
+    """BatchNorm over the rows of x [N, E] fp32 -> (y, save_mean, save_rstd); running estimates updated in place when training."""
+    N, E = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    for t in (gamma, beta, run_mean, run_var):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == E
+    y = torch.empty(N, E, device=x.device, dtype=torch.float32)
+    sm = torch.empty(E, device=x.device, dtype=torch.float32) if training else None
+    sr = torch.empty(E, device=x.device, dtype=torch.float32) if training else None
+    check(lib().sc_bn_rows_fwd(_p(x), x.stride(0), N, E, _p(gamma), _p(beta), _p(run_mean), _p(run_var), int(training), float(momentum),
+                               float(eps), _p(y), E, _p(sm), _p(sr), _stream()), "sc_bn_rows_fwd")
+    return y, sm, sr
+
+
+def bn_rows_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, save_mean: torch.Tensor, save_rstd: torch.Tensor):
+    N, E = x.shape
+    assert dy.dtype == torch.float32 and dy.stride(1) == 1 and tuple(dy.shape) == (N, E)
+    dx = torch.empty(N, E, device=x.device, dtype=torch.float32)
+    dg = torch.empty(E, device=x.device, dtype=torch.float32)
+    db = torch.empty(E, device=x.device, dtype=torch.float32)
+    check(lib().sc_bn_rows_bwd(_p(x), x.stride(0), _p(dy), dy.stride(0), N, E, _p(gamma), _p(save_mean), _p(save_rstd), _p(dx), E,
+                               _p(dg), _p(db), _stream()), "sc_bn_rows_bwd")
+    return dx, dg, db
 
 
 def softmax_fwd(scores: torch.Tensor, key_mask: torch.Tensor, rows_per_batch: int, scale: float, drop_p: float = 0.0,

@@ -1,5 +1,9 @@
-"""MLPLayers (avssl/module/projections.py:6-29): Linear / ReLU / Dropout stack without the trailing ReLU+Dropout."""
+"""MLPLayers (avssl/module/projections.py:6-29): Linear / ReLU / Dropout stack without the trailing ReLU + Dropout (the keyword
+projection 1024 -> 1024 -> 768 of the hybrid+ large recipe).  The Linear layers run in exact fp32 on the matrix pipe
+(linear_fn.LinearF32Fn): what they produce is compared against the whole vocabulary by an argmax."""
 from torch import nn
+
+from .linear_fn import linear_f32_autograd
 
 __all__ = ["MLPLayers"]
 
@@ -14,4 +18,6 @@ class MLPLayers(nn.Module):
         self.sequential = nn.Sequential(*seq[:-2])
 
     def forward(self, X):
-        return self.sequential(X)
+        for m in self.sequential:
+            X = linear_f32_autograd(X, m.weight, m.bias) if isinstance(m, nn.Linear) else m(X)
+        return X

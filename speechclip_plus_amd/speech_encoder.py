@@ -330,6 +330,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         host = torch.tensor([list(map(int, wav_len)), valid, feat_len], dtype=torch.int64).pin_memory()
         ints = host.to(self._dev, non_blocking=True)
         pl.feat_len = ints[2]
+        pl.feat_len._sc_host = list(feat_len)       # host twin (length-derived integers are known before any kernel runs)
         pl.len_dev.copy_(ints[0])
         pl.valid.copy_(ints[1])
         # The frozen encoder is a fixed sequence of ~130 launches over the plan's resident buffers.  Opt-in (SC_ENCODER_GRAPH=1):

@@ -10,11 +10,9 @@ one-row-per-utterance remainder of the post-LN layer (out_proj, LayerNorm, FFN, 
 projection) runs in fp32 on the master weights in csrc/headtail.hip - see head_tail.py.
 """
 import logging
-import math
 from typing import Optional, Tuple
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops
@@ -40,17 +38,38 @@ class TransformerEncoder(nn.Module):
         self.n_layers, self.d_model, self.nhead = n_layers, d_model, nhead
         self.norm_first, self.layer_norm_eps, self.dropout = norm_first, layer_norm_eps, dropout
 
+    def _layer(self, mod: nn.TransformerEncoderLayer, x: torch.Tensor, key_padding_mask: torch.Tensor) -> torch.Tensor:
+        """One post-LN nn.TransformerEncoderLayer on the library's kernels: norm1(x + drop(MHA(x))) -> norm2(. + drop(FFN(.)))
+        (mha_block.MhaNormFn / FfnNormFn; any head_dim).  Train mode runs the layer's three dropout sites."""
+        from .mha_block import FfnNormFn, _next_seed, mha_norm
+        p = float(self.dropout) if self.training else 0.0
+        x = mha_norm(x, mod.self_attn, mod.norm1, key_padding_mask, self.training, p_res=p)
+        return FfnNormFn.apply(x, mod.linear1.weight, mod.linear1.bias, mod.linear2.weight, mod.linear2.bias, mod.norm2.weight,
+                               mod.norm2.bias, mod.norm2.eps, p, _next_seed() if p > 0 else 0, _next_seed() if p > 0 else 0)
+
+    def _check(self, src: torch.Tensor) -> None:
+        if not src.is_cuda:
+            raise RuntimeError("TransformerEncoder runs on the HIP kernels: device tensors only (CPU restatement: oracle/head_ref.py)")
+        if self.norm_first:
+            raise NotImplementedError("norm_first = True is not used by any shipped config")
+
     def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
-        """Full-sequence path (every row is needed by the cascaded+/hybrid+ branches that feed CIF; scope row a11:
-        stock device-side torch ops until the head_dim 96/128 attention kernel of row f3 exists)."""
-        return self.model(src=src.float(), src_key_padding_mask=key_padding_mask)
+        """Full-sequence path (TransformerModels.py:73-83): every layer, then the final LayerNorm."""
+        from .mha_block import LayerNormFn
+        self._check(src)
+        output = src.float()
+        for mod in self.model.layers:
+            output = self._layer(mod, output, key_padding_mask)
+        norm = self.model.norm
+        return LayerNormFn.apply(output, norm.weight, norm.bias, norm.eps)
 
     def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
         """TransformerModels.py:16-45,85-97: inputs of every layer + output of the last, before the final norm."""
+        self._check(src)
         output, hidden = src.float(), []
         for mod in self.model.layers:
             hidden.append(output)
-            output = mod(output, src_key_padding_mask=key_padding_mask)
+            output = self._layer(mod, output, key_padding_mask)
         hidden.append(output)
         return tuple(hidden)
 
@@ -88,37 +107,14 @@ class MultiheadAttentionAndNorm(nn.Module):
         self.attentionBlock_Norm = nn.LayerNorm(d_model, eps=layer_norm_eps)
 
     def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
-        """LN(MHA(x, x, x) + x) (TransformerModels.py:120-126).  On a GPU the whole block - projections, S x S core as batched bf16
-        GEMMs (any head_dim that is a multiple of 64: 768 / 128 in the shipped recipes), residual, LayerNorm, and their backward -
-        runs on the library's kernels (mha_block.MhaNormFn).  Train mode applies nn.MultiheadAttention's dropout to the attention
-        probabilities."""
-        src = src.float()
-        mha = self.multihead_attn_layer
+        """LN(MHA(x, x, x) + x) (TransformerModels.py:120-126): the whole block - projections, S x S core as batched bf16 GEMMs (any
+        head_dim: 768 / 128 / 96 in the shipped recipes), residual, LayerNorm, and their backward - runs on the library's
+        kernels (mha_block.MhaNormFn).  Train mode applies nn.MultiheadAttention's dropout to the attention probabilities."""
         if not src.is_cuda:
-            return self.attentionBlock_Norm(mha(src, src, src, key_padding_mask=key_padding_mask)[0] + src)
-        D, H = src.shape[-1], mha.num_heads
-        if D % 64 == 0 and D % H == 0 and (D // H) % 64 == 0:
-            from .mha_block import mha_norm                  # whole block (projections, S x S core, residual, LayerNorm) on own kernels
-            return mha_norm(src, mha, self.attentionBlock_Norm, key_padding_mask, self.training)
-        return self._forward_stock_core(src, key_padding_mask)
-
-    def _forward_stock_core(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
-        """head_dim not a multiple of 64: projections on the library's GEMM, fp32 torch bmm core."""
-        mha = self.multihead_attn_layer
-        from .linear_fn import linear_bf16_autograd
-        B, S, D = src.shape
-        H = mha.num_heads
-        dh = D // H
-        qkv = linear_bf16_autograd(src, mha.in_proj_weight, mha.in_proj_bias)                  # (B, S, 3D)
-        q, k, v = (t.reshape(B, S, H, dh).transpose(1, 2).reshape(B * H, S, dh).contiguous() for t in qkv.split(D, dim=-1))
-        scores = torch.bmm(q, k.transpose(1, 2)).view(B, H, S, S) * dh ** -0.5
-        scores = scores.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
-        p = torch.softmax(scores, dim=-1).view(B * H, S, S)
-        if self.training and mha.dropout > 0:
-            p = torch.nn.functional.dropout(p, mha.dropout)
-        ctx = torch.bmm(p, v).view(B, H, S, dh).transpose(1, 2).reshape(B, S, D)
-        out = linear_bf16_autograd(ctx, mha.out_proj.weight, mha.out_proj.bias)
-        return self.attentionBlock_Norm(out + src)
+            raise RuntimeError("MultiheadAttentionAndNorm runs on the HIP kernels: device tensors only (CPU restatement: "
+                               "oracle/head_ref.py)")
+        from .mha_block import mha_norm
+        return mha_norm(src.float(), self.multihead_attn_layer, self.attentionBlock_Norm, key_padding_mask, self.training)
 
     def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
         return tuple([src, self.forward(src, key_padding_mask)])

@@ -1,6 +1,8 @@
-"""Scope row a11 (cascaded+/hybrid+ tail, stock torch ops): the product modules against golden vectors produced
-by the reference's own leaf files (cif.py, my_vector_quantizer.py, kw_bn.py; tests/golden/make_golden.py).
-These modules are device-agnostic torch code, so the fixtures are checked on CPU here and again on the GPU."""
+"""Helpers of tests/test_gpu_cascaded.py (not collected on their own): the product modules of scope row a11 (cascaded+/hybrid+
+tail: CIF, vector quantiser, keyword BatchNorm, the two plus-branches) against the golden vectors produced by the reference's own
+leaf files (cif.py, my_vector_quantizer.py, kw_bn.py; tests/golden/make_golden.py) and against the oracle.  The product modules
+run on the HIP kernels only, so every check here needs the GPU; the same fixtures pin the ORACLE on the CPU in
+tests/test_oracle_golden.py."""
 import numpy as np
 import pytest
 import torch
@@ -10,7 +12,7 @@ from conftest import weights_from
 T = torch.from_numpy
 
 
-def _cif(fx, dev="cpu"):
+def _cif(fx, dev="cuda"):
     from speechclip_plus_amd.cif import CIF
     m = CIF(cif_threshold=1.0, cif_output_dim=32, encoder_embed_dim=32, produce_weight_type="conv", num_layer=1,
             conv_cif_width=3, apply_scaling=True, apply_tail_handling=True, tail_handling_firing_threshold=0.5,
@@ -19,7 +21,7 @@ def _cif(fx, dev="cpu"):
     return m.to(dev)
 
 
-def check_cif(golden, dev="cpu"):
+def check_cif(golden, dev="cuda"):
     fx = golden("cif_d32.npz")
     m = _cif(fx, dev)
     feat = T(fx["feat"]).to(dev).requires_grad_(True)
@@ -47,7 +49,7 @@ def check_cif(golden, dev="cpu"):
     np.testing.assert_allclose(r["dsample_feats"].cpu().numpy(), fx["ns_feats"], rtol=1e-4, atol=1e-5)
 
 
-def check_vq(golden, dev="cpu"):
+def check_vq(golden, dev="cuda"):
     from speechclip_plus_amd.vector_quantizers import SimpleVectorQuantizer
     fx = golden("vq_v50.npz")
     vq = SimpleVectorQuantizer(temp="fixed=0.1", time_first=True, use_gumbel=False, hard=True).to(dev)
@@ -66,7 +68,7 @@ def check_vq(golden, dev="cpu"):
     np.testing.assert_allclose(x.grad.cpu().numpy(), fx["tr_gx"], rtol=1e-3, atol=1e-6)
 
 
-def check_bn(golden, dev="cpu"):
+def check_bn(golden, dev="cuda"):
     from speechclip_plus_amd.vector_quantizers import Kw_BatchNorm_dynamic
     fx = golden("kwbn_e16.npz")
     bn = Kw_BatchNorm_dynamic(kw_dim=16, init_bias=T(fx["init_bias"]), init_scale=T(fx["init_weight"]), std_scale=1.0).to(dev)
@@ -80,36 +82,25 @@ def check_bn(golden, dev="cpu"):
         np.testing.assert_allclose(sd[k].numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
 
 
-def test_cif_golden(golden):
-    check_cif(golden)
-
-
-def test_vq_golden(golden):
-    check_vq(golden)
-
-
-def test_kw_batchnorm_golden(golden):
-    check_bn(golden)
-
-
-def test_clip_text_encode_keywords_matches_loop():
+def check_clip_text_encode_keywords_matches_loop(dev="cuda"):
     """encode_keywords: the vectorised keyword splice equals the reference's per-row loop semantics
     (clip_official.py:261-263) and the int keyword_num variant; causal mask: EOT row ignores later positions."""
     from speechclip_plus_amd.clip_text import ClipModel, CONTEXT_LEN
     ids = torch.cat([torch.arange(0, 40), torch.tensor([49406, 49407])])
-    clip = ClipModel("ViT-B/32", device="cpu", reduce_subword_embbedding=ids, layers=2, seed=7).eval()
+    clip = ClipModel("ViT-B/32", device=dev, reduce_subword_embbedding=ids, layers=2, seed=7).eval()
     W = clip.model.token_embedding.weight.shape[1]
     g = torch.Generator().manual_seed(0)
-    kws = torch.randn(3, 6, W, generator=g) * 0.02
-    n = torch.tensor([6, 2, 4])
+    kws = (torch.randn(3, 6, W, generator=g) * 0.02).to(dev)
+    n = torch.tensor([6, 2, 4]).to(dev)
     out = clip.encode_keywords(kws, n)
     assert out.shape == (3, 512)
     for b in range(3):
         one = clip.encode_keywords(kws[b: b + 1, : int(n[b])], int(n[b]))
-        np.testing.assert_allclose(out[b].detach().numpy(), one[0].detach().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out[b].detach().cpu().numpy(), one[0].detach().cpu().numpy(), rtol=2e-2, atol=2e-3)
     kws2 = kws.clone()
     kws2[1, 2:] += 5.0                       # beyond utterance 1's 2 keywords: must not matter
-    np.testing.assert_allclose(clip.encode_keywords(kws2, n)[1].detach().numpy(), out[1].detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(clip.encode_keywords(kws2, n)[1].detach().cpu().numpy(), out[1].detach().cpu().numpy(), rtol=1e-5,
+                               atol=1e-6)
     assert all(not p.requires_grad for p in clip.parameters())
     kws.requires_grad_(True)
     clip.encode_keywords(kws, n).sum().backward()         # gradient flows THROUGH the frozen tower
@@ -133,12 +124,12 @@ def _small_cfg(kind, D=64, E=48):
                              "batch_first": True, "norm_first": False}}}})
 
 
-def build_branch(kind, dev="cpu"):
+def build_branch(kind, dev="cuda"):
     from speechclip_plus_amd import KW_CascadedBranchPlus, KW_HybridBranchPlus
     from speechclip_plus_amd.clip_text import ClipModel
     torch.manual_seed(11 if kind == "hybrid" else 12)
     ids = torch.cat([torch.arange(0, 200), torch.tensor([49406, 49407])])
-    clip = ClipModel("ViT-B/32", device="cpu", reduce_subword_embbedding=ids, layers=2, seed=3)
+    clip = ClipModel("ViT-B/32", device=dev, reduce_subword_embbedding=ids, layers=2, seed=3)
     cfg = _small_cfg(kind)
     if kind == "hybrid":
         br = KW_HybridBranchPlus(cfg, audio_dim=64, text_dim=512, out_dim=512, clip=clip)
@@ -153,7 +144,7 @@ def build_branch(kind, dev="cpu"):
     return br.to(dev), clip
 
 
-def check_branch_vs_oracle(kind, dev="cpu"):
+def check_branch_vs_oracle(kind, dev="cuda"):
     import oracle
     br, clip = build_branch(kind, dev)
     W = {k: v.detach().cpu().float() for k, v in br.state_dict().items()}
@@ -190,8 +181,3 @@ def check_branch_vs_oracle(kind, dev="cpu"):
             # every block -> rel-L2 <= 2e-2, cosine >= 0.999 (the tolerances of the HuBERT hidden states)
             assert float((got - want).norm() / want.norm()) < 2e-2
             assert float(torch.nn.functional.cosine_similarity(got, want, dim=-1).min()) > 0.999
-
-
-@pytest.mark.parametrize("kind", ["cascaded", "hybrid"])
-def test_plus_branch_vs_oracle(kind):
-    check_branch_vs_oracle(kind)

@@ -148,6 +148,50 @@ def make_head():
         **{"W_" + k: v for k, v in blk.state_dict().items()})
 
 
+def make_mha():
+    """MultiheadAttentionAndNorm at head_dim 64 (D = 128, 2 heads) and head_dim 96 (D = 192, 2 heads: the hybrid+ base
+    geometry 768 / 8 scaled down): output, input gradient and every parameter gradient (eval mode: dropout off)."""
+    TM = load_leaf("avssl/module/kw_modules/TransformerModels.py", "ref_tm")
+    du = load_leaf("avssl/util/data_utils.py", "ref_du")
+    for name, D, nhead, T, lens in [("mha_norm_d128_h2", 128, 2, 20, [20, 9, 1]), ("mha_norm_d192_h2", 192, 2, 20, [20, 13, 4])]:
+        torch.manual_seed(zlib.crc32(name.encode()) % 2**31)
+        blk = TM.MultiheadAttentionAndNorm(d_model=D, nhead=nhead, dropout=0.1, layer_norm_eps=1e-5, batch_first=True)
+        with torch.no_grad():
+            for n, p in blk.named_parameters():
+                if "Norm" in n or "bias" in n:
+                    p.add_(0.1 * torch.randn_like(p))
+        blk.eval()
+        src = torch.randn(len(lens), T, D, requires_grad=True)
+        kpm = du.get_keypadding_mask(T, torch.tensor(lens))
+        out = blk(src, kpm)
+        gout = torch.randn_like(out)
+        (out * gout).sum().backward()
+        npz(name + ".npz", src=src, lens=np.array(lens), out=out, gout=gout, g_src=src.grad, nhead=np.int64(nhead),
+            **{"W_" + k: v for k, v in blk.state_dict().items()}, **{"g_" + n: p.grad for n, p in blk.named_parameters()})
+
+
+def make_loss_variants():
+    """MaskedContrastiveLoss options beyond the shipped defaults (losses.py:213,226-245): margin, dcl, one-sided."""
+    ref = load_leaf("avssl/module/losses.py", "ref_losses_v")
+    for name, kw in [("loss_v_margin", dict(margin=0.3)), ("loss_v_dcl", dict(dcl=True)), ("loss_v_a2b", dict(b2a=False)),
+                     ("loss_v_b2a", dict(a2b=False)), ("loss_v_margin_dcl_trainT", dict(margin=0.2, dcl=True, temperature_trainable=True))]:
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 2**31)
+        B, E = 40, 32
+        A = unit(torch.randn(B, E, generator=g)).requires_grad_(True)
+        Bm = unit(torch.randn(B, E, generator=g) + 0.5 * A.detach()).requires_grad_(True)
+        ids = torch.arange(B) // 5
+        crit = ref.MaskedContrastiveLoss(temperature=0.07, **kw)
+        loss = crit(A, Bm, ids)
+        loss.backward()
+        extra = {}
+        if kw.get("temperature_trainable"):
+            extra["dtemp_param"] = crit.temperature.grad
+        loss_noidx = crit(A.detach(), Bm.detach(), None)
+        npz(name + ".npz", A=A, B=Bm, ids=ids, loss=loss, dA=A.grad, dB=Bm.grad, loss_noindex=loss_noidx,
+            margin=np.float32(kw.get("margin", 0.0)), dcl=np.int64(kw.get("dcl", False)), a2b=np.int64(kw.get("a2b", True)),
+            b2a=np.int64(kw.get("b2a", True)), trainT=np.int64(kw.get("temperature_trainable", False)), **extra)
+
+
 # --------------------------------------------------------------------------- weighted sum
 def make_wsum():
     ws = load_leaf("avssl/module/weighted_sum.py", "ref_ws")
@@ -369,10 +413,6 @@ def make_cascaded():
 
 
 if __name__ == "__main__":
-    make_loss()
-    make_head()
-    make_wsum()
-    make_masks()
-    make_retrieval()
-    make_hubert()
-    make_cascaded()
+    todo = sys.argv[1:] or ["loss", "head", "mha", "loss_variants", "wsum", "masks", "retrieval", "hubert", "cascaded"]
+    for what in todo:                       # e.g. `make_golden.py mha loss_variants` regenerates only those fixtures
+        globals()["make_" + what]()

@@ -1,21 +1,31 @@
-"""GPU: scope row a11 (cascaded+/hybrid+ tails; stock device-side torch ops fed by the HIP encoder).
-The golden-vector / oracle checks of tests/test_cascaded_cpu.py are repeated on the device, then the
-Cascaded+ base (BASELINE configs[2]) and Hybrid+ large (configs[4], reduced depth) recipes run end to end."""
+"""GPU: scope rows a11 / f3 (cascaded+/hybrid+ tails on the library's kernels).  The product modules against the reference's
+golden vectors and the oracle (tests/cascaded_checks.py), then the Cascaded+ base (BASELINE configs[2]) and Hybrid+ large
+(configs[4]) recipes end to end."""
 import dataclasses
 
 import pytest
 import torch
 import torch.nn.functional as F
 
-import test_cascaded_cpu as cc
+import cascaded_checks as cc
 
 pytestmark = pytest.mark.gpu
 
 
-def test_leaf_modules_on_device(golden):
+def test_cif_golden(golden):
     cc.check_cif(golden, "cuda")
+
+
+def test_vq_golden(golden):
     cc.check_vq(golden, "cuda")
+
+
+def test_kw_batchnorm_golden(golden):
     cc.check_bn(golden, "cuda")
+
+
+def test_clip_text_encode_keywords_matches_loop():
+    cc.check_clip_text_encode_keywords_matches_loop("cuda")
 
 
 @pytest.mark.parametrize("kind", ["cascaded", "hybrid"])

@@ -859,40 +859,6 @@ def test_mha_norm_block_vs_torch(dev, D, H, S, p_drop):
         assert rel_l2(out[valid], stock[valid]) < 1e-2
 
 
-@pytest.mark.parametrize("C,S,train", [(768, 499, True), (32, 61, True), (1024, 200, False)])
-def test_cif_fire_kernels_vs_scatter_add(dev, C, S, train):
-    """csrc/cif.hip (CifFireFn) against the scatter_add_ form of the same module on the CPU (cif.py:157-240 as mirrored by
-    speechclip_plus_amd/cif.py): output, gradient wrt the frames and wrt alpha (direct + through the cumulative sum); weights above
-    the threshold exercise the multi-fire frames, zero tails the padded ones."""
-    from speechclip_plus_amd.cif import CIF
-    B = 5
-    g = torch.Generator(device="cpu").manual_seed(17)
-    m = CIF(cif_threshold=1.0, cif_output_dim=C, encoder_embed_dim=C, conv_cif_width=3)
-    x0 = torch.randn(B, S, C, generator=g)
-    a0 = torch.rand(B, S, generator=g) * torch.tensor([0.1, 0.3, 0.6, 1.7, 2.6]).view(B, 1)
-    lens = torch.tensor([S, S - 7, S // 2, S, 9])
-    a0 = a0 * (torch.arange(S)[None, :] < lens[:, None])
-    tgt = (a0.sum(1)).floor().clip(min=1, max=75).long() if train else None
-    res = {}
-    for d in ("cpu", dev):
-        x = x0.detach().clone().to(d).requires_grad_()
-        a = a0.detach().clone().to(d).requires_grad_()
-        out = m.integrate_and_fire(x, a, target_lengths=None if tgt is None else tgt.to(d))
-        y = out["dsample_feats"]
-        w = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(d)
-        if train:                      # the inference branch (tail firing) edits its masks in place, as the reference: forward only
-            (y * w).sum().backward()
-        else:
-            x.grad, a.grad = torch.zeros_like(x), torch.zeros_like(a)
-        res[d] = (y.detach().cpu(), x.grad.cpu(), a.grad.cpu(), out["dsample_feats_length"].cpu())
-    y0, dx0, da0, l0 = res["cpu"]
-    y1, dx1, da1, l1 = res[dev]
-    assert torch.equal(l0, l1) and y0.shape == y1.shape
-    assert rel_l2(y1, y0) < 1e-5
-    if train:
-        assert rel_l2(dx1, dx0) < 1e-5 and rel_l2(da1, da0) < 1e-4
-
-
 @pytest.mark.parametrize("n,p_drop", [(72, 0.0), (512, 0.0), (1024, 0.2), (260, 0.5)])
 def test_softmax_rows_fwd_bwd_vs_torch(dev, n, p_drop):
     """csrc/softmax.hip on its own: masked row softmax (+ hash dropout) and its backward against fp32 torch, row lengths that use

@@ -1,0 +1,255 @@
+"""GPU: the kernels of the cascaded+/hybrid+ tail on their own (csrc/vq.hip, the CIF bookkeeping of csrc/cif.hip, the padded-head
+attention block) against plain fp32 / fp64 torch references of the same op and against the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import weights_from
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (200, 333, 52), (1600, 8112, 512), (77, 5, 4), (1, 130, 768)])
+@pytest.mark.parametrize("a_k,b_k", [(False, False), (True, True), (False, True), (True, False)])
+def test_sgemm_mfma_f32_every_layout_vs_fp64(M, N, K, a_k, b_k):
+    """exact-fp32 MFMA GEMM: every operand layout, ragged M / N / K, bias; error at the fp32 rounding level."""
+    from speechclip_plus_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ B.double().t() + bias.double()
+
+    def lay(x, kmajor):          # K-major operands keep a leading dimension that is a multiple of 4
+        if not kmajor:
+            if K % 4:
+                pytest.skip("row-major operands need K % 4 == 0")
+            return x.cuda().contiguous()
+        rows = x.shape[0]
+        ld = (rows + 3) // 4 * 4
+        buf = torch.zeros(K, ld)
+        buf[:, :rows] = x.t()
+        return buf.cuda()[:, :rows]
+
+    out = ops.sgemm_mfma(lay(A, a_k), lay(B, b_k), a_kmajor=a_k, b_kmajor=b_k, bias=bias.cuda())
+    assert out.shape == (M, N)
+    err = (out.double().cpu() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2e-6 * max(1.0, K ** 0.5 / 4), float(err)
+
+
+def test_linear_f32_autograd_matches_torch():
+    from speechclip_plus_amd.linear_fn import linear_f32_autograd
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 37, 96, generator=g).cuda().requires_grad_()
+    w = (torch.randn(40, 96, generator=g) * 0.1).cuda().requires_grad_()
+    b = torch.randn(40, generator=g).cuda().requires_grad_()
+    gy = torch.randn(3, 37, 40, generator=g).cuda()
+    linear_f32_autograd(x, w, b).backward(gy)
+    got = [x.grad.clone(), w.grad.clone(), b.grad.clone()]
+    x.grad = w.grad = b.grad = None
+    y = F.linear(x.double(), w.double(), b.double())
+    y.backward(gy.double())
+    assert rel(linear_f32_autograd(x, w, b), y) < 1e-6
+    for a, r in zip(got, [x.grad, w.grad, b.grad]):
+        assert rel(a, r) < 1e-5
+
+
+def _vq_reference(kw, table, temp, training):
+    """kw_branches.py:158-197 + my_vector_quantizer.py:64-165 in fp64 torch."""
+    kw, table = kw.double(), table.double()
+    cos = F.normalize(kw, dim=-1, eps=1e-8) @ F.normalize(table, dim=-1, eps=1e-8).t()
+    x = cos.clone()
+    x[:, [0, 2, 3]] = float("-inf")
+    k = x.argmax(-1)
+    hard = F.one_hot(k, x.shape[-1]).double()
+    soft = torch.softmax(x / temp, -1)
+    prob = hard + soft - soft.detach() if training else hard
+    p1 = torch.softmax(x, -1)
+    ent = -(p1 * torch.log(p1 + 1e-9)).sum(-1)
+    hp = hard.mean(0)
+    code_ppl = torch.exp(-(hp * torch.log(hp + 1e-7)).sum())
+    ap = p1.mean(0)
+    prob_ppl = torch.exp(-(ap * torch.log(ap + 1e-7)).sum())
+    return prob @ table, k, ent, code_ppl, prob_ppl, x
+
+
+@pytest.mark.parametrize("Nk,V,Et", [(300, 1000, 64), (1600, 8112, 512), (37, 205, 48)])
+def test_fused_keyword_vq_vs_fp64(Nk, V, Et):
+    """SimpleVectorQuantizer.quantize_keywords (cosine in exact fp32 MFMA -> mask -> argmax -> gather; straight-through backward)
+    against the fp64 statement of the reference's formulas: identical tokens, statistics, and the gradient to the keywords."""
+    from speechclip_plus_amd.vector_quantizers import SimpleVectorQuantizer
+    g = torch.Generator().manual_seed(Nk + V)
+    table = (torch.randn(V, Et, generator=g) * 0.02)
+    B = 4 if Nk % 4 == 0 else 1
+    kw = torch.randn(B, Nk // B, Et, generator=g)
+    gout = torch.randn(B, Nk // B, Et, generator=g)
+    vq = SimpleVectorQuantizer(temp="fixed=0.1").cuda()
+    table_d = table.cuda()
+    for training in (False, True):
+        vq.train(training)
+        kw_d = kw.cuda().requires_grad_()
+        res, out = vq.quantize_keywords(kw_d, table_d)
+        kw_r = kw.clone().double().requires_grad_()
+        ref_out, k, ent, code_ppl, prob_ppl, x = _vq_reference(kw_r.reshape(Nk, Et), table, 0.1, training)
+        # near-ties of the two best scores may legitimately resolve differently in fp32: none expected at these sizes
+        top2 = x.topk(2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-6
+        tok = res["targets"].reshape(-1).cpu()
+        assert torch.equal(tok[safe], k[safe]) and float(safe.float().mean()) > 0.99
+        assert rel(out.reshape(Nk, Et)[safe.cuda()], ref_out[safe]) < 1e-6
+        assert abs(float(res["code_perplexity"]) - float(code_ppl)) < 1e-3 * float(code_ppl)
+        assert abs(float(res["prob_perplexity"]) - float(prob_ppl)) < 1e-4 * float(prob_ppl)
+        assert rel(res["ent_per_t"], ent.view(B, Nk // B).mean(0)) < 1e-5
+        assert res["num_vars"] == V and res["temp"] == 0.1
+        assert torch.equal(res["subword_prob"].argmax(-1).reshape(-1).cpu(), tok)          # lazily materialised one-hot
+        if training:
+            out.backward(gout.cuda())
+            ref_out.backward(gout.reshape(Nk, Et).double())
+            e = rel(kw_d.grad.reshape(Nk, Et)[safe.cuda()], kw_r.grad.reshape(Nk, Et)[safe])
+            assert e < 2e-2, e                                    # bf16 operands in the two gradient GEMMs
+        else:
+            assert not out.requires_grad or out.grad_fn is not None
+
+
+def test_keyword_batchnorm_kernels_vs_torch():
+    from speechclip_plus_amd.vector_quantizers import Kw_BatchNorm_dynamic
+    g = torch.Generator().manual_seed(3)
+    E, B, N = 70, 5, 9
+    bn = Kw_BatchNorm_dynamic(E, torch.randn(E, generator=g) * 0.1, torch.rand(E, generator=g) + 0.5).cuda()
+    ref = torch.nn.BatchNorm1d(E).double()
+    ref.load_state_dict({k: v.double().cpu() if v.is_floating_point() else v.cpu() for k, v in bn.bn_layer.state_dict().items()})
+    x = torch.randn(B, N, E, generator=g)
+    gy = torch.randn(B, N, E, generator=g)
+    for _ in range(2):                                             # two training steps: running statistics accumulate
+        xd = x.cuda().requires_grad_()
+        y = bn.train()(xd)
+        y.backward(gy.cuda())
+        xr = x.double().requires_grad_()
+        yr = ref.train()(xr.permute(0, 2, 1)).permute(0, 2, 1)
+        yr.backward(gy.double())
+        assert rel(y, yr) < 1e-5 and rel(xd.grad, xr.grad) < 1e-4
+        assert rel(bn.bn_layer.weight.grad, ref.weight.grad) < 1e-4 and rel(bn.bn_layer.bias.grad, ref.bias.grad) < 1e-4
+        bn.zero_grad()
+        ref.zero_grad()
+    assert rel(bn.bn_layer.running_mean, ref.running_mean) < 1e-5 and rel(bn.bn_layer.running_var, ref.running_var) < 1e-5
+    assert int(bn.bn_layer.num_batches_tracked) == 2
+    assert rel(bn.eval()(x.cuda()), ref.eval()(x.double().permute(0, 2, 1)).permute(0, 2, 1)) < 1e-5
+
+
+@pytest.mark.parametrize("C,S", [(24, 90), (768, 499), (1024, 200)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_cif_bookkeeping_and_fire_vs_oracle(scaled, C, S):
+    """sc_cif_prepare + sc_cif_fwd (+ sc_cif_tail) and their backward against the oracle's scatter_add_ form (autograd): outputs,
+    counts, gradient to the features AND to the raw weights (through the scan, the scaling and the quantity output), multi-fire
+    frames included; no host read while the targets are known on the host."""
+    from oracle.cascaded_ref import integrate_and_fire
+    from speechclip_plus_amd.cif import CIF, _CifFn
+    g = torch.Generator().manual_seed(5 + scaled)
+    B = 6
+    lens = torch.tensor([S, S * 2 // 3, S // 3, S, 12, 5])
+    pad = torch.arange(S).unsqueeze(0) >= lens.unsqueeze(1)
+    x = torch.randn(B, S, C, generator=g)
+    a_raw = torch.rand(B, S, generator=g) * 0.9
+    a_raw[0, 10] = 1.0
+    tgt = torch.tensor([40, 9, 3, S + 40, 0, 2])       # more keywords than frames: multi-fire frames and the 75 cap
+    gout_seed = torch.Generator().manual_seed(9)
+    # ---- oracle (fp32 autograd)
+    xr = x.clone().requires_grad_()
+    ar = a_raw.clone().requires_grad_()
+    a = ar.clip(0, 1).masked_fill(pad, 0.0)
+    q = a.sum(1)
+    a2 = a * ((1.0 * tgt.float() + 1e-5) / q).unsqueeze(1) if scaled else a
+    ref, ref_len = integrate_and_fire(xr, a2, 1.0, target_given=scaled)
+    gout = torch.randn(ref.shape, generator=gout_seed)
+    gq = torch.randn(B, generator=gout_seed)
+    ((ref * gout).sum() + (q * gq).sum()).backward()
+    # ---- kernels
+    m = CIF(cif_output_dim=C, encoder_embed_dim=C).cuda()
+    flags = m.consistency_flags
+    xd = x.cuda().requires_grad_()
+    ad = a_raw.cuda().requires_grad_()
+    host = [int(t) for t in tgt]
+    T_known = max(min(max(t, 1), 75) for t in host) if scaled else None
+    st = {"thr": 1.0, "eps": 1e-5, "apply_scaling": scaled, "scaled": scaled, "tail": not scaled, "tail_thr": 0.5, "flags": flags,
+          "T_clip": T_known if scaled else 75}
+    slots, quantity, feat_len = _CifFn.apply(xd, ad, pad.cuda(), tgt.cuda() if scaled else None, st)
+    Tn = T_known if scaled else int(feat_len.max())
+    out = slots[:, :Tn]
+    assert feat_len.cpu().tolist() == ref_len.tolist()
+    assert out.shape == ref.shape
+    assert rel(out, ref) < 1e-5 and rel(quantity, q) < 1e-6
+    ((out * gout.cuda()).sum() + (quantity * gq.cuda()).sum()).backward()
+    assert rel(xd.grad, xr.grad) < 1e-5
+    assert rel(ad.grad, ar.grad) < 2e-5, rel(ad.grad, ar.grad)
+    pos, mism, _, _ = flags.tolist()
+    assert pos == B and mism == 0
+
+
+@pytest.mark.parametrize("name,tol", [("mha_norm_d128_h2", 2.5e-2), ("mha_norm_d192_h2", 2.5e-2), ("mha_norm_d64_h8", 2.5e-2)])
+def test_mha_norm_block_vs_reference_fixture(golden, name, tol):
+    """MultiheadAttentionAndNorm on the kernel path against the reference's own module (fixtures from TransformerModels.py):
+    head_dim 64, head_dim 96 (zero-padded to 128 inside the projection weights) and head_dim 8 (padded to 64)."""
+    from speechclip_plus_amd.transformer_models import MultiheadAttentionAndNorm
+    fx = golden(name + ".npz")
+    D, H = fx["src"].shape[-1], int(fx["nhead"])
+    blk = MultiheadAttentionAndNorm(d_model=D, nhead=H, dropout=0.1, layer_norm_eps=1e-5, batch_first=True)
+    blk.load_state_dict(weights_from(fx), strict=True)
+    blk = blk.cuda().eval()
+    src = T(fx["src"]).cuda().requires_grad_()
+    lens = T(np.asarray(fx["lens"])).cuda()
+    kpm = torch.arange(src.shape[1], device="cuda").unsqueeze(0) >= lens.unsqueeze(1)
+    out = blk(src, kpm)
+    valid = (~kpm).unsqueeze(-1).cpu()
+    assert rel(out.cpu() * valid, T(fx["out"]) * valid) < tol
+    if "gout" in fx:
+        (out * (T(fx["gout"]) * valid).cuda()).sum().backward()
+        # the fixture's gradient includes the padded query rows; restrict the reference to the valid ones by linearity is not
+        # possible from stored data, so compare the parameter gradients only where every row is valid (utterance 0) is not
+        # separable either: use utterances whose padded rows carry zero upstream gradient -> recompute the reference here
+        blk_ref = torch.nn.MultiheadAttention(D, H, dropout=0.0, batch_first=True).double()
+        ln_ref = torch.nn.LayerNorm(D, eps=1e-5).double()
+        sd = weights_from(fx)
+        blk_ref.load_state_dict({k.replace("multihead_attn_layer.", ""): v.double() for k, v in sd.items() if k.startswith("multihead")})
+        ln_ref.load_state_dict({k.replace("attentionBlock_Norm.", ""): v.double() for k, v in sd.items() if k.startswith("attentionBlock")})
+        s2 = T(fx["src"]).double().requires_grad_()
+        o2 = ln_ref(blk_ref(s2, s2, s2, key_padding_mask=kpm.cpu())[0] + s2)
+        assert rel(o2 * valid, T(fx["out"]) * valid) < 1e-5            # the in-test reference reproduces the fixture
+        (o2 * (T(fx["gout"]) * valid).double()).sum().backward()
+        assert rel(src.grad, s2.grad) < 4e-2
+        pairs = [(blk.multihead_attn_layer.in_proj_weight, blk_ref.in_proj_weight), (blk.multihead_attn_layer.in_proj_bias, blk_ref.in_proj_bias),
+                 (blk.multihead_attn_layer.out_proj.weight, blk_ref.out_proj.weight), (blk.multihead_attn_layer.out_proj.bias, blk_ref.out_proj.bias),
+                 (blk.attentionBlock_Norm.weight, ln_ref.weight), (blk.attentionBlock_Norm.bias, ln_ref.bias)]
+        for got, want in pairs:
+            assert rel(got.grad, want.grad) < 4e-2, (tuple(got.shape), rel(got.grad, want.grad))
+
+
+@pytest.mark.parametrize("name", ["head_d64_h8", "head_d64_h1"])
+def test_transformer_encoder_full_sequence_vs_reference_fixture(golden, name):
+    """TransformerEncoder.forward / extract_hidden_states over every row of [CLS ; frames] (the path the reference's
+    feature_extractor_s3prl and its non-plus branches use) on the kernels, against the reference's full-sequence output."""
+    from speechclip_plus_amd.transformer_models import TransformerEncoder
+    fx = golden(name + ".npz")
+    W = weights_from(fx)
+    D, H = fx["feat"].shape[-1], int(fx["nhead"])
+    enc = TransformerEncoder(n_layers=1, d_model=D, nhead=H, dim_feedforward=128, dropout=0.1)
+    enc.load_state_dict({k[len("self_att."):]: v for k, v in W.items() if k.startswith("self_att.")}, strict=True)
+    enc = enc.cuda().eval()
+    feat = T(fx["feat"]).cuda()
+    B = feat.shape[0]
+    src = torch.cat([W["cls"].cuda().expand(B, -1, -1), feat], dim=1).requires_grad_()
+    kpm = T(fx["kpm"]).cuda()
+    out = enc(src, kpm)
+    valid = (~kpm).unsqueeze(-1).cpu()
+    assert rel(out.cpu() * valid, T(fx["out_full"]) * valid) < 2.5e-2
+    hid = enc.extract_hidden_states(src, kpm)
+    assert len(hid) == 2 and rel(hid[-1].cpu() * valid, T(fx["hidden_last"]) * valid) < 2.5e-2
+    (out * valid.cuda()).sum().backward()                              # the whole layer is differentiable on the kernel path
+    assert torch.isfinite(src.grad).all() and float(src.grad.abs().sum()) > 0
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())

@@ -62,6 +62,79 @@ def test_mha_and_norm(golden):
     np.testing.assert_allclose(out.numpy(), fx["out"], rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("name", ["mha_norm_d128_h2", "mha_norm_d192_h2"])
+def test_mha_and_norm_with_gradients(golden, name):
+    """head_dim 64 and 96 (the hybrid+ base geometry): output, input gradient and every parameter gradient."""
+    fx = golden(name + ".npz")
+    W = {k: v.clone().requires_grad_(True) for k, v in weights_from(fx).items()}
+    src = T(fx["src"]).requires_grad_(True)
+    kpm = get_keypadding_mask(src.shape[1], T(fx["lens"]))
+    out = oracle.mha_and_norm_forward(W, "", src, kpm, int(fx["nhead"]))
+    np.testing.assert_allclose(out.detach().numpy(), fx["out"], rtol=1e-4, atol=2e-5)
+    (out * T(fx["gout"])).sum().backward()
+    np.testing.assert_allclose(src.grad.numpy(), fx["g_src"], rtol=1e-3, atol=3e-5)
+    for k in W:
+        np.testing.assert_allclose(W[k].grad.numpy(), fx["g_" + k], rtol=1e-3, atol=5e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["loss_v_margin", "loss_v_dcl", "loss_v_a2b", "loss_v_b2a", "loss_v_margin_dcl_trainT"])
+def test_loss_variants(golden, name):
+    """margin, decoupled (dcl) and one-sided forms of MaskedContrastiveLoss (losses.py:213,226-245)."""
+    fx = golden(name + ".npz")
+    A = T(fx["A"]).requires_grad_(True)
+    B = T(fx["B"]).requires_grad_(True)
+    kw = dict(margin=float(fx["margin"]), dcl=bool(fx["dcl"]), a2b=bool(fx["a2b"]), b2a=bool(fx["b2a"]))
+    p = None
+    inv_t = 1 / 0.07
+    if int(fx["trainT"]):
+        p = torch.tensor(float(np.log(1 / 0.07)), requires_grad=True)
+        inv_t = p.exp()
+    loss = oracle.masked_contrastive_loss(A, B, T(fx["ids"]), inv_temperature=inv_t, **kw)
+    loss.backward()
+    assert abs(loss.item() - fx["loss"].item()) < 1e-5
+    np.testing.assert_allclose(A.grad.numpy(), fx["dA"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(B.grad.numpy(), fx["dB"], rtol=1e-4, atol=1e-6)
+    if p is not None:
+        np.testing.assert_allclose(p.grad.numpy(), fx["dtemp_param"], rtol=1e-4)
+    l2 = oracle.masked_contrastive_loss(A.detach(), B.detach(), None, inv_temperature=float(inv_t), **kw)
+    assert abs(l2.item() - fx["loss_noindex"].item()) < 1e-5
+
+
+def test_cif_oracle_vs_reference_fixture(golden):
+    """oracle.cif_forward against the reference's cif.py vectors: training (target scaling, tail dropped), inference (tail
+    firing) and the post-scaling-step path; gradient to the features."""
+    fx = golden("cif_d32.npz")
+    W = {"downsampling." + k: v for k, v in weights_from(fx).items()}
+    feat = T(fx["feat"]).requires_grad_(True)
+    lens = T(fx["lens"])
+    pad = get_keypadding_mask(feat.shape[1], lens)
+    tgt = T(fx["tr_target"])
+    out, n, q = oracle.cif_forward(W, "downsampling.", feat, pad, tgt)
+    assert n.tolist() == fx["tr_len"].tolist()
+    np.testing.assert_allclose(out.detach().numpy(), fx["tr_feats"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(q.detach().numpy(), fx["tr_quantity"], rtol=1e-5)
+    (out * T(fx["tr_gout"])).sum().backward()
+    np.testing.assert_allclose(feat.grad.numpy(), fx["tr_gfeat"], rtol=1e-3, atol=1e-5)
+    with torch.no_grad():
+        out, n, q = oracle.cif_forward(W, "downsampling.", feat.detach(), pad, None)
+        assert n.tolist() == fx["ev_len"].tolist()
+        np.testing.assert_allclose(out.numpy(), fx["ev_feats"], rtol=1e-4, atol=1e-5)
+        out, n, _ = oracle.cif_forward(W, "downsampling.", feat.detach(), pad, tgt, apply_scaling=False)
+        assert n.tolist() == fx["ns_len"].tolist()
+        np.testing.assert_allclose(out.numpy(), fx["ns_feats"], rtol=1e-4, atol=1e-5)
+
+
+def test_vq_oracle_vs_reference_fixture(golden):
+    fx = golden("vq_v50.npz")
+    x = T(fx["x"])
+    assert torch.equal(oracle.vq_forward(x, 0.1, training=False), T(fx["ev_prob"]))
+    xt = x.clone().requires_grad_(True)
+    prob = oracle.vq_forward(xt * 1.0, 0.1, training=True)
+    np.testing.assert_allclose(prob.detach().numpy(), fx["tr_prob"], rtol=1e-5, atol=1e-6)
+    ((prob @ T(fx["emb"])) * T(fx["gk"])).sum().backward()
+    np.testing.assert_allclose(xt.grad.numpy(), fx["tr_gx"], rtol=1e-3, atol=1e-6)
+
+
 def test_weighted_sum(golden):
     fx = golden("wsum.npz")
     w = T(fx["weights"]).requires_grad_(True)
