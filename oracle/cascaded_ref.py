@@ -74,10 +74,13 @@ def cif_forward(W: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, pad: t
     return feats, lengths, quantity
 
 
-def vq_forward(scores: torch.Tensor, temp: float, training: bool, prob_msk=(0, 2, 3)) -> torch.Tensor:
+def vq_forward(scores: torch.Tensor, temp: float, training: bool, prob_msk=(0, 2, 3), forced: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``forced`` (test aid, not in the reference): token indices to use instead of the argmax - lets a parity test share the
+    DISCRETE choice between two implementations where the reference's own top-2 margin is a near-tie, and compare everything
+    continuous downstream."""
     s = scores.clone()
     s[..., list(prob_msk)] = float("-inf")
-    hard = F.one_hot(s.argmax(-1), s.shape[-1]).type_as(s)
+    hard = F.one_hot(s.argmax(-1) if forced is None else forced, s.shape[-1]).type_as(s)
     if not training:
         return hard
     soft = torch.softmax(s / temp, dim=-1)
@@ -115,7 +118,8 @@ def clip_encode_keywords(W: Dict[str, torch.Tensor], prefix: str, keywords: torc
     return x[torch.arange(B), n_kw + 1] @ W[prefix + "text_projection"]
 
 
-def _keyword_tail(W, feats, pad, feat_len, training, target_len, nhead_clip, sot, eot, vq_temp, apply_scaling):
+def _keyword_tail(W, feats, pad, feat_len, training, target_len, nhead_clip, sot, eot, vq_temp, apply_scaling, forced_tokens=None,
+                  aux: Optional[dict] = None):
     ds, ds_len, quantity = cif_forward(W, "downsampling.", feats, pad, target_len if training else None,
                                        apply_scaling=apply_scaling)
     kw = ds
@@ -138,22 +142,27 @@ def _keyword_tail(W, feats, pad, feat_len, training, target_len, nhead_clip, sot
         kw = (kw - mu) / torch.sqrt(var + 1e-5) * g + b
     emb = W["clip.model.token_embedding.weight"]
     cos = F.normalize(kw, dim=-1, eps=1e-8) @ F.normalize(emb, dim=-1, eps=1e-8).t()
-    prob = vq_forward(cos, vq_temp, training)
+    prob = vq_forward(cos, vq_temp, training, forced=forced_tokens)
+    if aux is not None:
+        masked = cos.detach().clone()
+        masked[..., [0, 2, 3]] = float("-inf")
+        aux.update(cos=masked, tokens=masked.argmax(-1), kw_projected=kw.detach())
     keywords = prob @ emb
     out = clip_encode_keywords(W, "clip.model.", keywords, ds_len, nhead_clip, sot, eot)
     return out, keywords, ds_len, quantity
 
 
 def cascaded_plus_forward(W, audio_feat, audio_len, nhead, training=False, target_len=None, nhead_clip=8, sot=49406,
-                          eot=49407, vq_temp=0.1, apply_scaling=True):
+                          eot=49407, vq_temp=0.1, apply_scaling=True, forced_tokens=None, aux=None):
     """kw_branches.py:701-753 -> (cascaded_audio_feat, keywords, dsample_len, quantity_out)."""
     pad = get_keypadding_mask(audio_feat.shape[1], audio_len)
     feats = mha_and_norm_forward(W, "self_att.", audio_feat, pad, nhead)
-    return _keyword_tail(W, feats, pad, audio_len, training, target_len, nhead_clip, sot, eot, vq_temp, apply_scaling)
+    return _keyword_tail(W, feats, pad, audio_len, training, target_len, nhead_clip, sot, eot, vq_temp, apply_scaling, forced_tokens,
+                         aux)
 
 
 def hybrid_plus_forward(W, audio_feat, audio_len, nhead, training=False, target_len=None, nhead_clip=8, sot=49406,
-                        eot=49407, vq_temp=0.1, apply_scaling=True):
+                        eot=49407, vq_temp=0.1, apply_scaling=True, forced_tokens=None, aux=None):
     """kw_branches.py:808-866 -> (parallel_audio_feat, cascaded_audio_feat, keywords, dsample_len, quantity_out)."""
     B, T, D = audio_feat.shape
     pad = get_keypadding_mask(T + 1, audio_len + 1)
@@ -161,5 +170,5 @@ def hybrid_plus_forward(W, audio_feat, audio_len, nhead, training=False, target_
     post = mha_and_norm_forward(W, "self_att.", src, pad, nhead)
     par = F.linear(post[:, 0], W["parallel_proj.weight"], W["parallel_proj.bias"])
     rest = _keyword_tail(W, post[:, 1:], pad[:, 1:], audio_len, training, target_len, nhead_clip, sot, eot, vq_temp,
-                         apply_scaling)
+                         apply_scaling, forced_tokens, aux)
     return (par,) + rest
