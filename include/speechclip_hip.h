@@ -159,7 +159,10 @@ int sc_posconv_prep(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_
  *   h    [NL, B*R, D] bf16 ; w [NL] fp32 = softmax(weights) (host computes the 13-element softmax)
  *   out  [B, R, D] bf16, written at row offset `row_off` inside each utterance (row_off = 1 leaves row 0
  *        for the CLS token of kw_branches.py:266-267), rows t in [0, R - row_off)
- *   bwd: dw[n] = sum_{b,t,d} g[b, t + row_off, d] * h[n, b, t, d]   (g fp32 [B, R, D])
+ *   bwd: dw[n] = sum_{b,t,d} g[b, t + row_off, d] * (h[n, b, t, d] - h[NL-1, b, t, d])   (g fp32 [B, R, D]).  The gradient of the
+ *        13 (25) logits is the softmax projection w_n (dw_n - sum_m w_m dw_m), invariant under a common shift of dw: the last
+ *        layer is subtracted element-wise BEFORE the accumulation, so the large common part <g, h> never enters the fp32 sums
+ *        (layers of a residual stream differ by 1e-1 .. 1e-2 of their norm; summing first would cost those digits)
  *   normalize != 0: every h[n, row, :] passes through a non-affine LayerNorm(D, eps 1e-5) first
  *        (normalize_features=True, weighted_sum.py:41-42; used by the HuBERT-large recipes), D <= 1024
  * ---------------------------------------------------------------------------------------------- */
@@ -241,7 +244,7 @@ int sc_cif_tail(const float* alpha, const float* csum, int32_t B, int32_t S, int
  *   sc_sgemm_mfma_f32  C [M, N] = A . B^T (+ bias[n]) in exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32): the cosine scores
  *                      decide an argmax over the vocabulary and the CIF weights a floor(), so no reduced-precision operand.
  *                      A: [M][K] row-major (a_kmajor 0) or [K][M] (a_kmajor 1); B: [N][K] (the nn.Linear layout) or [K][N].
- *                      lda / ldb % 4 == 0, 16-byte aligned operands, row-major operands K % 4 == 0; any M, N
+ *                      any M, N, K (16-byte loads when base and leading dimension allow, element loads otherwise)
  *   sc_vq_rowstats     x [Nk, ldx] fp32, V columns: columns listed in mask_cols_host (<= 4, host array: the special tokens 0, 2, 3) are
  *                      set to -inf IN PLACE (the reference's x[:, i] += -inf), idx = first argmax, lse_t = LSE(x / temp),
  *                      lse_1 = LSE(x), ent = - sum p log(p + 1e-9) with p = softmax(x)       (my_vector_quantizer.py:80-116)
@@ -332,16 +335,25 @@ int sc_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float*
 int sc_headmask_f32(float* q, float* Qm, int32_t H, int32_t D, int32_t dh, int32_t dir, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Masked symmetric InfoNCE (avssl/module/losses.py:185-245), logits [Bg,Bg] fp32 = A.B^T * inv_temp
- *   neg[i,j] = ids[i] != ids[j] or i == j ;  loss = 1/(2Bg) sum_i (-2 l_ii + LSE_row_i + LSE_col_i)
- *   sc_infonce_lse : row/col masked log-sum-exp (stable), per-sample terms, loss scalar
- *   sc_infonce_grad: G = dloss/dlogits * gscale (in place into G), dinv_temp partials
+ * Masked contrastive loss: MaskedContrastiveLoss.forward, avssl/module/losses.py:185-245 (ctor options :130-168).
+ *   logits[i,j] = inv_temp <A_i, B_j> - margin [i == j]        A, B [Bg, E] fp32 (unit-norm rows), inv_temp: DEVICE scalar
+ *   neg[i,j] = (ids ? ids[i] != ids[j] : i != j) || (!dcl && i == j)           (no MAX_EYE = 256 cap, losses.py:126)
+ *   loss = 1 / (Bg n_dir) sum_i [ a2b (-l_ii + log sum_j neg_ij e^{l_ij}) + b2a (-l_ii + log sum_j neg_ji e^{l_ji}) ]
+ *   sc_infonce_fwd : ONE launch - 64 x 64 logit tiles on the matrix pipe in exact fp32, LDS-tiled operands, per-tile masked
+ *                    (max, sum exp) partials, merged by the last-arriving workgroup (ticket) into lse_row / lse_col [Bg] and
+ *                    loss[0]; the scaled logits [Bg, Bg] are kept for the backward.  workspace: sc_infonce_workspace_floats(Bg)
+ *                    floats, ZEROED once by the caller before the first use (holds the ticket word; each launch leaves it 0),
+ *                    one workspace per stream.  E % 4 == 0.
+ *   sc_infonce_grad: G = inv_temp gscale dloss/dlogits [Bg, Bg] (dA = G . B, dB = G^T . A: sc_sgemm_mfma_f32), and
+ *                    dlogit_dot[i] = sum_j dloss/dlogit_ij <A_i, B_j>  (d loss / d inv_temp = sum_i dlogit_dot[i])
  * ---------------------------------------------------------------------------------------------- */
-int sc_infonce_lse(const float* logits, const int64_t* ids, int32_t Bg, float* lse_row, float* lse_col,
-                   float* loss, void* stream);
-int sc_infonce_grad(const float* logits, const int64_t* ids, const float* lse_row, const float* lse_col,
-                    int32_t Bg, const float* gscale /*device scalar*/, float* G, float* dlogit_dot /*[Bg]*/,
-                    void* stream);
+int64_t sc_infonce_workspace_floats(int32_t Bg);
+int sc_infonce_fwd(const float* A, const float* B, int32_t Bg, int32_t E, const int64_t* ids, const float* inv_temp, float margin,
+                   int32_t dcl, int32_t a2b, int32_t b2a, float* logits, float* lse_row, float* lse_col, float* loss,
+                   float* workspace, void* stream);
+int sc_infonce_grad(const float* logits, const int64_t* ids, const float* lse_row, const float* lse_col, int32_t Bg,
+                    const float* gscale /*device scalar*/, const float* inv_temp /*device scalar*/, float margin, int32_t dcl,
+                    int32_t a2b, int32_t b2a, float* G, float* dlogit_dot /*[Bg]*/, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step on a flat fp32 parameter buffer: torch.optim.Adam semantics (L2 weight decay added to

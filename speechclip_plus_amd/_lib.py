@@ -80,8 +80,10 @@ SIGNATURES = {
     "sc_cls_pool_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "sc_cls_pool_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "sc_sgemm_f32": [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
-    "sc_infonce_lse": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
-    "sc_infonce_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sc_infonce_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                       c_void_p, c_void_p, c_void_p],
+    "sc_infonce_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p,
+                        c_void_p, c_void_p],
     "sc_layernorm_bwd_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_float,
                               c_void_p, c_void_p, c_int, c_void_p],
     "sc_transpose_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p],
@@ -116,6 +118,8 @@ def lib() -> ctypes.CDLL:
             fn.restype = ctypes.c_int
         cdll.sc_last_error.argtypes = []
         cdll.sc_last_error.restype = ctypes.c_char_p
+        cdll.sc_infonce_workspace_floats.argtypes = [c_int]
+        cdll.sc_infonce_workspace_floats.restype = ctypes.c_int64
         cdll.sc_hash32.argtypes = [ctypes.c_uint32]
         cdll.sc_hash32.restype = ctypes.c_uint32
         _LIB = cdll

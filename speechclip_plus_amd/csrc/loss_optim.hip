@@ -1,7 +1,7 @@
 // fp32 kernels of the contrastive loss and the optimiser step.
 //   sc_sgemm_f32     generic strided fp32 GEMM (LDS-tiled 64x64x16, 4x4 register blocking)
-//   sc_infonce_lse   masked row / column log-sum-exp of the (Bg x Bg) logits + loss scalar
-//   sc_infonce_grad  dL/dlogits
+//   sc_infonce_fwd   logits (exact-fp32 MFMA) + masked row / column log-sum-exp + loss scalar in ONE launch
+//   sc_infonce_grad  dL/dlogits (x inv_temp) + the d inv_temp terms
 //   sc_sumsq_f32 / sc_adam_f32   global-norm clip + Adam on a flat parameter buffer
 // The loss is explicitly fp32 in the reference (avssl/model/kwClip.py:1012,1024); at Bg <= 512 these kernels
 // are launch/latency bound, so they favour simple, deterministic reductions over peak rate.
@@ -69,90 +69,166 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
 }
 
 // ------------------------------------------------------------------------------------------ InfoNCE
-// block i handles row i and column i.  neg[i,j] = (ids[i] != ids[j]) || i == j
-__global__ __launch_bounds__(256) void infonce_lse_kernel(const float* __restrict__ logits,
-                                                          const int64_t* __restrict__ ids, int Bg,
+// Masked contrastive loss (avssl/module/losses.py:185-245) with every option of the reference: margin on the positives, decoupled
+// form (dcl: the positive is left out of its own denominator), one-sided (a2b / b2a) or symmetric.
+//   logits[i,j] = inv_temp <A_i, B_j> - margin [i == j] ;   neg[i,j] = (ids ? ids[i] != ids[j] : i != j) || (!dcl && i == j)
+//   loss = 1/(Bg n_dir) sum_i [ a2b (-l_ii + log sum_j neg_ij e^{l_ij}) + b2a (-l_ii + log sum_j neg_ji e^{l_ji}) ]
+// FORWARD = ONE kernel.  Each workgroup owns a 64 x 64 tile of the logits: A and B rows staged through LDS (K-tiles of 16,
+// transposed on the way in), the product on the matrix pipe in exact fp32 (v_mfma_f32_32x32x2_f32, one 32 x 32 block per wave),
+// the scaled tile written out (the backward reads it) and reduced in LDS to per-tile row / column (max, sum exp) partials.  The
+// workgroup that takes the last ticket merges the partials of all tiles into the row / column log-sum-exps and the scalar loss
+// (fixed order: deterministic).  Cross-workgroup visibility: stores -> agent-scope release fence (+ explicit vmcnt drain) ->
+// barrier -> ticket (returning atomic) ; last arriver: agent-scope acquire fence -> barrier -> plain loads.
+// inv_temp comes from DEVICE memory (a trainable temperature never forces a host read).
+constexpr int LT = 68;       // LDS row pitch of the [k][64 rows] operand images (2-way conflicts on the b32 stores only: free)
+
+__global__ __launch_bounds__(256) void infonce_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int Bg, int E,
+                                                          const int64_t* __restrict__ ids, const float* __restrict__ inv_temp_p,
+                                                          float margin, int dcl, int a2b, int b2a, float* __restrict__ logits,
+                                                          float* __restrict__ part, float* __restrict__ diag,
                                                           float* __restrict__ lse_row, float* __restrict__ lse_col,
-                                                          float* __restrict__ terms) {
-    __shared__ float red[2][4];
-    const int i = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t idi = ids ? ids[i] : (int64_t)i;
-    float mr = -INFINITY, mc = -INFINITY;
-    for (int j = threadIdx.x; j < Bg; j += 256) {
-        const bool neg = (j == i) || (ids ? ids[j] != idi : true);
-        if (neg) {
-            mr = fmaxf(mr, logits[(int64_t)i * Bg + j]);
-            mc = fmaxf(mc, logits[(int64_t)j * Bg + i]);
-        }
-    }
-    mr = wave_max(mr);
-    mc = wave_max(mc);
-    if (lane == 0) { red[0][wave] = mr; red[1][wave] = mc; }
-    __syncthreads();
-    mr = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    mc = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
-    __syncthreads();
-    float sr = 0.f, sc = 0.f;
-    for (int j = threadIdx.x; j < Bg; j += 256) {
-        const bool neg = (j == i) || (ids ? ids[j] != idi : true);
-        if (neg) {
-            sr += __expf(logits[(int64_t)i * Bg + j] - mr);
-            sc += __expf(logits[(int64_t)j * Bg + i] - mc);
-        }
-    }
-    sr = wave_sum(sr);
-    sc = wave_sum(sc);
-    if (lane == 0) { red[0][wave] = sr; red[1][wave] = sc; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float lr = mr + logf((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
-        const float lc = mc + logf((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
-        lse_row[i] = lr;
-        lse_col[i] = lc;
-        terms[i] = -2.f * logits[(int64_t)i * Bg + i] + lr + lc;
-    }
-}
-
-__global__ __launch_bounds__(256) void reduce_mean_kernel(const float* __restrict__ terms, int n, float scale,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ loss, unsigned int* __restrict__ ticket) {
+    __shared__ float As[16][LT];
+    __shared__ float Bs[16][LT];
+    __shared__ float Ls[64][65];
+    __shared__ int last_flag;
     __shared__ float red[4];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += terms[i];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+    const int nt = gridDim.x;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    const int i0 = ti * 64, j0 = tj * 64;
+    const float it = inv_temp_p[0];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lr = tid >> 2, kq = (tid & 3) * 4;
+    for (int k0 = 0; k0 < E; k0 += 16) {
+        float4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+        if (k0 + kq < E) {                         // E % 4 == 0 (checked on the host)
+            if (i0 + lr < Bg) a = *(const float4*)(A + (int64_t)(i0 + lr) * E + k0 + kq);
+            if (j0 + lr < Bg) b = *(const float4*)(Bm + (int64_t)(j0 + lr) * E + k0 + kq);
+        }
+        __syncthreads();
+        As[kq + 0][lr] = a.x; As[kq + 1][lr] = a.y; As[kq + 2][lr] = a.z; As[kq + 3][lr] = a.w;
+        Bs[kq + 0][lr] = b.x; Bs[kq + 1][lr] = b.y; Bs[kq + 2][lr] = b.z; Bs[kq + 3][lr] = b.w;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + half][wm * 32 + l31], Bs[kk + half][wn * 32 + l31], acc, 0, 0, 0);
+    }
+    // scaled tile -> LDS (+ global)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, cc = wn * 32 + l31;
+        const int gi = i0 + rr, gj = j0 + cc;
+        const float l = acc[r] * it - ((gi == gj) ? margin : 0.f);
+        Ls[rr][cc] = l;
+        if (gi < Bg && gj < Bg) logits[(int64_t)gi * Bg + gj] = l;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+    // per-tile partials: threads 0..63 one row each, 64..127 one column each
+    float* prm = part;                                   // [nt][Bg] row max   (indexed by column tile)
+    float* prs = part + (int64_t)nt * Bg;                // row sum exp
+    float* pcm = part + (int64_t)2 * nt * Bg;            // [nt][Bg] col max   (indexed by row tile)
+    float* pcs = part + (int64_t)3 * nt * Bg;
+    if (tid < 128) {
+        const bool is_row = tid < 64;
+        const int o = tid & 63;
+        const int gfix = (is_row ? i0 : j0) + o;
+        if (gfix < Bg) {
+            const int64_t idf = ids ? ids[gfix] : (int64_t)gfix;
+            float m = -INFINITY;
+            for (int q = 0; q < 64; ++q) {
+                const int gvar = (is_row ? j0 : i0) + q;
+                if (gvar >= Bg) break;
+                const bool neg = (ids ? ids[gvar] != idf : gvar != gfix) || (!dcl && gvar == gfix);
+                if (neg) m = fmaxf(m, is_row ? Ls[o][q] : Ls[q][o]);
+            }
+            float sum = 0.f;
+            for (int q = 0; q < 64; ++q) {
+                const int gvar = (is_row ? j0 : i0) + q;
+                if (gvar >= Bg) break;
+                const bool neg = (ids ? ids[gvar] != idf : gvar != gfix) || (!dcl && gvar == gfix);
+                if (neg) sum += __expf((is_row ? Ls[o][q] : Ls[q][o]) - m);
+            }
+            if (is_row) { prm[(int64_t)tj * Bg + gfix] = m; prs[(int64_t)tj * Bg + gfix] = sum; }
+            else { pcm[(int64_t)ti * Bg + gfix] = m; pcs[(int64_t)ti * Bg + gfix] = sum; }
+            if (is_row && ti == tj) diag[gfix] = Ls[o][o];
+        }
+    }
+    // ---- ticket: the last workgroup to arrive finalises
+    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned t = atomicAdd(ticket, 1u);
+        last_flag = (t == total - 1);
+        if (t == total - 1) *ticket = 0;            // ready for the next launch on this stream
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float term = 0.f;
+    for (int i = tid; i < Bg; i += 256) {
+        float mr = -INFINITY, mc = -INFINITY;
+        for (int t = 0; t < nt; ++t) {
+            mr = fmaxf(mr, prm[(int64_t)t * Bg + i]);
+            mc = fmaxf(mc, pcm[(int64_t)t * Bg + i]);
+        }
+        float sr = 0.f, sc = 0.f;
+        for (int t = 0; t < nt; ++t) {
+            const float pm = prm[(int64_t)t * Bg + i], qm = pcm[(int64_t)t * Bg + i];
+            if (pm > -INFINITY) sr += prs[(int64_t)t * Bg + i] * __expf(pm - mr);
+            if (qm > -INFINITY) sc += pcs[(int64_t)t * Bg + i] * __expf(qm - mc);
+        }
+        const float lrow = mr + __logf(sr), lcol = mc + __logf(sc);     // no negatives at all: log 0 = -inf, as the reference
+        lse_row[i] = lrow;
+        lse_col[i] = lcol;
+        const float d = diag[i];
+        if (a2b) term += lrow - d;
+        if (b2a) term += lcol - d;
+    }
+    term = wave_sum(term);
+    if (lane == 0) red[wave] = term;
+    __syncthreads();
+    if (tid == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / ((float)Bg * (float)((a2b && b2a) ? 2 : 1));
 }
 
-// G[i,j] = gscale/(2Bg) * (neg * (exp(l - lse_row_i) + exp(l - lse_col_j)) - 2 [i == j]);
-// dlogit_dot[i] = sum_j G[i,j] * logits[i,j]   (for d/d inv_temp = sum / inv_temp)
-__global__ __launch_bounds__(256) void infonce_grad_kernel(const float* __restrict__ logits,
-                                                           const int64_t* __restrict__ ids,
-                                                           const float* __restrict__ lse_row,
-                                                           const float* __restrict__ lse_col, int Bg,
-                                                           const float* __restrict__ gscale, float* __restrict__ G,
-                                                           float* __restrict__ dlogit_dot) {
+// G[i,j] = inv_temp gscale / (Bg n_dir) (neg_ij (a2b e^{l - lse_row_i} + b2a e^{l - lse_col_j}) - (a2b + b2a) [i == j])
+//   (already multiplied by inv_temp: dA = G . B, dB = G^T . A need no further scaling);
+// dlogit_dot[i] = sum_j G[i,j] / inv_temp * <A_i, B_j> ... expressed through the stored logits: (l_ij + margin [i == j]) / inv_temp
+//   -> d loss / d inv_temp = sum_i dlogit_dot[i]
+__global__ __launch_bounds__(256) void infonce_grad_kernel(const float* __restrict__ logits, const int64_t* __restrict__ ids,
+                                                           const float* __restrict__ lse_row, const float* __restrict__ lse_col,
+                                                           int Bg, const float* __restrict__ gscale,
+                                                           const float* __restrict__ inv_temp_p, float margin, int dcl, int a2b,
+                                                           int b2a, float* __restrict__ G, float* __restrict__ dlogit_dot) {
     __shared__ float red[4];
     const int i = blockIdx.x;
     const int64_t idi = ids ? ids[i] : (int64_t)i;
     const float lr = lse_row[i];
-    const float gs = gscale[0] / (2.f * (float)Bg);
+    const float it = inv_temp_p[0];
+    const float gs = gscale[0] / ((float)Bg * (float)((a2b && b2a) ? 2 : 1));
+    const float npos = (float)((a2b ? 1 : 0) + (b2a ? 1 : 0));
     float dot = 0.f;
     for (int j = threadIdx.x; j < Bg; j += 256) {
         const float l = logits[(int64_t)i * Bg + j];
-        const bool neg = (j == i) || (ids ? ids[j] != idi : true);
+        const bool neg = (ids ? ids[j] != idi : j != i) || (!dcl && j == i);
         float g = 0.f;
-        if (neg) g = __expf(l - lr) + __expf(l - lse_col[j]);
-        if (j == i) g -= 2.f;
+        if (neg) g = (a2b ? __expf(l - lr) : 0.f) + (b2a ? __expf(l - lse_col[j]) : 0.f);
+        if (j == i) g -= npos;
         g *= gs;
-        G[(int64_t)i * Bg + j] = g;
-        dot += g * l;
+        G[(int64_t)i * Bg + j] = g * it;
+        dot += g * (l + ((j == i) ? margin : 0.f));
     }
     dot = wave_sum(dot);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
     __syncthreads();
-    if (threadIdx.x == 0) dlogit_dot[i] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) dlogit_dot[i] = ((red[0] + red[1]) + (red[2] + red[3])) / it;
 }
 
 // ------------------------------------------------------------------------------------------ optimiser
@@ -204,22 +280,34 @@ extern "C" int sc_sgemm_f32(const float* A, int64_t sai, int64_t sak, const floa
     return 0;
 }
 
-extern "C" int sc_infonce_lse(const float* logits, const int64_t* ids, int32_t Bg, float* lse_row, float* lse_col,
-                              float* loss, void* stream) {
-    SC_CHECK(logits && lse_row && lse_col && loss, "sc_infonce_lse: null pointer");
-    SC_CHECK(Bg > 0, "sc_infonce_lse: Bg");
-    // loss[0] = scalar, loss[1 .. Bg] = per-sample terms (caller provides Bg + 1 floats)
-    hipLaunchKernelGGL(infonce_lse_kernel, dim3(Bg), dim3(256), 0, (hipStream_t)stream, logits, ids, Bg, lse_row, lse_col, loss + 1);
-    SC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss + 1, Bg, 0.5f / (float)Bg, loss);
+extern "C" int64_t sc_infonce_workspace_floats(int32_t Bg) {
+    const int64_t nt = (Bg + 63) / 64;
+    return 4 * nt * Bg + Bg + 4;        // per-tile partials, diagonal, ticket word (+ padding)
+}
+
+extern "C" int sc_infonce_fwd(const float* A, const float* Bm, int32_t Bg, int32_t E, const int64_t* ids, const float* inv_temp,
+                              float margin, int32_t dcl, int32_t a2b, int32_t b2a, float* logits, float* lse_row, float* lse_col,
+                              float* loss, float* workspace, void* stream) {
+    SC_CHECK(A && Bm && inv_temp && logits && lse_row && lse_col && loss && workspace, "sc_infonce_fwd: null pointer");
+    SC_CHECK(Bg > 0 && E > 0 && E % 4 == 0 && (a2b || b2a), "sc_infonce_fwd: Bg=%d E=%d (E %% 4), a2b | b2a", Bg, E);
+    SC_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)Bm & 15) == 0, "sc_infonce_fwd: A / B must be 16-byte aligned");
+    const int nt = (Bg + 63) / 64;
+    float* part = workspace;
+    float* diag = workspace + (int64_t)4 * nt * Bg;
+    unsigned int* ticket = (unsigned int*)(diag + Bg);      // zero before the first launch; every launch leaves it zero
+    hipLaunchKernelGGL(infonce_fwd_kernel, dim3(nt, nt), dim3(256), 0, (hipStream_t)stream, A, Bm, Bg, E, ids, inv_temp, margin, dcl,
+                       a2b, b2a, logits, part, diag, lse_row, lse_col, loss, ticket);
     SC_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int sc_infonce_grad(const float* logits, const int64_t* ids, const float* lse_row, const float* lse_col,
-                               int32_t Bg, const float* gscale, float* G, float* dlogit_dot, void* stream) {
-    SC_CHECK(logits && lse_row && lse_col && gscale && G && dlogit_dot, "sc_infonce_grad: null pointer");
-    hipLaunchKernelGGL(infonce_grad_kernel, dim3(Bg), dim3(256), 0, (hipStream_t)stream, logits, ids, lse_row, lse_col, Bg, gscale, G, dlogit_dot);
+extern "C" int sc_infonce_grad(const float* logits, const int64_t* ids, const float* lse_row, const float* lse_col, int32_t Bg,
+                               const float* gscale, const float* inv_temp, float margin, int32_t dcl, int32_t a2b, int32_t b2a,
+                               float* G, float* dlogit_dot, void* stream) {
+    SC_CHECK(logits && lse_row && lse_col && gscale && inv_temp && G && dlogit_dot, "sc_infonce_grad: null pointer");
+    SC_CHECK(Bg > 0 && (a2b || b2a), "sc_infonce_grad: bad arguments");
+    hipLaunchKernelGGL(infonce_grad_kernel, dim3(Bg), dim3(256), 0, (hipStream_t)stream, logits, ids, lse_row, lse_col, Bg, gscale,
+                       inv_temp, margin, dcl, a2b, b2a, G, dlogit_dot);
     SC_LAUNCH_CHECK();
     return 0;
 }

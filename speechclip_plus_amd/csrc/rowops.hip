@@ -170,7 +170,11 @@ __global__ __launch_bounds__(256) void wsum_fwd_kernel(const uint16_t* __restric
     }
 }
 
-// dw_partial[blk, n] = sum over this block's elements of g[b, t + row_off, d] * h[n, b, t, d]
+// dw_partial[blk, n] = sum over this block's elements of g[b, t + row_off, d] * (h[n, b, t, d] - h[NL - 1, b, t, d])
+// The caller only uses the softmax-projected combination w_n (d_n - sum_m w_m d_m), which is invariant under a common shift of
+// the d_n: subtracting the LAST layer element-wise BEFORE the accumulation removes the large common part <g, h> that the
+// projection would cancel afterwards (the differences between layers of a residual stream are one to two orders of magnitude
+// smaller than the states themselves: summing first and subtracting later costs that many digits of the fp32 accumulators).
 __global__ __launch_bounds__(256) void wsum_bwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ g,
                                                        int NL, float* __restrict__ dw_partial, int B, int R, int D,
                                                        int row_off) {
@@ -189,12 +193,14 @@ __global__ __launch_bounds__(256) void wsum_bwd_kernel(const uint16_t* __restric
         const float* gp = g + (row + row_off) * D + cc * 8;
         const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
         const uint16_t* src = h + row * D + cc * 8;
+        const uint4 r = *(const uint4*)(src + (int64_t)(NL - 1) * plane);
 #pragma unroll
-        for (int n = 0; n < 32; ++n) {
-            if (n < NL) {
+        for (int n = 0; n < 31; ++n) {
+            if (n < NL - 1) {
                 const uint4 u = *(const uint4*)(src + n * plane);
-                acc[n] += g0[0] * bflo(u.x) + g0[1] * bfhi(u.x) + g0[2] * bflo(u.y) + g0[3] * bfhi(u.y) +
-                          g1[0] * bflo(u.z) + g1[1] * bfhi(u.z) + g1[2] * bflo(u.w) + g1[3] * bfhi(u.w);
+                acc[n] += g0[0] * (bflo(u.x) - bflo(r.x)) + g0[1] * (bfhi(u.x) - bfhi(r.x)) + g0[2] * (bflo(u.y) - bflo(r.y)) +
+                          g0[3] * (bfhi(u.y) - bfhi(r.y)) + g1[0] * (bflo(u.z) - bflo(r.z)) + g1[1] * (bfhi(u.z) - bfhi(r.z)) +
+                          g1[2] * (bflo(u.w) - bflo(r.w)) + g1[3] * (bfhi(u.w) - bfhi(r.w));
             }
         }
     }
@@ -314,16 +320,18 @@ __global__ __launch_bounds__(256) void wsum_norm_bwd_kernel(const uint16_t* __re
                 for (int j = 0; j < 8; ++j) gv[i][j] = 0.f;
             }
         }
+        float xr[NE][8];                 // reference layer (the last one): see wsum_bwd_kernel
+        load_row_norm<NE>(h + (int64_t)(NL - 1) * plane + row * D, lane, nchunks, D, 1e-5f, xr);
 #pragma unroll
-        for (int n = 0; n < 32; ++n) {
-            if (n < NL) {
+        for (int n = 0; n < 31; ++n) {
+            if (n < NL - 1) {
                 float xh[NE][8];
                 load_row_norm<NE>(h + n * plane + row * D, lane, nchunks, D, 1e-5f, xh);
                 float d = 0.f;
 #pragma unroll
                 for (int i = 0; i < NE; ++i)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) d += gv[i][j] * xh[i][j];
+                    for (int j = 0; j < 8; ++j) d += gv[i][j] * (xh[i][j] - xr[i][j]);
                 accn[n] += d;        // per-lane partial; reduced over the wave once at the end
             }
         }

@@ -66,27 +66,27 @@ __global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ fp32 MFMA GEMM
-// C[m, n] = sum_k A(m, k) B(n, k) (+ bias[n]).  Each operand is either ROW-major ([rows][K], the nn.Linear layout; K % 4 == 0) or K-major
-// ([K][rows]); any M, N, K; leading dimensions multiples of 4.
+// C[m, n] = sum_k A(m, k) B(n, k) (+ bias[n]).  Each operand is either ROW-major ([rows][K], the nn.Linear layout) or K-major ([K][rows]);
+// any M, N, K (16-byte loads when base and leading dimension are 16-byte multiples, element loads otherwise).
 // LDS image [k][LDT floats], LDT = 132: a fragment read is lane -> column (32 consecutive floats per half wave, conflict free);
 // row-major tiles are transposed on the way in (4 scalar LDS stores per 16-byte global load, 2-way conflicts = free on b32 stores).
 constexpr int LDT = 132;
 
 template <bool KMAJOR>
 __device__ __forceinline__ void sg_load(float4 (&r)[2], const float* __restrict__ P, int64_t ld, int rows, int K, int r0, int k0,
-                                        int tid) {
+                                        int tid, bool vec) {
     if constexpr (KMAJOR) {          // P[k][row]: thread -> (k = tid / 32 (+8), 4 consecutive rows)
         const int kr = tid >> 5, c = (tid & 31) * 4;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float* p = P + (int64_t)(k0 + kr + 8 * h) * ld + r0 + c;
             if (k0 + kr + 8 * h >= K) r[h] = float4{0.f, 0.f, 0.f, 0.f};
-            else if (r0 + c + 3 < rows) r[h] = *(const float4*)p;
+            else if (vec && r0 + c + 3 < rows) r[h] = *(const float4*)p;
             else {
                 r[h].x = r0 + c < rows ? p[0] : 0.f;
                 r[h].y = r0 + c + 1 < rows ? p[1] : 0.f;
                 r[h].z = r0 + c + 2 < rows ? p[2] : 0.f;
-                r[h].w = 0.f;
+                r[h].w = r0 + c + 3 < rows ? p[3] : 0.f;
             }
         }
     } else {                         // P[row][k]: thread -> (row = tid / 4 (+64), 4 consecutive k)
@@ -94,7 +94,15 @@ __device__ __forceinline__ void sg_load(float4 (&r)[2], const float* __restrict_
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int row = r0 + rr + 64 * h;
-            r[h] = (row < rows && k0 + kq < K) ? *(const float4*)(P + (int64_t)row * ld + k0 + kq) : float4{0.f, 0.f, 0.f, 0.f};
+            const float* p = P + (int64_t)row * ld + k0 + kq;
+            if (row >= rows || k0 + kq >= K) r[h] = float4{0.f, 0.f, 0.f, 0.f};
+            else if (vec && k0 + kq + 3 < K) r[h] = *(const float4*)p;
+            else {
+                r[h].x = p[0];
+                r[h].y = k0 + kq + 1 < K ? p[1] : 0.f;
+                r[h].z = k0 + kq + 2 < K ? p[2] : 0.f;
+                r[h].w = k0 + kq + 3 < K ? p[3] : 0.f;
+            }
         }
     }
 }
@@ -120,7 +128,7 @@ __device__ __forceinline__ void sg_stage(const float4 (&r)[2], float (*S)[LDT], 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256, 2) void sgemm_mfma_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
                                                            int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                           const float* __restrict__ bias) {
+                                                           const float* __restrict__ bias, int vec_a, int vec_b) {
     __shared__ float As[2][16][LDT];
     __shared__ float Bs[2][16][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -131,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_mfma_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
     float4 ra[2], rb[2];
-    sg_load<A_KMAJOR>(ra, A, lda, M, K, m0, 0, tid);
-    sg_load<B_KMAJOR>(rb, Bm, ldb, N, K, n0, 0, tid);
+    sg_load<A_KMAJOR>(ra, A, lda, M, K, m0, 0, tid, vec_a);
+    sg_load<B_KMAJOR>(rb, Bm, ldb, N, K, n0, 0, tid, vec_b);
     sg_stage<A_KMAJOR>(ra, As[0], tid);
     sg_stage<B_KMAJOR>(rb, Bs[0], tid);
     __syncthreads();
@@ -141,8 +149,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_mfma_kernel(const float* __restr
         const int cur = t & 1;
         const bool more = t + 1 < nk;
         if (more) {
-            sg_load<A_KMAJOR>(ra, A, lda, M, K, m0, (t + 1) * 16, tid);
-            sg_load<B_KMAJOR>(rb, Bm, ldb, N, K, n0, (t + 1) * 16, tid);
+            sg_load<A_KMAJOR>(ra, A, lda, M, K, m0, (t + 1) * 16, tid, vec_a);
+            sg_load<B_KMAJOR>(rb, Bm, ldb, N, K, n0, (t + 1) * 16, tid, vec_b);
         }
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) {
@@ -449,11 +457,11 @@ extern "C" int sc_sgemm_mfma_f32(const float* A, int64_t lda, int32_t a_kmajor, 
                                  float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, void* stream) {
     SC_CHECK(A && Bm && C, "sc_sgemm_mfma_f32: null pointer");
     SC_CHECK(M > 0 && N > 0 && K > 0, "sc_sgemm_mfma_f32: M=%d N=%d K=%d", M, N, K);
-    SC_CHECK((a_kmajor || K % 4 == 0) && (b_kmajor || K % 4 == 0), "sc_sgemm_mfma_f32: row-major operands need K %% 4 == 0 (K=%d)", K);
-    SC_CHECK(lda % 4 == 0 && ldb % 4 == 0 && ldc >= N, "sc_sgemm_mfma_f32: leading dimensions must be multiples of 4");
-    SC_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)Bm & 15) == 0, "sc_sgemm_mfma_f32: operands must be 16-byte aligned");
+    SC_CHECK(ldc >= N, "sc_sgemm_mfma_f32: ldc");
+    // 16-byte loads when the base and the leading dimension allow it, element loads otherwise (tiny / ragged operands)
+    const int vec_a = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0), vec_b = (ldb % 4 == 0) && (((uintptr_t)Bm & 15) == 0);
     const dim3 grid((N + 127) / 128, (M + 127) / 128);
-#define SG_LAUNCH(AK, BK) hipLaunchKernelGGL((sgemm_mfma_kernel<AK, BK>), grid, dim3(256), 0, (hipStream_t)stream, A, lda, Bm, ldb, C, ldc, M, N, K, bias)
+#define SG_LAUNCH(AK, BK) hipLaunchKernelGGL((sgemm_mfma_kernel<AK, BK>), grid, dim3(256), 0, (hipStream_t)stream, A, lda, Bm, ldb, C, ldc, M, N, K, bias, vec_a, vec_b)
     if (a_kmajor && b_kmajor) SG_LAUNCH(true, true);
     else if (a_kmajor) SG_LAUNCH(true, false);
     else if (b_kmajor) SG_LAUNCH(false, true);

@@ -1,9 +1,10 @@
 """MaskedContrastiveLoss (avssl/module/losses.py:129-245) on the HIP loss kernels.
 
-Same constructor, ``forward(feat_A, feat_B, index=None) -> scalar``, ``current_temperature`` and the
-``temperature`` parameter/attribute (log(1/T) when trainable, 1/T otherwise).  No MAX_EYE = 256 cap
-(losses.py:126: the reference cannot run B > 256; the masks are computed in-kernel from ``index``).
-``margin`` and ``dcl`` are accepted only at their shipped values (0.0 / False).
+Same constructor (temperature, temperature_trainable, margin, dcl, a2b, b2a - every option built), ``forward(feat_A, feat_B,
+index=None) -> scalar``, ``current_temperature`` and the ``temperature`` parameter / attribute (log(1/T) when trainable, 1/T
+otherwise).  No MAX_EYE = 256 cap (losses.py:126: the reference cannot run B > 256; the masks are computed in-kernel from
+``index``).  Forward = one launch (csrc/loss_optim.hip: sc_infonce_fwd); the temperature reaches the kernels as a DEVICE scalar,
+so a trainable temperature costs no host synchronisation in the step.
 """
 import numpy as np
 import torch
@@ -14,33 +15,30 @@ from . import ops
 
 class _InfoNCEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat_A, feat_B, inv_temp, index):
+    def forward(ctx, feat_A, feat_B, inv_temp, index, margin, dcl, a2b, b2a):
         A = feat_A.detach().float().contiguous()
         Bm = feat_B.detach().float().contiguous()
-        Bg, E = A.shape
-        it = float(inv_temp.detach()) if isinstance(inv_temp, torch.Tensor) else float(inv_temp)
-        logits = ops.sgemm(A, E, 1, Bm, E, 1, Bg, Bg, E, alpha=it)
+        it = inv_temp.detach().float().reshape(1).contiguous()
         ids = index.contiguous() if index is not None else None
-        loss, lse_row, lse_col = ops.infonce_lse(logits, ids)
-        ctx.save_for_backward(A, Bm, logits, lse_row, lse_col, ids if ids is not None else torch.empty(0))
+        loss, logits, lse_row, lse_col = ops.infonce_fwd(A, Bm, ids, it, margin, dcl, a2b, b2a)
+        ctx.save_for_backward(A, Bm, logits, lse_row, lse_col, it, ids if ids is not None else torch.empty(0))
         ctx.has_ids = ids is not None
-        ctx.it = it
+        ctx.opts = (margin, dcl, a2b, b2a)
         return loss[0].clone()
 
     @staticmethod
     def backward(ctx, g):
-        A, Bm, logits, lse_row, lse_col, ids = ctx.saved_tensors
+        A, Bm, logits, lse_row, lse_col, it, ids = ctx.saved_tensors
         ids = ids if ctx.has_ids else None
-        Bg, E = A.shape
-        G, dot = ops.infonce_grad(logits, ids, lse_row, lse_col, g.float().reshape(1).contiguous())
+        G, dot = ops.infonce_grad(logits, ids, lse_row, lse_col, g.float().reshape(1).contiguous(), it, *ctx.opts)
         dA = dB = dT = None
         if ctx.needs_input_grad[0]:
-            dA = ops.sgemm(G, Bg, 1, Bm, 1, E, Bg, E, Bg, alpha=ctx.it)      # G . B
+            dA = ops.sgemm_mfma(G, Bm, b_kmajor=True)                          # G . B     (G already carries inv_temp)
         if ctx.needs_input_grad[1]:
-            dB = ops.sgemm(G, 1, Bg, A, 1, E, Bg, E, Bg, alpha=ctx.it)       # G^T . A
+            dB = ops.sgemm_mfma(G, A, a_kmajor=True, b_kmajor=True)            # G^T . A
         if ctx.needs_input_grad[2]:
-            dT = dot.sum() / ctx.it                                          # d loss / d inv_temp
-        return dA, dB, dT, None
+            dT = dot.sum()                                                     # d loss / d inv_temp (device scalar)
+        return dA, dB, dT, None, None, None, None, None
 
 
 class MaskedContrastiveLoss(nn.Module):
@@ -48,14 +46,13 @@ class MaskedContrastiveLoss(nn.Module):
                  dcl: bool = False, a2b: bool = True, b2a: bool = True):
         super().__init__()
         assert a2b or b2a, "Cannot set both `a2b` and `b2a` to False."
-        if margin != 0.0 or dcl or not (a2b and b2a):
-            raise NotImplementedError("only the shipped loss configuration (margin 0, dcl false, a2b & b2a) is built")
         self.temperature_trainable = temperature_trainable
-        self.margin, self.dcl, self.a2b, self.b2a = margin, dcl, a2b, b2a
+        self.margin, self.dcl, self.a2b, self.b2a = float(margin), bool(dcl), bool(a2b), bool(b2a)
         if temperature_trainable:
             self.temperature = nn.Parameter(torch.ones([]) * np.log(1 / temperature))
         else:
             self.temperature = 1 / temperature
+        self._inv_temp_dev = {}
 
     @property
     def current_temperature(self) -> float:
@@ -77,5 +74,10 @@ class MaskedContrastiveLoss(nn.Module):
         assert feat_A.shape == feat_B.shape, (feat_A.shape, feat_B.shape)
         if index is not None:
             assert index.shape[0] == feat_A.shape[0], (index.shape, feat_A.shape)
-        inv_temp = torch.exp(self.temperature) if self.temperature_trainable else self.temperature
-        return _InfoNCEFn.apply(feat_A, feat_B, inv_temp, index)
+        if self.temperature_trainable:
+            inv_temp = torch.exp(self.temperature)
+        else:                                              # constant: one device scalar per device, built once
+            inv_temp = self._inv_temp_dev.get(feat_A.device)
+            if inv_temp is None:
+                inv_temp = self._inv_temp_dev[feat_A.device] = torch.full((1,), float(self.temperature), device=feat_A.device)
+        return _InfoNCEFn.apply(feat_A, feat_B, inv_temp, index, self.margin, self.dcl, self.a2b, self.b2a)

@@ -333,9 +333,9 @@ def vq_prep(kw: torch.Tensor, eps: float = 1e-8):
 def sgemm_mfma(A: torch.Tensor, Bm: torch.Tensor, a_kmajor: bool = False, b_kmajor: bool = False, bias: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C [M, N] = A . B^T (+ bias) in exact fp32 on the matrix pipe.  A: [M, K] (or [K, M] with a_kmajor), B: [N, K] (nn.Linear
-    layout; or [K, N] with b_kmajor); row-major operands need K % 4 == 0."""
-    assert A.dtype == torch.float32 and Bm.dtype == torch.float32 and A.stride(1) == 1 and Bm.stride(1) == 1
-    A, Bm = aligned16(A), aligned16(Bm)
+    layout; or [K, N] with b_kmajor); any M, N, K."""
+    assert A.dtype == torch.float32 and Bm.dtype == torch.float32
+    assert (A.stride(1) == 1 or A.shape[1] == 1) and (Bm.stride(1) == 1 or Bm.shape[1] == 1)
     K, M = A.shape if a_kmajor else A.shape[::-1]
     K2, N = Bm.shape if b_kmajor else Bm.shape[::-1]
     assert K == K2, (A.shape, Bm.shape)
@@ -531,7 +531,8 @@ def wsum_fwd(h: torch.Tensor, w_softmax: torch.Tensor, out: torch.Tensor, B: int
 
 def wsum_bwd(h: torch.Tensor, g: torch.Tensor, B: int, R: int, D: int, row_off: int, nblk: int = 1024,
              normalize: bool = False) -> torch.Tensor:
-    """returns d(softmaxed weights)[NL] = <g, h_n>."""
+    """returns d(softmaxed weights)[NL] up to a common shift: <g, h_n - h_last> (sc_wsum_bwd: the callers' softmax projection
+    w_n (d_n - sum_m w_m d_m) does not see the shift, and the fp32 sums keep the digits the projection needs)."""
     NL = h.shape[0]
     assert g.dtype == torch.float32
     part = torch.empty(nblk, NL, device=h.device, dtype=torch.float32)
@@ -579,24 +580,46 @@ def sgemm(A: torch.Tensor, sai: int, sak: int, Bm: torch.Tensor, sbj: int, sbk: 
     return out
 
 
-def infonce_lse(logits: torch.Tensor, ids: Optional[torch.Tensor]):
-    Bg = logits.shape[0]
-    lse_row = torch.empty(Bg, device=logits.device, dtype=torch.float32)
-    lse_col = torch.empty_like(lse_row)
-    loss = torch.empty(Bg + 1, device=logits.device, dtype=torch.float32)
+_INFONCE_WS = {}
+
+
+def _infonce_workspace(Bg: int, device) -> torch.Tensor:
+    """Per (device, stream, Bg) workspace of sc_infonce_fwd; zeroed once (it holds the ticket word, which every launch resets)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, Bg)
+    ws = _INFONCE_WS.get(key)
+    if ws is None:
+        ws = _INFONCE_WS[key] = torch.zeros(int(lib().sc_infonce_workspace_floats(Bg)), device=device, dtype=torch.float32)
+    return ws
+
+
+def infonce_fwd(A: torch.Tensor, Bm: torch.Tensor, ids: Optional[torch.Tensor], inv_temp: torch.Tensor, margin: float = 0.0,
+                dcl: bool = False, a2b: bool = True, b2a: bool = True):
+    """-> (loss [1], logits [Bg, Bg], lse_row [Bg], lse_col [Bg]); A, B [Bg, E] fp32 contiguous, inv_temp a device scalar tensor."""
+    Bg, E = A.shape
+    assert A.dtype == torch.float32 and Bm.dtype == torch.float32 and A.is_contiguous() and Bm.is_contiguous() and Bm.shape == A.shape
+    assert inv_temp.dtype == torch.float32 and inv_temp.is_cuda and inv_temp.numel() == 1
     if ids is not None:
-        assert ids.dtype == torch.int64
-    check(lib().sc_infonce_lse(_p(logits), _p(ids), Bg, _p(lse_row), _p(lse_col), _p(loss), _stream()), "sc_infonce_lse")
-    return loss, lse_row, lse_col
+        assert ids.dtype == torch.int64 and ids.is_contiguous()
+    A, Bm = aligned16(A), aligned16(Bm)
+    dev = A.device
+    logits = torch.empty(Bg, Bg, device=dev, dtype=torch.float32)
+    lse_row, lse_col = torch.empty(Bg, device=dev, dtype=torch.float32), torch.empty(Bg, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    ws = _infonce_workspace(Bg, dev)
+    check(lib().sc_infonce_fwd(_p(A), _p(Bm), Bg, E, _p(ids), _p(inv_temp), float(margin), int(dcl), int(a2b), int(b2a), _p(logits),
+                               _p(lse_row), _p(lse_col), _p(loss), _p(ws), _stream()), "sc_infonce_fwd")
+    return loss, logits, lse_row, lse_col
 
 
 def infonce_grad(logits: torch.Tensor, ids: Optional[torch.Tensor], lse_row: torch.Tensor, lse_col: torch.Tensor,
-                 gscale: torch.Tensor):
+                 gscale: torch.Tensor, inv_temp: torch.Tensor, margin: float = 0.0, dcl: bool = False, a2b: bool = True,
+                 b2a: bool = True):
+    """-> (G [Bg, Bg] = inv_temp * gscale * dloss/dlogits, dot [Bg] with sum(dot) = d loss / d inv_temp * gscale)."""
     Bg = logits.shape[0]
     G = torch.empty_like(logits)
     dot = torch.empty(Bg, device=logits.device, dtype=torch.float32)
-    check(lib().sc_infonce_grad(_p(logits), _p(ids), _p(lse_row), _p(lse_col), Bg, _p(gscale), _p(G), _p(dot), _stream()),
-          "sc_infonce_grad")
+    check(lib().sc_infonce_grad(_p(logits), _p(ids), _p(lse_row), _p(lse_col), Bg, _p(gscale), _p(inv_temp), float(margin), int(dcl),
+                                int(a2b), int(b2a), _p(G), _p(dot), _stream()), "sc_infonce_grad")
     return G, dot
 
 

@@ -317,6 +317,52 @@ def test_loss_golden(dev, golden, name):
         assert abs(l2.item() - float(fx["loss_noindex"])) < 2e-5 * max(1.0, abs(float(fx["loss_noindex"])))
 
 
+@pytest.mark.parametrize("name", ["loss_v_margin", "loss_v_dcl", "loss_v_a2b", "loss_v_b2a", "loss_v_margin_dcl_trainT"])
+def test_loss_variants_golden(dev, golden, name):
+    """margin / decoupled / one-sided MaskedContrastiveLoss (losses.py:213,226-245) against the reference leaf's vectors; two
+    launches back to back share the workspace (the ticket word must come back to zero)."""
+    from speechclip_plus_amd.losses import MaskedContrastiveLoss
+    fx = golden(name + ".npz")
+    crit = MaskedContrastiveLoss(temperature=0.07, temperature_trainable=bool(fx["trainT"]), margin=float(fx["margin"]),
+                                 dcl=bool(fx["dcl"]), a2b=bool(fx["a2b"]), b2a=bool(fx["b2a"])).to(dev)
+    A = torch.from_numpy(fx["A"]).to(dev).requires_grad_(True)
+    Bm = torch.from_numpy(fx["B"]).to(dev).requires_grad_(True)
+    ids = torch.from_numpy(fx["ids"]).to(dev)
+    for _ in range(2):
+        A.grad = Bm.grad = None
+        crit.zero_grad()
+        loss = crit(A, Bm, ids)
+        loss.backward()
+        assert abs(loss.item() - float(fx["loss"])) < 2e-5 * max(1.0, abs(float(fx["loss"])))
+        np.testing.assert_allclose(A.grad.cpu().numpy(), fx["dA"], rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(Bm.grad.cpu().numpy(), fx["dB"], rtol=2e-4, atol=2e-6)
+        if bool(fx["trainT"]):
+            np.testing.assert_allclose(crit.temperature.grad.cpu().numpy(), fx["dtemp_param"], rtol=2e-4)
+    l2 = crit(A.detach(), Bm.detach(), None)
+    assert abs(l2.item() - float(fx["loss_noindex"])) < 2e-5 * max(1.0, abs(float(fx["loss_noindex"])))
+
+
+@pytest.mark.parametrize("Bg,E", [(64, 512), (200, 768), (512, 512), (1000, 64)])
+def test_infonce_fused_forward_vs_fp64(dev, Bg, E):
+    """sc_infonce_fwd at the batch sizes of the recipes (64 per GPU ... 512 global, and a ragged one): logits, both
+    log-sum-exps and the loss against fp64 torch."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(Bg)
+    A = F.normalize(torch.randn(Bg, E, generator=g), dim=-1)
+    Bm = F.normalize(torch.randn(Bg, E, generator=g) + 0.5 * A, dim=-1)
+    ids = torch.arange(Bg) // 5
+    it = torch.full((1,), 1 / 0.07)
+    loss, logits, lr, lc = ops.infonce_fwd(A.to(dev), Bm.to(dev), ids.to(dev), it.to(dev))
+    ref = (A.double() @ Bm.double().t()) / 0.07
+    neg = (ids[:, None] != ids[None, :]) | torch.eye(Bg, dtype=torch.bool)
+    rl = torch.logsumexp(ref.masked_fill(~neg, float("-inf")), dim=1)
+    cl = torch.logsumexp(ref.masked_fill(~neg, float("-inf")), dim=0)
+    ref_loss = 0.5 * ((rl - ref.diag()).mean() + (cl - ref.diag()).mean())
+    assert float((logits.double().cpu() - ref).abs().max()) < 2e-5
+    assert float((lr.double().cpu() - rl).abs().max()) < 5e-5 and float((lc.double().cpu() - cl).abs().max()) < 5e-5
+    assert abs(float(loss) - float(ref_loss)) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------------ head
 @pytest.mark.parametrize("name", ["head_d64_h8", "head_d64_h1"])
 def test_parallel_branch_golden(dev, golden, name):
@@ -857,6 +903,35 @@ def test_mha_norm_block_vs_torch(dev, D, H, S, p_drop):
         with torch.no_grad():
             stock = norm(mha(x0, x0, x0, key_padding_mask=kpm)[0] + x0)
         assert rel_l2(out[valid], stock[valid]) < 1e-2
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_weighted_sum_logit_gradient_on_a_residual_stream(dev, normalize):
+    """sc_wsum_bwd on hidden states that differ little from layer to layer (a residual stream: h_n = base + 0.03 delta_n): the
+    gradient of the logits, w_n (d_n - sum_m w_m d_m), is a difference of nearly equal inner products.  Against fp64 on the SAME
+    bf16 states the kernel path must keep 4 digits (it subtracts the last layer before accumulating); what remains against an fp32
+    oracle in the model tests is then the bf16 representation of the states, not the kernel's arithmetic."""
+    from speechclip_plus_amd.weighted_sum import WeightedSumLayer
+    g = torch.Generator(device="cpu").manual_seed(5 + normalize)
+    NL, B, T, D = 13, 3, 200, 1024
+    base = torch.randn(B, T, D, generator=g) * 2.0 + 0.5
+    hs = [(base + 0.03 * torch.randn(B, T, D, generator=g)).to(torch.bfloat16) for _ in range(NL)]
+    gout = torch.randn(B, T, D, generator=g).to(torch.bfloat16).float()     # the layer's output is bf16: so is its gradient
+    w0 = torch.randn(NL, generator=g) * 0.5
+    layer = WeightedSumLayer(NL, normalize_features=normalize).to(dev)
+    with torch.no_grad():
+        layer.weights.copy_(w0)
+    out = layer([h.to(dev) for h in hs])
+    (out.float() * gout.to(dev)).sum().backward()
+    w = w0.double().requires_grad_()
+    stack = torch.stack([h.double() for h in hs])
+    if normalize:
+        stack = torch.nn.functional.layer_norm(stack, (D,))
+    ref = (torch.softmax(w, 0).view(NL, 1, 1, 1) * stack).sum(0)
+    (ref * gout.double()).sum().backward()
+    assert rel_l2(out.detach().float().cpu(), ref.detach().float()) < 5e-3
+    e = rel_l2(layer.weights.grad.double().cpu(), w.grad)
+    assert e < 1e-4, e
 
 
 @pytest.mark.parametrize("n,p_drop", [(72, 0.0), (512, 0.0), (1024, 0.2), (260, 0.5)])
