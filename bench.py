@@ -40,8 +40,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--cpu-utts", type=int, default=2, help="utterances in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-utts", type=int, default=8, help="utterances in the CPU-baseline sample: BASELINE configs[0] = batch 8 (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=2, help="timed CPU iterations per thread setting (after 1 warm-up)")
+    ap.add_argument("--cpu-full", action="store_true", help="the CPU baseline exactly as SURVEY 8d states it: 3 warm-up + 10 timed "
+                    "iterations, all host cores and 8 threads (several minutes; the default run is a bounded sample of the same workload)")
+    ap.add_argument("--no-recall", action="store_true", help="skip the recall@k parity field (5000-utterance synthetic eval set)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="deterministic train step: every dropout site off (A/B only; the "
                     "reference's train step runs HuBERT's and the head's dropout, which is the default here)")
@@ -140,17 +143,20 @@ def main():
     torch.cuda.synchronize()
     ops.set_timer(None)
     # ---- forward only (north_star: fraction of the MFMA bf16 peak on the HuBERT + attention-pool forward) ---------
-    fwd_ms = None
+    fwd_ms = fwd_train_ms = None
     if rank == 0 and args.model == "base":
-        model.eval()                                             # inference forward: no dropout
-        with torch.no_grad():
-            model(batch)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
+        def time_forward():
+            with torch.no_grad():
                 model(batch)
-            torch.cuda.synchronize()
-            fwd_ms = (time.perf_counter() - t1) / args.steps * 1e3
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    model(batch)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / args.steps * 1e3
+        fwd_train_ms = time_forward()                            # as the train step runs it: HuBERT + head dropout live
+        model.eval()                                             # inference forward: no dropout
+        fwd_ms = time_forward()
         model.train()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -189,7 +195,10 @@ def main():
                             "alg_tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None}
         cpu = None
         if world == 1 and args.cpu_utts > 0 and args.model == "base":
-            cpu = cpu_baseline(sd, model, args.cpu_utts, L, args.cpu_iters)
+            cpu = cpu_baseline(sd, model, args.cpu_utts, L, args.cpu_iters, args.cpu_full)
+        recall = None
+        if world == 1 and args.model == "base" and not args.no_recall:
+            recall = recall_parity(dev)
         result = {
             "metric": "utterances/sec (train step)", "value": round(B * world * args.steps / elapsed, 2),
             "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,6 +223,8 @@ def main():
             "rccl_ranks": rccl_ranks, "dist_backend": (os.environ.get("SC_DIST_BACKEND", "nccl") if dist is not None else None),
             "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,
             "forward": None if fwd_ms is None else forward_summary(fwd_ms, B, L, T),
+            "forward_train_mode": None if fwd_train_ms is None else forward_summary(fwd_train_ms, B, L, T),
+            "recall": recall,
         }
         print(json.dumps(result), flush=True)
     if dist is not None:
@@ -313,45 +324,86 @@ def pmc_traffic(kernel_substr):
     if not files:
         return {"traffic": None}
     data = json.load(open(files[-1]))
-    hits = [v for name, v in data.items() if kernel_substr in name]
+    src = source_sha("gemm256_bf16.hip" if "gemm256" in kernel_substr else "gemm_bf16.hip")
+    meta = data.get("_meta", {})
+    hits = [v for name, v in data.items() if kernel_substr in name and name != "_meta"]
     if not hits:
         return {"traffic": None}
+    if meta.get("kernel_source_sha256") != src:
+        # the counters were collected on another version of the kernel: stale, not reported
+        return {"traffic": None, "traffic_source": os.path.relpath(files[-1], ROOT) + " (stale: kernel source changed since; "
+                f"profile {str(meta.get('kernel_source_sha256'))[:12]} vs tree {src[:12]})"}
     n = sum(v["launches_sampled"] for v in hits)
     avg = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hits) / n
     return {"traffic": round(avg), "traffic_unit": "bytes/launch (PMC, avg over launches of all instantiations)",
             "traffic_source": os.path.relpath(files[-1], ROOT)}
 
 
-def cpu_baseline(sd, model, n_utts, L, iters):
-    """The oracle (kind "port": torch-CPU fp32 restatement of the reference maths) on the host cores:
-    same train step (HuBERT fwd no-grad, weighted sum, parallel head fwd/bwd, loss fwd/bwd) on n_utts utterances."""
+def source_sha(name: str) -> str:
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "speechclip_plus_amd", "csrc", name), "rb").read()).hexdigest()
+
+
+def recall_parity(dev):
+    """recall@{1,5,10} of the HIP model on the 5000-utterance synthetic eval set against the oracle numbers held by
+    tests/golden/recall_eval.npz (tools/recall_eval.py; the oracle itself is not run here)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import recall_eval
+    if not os.path.exists(recall_eval.FIXTURE):
+        return None
+    fx = dict(np.load(recall_eval.FIXTURE))
+    return recall_eval.hip_recall(recall_eval.build_model(str(dev)), fx)
+
+
+def cpu_baseline(sd, model, n_utts, L, iters, full=False):
+    """The oracle (kind "port": torch-CPU fp32 restatement of the reference maths) on the host cores, BASELINE configs[0]:
+    Parallel SpeechCLIP base, batch 8 (the reference's CPU-runnable case), same utterance length as the GPU workload.  Forward
+    (frozen HuBERT under no_grad + weighted sum + parallel head + loss) and forward + backward are timed separately inside each
+    iteration, at two thread settings: all host threads torch picks, and 8 (comparable across hosts).
+    Default: 1 warm-up + ``iters`` timed iterations per setting (a bounded sample: the step is deterministic in cost);
+    ``full`` = SURVEY 8d's 3 warm-up + 10 timed."""
     import oracle
     torch.manual_seed(0)
     head_W = {k: v.detach().cpu().float().clone().requires_grad_(True) for k, v in model.parallel_branch.state_dict().items()}
     ws = torch.zeros(13, requires_grad=True)
     wavs = [torch.randn(L) for _ in range(n_utts)]
     img = torch.nn.functional.normalize(torch.randn(n_utts, 512), dim=-1)
-    ids = torch.arange(n_utts)
+    ids = torch.arange(n_utts) // 5
     arch = oracle.HubertArch.base()
+    warm, timed = (3, 10) if full else (1, iters)
 
     def step():
+        t0 = time.perf_counter()
         with torch.no_grad():
             hs, fl = oracle.speech_encoder_forward(sd, arch, wavs)
         feat = oracle.weighted_sum(ws, hs)
         e = oracle.parallel_branch_forward(head_W, feat, fl, nhead=8)
         loss = oracle.masked_contrastive_loss(e / e.norm(dim=-1, keepdim=True), img, ids)
+        t1 = time.perf_counter()
         loss.backward()
-        return loss
+        return t1 - t0, time.perf_counter() - t0
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    dt = (time.perf_counter() - t0) / iters
-    return {"value": round(n_utts / dt, 4), "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_utts} utterances x {L} samples, {iters} timed train steps after 1 warm-up, torch fp32 "
-                      f"({torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs)",
-            "s_per_step": round(dt, 3)}
+    default_threads = torch.get_num_threads()
+    runs = {}
+    for threads in (default_threads, 8):
+        if threads in runs or threads > default_threads:
+            continue
+        torch.set_num_threads(threads)
+        for _ in range(warm):
+            step()
+        ts = [step() for _ in range(timed)]
+        fwd = sum(t[0] for t in ts) / len(ts)
+        tot = sum(t[1] for t in ts) / len(ts)
+        runs[threads] = {"threads": threads, "forward_s": round(fwd, 3), "forward_backward_s": round(tot, 3),
+                         "forward_utt_per_s": round(n_utts / fwd, 3), "train_step_utt_per_s": round(n_utts / tot, 3)}
+    torch.set_num_threads(default_threads)
+    best = runs[default_threads]
+    return {"value": best["train_step_utt_per_s"], "unit": "utterances/s", "cores": default_threads, "kind": "port",
+            "sample": f"BASELINE configs[0]: batch {n_utts} x {L} samples, {warm} warm-up + {timed} timed train steps per thread "
+                      f"setting, torch fp32 on {os.cpu_count()} logical CPUs",
+            "s_per_step": best["forward_backward_s"], "forward_utt_per_s": best["forward_utt_per_s"],
+            "by_threads": list(runs.values())}
 
 
 if __name__ == "__main__":

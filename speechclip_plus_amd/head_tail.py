@@ -181,6 +181,8 @@ class ParallelHeadFn(torch.autograd.Function):
         d_cls = d_x0.reshape(1, 1, D)
         d_ws, d_feat = None, None
         hd = ctx.handle
+        if hd is not None:
+            hd.check_fresh()
         if hd is not None and ctx.needs_input_grad[1]:
             d_soft = ops.wsum_bwd(hd.hidden, dX, B, R, D, 1, normalize=hd.normalize)
             d_ws = hd.w_soft * (d_soft - (hd.w_soft * d_soft).sum())

@@ -24,22 +24,7 @@ from .speech_encoder import FairseqSpeechEncoder_Hubert
 logger = logging.getLogger(__name__)
 
 
-class Config(dict):
-    """Minimal attribute-style nested dict (stands in for avssl/base/ordered_namespace.py)."""
-
-    def __init__(self, d=None, **kw):
-        super().__init__()
-        for k, v in {**(d or {}), **kw}.items():
-            self[k] = Config(v) if isinstance(v, dict) and not isinstance(v, Config) else v
-
-    def __getattr__(self, k):
-        try:
-            return self[k]
-        except KeyError as e:
-            raise AttributeError(k) from e
-
-    def __setattr__(self, k, v):
-        self[k] = v
+from .config import Config, load_config, synthetic_reduced_vocab  # noqa: E402,F401
 
 
 def _cif_args(d: int) -> dict:
@@ -47,14 +32,6 @@ def _cif_args(d: int) -> dict:
             "produce_weight_type": "conv", "cif_threshold": 1.0, "conv_cif_layer_num": 1, "conv_cif_width": 3,
             "conv_cif_dropout": 0.1, "apply_scaling": True, "scaling_step": 5000, "apply_tail_handling": True,
             "tail_handling_firing_threshold": 0.5, "add_cif_ctxt_layers": False}
-
-
-def synthetic_reduced_vocab(n: int = 8112, seed: int = 0) -> torch.Tensor:
-    """Stand-in for avssl/data/flickr_stat/text_clip_vocab_usage_byfreq.npy (8112 sub-words; 19787 for coco), which
-    does not travel to the GPU box: n distinct CLIP token ids that contain <|startoftext|> and <|endoftext|>."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    ids = torch.randperm(49406, generator=g)[: n - 2]
-    return torch.cat([ids, torch.tensor([49406, 49407])])
 
 
 def cascaded_plus_base_config(**overrides) -> Config:
@@ -173,7 +150,9 @@ class KWClip_GeneralTransformer(nn.Module):
     def __init__(self, config, image_encoder: Optional[Callable] = None, device: str = "cuda", hubert_state_dict=None,
                  hubert_arch=None):
         super().__init__()
-        self.config = config if isinstance(config, Config) else Config(config)
+        if isinstance(config, str):                   # path of a reference yaml recipe (config/**/*.yaml parse unchanged)
+            config = load_config(config)
+        self.config = config if isinstance(config, Config) else load_config(config)
         config = self.config
         self._device = torch.device(device)
         self.audio_encoder_type = config.audio_encoder.type
@@ -342,22 +321,54 @@ class KWClip_GeneralTransformer(nn.Module):
         losses_ = self.compute_loss(outputs["loss_feats"])
         return {"loss": losses_["loss"], **{f"train_{k}": v for k, v in losses_.items()}}
 
+    # --------------------------------------------------------------------------------------------- Lightning-shaped hooks
+    def configure_optimizers(self):
+        """kwClip.py:646-674: ``([optimizer], [{"scheduler": ..., "interval": "step"}])`` over getTrainableParams().  The optimiser
+        is the flat fused clip + Adam (optim.FlatAdamOptimizer, a torch.optim.Optimizer), the schedule a LambdaLR."""
+        from .optim import FlatAdamOptimizer, get_scheduler
+        oc = self.config.audio_encoder.optim
+        if oc.name != "Adam":
+            raise NotImplementedError(f"optimizer {oc.name}: the shipped recipes use Adam")
+        opt = FlatAdamOptimizer(self.getTrainableParams(), **{k: v for k, v in dict(oc.args).items()})
+        sched = self.config.audio_encoder.get("scheduler", None)
+        if sched is None:
+            return [opt], []
+        return [opt], [{"scheduler": get_scheduler(opt, **dict(sched)), "interval": "step"}]
+
+    def log_dict(self, metrics: dict, **kwargs) -> None:
+        """Stand-in for LightningModule.log_dict (pytorch_lightning is not installed here): keeps the last values."""
+        self.logged = getattr(self, "logged", {})
+        self.logged.update(metrics)
+
     # --------------------------------------------------------------------------------------------- validation (f4)
     def validation_step(self, batch: dict, batch_idx: int = 0) -> dict:
-        """kwClip.py:195-228: the features the epoch-end retrieval needs (source branch by ``retrieval.audio_feat_src``)."""
+        """kwClip.py:195-246: ``{"loss_feats", "log_metrics", "others"}`` (the reference's keys)."""
         with torch.no_grad():
             losses_, log_metrics, others = self.forward(batch)
-        src = self.config.retrieval.get("audio_feat_src", "parallel")
-        audio_feat = others["cascaded_audio_feat"] if src == "cascaded" else others["parallel_audio_feat"]
-        return {"id": others["id"], "audio_feat": audio_feat, "image_feat": others.get("image_feat", None),
-                "loss_feats": losses_, "log_metrics": log_metrics}
+        return {"loss_feats": losses_, "log_metrics": log_metrics, "others": others}
+
+    def validation_step_end(self, outputs: dict) -> dict:
+        """kwClip.py:248-285: loss on the gathered features, logged as ``val_*``; returns ``others``.  The reference moves every
+        tensor of ``others`` to the CPU here (a synchronisation per validation step); they stay on the device - the epoch-end
+        retrieval runs there."""
+        assert isinstance(outputs, dict)
+        with torch.no_grad():
+            losses_ = self.compute_loss(outputs["loss_feats"])
+        result = {f"val_{k}": v for k, v in losses_.items()}
+        result.update({f"val_{k}": (v.float().mean() if isinstance(v, torch.Tensor) else v) for k, v in outputs["log_metrics"].items()})
+        self.log_dict(result, on_step=True, on_epoch=True, prog_bar=True, logger=True, sync_dist=True)
+        return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in outputs["others"].items()}
 
     def validation_epoch_end(self, outputs: list) -> dict:
         """kwClip.py:447-482: one image embedding per id (the last seen, as the reference's dict does), audio x image scores
-        and recall@k in both directions - everything stays on the device (retrieval.mutualRetrieval)."""
+        and recall@k in both directions - everything stays on the device (retrieval.mutualRetrieval).  ``outputs``: the
+        ``others`` dicts returned by validation_step_end (or validation_step's full dicts)."""
         from .retrieval import mutualRetrieval
+        outputs = [o["others"] if "others" in o else o for o in outputs]
+        src = self.config.retrieval.get("audio_feat_src", "parallel")
+        key = "cascaded_audio_feat" if src == "cascaded" else "parallel_audio_feat"
         ids = torch.cat([o["id"] for o in outputs], dim=0)
-        audio = torch.cat([o["audio_feat"] for o in outputs], dim=0).float()
+        audio = torch.cat([o["audio_feat"] if "audio_feat" in o else o[key] for o in outputs], dim=0).float()
         imgs = torch.cat([o["image_feat"] for o in outputs], dim=0).float()
         # last occurrence of every id, ids kept in first-seen order (python dict semantics of the reference)
         uniq, inv = torch.unique(ids, return_inverse=True)
@@ -402,6 +413,16 @@ class KWClip_GeneralTransformer(nn.Module):
                                         "ignored": sorted(k for k in rest if k not in loadable)}
         return model
 
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path: str, config=None, **kw):
+        """example.py:9-10 ``KWClip_GeneralTransformer.load_from_checkpoint(path)``: a PyTorch-Lightning checkpoint file holds
+        ``state_dict`` and (via save_hyperparameters, avssl/base/base_model.py:14) the config under ``hyper_parameters``."""
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        if config is None:
+            hp = ckpt.get("hyper_parameters", {})
+            config = hp.get("config", hp)
+        return cls.from_reference_checkpoint(config, ckpt["state_dict"], **kw)
+
     # ---------------------------------------------------------------------------------------------
     def encode_speech(self, wav) -> dict:
         """kwClip.py:1042-1091 (un-normalised branch output)."""
@@ -415,12 +436,11 @@ class KWClip_GeneralTransformer(nn.Module):
                 "vq_results": output["vq_results"], "keywords": output["keywords"]}
 
     def feature_extractor_s3prl(self, wav) -> Tuple[torch.Tensor, Tuple]:
-        """kwClip.py:965-997: the HuBERT states (cloned: they live in a reused workspace) followed by the branch
-        layer's hidden states (full-sequence head path, stock torch ops)."""
+        """kwClip.py:965-997: the HuBERT states (fresh tensors: the encoder clones what it hands out) followed by the branch
+        layer's hidden states (full-sequence layer on the library's kernels)."""
         wav, wav_len = self.processWavs(wav)
         audio_feat, audio_len, hidden_states = self.forward_audio(wav, wav_len, return_hidden_states=True)
         assert isinstance(hidden_states, tuple)
-        hidden_states = tuple(h.clone() for h in hidden_states)
         with torch.no_grad():
             if self.cascaded_branch is not None:
                 hidden_states = hidden_states + tuple(self.cascaded_branch.extract_hidden_states(audio_feat, audio_len)[1:])

@@ -92,3 +92,37 @@ class FlatAdam:
         gn = ops.sumsq(self.flat_g) if self.max_grad_norm > 0 else None
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr if lr is None else lr, self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, self.step_count, gn, float(self.max_grad_norm))
+
+
+class FlatAdamOptimizer(torch.optim.Optimizer):
+    """``torch.optim.Optimizer`` face of FlatAdam, for loops that drive the optimiser themselves (PyTorch-Lightning's
+    ``configure_optimizers`` contract, avssl/model/kwClip.py:646-674): one parameter group; ``step()`` is the fused flat clip +
+    Adam launch at the group's current ``lr`` (so torch's LambdaLR schedulers work unchanged); ``zero_grad()`` clears the flat
+    gradient buffer.  Gradient clipping is the trainer's business in that setting (``max_grad_norm`` = 0 here by default)."""
+
+    def __init__(self, params, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 max_grad_norm: float = 0.0):
+        params = [p for p in params if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.flat = FlatAdam(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self.flat.step(lr=float(self.param_groups[0]["lr"]))
+        return loss
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat.zero_grad()                       # gradients live in the flat buffer: never set to None
+
+
+def get_scheduler(optimizer: torch.optim.Optimizer, name: str, **kw):
+    """avssl/optim/scheduler.py:41-47: LambdaLR over the reference's two schedules."""
+    base_lr = optimizer.param_groups[0]["lr"]
+    if name == "linear_warmup_decay":
+        fn = lambda step: linear_warmup_decay(step, int(kw["warmup"]), int(kw["max_step"]), base_lr, float(kw["final_lr"]))
+    elif name == "noam":
+        fn = lambda step: noam(step, int(kw.get("warmup", 4000)))
+    else:
+        raise NotImplementedError(f"scheduler {name}")
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, fn)

@@ -185,6 +185,7 @@ class _Plan:
         self.wav_in = torch.zeros(B, L, device=dev, dtype=torch.float32) if _USE_GRAPH and torch.device(dev).type == "cuda" else None
         self.graph, self.graph_warm = None, 0        # hipGraph of the frozen encoder forward for this geometry
         self.train = {}              # per unfrozen layer: activations kept for the backward (hubert_train.TrainableLayers)
+        self.generation = 0          # forwards run on this plan (weighted_sum.PaddedFeatHandle.check_fresh)
 
 
 class FairseqSpeechEncoder_Hubert(nn.Module):
@@ -317,6 +318,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         a, w = self.arch, self._w
         B, L = padded.shape
         pl = self._plan(B, L)
+        pl.generation += 1
         C, D, F, H = a.conv_dim, a.embed_dim, a.ffn_dim, a.heads
         R, M, T = pl.R, pl.M, pl.T
         # every length-derived integer of the step goes up in ONE asynchronous copy from pinned memory BEFORE the kernels are
@@ -503,7 +505,11 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             self.before_trainable()
         pl = self._encode(padded, lens, save)
         B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
-        hidden_states = tuple(pl.hidden[n].view(B, R, D)[:, :T] for n in range(self.arch.layers + 1))
+        # views of the plan's resident workspace; every PUBLIC return path below hands out clones (the reference returns fresh
+        # tensors: holding encoder outputs across calls must be safe), the weighted-sum fast path reads the workspace in place
+        views = tuple(pl.hidden[n].view(B, R, D)[:, :T] for n in range(self.arch.layers + 1))
+        want_states = return_hidden_states or (feat_select_idx or self.feat_select_idx) != FEAT_SELECT_IDX_WEIGHTED_SUM_MODE
+        hidden_states = tuple(v.clone() for v in views) if want_states else views
         feat = {"last_hidden_state": hidden_states[-1], "hidden_states": hidden_states}
         feat_len = pl.feat_len                                                          # :604-611 (uploaded in _encode)
         if feat_select_idx is None:
@@ -514,7 +520,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         elif feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             if self.before_trainable is not None:
                 self.before_trainable()                 # train.ContrastiveTrainer: join the optimiser's side stream here
-            ws_feat = self.weightedsum_layer.forward_padded(pl.hidden, B, R, T, D)
+            ws_feat = self.weightedsum_layer.forward_padded(pl.hidden, B, R, T, D, plan=pl)
             if save:                                    # the head's backward hands dX to the unfrozen layers (hubert_train.py)
                 tl = self.train_layers
                 ws_feat._sc_handle.layers_bwd = lambda dX, w_soft, _pl=pl: tl.backward(

@@ -19,11 +19,21 @@ from . import ops
 class PaddedFeatHandle:
     """Side-channel from the encoder to the branch head (same process, same step)."""
 
-    def __init__(self, src, hidden, ws_layer, w_soft, B, R, T, D, normalize=False):
+    def __init__(self, src, hidden, ws_layer, w_soft, B, R, T, D, normalize=False, plan=None):
         self.src, self.hidden, self.ws_layer, self.w_soft = src, hidden, ws_layer, w_soft
         self.normalize = normalize
         self.B, self.R, self.T, self.D = B, R, T, D
         self.layers_bwd = None       # set by the encoder when transformer layers are unfrozen: callable(dX, w_soft)
+        # ``hidden`` is the encoder plan's RESIDENT workspace: the next forward with the same (B, L) geometry overwrites it through
+        # raw-pointer kernels (no autograd version bump).  One outstanding forward per plan: a backward that arrives after the
+        # plan has been re-used must fail loudly instead of differentiating against the wrong states.
+        self.plan, self.generation = plan, (plan.generation if plan is not None else None)
+
+    def check_fresh(self) -> None:
+        if self.plan is not None and self.plan.generation != self.generation:
+            raise RuntimeError("the encoder ran another forward with the same batch geometry before this backward: its hidden "
+                               "states (a resident workspace) have been overwritten.  Run backward before the next forward, or "
+                               "clone what must outlive it (one outstanding forward per (B, L) plan; INTEGRATION.md)")
 
 
 class _WeightedSumFn(torch.autograd.Function):
@@ -53,7 +63,8 @@ class _WeightedSumSrcFn(torch.autograd.Function):
     cascaded+/hybrid+ branches consume ``feat`` with ordinary torch ops, and their gradient arrives here."""
 
     @staticmethod
-    def forward(ctx, weights, hidden, B, R, D, normalize):
+    def forward(ctx, weights, hidden, B, R, D, normalize, plan):
+        ctx.plan, ctx.generation = plan, (plan.generation if plan is not None else None)
         w_soft = torch.softmax(weights.detach().float(), dim=0).contiguous()
         src = torch.empty(B, R, D, device=hidden.device, dtype=torch.bfloat16)
         src[:, 0].zero_()                    # rows 1 .. R - 1 are written by the kernel; row 0 is the CLS slot
@@ -66,8 +77,11 @@ class _WeightedSumSrcFn(torch.autograd.Function):
     def backward(ctx, g):
         hidden, w_soft = ctx.saved_tensors
         B, R, D, normalize = ctx.dims
+        if ctx.plan is not None and ctx.plan.generation != ctx.generation:
+            raise RuntimeError("the encoder ran another forward with the same batch geometry before this backward (its resident "
+                               "hidden states were overwritten): one outstanding forward per (B, L) plan")
         d_soft = ops.wsum_bwd(hidden, g.float().contiguous(), B, R, D, 1, normalize=normalize)
-        return w_soft * (d_soft - (w_soft * d_soft).sum()), None, None, None, None, None
+        return w_soft * (d_soft - (w_soft * d_soft).sum()), None, None, None, None, None, None
 
 
 class WeightedSumLayer(nn.Module):
@@ -85,9 +99,9 @@ class WeightedSumLayer(nn.Module):
         out = _WeightedSumFn.apply(self.weights, h, 1, h.shape[1], D, self.normalize_features)
         return out.view(*shape)
 
-    def forward_padded(self, hidden: torch.Tensor, B: int, R: int, T: int, D: int) -> torch.Tensor:
+    def forward_padded(self, hidden: torch.Tensor, B: int, R: int, T: int, D: int, plan=None) -> torch.Tensor:
         w_soft = torch.softmax(self.weights.detach().float(), dim=0).contiguous()
-        src = _WeightedSumSrcFn.apply(self.weights, hidden, B, R, D, self.normalize_features)
+        src = _WeightedSumSrcFn.apply(self.weights, hidden, B, R, D, self.normalize_features, plan)
         feat = src[:, 1: T + 1]
-        feat._sc_handle = PaddedFeatHandle(src, hidden, self, w_soft, B, R, T, D, self.normalize_features)
+        feat._sc_handle = PaddedFeatHandle(src, hidden, self, w_soft, B, R, T, D, self.normalize_features, plan)
         return feat

@@ -3,8 +3,9 @@
 
 Runs in the build container on the CPU ORACLE (torch fp32 restatement of the reference maths): HuBERT-base with seeded weights ->
 weighted sum -> parallel branch -> 5000 audio embeddings; image embeddings are built FROM the oracle's audio embeddings (class
-mean of the centred captions + seeded noise) so that recall@1 is neither 0 nor 100; recall@{1,5,10} in both directions with the
-oracle's mutual_retrieval.  Stored (tests/golden/recall_eval.npz, ~2 MB): the image embeddings, the oracle's recalls, the rank of
+mean of the centred first three captions + seeded noise; captions 3 and 4 are held out of the construction) so that recall@1
+is neither 0 nor 100; recall@{1,5,10} in both directions with the oracle's mutual_retrieval, over all 5000 queries (the
+reference's protocol) and over the 2000 held-out queries (unbiased HIP-vs-oracle comparison).  Stored (tests/golden/recall_eval.npz, ~2 MB): the image embeddings, the oracle's recalls, the rank of
 the correct image for every utterance (rank-flip accounting), the first 64 oracle audio embeddings (cosine spot check) and the
 generation parameters.  Waveforms and weights are NOT stored: `eval_set()` regenerates them from the seeds (CPU torch.Generator
 streams: identical on every host with this torch build), for the GPU test and for bench.py's `recall` field.
@@ -22,55 +23,18 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
 
-SEED_W, SEED_HEAD, SEED_DATA = 7122, 7123, 20260
-PER_ID = 5
-WS_WEIGHTS = torch.linspace(-1, 1, 13)
-
-
-def utterance(k: int, j: int) -> torch.Tensor:
-    """Caption j of image id k: a per-id base signal (1.5 - 2.5 s) plus per-caption noise, ragged length."""
-    g = torch.Generator().manual_seed(SEED_DATA + k)
-    L = int(torch.randint(24000, 40001, (1,), generator=g))
-    base = torch.randn(L, generator=g)
-    gj = torch.Generator().manual_seed(SEED_DATA * 7 + k * PER_ID + j)
-    lj = L - int(torch.randint(0, 4001, (1,), generator=gj))
-    return 0.6 * base[:lj] + 0.5 * torch.randn(lj, generator=gj)
-
-
-def eval_set(n_ids: int):
-    """-> (list of n_ids * 5 waveforms, ids [n_ids * 5])"""
-    wavs = [utterance(k, j) for k in range(n_ids) for j in range(PER_ID)]
-    return wavs, torch.arange(n_ids).repeat_interleave(PER_ID)
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..", "tools")))
+from recall_eval import (GALLERY, PER_ID, WS_WEIGHTS, correct_rank, eval_set, head_weights, hubert_weights,  # noqa: E402
+                         images_from)
 
 
 def weights():
-    """Seeded HuBERT-base + parallel-branch weights.  The CLS token is scaled to 0.1: at unit scale the residual path of the CLS
-    row (a constant) dominates the pooled output and the embeddings of all utterances collapse onto one direction (|mean| =
-    0.999), which makes every rank a near-tie; a trained head does not do that."""
-    import oracle
-    head = oracle.init_parallel_branch_weights(seed=SEED_HEAD)
-    head["cls"] = head["cls"] * 0.1
-    return oracle.init_hubert_weights(oracle.HubertArch.base(), seed=SEED_W), head
-
-
-def images_from(a_o: torch.Tensor, ids: torch.Tensor, n_ids: int, sigma: float) -> torch.Tensor:
-    mu = a_o.mean(0, keepdim=True)
-    c = torch.stack([(a_o[ids == k] - mu).mean(0) for k in range(n_ids)])
-    c = c / c.norm(dim=-1, keepdim=True)
-    g = torch.Generator().manual_seed(SEED_DATA + 99)
-    noise = torch.randn(n_ids, a_o.shape[1], generator=g) / a_o.shape[1] ** 0.5
-    img = c + sigma * noise
-    return img / img.norm(dim=-1, keepdim=True)
+    return hubert_weights(), head_weights()
 
 
 def centred_scores(a: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
     """audio x image scores as the validation epoch computes them (kwClip.py:467-471): plain dot products of unit vectors."""
     return a @ img.t()
-
-
-def correct_rank(score: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-    own = score.gather(1, ids.unsqueeze(1))
-    return (score > own).sum(1)
 
 
 def main():
@@ -109,12 +73,15 @@ def main():
     score = centred_scores(a_o, img)
     img_ids = torch.arange(args.ids)
     AB, BA, mean = oracle.mutual_retrieval(score, score.t(), ids, img_ids, [1, 5, 10])
-    print("sigma", sigma, "A->I", AB, "I->A", BA)
+    held = (torch.arange(len(ids)) % PER_ID) >= GALLERY
+    AB_h, _, _ = oracle.mutual_retrieval(score[held], score[held].t(), ids[held], img_ids, [1, 5, 10])
+    print("sigma", sigma, "A->I", AB, "I->A", BA, "held-out A->I", AB_h)
     ks = [1, 5, 10]
     np.savez_compressed(args.out, image=img.numpy(), n_ids=np.int64(args.ids), sigma=np.float64(sigma),
                         rank=correct_rank(score, ids).numpy().astype(np.int32),
                         AB=np.array([AB[f"recall@{k}"] for k in ks]), BA=np.array([BA[f"recall@{k}"] for k in ks]),
                         mean=np.array([mean[f"recall@{k}"] for k in ks]), emb_head=emb[:64].numpy(),
+                        AB_heldout=np.array([AB_h[f"recall@{k}"] for k in ks]), gallery=np.int64(GALLERY),
                         margin=(score.gather(1, ids.unsqueeze(1)).squeeze(1) - score.masked_fill(
                             torch.nn.functional.one_hot(ids, args.ids).bool(), -9.0).max(1).values).numpy().astype(np.float32))
     print("wrote", args.out, os.path.getsize(args.out), "bytes;", f"{time.time() - t0:.0f} s")

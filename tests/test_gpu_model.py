@@ -130,12 +130,11 @@ def test_large_parallel_train_step():
     loss and gradients of one step against the oracle."""
     runs = [_large_parallel_step(seed) for seed in (8, 9, 10, 11)]
     for errs in runs:
-        assert not {k: v for k, v in errs.items() if k != "weightedsum" and v > 6e-2}, errs
+        assert not {k: v for k, v in errs.items() if v > 6e-2}, errs
     # the 3 weighted-sum logits' gradient is the softmax projection w (d - <w, d>) of three nearly equal inner products
-    # <g, LN(h_n)>: its norm can be small against the bf16 noise of each term, so the relative error scatters with the
-    # data seed (0.003 ... 0.07 measured): bound the median tightly and the worst case loosely
-    ws = sorted(e["weightedsum"] for e in runs)
-    assert ws[len(ws) // 2] < 3e-2 and ws[-1] < 0.15, ws
+    # <g, LN(h_n)>; sc_wsum_bwd accumulates the layer DIFFERENCES (tests/test_gpu_kernels.py::
+    # test_weighted_sum_logit_gradient_on_a_residual_stream pins the kernel itself to 1e-4 on given states)
+    print("weighted-sum logit gradient rel-L2 over 4 data seeds:", sorted(round(e["weightedsum"], 4) for e in runs))
 
 
 def _oracle_step(oracle, sd, o_arch, head_W, ws_w, wavs, img, ids, normalize=False):
@@ -397,13 +396,17 @@ def test_reference_checkpoint_round_trip_and_validation_epoch(setup):
         ids = (torch.arange(B) + chunk * B) // per
         batch = {"wav": (torch.randn(B, 8000, generator=g) * 0.3).cuda(), "wav_len": torch.full((B,), 8000),
                  "image": torch.randn(B, 512, generator=g).cuda(), "id": ids.cuda()}
-        outs_a.append(model.validation_step(batch, chunk))
-        outs_b.append(m2.validation_step(batch, chunk))
+        # the reference's hook chain (kwClip.py:195-285): validation_step -> validation_step_end -> list for the epoch end
+        step_out = model.validation_step(batch, chunk)
+        assert set(step_out) == {"loss_feats", "log_metrics", "others"}
+        outs_a.append(model.validation_step_end(step_out))
+        outs_b.append(m2.validation_step_end(m2.validation_step(batch, chunk)))
+    assert {"val_loss", "val_p_cl_loss", "val_cl_temp"} <= set(model.logged)
     for a, b in zip(outs_a, outs_b):
-        assert torch.equal(a["audio_feat"], b["audio_feat"])
+        assert torch.equal(a["parallel_audio_feat"], b["parallel_audio_feat"])
     rec = model.validation_epoch_end(outs_a)
     ids = torch.cat([o["id"] for o in outs_a]).cpu()
-    audio = torch.cat([o["audio_feat"] for o in outs_a]).float().cpu()
+    audio = torch.cat([o["parallel_audio_feat"] for o in outs_a]).float().cpu()
     imgs = torch.cat([o["image_feat"] for o in outs_a]).float().cpu()
     pairs = {}
     for i, v in zip(ids.tolist(), imgs):
@@ -413,6 +416,139 @@ def test_reference_checkpoint_round_trip_and_validation_epoch(setup):
     ref = oracle.mutual_retrieval(score, score.t(), ids, img_ids, model.recall_at)
     for got, want in zip(rec, ref):
         assert {k: round(float(v), 4) for k, v in got.items()} == {k: round(float(v), 4) for k, v in want.items()}
+    # example.py:9-10: load_from_checkpoint(path) on a Lightning-style file (state_dict + hyper_parameters.config)
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".ckpt") as f:
+        torch.save({"state_dict": ref_ckpt, "hyper_parameters": {"config": dict(cfg)}}, f.name)
+        m3 = KWClip_GeneralTransformer.load_from_checkpoint(f.name, device="cuda:0").eval()
+    out3 = m3.validation_step_end(m3.validation_step(batch, 0))
+    assert torch.equal(out3["parallel_audio_feat"], outs_a[-1]["parallel_audio_feat"])
+
+
+def test_second_forward_before_backward_fails_loudly_and_outputs_survive(setup):
+    """The encoder's hidden states live in a resident workspace per (B, L) geometry: a backward that arrives after another
+    forward re-used it must raise (not differentiate against the wrong states), and hidden states handed out to the caller are
+    fresh tensors that a later forward does not change."""
+    model, sd, o_arch, head_W, _ = setup
+    g = torch.Generator().manual_seed(3)
+    mk = lambda: {"wav": (torch.randn(3, 8000, generator=g) * 0.5).cuda(), "wav_len": torch.tensor([8000, 6000, 7000]),
+                  "image": torch.randn(3, 512, generator=g).cuda(), "id": torch.arange(3).cuda()}
+    b1, b2 = mk(), mk()
+    model.zero_grad(set_to_none=True)
+    loss1 = model.compute_loss(model(b1)[0])["loss"]
+    model(b2)                                               # same geometry: overwrites the plan's hidden states
+    with pytest.raises(RuntimeError, match="another forward"):
+        loss1.backward()
+    with torch.no_grad():
+        _, _, hs1 = model.audio_encoder(b1["wav"], b1["wav_len"], return_hidden_states=True)
+        keep = [h.clone() for h in hs1]
+        model.audio_encoder(b2["wav"], b2["wav_len"])
+    assert all(torch.equal(a, b) for a, b in zip(hs1, keep))
+
+
+def test_lightning_shaped_optimizer_hooks_match_the_trainer():
+    """configure_optimizers (kwClip.py:646-674): a torch.optim.Optimizer + a step-interval LambdaLR.  Driving them by hand
+    (zero_grad, backward, clip_grad_norm_, step, scheduler.step - what Lightning does) must give the ContrastiveTrainer's
+    parameters after the same steps."""
+    import dataclasses
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    arch = dataclasses.replace(ARCHS["hubert"], layers=2)
+    sd = random_hubert_state_dict(arch, seed=3)
+    g = torch.Generator().manual_seed(13)
+    B, L = 6, 9000
+    batch = {"wav": torch.randn(B, L, generator=g).cuda(), "wav_len": torch.tensor([9000, 7000, 9000, 5000, 8000, 9000]),
+             "image": torch.randn(B, 512, generator=g).cuda(), "id": torch.tensor([0, 1, 1, 2, 3, 4]).cuda()}
+    finals = []
+    for how in ("trainer", "hooks"):
+        torch.manual_seed(3)
+        cfg = base_parallel_config()
+        cfg.audio_encoder.max_audio_len = -1
+        cfg.audio_encoder.scheduler.warmup = 2                      # the schedule must matter within 3 steps
+        model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
+        if how == "trainer":
+            trainer = ContrastiveTrainer(model)
+            for _ in range(3):
+                trainer.step(batch)
+            torch.cuda.synchronize()
+            finals.append(trainer.opt.flat_p.clone())
+        else:
+            (opt,), (sch,) = model.configure_optimizers()
+            assert isinstance(opt, torch.optim.Optimizer) and sch["interval"] == "step"
+            for _ in range(3):
+                opt.zero_grad()
+                out = model.training_step_end(model.training_step(batch))
+                out["loss"].backward()
+                torch.nn.utils.clip_grad_norm_(model.getTrainableParams(), float(cfg.trainer.gradient_clip_val))
+                opt.step()
+                sch["scheduler"].step()
+            torch.cuda.synchronize()
+            finals.append(opt.flat.flat_p.clone())
+    assert float((finals[0] - finals[1]).abs().max()) < 2e-6 * float(finals[0].abs().max()), float((finals[0] - finals[1]).abs().max())
+
+
+YAML_HYBRID_BASE = """
+model_settings:
+  cascaded_objective_weight: 1.0
+  parallel_objective_weight: 1.0
+  parallel_branch:
+    transformer_args: {type: TransformerEncoder, n_layers: 1, d_model: 768, nhead: 8, dim_feedforward: 3072, dropout: 0.1,
+                       activation: gelu, layer_norm_eps: 1.0e-5, batch_first: true, norm_first: false}
+  cascaded_branch:
+    type: HybridBranch_dynamic
+    vq: {activation: gelu, type: SimpleVectorQuantizer, args: {temp: fixed=0.1, time_first: true, use_gumbel: false, hard: true}}
+    downsampling:
+      type: cif
+      cif: {quantity_loss_weight: 0.25, using_gt_len: false, cif_output_dim: 768, encoder_embed_dim: 768, produce_weight_type: conv,
+            cif_threshold: 1.0, conv_cif_layer_num: 1, conv_cif_width: 3, conv_cif_dropout: 0.1, apply_scaling: true,
+            scaling_step: 5000, apply_tail_handling: true, tail_handling_firing_threshold: 0.5, add_cif_ctxt_layers: false}
+    keyword: {detokenized_K_neighbors: 5, retrieve_method: cosine, batchnorms: {type: eachKw, std_scale: 1.0, learnable: true, parallel: true}}
+    transformer_args: {type: MultiheadAttentionAndNorm, n_layers: 1, d_model: 768, nhead: 8, dim_feedforward: 3072, dropout: 0.1,
+                       activation: gelu, layer_norm_eps: 1.0e-5, batch_first: true, norm_first: false}
+cl_loss: {type: MaskedContrastiveLoss, args: {temperature: 0.07, temperature_trainable: true, margin: 0.0, dcl: false, a2b: true, b2a: true}}
+retrieval: {audio_feat_src: parallel, recall_at: [1, 5, 10]}
+clip: {name: ViT-B/32, image_encoder_trainable: false, text_encoder_trainable: false,
+       reduce_subword_embbedding: ./avssl/data/flickr_stat/text_clip_vocab_usage_byfreq.npy}
+audio_encoder:
+  type: FairseqHubert
+  name: hubert_base
+  downsampling_rate: 320
+  pretrained: true
+  trainable: false
+  feat_select_idx: weighted_sum
+  layer_drop: 0.0
+  max_audio_len: 102400
+  optim: {name: Adam, args: {lr: 1.e-4, weight_decay: 1.e-6}}
+  scheduler: {name: linear_warmup_decay, warmup: 5000, max_step: 50000, final_lr: 1.e-8}
+trainer: {max_steps: 50000, gradient_clip_val: 4, accumulate_grad_batches: 1, precision: 16, strategy: dp}
+"""
+
+
+def test_model_from_reference_shaped_yaml_hybrid_plus_base():
+    """A recipe written with the reference's yaml keys (the Hybrid+ base geometry: d_model 768 with 8 heads = head_dim 96, the
+    shape the attention block pads to 128) builds the model and trains a step; the reduced-vocabulary table path that does not
+    exist here falls back to the synthetic 8112-sub-word table."""
+    import dataclasses
+    from speechclip_plus_amd import KWClip_GeneralTransformer, load_config, random_hubert_state_dict, set_dropout
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    cfg = load_config(YAML_HYBRID_BASE)
+    assert cfg.clip.embed_dim == 512 and cfg.clip.reduce_subword_embbedding.numel() == 8112
+    cfg.clip.layers = 2
+    arch = dataclasses.replace(ARCHS["hubert_base"], layers=2)
+    torch.manual_seed(5)
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=random_hubert_state_dict(arch, seed=5), hubert_arch=arch)
+    mha = model.cascaded_branch.self_att.multihead_attn_layer
+    assert mha.embed_dim // mha.num_heads == 96
+    set_dropout(model.train(), False)
+    g = torch.Generator().manual_seed(2)
+    B = 4
+    batch = {"wav": (torch.randn(B, 30000, generator=g) * 0.5).cuda(), "wav_len": torch.tensor([30000, 21000, 30000, 12000]),
+             "image": torch.randn(B, 512, generator=g).cuda(), "id": torch.tensor([0, 1, 1, 2]).cuda()}
+    trainer = ContrastiveTrainer(model)
+    l1, l2 = float(trainer.step(batch)), float(trainer.step(batch))
+    assert l1 == l1 and l2 == l2 and l2 < l1 + 0.1
 
 
 def test_unfrozen_layer_prelN_large_with_frozen_layer_above():

@@ -1,6 +1,7 @@
 """CPU-side checks that need no GPU: the C-ABI library loads and exports every declared symbol, host-side
 length / layout logic agrees with the oracle, metric + schedule helpers, loud failure without a device."""
 import ctypes
+import sys
 import os
 import re
 
@@ -120,3 +121,43 @@ def test_audio_transform_like_the_reference_test():
     assert out_2.shape == (100,)
     short = torch.randn(300)
     assert torch.equal(random_crop_max_length(short, 1000), short)                    # shorter than the cap: returned as is
+
+
+def test_recall_eval_generators_draw_the_oracles_streams():
+    """tools/recall_eval.py (used by bench.py without the oracle) must generate exactly the weights the fixture was made with."""
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import recall_eval
+    a = oracle.init_parallel_branch_weights(seed=recall_eval.SEED_HEAD)
+    a["cls"] = a["cls"] * 0.1
+    b = recall_eval.head_weights()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    ha = oracle.init_hubert_weights(oracle.HubertArch.base(), seed=recall_eval.SEED_W)
+    hb = recall_eval.hubert_weights()
+    assert set(ha) == set(hb) and all(torch.equal(ha[k], hb[k]) for k in ha)
+    w0 = recall_eval.utterance(3, 1)
+    assert 20000 <= len(w0) <= 40000 and torch.equal(w0, recall_eval.utterance(3, 1))
+
+
+def test_reference_yaml_recipes_parse_unchanged():
+    """Every yaml under the reference's config/ (present in the build container only) loads through load_config with the keys
+    the model reads; a recipe-shaped yaml text of our own covers the same code on any box."""
+    import glob
+    from speechclip_plus_amd import load_config
+    text = """
+model_settings: {cascaded_objective_weight: 0.0, parallel_objective_weight: 1.0,
+                 parallel_branch: {transformer_type: TransformerEncoder, need_projection: true,
+                                   transformer_args: {n_layers: 1, d_model: 768, nhead: 8, dim_feedforward: 3072, dropout: 0.1}}}
+cl_loss: {type: MaskedContrastiveLoss, args: {temperature: 0.07, temperature_trainable: false}}
+clip: {name: ViT-L/14, reduce_subword_embbedding: ./avssl/data/coco_stat/none.npy}
+audio_encoder: {type: FairseqHubert, name: hubert_large_ll60k, trainable: false, feat_select_idx: weighted_sum,
+                optim: {name: Adam, args: {lr: 1.e-4, weight_decay: 1.e-6}}}
+"""
+    cfg = load_config(text)
+    assert cfg.clip.embed_dim == 768 and cfg.clip.reduce_subword_embbedding.numel() == 19787
+    assert cfg.retrieval.recall_at == [1, 5, 10] and cfg.audio_encoder.optim.args.lr == 1e-4
+    files = glob.glob("/root/reference/config/*/*/*.yaml") + glob.glob("/root/reference/config/*/*/*/*.yaml")
+    for f in files:
+        c = load_config(f, reference_root="/root/reference")
+        assert c.audio_encoder.type == "FairseqHubert" and c.cl_loss.type == "MaskedContrastiveLoss"
+        assert c.clip.embed_dim in (512, 768)
