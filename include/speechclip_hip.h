@@ -29,6 +29,9 @@ typedef uint16_t sc_bf16;
 
 const char* sc_last_error(void);
 int sc_abi_version(void);
+/* tuning switches for same-process A/B measurements (tools/); results never depend on them.  key 0: the 256-row GEMM leaves a
+ * tile's output stores in flight across the next tile's first operand wait (default 1). */
+int sc_set_option(int32_t key, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 MFMA GEMM with fused epilogue:  C = epi(A . W^T)      (every Linear / Conv1d on the path)

@@ -37,6 +37,7 @@ class GemmArgs(ctypes.Structure):
 # library exports every symbol the header declares.
 SIGNATURES = {
     "sc_abi_version": [],
+    "sc_set_option": [c_int, c_int],
     "sc_gemm_bf16": [ctypes.POINTER(GemmArgs), c_void_p],
     "sc_attn_fwd_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
                          c_float, ctypes.c_uint32, c_void_p],

@@ -149,19 +149,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                 psum += pv[r];
             }
             l_run += psum;
-            if (DROP) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const uint32_t kidx = (uint32_t)(kbase + (r & 3) + 8 * (r >> 2) + 4 * half);
-                    const uint32_t hsh = sc_hash32(((drop_row + kidx) >> 1) ^ drop_seed);
-                    if ((hsh & 0xffffu) < drop_thr) pv[r] = 0.f;
-                    if ((hsh >> 16) < drop_thr) pv[r + 1] = 0.f;
-                }
-            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[s2][j] = (__bf16)pv[8 * s2 + j];
+            if (DROP) {
+                // the keep test runs on both 16-bit halves of a hash word at once and lands as an AND mask on the packed bf16 pair
+                // (same mask bits as sc_keep8: keep iff the element's 16-bit field >= thr):  x = sat(h - (thr - 1)) is 0 exactly for
+                // the dropped fields; min(x, 1) * 0xffff widens that to the lane mask.  Four packed integer ops per PAIR and no
+                // compare -> VCC -> select chain (that chain, not the hash, was two thirds of the dropout cost).
+                // (inline asm: written with vector builtins the compiler folds the sequence back into v_cmp + v_cndmask)
+                const uint32_t t1 = drop_thr - 1u;
+                const uint32_t thr2 = t1 | (t1 << 16), one2 = 0x00010001u;
+                const uint32_t pair0 = ((drop_row + (uint32_t)(kbase + 4 * half)) >> 1);      // drop_row, kbase even
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    uint4 w = __builtin_bit_cast(uint4, pf[s2]);
+                    uint32_t* wp = (uint32_t*)&w;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = 8 * s2 + 2 * q;                                         // elements r, r + 1
+                        const uint32_t hsh = sc_hash32((pair0 + (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2))) ^ drop_seed);
+                        uint32_t x, m;
+                        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(x) : "v"(hsh), "s"(thr2));
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(x), "s"(one2));
+                        asm("v_pk_sub_u16 %0, 0, %1" : "=v"(m) : "v"(m));                      // 0 - {0, 1} = {0, 0xffff}
+                        wp[q] &= m;
+                    }
+                    pf[s2] = __builtin_bit_cast(bf16x8, w);
+                }
+            }
         };
         auto pv_block = [&](int kb, const bf16x8 (&pf)[2]) {
 #pragma unroll

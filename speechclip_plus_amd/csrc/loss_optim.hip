@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
 // barrier -> ticket (returning atomic) ; last arriver: agent-scope acquire fence -> barrier -> plain loads.
 // inv_temp comes from DEVICE memory (a trainable temperature never forces a host read).
 constexpr int LT = 68;       // LDS row pitch of the [k][64 rows] operand images (2-way conflicts on the b32 stores only: free)
+constexpr int KTL = 64;      // K-tile of the logits product
 
 __global__ __launch_bounds__(256) void infonce_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int Bg, int E,
                                                           const int64_t* __restrict__ ids, const float* __restrict__ inv_temp_p,
@@ -88,8 +89,8 @@ __global__ __launch_bounds__(256) void infonce_fwd_kernel(const float* __restric
                                                           float* __restrict__ part, float* __restrict__ diag,
                                                           float* __restrict__ lse_row, float* __restrict__ lse_col,
                                                           float* __restrict__ loss, unsigned int* __restrict__ ticket) {
-    __shared__ float As[16][LT];
-    __shared__ float Bs[16][LT];
+    __shared__ float As[KTL][LT];
+    __shared__ float Bs[KTL][LT];
     __shared__ float Ls[64][65];
     __shared__ int last_flag;
     __shared__ float red[4];
@@ -102,19 +103,34 @@ __global__ __launch_bounds__(256) void infonce_fwd_kernel(const float* __restric
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // K-tiles of 64: a workgroup's K loop is a chain of dependent global-load round trips (one tile = the whole problem at
+    // Bg = 64), so each trip carries 4 x 16 bytes per thread and operand, and the next tile's loads fly under this tile's MFMAs
     const int lr = tid >> 2, kq = (tid & 3) * 4;
-    for (int k0 = 0; k0 < E; k0 += 16) {
-        float4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-        if (k0 + kq < E) {                         // E % 4 == 0 (checked on the host)
-            if (i0 + lr < Bg) a = *(const float4*)(A + (int64_t)(i0 + lr) * E + k0 + kq);
-            if (j0 + lr < Bg) b = *(const float4*)(Bm + (int64_t)(j0 + lr) * E + k0 + kq);
+    float4 ra[4], rb[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = k0 + c * 16 + kq;
+            ra[c] = rb[c] = float4{0.f, 0.f, 0.f, 0.f};
+            if (k < E) {                           // E % 4 == 0 (checked on the host)
+                if (i0 + lr < Bg) ra[c] = *(const float4*)(A + (int64_t)(i0 + lr) * E + k);
+                if (j0 + lr < Bg) rb[c] = *(const float4*)(Bm + (int64_t)(j0 + lr) * E + k);
+            }
         }
-        __syncthreads();
-        As[kq + 0][lr] = a.x; As[kq + 1][lr] = a.y; As[kq + 2][lr] = a.z; As[kq + 3][lr] = a.w;
-        Bs[kq + 0][lr] = b.x; Bs[kq + 1][lr] = b.y; Bs[kq + 2][lr] = b.z; Bs[kq + 3][lr] = b.w;
+    };
+    load_tile(0);
+    for (int k0 = 0; k0 < E; k0 += KTL) {
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 16; kk += 2)
+        for (int c = 0; c < 4; ++c) {
+            const int kk = c * 16 + kq;
+            As[kk + 0][lr] = ra[c].x; As[kk + 1][lr] = ra[c].y; As[kk + 2][lr] = ra[c].z; As[kk + 3][lr] = ra[c].w;
+            Bs[kk + 0][lr] = rb[c].x; Bs[kk + 1][lr] = rb[c].y; Bs[kk + 2][lr] = rb[c].z; Bs[kk + 3][lr] = rb[c].w;
+        }
+        __syncthreads();
+        if (k0 + KTL < E) load_tile(k0 + KTL);
+#pragma unroll
+        for (int kk = 0; kk < KTL; kk += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + half][wm * 32 + l31], Bs[kk + half][wn * 32 + l31], acc, 0, 0, 0);
     }
     // scaled tile -> LDS (+ global)

@@ -39,4 +39,16 @@ extern "C" uint32_t sc_hash32(uint32_t x) {
 }
 
 extern "C" const char* sc_last_error(void) { return g_err; }
-extern "C" int sc_abi_version(void) { return 1; }
+extern "C" int sc_abi_version(void) { return 2; }
+
+// tuning switches for same-process A/B measurements (tools/): not part of the computation's contract, results never depend on them
+static int g_options[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+int sc_option(int key) { return (key >= 0 && key < 8) ? g_options[key] : 0; }
+extern "C" int sc_set_option(int32_t key, int32_t value) {
+    if (key < 0 || key >= 8) {
+        sc_set_error("sc_set_option: key %d out of range", key);
+        return -1;
+    }
+    g_options[key] = value;
+    return 0;
+}

@@ -24,3 +24,15 @@ for _ in range(7):
     ts.append(e0.elapsed_time(e1) / 5)
 ms = sorted(ts)[len(ts) // 2]
 print(f"attn_fwd {ms*1e3:.1f} us  alg {4.0*B*T*T*D/ms/1e9:.1f} TFLOP/s")
+# train-mode variant: probability dropout p = 0.1 inside the kernel
+ts = []
+for _ in range(7):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ops.attn_fwd(qk, vt, valid, out, B, R, H, D, 0.125, drop_p=0.1, drop_seed=1234)
+    e1.record()
+    torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) / 5)
+ms = sorted(ts)[len(ts) // 2]
+print(f"attn_fwd (dropout 0.1) {ms*1e3:.1f} us  alg {4.0*B*T*T*D/ms/1e9:.1f} TFLOP/s")

@@ -17,6 +17,15 @@ shapes = [  # name, M, N, K, lda(None = K), act, residual
     ("conv4", B * 4 * R, C, 3 * C, 2 * C, 1, False), ("conv6", B * R, C, 2 * C, 2 * C, 1, False),
 ]
 tiles = [int(t) for t in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "2"])]
+# "opt0=a,b": A/B of tuning switch 0 (sc_set_option) instead of tile families, e.g. `bench_gemm.py 0 opt0=1,0`
+optab = None
+for a in sys.argv[2:]:
+    if a.startswith("opt"):
+        key, vals = a[3:].split("=")
+        optab = (int(key), [int(v) for v in vals.split(",")])
+from speechclip_plus_amd._lib import lib as _lib
+if optab:
+    tiles = optab[1]
 rounds = 5
 out = {}
 for name, m, n, k, lda, act, res in shapes:
@@ -31,8 +40,10 @@ for name, m, n, k, lda, act, res in shapes:
         for t in tiles:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+            if optab:
+                _lib().sc_set_option(optab[0], t)
             for _ in range(3):
-                ops.gemm_raw(A, lda, W, k, Cm, n, m, n, k, bias=bias, residual=Rm, ldr=n, act=act, tile=t)
+                ops.gemm_raw(A, lda, W, k, Cm, n, m, n, k, bias=bias, residual=Rm, ldr=n, act=act, tile=0 if optab else t)
             e1.record()
             torch.cuda.synchronize()
             if r > 0:

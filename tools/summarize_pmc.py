@@ -9,7 +9,8 @@ fetch_dir, write_dir, stats_csv, out = sys.argv[1:5]
 
 def per_kernel(d, cname):
     vals = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])):
+    files = glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv")
+    for r in csv.DictReader(open(files[0])):
         if r["Counter_Name"] == cname:
             vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return vals
@@ -23,6 +24,11 @@ for k in f:
     fa, wa = sum(f[k]) / len(f[k]), sum(w[k]) / len(w[k])
     res[k] = {"launches_sampled": len(f[k]), "fetch_size_kib_raw": round(fa, 1), "write_size_kib": round(wa, 1),
               "hbm_bytes_per_launch": round((2.0 * fa + wa) * 1024.0)}
+# provenance: bench.py reports these counters only while the kernel source they were measured on is the tree's
+import hashlib, os
+_csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speechclip_plus_amd", "csrc")
+res["_meta"] = {"kernel_source_sha256": hashlib.sha256(open(os.path.join(_csrc, "gemm256_bf16.hip"), "rb").read()).hexdigest(),
+                "command": "python3 bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-recall"}
 json.dump(res, open(out + "_traffic.json", "w"), indent=1, sort_keys=True)
 rows = list(csv.DictReader(open(stats_csv)))
 with open(out + "_kernel_stats.csv", "w") as fo:
