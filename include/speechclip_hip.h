@@ -359,6 +359,29 @@ int sc_infonce_grad(const float* logits, const int64_t* ids, const float* lse_ro
                     int32_t a2b, int32_t b2a, float* G, float* dlogit_dot /*[Bg]*/, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused driver: ONE call enqueues a whole frozen HuBERT encoder layer (fairseq TransformerSentenceEncoderLayer as invoked at
+ * avssl/module/speech_encoder_plus.py:49-53) on the caller's stream - QKV GEMM (V^T epilogue) -> attention -> out_proj (+bias,
+ * dropout, +residual) -> LayerNorm -> FC1 (+bias, GELU) -> FC2 (+bias, dropout, +residual) -> LayerNorm; pre_ln = 1: the
+ * HuBERT-large order (LayerNorms in front of the two halves).  x / out: [B*R, D] bf16 in the padded row layout, head_dim 64.
+ * Scratch (caller-owned, sc_workspace_bytes(SC_WS_HUBERT_LAYER, B*R, D, F) bytes in total): qk [B*R, 2D], vt [B, H, 64, R],
+ * ctx / pre / x1 [B*R, D], ffn [B*R, F], all bf16.  p_attn / p_res = 0 in inference; seeds as in sc_gemm_args / sc_attn_fwd_bf16.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const sc_bf16* x; sc_bf16* out;
+    const int32_t* valid_len;                 /* [B] keys per utterance */
+    int32_t B, R, T, D, F, H, pre_ln, reserved;
+    const sc_bf16 *qkv_w, *o_w, *fc1_w, *fc2_w;     /* [3D, D], [D, D], [F, D], [D, F] */
+    const float *qkv_b, *o_b, *fc1_b, *fc2_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float eps, p_attn, p_res;
+    uint32_t seed_attn, seed_o, seed_fc2;
+    sc_bf16 *qk, *vt, *ctx, *pre, *x1, *ffn;        /* scratch */
+} sc_hubert_layer_args;
+int sc_hubert_layer_fwd(const sc_hubert_layer_args* args, void* stream);
+#define SC_WS_INFONCE 0       /* a = Bg */
+#define SC_WS_HUBERT_LAYER 1  /* a = B*R rows, b = D, c = F */
+int64_t sc_workspace_bytes(int32_t what, int64_t a, int64_t b, int64_t c);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimiser step on a flat fp32 parameter buffer: torch.optim.Adam semantics (L2 weight decay added to
  * the gradient), gradient clipping by global norm folded in (avssl/model/kwClip.py:646-674 +
  * trainer.gradient_clip_val).  sumsq: partial sums of squares for the global norm.

@@ -33,11 +33,26 @@ class GemmArgs(ctypes.Structure):
     ]
 
 
+class HubertLayerArgs(ctypes.Structure):
+    """Mirror of ``sc_hubert_layer_args`` (include/speechclip_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("out", c_void_p), ("valid_len", c_void_p),
+        ("B", c_int), ("R", c_int), ("T", c_int), ("D", c_int), ("F", c_int), ("H", c_int), ("pre_ln", c_int), ("reserved", c_int),
+        ("qkv_w", c_void_p), ("o_w", c_void_p), ("fc1_w", c_void_p), ("fc2_w", c_void_p),
+        ("qkv_b", c_void_p), ("o_b", c_void_p), ("fc1_b", c_void_p), ("fc2_b", c_void_p),
+        ("ln1_g", c_void_p), ("ln1_b", c_void_p), ("ln2_g", c_void_p), ("ln2_b", c_void_p),
+        ("eps", ctypes.c_float), ("p_attn", ctypes.c_float), ("p_res", ctypes.c_float),
+        ("seed_attn", ctypes.c_uint32), ("seed_o", ctypes.c_uint32), ("seed_fc2", ctypes.c_uint32),
+        ("qk", c_void_p), ("vt", c_void_p), ("ctx", c_void_p), ("pre", c_void_p), ("x1", c_void_p), ("ffn", c_void_p),
+    ]
+
+
 # name -> argtypes (all return int except sc_last_error); kept in one table so tests can check that the
 # library exports every symbol the header declares.
 SIGNATURES = {
     "sc_abi_version": [],
     "sc_set_option": [c_int, c_int],
+    "sc_hubert_layer_fwd": [ctypes.POINTER(HubertLayerArgs), c_void_p],
     "sc_gemm_bf16": [ctypes.POINTER(GemmArgs), c_void_p],
     "sc_attn_fwd_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
                          c_float, ctypes.c_uint32, c_void_p],
@@ -119,6 +134,8 @@ def lib() -> ctypes.CDLL:
             fn.restype = ctypes.c_int
         cdll.sc_last_error.argtypes = []
         cdll.sc_last_error.restype = ctypes.c_char_p
+        cdll.sc_workspace_bytes.argtypes = [c_int, c_i64, c_i64, c_i64]
+        cdll.sc_workspace_bytes.restype = ctypes.c_int64
         cdll.sc_infonce_workspace_floats.argtypes = [c_int]
         cdll.sc_infonce_workspace_floats.restype = ctypes.c_int64
         cdll.sc_hash32.argtypes = [ctypes.c_uint32]

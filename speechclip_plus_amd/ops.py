@@ -8,7 +8,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import GemmArgs, check, lib
+from ._lib import GemmArgs, HubertLayerArgs, check, lib
 
 
 def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
@@ -113,6 +113,22 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     rows = (M if alg_rows is None else alg_rows) * nb1 * nb2
     _timer.add("gemm_bf16_" + gemm_tile_name(M, N, K, n_split, nb1 * nb2, tile), ev0, ev1, 2.0 * rows * N * K,
                tag=f"M{M} N{N} K{K} lda{lda} act{act} res{int(residual is not None)} z{nb1 * nb2}")
+
+
+def hubert_layer_fwd(x: torch.Tensor, out: torch.Tensor, valid_len: torch.Tensor, w: dict, i: int, pl, B: int, R: int, T: int, D: int,
+                     F_: int, H: int, pre_ln: bool, p_attn: float = 0.0, p_res: float = 0.0, seeds=(0, 0, 0)) -> None:
+    """One frozen HuBERT encoder layer in ONE C-ABI call (sc_hubert_layer_fwd: QKV -> attention -> out_proj -> LN -> FC1 -> FC2 ->
+    LN on the caller's stream).  ``w``: the encoder's weight dict (keys l{i}_*), ``pl``: its plan (scratch buffers)."""
+    a = HubertLayerArgs()
+    a.x, a.out, a.valid_len = _p(x), _p(out), _p(valid_len)
+    a.B, a.R, a.T, a.D, a.F, a.H, a.pre_ln = B, R, T, D, F_, H, int(pre_ln)
+    a.qkv_w, a.o_w, a.fc1_w, a.fc2_w = _p(w[f"l{i}_qkv_w"]), _p(w[f"l{i}_o_w"]), _p(w[f"l{i}_fc1_w"]), _p(w[f"l{i}_fc2_w"])
+    a.qkv_b, a.o_b, a.fc1_b, a.fc2_b = _p(w[f"l{i}_qkv_b"]), _p(w[f"l{i}_o_b"]), _p(w[f"l{i}_fc1_b"]), _p(w[f"l{i}_fc2_b"])
+    a.ln1_g, a.ln1_b, a.ln2_g, a.ln2_b = _p(w[f"l{i}_ln1_g"]), _p(w[f"l{i}_ln1_b"]), _p(w[f"l{i}_ln2_g"]), _p(w[f"l{i}_ln2_b"])
+    a.eps, a.p_attn, a.p_res = 1e-5, float(p_attn), float(p_res)
+    a.seed_attn, a.seed_o, a.seed_fc2 = (int(s) & 0xffffffff for s in seeds)
+    a.qk, a.vt, a.ctx, a.pre, a.x1, a.ffn = _p(pl.qk), _p(pl.vt), _p(pl.ctx), _p(pl.pre), _p(pl.x1), _p(pl.ffn)
+    check(lib().sc_hubert_layer_fwd(ctypes.byref(a), _stream()), "sc_hubert_layer_fwd")
 
 
 def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,

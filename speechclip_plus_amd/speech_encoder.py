@@ -435,6 +435,10 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                     tl.layer_forward(i, x, pl.hidden[i + 1], pl, save,
                                      drops=(p_res, p_att, sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)) if seeds else None)
                     continue
+                if ops._timer is None:          # one C-ABI call per frozen layer (sc_hubert_layer_fwd); the per-op path below is
+                    ops.hubert_layer_fwd(x, pl.hidden[i + 1], pl.valid, w, i, pl, B, R, T, D, F, H, False, p_att, p_res,
+                                         (sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)))   # kept for bench.py's per-kernel timer
+                    continue
                 qkv_attn(x, i)
                 # train mode: dropout1 / dropout3 of fairseq's TransformerSentenceEncoderLayer in the GEMM epilogues (before the
                 # residual add), attention dropout inside the attention kernel
@@ -459,6 +463,10 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 if tl is not None and (i in tl.ids or i in tl.pass_ids):
                     tl.layer_forward(i, x, pl.hidden[i + 1], pl, save,
                                      drops=(p_res, p_att, sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)) if seeds else None)
+                    continue
+                if ops._timer is None:
+                    ops.hubert_layer_fwd(x, pl.hidden[i + 1], pl.valid, w, i, pl, B, R, T, D, F, H, True, p_att, p_res,
+                                         (sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)))
                     continue
                 ops.layernorm_bf16(x, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
                 qkv_attn(pl.x1, i)
