@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape GEMM timing table to stderr")
     ap.add_argument("--unfreeze", type=int, default=0, help="train the top K HuBERT transformer layers too (audio_encoder.trainable "
                     "+ unfreeze_layers; NOT the headline configuration, which freezes HuBERT like every shipped recipe)")
+    ap.add_argument("--trainable", action="store_true", help="audio_encoder.trainable: true - the WHOLE HuBERT trains (conv extractor, "
+                    "projection, pos_conv, every layer: fwd + bwd + Adam); NOT the headline configuration")
     ap.add_argument("--model", choices=["base", "large", "cascaded_plus", "hybrid_plus_large"], default="base",
                     help="base = BASELINE configs[1] (headline); large = Parallel large; cascaded_plus = configs[2]; "
                          "hybrid_plus_large = configs[4] recipe on one GPU")
@@ -102,6 +104,8 @@ def main():
         nl = 24 if large else 12
         cfg.audio_encoder.trainable = True
         cfg.audio_encoder.unfreeze_layers = list(range(nl - args.unfreeze, nl))
+    if args.trainable:
+        cfg.audio_encoder.trainable = True
     model = KWClip_GeneralTransformer(cfg, device=str(dev), hubert_state_dict=sd)
     model.train()
     if args.no_dropout:
@@ -205,6 +209,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"[top {args.unfreeze} HuBERT layers unfrozen: fwd + bwd + Adam] " if args.unfreeze else "") +
+                                   ("[whole HuBERT trainable: fwd + bwd + Adam] " if args.trainable else "") +
                                    {"base": "Parallel SpeechCLIP base train step (HuBERT-base frozen fwd + weighted sum + CLS "
                                             "attention-pool head fwd/bwd + InfoNCE fwd/bwd + Adam)",
                                     "large": "Parallel SpeechCLIP large train step (HuBERT-large frozen fwd + normalised weighted sum + "

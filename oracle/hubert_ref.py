@@ -45,6 +45,8 @@ class HubertArch:
     pos_conv_groups: int = 16
     normalize_wav: bool = False          # fairseq task cfg.normalize (False base, True large)
     downsample_rate: int = 320
+    feature_grad_mult: float = 1.0       # fairseq HubertConfig.feature_grad_mult (0.1 in hubert_base_librispeech.yaml); only acts
+                                         # on the backward of a TRAINABLE encoder
 
     @staticmethod
     def base() -> "HubertArch":
@@ -210,6 +212,9 @@ def hubert_forward(W, arch: HubertArch, padded_wav: torch.Tensor, wav_padding_ma
     Returns layer_results = [encoder input, out_1 .. out_NL], each (B, T, D)."""
     conv_outs = [] if debug is not None else None
     feats = conv_feature_extractor(W, arch, padded_wav, conv_outs)          # :75
+    fgm = getattr(arch, "feature_grad_mult", 1.0)
+    if fgm != 1.0 and feats.requires_grad:                                   # fairseq HubertModel.forward: GradMultiply.apply(features,
+        feats = feats * fgm + feats.detach() * (1.0 - fgm)                   # feature_grad_mult): identity forward, scaled backward
     feats = feats.transpose(1, 2)                                            # :77
     feats = F.layer_norm(feats, (arch.conv_dim,), W["layer_norm.weight"], W["layer_norm.bias"], 1e-5)  # :78
     T = feats.shape[1]

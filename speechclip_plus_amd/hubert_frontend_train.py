@@ -1,0 +1,278 @@
+"""Trainable HuBERT front end (scope row f2, the part ``audio_encoder.trainable: true`` adds to hubert_train.TrainableLayers):
+conv feature extractor, feature LayerNorm, post_extract_proj, the positional conv block and the encoder LayerNorm
+(avssl/module/speech_encoder_plus.py:556-562: with ``trainable`` and no reinit / unfreeze list EVERY encoder parameter trains;
+the arithmetic is fairseq's ConvFeatureExtractionModel / HubertModel / TransformerEncoder, :29-40, :75-87).
+
+Forward (train mode) keeps what the backward needs; backward is a manual chain on the library's kernels, entered from
+TrainableLayers.backward with the gradient of ``hidden[0]``:
+
+    encoder LayerNorm'  ->  pos_conv: GELU', grouped Toeplitz GEMM with the flipped kernel (input gradient, + the residual path in
+    the epilogue), per-group weight gradient over the halo-padded slab  ->  padded-frame mask  ->  dropout_input mask
+    ->  post_extract_proj dgrad / wgrad  ->  feature LayerNorm'  ->  x feature_grad_mult (fairseq GradMultiply)
+    ->  conv layers 6 .. 1: GELU' (large: + LayerNorm'), weight gradient = dy^T . (strided im2col VIEW of the layer input, no copy
+        of the windows), input gradient = dy . W followed by the overlap-add of the k = 3 / stride 2 windows (k = 2 windows do
+        not overlap: a reshape)
+    ->  conv layer 0 (C_in = 1, k = 10) with its GroupNorm (base) / LayerNorm (large): the one piece left to torch autograd
+        (``F.conv1d`` + ``F.group_norm`` / ``F.layer_norm`` + GELU on the fp32 waveform; 1 input channel, 0.3 % of the conv flops).
+
+pos_conv is weight-normalised in fairseq (``weight_g``, ``weight_v``, norm over dims 0, 1): those two tensors are the
+parameters; the folded weight and the chain rule back to them are a few small torch ops on 4.7 M elements.
+No shipped recipe trains HuBERT; parity: tests/test_gpu_model.py::test_fully_trainable_hubert_gradients_vs_oracle.
+"""
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+
+def _key(name: str) -> str:
+    return name.replace(".", "_")
+
+
+class TrainableFrontend(nn.Module):
+    def __init__(self, arch, sd: Dict[str, torch.Tensor], device):
+        super().__init__()
+        self.arch = arch
+        a = arch
+        names = []
+        for i in range(len(a.conv_kernels)):
+            names.append(f"feature_extractor.conv_layers.{i}.0.weight")
+            if a.conv_bias:
+                names.append(f"feature_extractor.conv_layers.{i}.0.bias")
+            if a.extractor_mode == "default" and i == 0:
+                names += [f"feature_extractor.conv_layers.{i}.2.weight", f"feature_extractor.conv_layers.{i}.2.bias"]
+            if a.extractor_mode == "layer_norm":
+                names += [f"feature_extractor.conv_layers.{i}.2.1.weight", f"feature_extractor.conv_layers.{i}.2.1.bias"]
+        names += ["layer_norm.weight", "layer_norm.bias", "post_extract_proj.weight", "post_extract_proj.bias",
+                  "encoder.pos_conv.0.bias", "encoder.layer_norm.weight", "encoder.layer_norm.bias"]
+        self.p = nn.ParameterDict()
+        self.fairseq_names = {}
+        for n in names:
+            self.p[_key(n)] = nn.Parameter(sd[n].detach().float().clone().to(device))
+            self.fairseq_names[_key(n)] = n
+        # weight-normalised positional conv: parameters weight_g / weight_v (norm over dims 0, 1 per tap: torch weight_norm dim=2)
+        if "encoder.pos_conv.0.weight_g" in sd:
+            g, v = sd["encoder.pos_conv.0.weight_g"].detach().float(), sd["encoder.pos_conv.0.weight_v"].detach().float()
+        else:                                # a folded weight: start from g = |w|, v = w (the same function)
+            v = sd["encoder.pos_conv.0.weight"].detach().float()
+            g = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+        for n, t in (("encoder.pos_conv.0.weight_g", g), ("encoder.pos_conv.0.weight_v", v)):
+            self.p[_key(n)] = nn.Parameter(t.clone().to(device))
+            self.fairseq_names[_key(n)] = n
+        self._gen = None
+        self._c = {}
+
+    def P(self, name: str) -> nn.Parameter:
+        return self.p[_key(name)]
+
+    @staticmethod
+    def _gacc(p: torch.Tensor) -> torch.Tensor:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return p.grad
+
+    def pos_weight(self) -> torch.Tensor:
+        g, v = self.P("encoder.pos_conv.0.weight_g"), self.P("encoder.pos_conv.0.weight_v")
+        return g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+
+    def refresh(self) -> None:
+        """bf16 working copies of the masters in the kernels' layouts, rebuilt after every optimiser step."""
+        from .optim import param_generation
+        gen = (param_generation(),) + tuple((p.data_ptr(), p._version) for p in self.p.values())
+        if gen == self._gen:
+            return
+        a, c = self.arch, {}
+        bf = lambda t: t.detach().to(torch.bfloat16).contiguous()
+        f32 = lambda t: ops.aligned16(t.detach().float().contiguous())
+        for i in range(1, len(a.conv_kernels)):
+            w = self.P(f"feature_extractor.conv_layers.{i}.0.weight").detach()           # [C_out, C_in, k]
+            c[f"conv{i}_w"] = bf(w.permute(0, 2, 1).reshape(w.shape[0], -1))               # tap-major [C_out, k C_in]
+            c[f"conv{i}_wT"] = bf(w.permute(0, 2, 1).reshape(w.shape[0], -1).t())          # [k C_in, C_out]
+            c[f"conv{i}_b"] = f32(self.P(f"feature_extractor.conv_layers.{i}.0.bias")) if a.conv_bias else None
+            if a.extractor_mode == "layer_norm":
+                c[f"conv{i}_g"] = f32(self.P(f"feature_extractor.conv_layers.{i}.2.1.weight"))
+                c[f"conv{i}_beta"] = f32(self.P(f"feature_extractor.conv_layers.{i}.2.1.bias"))
+        c["ln_feat_g"], c["ln_feat_b"] = f32(self.P("layer_norm.weight")), f32(self.P("layer_norm.bias"))
+        pw = self.P("post_extract_proj.weight").detach()
+        c["proj_w"], c["proj_wT"], c["proj_b"] = bf(pw), bf(pw.t()), f32(self.P("post_extract_proj.bias"))
+        D, G, Kp = a.embed_dim, a.pos_conv_groups, a.pos_conv_kernel
+        Dg = D // G
+        w = self.pos_weight().detach().reshape(G, Dg, Dg, Kp)                              # [g][co][ci][tap]
+        c["pos_w"] = bf(w.permute(0, 1, 3, 2).reshape(G, Dg, Kp * Dg))                      # forward: [g][co][tap ci]
+        c["pos_w_flip"] = bf(w.flip(3).permute(0, 2, 3, 1).reshape(G, Dg, Kp * Dg))         # dgrad:   [g][ci][tap' co], tap' = K-1-tap
+        c["pos_b"] = f32(self.P("encoder.pos_conv.0.bias"))
+        c["ln_enc_g"], c["ln_enc_b"] = f32(self.P("encoder.layer_norm.weight")), f32(self.P("encoder.layer_norm.bias"))
+        self._c, self._gen = c, gen
+
+    # ------------------------------------------------------------------------------------------------- forward
+    def forward_frontend(self, pl, L: int, p_in: float, p_res: float, seed_in: int, seed_enc: int) -> None:
+        """waveform in pl.wav_pad -> pl.hidden[0]; keeps the activations of every stage in ``pl.front``."""
+        a, c = self.arch, self._c
+        B, R, M, T = pl.B, pl.R, pl.M, pl.T
+        C, D = a.conv_dim, a.embed_dim
+        dev = pl.wav_pad.device
+        st = pl.front = {"p_in": p_in, "p_res": p_res, "seed_in": seed_in, "seed_enc": seed_enc}
+        ln_mode = a.extractor_mode == "layer_norm"
+        # ---- conv layer 0 (+ GroupNorm / LayerNorm, GELU): torch autograd on the fp32 waveform
+        with torch.enable_grad():
+            w0 = self.P("feature_extractor.conv_layers.0.0.weight")
+            b0 = self.P("feature_extractor.conv_layers.0.0.bias") if a.conv_bias else None
+            x0 = F.conv1d(pl.wav_pad[:, None, :L], w0, b0, stride=a.conv_strides[0])                 # [B, C, T0]
+            if ln_mode:
+                n0 = F.layer_norm(x0.transpose(1, 2), (C,), self.P("feature_extractor.conv_layers.0.2.1.weight"),
+                                  self.P("feature_extractor.conv_layers.0.2.1.bias"))
+            else:
+                n0 = F.group_norm(x0, C, self.P("feature_extractor.conv_layers.0.2.weight"),
+                                  self.P("feature_extractor.conv_layers.0.2.bias")).transpose(1, 2)
+            f0 = F.gelu(n0)                                                                              # [B, T0, C]
+        st["f0"] = f0
+        T0 = f0.shape[1]
+        assert T0 == pl.T_l[0]
+        pl.conv[0][: B * pl.R_l[0]].view(B, pl.R_l[0], C)[:, :T0] = f0.detach().to(torch.bfloat16)
+        # ---- conv layers 1 .. 6 on the strided-row GEMM, pre-activations kept
+        st["u"], st["n"] = {}, {}
+        for i in range(1, len(a.conv_kernels)):
+            k, s = a.conv_kernels[i], a.conv_strides[i]
+            rows = B * pl.R_l[i]
+            u = torch.empty(rows, C, device=dev, dtype=torch.bfloat16)
+            ops.gemm_raw(pl.conv[i - 1], s * C, c[f"conv{i}_w"], k * C, u, C, rows, C, k * C, bias=c[f"conv{i}_b"], alg_rows=B * pl.T_l[i],
+                         tap_c=C if (k == 3 and s == 2) else 0)
+            st["u"][i] = u
+            if ln_mode:
+                n = ops.layernorm_bf16(u, c[f"conv{i}_g"], c[f"conv{i}_beta"])
+                st["n"][i] = n
+                ops.act_bf16(n, 1, out=pl.conv[i][:rows])
+            else:
+                ops.act_bf16(u, 1, out=pl.conv[i][:rows])
+        # ---- feature LayerNorm, projection (+ dropout_input)
+        ops.layernorm_bf16(pl.conv[-1][:M], c["ln_feat_g"], c["ln_feat_b"], out=pl.feat_ln)
+        ops.linear_bf16(pl.feat_ln, c["proj_w"], c["proj_b"], out=pl.x_proj, alg_rows=B * T, drop_p=p_in, drop_seed=seed_in)
+        # ---- zero padded frames, pos_conv (pre-activation kept) + GELU + residual, encoder LayerNorm
+        G, Kp = a.pos_conv_groups, a.pos_conv_kernel
+        Dg, Rp = D // G, R + 2 * pl.halo
+        ops.posconv_prep(pl.x_proj, pl.valid, pl.xz, pl.xg, B, R, D, G, pl.halo)
+        u_pos = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+        ops.gemm_raw(pl.xg, Dg, c["pos_w"], Kp * Dg, u_pos, D, R, Dg, Kp * Dg, bias=c["pos_b"], nb1=G, nb2=B,
+                     sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, R * D), sBias=(Dg, 0), alg_rows=T)
+        st["u_pos"] = u_pos
+        y = ops.act_bf16(u_pos, 1)
+        pre = st["pre"] = (pl.xz.float() + y.float()).to(torch.bfloat16)          # x + gelu(pos_conv(x))  (one elementwise pass)
+        if a.layer_norm_first:
+            pl.hidden[0].copy_(pre)
+        else:
+            ops.layernorm_bf16(pre, c["ln_enc_g"], c["ln_enc_b"], out=pl.hidden[0])
+        if p_res > 0:
+            ops.dropout_bf16(pl.hidden[0], p_res, seed_enc, out=pl.hidden[0])
+
+    # ------------------------------------------------------------------------------------------------- backward
+    def backward_frontend(self, pl, dh0: torch.Tensor) -> None:
+        """dh0 [M, D] bf16: gradient of hidden[0] (rows t >= T are zero)."""
+        a, c, st = self.arch, self._c, pl.front
+        B, R, M, T = pl.B, pl.R, pl.M, pl.T
+        C, D = a.conv_dim, a.embed_dim
+        dev = dh0.device
+        ln_mode = a.extractor_mode == "layer_norm"
+        acc = lambda name, g: self._gacc(self.P(name)).add_(g.reshape(self.P(name).shape))
+        if st["p_res"] > 0:
+            dh0 = ops.dropout_bf16(dh0, st["p_res"], st["seed_enc"])
+        # ---- encoder LayerNorm
+        if a.layer_norm_first:
+            dpre = dh0
+        else:
+            dpre, dg, db = ops.layernorm_bwd(st["pre"], dh0, c["ln_enc_g"], 1e-5, want_param_grads=True)
+            acc("encoder.layer_norm.weight", dg)
+            acc("encoder.layer_norm.bias", db)
+        # ---- pos_conv:  pre = xz + gelu(u),  u = conv(xz) + b
+        G, Kp = a.pos_conv_groups, a.pos_conv_kernel
+        Dg, halo = D // G, pl.halo
+        Rp = R + 2 * halo
+        du = ops.act_bf16(st["u_pos"], 1, df=dpre)
+        # slab of du (group-major, halo-padded, frames of every utterance kept: the mask argument is "all R frames valid")
+        all_valid = torch.full((B,), R, device=dev, dtype=torch.int32)
+        du_z = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+        dug = torch.zeros(G, B, Rp, Dg, device=dev, dtype=torch.bfloat16)
+        ops.posconv_prep(du, all_valid, du_z, dug, B, R, D, G, halo)
+        # weight gradient per group: du_g^T [Dg, B Rp] . Toeplitz view of the forward slab [B Rp, Kp Dg] (row m starts at slab row m).
+        # du rows are laid out with the slab's row pitch (Rp per utterance): the halo rows multiply windows that straddle two
+        # utterances and must be zero - they are (dug's halos), shifted by `halo` rows against the window index.
+        gw = torch.empty(G, Dg, Kp * Dg, device=dev, dtype=torch.float32)
+        gb = torch.empty(D, device=dev, dtype=torch.float32)
+        rows_p = B * Rp
+        xg_flat = pl.xg.view(G, -1)
+        du_rows = torch.zeros(G, rows_p, Dg, device=dev, dtype=torch.bfloat16)      # window index m = b Rp + t  <->  du[b, t]
+        du_rows.view(G, B, Rp, Dg)[:, :, :R] = dug[:, :, halo: halo + R]
+        slack = torch.zeros(Kp * Dg, device=dev, dtype=torch.bfloat16)
+        for g in range(G):
+            # the last windows of the last utterance read past this group's slab: give the view its own zero slack
+            src = torch.cat([xg_flat[g], slack])
+            cols = torch.as_strided(src, (rows_p, Kp * Dg), (Dg, 1))
+            gbg = torch.empty(Dg, device=dev, dtype=torch.float32)
+            ops.wgrad_bf16(du_rows[g], cols, gw[g], gbg, beta=0.0)
+            gb[g * Dg: (g + 1) * Dg] = gbg
+        acc("encoder.pos_conv.0.bias", gb)
+        # chain rule to weight_g / weight_v through the fold (small tensors: torch autograd)
+        dW = gw.view(G, Dg, Kp, Dg).permute(0, 1, 3, 2).reshape(D, Dg, Kp)             # [co][ci][tap]
+        with torch.enable_grad():
+            w = self.pos_weight()
+        gg, gv = torch.autograd.grad(w, [self.P("encoder.pos_conv.0.weight_g"), self.P("encoder.pos_conv.0.weight_v")], dW)
+        acc("encoder.pos_conv.0.weight_g", gg)
+        acc("encoder.pos_conv.0.weight_v", gv)
+        # input gradient: dx[s] = sum_tap' du_slab[s + 1 + tap'] . W_flip[tap']  (+ the residual path dpre in the epilogue)
+        dxz = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+        dug_flat = torch.cat([dug.view(-1), torch.zeros(Dg, device=dev, dtype=torch.bfloat16)])   # + one slab row of slack
+        ops.gemm_raw(dug_flat[Dg:], Dg, c["pos_w_flip"], Kp * Dg, dxz, D, R, Dg, Kp * Dg, residual=dpre, ldr=D, nb1=G, nb2=B,
+                     sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, R * D), sR=(Dg, R * D), alg_rows=T)
+        # padded frames were zeroed in the forward (x[padding_mask] = 0): no gradient to them
+        dx_proj = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+        ops.posconv_prep(dxz, pl.valid, dx_proj, dug, B, R, D, G, halo)
+        if st["p_in"] > 0:
+            dx_proj = ops.dropout_bf16(dx_proj, st["p_in"], st["seed_in"])
+        # ---- post_extract_proj, feature LayerNorm
+        ops.wgrad_bf16(dx_proj, pl.feat_ln, self._gacc(self.P("post_extract_proj.weight")), self._gacc(self.P("post_extract_proj.bias")))
+        dfl = ops.linear_bf16(dx_proj, c["proj_wT"])
+        df, dg, db = ops.layernorm_bwd(pl.conv[-1][:M], dfl, c["ln_feat_g"], 1e-5, want_param_grads=True)
+        acc("layer_norm.weight", dg)
+        acc("layer_norm.bias", db)
+        fgm = float(getattr(a, "feature_grad_mult", 1.0))
+        if fgm != 1.0:                       # fairseq GradMultiply on the extractor's output
+            df = (df.float() * fgm).to(torch.bfloat16)
+        # ---- conv layers 6 .. 1
+        for i in range(len(a.conv_kernels) - 1, 0, -1):
+            k, s = a.conv_kernels[i], a.conv_strides[i]
+            rows = B * pl.R_l[i]
+            u = st["u"][i]
+            if ln_mode:
+                dn = ops.act_bf16(st["n"][i], 1, df=df)
+                du, dg, db = ops.layernorm_bwd(u, dn, c[f"conv{i}_g"], 1e-5, want_param_grads=True)
+                acc(f"feature_extractor.conv_layers.{i}.2.1.weight", dg)
+                acc(f"feature_extractor.conv_layers.{i}.2.1.bias", db)
+            else:
+                du = ops.act_bf16(u, 1, df=df)
+            # weight gradient: dy^T . im2col VIEW of the layer input (rows overlap in memory: lda = s C < K = k C)
+            cols = torch.as_strided(pl.conv[i - 1], (rows, k * C), (s * C, 1))
+            gw = torch.empty(C, k * C, device=dev, dtype=torch.float32)
+            gbias = torch.empty(C, device=dev, dtype=torch.float32) if a.conv_bias else None
+            ops.wgrad_bf16(du, cols, gw, gbias, beta=0.0)
+            acc(f"feature_extractor.conv_layers.{i}.0.weight", gw.view(C, k, C).permute(0, 2, 1))
+            if a.conv_bias:
+                acc(f"feature_extractor.conv_layers.{i}.0.bias", gbias)
+            # input gradient: windows of dcols = du . W back onto the rows they were cut from
+            dcols = ops.linear_bf16(du, c[f"conv{i}_wT"])                                   # [rows, k C]
+            if k == s:                                                                     # non-overlapping windows: a reshape
+                df = dcols.view(rows * s, C)
+            else:
+                assert k == 3 and s == 2
+                df = torch.empty(rows, 2, C, device=dev, dtype=torch.bfloat16)
+                df[:, 0] = dcols[:, :C]
+                df[:, 1] = dcols[:, C: 2 * C]
+                df[1:, 0] += dcols[:-1, 2 * C:]                                              # tap 2 of window m = row 2 (m + 1)
+                df = df.view(rows * 2, C)
+        # ---- conv layer 0: torch autograd from the saved graph
+        f0 = st["f0"]
+        T0 = f0.shape[1]
+        g0 = df.view(B, pl.R_l[0], C)[:, :T0].float()
+        f0.backward(g0)
+        pl.front = None

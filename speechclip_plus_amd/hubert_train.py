@@ -68,6 +68,7 @@ class TrainableLayers(nn.Module):
                 self.p[_key(i, name)] = nn.Parameter(t.to(device))
                 self.fairseq_names[_key(i, name)] = f"encoder.layers.{i}.{name}"
         self._copies, self._versions = {}, None
+        self.frontend = None                     # hubert_frontend_train.TrainableFrontend when the whole encoder trains
         self.grad_ready_hook = None              # callable(layer_id): every gradient of that layer has been enqueued (train.py)
 
     def invalidate(self) -> None:
@@ -170,9 +171,14 @@ class TrainableLayers(nn.Module):
                 g = ops.layernorm_bwd(pl.hidden[i + 1], g, ones, 1e-5)
             d_out = g if d_out is None else d_out + g
             assert i in pl.train, "unfrozen layers ran without saved activations (forward in eval / no_grad mode?)"
-            d_out = self._layer_backward(i, pl, d_out, need_dx=i > lo, train=i in self.ids)
+            d_out = self._layer_backward(i, pl, d_out, need_dx=i > lo or self.frontend is not None, train=i in self.ids)
             if self.grad_ready_hook is not None and i in self.ids:
                 self.grad_ready_hook(i)
+        if self.frontend is not None:                      # lo == 0: on into the front end with d hidden[0]
+            g = (dfeat * w_soft[0]).to(torch.bfloat16)
+            if normalize:
+                g = ops.layernorm_bwd(pl.hidden[0], g, ones, 1e-5)
+            self.frontend.backward_frontend(pl, d_out + g)
 
     def _layer_backward(self, i: int, pl, d_out: torch.Tensor, need_dx: bool, train: bool = True):
         a, c, s = self.arch, self._copies[i], pl.train[i]

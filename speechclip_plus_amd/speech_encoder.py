@@ -55,6 +55,8 @@ class HubertArch:
     attention_dropout: float = 0.1     # on the attention probabilities
     activation_dropout: float = 0.0    # after the FFN activation
     dropout_input: float = 0.1         # on post_extract_proj's output
+    feature_grad_mult: float = 0.1     # fairseq GradMultiply on the conv extractor's output (hubert_base_librispeech.yaml: 0.1;
+                                       # hubert_large_librivox.yaml: 1.0); acts only on the backward of a fully trainable encoder
 
 
 ARCHS = {
@@ -62,7 +64,8 @@ ARCHS = {
     "hubert_base": HubertArch(),
     "hubert_large_ll60k": HubertArch(embed_dim=1024, ffn_dim=4096, layers=24, heads=16, extractor_mode="layer_norm",
                                      conv_bias=True, layer_norm_first=True, normalize_wav=True, dropout=0.0,
-                                     attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0),
+                                     attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0,
+                                     feature_grad_mult=1.0),
 }
 
 
@@ -204,13 +207,13 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self.trainable = trainable
         assert not (len(reinit_layers) > 0 and len(unfreeze_layers) > 0)               # speech_encoder_plus.py:416
         train_ids = sorted(set(int(i) for i in (list(reinit_layers) or list(unfreeze_layers))))
+        self._train_all = False
         if train_ids:
             assert trainable, "reinit_layers / unfreeze_layers need trainable: true (speech_encoder_plus.py:419,434)"
         elif trainable:
-            raise NotImplementedError(
-                "audio_encoder.trainable without reinit_layers / unfreeze_layers fine-tunes the conv extractor, projection and "
-                "pos_conv too; their backward is not built (scope row f2 covers the transformer layers). No shipped recipe "
-                "trains HuBERT (SURVEY F3)")
+            # speech_encoder_plus.py:556-562: every encoder parameter trains (conv extractor, projection, pos_conv, all layers)
+            self._train_all = True
+            train_ids = list(range(self.arch.layers))
         self._train_ids = train_ids
         assert self.arch.extractor_mode in ("default", "layer_norm"), self.arch.extractor_mode
         assert self.arch.embed_dim == self.arch.heads * 64, "the attention kernel is built for head_dim 64"
@@ -241,6 +244,11 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if train_ids:
             from .hubert_train import TrainableLayers
             self.train_layers = TrainableLayers(self.arch, state_dict, train_ids, self._dev, reinit=len(reinit_layers) > 0, seed=seed)
+        self.frontend = None
+        if self._train_all:
+            from .hubert_frontend_train import TrainableFrontend
+            self.frontend = TrainableFrontend(self.arch, state_dict, self._dev)
+            self.train_layers.frontend = self.frontend
         self._plans: Dict[Tuple[int, int], _Plan] = {}
         if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             self.weightedsum_layer = WeightedSumLayer(
@@ -301,6 +309,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if self.train_layers is None:
             return ws
         layer_params = list(self.train_layers.parameters())
+        if self.frontend is not None:
+            layer_params = layer_params + list(self.frontend.parameters())
         return layer_params if len(self.reinit_layers) > 0 else layer_params + ws
 
     # ------------------------------------------------------------------------------------------ forward
@@ -388,6 +398,21 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         len_dev = pl.len_dev
         # a1: (optional) utterance layer-norm + zero pad                                (:506-518)
         ops.wav_prep(padded, len_dev, pl.wav_pad, a.normalize_wav)
+        scale = (D // H) ** -0.5
+        train_front = self.frontend is not None      # (also in eval: the frozen copies in self._w are the INITIAL weights)
+        if train_front:           # fully trainable encoder: the front end keeps its activations (hubert_frontend_train.py)
+            self.frontend.refresh()
+            self.frontend.forward_frontend(pl, L, p_in, p_res, sd(0), sd(1))
+        else:
+            self._frontend_frozen(pl, w, seeds, sd, p_in, p_res)
+        self._layers(pl, w, seeds, sd, p_res, p_att, save, scale, first_hidden_done=train_front)
+
+    @torch.no_grad()
+    def _frontend_frozen(self, pl, w, seeds, sd, p_in, p_res) -> None:
+        a = self.arch
+        B, L = pl.B, pl.L
+        C, D, F, H = a.conv_dim, a.embed_dim, a.ffn_dim, a.heads
+        R, M, T = pl.R, pl.M, pl.T
         # a2: conv feature extractor                                                    (:75)
         ln_mode = a.extractor_mode == "layer_norm"
         if ln_mode:       # large: conv (+bias) -> LayerNorm(512) -> GELU after every layer
@@ -413,7 +438,13 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         ops.gemm_raw(pl.xg, Dg, w["pos_w"], Kp * Dg, pl.pre, D, R, Dg, Kp * Dg, bias=w["pos_b"], residual=pl.xz, ldr=D,
                      act=1, nb1=G, nb2=B, sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, R * D),
                      sBias=(Dg, 0), sR=(Dg, R * D), alg_rows=T)
-        scale = (D // H) ** -0.5
+
+    @torch.no_grad()
+    def _layers(self, pl, w, seeds, sd, p_res, p_att, save, scale, first_hidden_done) -> None:
+        a = self.arch
+        B, L = pl.B, pl.L
+        C, D, F, H = a.conv_dim, a.embed_dim, a.ffn_dim, a.heads
+        R, M, T = pl.R, pl.M, pl.T
 
         def qkv_attn(x, i):
             ops.gemm_raw(x, D, w[f"l{i}_qkv_w"], D, pl.qk, 2 * D, M, 3 * D, D, bias=w[f"l{i}_qkv_b"], Ct=pl.vt,
@@ -423,9 +454,10 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
 
         if not a.layer_norm_first:
             # a5: post-LN layers (base): x = LN1(x + attn(x)); x = LN2(x + ffn(x))       (:39-40, :49-53)
-            ops.layernorm_bf16(pl.pre, w["ln_enc_g"], w["ln_enc_b"], out=pl.hidden[0])
-            if p_res > 0:
-                ops.dropout_bf16(pl.hidden[0], p_res, sd(1), out=pl.hidden[0])                 # F.dropout after the LN (:42)
+            if not first_hidden_done:
+                ops.layernorm_bf16(pl.pre, w["ln_enc_g"], w["ln_enc_b"], out=pl.hidden[0])
+                if p_res > 0:
+                    ops.dropout_bf16(pl.hidden[0], p_res, sd(1), out=pl.hidden[0])             # F.dropout after the LN (:42)
             tl = self.train_layers
             if tl is not None:
                 tl.refresh()
@@ -452,9 +484,10 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         else:
             # pre-LN layers (large): x = x + attn(LN1(x)); x = x + ffn(LN2(x)); layer_results are NOT passed through
             # the encoder's final LayerNorm (fairseq applies it to `x` only, which the reference never reads)
-            pl.hidden[0].copy_(pl.pre)
-            if p_res > 0:
-                ops.dropout_bf16(pl.hidden[0], p_res, sd(1), out=pl.hidden[0])
+            if not first_hidden_done:
+                pl.hidden[0].copy_(pl.pre)
+                if p_res > 0:
+                    ops.dropout_bf16(pl.hidden[0], p_res, sd(1), out=pl.hidden[0])
             tl = self.train_layers
             if tl is not None:
                 tl.refresh()

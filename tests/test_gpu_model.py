@@ -425,6 +425,80 @@ def test_reference_checkpoint_round_trip_and_validation_epoch(setup):
     assert torch.equal(out3["parallel_audio_feat"], outs_a[-1]["parallel_audio_feat"])
 
 
+@pytest.mark.parametrize("large", [False, True])
+def test_fully_trainable_hubert_gradients_vs_oracle(large):
+    """audio_encoder.trainable: true with no reinit / unfreeze list (speech_encoder_plus.py:556-562): EVERY encoder parameter
+    trains - conv feature extractor (GroupNorm / LayerNorm variants), feature LayerNorm, post_extract_proj, the weight-normalised
+    positional conv (weight_g, weight_v), encoder LayerNorm and all transformer layers; fairseq's feature_grad_mult scales the
+    gradient entering the extractor.  One step: loss and every gradient against the oracle's autograd."""
+    import dataclasses
+    import oracle
+    from oracle.hubert_ref import fold_weight_norm
+    from speechclip_plus_amd import (set_dropout, KWClip_GeneralTransformer, base_parallel_config, large_parallel_config,
+                                     random_hubert_state_dict)
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    arch = dataclasses.replace(ARCHS["hubert_large_ll60k" if large else "hubert"], layers=2, feature_grad_mult=0.1)
+    sd = random_hubert_state_dict(arch, seed=19)
+    torch.manual_seed(19)
+    cfg = large_parallel_config() if large else base_parallel_config()
+    cfg.audio_encoder.max_audio_len = -1
+    cfg.audio_encoder.trainable = True
+    model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
+    enc = model.audio_encoder
+    assert enc.frontend is not None and enc.train_layers.ids == [0, 1]
+    with torch.no_grad():
+        enc.weightedsum_layer.weights.copy_(torch.tensor([0.2, -0.1, 0.4]))
+    g = torch.Generator().manual_seed(8)
+    lens = [9000, 6100, 9000, 4100]
+    wavs = [torch.randn(l, generator=g) * 0.5 for l in lens]
+    B = len(lens)
+    E = 768 if large else 512
+    img = torch.randn(B, E, generator=g)
+    ids = torch.tensor([0, 1, 1, 2])
+    wav = torch.zeros(B, max(lens))
+    for b, x in enumerate(wavs):
+        wav[b, : len(x)] = x
+    batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": img.cuda(), "id": ids.cuda()}
+    names = dict(enc.train_layers.fairseq_names)
+    params = {enc.train_layers.fairseq_names[k]: p for k, p in enc.train_layers.p.items()}
+    params.update({enc.frontend.fairseq_names[k]: p for k, p in enc.frontend.p.items()})
+    assert {id(p) for p in params.values()} <= {id(p) for p in model.getTrainableParams()}
+    out = model.compute_loss(model(batch)[0])
+    out["loss"].backward()
+    # ---- oracle: same weights, everything requires grad; pos_conv through its weight-norm parameters
+    o_arch = oracle.HubertArch.large() if large else oracle.HubertArch.base()
+    o_arch.layers, o_arch.feature_grad_mult = 2, 0.1
+    W = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if k != "encoder.pos_conv.0.weight"}
+    v0 = sd["encoder.pos_conv.0.weight"].clone().float()
+    W["encoder.pos_conv.0.weight_g"] = v0.pow(2).sum(dim=(0, 1), keepdim=True).sqrt().requires_grad_(True)
+    W["encoder.pos_conv.0.weight_v"] = v0.clone().requires_grad_(True)
+    Wf = dict(W)
+    Wf["encoder.pos_conv.0.weight"] = fold_weight_norm(W["encoder.pos_conv.0.weight_g"], W["encoder.pos_conv.0.weight_v"])
+    hs_o, fl = oracle.speech_encoder_forward(Wf, o_arch, wavs)
+    head_W = {k: v.detach().cpu().float() for k, v in model.parallel_branch.state_dict().items()}
+    ws_w = enc.weightedsum_layer.weights.detach().cpu()
+    feat = oracle.weighted_sum(ws_w, list(hs_o), large)
+    e = oracle.parallel_branch_forward(head_W, feat, fl, nhead=8)
+    loss_o = oracle.masked_contrastive_loss(e / e.norm(dim=-1, keepdim=True), img / img.norm(dim=-1, keepdim=True), ids)
+    loss_o.backward()
+    assert abs(out["loss"].item() - loss_o.item()) < 5e-3
+    errs = {}
+    for name, p in params.items():
+        ref = W[name].grad
+        if ref is None:           # pre-LN: the encoder's final LayerNorm acts on an output the reference never reads
+            assert name.startswith("encoder.layer_norm.") and (p.grad is None or float(p.grad.abs().sum()) == 0.0), name
+            continue
+        assert p.grad is not None, name
+        if float(ref.norm()) > 1e-9:
+            errs[name] = rel_l2(p.grad, ref)
+    bad = {k: v for k, v in errs.items() if v > 8e-2}
+    assert not bad, (bad, max(errs.values()))
+    front = {k: v for k, v in errs.items() if not k.startswith("encoder.layers.")}
+    print("fully trainable (%s): worst front-end gradient rel-L2 %.3g (%s), worst layer gradient %.3g" %
+          ("large" if large else "base", max(front.values()), max(front, key=front.get),
+           max(v for k, v in errs.items() if k.startswith("encoder.layers."))))
+
+
 def test_second_forward_before_backward_fails_loudly_and_outputs_survive(setup):
     """The encoder's hidden states live in a resident workspace per (B, L) geometry: a backward that arrives after another
     forward re-used it must raise (not differentiate against the wrong states), and hidden states handed out to the caller are
