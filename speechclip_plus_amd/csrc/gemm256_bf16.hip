@@ -57,7 +57,7 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 // BN = 256 or 192 output columns per tile (wave block 128 x 64 or 128 x 48).  The narrower tile exists for wave
 // quantisation: with M = 32768, N = 768 / 2304 give 384 / 1152 tiles of 256 x 256 (1.5 / 4.5 rounds over 256 CUs) but
 // 512 / 1536 tiles of 256 x 192 (exactly 2 / 6 rounds).
-template <int DIAG, int BN, int ACT, int DROP>
+template <int DIAG, int BN, int ACT, int DROP, int RES>
 __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     constexpr int TN = BN / 4, FN = TN / 16, NB1 = FN - 2;   // per-wave columns, fragments, fragments of n-sub 1
     constexpr int NBI = BN / 64;                             // B-tile DMA instructions per wave and K-tile
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     const uint16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const uint16_t* W = p.W + z1 * p.sW1 + z2 * p.sW2;
     const float* bias = p.bias ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
-    const uint16_t* Rs = p.residual ? p.residual + z1 * p.sR1 + z2 * p.sR2 : nullptr;
+    const uint16_t* Rs = (RES && p.residual) ? p.residual + z1 * p.sR1 + z2 * p.sR2 : nullptr;   // RES: compile-time variant (registers)
     const int64_t coff = z1 * p.sC1 + z2 * p.sC2;
 
     // ---- DMA sources: one wave-instruction = 8 rows; A: 2 halves x 16 instr (wave w issues {w, w + 8} of each half),
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
                 _Pragma("unroll") for (int ni = 0; ni < ((NS) == 0 ? 2 : NB1); ++ni)                     \
                     acc[(MS) * 4 + mi][(NS) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(         \
-                        af[mi][kk], BF[ni][kk], acc[(MS) * 4 + mi][(NS) * 2 + ni], 0, 0, 0);             \
+                        BF[ni][kk], af[mi][kk], acc[(MS) * 4 + mi][(NS) * 2 + ni], 0, 0, 0);             \
         __builtin_amdgcn_s_setprio(0);                                                                   \
     } while (0)
 
@@ -176,15 +176,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         SC_STAMP(0);
         // accumulators start from the bias (a lane's fragment column is fixed: n = wave's first column + 16 ni + lane % 16),
         // so the epilogue neither waits on a bias load nor spends an add per element
+        // The MFMA is issued with the WEIGHT fragment as its first operand: an accumulator fragment is then the transposed
+        // 16 x 16 block, i.e. a lane owns ONE output row (m = 16 mi + lane % 16) and FOUR CONSECUTIVE columns
+        // (n = 16 ni + 4 (lane / 16) + r) - the epilogue assembles 16-byte row chunks in registers (one lane-row exchange per
+        // fragment pair) and needs no LDS staging.
         f32x4 acc[8][FN];
-        int bl = lane & 15;
+        int bl = lane >> 4;
         asm volatile("" : "+v"(bl));
 #pragma unroll
         for (int ni = 0; ni < FN; ++ni) {
-            const int n = n0 + wn * TN + ni * 16 + bl;
-            const float bvn = (bias && n < p.N) ? bias[n] : 0.f;
+            const int n = n0 + wn * TN + ni * 16 + 4 * bl;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias && n + 4 <= p.N) bv = *(const f32x4*)(bias + n);
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = f32x4{bvn, bvn, bvn, bvn};
+            for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = bv;
         }
         bf16x8 af[4][2], b0[2][2], b1[NB1][2];
 
@@ -303,8 +308,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                                     const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
                                     v = f32x4{g0.x, g0.y, g1.x, g1.y};
                                 }
-                                const int nl = nj * 16 + (el & 15), mlc = mi * 4 + (el >> 4);
-                                *(f32x4*)(Cw + nl * 64 + ((mlc ^ (nl & 15)) << 2)) = v;
+                                const int ml = mi * 16 + (el & 15);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int nl = nj * 16 + 4 * (el >> 4) + r;
+                                    Cw[nl * 64 + (((ml >> 2) ^ (nl & 15)) << 2) + (ml & 3)] = v[r];
+                                }
                             }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
@@ -329,41 +338,39 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
                     }
-            } else {
+            } else if (RES) {
+                // ---- tiles with a residual: staged through the wave's private 8 KiB of buffer last_par, 32 rows a pass, so that
+                // every store instruction writes FULL 128-byte rows (non-temporal: the output is the next residual stream and is
+                // read next by a LayerNorm pass) and every residual load is a full row too.  Measured against the register-direct
+                // form below on the out_proj / fc2 shapes: 60 vs 76 us / 138 vs 160 us.  Fragments go in as 16-byte chunks (a lane
+                // owns 4 consecutive columns of one row), chunk index XOR row & 15: conflict-free writes and reads.
 #pragma unroll
-            for (int ms = 0; ms < 4; ++ms) {
-                const int wm0 = cm0 + wm * 128 + ms * 32;   // first row of this pass
+                for (int ms = 0; ms < 4; ++ms) {
+                    const int wm0 = cm0 + wm * 128 + ms * 32;
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < FN; ++ni) {
-                        f32x4 v = acc[ms * 2 + mi][ni];
-                        if (ACT == 1) {
-                            const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
-                            v = f32x4{g0.x, g0.y, g1.x, g1.y};
+                        for (int ni = 0; ni < FN; ++ni) {
+                            f32x4 v = acc[ms * 2 + mi][ni];
+                            if (ACT == 1) {
+                                const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+                                v = f32x4{g0.x, g0.y, g1.x, g1.y};
+                            }
+                            const int ml = mi * 16 + (el & 15), ch = ni * 4 + (el >> 4);
+                            *(f32x4*)(Cw + ml * 64 + ((ch ^ (ml & 15)) << 2)) = v;
                         }
-                        const int ml = mi * 16 + 4 * (el >> 4), nl = ni * 16 + (el & 15);
-                        // the four lane groups hold rows 4 apart: with a 64-float pitch they would share banks, so
-                        // 16-column blocks are XOR-swizzled by (row >> 2) & 3 = lane >> 4 (TN = 64) / rows padded (TN = 48)
-                        const int ns = TN == 64 ? (nl ^ ((el >> 4) << 4)) : nl;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) Cw[(ml + r) * TNP + ns] = v[r];
-                    }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);   // keep each pass's address arithmetic inside the pass (VGPR budget)
-                if (ms == 0) SC_STAMP(3);
-                {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int it = 0; it < CPR / 2; ++it) {
                         const int q = it * 64 + el;
                         const int row = q / CPR, cc = q % CPR;
                         const int m = wm0 + row, n = wn0 + cc * 8;
                         if (m < p.M && n + 8 <= p.N) {
-                            const int cs = TN == 64 ? ((cc * 8) ^ (((row >> 2) & 3) << 4)) : cc * 8;
-                            const f32x4 lo = *(const f32x4*)(Cw + row * TNP + cs);
-                            const f32x4 hi = *(const f32x4*)(Cw + row * TNP + cs + 4);
+                            const f32x4 lo = *(const f32x4*)(Cw + row * 64 + (((2 * cc) ^ (row & 15)) << 2));
+                            const f32x4 hi = *(const f32x4*)(Cw + row * 64 + (((2 * cc + 1) ^ (row & 15)) << 2));
                             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            if (DROP) {                      // train-mode dropout before the residual add (F.dropout semantics)
+                            if (DROP) {
                                 const uint32_t keep = sc_keep8((uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_seed, drop_thr);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * drop_scale : 0.f;
@@ -391,11 +398,79 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                             }
                         }
                     }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                if (ms == 0) SC_STAMP(4);
-            }
+            } else {
+                // ---- register-direct epilogue.  Per output row m (one lane) and fragment PAIR (2p, 2p + 1): after
+                // v_permlane16_swap the lanes of even lane-rows (lane / 16 = 0, 2) hold 8 consecutive columns of fragment 2p, the
+                // odd ones 8 consecutive columns of fragment 2p + 1: GELU, dropout, residual and one 16-byte store per lane, with
+                // no LDS round trip and no wait between fragments (the VALU stream of the GELU and the store issue overlap).
+                // Tiles WITHOUT a residual only (GELU / conv / QKV / projection launches: 3 - 5 % faster than the staged form).
+                const int g = el >> 4, l15 = el & 15;
+                const int coff8 = ((g >> 1) << 3) + ((g & 1) << 4);
+                auto finish8 = [&](float (&v)[8], int m, int n) {
+                    if (m < p.M && n + 8 <= p.N) {
+                        if (DROP) {                      // train-mode dropout before the residual add (F.dropout semantics)
+                            const uint32_t keep = sc_keep8((uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_seed, drop_thr);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * drop_scale : 0.f;
+                        }
+                        if (p.out_f32) {
+                            float* C = (float*)p.C + coff + (int64_t)m * p.ldc + n;
+                            *(f32x4*)C = f32x4{v[0], v[1], v[2], v[3]};
+                            *(f32x4*)(C + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        } else {
+                            uint16_t* C = (uint16_t*)p.C + coff + (int64_t)m * p.ldc + n;
+                            uint4 o;
+                            o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                            o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+                            *(uint4*)C = o;              // plain stores: the L2 merges a row's two 64-byte halves
+                        }
+                    }
+                };
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    const int m = cm0 + wm * 128 + mi * 16 + l15;
+#pragma unroll
+                    for (int pr = 0; pr < FN / 2; ++pr) {
+                        f32x4 Fv = acc[mi][2 * pr], Gv = acc[mi][2 * pr + 1];
+                        if (ACT == 1) {
+                            const f32x2 a0 = gelu_erf2(f32x2{Fv[0], Fv[1]}), a1 = gelu_erf2(f32x2{Fv[2], Fv[3]});
+                            const f32x2 b0 = gelu_erf2(f32x2{Gv[0], Gv[1]}), b1 = gelu_erf2(f32x2{Gv[2], Gv[3]});
+                            Fv = f32x4{a0.x, a0.y, a1.x, a1.y};
+                            Gv = f32x4{b0.x, b0.y, b1.x, b1.y};
+                        }
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {    // odd lane-rows of F <-> even lane-rows of G
+                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(Fv[r]), __float_as_uint(Gv[r]), false, false);
+                            v[r] = __uint_as_float(sw[0]);
+                            v[4 + r] = __uint_as_float(sw[1]);
+                        }
+                        finish8(v, m, wn0 + pr * 32 + coff8);
+                    }
+                    if ((FN & 1) && (mi & 1)) {
+                        // 192-wide tiles: the odd (third) fragment is paired ACROSS two row blocks - after the exchange the even
+                        // lane-rows hold 8 consecutive columns of row block mi - 1, the odd ones 8 consecutive columns of row
+                        // block mi: 16-byte stores here too
+                        f32x4 Fv = acc[mi - 1][FN - 1], Gv = acc[mi][FN - 1];
+                        if (ACT == 1) {
+                            const f32x2 a0 = gelu_erf2(f32x2{Fv[0], Fv[1]}), a1 = gelu_erf2(f32x2{Fv[2], Fv[3]});
+                            const f32x2 b0 = gelu_erf2(f32x2{Gv[0], Gv[1]}), b1 = gelu_erf2(f32x2{Gv[2], Gv[3]});
+                            Fv = f32x4{a0.x, a0.y, a1.x, a1.y};
+                            Gv = f32x4{b0.x, b0.y, b1.x, b1.y};
+                        }
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(Fv[r]), __float_as_uint(Gv[r]), false, false);
+                            v[r] = __uint_as_float(sw[0]);
+                            v[4 + r] = __uint_as_float(sw[1]);
+                        }
+                        finish8(v, m - ((g & 1) ? 0 : 16), wn0 + (FN - 1) * 16 + ((g >> 1) << 3));
+                    }
+                }
             }
         }
         SC_STAMP(5);
@@ -407,11 +482,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
 
 }  // namespace
 
-template <int DIAG, int BN, int ACT, int DROP>
-static int launch256_(const sc_gemm_args& a, hipStream_t s) {
+template <int DIAG, int BN, int ACT, int DROP, int RES>
+static int launch256__(const sc_gemm_args& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DIAG, BN, ACT, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DIAG, BN, ACT, DROP, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) {
             sc_set_error("hipFuncSetAttribute(gemm256): %s", hipGetErrorString(e));
             return -3;
@@ -420,9 +495,17 @@ static int launch256_(const sc_gemm_args& a, hipStream_t s) {
     }
     const int nM = (a.M + 255) / 256, nN = (a.N + BN - 1) / BN;
     dim3 grid(std::min(nM * nN, sc_num_cus()), 1, a.nb1 * a.nb2);
-    hipLaunchKernelGGL((gemm256_kernel<DIAG, BN, ACT, DROP>), grid, dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm256_kernel<DIAG, BN, ACT, DROP, RES>), grid, dim3(512), LDS_BYTES, s, a);
     SC_LAUNCH_CHECK();
     return 0;
+}
+
+template <int DIAG, int BN, int ACT, int DROP>
+static int launch256_(const sc_gemm_args& a, hipStream_t s) {
+    if constexpr (DIAG == 0) {          // the residual epilogue is its own instantiation (its prefetch registers)
+        if (a.residual) return launch256__<DIAG, BN, ACT, DROP, 1>(a, s);
+    }
+    return launch256__<DIAG, BN, ACT, DROP, 0>(a, s);
 }
 
 template <int DIAG, int BN>
@@ -444,9 +527,11 @@ static double tile_cost(const sc_gemm_args& a, int BN) {
 int sc_gemm256_launch(const sc_gemm_args& a_in, hipStream_t s) {
     sc_gemm_args a = a_in;
     // bit 0: non-temporal C stores.  auto = only when a residual is given (the output is the next residual stream and is read
-    // next by a LayerNorm pass).  Extending it to every large output was measured and reverted: FC1 itself gains 2 % but FC2 then
-    // reads its 201 MB A operand from HBM instead of the MALL (145 -> 165 us), encoder forward +2 % (same-box A/B).
-    a.reserved = a_in.reserved == 1 || (a_in.reserved == 0 && a_in.residual != nullptr);
+    // next by a LayerNorm pass; those tiles leave through the LDS-staged epilogue as full 128-byte rows).  Extending it to every large
+    // output was measured and reverted in round 1 (FC2 then reads its A operand from HBM instead of the MALL); on the
+    // register-direct epilogue it must stay off: half-line non-temporal writes cost 25 % (75.7 vs 55.9 us on the out_proj shape).
+    a.reserved = (a_in.reserved == 1 || (a_in.reserved == 0 && a_in.residual != nullptr)) ? 1 : 0;
+    if (sc_option(1)) a.reserved = 0;      // A/B switch (tools/): plain stores everywhere
     if (a.tile == 32) return launch256<3, 256>(a, s);   // diagnostics only (tools/epi_probe.py, tools/epi_stamps.py)
     if (a.tile == 34) return launch256<4, 256>(a, s);
     if (a.tile == 7) return launch256<0, 192>(a, s);
