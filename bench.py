@@ -192,6 +192,8 @@ def main():
                     "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                     "alg_gflop_per_launch": round(dom["work"] / dom["launches"] / 1e9, 3)}
             roof.update(pmc_traffic("gemm256_kernel<0," if dom_name == "gemm_bf16_256x256" else "gemm_bf16_kernel<128, 128>"))
+            if dom_name == "gemm_bf16_256x256" and world == 1:
+                roof["k_loop"] = k_loop_clock(dev)
             for k, v in summ.items():
                 if not k.startswith("gemm_bf16_"):
                     continue          # event brackets are validated against rocprofv3 for the GEMM launches only
@@ -329,7 +331,7 @@ def pmc_traffic(kernel_substr):
     if not files:
         return {"traffic": None}
     data = json.load(open(files[-1]))
-    src = source_sha("gemm256_bf16.hip" if "gemm256" in kernel_substr else "gemm_bf16.hip")
+    src = source_sha(("gemm256_bf16.hip", "gemm_epilogue.inc") if "gemm256" in kernel_substr else ("gemm_bf16.hip",))
     meta = data.get("_meta", {})
     hits = [v for name, v in data.items() if kernel_substr in name and name != "_meta"]
     if not hits:
@@ -344,9 +346,39 @@ def pmc_traffic(kernel_substr):
             "traffic_source": os.path.relpath(files[-1], ROOT)}
 
 
-def source_sha(name: str) -> str:
+def k_loop_clock(dev):
+    """Shader clock and cycles per K-tile INSIDE the dominant kernel's K loop, from its stamped diagnostic build (tile 34: s_memtime
+    and s_memrealtime around every tile's K loop; same code otherwise, its launch time equals the production kernel's) on the
+    step's QKV and FC1 shapes.  `peak` above is the 2.4 GHz figure; under this load the chip holds the clock reported here, and a
+    K-tile cannot take fewer than 2048 cycles (2 waves x 64 MFMA x 16 cycles per SIMD)."""
+    from speechclip_plus_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    Bq, R, D, F = 64, 512, 768, 3072
+    out = {"mfma_paced_cycles_per_k_tile": 2048, "nominal_clock_ghz": 2.4}
+    for name, n, act in (("qkv", 3 * D, 0), ("fc1", F, 1)):
+        A = torch.randn(Bq * R, D, generator=g).to(torch.bfloat16).to(dev)
+        W = (torch.randn(n, D, generator=g) * D ** -0.5).to(torch.bfloat16).to(dev)
+        bias = torch.randn(n, generator=g).to(dev)
+        C = torch.empty(Bq * R, n, device=dev, dtype=torch.bfloat16)
+        dbg = torch.zeros(4 * 8 * 8 * 8, device=dev, dtype=torch.int64)
+        for _ in range(6):
+            ops.gemm_raw(A, D, W, D, C, n, Bq * R, n, D, bias=bias, act=act, tile=34, Ct=dbg.view(torch.bfloat16))
+        torch.cuda.synchronize()
+        raw = dbg.view(4, 8, 8, 8).cpu().double()
+        cyc = raw[..., 7] - raw[..., 6]
+        wall_ns = (raw[..., 2] - raw[..., 1]) * 10.0
+        ok = (raw[..., 0] != 0) & (wall_ns > 0)
+        out[name] = {"shader_clock_ghz": round(float((cyc[ok] / wall_ns[ok]).median()), 3),
+                     "cycles_per_k_tile": round(float((cyc[ok] / (D // 64)).median()))}
+    return out
+
+
+def source_sha(names) -> str:
     import hashlib
-    return hashlib.sha256(open(os.path.join(ROOT, "speechclip_plus_amd", "csrc", name), "rb").read()).hexdigest()
+    h = hashlib.sha256()
+    for name in names:
+        h.update(open(os.path.join(ROOT, "speechclip_plus_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
 
 
 def recall_parity(dev):

@@ -29,8 +29,8 @@ typedef uint16_t sc_bf16;
 
 const char* sc_last_error(void);
 int sc_abi_version(void);
-/* tuning switches for same-process A/B measurements (tools/); results never depend on them.  key 0: the 256-row GEMM leaves a
- * tile's output stores in flight across the next tile's first operand wait (default 1). */
+/* tuning switches for same-process A/B measurements (tools/); results never depend on them.  key 1: the 256- / 128-row GEMMs use
+ * plain instead of non-temporal stores on tiles with a residual. */
 int sc_set_option(int32_t key, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------
@@ -64,7 +64,9 @@ typedef struct {
     int32_t nb1, nb2;             /* batch = nb1*nb2 (>= 1 each) */
     int64_t sA1, sA2, sW1, sW2, sC1, sC2, sBias1, sBias2, sR1, sR2;
     int32_t tile;                 /* 0 auto | 1: 128x128 (4 waves) | 2: 256-row tile, 8 waves, width 256 or 192 by wave quantisation
-                                     (7 / 8 force 192 / 256) | 3: 128x64 */
+                                     (7 / 8 force 192 / 256) | 3: 128x64 | 9: 128-row tile, 4 waves, TWO workgroups per CU, width
+                                     256 or 192 (10 / 11 force 256 / 192): same wave block, K order and epilogue as 2, bit-identical
+                                     results; an alternative schedule kept for comparison, never chosen by 0 */
     int32_t reserved;             /* store policy of the bf16 C tile (256-row kernels): 0 auto = non-temporal stores when a residual
                                      is given (the output is the next residual stream, not re-read by this kernel; measured
                                      -3.5 % GEMM time per step), 1 always non-temporal, 2 never */

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(HERE, "..", "include"))
 LIB = os.path.join(CSRC, "libspeechclip_hip.so")
-SOURCES = ["sc_error.cpp", "hubert_layer.cpp", "gemm_bf16.hip", "gemm256_bf16.hip", "attention.hip", "attention_bwd.hip", "rowops.hip", "frontend.hip", "clspool.hip",
+SOURCES = ["sc_error.cpp", "hubert_layer.cpp", "gemm_bf16.hip", "gemm256_bf16.hip", "gemm128_bf16.hip", "attention.hip", "attention_bwd.hip", "rowops.hip", "frontend.hip", "clspool.hip",
            "loss_optim.hip", "headtail.hip", "backward.hip", "softmax.hip", "cif.hip", "vq.hip"]
 
 
@@ -20,7 +20,7 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "sc_common.h"), os.path.join(INCLUDE, "speechclip_hip.h")]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))] + [os.path.join(INCLUDE, "speechclip_hip.h")]
     objs = []
     procs = []
     for src in SOURCES:

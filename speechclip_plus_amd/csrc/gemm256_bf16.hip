@@ -154,6 +154,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             ((long long*)p.Ct)[(((blockIdx.x >> 6) * 8 + iter_) * 8 + wave) * 8 + (K)] = wall_clock64();     \
     } while (0)
 
+#define SC_STAMPC(K)                                                                                         \
+    do {                                                                                                     \
+        if (DIAG == 4 && (blockIdx.x & 63) == 0 && lane == 0 && iter_ < 8)                                   \
+            ((long long*)p.Ct)[(((blockIdx.x >> 6) * 8 + iter_) * 8 + wave) * 8 + (K)] = clock64();          \
+    } while (0)
+
 #define SC_MFMA_QUAD(MS, NS, BF)                                                                         \
     do {                                                                                                 \
         __builtin_amdgcn_s_setprio(1);                                                                   \
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         SC_STAMP(1);
+        SC_STAMPC(6);                                // shader-clock ticks around the K loop (tools/epi_stamps.py: clock under load)
         SC_BAR();
         if (wm == 1) SC_BAR();                       // stagger the second wave group by one barrier interval
 
@@ -255,6 +262,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         } while (++kt < nk);
         if (wm == 0) SC_BAR();                       // pairs the staggered group's last barrier
         SC_STAMP(2);
+        SC_STAMPC(7);
 
         // ---- next tile's K-tile 0 into the buffer the last K-tile did not use (its last reads are a K-tile old) ---------
         const int last_par = (nk - 1 + base) & 1;
@@ -281,197 +289,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             //      32 rows a pass: fragments -> LDS (fp32) -> full 16-B row chunks -> +residual -> bf16 stores ----------
             // lane id re-materialised through an opaque asm: everything below that depends only on the lane would otherwise be
             // hoisted out of the tile loop as loop-invariant and stay live across the K loop (VGPR budget: 256)
-            int el = lane;
-            asm volatile("" : "+v"(el));
-            float* Cw = (float*)(smem + last_par * BUF_BYTES + wave * EPI_BYTES);
-            const bool transposed = (p.n_split >= 0) && (cn0 >= p.n_split);
-            const int wn0 = cn0 + wn * TN;                // wave's first column
-            constexpr int CPR = TN / 8;                   // 8-column chunks per row
-            constexpr int TNP = TN == 48 ? 52 : TN;       // LDS row pitch in floats (48: padded against bank conflicts)
-            if (transposed) {
-                // V^T store (QKV GEMM, columns >= n_split): passes of 64 rows (m) x 32 columns (n) staged as [n][64 m] so a
-                // column's 64 consecutive frames leave as one full 128-B line; 16-B m-chunks XOR-swizzled by n & 15 (the 16
-                // lanes of a fragment row group write the same m-chunk of 16 different n: 256-B stride otherwise)
-                const int H = (p.N - p.n_split) / p.dh;
-#pragma unroll
-                for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                    for (int ng = 0; ng < (FN + 1) / 2; ++ng) {
-                        const int nfr = (FN - 2 * ng) < 2 ? (FN - 2 * ng) : 2;      // fragments (16 n each) in this pass
-#pragma unroll
-                        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                            for (int nj = 0; nj < 2; ++nj) {
-                                if (nj >= nfr) continue;
-                                f32x4 v = acc[mh * 4 + mi][ng * 2 + nj];
-                                if (ACT == 1) {
-                                    const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
-                                    v = f32x4{g0.x, g0.y, g1.x, g1.y};
-                                }
-                                const int ml = mi * 16 + (el & 15);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int nl = nj * 16 + 4 * (el >> 4) + r;
-                                    Cw[nl * 64 + (((ml >> 2) ^ (nl & 15)) << 2) + (ml & 3)] = v[r];
-                                }
-                            }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int it = 0; it < 4; ++it) {
-                            if (it >= 2 * nfr) continue;
-                            const int q = it * 64 + el;
-                            const int nrow = q >> 3, mc = q & 7;
-                            const int m = cm0 + wm * 128 + mh * 64 + mc * 8, n = wn0 + ng * 32 + nrow;
-                            if (m < p.M && n < p.N) {
-                                const f32x4 lo = *(const f32x4*)(Cw + nrow * 64 + (((2 * mc) ^ (nrow & 15)) << 2));
-                                const f32x4 hi = *(const f32x4*)(Cw + nrow * 64 + (((2 * mc + 1) ^ (nrow & 15)) << 2));
-                                const int nn = n - p.n_split, hh = nn / p.dh, d = nn % p.dh;
-                                const int b = m / p.R, t = m % p.R;
-                                uint16_t* dst = p.Ct + (((int64_t)b * H + hh) * p.dh + d) * p.R + t;
-                                uint4 o;
-                                o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]);
-                                o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
-                                *(uint4*)dst = o;
-                            }
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-            } else if (RES) {
-                // ---- tiles with a residual: staged through the wave's private 8 KiB of buffer last_par, 32 rows a pass, so that
-                // every store instruction writes FULL 128-byte rows (non-temporal: the output is the next residual stream and is
-                // read next by a LayerNorm pass) and every residual load is a full row too.  Measured against the register-direct
-                // form below on the out_proj / fc2 shapes: 60 vs 76 us / 138 vs 160 us.  Fragments go in as 16-byte chunks (a lane
-                // owns 4 consecutive columns of one row), chunk index XOR row & 15: conflict-free writes and reads.
-#pragma unroll
-                for (int ms = 0; ms < 4; ++ms) {
-                    const int wm0 = cm0 + wm * 128 + ms * 32;
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < FN; ++ni) {
-                            f32x4 v = acc[ms * 2 + mi][ni];
-                            if (ACT == 1) {
-                                const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
-                                v = f32x4{g0.x, g0.y, g1.x, g1.y};
-                            }
-                            const int ml = mi * 16 + (el & 15), ch = ni * 4 + (el >> 4);
-                            *(f32x4*)(Cw + ml * 64 + ((ch ^ (ml & 15)) << 2)) = v;
-                        }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int it = 0; it < CPR / 2; ++it) {
-                        const int q = it * 64 + el;
-                        const int row = q / CPR, cc = q % CPR;
-                        const int m = wm0 + row, n = wn0 + cc * 8;
-                        if (m < p.M && n + 8 <= p.N) {
-                            const f32x4 lo = *(const f32x4*)(Cw + row * 64 + (((2 * cc) ^ (row & 15)) << 2));
-                            const f32x4 hi = *(const f32x4*)(Cw + row * 64 + (((2 * cc + 1) ^ (row & 15)) << 2));
-                            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            if (DROP) {
-                                const uint32_t keep = sc_keep8((uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_seed, drop_thr);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * drop_scale : 0.f;
-                            }
-                            if (Rs) {
-                                const uint4 rv = *(const uint4*)(Rs + (int64_t)m * p.ldr + n);
-                                v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
-                                v[4] += bflo(rv.z); v[5] += bfhi(rv.z); v[6] += bflo(rv.w); v[7] += bfhi(rv.w);
-                            }
-                            if (p.out_f32) {
-                                float* C = (float*)p.C + coff + (int64_t)m * p.ldc + n;
-                                *(f32x4*)C = f32x4{v[0], v[1], v[2], v[3]};
-                                *(f32x4*)(C + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                            } else {
-                                uint16_t* C = (uint16_t*)p.C + coff + (int64_t)m * p.ldc + n;
-                                uint4 o;
-                                o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                                o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-                                if (p.reserved & 1) {
-                                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-                                    __builtin_nontemporal_store(u32x4{o.x, o.y, o.z, o.w}, (u32x4*)C);
-                                } else {
-                                    *(uint4*)C = o;
-                                }
-                            }
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                // ---- register-direct epilogue.  Per output row m (one lane) and fragment PAIR (2p, 2p + 1): after
-                // v_permlane16_swap the lanes of even lane-rows (lane / 16 = 0, 2) hold 8 consecutive columns of fragment 2p, the
-                // odd ones 8 consecutive columns of fragment 2p + 1: GELU, dropout, residual and one 16-byte store per lane, with
-                // no LDS round trip and no wait between fragments (the VALU stream of the GELU and the store issue overlap).
-                // Tiles WITHOUT a residual only (GELU / conv / QKV / projection launches: 3 - 5 % faster than the staged form).
-                const int g = el >> 4, l15 = el & 15;
-                const int coff8 = ((g >> 1) << 3) + ((g & 1) << 4);
-                auto finish8 = [&](float (&v)[8], int m, int n) {
-                    if (m < p.M && n + 8 <= p.N) {
-                        if (DROP) {                      // train-mode dropout before the residual add (F.dropout semantics)
-                            const uint32_t keep = sc_keep8((uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_seed, drop_thr);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * drop_scale : 0.f;
-                        }
-                        if (p.out_f32) {
-                            float* C = (float*)p.C + coff + (int64_t)m * p.ldc + n;
-                            *(f32x4*)C = f32x4{v[0], v[1], v[2], v[3]};
-                            *(f32x4*)(C + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                        } else {
-                            uint16_t* C = (uint16_t*)p.C + coff + (int64_t)m * p.ldc + n;
-                            uint4 o;
-                            o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                            o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-                            *(uint4*)C = o;              // plain stores: the L2 merges a row's two 64-byte halves
-                        }
-                    }
-                };
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
-                    const int m = cm0 + wm * 128 + mi * 16 + l15;
-#pragma unroll
-                    for (int pr = 0; pr < FN / 2; ++pr) {
-                        f32x4 Fv = acc[mi][2 * pr], Gv = acc[mi][2 * pr + 1];
-                        if (ACT == 1) {
-                            const f32x2 a0 = gelu_erf2(f32x2{Fv[0], Fv[1]}), a1 = gelu_erf2(f32x2{Fv[2], Fv[3]});
-                            const f32x2 b0 = gelu_erf2(f32x2{Gv[0], Gv[1]}), b1 = gelu_erf2(f32x2{Gv[2], Gv[3]});
-                            Fv = f32x4{a0.x, a0.y, a1.x, a1.y};
-                            Gv = f32x4{b0.x, b0.y, b1.x, b1.y};
-                        }
-                        float v[8];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {    // odd lane-rows of F <-> even lane-rows of G
-                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(Fv[r]), __float_as_uint(Gv[r]), false, false);
-                            v[r] = __uint_as_float(sw[0]);
-                            v[4 + r] = __uint_as_float(sw[1]);
-                        }
-                        finish8(v, m, wn0 + pr * 32 + coff8);
-                    }
-                    if ((FN & 1) && (mi & 1)) {
-                        // 192-wide tiles: the odd (third) fragment is paired ACROSS two row blocks - after the exchange the even
-                        // lane-rows hold 8 consecutive columns of row block mi - 1, the odd ones 8 consecutive columns of row
-                        // block mi: 16-byte stores here too
-                        f32x4 Fv = acc[mi - 1][FN - 1], Gv = acc[mi][FN - 1];
-                        if (ACT == 1) {
-                            const f32x2 a0 = gelu_erf2(f32x2{Fv[0], Fv[1]}), a1 = gelu_erf2(f32x2{Fv[2], Fv[3]});
-                            const f32x2 b0 = gelu_erf2(f32x2{Gv[0], Gv[1]}), b1 = gelu_erf2(f32x2{Gv[2], Gv[3]});
-                            Fv = f32x4{a0.x, a0.y, a1.x, a1.y};
-                            Gv = f32x4{b0.x, b0.y, b1.x, b1.y};
-                        }
-                        float v[8];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(Fv[r]), __float_as_uint(Gv[r]), false, false);
-                            v[r] = __uint_as_float(sw[0]);
-                            v[4 + r] = __uint_as_float(sw[1]);
-                        }
-                        finish8(v, m - ((g & 1) ? 0 : 16), wn0 + (FN - 1) * 16 + ((g >> 1) << 3));
-                    }
-                }
-            }
+#include "gemm_epilogue.inc"
         }
         SC_STAMP(5);
         ++iter_;

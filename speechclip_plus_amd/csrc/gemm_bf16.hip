@@ -262,6 +262,8 @@ int launch(const sc_gemm_args& a, hipStream_t s) {
 }  // namespace
 
 int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s);    // gemm256_bf16.hip
+int sc_gemm128_launch(const sc_gemm_args& a, hipStream_t s);    // gemm128_bf16.hip
+bool sc_gemm128_fits(const sc_gemm_args& a);
 
 extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     SC_CHECK(args != nullptr, "sc_gemm_bf16: null args");
@@ -304,6 +306,11 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
             SC_CHECK(a.n_split < 0 || a.n_split % 192 == 0 || a.n_split % 256 == 0,
                      "sc_gemm_bf16: 256-row tiles need n_split %% 192 == 0 or %% 256 == 0");
             return sc_gemm256_launch(a, s);
+        case 9: case 10: case 11: case 33:          // 128-row tile, two workgroups per CU; 10 / 11 force the width (256 / 192)
+            SC_CHECK(a.n_split < 0 || a.n_split % 192 == 0 || a.n_split % 256 == 0,
+                     "sc_gemm_bf16: 128-row duo tiles need n_split %% 192 == 0 or %% 256 == 0");
+            SC_CHECK(sc_gemm128_fits(a), "sc_gemm_bf16: operands beyond the 32-bit offsets of the 128-row duo kernel");
+            return sc_gemm128_launch(a, s);
         case 3:
             SC_CHECK(a.n_split < 0, "sc_gemm_bf16: 128x64 tile has no transposed store");
             return launch<128, 64>(a, s);

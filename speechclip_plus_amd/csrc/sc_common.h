@@ -114,7 +114,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // host side
 void sc_set_error(const char* fmt, ...);
 int sc_num_cus();   // compute units of the current device (immutable cache; 256 on MI355X)
-int sc_option(int key);   // tuning switches (sc_set_option): 0 = gemm256 leaves the previous tile's stores in flight (default 1)
+int sc_option(int key);   // tuning switches (sc_set_option): 1 = plain stores on residual tiles of the 256- / 128-row GEMMs
 #define SC_CHECK(cond, ...)                 \
     do {                                    \
         if (!(cond)) {                      \

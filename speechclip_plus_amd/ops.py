@@ -71,7 +71,7 @@ def gemm_tile_name(M: int, N: int, K: int, n_split: int, batch: int, tile: int =
             tile = 2
         else:
             tile = 1
-    return {1: "128x128", 2: "256x256", 3: "128x64", 7: "256x256", 8: "256x256"}.get(tile, "diag")
+    return {1: "128x128", 2: "256x256", 3: "128x64", 7: "256x256", 8: "256x256", 9: "128x256_duo", 10: "128x256_duo", 11: "128x256_duo"}.get(tile, "diag")
 
 
 def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tensor, ldc: int, M: int, N: int, K: int,

@@ -24,6 +24,7 @@ for a in sys.argv[2:]:
         key, vals = a[3:].split("=")
         optab = (int(key), [int(v) for v in vals.split(",")])
 from speechclip_plus_amd._lib import lib as _lib
+base_tile = int(sys.argv[1].split(",")[0]) if len(sys.argv) > 1 else 0
 if optab:
     tiles = optab[1]
 rounds = 5
@@ -43,7 +44,7 @@ for name, m, n, k, lda, act, res in shapes:
             if optab:
                 _lib().sc_set_option(optab[0], t)
             for _ in range(3):
-                ops.gemm_raw(A, lda, W, k, Cm, n, m, n, k, bias=bias, residual=Rm, ldr=n, act=act, tile=0 if optab else t)
+                ops.gemm_raw(A, lda, W, k, Cm, n, m, n, k, bias=bias, residual=Rm, ldr=n, act=act, tile=base_tile if optab else t)
             e1.record()
             torch.cuda.synchronize()
             if r > 0:

@@ -27,7 +27,10 @@ for k in f:
 # provenance: bench.py reports these counters only while the kernel source they were measured on is the tree's
 import hashlib, os
 _csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speechclip_plus_amd", "csrc")
-res["_meta"] = {"kernel_source_sha256": hashlib.sha256(open(os.path.join(_csrc, "gemm256_bf16.hip"), "rb").read()).hexdigest(),
+_h = hashlib.sha256()
+for _n in ("gemm256_bf16.hip", "gemm_epilogue.inc"):
+    _h.update(open(os.path.join(_csrc, _n), "rb").read())
+res["_meta"] = {"kernel_source_sha256": _h.hexdigest(),
                 "command": "python3 bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-recall"}
 json.dump(res, open(out + "_traffic.json", "w"), indent=1, sort_keys=True)
 rows = list(csv.DictReader(open(stats_csv)))
