@@ -159,6 +159,15 @@ int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, const float
 int sc_posconv_prep(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_bf16* xg, int32_t B, int32_t R,
                     int32_t D, int32_t G, int32_t halo, void* stream);
 
+/* HuBERT positional convolution on the slab layout above + bias + GELU + residual (speech_encoder_plus.py:32-37: grouped Conv1d,
+ * kernel Kp = 128, padding 64, SamePad drops the last frame):
+ *   out[b*R + t, g*Dg + n] = gelu(bias[g*Dg + n] + sum_j sum_ci w[g][n][j*Dg + ci] * xg[g][b][t + j][ci]) + residual[b*R + t, g*Dg + n]
+ * w [G, Dg, Kp*Dg] tap-major per group, Dg = D / G in {48, 64}, Rp = rows of an xg slab (>= R + Kp - 1).  The input slab of a
+ * (group, utterance, 512-frame block) stays in LDS for all taps; only the weights stream.  Same arithmetic as the sc_gemm_bf16
+ * formulation (lda = Dg, K = Kp*Dg, act = 1, residual): bit-identical results. */
+int sc_posconv_bf16(const sc_bf16* xg, const sc_bf16* w, const float* bias, const sc_bf16* residual, sc_bf16* out, int32_t B,
+                    int32_t R, int32_t D, int32_t G, int32_t Kp, int32_t Rp, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weighted sum over hidden states (avssl/module/weighted_sum.py:26-45).
  *   h    [NL, B*R, D] bf16 ; w [NL] fp32 = softmax(weights) (host computes the 13-element softmax)

@@ -538,6 +538,23 @@ def posconv_prep(x: torch.Tensor, valid_len: torch.Tensor, xz: torch.Tensor, xg:
     check(lib().sc_posconv_prep(_p(x), _p(valid_len), _p(xz), _p(xg), B, R, D, G, halo, _stream()), "sc_posconv_prep")
 
 
+def posconv(xg: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor], out: torch.Tensor,
+            B: int, R: int, D: int, G: int, Kp: int, alg_rows: Optional[int] = None) -> None:
+    """HuBERT positional convolution + bias + GELU + residual on the slab layout of ``posconv_prep`` (sc_posconv_bf16):
+    xg [G, B, Rp, D/G] bf16, w [G, D/G, Kp*D/G] bf16 tap-major, out / residual [B*R, D] bf16."""
+    assert xg.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+    assert xg.is_contiguous() and w.is_contiguous() and out.is_contiguous() and xg.shape[0] == G and xg.shape[1] == B
+    Rp = xg.shape[2]
+    if _timer is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().sc_posconv_bf16(_p(xg), _p(w), _p(bias), _p(residual), _p(out), B, R, D, G, Kp, Rp, _stream()), "sc_posconv_bf16")
+    if _timer is not None:
+        ev1.record()
+        rows = R if alg_rows is None else alg_rows
+        _timer.add("posconv", ev0, ev1, 2.0 * B * rows * D * Kp * (D // G))
+
+
 def wsum_fwd(h: torch.Tensor, w_softmax: torch.Tensor, out: torch.Tensor, B: int, R: int, D: int, row_off: int,
              normalize: bool = False) -> None:
     NL = h.shape[0]

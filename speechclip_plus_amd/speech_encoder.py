@@ -435,9 +435,13 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         G, Kp = a.pos_conv_groups, a.pos_conv_kernel
         Dg, Rp = D // G, R + 2 * pl.halo
         ops.posconv_prep(pl.x_proj, pl.valid, pl.xz, pl.xg, B, R, D, G, pl.halo)
-        ops.gemm_raw(pl.xg, Dg, w["pos_w"], Kp * Dg, pl.pre, D, R, Dg, Kp * Dg, bias=w["pos_b"], residual=pl.xz, ldr=D,
-                     act=1, nb1=G, nb2=B, sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, R * D),
-                     sBias=(Dg, 0), sR=(Dg, R * D), alg_rows=T)
+        if Dg in (48, 64) and Kp == 128:
+            # the input slab of a (group, utterance) stays in LDS for all 128 taps (csrc/posconv.hip); same arithmetic as the GEMM below
+            ops.posconv(pl.xg, w["pos_w"], w["pos_b"], pl.xz, pl.pre, B, R, D, G, Kp, alg_rows=T)
+        else:
+            ops.gemm_raw(pl.xg, Dg, w["pos_w"], Kp * Dg, pl.pre, D, R, Dg, Kp * Dg, bias=w["pos_b"], residual=pl.xz, ldr=D,
+                         act=1, nb1=G, nb2=B, sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, R * D),
+                         sBias=(Dg, 0), sR=(Dg, R * D), alg_rows=T)
 
     @torch.no_grad()
     def _layers(self, pl, w, seeds, sd, p_res, p_att, save, scale, first_hidden_done) -> None:

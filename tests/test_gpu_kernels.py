@@ -179,6 +179,37 @@ def test_gemm_transposed_store_and_batch(dev):
     assert rel_l2(out, ref) < 6e-3
 
 
+@pytest.mark.parametrize("D,G,R,B", [(768, 16, 512, 3), (768, 16, 256, 2), (768, 16, 640, 2), (1024, 16, 384, 2)])
+def test_posconv_slab_kernel(dev, D, G, R, B):
+    """sc_posconv_bf16 (input slab resident in LDS, weights streamed) against fp32 grouped Conv1d (fairseq pos_conv + SamePad + GELU +
+    residual) and, bit for bit, against the sc_gemm_bf16 formulation it replaces; full and partial 512-frame blocks, Dg = 48 and 64."""
+    ops = _ops()
+    Kp, Dg = 128, D // G
+    halo = Kp // 2
+    Rp = R + 2 * halo
+    g = torch.Generator(device="cpu").manual_seed(D + R)
+    x = bf(torch.randn(B, R, D, generator=g)).to(dev)
+    lens = [R, max(1, R - 37), 5][:B]
+    for b, n in enumerate(lens):
+        x[b, n:] = 0                                                       # padded frames are zero (posconv_prep's contract)
+    wconv = bf(torch.randn(D, Dg, Kp, generator=g) * (Dg * Kp) ** -0.5).to(dev)   # Conv1d weight [out, in / groups, k]
+    bias = torch.randn(D, generator=g).to(dev)
+    valid = torch.tensor(lens, dtype=torch.int32, device=dev)
+    xz = torch.empty(B * R, D, device=dev, dtype=torch.bfloat16)
+    xg = torch.zeros(G, B, Rp, Dg, device=dev, dtype=torch.bfloat16)
+    ops.posconv_prep(x.view(B * R, D), valid, xz, xg, B, R, D, G, halo)
+    w = wconv.reshape(G, Dg, Dg, Kp).permute(0, 1, 3, 2).reshape(G, Dg, Kp * Dg).contiguous()     # tap-major per group
+    out = torch.full((B * R, D), 7.0, device=dev, dtype=torch.bfloat16)
+    ops.posconv(xg, w, bias, xz, out, B, R, D, G, Kp)
+    ref = F.conv1d(x.float().transpose(1, 2), wconv.float(), bias, padding=halo, groups=G)[:, :, :R].transpose(1, 2)
+    ref = (F.gelu(ref) + x.float()).reshape(B * R, D)
+    assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
+    out_g = torch.zeros(B * R, D, device=dev, dtype=torch.bfloat16)
+    ops.gemm_raw(xg, Dg, w, Kp * Dg, out_g, D, R, Dg, Kp * Dg, bias=bias, residual=xz, ldr=D, act=1, nb1=G, nb2=B,
+                 sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, R * D), sBias=(Dg, 0), sR=(Dg, R * D))
+    assert torch.equal(out, out_g), "same k order, bias-initialised accumulators, GELU and rounding as the GEMM formulation"
+
+
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("R,lens", [(128, [128, 1, 37]), (256, [200, 256, 65]), (512, [499, 300, 33])])
 def test_attention(dev, R, lens):
