@@ -76,6 +76,16 @@ static void run(unsigned short* C, int M, int N, const char* name, int cus = 256
 }
 
 int main() {
+    {   // a 2.1 GB output (conv layer 0's): does the write rate hold beyond the Infinity Cache / TLB reach?
+        unsigned short* C;
+        const int Mb = 2048000, Nb = 512;
+        CK(hipMalloc(&C, (size_t)Mb * Nb * 2));
+        CK(hipMemset(C, 0, (size_t)Mb * Nb * 2));
+        run<1, 0>(C, Mb, Nb, "8 rows x 128 B (full lines)");
+        run<1, 1>(C, Mb, Nb, "8 rows x 128 B, nontemporal");
+        run<0, 0>(C, Mb, Nb, "16 rows x 64 B");
+        CK(hipFree(C));
+    }
     const int M = 32768;
     for (int N : {768, 2304, 3072}) {
         unsigned short* C;
