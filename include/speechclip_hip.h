@@ -319,6 +319,10 @@ int sc_act_bf16(const sc_bf16* u, const sc_bf16* df, sc_bf16* out, int64_t n, in
  *                       fairseq's encoder dropout after pos_conv + LayerNorm (speech_encoder_plus.py:41), train mode only */
 int sc_dropout_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* out, int64_t ldo, int64_t rows, int32_t D, float p, uint32_t seed,
                     void* stream);
+/* the multiplier F.dropout applies, as fp32: out[i] = keep(i, seed) ? 1 / (1 - p) : 0, keep = the stateless hash mask above
+ * (element index i); n % 8 == 0.  The CLS head's four masks (nn.TransformerEncoderLayer dropout / dropout1 / dropout2 and the
+ * attention-weight dropout, avssl/module/kw_modules/TransformerModels.py:61-81) are products with these. */
+int sc_dropout_mult_f32(float* out, int64_t n, float p, uint32_t seed, void* stream);
 int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int64_t ldy, int32_t rows, int32_t cols,
                       float* colsum_partial /* NULL, or [ceil(rows / 64), cols] fp32: per-64-row-block column sums of x */, void* stream);
 int sc_colsum_bf16(const sc_bf16* x, int64_t ldx, int64_t rows, int32_t cols, float* partial, int32_t nblk, void* stream);

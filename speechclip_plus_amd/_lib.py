@@ -67,6 +67,7 @@ SIGNATURES = {
     "sc_conv0_gn_gelu": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "sc_conv0_ln_gelu": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p],
     "sc_posconv_prep": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_dropout_mult_f32": [c_void_p, c_i64, c_float, ctypes.c_uint32, c_void_p],
     "sc_posconv_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "sc_wsum_fwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "sc_wsum_bwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

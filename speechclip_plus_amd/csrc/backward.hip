@@ -165,7 +165,33 @@ __global__ void dropout_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint
     *(uint4*)(out + row * ldo + c) = o;
 }
 
+// out[i] = keep(i) ? 1 / (1 - p) : 0  (the multiplier F.dropout applies), same stateless hash as everywhere else: one launch in place of
+// rand + compare + cast + scale
+__global__ void dropout_mult_kernel(float* __restrict__ out, int64_t n8, uint32_t thr, float scale, uint32_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const uint32_t keep = sc_keep8((uint32_t)(i * 8), seed, thr);
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a[e] = (keep >> e) & 1u ? scale : 0.f;
+        b[e] = (keep >> (4 + e)) & 1u ? scale : 0.f;
+    }
+    *(f32x4*)(out + i * 8) = a;
+    *(f32x4*)(out + i * 8 + 4) = b;
+}
+
 }  // namespace
+
+extern "C" int sc_dropout_mult_f32(float* out, int64_t n, float p, uint32_t seed, void* stream) {
+    SC_CHECK(out && n > 0 && n % 8 == 0 && n < ((int64_t)1 << 32) && ((uintptr_t)out % 16) == 0, "sc_dropout_mult_f32: n=%lld must be a positive multiple of 8 below 2^32, out 16-byte aligned", (long long)n);
+    SC_CHECK(p >= 0.f && p < 1.f, "sc_dropout_mult_f32: p=%f", (double)p);
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(dropout_mult_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n8,
+                       (uint32_t)(p * 65536.f + 0.5f), 1.f / (1.f - p), seed);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int sc_dropout_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* out, int64_t ldo, int64_t rows, int32_t D, float p, uint32_t seed,
                                void* stream) {

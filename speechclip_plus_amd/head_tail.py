@@ -84,7 +84,7 @@ class ParallelHeadFn(torch.autograd.Function):
         ops.sgemm_ex(Qm, (D, 1, 0), Wk, (1, D, 0), a, D, H, D, D, alpha=dh ** -0.5)
         scores = ops.cls_scores(src, a, False, B, R, D, H)
         pd = float(module.dropout) if module.training else 0.0
-        mk = (lambda *shape: (torch.rand(*shape, device=dev) >= pd).float().mul_(1.0 / (1.0 - pd))) if pd > 0 else None
+        mk = (lambda *shape: ops.dropout_mult(shape, pd, dev)) if pd > 0 else None      # one launch per mask (was rand / compare / cast / scale)
         mult = mk(B, H, R) if mk else None
         p, m = ops.cls_pool_fwd(src, scores, lens, B, R, D, H, mult)   # m [B, H, D]
         # ---- value projection per head (softmax sums to 1 => + bv), out_proj, post-LN layer on B rows

@@ -268,6 +268,22 @@ def dropout_bf16(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tenso
     return out
 
 
+_mult_calls = [0]
+
+
+def dropout_mult(shape, p: float, device) -> torch.Tensor:
+    """fp32 multiplier of F.dropout(., p) for a tensor of ``shape`` (numel a multiple of 8): keep ? 1 / (1 - p) : 0, one launch.  The
+    seed is a function of torch's seed and a call counter (reproducible under torch.manual_seed, no device RNG state)."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    out = torch.empty(n, device=device, dtype=torch.float32)
+    _mult_calls[0] += 1
+    seed = ((torch.initial_seed() * 0x9E3779B1) ^ (_mult_calls[0] * 0x85EBCA6B)) & 0xffffffff
+    check(lib().sc_dropout_mult_f32(_p(out), n, float(p), seed, _stream()), "sc_dropout_mult_f32")
+    return out.view(*shape)
+
+
 def cif_fwd(x: torch.Tensor, alpha: torch.Tensor, csum: torch.Tensor, T: int, thr: float) -> torch.Tensor:
     """integrate-and-fire accumulation: x [B,S,C] fp32, alpha / csum [B,S] fp32 -> out [B,T+1,C] (see sc_cif_fwd)."""
     B, S, C = x.shape

@@ -179,6 +179,24 @@ def test_gemm_transposed_store_and_batch(dev):
     assert rel_l2(out, ref) < 6e-3
 
 
+def test_dropout_multiplier(dev):
+    """sc_dropout_mult_f32: values in {0, 1 / (1 - p)}, the same mask bits as the bf16 dropout kernel for the same seed, a fresh
+    mask per call, reproducible under torch.manual_seed."""
+    ops = _ops()
+    p, n = 0.1, 64 * 768
+    torch.manual_seed(11)
+    a = ops.dropout_mult((64, 768), p, dev)
+    b = ops.dropout_mult((64, 768), p, dev)
+    assert set(torch.unique(a).tolist()) == {0.0, float(torch.tensor(1.0 / (1.0 - p), dtype=torch.float32))}
+    assert abs(float((a > 0).float().mean()) - (1 - p)) < 0.01 and not torch.equal(a, b)
+    # same bits as sc_dropout_bf16 on a tensor of ones with the seed the call used
+    calls = ops._mult_calls[0]
+    seed = ((torch.initial_seed() * 0x9E3779B1) ^ (calls * 0x85EBCA6B)) & 0xffffffff
+    ones = torch.ones(64, 768, device=dev, dtype=torch.bfloat16)
+    ref = ops.dropout_bf16(ones, p, seed)
+    assert torch.equal(ref > 0, b > 0)
+
+
 @pytest.mark.parametrize("D,G,R,B", [(768, 16, 512, 3), (768, 16, 256, 2), (768, 16, 640, 2), (1024, 16, 384, 2)])
 def test_posconv_slab_kernel(dev, D, G, R, B):
     """sc_posconv_bf16 (input slab resident in LDS, weights streamed) against fp32 grouped Conv1d (fairseq pos_conv + SamePad + GELU +
@@ -431,8 +449,9 @@ def test_parallel_branch_golden(dev, golden, name):
 
 def test_parallel_branch_train_mode_dropout_vs_oracle(dev, golden):
     """Train mode of the CLS head (the four dropout sites of nn.TransformerEncoderLayer, p = 0.1 in the recipes; p = 0.3 here)
-    against the oracle's train-mode restatement fed the SAME masks: they are drawn from torch's device generator in a fixed
-    order (head_tail.ParallelHeadFn), so re-seeding reproduces them.  Output, feature / cls / parameter gradients."""
+    against the oracle's train-mode restatement fed the SAME masks: stateless hash masks drawn in a fixed order
+    (head_tail.ParallelHeadFn -> ops.dropout_mult), a function of torch's seed and a call counter, so rewinding the counter
+    reproduces them.  Output, feature / cls / parameter gradients."""
     import oracle
     from conftest import weights_from
     from speechclip_plus_amd import Config, KW_ParallelBranch
@@ -450,11 +469,13 @@ def test_parallel_branch_train_mode_dropout_vs_oracle(dev, golden):
     B, T = feat.shape[:2]
     R = (T + 1 + 127) // 128 * 128
     torch.manual_seed(77)
+    ops = _ops()
+    calls0 = ops._mult_calls[0]                    # the masks are a function of torch's seed and this call counter (ops.dropout_mult)
     out = br(audio_feat=feat, audio_feat_len=alen.to(dev))["parallel_audio_feat"]
     gout = torch.from_numpy(fx["gout"]).to(dev)
     (out * gout).sum().backward()
-    torch.manual_seed(77)
-    mk = lambda *shape: ((torch.rand(*shape, device=dev) >= pd).float() / (1.0 - pd)).cpu()
+    ops._mult_calls[0] = calls0
+    mk = lambda *shape: ops.dropout_mult(shape, pd, dev).cpu()
     mult, k1, kf, k2 = mk(B, nhead, R), mk(B, D), mk(B, Fd), mk(B, D)
     assert 0.5 < float((mult > 0).float().mean()) < 0.9
     row0 = {"dropout1": k1, "dropout": kf, "dropout2": k2}
