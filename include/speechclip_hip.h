@@ -333,9 +333,7 @@ int sc_colsum_bf16(const sc_bf16* x, int64_t ldx, int64_t rows, int32_t cols, fl
  *   avssl/module/kw_modules/TransformerModels.py:48-97 and consumed at avssl/model/kw_branches.py:266-280.
  *   sc_sgemm_f32_ex : C[z][i,j] = alpha sum_k A[z][i*sai + k*sak] B[z][j*sbj + k*sbk] (+ bias[z][j]) + beta C[z][i,j]
  *                     (beta = 1 accumulates weight gradients straight into the flat gradient buffer; with a workspace,
- *                     few-tile products are split along K: every slice writes its partial tile, the last slice of a tile to
- *                     arrive adds them in slice order and applies the epilogue - one launch, order-independent result.  The
- *                     workspace's first 128 words are the arrival counters: ZERO them once; every launch leaves them zero)
+ *                     few-tile products are split along K and the slices reduced in order)
  *   sc_rowln_f32_fwd: y = LayerNorm(x + res) gamma + beta ; res_stride 0 broadcasts one residual row (the CLS token)
  *   sc_rowln_f32_bwd: dx ; dgamma += sum_rows dy xhat ; dbeta += sum_rows dy   (fixed row order, no atomics)
  *   sc_gelu_f32     : df == NULL: out = gelu(u) (erf form) ; else out = df * gelu'(u)

@@ -19,11 +19,9 @@ __global__ __launch_bounds__(256) void sgemm_ex_kernel(const float* __restrict__
                                                        const float* __restrict__ Bm, int64_t sbj, int64_t sbk, int64_t sbz,
                                                        float* __restrict__ C, int64_t ldc, int64_t scz, int M, int N, int K,
                                                        float alpha, float beta, const float* __restrict__ bias,
-                                                       int64_t sbiasz, int S, int Kc, float* __restrict__ P,
-                                                       unsigned int* __restrict__ tickets) {
+                                                       int64_t sbiasz, int S, int Kc, float* __restrict__ P) {
     __shared__ __attribute__((aligned(16))) float As[TK][TS + 4];
     __shared__ __attribute__((aligned(16))) float Bs[TK][TS + 4];
-    __shared__ int last_flag;
     // split-K: blockIdx.z = z * S + ks ; slice ks reduces k in [ks Kc, min(K, (ks + 1) Kc)) into the workspace P[ks][z][M][N]
     const int z = blockIdx.z / S, ks = blockIdx.z - z * S;
     A += z * saz + (int64_t)ks * Kc * sak;
@@ -102,44 +100,6 @@ __global__ __launch_bounds__(256) void sgemm_ex_kernel(const float* __restrict__
         }
         __syncthreads();
     }
-    const int nbatch = gridDim.z / S;
-    if (S > 1) {
-        // split-K: the slice's partial tile goes to the workspace; the LAST slice of this output tile to arrive (ticket) adds the S
-        // partials in slice order - the sum does not depend on which one that was - and applies the epilogue: no second launch
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int gi = i0 + ty * 4 + a;
-            if (gi >= M) continue;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int gj = j0 + tx * 4 + b;
-                if (gj < N) P[(((int64_t)ks * nbatch + z) * M + gi) * N + gj] = acc[a][b];
-            }
-        }
-        __threadfence();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            unsigned int* tk = tickets + ((z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
-            const unsigned int t = atomicAdd(tk, 1u);
-            last_flag = (t == (unsigned)S - 1);
-            if (last_flag) *tk = 0;                   // ready for the next launch on this stream
-        }
-        __syncthreads();
-        if (!last_flag) return;
-        __threadfence();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int gi = i0 + ty * 4 + a, gj = j0 + tx * 4 + b;
-                float v = 0.f;
-                if (gi < M && gj < N)
-                    for (int s2 = 0; s2 < S; ++s2) v += P[(((int64_t)s2 * nbatch + z) * M + gi) * N + gj];
-                acc[a][b] = v;
-            }
-    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int gi = i0 + ty * 4 + a;
@@ -148,11 +108,32 @@ __global__ __launch_bounds__(256) void sgemm_ex_kernel(const float* __restrict__
         for (int b = 0; b < 4; ++b) {
             const int gj = j0 + tx * 4 + b;
             if (gj >= N) continue;
+            if (S > 1) {
+                P[(((int64_t)ks * gridDim.z / S + z) * M + gi) * N + gj] = acc[a][b];
+                continue;
+            }
             float v = alpha * acc[a][b] + (bias ? bias[gj] : 0.f);
             if (beta != 0.f) v += beta * C[gi * ldc + gj];
             C[gi * ldc + gj] = v;
         }
     }
+}
+
+// C[z][i, j] = alpha * sum_s P[s][z][i][j] (+ bias[z][j]) + beta * C[z][i, j]   (slices added in order: deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ P, int S, int nbatch, int M, int N, float* __restrict__ C,
+                                     int64_t ldc, int64_t scz, float alpha, float beta, const float* __restrict__ bias,
+                                     int64_t sbiasz) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, per = (int64_t)M * N, total = per * nbatch;
+    if (e >= total) return;
+    const int z = (int)(e / per);
+    const int64_t r = e - z * per;
+    const int i = (int)(r / N), j = (int)(r - (int64_t)i * N);
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += P[(int64_t)s * total + e];
+    v = alpha * v + (bias ? bias[z * sbiasz + j] : 0.f);
+    float* c = C + z * scz + (int64_t)i * ldc + j;
+    if (beta != 0.f) v += beta * *c;
+    *c = v;
 }
 
 // ---------------------------------------------------------------------------------------------- row LayerNorm
@@ -298,11 +279,10 @@ extern "C" int sc_sgemm_f32_ex(const float* A, int64_t sai, int64_t sak, int64_t
     // enough workgroups to cover the chip, partial sums through the caller's workspace, slices reduced in order
     const int tiles = ((N + TS - 1) / TS) * ((M + TS - 1) / TS) * nbatch;
     int S = 1;
-    constexpr int NTICKET = 128;                     // first words of the workspace: one arrival counter per output tile
-    if (workspace && tiles < NTICKET && K >= 256 && workspace_floats > NTICKET) {
+    if (workspace && tiles < 128 && K >= 256) {
         S = std::min((sc_num_cus() + tiles - 1) / tiles, K / 64);
         const int64_t per = (int64_t)M * N * nbatch;
-        S = (int)std::min<int64_t>(S, (workspace_floats - NTICKET) / per);
+        S = (int)std::min<int64_t>(S, workspace_floats / per);
         if (S < 2) S = 1;
     }
     int Kc = K;
@@ -312,8 +292,14 @@ extern "C" int sc_sgemm_f32_ex(const float* A, int64_t sai, int64_t sak, int64_t
     }
     dim3 grid((N + TS - 1) / TS, (M + TS - 1) / TS, nbatch * S);
     hipLaunchKernelGGL(sgemm_ex_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, sai, sak, saz, Bm, sbj, sbk, sbz, C, ldc, scz,
-                       M, N, K, alpha, beta, bias, sbiasz, S, Kc, workspace ? workspace + NTICKET : nullptr, (unsigned int*)workspace);
+                       M, N, K, alpha, beta, bias, sbiasz, S, Kc, workspace);
     SC_LAUNCH_CHECK();
+    if (S > 1) {
+        const int64_t total = (int64_t)M * N * nbatch;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace,
+                           S, nbatch, M, N, C, ldc, scz, alpha, beta, bias, sbiasz);
+        SC_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -690,11 +690,10 @@ _SPLITK_WS = {}
 
 
 def _splitk_workspace(device) -> torch.Tensor:
-    """Per-device scratch for split-K partial sums (8 Mi floats; calls on one stream are serialised, so one buffer serves).  Zeroed
-    once: its first 128 words are the arrival counters of sc_sgemm_f32_ex's in-kernel slice merge, which every launch leaves zero."""
+    """Per-device scratch for split-K partial sums (8 Mi floats; calls on one stream are serialised, so one buffer serves)."""
     ws = _SPLITK_WS.get(device)
     if ws is None:
-        ws = _SPLITK_WS[device] = torch.zeros(8 << 20, device=device, dtype=torch.float32)
+        ws = _SPLITK_WS[device] = torch.empty(8 << 20, device=device, dtype=torch.float32)
     return ws
 
 
