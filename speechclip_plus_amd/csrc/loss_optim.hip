@@ -173,19 +173,22 @@ __global__ __launch_bounds__(256) void infonce_fwd_kernel(const float* __restric
             if (is_row && ti == tj) diag[gfix] = Ls[o][o];
         }
     }
-    // ---- ticket: the last workgroup to arrive finalises
-    __threadfence();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned total = gridDim.x * gridDim.y;
-        const unsigned t = atomicAdd(ticket, 1u);
-        last_flag = (t == total - 1);
-        if (t == total - 1) *ticket = 0;            // ready for the next launch on this stream
+    // ---- ticket: the last workgroup to arrive finalises.  A single-tile launch (Bg <= 64, the per-GPU batch of the recipes) is
+    // its own last arriver: no fence - an agent-scope release on this part writes the XCD's L2 back, ~30 us after a GEMM
+    if (gridDim.x * gridDim.y > 1) {
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned total = gridDim.x * gridDim.y;
+            const unsigned t = atomicAdd(ticket, 1u);
+            last_flag = (t == total - 1);
+            if (t == total - 1) *ticket = 0;            // ready for the next launch on this stream
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        __threadfence();
     }
-    __syncthreads();
-    if (!last_flag) return;
-    __threadfence();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float term = 0.f;
