@@ -29,7 +29,7 @@ typedef uint16_t sc_bf16;
 
 const char* sc_last_error(void);
 int sc_abi_version(void);
-/* tuning switches for same-process A/B measurements (tools/); results never depend on them.  key 1: the 256- / 128-row GEMMs use
+/* tuning switches for same-process A/B measurements (tools/); results never depend on them.  key 1: the 256-row GEMM uses
  * plain instead of non-temporal stores on tiles with a residual. */
 int sc_set_option(int32_t key, int32_t value);
 
@@ -49,7 +49,8 @@ int sc_set_option(int32_t key, int32_t value);
  *   columns n >= n_split (if n_split >= 0) are stored TRANSPOSED per head into Ct:
  *       Ct[(((m / R) * H + (n-n_split)/dh) * dh + (n-n_split)%dh) * R + m % R]     (V^T for attention)
  *   batch: grid.z = nb1*nb2 ; operand pointers advance by  (z / nb2) * s?1 + (z % nb2) * s?2  elements.
- *   Requirements: K % 64 == 0, lda/ldw % 8 == 0, pointers 16-byte aligned, ldc % 8 == 0.
+ *   Requirements: K % 64 == 0, lda/ldw % 8 == 0, ldc % 8 == 0; A, W, C, residual AND bias 16-byte aligned (the epilogue reads the
+ *   bias in groups of four floats), sBias1 / sBias2 multiples of 4.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     const sc_bf16* A; int64_t lda;
@@ -64,9 +65,8 @@ typedef struct {
     int32_t nb1, nb2;             /* batch = nb1*nb2 (>= 1 each) */
     int64_t sA1, sA2, sW1, sW2, sC1, sC2, sBias1, sBias2, sR1, sR2;
     int32_t tile;                 /* 0 auto | 1: 128x128 (4 waves) | 2: 256-row tile, 8 waves, width 256 or 192 by wave quantisation
-                                     (7 / 8 force 192 / 256) | 3: 128x64 | 9: 128-row tile, 4 waves, TWO workgroups per CU, width
-                                     256 or 192 (10 / 11 force 256 / 192): same wave block, K order and epilogue as 2, bit-identical
-                                     results; an alternative schedule kept for comparison, never chosen by 0 */
+                                     (7 / 8 force 192 / 256) | 3: 128x64.  Every tile family accumulates k in the same order and
+                                     shares the epilogue arithmetic: results do not depend on the choice */
     int32_t reserved;             /* store policy of the bf16 C tile (256-row kernels): 0 auto = non-temporal stores when a residual
                                      is given (the output is the next residual stream, not re-read by this kernel; measured
                                      -3.5 % GEMM time per step), 1 always non-temporal, 2 never */

@@ -87,6 +87,28 @@ def vq_forward(scores: torch.Tensor, temp: float, training: bool, prob_msk=(0, 2
     return hard + soft - soft.detach()
 
 
+def clip_text_transformer(W: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, heads: int) -> torch.Tensor:
+    """openai/CLIP ``Transformer`` of the text tower (pre-LN residual blocks, causal mask, QuickGELU): (B, 77, W) -> (B, 77, W)."""
+    B, S, Wd = x.shape
+    mask = torch.full((S, S), float("-inf")).triu_(1)
+    layers = 1 + max(int(k.split(".")[len(prefix.split(".")) + 1]) for k in W if k.startswith(prefix + "transformer.resblocks."))
+    dh = Wd // heads
+    for i in range(layers):
+        p = f"{prefix}transformer.resblocks.{i}."
+        y = F.layer_norm(x, (Wd,), W[p + "ln_1.weight"], W[p + "ln_1.bias"])
+        q, k, v = F.linear(y, W[p + "attn.in_proj_weight"], W[p + "attn.in_proj_bias"]).split(Wd, dim=-1)
+        q = q.view(B, S, heads, dh).transpose(1, 2) * dh ** -0.5
+        k = k.view(B, S, heads, dh).transpose(1, 2)
+        v = v.view(B, S, heads, dh).transpose(1, 2)
+        a = torch.softmax(q @ k.transpose(-1, -2) + mask, dim=-1)
+        o = (a @ v).transpose(1, 2).reshape(B, S, Wd)
+        x = x + F.linear(o, W[p + "attn.out_proj.weight"], W[p + "attn.out_proj.bias"])
+        y = F.layer_norm(x, (Wd,), W[p + "ln_2.weight"], W[p + "ln_2.bias"])
+        y = F.linear(y, W[p + "mlp.c_fc.weight"], W[p + "mlp.c_fc.bias"])
+        x = x + F.linear(y * torch.sigmoid(1.702 * y), W[p + "mlp.c_proj.weight"], W[p + "mlp.c_proj.bias"])
+    return x
+
+
 def clip_encode_keywords(W: Dict[str, torch.Tensor], prefix: str, keywords: torch.Tensor, n_kw: torch.Tensor,
                          heads: int, sot: int, eot: int) -> torch.Tensor:
     B, N, Wd = keywords.shape
@@ -98,22 +120,7 @@ def clip_encode_keywords(W: Dict[str, torch.Tensor], prefix: str, keywords: torc
         x[b, 1: 1 + n] = keywords[b, :n]
         x[b, 1 + n] = emb[eot]
     x = x + W[prefix + "positional_embedding"]
-    mask = torch.full((77, 77), float("-inf")).triu_(1)
-    layers = 1 + max(int(k.split(".")[len(prefix.split(".")) + 1]) for k in W if k.startswith(prefix + "transformer.resblocks."))
-    dh = Wd // heads
-    for i in range(layers):
-        p = f"{prefix}transformer.resblocks.{i}."
-        y = F.layer_norm(x, (Wd,), W[p + "ln_1.weight"], W[p + "ln_1.bias"])
-        q, k, v = F.linear(y, W[p + "attn.in_proj_weight"], W[p + "attn.in_proj_bias"]).split(Wd, dim=-1)
-        q = q.view(B, 77, heads, dh).transpose(1, 2) * dh ** -0.5
-        k = k.view(B, 77, heads, dh).transpose(1, 2)
-        v = v.view(B, 77, heads, dh).transpose(1, 2)
-        a = torch.softmax(q @ k.transpose(-1, -2) + mask, dim=-1)
-        o = (a @ v).transpose(1, 2).reshape(B, 77, Wd)
-        x = x + F.linear(o, W[p + "attn.out_proj.weight"], W[p + "attn.out_proj.bias"])
-        y = F.layer_norm(x, (Wd,), W[p + "ln_2.weight"], W[p + "ln_2.bias"])
-        y = F.linear(y, W[p + "mlp.c_fc.weight"], W[p + "mlp.c_fc.bias"])
-        x = x + F.linear(y * torch.sigmoid(1.702 * y), W[p + "mlp.c_proj.weight"], W[p + "mlp.c_proj.bias"])
+    x = clip_text_transformer(W, prefix, x, heads)
     x = F.layer_norm(x, (Wd,), W[prefix + "ln_final.weight"], W[prefix + "ln_final.bias"])
     return x[torch.arange(B), n_kw + 1] @ W[prefix + "text_projection"]
 

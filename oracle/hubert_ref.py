@@ -19,6 +19,13 @@ restated from its published algorithm:
 * MultiheadAttention: q = (x Wq + bq) * dh^-0.5 ; k, v ; softmax in fp32 with -inf key mask.
 
 State-dict key names are fairseq's (with ``encoder.pos_conv.0.weight`` already folded).
+
+``store`` (default None = the fp32 reference arithmetic): a CONTROL for the recall-parity question.  When a
+callable is given (``bf16_store``), it is applied at exactly the tensors the HIP path keeps in bf16 - every conv output, the
+feature LayerNorm, the projection, the pos_conv sum, every LayerNorm output, Q / K / V, the attention probabilities in front of
+P.V (their row sum stays fp32), the context, both residual sums and the FFN activation - and ``bf16_weights`` rounds the GEMM
+weights the kernels hold in bf16 (biases, norm affines and conv layer 0 stay fp32 there too).  Everything else (accumulation,
+softmax, GELU, statistics) stays fp32.  That separates "what bf16 storage does to the result" from "what a kernel defect does".
 """
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -105,6 +112,25 @@ def init_hubert_weights(arch: HubertArch, seed: int = 7122, std: float = 0.02) -
     return W
 
 
+def bf16_store(t: torch.Tensor) -> torch.Tensor:
+    """Round to bf16 (nearest even, as the kernels' v_cvt_pk_bf16_f32) and back to fp32."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def bf16_weights(W: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The weights as the HIP path holds them: GEMM operands in bf16 (conv layers 1-6, post_extract_proj, pos_conv, q/k/v/out
+    projections, fc1, fc2); conv layer 0, every bias and every norm affine in fp32 (speech_encoder.py:_load_weights)."""
+    out = {}
+    for k, v in W.items():
+        gemm = k.endswith(".weight") and v.dim() >= 2 and not k.startswith("feature_extractor.conv_layers.0.")
+        out[k] = bf16_store(v) if gemm else v
+    return out
+
+
+def _keep(t):
+    return t
+
+
 def fold_weight_norm(weight_g: torch.Tensor, weight_v: torch.Tensor) -> torch.Tensor:
     """nn.utils.weight_norm(conv, dim=2): w = g * v / ||v|| with the norm over dims (0, 1)."""
     n = weight_v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
@@ -124,8 +150,9 @@ def preprocess_input(wavs: Sequence[torch.Tensor], normalize: bool):
     return padded, mask
 
 
-def conv_feature_extractor(W, arch: HubertArch, x: torch.Tensor, collect: Optional[list] = None) -> torch.Tensor:
+def conv_feature_extractor(W, arch: HubertArch, x: torch.Tensor, collect: Optional[list] = None, store=None) -> torch.Tensor:
     """fairseq ConvFeatureExtractionModel.forward: (B, L) -> (B, C, T)."""
+    st = store or _keep
     x = x.unsqueeze(1)
     for i, (k, s) in enumerate(zip(arch.conv_kernels, arch.conv_strides)):
         w = W[f"feature_extractor.conv_layers.{i}.0.weight"]
@@ -136,10 +163,12 @@ def conv_feature_extractor(W, arch: HubertArch, x: torch.Tensor, collect: Option
                              W[f"feature_extractor.conv_layers.{i}.2.weight"],
                              W[f"feature_extractor.conv_layers.{i}.2.bias"], 1e-5)
         elif arch.extractor_mode == "layer_norm":
+            if i > 0:
+                x = st(x)               # the conv GEMM's bf16 output in front of the LayerNorm (layer 0 fuses conv + LN + GELU)
             x = F.layer_norm(x.transpose(1, 2), (arch.conv_dim,),
                              W[f"feature_extractor.conv_layers.{i}.2.1.weight"],
                              W[f"feature_extractor.conv_layers.{i}.2.1.bias"], 1e-5).transpose(1, 2)
-        x = F.gelu(x)
+        x = st(F.gelu(x))
         if collect is not None:
             collect.append(x)
     return x
@@ -154,28 +183,36 @@ def forward_padding_mask(T: int, padding_mask: torch.Tensor) -> torch.Tensor:
     return padding_mask.all(-1)
 
 
-def self_attention(W, p: str, x: torch.Tensor, key_padding_mask: Optional[torch.Tensor], heads: int, drop=None) -> torch.Tensor:
+def self_attention(W, p: str, x: torch.Tensor, key_padding_mask: Optional[torch.Tensor], heads: int, drop=None, store=None) -> torch.Tensor:
     """fairseq MultiheadAttention (self-attention).  x: (B, T, D).  ``drop`` (train mode): applied to the attention
     probabilities (B, H, T, T), fairseq's dropout_module(attn_weights)."""
     B, T, D = x.shape
     dh = D // heads
-    q = F.linear(x, W[p + "q_proj.weight"], W[p + "q_proj.bias"]) * dh ** -0.5
-    k = F.linear(x, W[p + "k_proj.weight"], W[p + "k_proj.bias"])
-    v = F.linear(x, W[p + "v_proj.weight"], W[p + "v_proj.bias"])
+    st = store or _keep
+    # fairseq scales q before the product; dh^-0.5 = 1/8 is a power of two, so scaling the stored (bf16) q commutes with the rounding
+    q = st(F.linear(x, W[p + "q_proj.weight"], W[p + "q_proj.bias"])) * dh ** -0.5
+    k = st(F.linear(x, W[p + "k_proj.weight"], W[p + "k_proj.bias"]))
+    v = st(F.linear(x, W[p + "v_proj.weight"], W[p + "v_proj.bias"]))
     q = q.view(B, T, heads, dh).transpose(1, 2)
     k = k.view(B, T, heads, dh).transpose(1, 2)
     v = v.view(B, T, heads, dh).transpose(1, 2)
     s = q @ k.transpose(-1, -2)
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
-    a = torch.softmax(s.float(), dim=-1)
-    if drop is not None:
-        a = drop(a)
-    o = (a @ v).transpose(1, 2).reshape(B, T, D)
+    if store is None:
+        a = torch.softmax(s.float(), dim=-1)
+        if drop is not None:
+            a = drop(a)
+        o = a @ v
+    else:               # flash form: un-normalised probabilities rounded in front of P.V, fp32 row sum, one division at the end
+        assert drop is None
+        e = torch.exp(s.float() - s.float().amax(dim=-1, keepdim=True))
+        o = (st(e) @ v) / e.sum(dim=-1, keepdim=True)
+    o = st(o.transpose(1, 2).reshape(B, T, D))
     return F.linear(o, W[p + "out_proj.weight"], W[p + "out_proj.bias"])
 
 
-def encoder_layer(W, arch: HubertArch, i: int, x: torch.Tensor, kpm: Optional[torch.Tensor], drop=None) -> torch.Tensor:
+def encoder_layer(W, arch: HubertArch, i: int, x: torch.Tensor, kpm: Optional[torch.Tensor], drop=None, store=None) -> torch.Tensor:
     """fairseq TransformerSentenceEncoderLayer.forward.  ``drop`` = None: eval mode.  Train mode (the reference's training
     step runs the frozen HuBERT in train mode, see hubert_forward): ``drop(site, layer, tensor)`` is called at the layer's
     dropout sites - "attn" (attention probabilities), "dropout1" (after out_proj, before the residual), "dropout3" (after
@@ -186,22 +223,25 @@ def encoder_layer(W, arch: HubertArch, i: int, x: torch.Tensor, kpm: Optional[to
     d1 = (lambda t: drop("dropout1", i, t)) if drop is not None else (lambda t: t)
     d3 = (lambda t: drop("dropout3", i, t)) if drop is not None else (lambda t: t)
 
+    st = store or _keep
+
     def ln(name, t):
-        return F.layer_norm(t, (D,), W[p + name + ".weight"], W[p + name + ".bias"], 1e-5)
+        return st(F.layer_norm(t, (D,), W[p + name + ".weight"], W[p + name + ".bias"], 1e-5))
+
+    def ffn(t):
+        return F.linear(st(F.gelu(F.linear(t, W[p + "fc1.weight"], W[p + "fc1.bias"]))), W[p + "fc2.weight"], W[p + "fc2.bias"])
 
     if not arch.layer_norm_first:
-        x = ln("self_attn_layer_norm", x + d1(self_attention(W, p + "self_attn.", x, kpm, arch.heads, d_att)))
-        h = F.linear(F.gelu(F.linear(x, W[p + "fc1.weight"], W[p + "fc1.bias"])), W[p + "fc2.weight"], W[p + "fc2.bias"])
-        x = ln("final_layer_norm", x + d3(h))
+        x = ln("self_attn_layer_norm", st(x + d1(self_attention(W, p + "self_attn.", x, kpm, arch.heads, d_att, store))))
+        x = ln("final_layer_norm", st(x + d3(ffn(x))))
     else:
-        x = x + d1(self_attention(W, p + "self_attn.", ln("self_attn_layer_norm", x), kpm, arch.heads, d_att))
-        y = ln("final_layer_norm", x)
-        x = x + d3(F.linear(F.gelu(F.linear(y, W[p + "fc1.weight"], W[p + "fc1.bias"])), W[p + "fc2.weight"], W[p + "fc2.bias"]))
+        x = st(x + d1(self_attention(W, p + "self_attn.", ln("self_attn_layer_norm", x), kpm, arch.heads, d_att, store)))
+        x = st(x + d3(ffn(ln("final_layer_norm", x))))
     return x
 
 
 def hubert_forward(W, arch: HubertArch, padded_wav: torch.Tensor, wav_padding_mask: Optional[torch.Tensor],
-                   debug: Optional[dict] = None, drop=None) -> List[torch.Tensor]:
+                   debug: Optional[dict] = None, drop=None, store=None) -> List[torch.Tensor]:
     """customHubertForward (speech_encoder_plus.py:67-107) + patched extract_features (:29-64).
 
     ``drop`` = None is eval mode.  In the reference's TRAINING step the frozen HuBERT is in train mode (the constructor's
@@ -210,16 +250,17 @@ def hubert_forward(W, arch: HubertArch, padded_wav: torch.Tensor, wav_padding_ma
     LayerNorm, :42) and the per-layer sites of encoder_layer; the caller supplies the masks (the oracle has no RNG of its own).
 
     Returns layer_results = [encoder input, out_1 .. out_NL], each (B, T, D)."""
+    st = store or _keep
     conv_outs = [] if debug is not None else None
-    feats = conv_feature_extractor(W, arch, padded_wav, conv_outs)          # :75
+    feats = conv_feature_extractor(W, arch, padded_wav, conv_outs, store)   # :75
     fgm = getattr(arch, "feature_grad_mult", 1.0)
     if fgm != 1.0 and feats.requires_grad:                                   # fairseq HubertModel.forward: GradMultiply.apply(features,
         feats = feats * fgm + feats.detach() * (1.0 - fgm)                   # feature_grad_mult): identity forward, scaled backward
     feats = feats.transpose(1, 2)                                            # :77
-    feats = F.layer_norm(feats, (arch.conv_dim,), W["layer_norm.weight"], W["layer_norm.bias"], 1e-5)  # :78
+    feats = st(F.layer_norm(feats, (arch.conv_dim,), W["layer_norm.weight"], W["layer_norm.bias"], 1e-5))  # :78
     T = feats.shape[1]
     pm = forward_padding_mask(T, wav_padding_mask) if wav_padding_mask is not None else None        # :81-82
-    x = F.linear(feats, W["post_extract_proj.weight"], W["post_extract_proj.bias"])                 # :84-85
+    x = st(F.linear(feats, W["post_extract_proj.weight"], W["post_extract_proj.bias"]))             # :84-85
     if debug is not None:
         debug["conv"] = conv_outs
         debug["proj"] = x.clone()
@@ -235,23 +276,23 @@ def hubert_forward(W, arch: HubertArch, padded_wav: torch.Tensor, wav_padding_ma
     if k % 2 == 0:
         xc = xc[:, :, :-1]                                                   # SamePad
     xc = F.gelu(xc).transpose(1, 2)                                          # :35-36
-    x = x + xc                                                               # :37
+    x = st(x + xc)                                                           # :37
     if not arch.layer_norm_first:
-        x = F.layer_norm(x, (arch.embed_dim,), W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], 1e-5)  # :39-40
+        x = st(F.layer_norm(x, (arch.embed_dim,), W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], 1e-5))  # :39-40
     if drop is not None:
         x = drop("encoder", -1, x)                                           # :42
     layer_results = [x]                                                      # :47
     for i in range(arch.layers):                                             # :49-53 (layerdrop 0)
-        x = encoder_layer(W, arch, i, x, pm, drop)
+        x = encoder_layer(W, arch, i, x, pm, drop, store)
         layer_results.append(x)
     return layer_results
 
 
-def speech_encoder_forward(W, arch: HubertArch, wavs: Sequence[torch.Tensor], drop=None):
+def speech_encoder_forward(W, arch: HubertArch, wavs: Sequence[torch.Tensor], drop=None, store=None):
     """FairseqSpeechEncoder_Hubert.forward (no crop; eval unless ``drop`` is given, see hubert_forward): returns
     (hidden_states tuple, feat_len).  speech_encoder_plus.py:554-611."""
     padded, mask = preprocess_input(wavs, arch.normalize_wav)
-    hs = hubert_forward(W, arch, padded, mask, drop=drop)
+    hs = hubert_forward(W, arch, padded, mask, drop=drop, store=store)
     T = hs[-1].shape[1]
     feat_len = torch.tensor(feat_len_rule([len(w) for w in wavs], T, arch.downsample_rate), dtype=torch.long)
     return tuple(hs), feat_len

@@ -8,9 +8,11 @@ Architecture restated from the published model: token_embedding (V x W), learned
 E = 512; ViT-L/14: W = 768, 12 heads, 12 layers, E = 768.  Parameter names follow openai/CLIP's state dict
 (``model.token_embedding.weight``, ``model.transformer.resblocks.{i}.attn.in_proj_weight``, ...) so a real
 checkpoint can be loaded with ``load_state_dict``.  The gradient flows THROUGH the frozen tower to the keyword embeddings:
-on a GPU the transformer blocks run on the library's kernels (clip_text_hip.py: bf16 GEMMs, causal attention forward and
-backward, LayerNorm / QuickGELU forward and backward); the stock-op modules below define the parameters, serve a trainable
-tower and the CPU.
+the transformer blocks run on the library's kernels (clip_text_hip.py: bf16 GEMMs, causal attention forward and backward,
+LayerNorm / QuickGELU forward and backward), ``ln_final`` and ``text_projection`` act on the B end-of-text rows only, in fp32
+(row LayerNorm kernel + exact-fp32 matrix-pipe GEMM).  The nn modules below are PARAMETER CONTAINERS under openai/CLIP's names:
+they have no arithmetic of their own - there is no stock-op or CPU path (a trainable text tower, which no shipped recipe uses,
+raises).
 """
 from collections import OrderedDict
 from typing import Optional, Union
@@ -23,9 +25,14 @@ CLIP_TEXT_ARCHS = {"ViT-B/32": dict(width=512, heads=8, layers=12, embed_dim=512
 SOT_TOKEN, EOT_TOKEN, CLIP_VOCAB, CONTEXT_LEN = 49406, 49407, 49408, 77
 
 
+def _no_eager(what: str):
+    raise RuntimeError(f"{what} holds the CLIP text tower's parameters only; the arithmetic runs on the HIP kernels through "
+                       "ClipModel.encode_keywords (speechclip_plus_amd has no stock-op / CPU path)")
+
+
 class QuickGELU(nn.Module):
     def forward(self, x: torch.Tensor):
-        return x * torch.sigmoid(1.702 * x)
+        _no_eager("QuickGELU")
 
 
 class ResidualAttentionBlock(nn.Module):
@@ -37,10 +44,8 @@ class ResidualAttentionBlock(nn.Module):
                                               ("c_proj", nn.Linear(d_model * 4, d_model))]))
         self.ln_2 = nn.LayerNorm(d_model)
 
-    def forward(self, x: torch.Tensor, attn_mask: torch.Tensor):
-        y = self.ln_1(x)
-        x = x + self.attn(y, y, y, need_weights=False, attn_mask=attn_mask.to(dtype=x.dtype, device=x.device))[0]
-        return x + self.mlp(self.ln_2(x))
+    def forward(self, x: torch.Tensor, attn_mask: torch.Tensor = None):
+        _no_eager("ResidualAttentionBlock")
 
 
 class _TextTransformer(nn.Module):
@@ -49,10 +54,8 @@ class _TextTransformer(nn.Module):
         self.width, self.layers = width, layers
         self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads) for _ in range(layers)])
 
-    def forward(self, x: torch.Tensor, attn_mask: torch.Tensor):
-        for blk in self.resblocks:
-            x = blk(x, attn_mask)
-        return x
+    def forward(self, x: torch.Tensor, attn_mask: torch.Tensor = None):
+        _no_eager("the text transformer")
 
 
 class _ClipTextCore(nn.Module):
@@ -70,8 +73,29 @@ class _ClipTextCore(nn.Module):
             self.token_embedding.weight.copy_(torch.randn(vocab, width, generator=g) * 0.02)
             self.positional_embedding.copy_(torch.randn(CONTEXT_LEN, width, generator=g) * 0.01)
             self.text_projection.copy_(torch.randn(width, embed_dim, generator=g) * width ** -0.5)
-        mask = torch.full((CONTEXT_LEN, CONTEXT_LEN), float("-inf")).triu_(1)
-        self.register_buffer("attn_mask", mask, persistent=False)
+
+
+class _EotHeadFn(torch.autograd.Function):
+    """``ln_final`` + ``@ text_projection`` on the B end-of-text rows (clip_official.py:270-277), fp32, frozen parameters:
+    sc_rowln_f32_fwd / _bwd and the exact-fp32 matrix-pipe GEMM; gradient w.r.t. the rows only."""
+
+    @staticmethod
+    def forward(ctx, rows, gamma, beta, eps, proj):
+        from . import ops
+        x = rows.detach().float().contiguous()
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y, xhat, rstd = ops.rowln_fwd(x, None, 0, g, b, eps)
+        P = proj.detach().float().contiguous()                       # [W, E]: K-major for out = y @ P
+        ctx.save_for_backward(xhat, rstd, g, P)
+        return ops.sgemm_mfma(y, P, b_kmajor=True)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from . import ops
+        xhat, rstd, g, P = ctx.saved_tensors
+        dy = ops.sgemm_mfma(d_out.float().contiguous(), P)           # dy[b, w] = sum_e d_out[b, e] P[w, e]
+        scratch = torch.zeros(2, g.numel(), device=g.device, dtype=torch.float32)      # the frozen affine's gradient: discarded
+        return ops.rowln_bwd(dy, xhat, g, rstd, scratch[0], scratch[1]), None, None, None, None
 
 
 class ClipModel(nn.Module):
@@ -110,17 +134,22 @@ class ClipModel(nn.Module):
         self.to(device)
 
     def _transformer(self, x: torch.Tensor) -> torch.Tensor:
-        """(B, 77, W) -> (B, 77, W).  Frozen tower on a GPU with head_dim 64: the library's bf16 kernels, forward and input
-        gradient (clip_text_hip.TextTowerFn); otherwise the stock-op blocks defined above."""
+        """(B, 77, W) -> (B, 77, W) on the library's bf16 kernels, forward and input gradient (clip_text_hip.TextTowerFn).  The
+        tower is frozen in every shipped recipe (clip_official.py:113-134) and both published towers have head_dim 64."""
         core = self.model
         heads = core.transformer.resblocks[0].attn.num_heads
-        if x.is_cuda and not self.text_encoder_trainable and core.transformer.width == 64 * heads:
-            from .clip_text_hip import TextTowerFn, prepare_weights
-            key = (x.device, tuple((p.data_ptr(), p._version) for p in core.transformer.parameters()))
-            if getattr(self, "_hip_key", None) != key:          # (re)converted when a checkpoint is loaded or the module moves
-                self._hip_weights, self._hip_key = prepare_weights(core.transformer, x.device), key
-            return TextTowerFn.apply(x, self._hip_weights, heads)
-        return core.transformer(x.permute(1, 0, 2), core.attn_mask).permute(1, 0, 2)
+        if not x.is_cuda:
+            raise RuntimeError("the CLIP text tower runs on the HIP kernels: device tensors only")
+        if self.text_encoder_trainable:
+            raise NotImplementedError("text_encoder_trainable: no shipped recipe trains the CLIP text tower; only the frozen tower "
+                                      "(forward + input gradient) is built")
+        if core.transformer.width != 64 * heads:
+            raise NotImplementedError(f"text tower head_dim {core.transformer.width // heads}: the attention kernels are built for 64")
+        from .clip_text_hip import TextTowerFn, prepare_weights
+        key = (x.device, tuple((p.data_ptr(), p._version) for p in core.transformer.parameters()))
+        if getattr(self, "_hip_key", None) != key:              # (re)converted when a checkpoint is loaded or the module moves
+            self._hip_weights, self._hip_key = prepare_weights(core.transformer, x.device), key
+        return TextTowerFn.apply(x, self._hip_weights, heads)
 
     def update_device(self, device):
         self.device = device
@@ -157,7 +186,7 @@ class ClipModel(nn.Module):
             x = torch.cat([x[:, :1], keywords, x[:, 1 + keyword_num:]], dim=1)
         x = x + self.model.positional_embedding
         x = self._transformer(x)
-        x = self.model.ln_final(x)
-        if index is not None:
-            return x[torch.arange(bsz, device=dev), index] @ self.model.text_projection
-        return x[:, 1 + keyword_num] @ self.model.text_projection
+        # LayerNorm is per row: only the end-of-text row of every sample goes through ln_final and the projection
+        rows = x[torch.arange(bsz, device=dev), index] if index is not None else x[:, 1 + keyword_num]
+        ln = self.model.ln_final
+        return _EotHeadFn.apply(rows, ln.weight, ln.bias, ln.eps, self.model.text_projection)

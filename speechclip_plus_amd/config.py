@@ -48,8 +48,11 @@ def synthetic_reduced_vocab(n: int = 8112, seed: int = 0):
     return torch.cat([ids, torch.tensor([49406, 49407])])
 
 
-def load_config(src: Union[str, dict], reference_root: str = ".") -> Config:
-    """``src``: path of a reference yaml recipe, yaml text, or an already parsed dict."""
+def load_config(src: Union[str, dict], reference_root: str = ".", allow_synthetic_vocab: bool = False) -> Config:
+    """``src``: path of a reference yaml recipe, yaml text, or an already parsed dict.  A recipe's reduced-vocabulary table
+    (``clip.reduce_subword_embbedding``, a .npy of CLIP token ids under the reference's ``avssl/data/*_stat/``) must exist under
+    ``reference_root``: with a real checkpoint a made-up reduced-index -> token-id table would silently decode wrong keywords.
+    ``allow_synthetic_vocab=True`` (benchmarks and tests on random weights) substitutes a synthetic table of the same size."""
     if isinstance(src, dict):
         cfg = Config(src)
     else:
@@ -68,6 +71,10 @@ def load_config(src: Union[str, dict], reference_root: str = ".") -> Config:
         path = vocab if os.path.isabs(vocab) else os.path.join(reference_root, vocab)
         if os.path.exists(path):
             clip["reduce_subword_embbedding"] = path
+        elif not allow_synthetic_vocab:
+            raise FileNotFoundError(f"reduced-vocabulary table {path} not found (clip.reduce_subword_embbedding = {vocab!r}): point "
+                                    "reference_root at the reference checkout, or pass allow_synthetic_vocab=True when running "
+                                    "on random weights")
         else:
             stat = "coco" if "coco" in vocab else "flickr"
             logger.warning("reduced-vocabulary table %s not found: using a synthetic table of %d sub-words", vocab,

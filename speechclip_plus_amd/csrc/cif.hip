@@ -194,7 +194,9 @@ __global__ __launch_bounds__(256) void cif_prepare_kernel(const float* __restric
     }
     const float q = (float)block_sum_d(loc, red);
     float ratio = 1.f;
-    if (scale) ratio = (thr * (float)target[b] + eps) / q;
+    // an utterance whose clipped weights are all zero (q = 0) cannot be rescaled: its weights stay 0 and it yields feat_len 1
+    // (the reference divides by zero here; its per-call assert only asks for ONE positive utterance) - no inf / NaN downstream
+    if (scale) ratio = q > 0.f ? (thr * (float)target[b] + eps) / q : 0.f;
     loc = 0.0;
 #pragma unroll
     for (int i = 0; i < PREP_PER; ++i) {
@@ -222,7 +224,8 @@ __global__ __launch_bounds__(256) void cif_prepare_kernel(const float* __restric
     }
     if (threadIdx.x == 0) {
         int64_t fl = (int64_t)floorf((float)total / thr);
-        fl = fl < 1 ? 1 : (fl > max_feat ? max_feat : fl);
+        const int64_t cap = max_feat < T ? max_feat : T;    // T = slots the host allocated (sized from the targets when it knows them)
+        fl = fl < 1 ? 1 : (fl > cap ? cap : fl);
         feat_len[b] = fl;
         quantity[b] = q;
         ratio_out[b] = ratio;

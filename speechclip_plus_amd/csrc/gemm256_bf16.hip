@@ -302,14 +302,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
 
 template <int DIAG, int BN, int ACT, int DROP, int RES>
 static int launch256__(const sc_gemm_args& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DIAG, BN, ACT, DROP, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) {
-            sc_set_error("hipFuncSetAttribute(gemm256): %s", hipGetErrorString(e));
-            return -3;
-        }
-        attr_set = true;
+    static sc_lds_attr_once attr;
+    if (hipError_t e = sc_set_max_lds_once(attr, gemm256_kernel<DIAG, BN, ACT, DROP, RES>, LDS_BYTES); e != hipSuccess) {
+        sc_set_error("hipFuncSetAttribute(gemm256): %s", hipGetErrorString(e));
+        return -3;
     }
     const int nM = (a.M + 255) / 256, nN = (a.N + BN - 1) / BN;
     dim3 grid(std::min(nM * nN, sc_num_cus()), 1, a.nb1 * a.nb2);

@@ -242,15 +242,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
 template <int BM, int BN>
 int launch(const sc_gemm_args& a, hipStream_t s) {
     using Cfg = GemmCfg<BM, BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) {
-            sc_set_error("hipFuncSetAttribute(gemm %dx%d): %s", BM, BN, hipGetErrorString(e));
-            return -3;
-        }
-        attr_set = true;
+    static sc_lds_attr_once attr;
+    if (hipError_t e = sc_set_max_lds_once(attr, gemm_bf16_kernel<BM, BN>, Cfg::LDS_BYTES); e != hipSuccess) {
+        sc_set_error("hipFuncSetAttribute(gemm %dx%d): %s", BM, BN, hipGetErrorString(e));
+        return -3;
     }
     const int nM = (a.M + BM - 1) / BM, nN = (a.N + BN - 1) / BN;
     dim3 grid(nM * nN, 1, a.nb1 * a.nb2);
@@ -262,8 +257,6 @@ int launch(const sc_gemm_args& a, hipStream_t s) {
 }  // namespace
 
 int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s);    // gemm256_bf16.hip
-int sc_gemm128_launch(const sc_gemm_args& a, hipStream_t s);    // gemm128_bf16.hip
-bool sc_gemm128_fits(const sc_gemm_args& a);
 
 extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     SC_CHECK(args != nullptr, "sc_gemm_bf16: null args");
@@ -284,6 +277,9 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     if (a.nb1 < 1) a.nb1 = 1;
     if (a.nb2 < 1) a.nb2 = 1;
     if (a.residual) SC_CHECK(a.ldr % 8 == 0 && ((uintptr_t)a.residual % 16) == 0, "sc_gemm_bf16: residual alignment");
+    // the epilogues read the bias as 16-byte f32x4 groups (gemm_epilogue.inc): base and batch strides must keep that alignment
+    if (a.bias) SC_CHECK(((uintptr_t)a.bias % 16) == 0 && a.sBias1 % 4 == 0 && a.sBias2 % 4 == 0,
+                         "sc_gemm_bf16: bias must be 16-byte aligned with batch strides that are multiples of 4 floats");
     if (a.n_split >= 0) {
         SC_CHECK(a.Ct != nullptr && a.dh > 0 && a.R > 0, "sc_gemm_bf16: transposed store needs Ct, dh, R");
         SC_CHECK(a.n_split % 128 == 0 && a.R % 128 == 0 && (a.N - a.n_split) % a.dh == 0 && a.M % a.R == 0,
@@ -306,11 +302,6 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
             SC_CHECK(a.n_split < 0 || a.n_split % 192 == 0 || a.n_split % 256 == 0,
                      "sc_gemm_bf16: 256-row tiles need n_split %% 192 == 0 or %% 256 == 0");
             return sc_gemm256_launch(a, s);
-        case 9: case 10: case 11: case 33:          // 128-row tile, two workgroups per CU; 10 / 11 force the width (256 / 192)
-            SC_CHECK(a.n_split < 0 || a.n_split % 192 == 0 || a.n_split % 256 == 0,
-                     "sc_gemm_bf16: 128-row duo tiles need n_split %% 192 == 0 or %% 256 == 0");
-            SC_CHECK(sc_gemm128_fits(a), "sc_gemm_bf16: operands beyond the 32-bit offsets of the 128-row duo kernel");
-            return sc_gemm128_launch(a, s);
         case 3:
             SC_CHECK(a.n_split < 0, "sc_gemm_bf16: 128x64 tile has no transposed store");
             return launch<128, 64>(a, s);

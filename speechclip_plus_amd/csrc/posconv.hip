@@ -183,14 +183,10 @@ static int launch_posconv(const uint16_t* xg, const uint16_t* w, const float* bi
                           int D, int G, int Kp, int Rp, hipStream_t s) {
     constexpr int PC_ROWS = NW * 64;
     constexpr int LDS = (PC_ROWS + 128) * 128 + 3 * (2 * DG / 32) * DG * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)posconv_kernel<DG, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) {
-            sc_set_error("hipFuncSetAttribute(posconv): %s", hipGetErrorString(e));
-            return -3;
-        }
-        attr_set = true;
+    static sc_lds_attr_once attr;
+    if (hipError_t e = sc_set_max_lds_once(attr, posconv_kernel<DG, NW>, LDS); e != hipSuccess) {
+        sc_set_error("hipFuncSetAttribute(posconv): %s", hipGetErrorString(e));
+        return -3;
     }
     const int mb = (R + PC_ROWS - 1) / PC_ROWS;
     hipLaunchKernelGGL((posconv_kernel<DG, NW>), dim3(G * B * mb), dim3(NW * 64), LDS, s, xg, w, bias, res, out, B, R, D, G, Kp, Rp);

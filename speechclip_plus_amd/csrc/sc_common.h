@@ -2,8 +2,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 #include "speechclip_hip.h"
+
+// One-time, thread-safe raise of a kernel's dynamic-LDS limit (first launch of an instantiation may come from any host thread:
+// std::call_once instead of an unguarded static flag).  Returns the result of the one attempt on every call.
+struct sc_lds_attr_once {
+    std::once_flag flag;
+    hipError_t err = hipSuccess;
+};
+template <class Kernel>
+static inline hipError_t sc_set_max_lds_once(sc_lds_attr_once& st, Kernel kernel, int bytes) {
+    std::call_once(st.flag, [&] { st.err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+    return st.err;
+}
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

@@ -80,4 +80,5 @@ class MaskedContrastiveLoss(nn.Module):
             inv_temp = self._inv_temp_dev.get(feat_A.device)
             if inv_temp is None:
                 inv_temp = self._inv_temp_dev[feat_A.device] = torch.full((1,), float(self.temperature), device=feat_A.device)
-        return _InfoNCEFn.apply(feat_A, feat_B, inv_temp, index, self.margin, self.dcl, self.a2b, self.b2a)
+        # losses.py:219-220 subtracts the margin only ``if self.margin > 0.0``: a negative margin is the plain loss
+        return _InfoNCEFn.apply(feat_A, feat_B, inv_temp, index, max(self.margin, 0.0), self.dcl, self.a2b, self.b2a)

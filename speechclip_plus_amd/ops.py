@@ -86,6 +86,7 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     assert C.dtype == (torch.float32 if out_f32 else torch.bfloat16)
     if bias is not None:
         assert bias.dtype == torch.float32
+        bias = aligned16(bias)          # sc_gemm_bf16 reads the bias in 16-byte groups; trainable biases are 4-byte-aligned views
     if residual is not None:
         assert residual.dtype == torch.bfloat16
     a = GemmArgs()

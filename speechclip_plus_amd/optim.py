@@ -115,6 +115,27 @@ class FlatAdamOptimizer(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()                       # gradients live in the flat buffer: never set to None
 
+    # The Adam moments and the bias-correction step live in the flat buffers, not in ``self.state``: carry them through
+    # checkpoints explicitly, or a resumed run would restart Adam from zero moments at step 1 (torch.optim.Adam, which the
+    # reference uses, resumes exactly).
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat_adam"] = {"m": self.flat.m.detach().clone(), "v": self.flat.v.detach().clone(),
+                           "step_count": int(self.flat.step_count), "numel": int(self.flat.n)}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        fa = state_dict.pop("flat_adam", None)
+        if fa is None:
+            raise KeyError("optimizer state has no 'flat_adam' entry (not saved by FlatAdamOptimizer.state_dict)")
+        if int(fa["numel"]) != self.flat.n:
+            raise ValueError(f"optimizer state holds {int(fa['numel'])} parameters, this optimizer manages {self.flat.n}")
+        super().load_state_dict(state_dict)
+        self.flat.m.copy_(fa["m"])
+        self.flat.v.copy_(fa["v"])
+        self.flat.step_count = int(fa["step_count"])
+
 
 def get_scheduler(optimizer: torch.optim.Optimizer, name: str, **kw):
     """avssl/optim/scheduler.py:41-47: LambdaLR over the reference's two schedules."""

@@ -1,38 +1,41 @@
-"""mutualRetrieval (avssl/module/retrieval.py:6-121): recall@k in both directions from a score matrix.
-Metric code, not a kernel: argsort + gathers on whatever device the scores live on."""
-from typing import Tuple
+"""Recall@k of the validation epoch - same signature and result dictionaries as the reference's ``mutualRetrieval``
+(avssl/module/retrieval.py:6-121; scores built at avssl/model/kwClip.py:447-482).
+
+The reference sorts every score row and looks the answers up in rank order.  Here no row is sorted: a query hits at k iff fewer
+than k candidates score strictly above its best-scoring correct candidate, so one masked row maximum and one comparison count per
+direction give every k at once (on the device the scores live on).  Exact float ties between a correct and a wrong candidate
+count for the query; the reference leaves them to the order of an unstable ``argsort``, i.e. undefined."""
+from typing import Dict, Sequence, Tuple
 
 import torch
+
+
+def _recall(score: torch.Tensor, query_ids: torch.Tensor, cand_ids: torch.Tensor, ks: Sequence[int], cand_title: str) -> Dict[str, float]:
+    """score [Q, C]; a candidate c is correct for query q iff cand_ids[c] == query_ids[q] (an image with several captions has
+    several correct candidates; one of them inside the top k is a hit)."""
+    correct = cand_ids.unsqueeze(0) == query_ids.unsqueeze(1)
+    best = score.masked_fill(~correct, float("-inf")).amax(dim=1, keepdim=True)
+    ahead = (score > best).sum(dim=1)                    # a query without any correct candidate has best = -inf: never a hit
+    ahead = torch.where(correct.any(dim=1), ahead, torch.full_like(ahead, score.shape[1]))
+    out = {}
+    for k in ks:
+        if k > score.shape[1]:
+            print(f"recall@{k} asks for more than the {score.shape[1]} {cand_title} candidates there are; counted over all of them")
+        out[f"recall@{k}"] = 100.0 * (ahead < k).float().mean().item()
+    return out
 
 
 def mutualRetrieval(score_per_A: torch.Tensor, score_per_B: torch.Tensor, AB_answers: torch.Tensor,
                     BA_answers: torch.Tensor, recall_at: list, modality_A_title: str = "audio",
                     modality_B_title: str = "image") -> Tuple[dict, dict, dict]:
-    assert len(score_per_A.shape) == 2 and len(score_per_B.shape) == 2
-    assert len(AB_answers.shape) == 1 and len(BA_answers.shape) == 1
-    assert score_per_A.shape == (len(AB_answers), len(BA_answers)), "{} , {}".format(
-        score_per_A.shape, (len(AB_answers), len(BA_answers)))
-    assert score_per_B.shape == (len(BA_answers), len(AB_answers)), "{} , {}".format(
-        score_per_B.shape, (len(BA_answers), len(AB_answers)))
-    dev = score_per_A.device
-    AB_answers, BA_answers = AB_answers.to(dev), BA_answers.to(dev)
-    order_A = torch.argsort(score_per_A, dim=1, descending=True)
-    order_B = torch.argsort(score_per_B, dim=1, descending=True)
-    rank_AB = BA_answers[order_A] == AB_answers.unsqueeze(-1)
-    rank_BA = AB_answers[order_B] == BA_answers.unsqueeze(-1)
-    recall_results_AB, recall_results_BA, recall_results_mean = {}, {}, {}
-    for k in recall_at:
-        if k > rank_AB.shape[1]:
-            print("recall@{} is not eligible for #{} {} samples".format(k, rank_AB.shape[1], modality_B_title))
-        recall_results_AB["recall@{}".format(k)] = (
-            rank_AB[:, : min(k, rank_AB.shape[1])].any(dim=1).sum() / rank_AB.shape[0]).item()
-    for k in recall_at:
-        if k > rank_BA.shape[1]:
-            print("recall@{} is not eligible for #{} {} samples".format(k, rank_BA.shape[1], modality_A_title))
-        recall_results_BA["recall@{}".format(k)] = (
-            rank_BA[:, : min(k, rank_BA.shape[1])].any(dim=1).sum() / rank_BA.shape[0]).item()
-    for _k in ["recall@{}".format(r) for r in recall_at]:
-        recall_results_BA[_k] *= 100
-        recall_results_AB[_k] *= 100
-        recall_results_mean[_k] = (recall_results_BA[_k] + recall_results_AB[_k]) / 2.0
-    return recall_results_AB, recall_results_BA, recall_results_mean
+    nA, nB = AB_answers.numel(), BA_answers.numel()
+    if AB_answers.dim() != 1 or BA_answers.dim() != 1:
+        raise AssertionError("answers must be 1-d id vectors")
+    if tuple(score_per_A.shape) != (nA, nB) or tuple(score_per_B.shape) != (nB, nA):
+        raise AssertionError(f"score shapes {tuple(score_per_A.shape)} / {tuple(score_per_B.shape)} do not match {nA} x {nB} answers")
+    a_ids = AB_answers.to(score_per_A.device)
+    b_ids = BA_answers.to(score_per_A.device)
+    results_AB = _recall(score_per_A, a_ids, b_ids, recall_at, modality_B_title)
+    results_BA = _recall(score_per_B.to(score_per_A.device), b_ids, a_ids, recall_at, modality_A_title)
+    results_mean = {key: 0.5 * (results_AB[key] + results_BA[key]) for key in results_AB}
+    return results_AB, results_BA, results_mean

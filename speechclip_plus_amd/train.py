@@ -20,8 +20,12 @@ from .parallel import GradAllReduce, dp_world, gather_loss_feats, scale_replicat
 
 
 class ContrastiveTrainer:
-    def __init__(self, model, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, model, group: Optional[dist.ProcessGroup] = None, check_every: int = 200):
         self.model, self.group = model, group
+        # every ``check_every`` steps the CIF modules' device-side consistency counters are read (one host synchronisation): the
+        # reference asserts on every call; here the training path never reads the device, so the assertion is deferred, not dropped
+        self.check_every = int(check_every)
+        self._cif = [m for m in model.modules() if hasattr(m, "check_flags") and hasattr(m, "consistency_flags")]
         cfg = model.config
         oc = cfg.audio_encoder.optim
         assert oc.name == "Adam", "the shipped recipes use Adam"
@@ -101,7 +105,18 @@ class ContrastiveTrainer:
                 self._finish(lr)
         self._pending = True
         model.global_step += 1
+        if self._cif and self.check_every > 0 and model.global_step % self.check_every == 0:
+            self.check_consistency()
         return loss.detach()
+
+    def check_consistency(self) -> None:
+        """Reads the CIF counters (synchronises).  Raises if a call saw no positive weight sum at all (the reference's assert) or
+        if a keyword count disagreed with the host-side target the output buffer was sized from."""
+        for m in self._cif:
+            flags = m.check_flags()
+            if flags["count_mismatches"] > 0:
+                raise RuntimeError(f"CIF: {flags['count_mismatches']} keyword counts differed from clip(target_len, 1, 75) while the "
+                                   f"output was sized from the host-side targets ({flags})")
 
     def _finish(self, lr: float) -> None:
         scale_replicated_grads(self.replicated, self.group)

@@ -140,9 +140,11 @@ def test_hybrid_plus_large_end_to_end():
     assert l1 == l1
 
 
-def test_clip_text_tower_kernels_match_stock_blocks():
+def test_clip_text_tower_kernels_match_the_oracle():
     """clip_text_hip.TextTowerFn (bf16 kernels: GEMMs, causal attention fwd / bwd, LayerNorm and QuickGELU fwd / bwd) against the
-    stock fp32 blocks of the same frozen tower: output and input gradient."""
+    CPU oracle's restatement of the same frozen tower (oracle.clip_text_transformer, fp32 + autograd): output and input
+    gradient; and encode_keywords end to end (prompt splice, tower, ln_final + projection on the EOT rows) with its gradient."""
+    import oracle
     from speechclip_plus_amd.clip_text import ClipModel
     torch.manual_seed(2)
     clip = ClipModel("ViT-B/32", device="cuda:0", layers=3).eval()
@@ -152,16 +154,35 @@ def test_clip_text_tower_kernels_match_stock_blocks():
             for ln in (blk.ln_1, blk.ln_2):
                 ln.weight.add_(torch.randn_like(ln.weight) * 0.1)
                 ln.bias.add_(torch.randn_like(ln.bias) * 0.1)
+        core.ln_final.weight.add_(torch.randn_like(core.ln_final.weight) * 0.1)
+        core.ln_final.bias.add_(torch.randn_like(core.ln_final.bias) * 0.1)
+    W = {"model." + k: v.detach().cpu().float() for k, v in core.state_dict().items()}
     g = torch.Generator().manual_seed(4)
     B = 5
-    x = (torch.randn(B, 77, 512, generator=g) * 0.5).cuda().requires_grad_()
-    dy = torch.randn(B, 77, 512, generator=g).cuda()
+    x0 = torch.randn(B, 77, 512, generator=g) * 0.5
+    dy = torch.randn(B, 77, 512, generator=g)
+    x = x0.cuda().requires_grad_()
     y = clip._transformer(x)
-    y.backward(dy)
-    gx = x.grad.clone()
-    x2 = x.detach().clone().requires_grad_()
-    y_ref = core.transformer(x2.permute(1, 0, 2), core.attn_mask).permute(1, 0, 2)
+    y.backward(dy.cuda())
+    x2 = x0.clone().requires_grad_()
+    y_ref = oracle.clip_text_transformer(W, "model.", x2, heads=8)
     y_ref.backward(dy)
-    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    rel = lambda a, b: float((a.detach().cpu().float() - b.detach().float()).norm() / b.detach().float().norm())
     assert rel(y, y_ref) < 2e-2, rel(y, y_ref)
-    assert rel(gx, x2.grad) < 3e-2, rel(gx, x2.grad)
+    assert rel(x.grad, x2.grad) < 3e-2, rel(x.grad, x2.grad)
+    with pytest.raises(RuntimeError):                            # the nn blocks are parameter containers: no stock-op arithmetic
+        core.transformer(x.detach())
+    # encode_keywords end to end
+    kw0 = torch.randn(B, 6, 512, generator=g) * 0.02
+    n = torch.tensor([6, 1, 4, 2, 5])
+    d_out = torch.randn(B, 512, generator=g)
+    kw = kw0.cuda().requires_grad_()
+    out = clip.encode_keywords(kw, n.cuda())
+    out.backward(d_out.cuda())
+    kw2 = kw0.clone().requires_grad_()
+    ref = oracle.clip_encode_keywords(W, "model.", kw2, n, heads=8, sot=49406, eot=49407)
+    ref.backward(d_out)
+    assert rel(out, ref) < 2e-2, rel(out, ref)
+    assert rel(kw.grad, kw2.grad) < 4e-2, rel(kw.grad, kw2.grad)
+    for b in range(B):                                           # rows beyond the utterance's keywords carry no gradient
+        assert float(kw.grad[b, int(n[b]):].abs().sum()) == 0

@@ -62,12 +62,12 @@ def test_gemm(dev, M, N, K, act, use_bias, use_res, out_f32):
     assert float((out.float() - ref).abs().max()) < (1e-3 if out_f32 else 0.06) * (1 + float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("tile", [2, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [2, 7, 8])
 @pytest.mark.parametrize("M,N,K,act,use_res", [(512, 768, 768, 0, True), (1024, 512, 1536, 1, False), (700, 2408, 128, 0, True),
                                                 (2048, 3072, 768, 1, False), (512, 256, 64, 0, False), (6000, 512, 1024, 1, False)])
 def test_gemm_tile256(dev, M, N, K, act, use_res, tile):
-    """The 256-row persistent kernel (tile = 2, 7, 8) and the 128-row two-workgroups-per-CU kernel (9, 10, 11) against fp32 torch
-    and against the 128x128 variant, incl. M / N tails, short K."""
+    """The 256-row persistent kernel (tile = 2 by cost model, 7 / 8 = forced 256- / 192-wide) against fp32 torch and against the
+    128x128 variant, incl. M / N tails, short K."""
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g)).to(dev)
@@ -85,7 +85,7 @@ def test_gemm_tile256(dev, M, N, K, act, use_res, tile):
     assert torch.equal(out, out1), "both tile variants accumulate k in the same order and share the epilogue maths"
 
 
-@pytest.mark.parametrize("tile", [2, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [2, 7, 8])
 def test_gemm_tile256_transposed_store(dev, tile):
     ops = _ops()
     B, R, D, H = 2, 384, 768, 12
@@ -130,7 +130,7 @@ def test_gemm_strided_rows_conv(dev):
     x2 = bf(torch.randn(Tin2 + 8, C, generator=g)).to(dev)
     Tout2 = (Tin2 - 3) // 2 + 1
     ref2 = F.gelu(F.conv1d(x2[:Tin2].float().T.unsqueeze(0), w.float(), stride=2))[0].T
-    for tile in (7, 8, 10, 11):
+    for tile in (7, 8):
         o0 = torch.zeros(Tout2, C, device=dev, dtype=torch.bfloat16)
         o1 = torch.zeros(Tout2, C, device=dev, dtype=torch.bfloat16)
         ops.gemm_raw(x2, 2 * C, wk, 3 * C, o0, C, Tout2, C, 3 * C, act=1, tile=tile)
@@ -751,7 +751,7 @@ def test_gemm_random_shape_fuzz(dev):
         M = rng.choice([1, 7, 63, 64, 129, 255, 256, 257, 511, 700, 1000, 2048, 3001, 8192, 70000])
         N = 8 * rng.randint(1, 130)
         K = 64 * rng.randint(1, 20)
-        cases.append((M, N, K, rng.random() < 0.5, rng.random() < 0.4, rng.random() < 0.4, rng.random() < 0.25, rng.choice([0, 1, 2, 3, 7, 8, 9, 10, 11])))
+        cases.append((M, N, K, rng.random() < 0.5, rng.random() < 0.4, rng.random() < 0.4, rng.random() < 0.25, rng.choice([0, 1, 2, 3, 7, 8, 2, 7, 8])))
     # narrow outputs on the 128 x 64 tile (the grouped pos_conv is 48 wide)
     cases += [(300, 48, 192, True, True, True, False, 3), (129, 40, 64, True, False, False, True, 3), (1000, 8, 128, False, True, False, False, 3),
               (257, 24, 320, True, False, True, False, 3), (640, 56, 128, True, True, False, False, 3), (512, 64, 256, False, False, True, False, 3)]
@@ -855,7 +855,7 @@ def test_dropout_masks_gemm_rows_attention(dev):
     assert torch.equal(y, bf(torch.where(keep, x.float() / (1 - p), torch.zeros((), device=dev))))
     assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
     # GEMM epilogue: dropout after bias / GELU, before the residual; both tile families
-    for M, N, K, tile in ((300, 136, 128, 1), (1000, 512, 192, 2), (700, 776, 64, 7), (1000, 512, 192, 10), (700, 776, 64, 11)):
+    for M, N, K, tile in ((300, 136, 128, 1), (1000, 512, 192, 2), (700, 776, 64, 7), (700, 776, 64, 8)):
         A = bf(torch.randn(M, K, generator=g)).to(dev)
         W = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
         bias = torch.randn(N, generator=g).to(dev)

@@ -562,6 +562,53 @@ def test_lightning_shaped_optimizer_hooks_match_the_trainer():
     assert float((finals[0] - finals[1]).abs().max()) < 2e-6 * float(finals[0].abs().max()), float((finals[0] - finals[1]).abs().max())
 
 
+def test_optimizer_state_dict_resumes_bit_identically():
+    """FlatAdamOptimizer keeps the Adam moments and the step counter in flat buffers outside ``Optimizer.state``; its
+    state_dict / load_state_dict must carry them: two steps, checkpoint, one more step == restore into a fresh
+    model + optimiser, that same third step - bit for bit (the step is deterministic with dropout off)."""
+    import dataclasses
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    arch = dataclasses.replace(ARCHS["hubert"], layers=1)
+    sd = random_hubert_state_dict(arch, seed=3)
+    g = torch.Generator().manual_seed(17)
+    B, L = 4, 8000
+    batch = {"wav": torch.randn(B, L, generator=g).cuda(), "wav_len": torch.tensor([8000, 6000, 8000, 5000]),
+             "image": torch.randn(B, 512, generator=g).cuda(), "id": torch.tensor([0, 1, 1, 2]).cuda()}
+
+    def make():
+        torch.manual_seed(3)
+        cfg = base_parallel_config()
+        cfg.audio_encoder.max_audio_len = -1
+        model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
+        (opt,), (sch,) = model.configure_optimizers()
+        return model, opt, sch["scheduler"]
+
+    def one_step(model, opt, sch):
+        opt.zero_grad()
+        model.training_step_end(model.training_step(batch))["loss"].backward()
+        opt.step()
+        sch.step()
+
+    model, opt, sch = make()
+    one_step(model, opt, sch)
+    one_step(model, opt, sch)
+    ckpt = {"model": {k: v.clone() for k, v in model.state_dict().items()}, "opt": opt.state_dict(), "sch": sch.state_dict()}
+    assert ckpt["opt"]["flat_adam"]["step_count"] == 2 and float(ckpt["opt"]["flat_adam"]["v"].abs().sum()) > 0
+    one_step(model, opt, sch)
+    torch.cuda.synchronize()
+    want = opt.flat.flat_p.clone()
+    model2, opt2, sch2 = make()
+    model2.load_state_dict(ckpt["model"])
+    opt2.load_state_dict(ckpt["opt"])
+    sch2.load_state_dict(ckpt["sch"])
+    one_step(model2, opt2, sch2)
+    torch.cuda.synchronize()
+    assert torch.equal(opt2.flat.flat_p, want)
+    with pytest.raises(KeyError):
+        opt2.load_state_dict({k: v for k, v in ckpt["opt"].items() if k != "flat_adam"})
+
+
 YAML_HYBRID_BASE = """
 model_settings:
   cascaded_objective_weight: 1.0
@@ -602,12 +649,14 @@ trainer: {max_steps: 50000, gradient_clip_val: 4, accumulate_grad_batches: 1, pr
 def test_model_from_reference_shaped_yaml_hybrid_plus_base():
     """A recipe written with the reference's yaml keys (the Hybrid+ base geometry: d_model 768 with 8 heads = head_dim 96, the
     shape the attention block pads to 128) builds the model and trains a step; the reduced-vocabulary table path that does not
-    exist here falls back to the synthetic 8112-sub-word table."""
+    exist here raises unless the synthetic 8112-sub-word table is asked for."""
     import dataclasses
     from speechclip_plus_amd import KWClip_GeneralTransformer, load_config, random_hubert_state_dict, set_dropout
     from speechclip_plus_amd.speech_encoder import ARCHS
     from speechclip_plus_amd.train import ContrastiveTrainer
-    cfg = load_config(YAML_HYBRID_BASE)
+    with pytest.raises(FileNotFoundError):               # a real recipe must find its vocabulary table ...
+        load_config(YAML_HYBRID_BASE)
+    cfg = load_config(YAML_HYBRID_BASE, allow_synthetic_vocab=True)       # ... random-weight runs opt in to a synthetic one
     assert cfg.clip.embed_dim == 512 and cfg.clip.reduce_subword_embbedding.numel() == 8112
     cfg.clip.layers = 2
     arch = dataclasses.replace(ARCHS["hubert_base"], layers=2)

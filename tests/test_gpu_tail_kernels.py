@@ -245,3 +245,26 @@ def test_transformer_encoder_full_sequence_vs_reference_fixture(golden, name):
     (out * valid.cuda()).sum().backward()                              # the whole layer is differentiable on the kernel path
     assert torch.isfinite(src.grad).all() and float(src.grad.abs().sum()) > 0
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
+
+
+def test_cif_prepare_guards_all_zero_weights_and_clamps_to_the_allocated_slots():
+    """an utterance whose clipped weights are all zero must not produce inf / NaN under the target-length scaling
+    (ratio 0, feat_len 1), and feat_len is clamped to the slots the host allocated (T), not only to MAX_FEAT_LEN."""
+    from speechclip_plus_amd import ops
+    dev = "cuda:0"
+    B, S = 3, 40
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(B, S, generator=g)
+    a[1] = -0.5                                            # clips to all-zero
+    pad = torch.zeros(B, S, dtype=torch.bool)
+    pad[2, 30:] = True
+    target = torch.tensor([4, 3, 9])
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    r = ops.cif_prepare(a.to(dev), pad.to(dev), target.to(dev), True, 1.0, 1e-5, 75, 6, flags)     # host sized the output for 6 slots
+    torch.cuda.synchronize()
+    for k in ("alpha", "csum", "quantity", "ratio"):
+        assert bool(torch.isfinite(r[k]).all()), k
+    assert r["feat_len"].tolist() == [4, 1, 6]             # utterance 2 asked for 9 keywords: clamped to the 6 allocated slots
+    assert float(r["alpha"][1].abs().sum()) == 0.0 and float(r["ratio"][1]) == 0.0
+    assert flags[0].item() == 2                            # two utterances with a positive weight sum
+    assert flags[1].item() == 2                            # utterance 1 (1 != 3) and utterance 2 (6 != 9) disagree with their targets

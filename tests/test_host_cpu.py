@@ -153,7 +153,9 @@ clip: {name: ViT-L/14, reduce_subword_embbedding: ./avssl/data/coco_stat/none.np
 audio_encoder: {type: FairseqHubert, name: hubert_large_ll60k, trainable: false, feat_select_idx: weighted_sum,
                 optim: {name: Adam, args: {lr: 1.e-4, weight_decay: 1.e-6}}}
 """
-    cfg = load_config(text)
+    with pytest.raises(FileNotFoundError):
+        load_config(text)
+    cfg = load_config(text, allow_synthetic_vocab=True)
     assert cfg.clip.embed_dim == 768 and cfg.clip.reduce_subword_embbedding.numel() == 19787
     assert cfg.retrieval.recall_at == [1, 5, 10] and cfg.audio_encoder.optim.args.lr == 1e-4
     files = glob.glob("/root/reference/config/*/*/*.yaml") + glob.glob("/root/reference/config/*/*/*/*.yaml")

@@ -103,7 +103,7 @@ def build_model(device: str = "cuda:0"):
     return model
 
 
-def hip_recall(model, fixture: dict, batch: int = 125) -> dict:
+def hip_recall(model, fixture: dict, batch: int = 40, dump: str = None) -> dict:
     """Embeds the 5000 utterances with ``model`` and compares recall@{1,5,10} with the oracle numbers held by the fixture."""
     import numpy as np
     from speechclip_plus_amd import mutualRetrieval
@@ -117,6 +117,9 @@ def hip_recall(model, fixture: dict, batch: int = 125) -> dict:
         for s in range(0, len(order), batch):
             sel = order[s: s + batch]
             emb[sel] = model.encode_speech([wavs[i].to(dev) for i in sel])["parallel_audio_feat"].float().cpu()
+    if dump:
+        import numpy as _np
+        _np.save(dump, emb.numpy())
     a = F.normalize(emb, dim=-1)
     score = a.to(dev) @ image.to(dev).t()
     img_ids = torch.arange(n_ids, device=dev)
