@@ -146,6 +146,10 @@ def main():
         trainer.step(batch)
     torch.cuda.synchronize()
     ops.set_timer(None)
+    # ---- N > 1: K more steps with brackets around the collectives (every rank), so that a scaling record explains itself ---------
+    collectives = None
+    if dist is not None:
+        collectives = collective_report(dist, dev, args.steps, elapsed / args.steps * 1e3, lambda: trainer.step(batch))
     # ---- forward only (north_star: fraction of the MFMA bf16 peak on the HuBERT + attention-pool forward) ---------
     fwd_ms = fwd_train_ms = None
     if rank == 0 and args.model == "base":
@@ -228,6 +232,7 @@ def main():
                                    "on, as the reference's train step: HuBERT in train mode (base: input / residual / attention "
                                    "p=0.1; large: 0) + head p=0.1; masks = stateless hash inside the GEMM / attention kernels")},
             "rccl_ranks": rccl_ranks, "dist_backend": (os.environ.get("SC_DIST_BACKEND", "nccl") if dist is not None else None),
+            "collectives": collectives,
             "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,
             "forward": None if fwd_ms is None else forward_summary(fwd_ms, B, L, T),
             "forward_train_mode": None if fwd_train_ms is None else forward_summary(fwd_train_ms, B, L, T),
@@ -254,6 +259,40 @@ def launch_ranks(n: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
+
+
+def collective_report(dist, dev, steps: int, own_ms_per_step: float, step_fn) -> dict:
+    """N > 1 diagnostics (every rank calls this; the numbers of all ranks come back on each).  ``steps`` more steps run with
+    brackets (speechclip_plus_amd.parallel.CommTimer) around the packed all-gather (main stream: all of it is exposed, and it
+    absorbs the arrival skew between ranks), the gradient all-reduce (side stream) and the main stream's wait for the side stream
+    at the next step's join point (= the part of all-reduce + clip + Adam that the frozen encoder forward did not hide).
+    ``own_ms_per_step``: this rank's own clock over the TIMED region (before the max over ranks that ``value`` uses)."""
+    from speechclip_plus_amd.parallel import CommTimer, set_comm_timer
+    world = dist.get_world_size()
+    timer = CommTimer()
+    set_comm_timer(timer)
+    for _ in range(steps):
+        step_fn()
+    summ = timer.summary(steps)
+    set_comm_timer(None)
+    names = ("all_gather", "all_reduce", "join_wait")
+    mine = [own_ms_per_step] + [summ.get(n, {}).get("us_per_step", 0.0) for n in names]
+    on_dev = os.environ.get("SC_DIST_BACKEND", "nccl") == "nccl"
+    t = torch.tensor(mine, dtype=torch.float64, device=dev if on_dev else "cpu")
+    allt = torch.empty(world * len(mine), dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(allt, t)
+    allt = allt.view(world, len(mine)).cpu()
+    out = {"measured_in": f"{steps} extra steps with event brackets on the issuing streams (not the timed region)",
+           "ms_per_step_by_rank": {"min": round(float(allt[:, 0].min()), 3), "max": round(float(allt[:, 0].max()), 3),
+                                   "all": [round(float(v), 3) for v in allt[:, 0]]}}
+    for i, n in enumerate(names):
+        col = allt[:, 1 + i]
+        out[n + "_us"] = {"rank0": round(float(col[0]), 1), "min": round(float(col.min()), 1), "max": round(float(col.max()), 1),
+                          "calls_per_step": summ.get(n, {}).get("calls_per_step", 0)}
+    exposed = allt[:, 1] + allt[:, 3]
+    out["exposed_us_per_step"] = {"rank0": round(float(exposed[0]), 1), "max": round(float(exposed.max()), 1),
+                                  "is": "all_gather (on the main stream) + join_wait (main stream blocked on the side stream)"}
+    return out
 
 
 def count_ranks(dist, dev) -> int:
@@ -287,9 +326,19 @@ def rehearse_launch(args, world: int) -> None:
     ar.launch()
     ar.wait()
     assert float(flat[0]) == world * (world + 1) / 2
+    collectives = None
+    if world > 1:                                   # the N > 1 diagnostics field, here with wall-clock brackets on CPU tensors
+        def step():
+            x = torch.randn(B, E, requires_grad=True)
+            gather_loss_feats(x, torch.randn(B, E), torch.arange(B) + rank * B)[0].sum().backward()
+            f = torch.ones(1000)
+            r = GradAllReduce(f)
+            r.launch()
+            r.wait()
+        collectives = collective_report(dist, "cpu", 3, 1.0 + rank, step)
     if rank == 0:
         print(json.dumps({"metric": "utterances/sec (train step)", "value": None, "unit": "utterances/s", "n_gpus": world,
-                          "steps": 0, "warmup": 0, "rehearsal": "launch plumbing only (no GPU work)", "rccl_ranks": ranks,
+                          "steps": 0, "warmup": 0, "rehearsal": "launch plumbing only (no GPU work)", "rccl_ranks": ranks, "collectives": collectives,
                           "dist_backend": os.environ.get("SC_DIST_BACKEND", "gloo") if world > 1 else None}), flush=True)
     if world > 1:
         dist.barrier()
@@ -382,8 +431,9 @@ def source_sha(names) -> str:
 
 
 def recall_parity(dev):
-    """recall@{1,5,10} of the HIP model on the 5000-utterance synthetic eval set against the oracle numbers held by
-    tests/golden/recall_eval.npz (tools/recall_eval.py; the oracle itself is not run here)."""
+    """recall@{1,5,10} of the HIP model on the 5000-utterance synthetic eval set against the two references held by
+    tests/golden/recall_eval.npz - the fp32 oracle and the bf16-storage-emulated oracle (tools/recall_eval.py; the oracle itself is
+    not run here)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import recall_eval

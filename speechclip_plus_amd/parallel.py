@@ -19,6 +19,71 @@ import torch
 import torch.distributed as dist
 
 
+class CommTimer:
+    """Brackets around the step's collectives, for the N > 1 diagnostics of bench.py (``collectives`` field): HIP events recorded
+    on the stream the collective is issued on (the all-gather on the main stream, the all-reduce on its side stream, the main
+    stream's wait for the side stream at the join point), wall clock for CPU tensors (gloo rehearsal).  Off unless installed with
+    ``set_comm_timer``: the timed region of the bench runs without it."""
+
+    def __init__(self):
+        self.spans = {}
+
+    class _Span:
+        def __init__(self, timer, name, cuda):
+            self.timer, self.name, self.cuda = timer, name, cuda
+
+        def __enter__(self):
+            if self.cuda:
+                self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            else:
+                import time
+                self.t0 = time.perf_counter()
+            return self
+
+        def __exit__(self, *exc):
+            if self.cuda:
+                self.e1.record()
+                self.timer.spans.setdefault(self.name, []).append((self.e0, self.e1))
+            else:
+                import time
+                self.timer.spans.setdefault(self.name, []).append(time.perf_counter() - self.t0)
+            return False
+
+    def span(self, name: str, cuda: bool):
+        return CommTimer._Span(self, name, cuda)
+
+    def summary(self, steps: int) -> dict:
+        """microseconds per step and calls per step of every bracket (synchronises)."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        out = {}
+        for name, spans in self.spans.items():
+            us = sum(s * 1e6 if isinstance(s, float) else s[0].elapsed_time(s[1]) * 1e3 for s in spans)
+            out[name] = {"us_per_step": round(us / max(steps, 1), 1), "calls_per_step": round(len(spans) / max(steps, 1), 2)}
+        return out
+
+
+_comm_timer: Optional["CommTimer"] = None
+
+
+def set_comm_timer(t: Optional["CommTimer"]) -> None:
+    global _comm_timer
+    _comm_timer = t
+
+
+class _NoSpan:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def comm_span(name: str, cuda: bool):
+    return _comm_timer.span(name, cuda) if _comm_timer is not None else _NoSpan()
+
+
 def dp_world(group: Optional[dist.ProcessGroup] = None) -> int:
     """World size as the data-parallel code sees it: 1 without an initialised process group.  With SC_FORCE_COLLECTIVES=1 a
     one-rank group reports 2 to the callers' "is there anything to exchange" checks, so every collective of the step is
@@ -41,7 +106,8 @@ class _AllGatherRows(torch.autograd.Function):
         ctx.rank = dist.get_rank(group)
         ctx.n = x.shape[0]
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
-        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        with comm_span("all_gather", x.is_cuda):
+            dist.all_gather_into_tensor(out, x.contiguous(), group=group)
         return out
 
     @staticmethod
@@ -93,10 +159,14 @@ class GradAllReduce:
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
+            with torch.cuda.stream(self.stream), comm_span("all_reduce", True):
                 self.work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            self.work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            with comm_span("all_reduce", False):
+                self.work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if not self.flat_grad.is_cuda:
+                    self.work.wait()             # CPU tensors (gloo rehearsal): the bracket is wall clock, so it must cover the wait
+                    self.work = None
 
     def wait(self) -> None:
         if self.work is not None:

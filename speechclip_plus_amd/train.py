@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from .optim import FlatAdam, linear_warmup_decay
-from .parallel import GradAllReduce, dp_world, gather_loss_feats, scale_replicated_grads
+from .parallel import GradAllReduce, comm_span, dp_world, gather_loss_feats, scale_replicated_grads
 
 
 class ContrastiveTrainer:
@@ -59,17 +59,21 @@ class ContrastiveTrainer:
         lo, hi = self._layer_span[i]
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
+            with torch.cuda.stream(self.side), comm_span("all_reduce", True):
                 dist.all_reduce(self.opt.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
         else:
-            dist.all_reduce(self.opt.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            with comm_span("all_reduce", False):
+                dist.all_reduce(self.opt.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
         self._reduced.append((lo, hi))
 
     def join(self) -> None:
         """Make the current stream wait for the optimiser work of the previous step (no host synchronisation)."""
         if self._pending:
             if self.side is not None:
-                torch.cuda.current_stream().wait_stream(self.side)
+                # bracket = how long the main stream sits blocked here: the part of the side stream's work (all-reduce, clip + Adam)
+                # that the next step's frozen encoder forward did NOT cover
+                with comm_span("join_wait", True):
+                    torch.cuda.current_stream().wait_stream(self.side)
             self.opt.zero_grad()                      # gradients of the finished step stay readable until the next step needs the buffer
         self._pending = False
 
@@ -127,7 +131,8 @@ class ContrastiveTrainer:
             pos = 0
             for lo, hi in sorted(self._reduced) + [(self.opt.n, self.opt.n)]:
                 if lo > pos and self._world() > 1:
-                    dist.all_reduce(self.opt.flat_g[pos:lo], op=dist.ReduceOp.SUM, group=self.group)
+                    with comm_span("all_reduce", self.opt.flat_g.is_cuda):
+                        dist.all_reduce(self.opt.flat_g[pos:lo], op=dist.ReduceOp.SUM, group=self.group)
                 pos = max(pos, hi)
             self._reduced = []
         self.opt.step(lr=lr)

@@ -89,6 +89,13 @@ def test_bench_self_launches_its_ranks():
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["dist_backend"] == "gloo"
+    # the N > 1 diagnostics: per-collective time, exposed time, per-rank step time - present and sane
+    c = rec["collectives"]
+    assert c["ms_per_step_by_rank"]["all"] == [1.0, 2.0] and c["ms_per_step_by_rank"]["max"] == 2.0
+    for key in ("all_gather_us", "all_reduce_us", "join_wait_us"):
+        assert set(c[key]) >= {"rank0", "min", "max", "calls_per_step"} and c[key]["min"] <= c[key]["max"]
+    assert c["all_gather_us"]["calls_per_step"] == 1 and c["all_reduce_us"]["calls_per_step"] == 1 and c["all_gather_us"]["rank0"] > 0
+    assert abs(c["exposed_us_per_step"]["rank0"] - c["all_gather_us"]["rank0"] - c["join_wait_us"]["rank0"]) < 0.2
     # a failing rank must surface as a non-zero exit code of the parent
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch", "--batch", "-1"],
                        env=env, capture_output=True, text=True, timeout=170)

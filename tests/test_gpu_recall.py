@@ -1,25 +1,25 @@
 """GPU: recall@k parity on the Flickr8k-test-shaped synthetic eval set of SURVEY 8d (1000 image ids x 5 utterances = 5000 audio
-queries; tests/golden/recall_eval.npz generated from the CPU oracle by tests/golden/make_recall_fixture.py).
+queries), round-3 form.  North star: recall@1 within +-0.1 of the reference, recall@k identical.
 
-The HIP model (same seeded weights, waveforms regenerated from the same seeds) embeds the 5000 utterances; recall@{1,5,10} in both
-directions is computed by the product's mutualRetrieval against the fixture's image embeddings and compared with the oracle's
-numbers.  Resolution: one utterance = 0.02 points of A->I recall, one image = 0.1 points of I->A recall.
+The fixture (tests/golden/make_recall_fixture.py, run in the build container on the CPU oracle) holds TWO references:
+  * fp32      the oracle as it restates the reference's arithmetic;
+  * bf16emu   the same oracle with bf16 rounding at exactly the tensors the HIP path stores in bf16 and on the GEMM weights it
+              holds in bf16 (oracle/hubert_ref.py: bf16_store, bf16_weights) - what ANY implementation with this storage format
+              computes, up to summation order.
+and an image gallery whose confusions are planted at discrete score levels (tools/recall_eval.build_gallery), so that the eval
+set's own margins resolve +-0.1: tests/golden/recall_eval_margins.json lists the oracle's margin histogram; 0.1 % of the held-out
+queries lie within 3 sigma of the bf16 margin noise at the rank-1 boundary, none at the rank-5 / rank-10 boundaries.
 
-Measured (MI355X, r02): A->I recall@1/5/10 HIP 48.66 / 75.62 / 83.96 vs oracle 50.04 / 76.34 / 84.52; I->A 93.4 / 99.8 / 100 vs
-93.7 / 99.9 / 100; 161 of 5000 utterances change their rank-1 status, every one of them with an oracle score margin (own image vs
-best other image) below 8.4e-3; embedding cosine HIP vs oracle >= 0.99973.
+What round 2 measured as "-0.56 points, bf16 noise" was neither: the oracle had been embedded in length-sorted batches of 40 and
+the HIP model in batches of 125, and conv layer 0's GroupNorm takes its statistics over the PADDED batch length (fairseq
+semantics, reproduced by both).  With the batch composition fixed (recall_eval.BATCH, part of the protocol now) the HIP embeddings
+sit at the same distance from the fp32 oracle as the emulation does (0.0056, of which 0.0050 is ONE common shift caused by the
+bf16 weights) and 0.0028 from the emulation itself with no common component - storage precision, no kernel bias.
 
-Why this set cannot resolve the north-star's +-0.1 on recall@1 - for ANY reduced-precision implementation, the reference's own
-precision-16 GPU recipe included: with random (untrained) weights the CLS pooling averages ~100 statistically identical frames, so
-all 5000 embeddings share one dominant direction and the part that tells utterances apart is ~9 % of the norm; the bf16 encoder's
-error is ~2.3 % of the norm (cosine 0.9997), i.e. a quarter of the signal, and 5.5 % of the utterances have an oracle margin
-below 1e-3.  In addition the image embeddings are built from the ORACLE's audio embeddings (class means), which hands the oracle
-its own rounding noise as signal and biases the comparison against any other implementation (the -1.4 points at @1).  A trained
-checkpoint (embeddings spread over the sphere) is what resolves +-0.1; none exists offline.  The test therefore pins what this
-set CAN show: (a) the embeddings agree (cosine >= 0.9995), (b) every rank-1 flip is a near-tie of the oracle's own scores
-(margin < 1.2e-2), (c) recalls within 2.0 points at @1 and 1.0 at @5 / @10, both directions, and - the unbiased comparison - within
-1.0 point on the 2000 HELD-OUT queries (captions 3 and 4 of every id, which never entered an image embedding).  bench.py reports
-the same numbers in its ``recall`` field (tools/recall_eval.py)."""
+The test requires, against BOTH references: recall@1 within 0.1 (all queries, the 2000 held-out ones, and image -> audio), recall@5
+and recall@10 identical; and as evidence that the remaining difference is storage precision: the HIP embeddings are closer to the
+emulated oracle than the emulated oracle is to fp32, and the measured HIP-vs-fp32 margin noise puts < 0.2 % of the held-out
+queries inside 3 sigma."""
 import os
 import sys
 
@@ -36,10 +36,17 @@ def test_recall_at_k_matches_the_oracle_on_5000_utterances(golden):
     fx = golden("recall_eval.npz")
     r = recall_eval.hip_recall(recall_eval.build_model(), fx)
     print("recall parity:", r)
-    assert r["queries"] == 5000 and r["images"] == 1000
-    assert r["embedding_cosine_min"] > 0.9995
-    assert r["worst_oracle_margin_of_a_flip"] < 1.2e-2
-    for key, tol1, tolk in [("audio_to_image", 2.0, 1.0), ("image_to_audio", 2.0, 1.0), ("audio_to_image_heldout", 1.0, 1.0)]:
-        hip, ora = r[key]["hip"], r[key]["oracle"]
-        assert abs(hip[0] - ora[0]) <= tol1, (key, hip, ora)
-        assert max(abs(h - o) for h, o in zip(hip[1:], ora[1:])) <= tolk, (key, hip, ora)
+    assert r["queries"] == 5000 and r["images"] == 1000 and r["batch"] == recall_eval.BATCH
+    hip = r["hip"]
+    for ref in ("oracle_fp32", "oracle_bf16emu"):
+        o = r[ref]
+        for key in ("audio_to_image", "audio_to_image_heldout", "image_to_audio"):
+            assert abs(hip[key][0] - o[key][0]) <= 0.1, (ref, key, hip[key], o[key])          # recall@1: north star's +-0.1
+            assert hip[key][1:] == o[key][1:], (ref, key, hip[key], o[key])                   # recall@5, @10: identical
+        assert o["embedding_cosine_min"] > 0.9999, (ref, o)
+    # precision, not defect: no further from the emulated oracle than the emulation is from fp32 ...
+    assert r["oracle_bf16emu"]["embedding_distance_mean"] <= r["emulation_distance_from_fp32"], r
+    # ... and as far from fp32 as the emulation itself (same storage format), within 25 %
+    assert r["oracle_fp32"]["embedding_distance_mean"] <= 1.25 * r["emulation_distance_from_fp32"], r
+    # the eval set resolves the target: < 0.2 % of the held-out queries within 3 sigma of the measured margin noise
+    assert max(r["margin_noise_vs_fp32"]["heldout_fraction_within_3_sigma_at_1_5_10"]) < 0.002, r["margin_noise_vs_fp32"]

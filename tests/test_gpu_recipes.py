@@ -108,7 +108,7 @@ def test_plus_recipe_train_step_vs_oracle_at_full_dims(kind):
     margin = cos.gather(-1, aux["tokens"].unsqueeze(-1)) - cos.gather(-1, tok_hip.unsqueeze(-1))
     assert float(margin[differ].max() if differ.any() else 0.0) < NEAR_TIE, (margin[differ], int(differ.sum()), int(valid.sum()))
     agreement = 1.0 - float(differ.sum()) / float(valid.sum())
-    assert agreement >= 0.6, agreement
+    assert agreement >= 0.9, agreement            # measured: 27 of 27 at both recipes
     print(f"{kind}: token agreement {agreement:.3f} over {int(valid.sum())} keywords; worst margin of a flipped one "
           f"{float(margin[differ].max()) if differ.any() else 0.0:.2e}")
     # ---- oracle with the discrete choices shared: everything continuous

@@ -1,12 +1,15 @@
 """CPU: the oracle (torch fp32 restatement) against the golden vectors produced by the reference's own
 leaf files (tests/golden/make_golden.py) and against the independent HF HuBERT implementation."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 import oracle
 from oracle.lengths import conv_out_lengths, fairseq_valid_frames, feat_len_rule, get_keypadding_mask
-from conftest import weights_from
+from conftest import ROOT, weights_from
 
 T = torch.from_numpy
 
@@ -232,3 +235,46 @@ def test_head_train_mode_dropout_sites_vs_torch_layer():
         W, "enc.", x, kpm, 1, H, drop=lambda site, i, t: t if site == "attn" else t * masks[site])
     valid = ~kpm
     np.testing.assert_allclose(out[valid].detach().numpy(), ref[valid].detach().numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_recall_fixture_is_reproduced_by_the_oracle_and_resolves_the_target(golden):
+    """tests/golden/recall_eval.npz (round 3): (a) the fp32 oracle and its bf16-storage emulation reproduce the stored embeddings
+    of the utterances of one protocol batch (the batch that holds utterance 0: same length-sorted composition, BATCH = 40);
+    (b) the stored ranks give the recalls of recall_eval_margins.json, and the two references agree on every rank-1 / 5 / 10
+    decision; (c) the eval set resolves +-0.1: < 0.2 % of the held-out queries have an oracle margin within 3 sigma of the
+    emulation's margin noise at any of the three boundaries."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import recall_eval as rev
+    fx = golden("recall_eval.npz")
+    summ = json.load(open(os.path.join(ROOT, "tests", "golden", "recall_eval_margins.json")))
+    n_ids = int(fx["n_ids"])
+    assert int(fx["batch"]) == rev.BATCH == summ["protocol"]["batch"]
+    wavs, ids = rev.eval_set(n_ids)
+    order = sorted(range(len(wavs)), key=lambda i: len(wavs[i]))
+    pos = order.index(0)
+    sel = order[pos // rev.BATCH * rev.BATCH: pos // rev.BATCH * rev.BATCH + rev.BATCH]
+    Wh, Whead, arch = rev.hubert_weights(), rev.head_weights(), oracle.HubertArch.base()
+    members = [i for i in sel if i < 64]
+    assert 0 in members
+    for name, W, store in (("fp32", Wh, None), ("bf16emu", oracle.bf16_weights(Wh), oracle.bf16_store)):
+        with torch.no_grad():
+            hs, fl = oracle.speech_encoder_forward(W, arch, [wavs[i] for i in sel], store=store)
+            f = oracle.weighted_sum(rev.WS_WEIGHTS, hs)
+            e = oracle.parallel_branch_forward(Whead, f if store is None else store(f), fl, nhead=8)
+        want = T(fx["emb_head_" + name])
+        for i in members:
+            got = e[sel.index(i)]
+            assert float((got - want[i]).norm() / want[i].norm()) < 2e-4, (name, i)      # thread count / summation order only
+    held = (torch.arange(len(ids)) % rev.PER_ID) >= rev.GALLERY
+    for name in ("fp32", "bf16emu"):
+        r_ai, r_ia = T(fx["rank_ai_" + name]).long(), T(fx["rank_ia_" + name]).long()
+        assert rev.recalls(r_ai) == summ[name]["audio_to_image"] and rev.recalls(r_ia) == summ[name]["image_to_audio"]
+        assert rev.recalls(r_ai, held) == summ[name]["audio_to_image_heldout"]
+    for k in (1, 5, 10):
+        assert torch.equal(T(fx["rank_ai_fp32"]).long() < k, T(fx["rank_ai_bf16emu"]).long() < k)
+        assert torch.equal(T(fx["rank_ia_fp32"]).long() < k, T(fx["rank_ia_bf16emu"]).long() < k)
+    sigma = summ["bf16emu"]["margin_noise_sigma"]
+    m = T(fx["margin_ai_fp32"])
+    assert float((m[held].abs() < 3 * sigma).float().mean(0).max()) < 0.002
+    assert 0 < rev.recalls(T(fx["rank_ai_fp32"]).long())[0] < 100          # neither 0 nor 100 (SURVEY 8d)
