@@ -28,7 +28,7 @@ extern "C" {
 typedef uint16_t sc_bf16;
 
 const char* sc_last_error(void);
-int sc_abi_version(void);
+int sc_abi_version(void);     /* 3 since round 3 (sc_gemm_args grew the LayerNorm-folding fields) */
 /* tuning switches for same-process A/B measurements (tools/); results never depend on them.  key 1: the 256-row GEMM uses
  * plain instead of non-temporal stores on tiles with a residual. */
 int sc_set_option(int32_t key, int32_t value);
@@ -78,8 +78,27 @@ typedef struct {
                                      re-read while still in the L2 instead of 16 K-tiles later from the fabric. Only the
                                      fp32 summation order over k changes; every tile family uses the same order, so results do not depend on
                                      the dispatcher's choice. */
-    int32_t pad_;
+    /* ---- LayerNorm folded into its neighbour GEMMs (256-row tile family only; see csrc/gemm256_bf16.hip, "LN").  A row-statistics
+     * buffer is [M][8][2] fp32: per row 8 strip slots of (sum, sum of squares) - one strip per N-tile of the GEMM that wrote it, at most 4 used (N <= 1024); the
+     * strips a producer does not write must be ZERO (allocate the buffer zeroed): consumers add the first four slots of a line.
+     *   consumer (no residual, no dropout): A holds RAW (pre-LayerNorm) rows, W = W0 diag(gamma) folded by the caller,
+     *       ln_stats / ln_ns = the statistics of A's rows and the number of valid strips, ln_colsum[n] = sum_k W[n,k] (of the bf16
+     *       values), bias[n] = sum_k beta[k] W0[n,k] + bias0[n];   C = rstd_m (A W^T - mean_m ln_colsum) + bias  -> act -> store
+     *   producer (residual given, act = 0): stats_out receives the statistics of the bf16 rows of C (strip = N-tile index;
+     *       sc_gemm_stats_strips() tells how many the dispatcher's tile width gives); res_stats (+ res_ns, res_gamma, res_beta):
+     *       the residual operand holds RAW rows too and enters as LayerNorm(residual row) = (r - mean) rstd gamma[n] + beta[n].
+     *   ln_eps: the LayerNorm epsilon of both uses. */
+    int32_t ln_ns;
+    const float* ln_stats;
+    const float* ln_colsum;
+    const float* res_stats;
+    const float* res_gamma;
+    const float* res_beta;
+    float* stats_out;
+    int32_t res_ns;
+    float ln_eps;
 } sc_gemm_args;
+int32_t sc_gemm_stats_strips(const sc_gemm_args* args);   /* strips a producer launch with these args writes per row (0: not on the 256-row family) */
 int sc_gemm_bf16(const sc_gemm_args* args, void* stream);
 uint32_t sc_hash32(uint32_t x);   /* host twin of the kernels' dropout hash (lowbias32): reconstructs a mask exactly */
 
@@ -184,6 +203,14 @@ int sc_wsum_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, int3
                 int32_t row_off, int32_t normalize, void* stream);
 int sc_wsum_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial /*[nblk, NL]*/, int32_t nblk,
                 int32_t B, int32_t R, int32_t D, int32_t row_off, int32_t normalize, void* stream);
+/* The same sums over RAW hidden states (LayerNorm folded into the encoder GEMMs, see sc_gemm_args): layers n >= first_lazy of h hold
+ * the rows in FRONT of the layer's final LayerNorm; stats [NL][B*R][8][2] fp32 their row statistics (ns valid strips), gamma / beta
+ * [NL][D] the LayerNorm affines (rows < first_lazy unused): the summed state is (raw - mean) rstd gamma_n + beta_n in fp32. */
+int sc_wsum_lazy_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, int32_t B, int32_t R, int32_t D, int32_t row_off,
+                     const float* stats, const float* gamma, const float* beta, int32_t first_lazy, int32_t ns, float eps, void* stream);
+int sc_wsum_lazy_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial /*[nblk, NL]*/, int32_t nblk, int32_t B, int32_t R,
+                     int32_t D, int32_t row_off, const float* stats, const float* gamma, const float* beta, int32_t first_lazy,
+                     int32_t ns, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CLS attention pooling (the query row 0 of the parallel branch's TransformerEncoder layer;
@@ -390,6 +417,17 @@ typedef struct {
     float eps, p_attn, p_res;
     uint32_t seed_attn, seed_o, seed_fc2;
     sc_bf16 *qk, *vt, *ctx, *pre, *x1, *ffn;        /* scratch */
+    /* ---- fused_ln = 1 (post-LN order only): no LayerNorm launch - the residual stream stays RAW and the two LayerNorms are folded
+     * into their neighbour GEMMs (sc_gemm_args, "LayerNorm folded").  `out` then receives the rows in FRONT of the layer's final
+     * LayerNorm and out_stats their row statistics; x may itself be such a raw output (x_stats != NULL, x_ns strips, x_ln_g / x_ln_b =
+     * the affine of the LayerNorm that applies to it; qkv_w / qkv_b / qkv_colsum are then the folded forms for THAT LayerNorm).
+     * fc1_w / fc1_b / fc1_colsum are always the forms folded with ln1; ln1_g / ln1_b are still read (the residual of fc2).
+     * stats1: scratch for the statistics of `pre`.  x1 is not used. */
+    int32_t fused_ln, x_ns;
+    const float* x_stats;
+    const float *x_ln_g, *x_ln_b;
+    const float *qkv_colsum, *fc1_colsum;
+    float *stats1, *out_stats;
 } sc_hubert_layer_args;
 int sc_hubert_layer_fwd(const sc_hubert_layer_args* args, void* stream);
 #define SC_WS_INFONCE 0       /* a = Bg */

@@ -29,7 +29,9 @@ class GemmArgs(ctypes.Structure):
         ("sBias1", c_i64), ("sBias2", c_i64), ("sR1", c_i64), ("sR2", c_i64),
         ("tile", c_int), ("reserved", c_int),
         ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32),
-        ("tap_c", c_int), ("pad_", c_int),
+        ("tap_c", c_int), ("ln_ns", c_int),
+        ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("res_stats", c_void_p), ("res_gamma", c_void_p), ("res_beta", c_void_p),
+        ("stats_out", c_void_p), ("res_ns", c_int), ("ln_eps", ctypes.c_float),
     ]
 
 
@@ -44,6 +46,8 @@ class HubertLayerArgs(ctypes.Structure):
         ("eps", ctypes.c_float), ("p_attn", ctypes.c_float), ("p_res", ctypes.c_float),
         ("seed_attn", ctypes.c_uint32), ("seed_o", ctypes.c_uint32), ("seed_fc2", ctypes.c_uint32),
         ("qk", c_void_p), ("vt", c_void_p), ("ctx", c_void_p), ("pre", c_void_p), ("x1", c_void_p), ("ffn", c_void_p),
+        ("fused_ln", c_int), ("x_ns", c_int), ("x_stats", c_void_p), ("x_ln_g", c_void_p), ("x_ln_b", c_void_p),
+        ("qkv_colsum", c_void_p), ("fc1_colsum", c_void_p), ("stats1", c_void_p), ("out_stats", c_void_p),
     ]
 
 
@@ -71,6 +75,10 @@ SIGNATURES = {
     "sc_posconv_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "sc_wsum_fwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "sc_wsum_bwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_wsum_lazy_fwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                         c_void_p],
+    "sc_wsum_lazy_bwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                         c_float, c_void_p],
     "sc_cls_scores": [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "sc_cif_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p],
     "sc_cif_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p],
@@ -95,6 +103,7 @@ SIGNATURES = {
                        c_void_p],
     "sc_softmax_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint32, c_void_p],
     "sc_softmax_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint32, c_void_p],
+    "sc_gemm_stats_strips": [ctypes.POINTER(GemmArgs)],
     "sc_cls_pool_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "sc_cls_pool_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "sc_sgemm_f32": [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_float, c_void_p, c_void_p],

@@ -37,6 +37,15 @@ constexpr int HALF_BYTES = 128 * ROWB;           // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;        // A0 A1 B0 B1
 constexpr int LDS_BYTES = 2 * BUF_BYTES;         // 128 KiB
 constexpr int EPI_BYTES = BUF_BYTES / 8;         // per-wave epilogue staging inside ONE ring buffer: 8 KiB
+// LN = 2 (row-statistics producer, see below): per wave [32 rows][8 chunks] (sum, sum of squares) of one epilogue pass, then
+// [128 rows] per wave for the whole tile, behind the ring
+constexpr int STATL_BYTES = 8 * 32 * 4 * 8;      // 8 KiB (chunk pairs: adjacent lanes are added by DPP first)
+constexpr int STATW_BYTES = 8 * 128 * 8;         // 8 KiB
+// LN != 0: the tile's 256 statistics rows (first 4 strips = 32 bytes each) and two vectors of column constants, prefetched by
+// LDS-DMA during K-tile 0 so that the epilogue never waits for global memory
+constexpr int ROWST_BYTES = 256 * 32;            // 8 KiB
+constexpr int COLC_BYTES = 2 * 256 * 4;          // 2 KiB
+constexpr int SC_STAT_STRIDE = 8;                // strips per row in a statistics buffer: [M][8][2] fp32 (one 64-byte line per row)
 
 #define SC_BAR()                               \
     do {                                       \
@@ -57,11 +66,23 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 // BN = 256 or 192 output columns per tile (wave block 128 x 64 or 128 x 48).  The narrower tile exists for wave
 // quantisation: with M = 32768, N = 768 / 2304 give 384 / 1152 tiles of 256 x 256 (1.5 / 4.5 rounds over 256 CUs) but
 // 512 / 1536 tiles of 256 x 192 (exactly 2 / 6 rounds).
-template <int DIAG, int BN, int ACT, int DROP, int RES>
+//
+// LN: LayerNorm without a LayerNorm kernel (round 3; the encoder layer's two LayerNorms used to be 25 launches and 2.4 GB of
+// HBM traffic per forward).  A LayerNorm sits between a residual GEMM (out_proj / fc2: "producer") and the next GEMM (fc1 / QKV:
+// "consumer"), and its output is also the next residual.  Here the residual stream stays RAW (pre-LayerNorm rows, bf16) and
+//   LN = 2  the producer's epilogue also emits, per output row and column strip (= N-tile), the sum and the sum of squares of
+//           the bf16 values it stored (p.stats_out [M][8][2]); if its residual operand is itself a raw row (p.res_stats), it is
+//           normalised on the fly: r = (raw - mean) rstd gamma[n] + beta[n];
+//   LN = 1  the consumer multiplies the RAW rows with W' = W diag(gamma) (folded on the host) and finishes in its epilogue:
+//           y = rstd_m (acc - mean_m s_n) + c_n,  s_n = sum_k W'[n,k],  c_n = sum_k beta[k] W[n,k] + bias[n]  (p.ln_colsum, p.bias),
+//           mean_m / rstd_m from the producer's strips (p.ln_stats, p.ln_ns).
+template <int DIAG, int BN, int ACT, int DROP, int RES, int LN>
 __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     constexpr int TN = BN / 4, FN = TN / 16, NB1 = FN - 2;   // per-wave columns, fragments, fragments of n-sub 1
     constexpr int NBI = BN / 64;                             // B-tile DMA instructions per wave and K-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LN_OFF_ROWST = LDS_BYTES + (LN == 2 ? STATL_BYTES + STATW_BYTES : 0);
+    constexpr int LN_OFF_COLC = LN_OFF_ROWST + ROWST_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -120,6 +141,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
 #pragma unroll
         for (int i = 0; i < NBI; ++i)
             glds16(b_src[i] + k0, smem + par * BUF_BYTES + 2 * HALF_BYTES + (i * 8 + wave) * 1024);
+    };
+    // LN: statistics rows of the tile (consumer: of A's rows; producer: of the raw residual's rows) and the column constants
+    // (consumer: s_n, c_n; producer: gamma, beta of the residual's LayerNorm) -> LDS.  One 16-byte piece per lane: wave w brings
+    // rows 32 w .. 32 w + 31 (two pieces each), waves 0 / 1 one vector of 256 columns each.
+    auto dma_ln = [&](int m0, int n0) {
+        const float* st = LN == 1 ? p.ln_stats : p.res_stats;
+        if (LN != 0 && st) {
+            int sl = lane;
+            asm volatile("" : "+v"(sl));
+            const int row = wave * 32 + (sl >> 1);
+            glds16(st + (int64_t)min(m0 + row, p.M - 1) * (2 * SC_STAT_STRIDE) + (sl & 1) * 4, smem + LN_OFF_ROWST + wave * 1024);
+            if (wave < 2) {
+                const float* v = LN == 1 ? (wave == 0 || !bias ? p.ln_colsum : bias) : (wave == 0 ? p.res_gamma : p.res_beta);
+                glds16(v + min(n0 + sl * 4, p.N - 4), smem + LN_OFF_COLC + wave * 1024);
+            }
+        }
     };
 #define SC_WAIT_NBI()                                                      \
     do {                                                                   \
@@ -193,7 +230,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         for (int ni = 0; ni < FN; ++ni) {
             const int n = n0 + wn * TN + ni * 16 + 4 * bl;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (bias && n + 4 <= p.N) bv = *(const f32x4*)(bias + n);
+            if (LN != 1 && bias && n + 4 <= p.N) bv = *(const f32x4*)(bias + n);      // LN = 1: the bias is part of c_n (epilogue)
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = bv;
         }
@@ -236,6 +273,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
                 b1[ni][0] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off0);
                 b1[ni][1] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off1);
             }
+            if (LN != 0 && kt == 0) dma_ln(m0, n0);      // older than every later wait of this K loop: in LDS long before the epilogue
             if (kt + 1 < nk) dma_A(par ^ 1, koff(kt + 1));
             SC_BAR();
             SC_MFMA_QUAD(0, 1, b1);
@@ -293,23 +331,44 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         }
         SC_STAMP(5);
         ++iter_;
-        if (!has_next) break;
-        SC_BAR();                                    // every wave is done with its staging region before B(1) lands in it
+        if (LN == 2) {
+            // the tile's row statistics: the four column strips of the waves wn = 0..3 are added in order and leave as ONE strip
+            // per (row, N-tile).  The barrier doubles as the one below.
+            SC_BAR();
+            if (tid < 256) {
+                const int rw = tid & 127, g = tid >> 7;
+                const f32x2* sw = (const f32x2*)(smem + LDS_BYTES + STATL_BYTES);
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) {
+                    const f32x2 t = sw[(g * 4 + w2) * 128 + rw];
+                    a += t.x;
+                    b += t.y;
+                }
+                const int m = cm0 + g * 128 + rw;
+                if (m < p.M) *(f32x2*)(p.stats_out + ((int64_t)m * SC_STAT_STRIDE + cn0 / BN) * 2) = f32x2{a, b};
+            }
+            if (!has_next) break;
+        } else {
+            if (!has_next) break;
+            SC_BAR();                                // every wave is done with its staging region before B(1) lands in it
+        }
     }
 }
 
 }  // namespace
 
-template <int DIAG, int BN, int ACT, int DROP, int RES>
+template <int DIAG, int BN, int ACT, int DROP, int RES, int LN>
 static int launch256__(const sc_gemm_args& a, hipStream_t s) {
+    constexpr int LDS = LDS_BYTES + (LN == 2 ? STATL_BYTES + STATW_BYTES : 0) + (LN != 0 ? ROWST_BYTES + COLC_BYTES : 0);
     static sc_lds_attr_once attr;
-    if (hipError_t e = sc_set_max_lds_once(attr, gemm256_kernel<DIAG, BN, ACT, DROP, RES>, LDS_BYTES); e != hipSuccess) {
+    if (hipError_t e = sc_set_max_lds_once(attr, gemm256_kernel<DIAG, BN, ACT, DROP, RES, LN>, LDS); e != hipSuccess) {
         sc_set_error("hipFuncSetAttribute(gemm256): %s", hipGetErrorString(e));
         return -3;
     }
     const int nM = (a.M + 255) / 256, nN = (a.N + BN - 1) / BN;
     dim3 grid(std::min(nM * nN, sc_num_cus()), 1, a.nb1 * a.nb2);
-    hipLaunchKernelGGL((gemm256_kernel<DIAG, BN, ACT, DROP, RES>), grid, dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm256_kernel<DIAG, BN, ACT, DROP, RES, LN>), grid, dim3(512), LDS, s, a);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -317,9 +376,17 @@ static int launch256__(const sc_gemm_args& a, hipStream_t s) {
 template <int DIAG, int BN, int ACT, int DROP>
 static int launch256_(const sc_gemm_args& a, hipStream_t s) {
     if constexpr (DIAG == 0) {          // the residual epilogue is its own instantiation (its prefetch registers)
-        if (a.residual) return launch256__<DIAG, BN, ACT, DROP, 1>(a, s);
+        if (a.residual) {
+            if constexpr (ACT == 0) {   // statistics producer: residual GEMMs without an activation (out_proj, fc2)
+                if (a.stats_out) return launch256__<DIAG, BN, ACT, DROP, 1, 2>(a, s);
+            }
+            return launch256__<DIAG, BN, ACT, DROP, 1, 0>(a, s);
+        }
+        if constexpr (DROP == 0) {      // LayerNorm-folded consumer (QKV, fc1): no dropout site there
+            if (a.ln_stats) return launch256__<DIAG, BN, ACT, DROP, 0, 1>(a, s);
+        }
     }
-    return launch256__<DIAG, BN, ACT, DROP, 0>(a, s);
+    return launch256__<DIAG, BN, ACT, DROP, 0, 0>(a, s);
 }
 
 template <int DIAG, int BN>
@@ -338,6 +405,16 @@ static double tile_cost(const sc_gemm_args& a, int BN) {
     return rounds * BN * (BN == 192 ? 1.12 : 1.0);       // measured: a 256 x 192 tile runs ~12 % below the 256 x 256 rate
 }
 
+// output tile width the dispatcher picks for this problem (the statistics producer writes one strip per N-tile: its consumers
+// need the count)
+int sc_gemm256_bn(const sc_gemm_args& a) {
+    if (a.tile == 7) return 192;
+    if (a.tile == 8 || a.tile == 32 || a.tile == 34) return 256;
+    const bool ok192 = (a.n_split < 0 || a.n_split % 192 == 0);
+    const bool ok256 = (a.n_split < 0 || a.n_split % 256 == 0);
+    return (ok192 && (!ok256 || tile_cost(a, 192) < tile_cost(a, 256))) ? 192 : 256;
+}
+
 int sc_gemm256_launch(const sc_gemm_args& a_in, hipStream_t s) {
     sc_gemm_args a = a_in;
     // bit 0: non-temporal C stores.  auto = only when a residual is given (the output is the next residual stream and is read
@@ -350,8 +427,6 @@ int sc_gemm256_launch(const sc_gemm_args& a_in, hipStream_t s) {
     if (a.tile == 34) return launch256<4, 256>(a, s);
     if (a.tile == 7) return launch256<0, 192>(a, s);
     if (a.tile == 8) return launch256<0, 256>(a, s);
-    const bool ok192 = (a.n_split < 0 || a.n_split % 192 == 0);
-    const bool ok256 = (a.n_split < 0 || a.n_split % 256 == 0);
-    if (ok192 && (!ok256 || tile_cost(a, 192) < tile_cost(a, 256))) return launch256<0, 192>(a, s);
+    if (sc_gemm256_bn(a) == 192) return launch256<0, 192>(a, s);
     return launch256<0, 256>(a, s);
 }

@@ -257,6 +257,13 @@ int launch(const sc_gemm_args& a, hipStream_t s) {
 }  // namespace
 
 int sc_gemm256_launch(const sc_gemm_args& a, hipStream_t s);    // gemm256_bf16.hip
+int sc_gemm256_bn(const sc_gemm_args& a);
+
+extern "C" int32_t sc_gemm_stats_strips(const sc_gemm_args* a) {
+    if (!a || a->N <= 0) return 0;
+    const int bn = sc_gemm256_bn(*a);
+    return (a->N + bn - 1) / bn;
+}
 
 extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     SC_CHECK(args != nullptr, "sc_gemm_bf16: null args");
@@ -288,8 +295,27 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     } else {
         a.n_split = -1;
     }
+    const bool ln = a.ln_stats || a.stats_out || a.res_stats;
+    if (ln) {
+        // LayerNorm folded into the GEMMs: built into the 256-row tile family only (csrc/gemm256_bf16.hip)
+        SC_CHECK(a.tile == 0 || a.tile == 2 || a.tile == 7 || a.tile == 8, "sc_gemm_bf16: LayerNorm folding needs the 256-row tile family");
+        SC_CHECK(a.nb1 * a.nb2 == 1 && a.out_f32 == 0, "sc_gemm_bf16: LayerNorm folding: no batch, bf16 output");
+        SC_CHECK(a.ln_eps > 0.f, "sc_gemm_bf16: LayerNorm folding needs ln_eps");
+        if (a.ln_stats) {
+            SC_CHECK(a.ln_colsum && a.ln_ns >= 1 && a.ln_ns <= 4 && !a.residual && a.drop_p == 0.f && !a.stats_out && !a.res_stats,
+                     "sc_gemm_bf16: a LayerNorm-folded consumer takes ln_stats + ln_colsum (1..4 strips), no residual, no dropout");
+            SC_CHECK(((uintptr_t)a.ln_colsum % 16) == 0 && ((uintptr_t)a.ln_stats % 16) == 0, "sc_gemm_bf16: ln_colsum / ln_stats alignment");
+        } else {
+            SC_CHECK(a.stats_out && a.residual && a.act == 0, "sc_gemm_bf16: a statistics producer needs stats_out, a residual and act = 0");
+            SC_CHECK((a.N + sc_gemm256_bn(a) - 1) / sc_gemm256_bn(a) <= 4, "sc_gemm_bf16: more than 4 statistics strips (N = %d > 1024)", a.N);
+            if (a.res_stats)
+                SC_CHECK(a.res_gamma && a.res_beta && a.res_ns >= 1 && a.res_ns <= 4 && ((uintptr_t)a.res_gamma % 16) == 0 &&
+                         ((uintptr_t)a.res_beta % 16) == 0, "sc_gemm_bf16: a raw residual needs res_gamma / res_beta (16-byte aligned) and 1..4 strips");
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     int tile = a.tile;
+    if (tile == 0 && ln) tile = 2;
     if (tile == 0) {
         const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.nb1 * a.nb2;
         if (a.N <= 64 && a.n_split < 0) tile = 3;            // narrow outputs (grouped pos_conv, N = 48)

@@ -38,12 +38,45 @@ extern "C" int64_t sc_workspace_bytes(int32_t what, int64_t a, int64_t b, int64_
 }
 
 extern "C" int sc_hubert_layer_fwd(const sc_hubert_layer_args* p, void* stream) {
-    SC_CHECK(p && p->x && p->out && p->valid_len && p->qk && p->vt && p->ctx && p->pre && p->x1 && p->ffn, "sc_hubert_layer_fwd: null pointer");
+    SC_CHECK(p && p->x && p->out && p->valid_len && p->qk && p->vt && p->ctx && p->pre && (p->x1 || p->fused_ln) && p->ffn,
+             "sc_hubert_layer_fwd: null pointer");
     SC_CHECK(p->B > 0 && p->R > 0 && p->R % 128 == 0 && p->H > 0 && p->D == p->H * 64 && p->F > 0 && p->T > 0 && p->T <= p->R,
              "sc_hubert_layer_fwd: B=%d R=%d (%% 128) T=%d D=%d (= 64 H) F=%d", p->B, p->R, p->T, p->D, p->F);
     const int M = p->B * p->R, D = p->D, F = p->F, H = p->H;
     const float scale = 0.125f;       // head_dim 64
     int rc;
+    if (p->fused_ln) {
+        // LayerNorm-free form: QKV (A raw or materialised) -> attention -> out_proj (+ lazily normalised residual, statistics of
+        // `pre`) -> FC1 on the raw `pre` with the LN1-folded weights -> FC2 (+ LN1(pre) as residual, statistics of `out`)
+        SC_CHECK(!p->pre_ln, "sc_hubert_layer_fwd: fused_ln is built for the post-LN order");
+        SC_CHECK(p->fc1_colsum && p->stats1 && p->out_stats && (!p->x_stats || (p->x_ln_g && p->x_ln_b && p->qkv_colsum && p->x_ns > 0)),
+                 "sc_hubert_layer_fwd: fused_ln needs fc1_colsum, stats1, out_stats (and x_ln_g / x_ln_b / qkv_colsum with x_stats)");
+        sc_gemm_args a;
+        auto fill = [&](const sc_bf16* A, int64_t lda, const sc_bf16* W, int64_t ldw, void* C, int64_t ldc, int N, int K, const float* bias) {
+            memset(&a, 0, sizeof(a));
+            a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc;
+            a.M = M; a.N = N; a.K = K; a.bias = bias;
+            a.n_split = -1; a.nb1 = a.nb2 = 1; a.ln_eps = p->eps;
+        };
+        fill(p->x, D, p->qkv_w, D, p->qk, 2 * D, 3 * D, D, p->qkv_b);
+        a.Ct = p->vt; a.n_split = 2 * D; a.R = p->R; a.dh = 64;
+        if (p->x_stats) { a.ln_stats = p->x_stats; a.ln_ns = p->x_ns; a.ln_colsum = p->qkv_colsum; }
+        if ((rc = sc_gemm_bf16(&a, stream))) return rc;
+        if ((rc = sc_attn_fwd_bf16(p->qk, 2 * D, p->vt, p->valid_len, p->ctx, D, p->B, p->R, H, D, scale, nullptr, 0, p->p_attn, p->seed_attn, stream)))
+            return rc;
+        fill(p->ctx, D, p->o_w, D, p->pre, D, D, D, p->o_b);
+        a.residual = p->x; a.ldr = D; a.drop_p = p->p_res; a.drop_seed = p->seed_o; a.stats_out = p->stats1;
+        if (p->x_stats) { a.res_stats = p->x_stats; a.res_ns = p->x_ns; a.res_gamma = p->x_ln_g; a.res_beta = p->x_ln_b; }
+        const int ns1 = sc_gemm_stats_strips(&a);
+        if ((rc = sc_gemm_bf16(&a, stream))) return rc;
+        fill(p->pre, D, p->fc1_w, D, p->ffn, F, F, D, p->fc1_b);
+        a.act = 1; a.ln_stats = p->stats1; a.ln_ns = ns1; a.ln_colsum = p->fc1_colsum;
+        if ((rc = sc_gemm_bf16(&a, stream))) return rc;
+        fill(p->ffn, F, p->fc2_w, F, p->out, D, D, F, p->fc2_b);
+        a.residual = p->pre; a.ldr = D; a.drop_p = p->p_res; a.drop_seed = p->seed_fc2; a.stats_out = p->out_stats;
+        a.res_stats = p->stats1; a.res_ns = ns1; a.res_gamma = p->ln1_g; a.res_beta = p->ln1_b;
+        return sc_gemm_bf16(&a, stream);
+    }
     const sc_bf16* attn_in = p->x;
     if (p->pre_ln) {                  // x1 = LN1(x)
         if ((rc = sc_layernorm_bf16(p->x, D, p->ln1_g, p->ln1_b, p->x1, D, M, D, p->eps, 0, stream))) return rc;

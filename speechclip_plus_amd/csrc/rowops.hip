@@ -216,6 +216,120 @@ __global__ __launch_bounds__(256) void wsum_bwd_kernel(const uint16_t* __restric
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------- weighted sum over RAW hidden states
+// Round 3 (LayerNorm folded into the encoder GEMMs, csrc/gemm256_bf16.hip "LN"): layers n >= first_lazy of h hold the RAW rows in
+// front of the layer's final LayerNorm, with their row statistics in stats[n][row][8][2] (ns valid strips of (sum, sum of
+// squares)); the hidden state the reference sums is LN(raw) = (raw - mean) rstd gamma_n + beta_n, evaluated here in fp32.
+struct LazyLn {
+    const float* stats;      // [NL][B*R][8][2]
+    const float* gamma;      // [NL][D]
+    const float* beta;       // [NL][D]
+    int first_lazy, ns;
+    float eps;
+};
+
+__device__ __forceinline__ void lazy_row_stats(const LazyLn& z, int n, int64_t rows_total, int64_t row, int D, float& mean, float& rstd) {
+    const float* sp = z.stats + ((int64_t)n * rows_total + row) * 16;
+    float s1 = 0.f, s2 = 0.f;
+    for (int st = 0; st < z.ns; ++st) {
+        const f32x2 t = *(const f32x2*)(sp + 2 * st);
+        s1 += t.x;
+        s2 += t.y;
+    }
+    const float inv = 1.f / (float)D;
+    mean = s1 * inv;
+    rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + z.eps);
+}
+
+__device__ __forceinline__ void lazy_load8(const LazyLn& z, const uint16_t* __restrict__ src, int n, int64_t rows_total, int64_t row, int D,
+                                           int cc, float (&x)[8]) {
+    const uint4 u = *(const uint4*)src;
+    x[0] = bflo(u.x); x[1] = bfhi(u.x); x[2] = bflo(u.y); x[3] = bfhi(u.y);
+    x[4] = bflo(u.z); x[5] = bfhi(u.z); x[6] = bflo(u.w); x[7] = bfhi(u.w);
+    if (n >= z.first_lazy) {
+        float mean, rstd;
+        lazy_row_stats(z, n, rows_total, row, D, mean, rstd);
+        const float* gp = z.gamma + (int64_t)n * D + cc * 8;
+        const float* bp = z.beta + (int64_t)n * D + cc * 8;
+        const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4), b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[e] = fmaf((x[e] - mean) * rstd, g0[e], b0[e]);
+            x[4 + e] = fmaf((x[4 + e] - mean) * rstd, g1[e], b1[e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wsum_lazy_fwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w, int NL,
+                                                            uint16_t* __restrict__ out, int B, int R, int D, int row_off, LazyLn z) {
+    const int64_t chunks_per_row = D >> 3;
+    const int64_t rows_total = (int64_t)B * R;
+    const int64_t total = rows_total * chunks_per_row;
+    const int64_t plane = rows_total * D;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = q / chunks_per_row;
+        const int cc = (int)(q % chunks_per_row);
+        const int t = (int)(row % R);
+        if (t + row_off >= R) continue;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint16_t* src = h + row * D + cc * 8;
+        for (int n = 0; n < NL; ++n) {
+            float x[8];
+            lazy_load8(z, src + n * plane, n, rows_total, row, D, cc, x);
+            const float wn = w[n];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(wn, x[e], acc[e]);
+        }
+        uint4 o;
+        o.x = pack2bf(acc[0], acc[1]); o.y = pack2bf(acc[2], acc[3]);
+        o.z = pack2bf(acc[4], acc[5]); o.w = pack2bf(acc[6], acc[7]);
+        *(uint4*)(out + (row + row_off) * D + cc * 8) = o;
+    }
+}
+
+// as wsum_bwd_kernel (differences against the last layer, see there), hidden states evaluated lazily
+__global__ __launch_bounds__(256) void wsum_lazy_bwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ g, int NL,
+                                                            float* __restrict__ dw_partial, int B, int R, int D, int row_off, LazyLn z) {
+    __shared__ float red[4][32];
+    const int64_t chunks_per_row = D >> 3;
+    const int64_t rows_total = (int64_t)B * R;
+    const int64_t total = rows_total * chunks_per_row;
+    const int64_t plane = rows_total * D;
+    float acc[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) acc[n] = 0.f;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = q / chunks_per_row;
+        const int cc = (int)(q % chunks_per_row);
+        const int t = (int)(row % R);
+        if (t + row_off >= R) continue;
+        const float* gp = g + (row + row_off) * D + cc * 8;
+        const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+        const uint16_t* src = h + row * D + cc * 8;
+        float r[8];
+        lazy_load8(z, src + (int64_t)(NL - 1) * plane, NL - 1, rows_total, row, D, cc, r);
+#pragma unroll
+        for (int n = 0; n < 31; ++n) {
+            if (n < NL - 1) {
+                float x[8];
+                lazy_load8(z, src + n * plane, n, rows_total, row, D, cc, x);
+                acc[n] += g0[0] * (x[0] - r[0]) + g0[1] * (x[1] - r[1]) + g0[2] * (x[2] - r[2]) + g0[3] * (x[3] - r[3]) +
+                          g1[0] * (x[4] - r[4]) + g1[1] * (x[5] - r[5]) + g1[2] * (x[6] - r[6]) + g1[3] * (x[7] - r[7]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        const float sm = wave_sum(acc[n]);
+        if (lane == 0) red[wave][n] = sm;
+    }
+    __syncthreads();
+    if (threadIdx.x < NL)
+        dw_partial[(int64_t)blockIdx.x * NL + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // ---------------------------------------------------------------------------------------- weighted sum, normalised
 // normalize_features = True (HuBERT-large recipes): out = sum_n w[n] * LayerNorm_noaffine(h[n, row, :]).
 // One wave per row (D <= 1024 -> <= 16 elements per lane held in registers), wavefront reductions per layer.
@@ -431,6 +545,32 @@ extern "C" int sc_wsum_bwd(const sc_bf16* h, const float* g, int32_t NL, float* 
         return 0;
     }
     hipLaunchKernelGGL(wsum_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, h, g, NL, dw_partial, B, R, D, row_off);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_wsum_lazy_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, int32_t B, int32_t R, int32_t D,
+                                int32_t row_off, const float* stats, const float* gamma, const float* beta, int32_t first_lazy,
+                                int32_t ns, float eps, void* stream) {
+    SC_CHECK(h && w && out && stats && gamma && beta, "sc_wsum_lazy_fwd: null pointer");
+    SC_CHECK(NL >= 1 && NL <= 32 && D % 8 == 0 && row_off >= 0 && row_off < R && ns >= 1 && ns <= 8 && first_lazy >= 0 && eps > 0.f,
+             "sc_wsum_lazy_fwd: bad NL / D / row_off / strips");
+    const LazyLn z{stats, gamma, beta, first_lazy, ns, eps};
+    const int64_t total = (int64_t)B * R * (D / 8);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wsum_lazy_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, w, NL, out, B, R, D, row_off, z);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_wsum_lazy_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial, int32_t nblk, int32_t B, int32_t R,
+                                int32_t D, int32_t row_off, const float* stats, const float* gamma, const float* beta,
+                                int32_t first_lazy, int32_t ns, float eps, void* stream) {
+    SC_CHECK(h && g && dw_partial && stats && gamma && beta, "sc_wsum_lazy_bwd: null pointer");
+    SC_CHECK(NL >= 1 && NL <= 32 && D % 8 == 0 && nblk >= 1 && row_off >= 0 && row_off < R && ns >= 1 && ns <= 8 && eps > 0.f,
+             "sc_wsum_lazy_bwd: bad args");
+    const LazyLn z{stats, gamma, beta, first_lazy, ns, eps};
+    hipLaunchKernelGGL(wsum_lazy_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, h, g, NL, dw_partial, B, R, D, row_off, z);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -39,7 +39,7 @@ extern "C" uint32_t sc_hash32(uint32_t x) {
 }
 
 extern "C" const char* sc_last_error(void) { return g_err; }
-extern "C" int sc_abi_version(void) { return 2; }
+extern "C" int sc_abi_version(void) { return 3; }
 
 // tuning switches for same-process A/B measurements (tools/): not part of the computation's contract, results never depend on them
 static int g_options[8] = {1, 0, 0, 0, 0, 0, 0, 0};

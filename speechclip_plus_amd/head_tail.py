@@ -184,7 +184,7 @@ class ParallelHeadFn(torch.autograd.Function):
         if hd is not None:
             hd.check_fresh()
         if hd is not None and ctx.needs_input_grad[1]:
-            d_soft = ops.wsum_bwd(hd.hidden, dX, B, R, D, 1, normalize=hd.normalize)
+            d_soft = ops.wsum_bwd(hd.hidden, dX, B, R, D, 1, normalize=hd.normalize, lazy=hd.lazy)
             d_ws = hd.w_soft * (d_soft - (hd.w_soft * d_soft).sum())
         if hd is not None and hd.layers_bwd is not None:           # unfrozen HuBERT layers: continue the chain below the weighted sum
             hd.layers_bwd(dX, hd.w_soft)

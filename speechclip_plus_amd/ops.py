@@ -78,10 +78,14 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
              bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ldr: int = 0, act: int = 0,
              out_f32: bool = False, Ct: Optional[torch.Tensor] = None, n_split: int = -1, R: int = 0, dh: int = 0,
              nb1: int = 1, nb2: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sBias=(0, 0), sR=(0, 0),
-             alg_rows: Optional[int] = None, tile: int = 0, drop_p: float = 0.0, drop_seed: int = 0, tap_c: int = 0) -> None:
+             alg_rows: Optional[int] = None, tile: int = 0, drop_p: float = 0.0, drop_seed: int = 0, tap_c: int = 0,
+             ln_stats: Optional[torch.Tensor] = None, ln_ns: int = 0, ln_colsum: Optional[torch.Tensor] = None,
+             res_stats: Optional[torch.Tensor] = None, res_ns: int = 0, res_gamma: Optional[torch.Tensor] = None,
+             res_beta: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None, ln_eps: float = 0.0) -> int:
     """C = epi(A . W^T); see sc_gemm_args in include/speechclip_hip.h.  Pointers are the tensors' data_ptr()
     (pass a sliced view to offset).  ``alg_rows``: rows that are algorithmic work (excludes layout padding),
-    used only by the optional KernelTimer."""
+    used only by the optional KernelTimer.  ``ln_*`` / ``res_*`` / ``stats_out``: LayerNorm folded into the GEMM (row-statistics
+    buffers are [M, 8, 2] fp32); returns the number of statistics strips written per row (0 without ``stats_out``)."""
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16
     assert C.dtype == (torch.float32 if out_f32 else torch.bfloat16)
     if bias is not None:
@@ -104,22 +108,35 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     a.tile = tile
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed) & 0xffffffff
     a.tap_c = int(tap_c)
+    strips = 0
+    if ln_stats is not None or stats_out is not None:
+        for t in (ln_stats, ln_colsum, res_stats, res_gamma, res_beta, stats_out):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+        a.ln_stats, a.ln_ns, a.ln_colsum = _p(ln_stats), int(ln_ns), _p(ln_colsum)
+        a.res_stats, a.res_ns, a.res_gamma, a.res_beta = _p(res_stats), int(res_ns), _p(res_gamma), _p(res_beta)
+        a.stats_out, a.ln_eps = _p(stats_out), float(ln_eps)
+        if stats_out is not None:
+            assert stats_out.numel() >= M * 16
+            strips = int(lib().sc_gemm_stats_strips(ctypes.byref(a)))
     if _timer is None:
         check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
-        return
+        return strips
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
     ev1.record()
     rows = (M if alg_rows is None else alg_rows) * nb1 * nb2
-    _timer.add("gemm_bf16_" + gemm_tile_name(M, N, K, n_split, nb1 * nb2, tile), ev0, ev1, 2.0 * rows * N * K,
-               tag=f"M{M} N{N} K{K} lda{lda} act{act} res{int(residual is not None)} z{nb1 * nb2}")
+    _timer.add("gemm_bf16_" + gemm_tile_name(M, N, K, n_split, nb1 * nb2, 2 if (tile == 0 and strips + ln_ns > 0) else tile), ev0, ev1,
+               2.0 * rows * N * K, tag=f"M{M} N{N} K{K} lda{lda} act{act} res{int(residual is not None)} z{nb1 * nb2}")
+    return strips
 
 
 def hubert_layer_fwd(x: torch.Tensor, out: torch.Tensor, valid_len: torch.Tensor, w: dict, i: int, pl, B: int, R: int, T: int, D: int,
-                     F_: int, H: int, pre_ln: bool, p_attn: float = 0.0, p_res: float = 0.0, seeds=(0, 0, 0)) -> None:
+                     F_: int, H: int, pre_ln: bool, p_attn: float = 0.0, p_res: float = 0.0, seeds=(0, 0, 0), fused=None) -> None:
     """One frozen HuBERT encoder layer in ONE C-ABI call (sc_hubert_layer_fwd: QKV -> attention -> out_proj -> LN -> FC1 -> FC2 ->
-    LN on the caller's stream).  ``w``: the encoder's weight dict (keys l{i}_*), ``pl``: its plan (scratch buffers)."""
+    LN on the caller's stream).  ``w``: the encoder's weight dict (keys l{i}_*), ``pl``: its plan (scratch buffers).
+    ``fused`` = (x_stats or None, x_ns, out_stats): the LayerNorm-free form (the LayerNorms folded into the GEMMs; ``out`` receives
+    raw rows + statistics); x_stats None = ``x`` is an ordinary, materialised input (layer 0)."""
     a = HubertLayerArgs()
     a.x, a.out, a.valid_len = _p(x), _p(out), _p(valid_len)
     a.B, a.R, a.T, a.D, a.F, a.H, a.pre_ln = B, R, T, D, F_, H, int(pre_ln)
@@ -129,7 +146,23 @@ def hubert_layer_fwd(x: torch.Tensor, out: torch.Tensor, valid_len: torch.Tensor
     a.eps, a.p_attn, a.p_res = 1e-5, float(p_attn), float(p_res)
     a.seed_attn, a.seed_o, a.seed_fc2 = (int(s) & 0xffffffff for s in seeds)
     a.qk, a.vt, a.ctx, a.pre, a.x1, a.ffn = _p(pl.qk), _p(pl.vt), _p(pl.ctx), _p(pl.pre), _p(pl.x1), _p(pl.ffn)
+    if fused is not None:
+        x_stats, x_ns, out_stats = fused
+        a.fused_ln = 1
+        a.fc1_w, a.fc1_b, a.fc1_colsum = _p(w[f"l{i}_fc1_wf"]), _p(w[f"l{i}_fc1_cf"]), _p(w[f"l{i}_fc1_sf"])
+        a.stats1, a.out_stats = _p(pl.stats1), _p(out_stats)
+        if x_stats is not None:
+            a.x_stats, a.x_ns = _p(x_stats), int(x_ns)
+            a.x_ln_g, a.x_ln_b = _p(w[f"l{i - 1}_ln2_g"]), _p(w[f"l{i - 1}_ln2_b"])
+            a.qkv_w, a.qkv_b, a.qkv_colsum = _p(w[f"l{i}_qkv_wf"]), _p(w[f"l{i}_qkv_cf"]), _p(w[f"l{i}_qkv_sf"])
     check(lib().sc_hubert_layer_fwd(ctypes.byref(a), _stream()), "sc_hubert_layer_fwd")
+
+
+def gemm_stats_strips(M: int, N: int) -> int:
+    """Row-statistics strips a producer GEMM [M, N] writes (one per N-tile of the width the dispatcher picks)."""
+    a = GemmArgs()
+    a.M, a.N, a.K, a.n_split, a.nb1, a.nb2 = int(M), int(N), 64, -1, 1, 1
+    return int(lib().sc_gemm_stats_strips(ctypes.byref(a)))
 
 
 def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
@@ -572,20 +605,38 @@ def posconv(xg: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], res
         _timer.add("posconv", ev0, ev1, 2.0 * B * rows * D * Kp * (D // G))
 
 
+class LazyStates:
+    """Hidden states kept RAW (in front of their LayerNorm) with row statistics (speech_encoder: LayerNorm folded into the encoder
+    GEMMs): ``stats`` [NL, B*R, 8, 2] fp32, ``gamma`` / ``beta`` [NL, D] fp32, layers >= ``first_lazy`` are raw, ``ns`` valid strips."""
+
+    def __init__(self, stats, gamma, beta, first_lazy: int, ns: int, eps: float):
+        self.stats, self.gamma, self.beta, self.first_lazy, self.ns, self.eps = stats, gamma, beta, int(first_lazy), int(ns), float(eps)
+
+
 def wsum_fwd(h: torch.Tensor, w_softmax: torch.Tensor, out: torch.Tensor, B: int, R: int, D: int, row_off: int,
-             normalize: bool = False) -> None:
+             normalize: bool = False, lazy: Optional[LazyStates] = None) -> None:
     NL = h.shape[0]
+    if lazy is not None:
+        assert not normalize
+        check(lib().sc_wsum_lazy_fwd(_p(h), _p(w_softmax), NL, _p(out), B, R, D, row_off, _p(lazy.stats), _p(lazy.gamma), _p(lazy.beta),
+                                     lazy.first_lazy, lazy.ns, lazy.eps, _stream()), "sc_wsum_lazy_fwd")
+        return
     assert h.dtype == torch.bfloat16 and w_softmax.dtype == torch.float32 and out.dtype == torch.bfloat16
     check(lib().sc_wsum_fwd(_p(h), _p(w_softmax), NL, _p(out), B, R, D, row_off, int(normalize), _stream()), "sc_wsum_fwd")
 
 
 def wsum_bwd(h: torch.Tensor, g: torch.Tensor, B: int, R: int, D: int, row_off: int, nblk: int = 1024,
-             normalize: bool = False) -> torch.Tensor:
+             normalize: bool = False, lazy: Optional[LazyStates] = None) -> torch.Tensor:
     """returns d(softmaxed weights)[NL] up to a common shift: <g, h_n - h_last> (sc_wsum_bwd: the callers' softmax projection
     w_n (d_n - sum_m w_m d_m) does not see the shift, and the fp32 sums keep the digits the projection needs)."""
     NL = h.shape[0]
     assert g.dtype == torch.float32
     part = torch.empty(nblk, NL, device=h.device, dtype=torch.float32)
+    if lazy is not None:
+        assert not normalize
+        check(lib().sc_wsum_lazy_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, _p(lazy.stats), _p(lazy.gamma), _p(lazy.beta),
+                                     lazy.first_lazy, lazy.ns, lazy.eps, _stream()), "sc_wsum_lazy_bwd")
+        return part.sum(0)
     check(lib().sc_wsum_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, int(normalize), _stream()), "sc_wsum_bwd")
     return part.sum(0)
 

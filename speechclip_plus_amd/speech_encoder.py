@@ -132,6 +132,14 @@ def random_hubert_state_dict(arch: HubertArch, seed: int = 7122) -> Dict[str, to
 
 
 _USE_GRAPH = os.environ.get("SC_ENCODER_GRAPH", "0") == "1"      # opt-in: measured +-0 on one GPU
+# Round 3, opt-in (SC_FUSED_LN=1): the frozen post-LN encoder WITHOUT LayerNorm launches - the two LayerNorms of a layer folded into
+# their neighbour GEMMs, residual stream / hidden states kept as raw rows + row statistics (csrc/gemm256_bf16.hip "LN").  Correct
+# (slightly closer to the oracle than the LayerNorm kernels: 8.8e-3 vs 9.7e-3 worst hidden state) but NOT faster: same-box A/B at
+# B = 64 x 10 s: forward 11.75-11.77 ms folded vs 11.70-11.77 ms with the 25 LayerNorm launches, train step 13.6-14.0 vs 13.4 ms
+# (the weighted sum and its backward normalise 12 states on the fly).  The 24 launches and 2.4 GB of LayerNorm traffic it removes
+# (0.6 ms) come back as VALU work in GEMM epilogues that are already issue-bound (+12 us fc1, +19 fc2, +6 QKV, +7 out_proj per
+# launch with all operands prefetched into LDS; +25..45 before that).  DESIGN.md section 7.
+_FUSED_LN = os.environ.get("SC_FUSED_LN", "0") == "1"
 
 
 def _mix32(x: int) -> int:
@@ -183,6 +191,11 @@ class _Plan:
         self.ctx = z(M, D)
         self.ffn = z(M, F)
         self.hidden = z(arch.layers + 1, M, D)
+        # LayerNorm-free layers: hidden[n >= 1] then hold the rows in FRONT of layer n's final LayerNorm, stats[n] their (sum, sum of
+        # squares) strips, stats1 the scratch for the rows in front of LN1; lazy = how consumers read such states (ops.LazyStates)
+        self.stats = z(arch.layers + 1, M, 8, 2, dtype=torch.float32)
+        self.stats1 = z(M, 8, 2, dtype=torch.float32)
+        self.lazy = None
         self.valid = torch.zeros(B, device=dev, dtype=torch.int32)
         self.len_dev = torch.zeros(B, device=dev, dtype=torch.int64)
         self.wav_in = torch.zeros(B, L, device=dev, dtype=torch.float32) if _USE_GRAPH and torch.device(dev).type == "cuda" else None
@@ -299,6 +312,26 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"] = bf(sd[p + "fc1.weight"]), f32(sd[p + "fc1.bias"])
             w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"] = bf(sd[p + "fc2.weight"]), f32(sd[p + "fc2.bias"])
             w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"] = f32(sd[p + "final_layer_norm.weight"]), f32(sd[p + "final_layer_norm.bias"])
+        if not a.layer_norm_first:
+            # LayerNorm folded into the consumer GEMM (csrc/gemm256_bf16.hip "LN"): W' = W diag(gamma) in bf16, s_n = sum_k W'[n,k] (of
+            # the bf16 values the kernel multiplies), c_n = sum_k beta_k W[n,k] + b_n; fc1 with the layer's own LN1, QKV of layer i >= 1
+            # with layer i - 1's final LayerNorm
+            def fold(W32, b32, g, beta):
+                Wf = (W32.float() * g.float()[None, :]).to(torch.bfloat16)
+                return (Wf.to(dev).contiguous(), f32(Wf.float().sum(1)), f32(W32.float() @ beta.float() + b32.float()))
+            for i in range(a.layers):
+                p = f"encoder.layers.{i}."
+                w[f"l{i}_fc1_wf"], w[f"l{i}_fc1_sf"], w[f"l{i}_fc1_cf"] = fold(sd[p + "fc1.weight"], sd[p + "fc1.bias"],
+                                                                               sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"])
+                if i > 0:
+                    q = f"encoder.layers.{i - 1}."
+                    Wqkv = torch.cat([sd[p + f"self_attn.{n}.weight"] for n in ("q_proj", "k_proj", "v_proj")], 0)
+                    bqkv = torch.cat([sd[p + f"self_attn.{n}.bias"] for n in ("q_proj", "k_proj", "v_proj")], 0)
+                    w[f"l{i}_qkv_wf"], w[f"l{i}_qkv_sf"], w[f"l{i}_qkv_cf"] = fold(Wqkv, bqkv, sd[q + "final_layer_norm.weight"],
+                                                                                   sd[q + "final_layer_norm.bias"])
+            # affines of the LayerNorm that turns raw state n into hidden state n (row 0: hidden[0] is materialised)
+            w["lazy_gamma"] = f32(torch.stack([torch.ones(a.embed_dim)] + [sd[f"encoder.layers.{i}.final_layer_norm.weight"].float() for i in range(a.layers)]))
+            w["lazy_beta"] = f32(torch.stack([torch.zeros(a.embed_dim)] + [sd[f"encoder.layers.{i}.final_layer_norm.bias"].float() for i in range(a.layers)]))
         self._w = w          # frozen device tensors (not nn.Parameters: no grads, no optimizer state)
 
     def trainable_params(self) -> list:
@@ -465,6 +498,10 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             tl = self.train_layers
             if tl is not None:
                 tl.refresh()
+            pl.lazy = None
+            if _FUSED_LN and tl is None and self._dev.type == "cuda":
+                self._layers_fused(pl, w, sd, p_res, p_att, scale)
+                return
             for i in range(a.layers):
                 x = pl.hidden[i]
                 if tl is not None and (i in tl.ids or i in tl.pass_ids):   # unfrozen (or frozen above an unfrozen one): activations kept
@@ -514,6 +551,52 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.hidden[i + 1], residual=pl.pre,
                                 alg_rows=B * T, drop_p=p_res, drop_seed=sd(3 * i + 4))
 
+    @torch.no_grad()
+    def _layers_fused(self, pl, w, sd, p_res, p_att, scale) -> None:
+        """a5 without LayerNorm launches (frozen post-LN layers): hidden[i + 1] receives the rows in front of layer i's final
+        LayerNorm and pl.stats[i + 1] their statistics; consumers (the next layer, the weighted sum) normalise on the fly."""
+        a = self.arch
+        B, R, M, T = pl.B, pl.R, pl.M, pl.T
+        D, F, H = a.embed_dim, a.ffn_dim, a.heads
+        ns = ops.gemm_stats_strips(M, D)
+        for i in range(a.layers):
+            x, out = pl.hidden[i], pl.hidden[i + 1]
+            xs = pl.stats[i] if i > 0 else None
+            seeds = (sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4))
+            if ops._timer is None:
+                ops.hubert_layer_fwd(x, out, pl.valid, w, i, pl, B, R, T, D, F, H, False, p_att, p_res, seeds, fused=(xs, ns, pl.stats[i + 1]))
+                continue
+            # the same sequence op by op (bench.py's per-kernel timer)
+            ln = dict(ln_eps=1e-5)
+            if xs is None:
+                ops.gemm_raw(x, D, w[f"l{i}_qkv_w"], D, pl.qk, 2 * D, M, 3 * D, D, bias=w[f"l{i}_qkv_b"], Ct=pl.vt, n_split=2 * D, R=R,
+                             dh=D // H, alg_rows=B * T)
+            else:
+                ops.gemm_raw(x, D, w[f"l{i}_qkv_wf"], D, pl.qk, 2 * D, M, 3 * D, D, bias=w[f"l{i}_qkv_cf"], Ct=pl.vt, n_split=2 * D, R=R,
+                             dh=D // H, alg_rows=B * T, ln_stats=xs, ln_ns=ns, ln_colsum=w[f"l{i}_qkv_sf"], **ln)
+            ops.attn_fwd(pl.qk, pl.vt, pl.valid, pl.ctx, B, R, H, D, scale, alg_flops=4.0 * B * T * T * D, drop_p=p_att, drop_seed=seeds[0])
+            res = {} if xs is None else dict(res_stats=xs, res_ns=ns, res_gamma=w[f"l{i - 1}_ln2_g"], res_beta=w[f"l{i - 1}_ln2_b"])
+            ns1 = ops.gemm_raw(pl.ctx, D, w[f"l{i}_o_w"], D, pl.pre, D, M, D, D, bias=w[f"l{i}_o_b"], residual=x, ldr=D, alg_rows=B * T,
+                               drop_p=p_res, drop_seed=seeds[1], stats_out=pl.stats1, **res, **ln)
+            ops.gemm_raw(pl.pre, D, w[f"l{i}_fc1_wf"], D, pl.ffn, F, M, F, D, bias=w[f"l{i}_fc1_cf"], act=1, alg_rows=B * T,
+                         ln_stats=pl.stats1, ln_ns=ns1, ln_colsum=w[f"l{i}_fc1_sf"], **ln)
+            ops.gemm_raw(pl.ffn, F, w[f"l{i}_fc2_w"], F, out, D, M, D, F, bias=w[f"l{i}_fc2_b"], residual=pl.pre, ldr=D, alg_rows=B * T,
+                         drop_p=p_res, drop_seed=seeds[2], stats_out=pl.stats[i + 1], res_stats=pl.stats1, res_ns=ns1,
+                         res_gamma=w[f"l{i}_ln1_g"], res_beta=w[f"l{i}_ln1_b"], **ln)
+        pl.lazy = ops.LazyStates(pl.stats, w["lazy_gamma"], w["lazy_beta"], first_lazy=1, ns=ns, eps=1e-5)
+
+    def _materialised_states(self, pl) -> tuple:
+        """Hidden states as the reference returns them (fresh tensors).  With the LayerNorm-free layers states 1.. are raw rows: their
+        LayerNorm runs here, on request only (the weighted sum normalises on the fly)."""
+        B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
+        if pl.lazy is None:
+            return tuple(pl.hidden[n].view(B, R, D)[:, :T].clone() for n in range(self.arch.layers + 1))
+        out = [pl.hidden[0].view(B, R, D)[:, :T].clone()]
+        for n in range(1, self.arch.layers + 1):
+            y = ops.layernorm_bf16(pl.hidden[n], self._w[f"l{n - 1}_ln2_g"], self._w[f"l{n - 1}_ln2_b"])
+            out.append(y.view(B, R, D)[:, :T].clone())
+        return tuple(out)
+
     def forward(self, wav: Union[torch.Tensor, list], wav_len: Union[torch.Tensor, list] = [],
                 feat_select_idx: Union[str, list] = None, return_hidden_states: bool = False) -> Tuple:
         # :539-554.  Fast path: an already padded (B, L) device batch that needs no crop goes to the kernels as is
@@ -552,9 +635,10 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
         # views of the plan's resident workspace; every PUBLIC return path below hands out clones (the reference returns fresh
         # tensors: holding encoder outputs across calls must be safe), the weighted-sum fast path reads the workspace in place
-        views = tuple(pl.hidden[n].view(B, R, D)[:, :T] for n in range(self.arch.layers + 1))
         want_states = return_hidden_states or (feat_select_idx or self.feat_select_idx) != FEAT_SELECT_IDX_WEIGHTED_SUM_MODE
-        hidden_states = tuple(v.clone() for v in views) if want_states else views
+        # (without want_states the tuple is only a placeholder: the weighted sum reads the plan's workspace, raw or not, in place)
+        hidden_states = self._materialised_states(pl) if want_states else tuple(pl.hidden[n].view(B, R, D)[:, :T]
+                                                                                 for n in range(self.arch.layers + 1))
         feat = {"last_hidden_state": hidden_states[-1], "hidden_states": hidden_states}
         feat_len = pl.feat_len                                                          # :604-611 (uploaded in _encode)
         if feat_select_idx is None:

@@ -28,6 +28,7 @@ class PaddedFeatHandle:
         # raw-pointer kernels (no autograd version bump).  One outstanding forward per plan: a backward that arrives after the
         # plan has been re-used must fail loudly instead of differentiating against the wrong states.
         self.plan, self.generation = plan, (plan.generation if plan is not None else None)
+        self.lazy = getattr(plan, "lazy", None)      # ops.LazyStates: the hidden states are raw rows + row statistics
 
     def check_fresh(self) -> None:
         if self.plan is not None and self.plan.generation != self.generation:
@@ -68,7 +69,8 @@ class _WeightedSumSrcFn(torch.autograd.Function):
         w_soft = torch.softmax(weights.detach().float(), dim=0).contiguous()
         src = torch.empty(B, R, D, device=hidden.device, dtype=torch.bfloat16)
         src[:, 0].zero_()                    # rows 1 .. R - 1 are written by the kernel; row 0 is the CLS slot
-        ops.wsum_fwd(hidden, w_soft, src, B, R, D, 1, normalize)
+        ctx.lazy = getattr(plan, "lazy", None)
+        ops.wsum_fwd(hidden, w_soft, src, B, R, D, 1, normalize, lazy=ctx.lazy)
         ctx.save_for_backward(hidden, w_soft)
         ctx.dims = (B, R, D, normalize)
         return src
@@ -80,7 +82,7 @@ class _WeightedSumSrcFn(torch.autograd.Function):
         if ctx.plan is not None and ctx.plan.generation != ctx.generation:
             raise RuntimeError("the encoder ran another forward with the same batch geometry before this backward (its resident "
                                "hidden states were overwritten): one outstanding forward per (B, L) plan")
-        d_soft = ops.wsum_bwd(hidden, g.float().contiguous(), B, R, D, 1, normalize=normalize)
+        d_soft = ops.wsum_bwd(hidden, g.float().contiguous(), B, R, D, 1, normalize=normalize, lazy=ctx.lazy)
         return w_soft * (d_soft - (w_soft * d_soft).sum()), None, None, None, None, None, None
 
 

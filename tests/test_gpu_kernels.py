@@ -1018,3 +1018,64 @@ def test_softmax_rows_fwd_bwd_vs_torch(dev, n, p_drop):
     dS = ops.softmax_bwd(dPd, P, scale, p_drop, seed)
     # the kernel differentiates through the bf16-rounded P it is given: compare against the fp32 gradient at bf16 tolerance
     assert rel_l2(dS[live], sr.grad[live]) < 1.5e-2
+
+
+@pytest.mark.parametrize("tile", [7, 8])
+def test_gemm_layernorm_folding(dev, tile):
+    """LayerNorm without a LayerNorm kernel (sc_gemm_args ln_* / res_* / stats_out, csrc/gemm256_bf16.hip "LN"): a residual GEMM emits
+    the row statistics of what it stores, the next GEMM multiplies the RAW rows with W diag(gamma) and finishes the normalisation in its
+    epilogue, and a residual operand that is itself raw is normalised on the fly - against the explicit fp32 form, on both tile
+    widths (6 and 8 column chunks per row in the producer's epilogue), with an M tail."""
+    import numpy as np
+    ops = _ops()
+    M, D, F_, K0 = 1000, 768, 1024, 256
+    g = torch.Generator(device="cpu").manual_seed(100 + tile)
+    A0 = bf(torch.randn(M, K0, generator=g)).to(dev)
+    W0 = bf(torch.randn(D, K0, generator=g) * K0 ** -0.5).to(dev)
+    b0 = torch.randn(D, generator=g).to(dev)
+    R0 = bf(torch.randn(M, D, generator=g) + 0.7).to(dev)                 # rows with a non-zero mean
+    # ---- producer with a plain residual
+    C0 = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+    st0 = torch.zeros(M, 8, 2, device=dev, dtype=torch.float32)
+    ns0 = ops.gemm_raw(A0, K0, W0, K0, C0, D, M, D, K0, bias=b0, residual=R0, ldr=D, tile=tile, stats_out=st0, ln_eps=1e-5)
+    assert ns0 == (4 if tile == 7 else 3)
+    ref0 = A0.float() @ W0.float().T + b0 + R0.float()
+    assert rel_l2(C0, ref0) < 6e-3
+    c0 = C0.float()
+    s = st0[:, :ns0].sum(1)
+    assert rel_l2(s[:, 0], c0.sum(1)) < 1e-5 and rel_l2(s[:, 1], (c0 * c0).sum(1)) < 1e-5
+    # ---- consumer: y = gelu(LN(C0) W1^T + b1) through the folded weights
+    gam, bet = (1 + 0.1 * torch.randn(D, generator=g)).to(dev), (0.1 * torch.randn(D, generator=g)).to(dev)
+    W1 = (torch.randn(F_, D, generator=g) * D ** -0.5).to(dev)
+    b1 = torch.randn(F_, generator=g).to(dev)
+    W1f = (W1 * gam[None, :]).to(torch.bfloat16).contiguous()
+    colsum = W1f.float().sum(1).contiguous()
+    cvec = (W1 @ bet + b1).contiguous()
+    ln0 = F.layer_norm(c0, (D,), gam, bet, 1e-5)
+    for act in (0, 1):
+        Y = torch.zeros(M, F_, device=dev, dtype=torch.bfloat16)
+        ops.gemm_raw(C0, D, W1f, D, Y, F_, M, F_, D, bias=cvec, act=act, tile=tile, ln_stats=st0, ln_ns=ns0, ln_colsum=colsum, ln_eps=1e-5)
+        ref = ln0 @ W1.T + b1
+        ref = F.gelu(ref) if act else ref
+        assert rel_l2(Y, ref) < 8e-3, (act, rel_l2(Y, ref))
+    # ---- producer whose residual is the raw C0: C1 = A1 W2^T + b2 + LN(C0), with statistics
+    A1 = bf(torch.randn(M, F_, generator=g)).to(dev)
+    W2 = bf(torch.randn(D, F_, generator=g) * F_ ** -0.5).to(dev)
+    b2 = torch.randn(D, generator=g).to(dev)
+    C1 = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+    st1 = torch.zeros(M, 8, 2, device=dev, dtype=torch.float32)
+    for p_drop in (0.0, 0.1):
+        ns1 = ops.gemm_raw(A1, F_, W2, F_, C1, D, M, D, F_, bias=b2, residual=C0, ldr=D, tile=tile, stats_out=st1, res_stats=st0,
+                           res_ns=ns0, res_gamma=gam, res_beta=bet, ln_eps=1e-5, drop_p=p_drop, drop_seed=77)
+        prod = A1.float() @ W2.float().T + b2
+        if p_drop > 0:
+            keep = torch.from_numpy(_keep_mask(np.arange(M * D, dtype=np.int64), 77, p_drop)).view(M, D).to(dev)
+            prod = torch.where(keep, prod / (1 - p_drop), torch.zeros_like(prod))
+        ref1 = prod + ln0
+        assert rel_l2(C1, ref1) < 6e-3, rel_l2(C1, ref1)
+        c1 = C1.float()
+        s1 = st1[:, :ns1].sum(1)
+        assert rel_l2(s1[:, 0], c1.sum(1)) < 1e-5 and rel_l2(s1[:, 1], (c1 * c1).sum(1)) < 1e-5
+    # the 128-row tile family has no LayerNorm folding: asking for it there is an error, not a silent plain GEMM
+    with pytest.raises(RuntimeError):
+        ops.gemm_raw(C0, D, W1f, D, Y, F_, M, F_, D, bias=cvec, tile=1, ln_stats=st0, ln_ns=ns0, ln_colsum=colsum, ln_eps=1e-5)

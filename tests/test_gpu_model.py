@@ -60,6 +60,47 @@ def test_encoder_hidden_states(setup):
     print("worst hidden-state rel-L2", worst)
 
 
+def test_layernorm_free_layers_match_the_layernorm_kernels(setup):
+    """Round 3, opt-in (SC_FUSED_LN=1; measured no faster, see speech_encoder.py): the frozen post-LN encoder without LayerNorm
+    launches (LayerNorms folded into the GEMMs, hidden states kept raw + row statistics, speech_encoder._layers_fused).  Against the
+    default form (explicit LayerNorm kernels) on the same weights and inputs: every hidden state, the weighted sum and - through the head - the weighted-sum gradient; eval and
+    train mode (the dropout masks are the same stateless hashes in both forms, so the train-mode outputs are comparable too)."""
+    from speechclip_plus_amd import speech_encoder as se
+    model, sd, o_arch, head_W, oracle = setup
+    enc = model.audio_encoder
+    g = torch.Generator().manual_seed(12)
+    lens = [14000, 9000, 16000, 3300, 12001]
+    wavs = [torch.randn(l, generator=g).cuda() for l in lens]
+    default = se._FUSED_LN
+    res = {}
+    try:
+        for fused in (True, False):
+            se._FUSED_LN = fused
+            for train in (False, True):
+                enc.train(train)
+                enc._drop_calls = 0                      # same per-site dropout seeds in both forms
+                with torch.no_grad():
+                    feat, feat_len, hs = enc(wavs, return_hidden_states=True)
+                pl = enc._plan(len(lens), max(lens))
+                assert (pl.lazy is not None) == fused
+                res[(fused, train)] = (feat.float().clone(), [h.float().clone() for h in hs])
+    finally:
+        se._FUSED_LN = default
+        enc.eval()
+    for train in (False, True):
+        f1, h1 = res[(True, train)]
+        f0, h0 = res[(False, train)]
+        for n in range(13):
+            assert rel_l2(h1[n], h0[n]) < 1.2e-2, (train, n, rel_l2(h1[n], h0[n]))
+        assert rel_l2(f1, f0) < 1.2e-2, (train, rel_l2(f1, f0))
+    # both against the oracle (eval): the LayerNorm-free form is not further away than the LayerNorm kernels were
+    hs_o, _ = oracle.speech_encoder_forward(sd, o_arch, [w.cpu() for w in wavs])
+    e1 = max(rel_l2(res[(True, False)][1][n], hs_o[n]) for n in range(13))
+    e0 = max(rel_l2(res[(False, False)][1][n], hs_o[n]) for n in range(13))
+    print("worst hidden-state rel-L2 vs oracle: LayerNorm-free", e1, " LayerNorm kernels", e0)
+    assert e1 < 2e-2 and e1 < 1.15 * e0 + 1e-3
+
+
 def test_encoder_large_arch():
     """HuBERT-large wiring (layer_norm extractor with conv bias, utterance-normalised waveform, pre-LN layers,
     D = 1024 / 16 heads / F = 4096) at reduced depth (3 layers) against the oracle."""

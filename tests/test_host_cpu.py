@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/speechclip_hip.h but not exported"
     assert set(_lib.SIGNATURES) | {"sc_last_error", "sc_hash32", "sc_infonce_workspace_floats", "sc_workspace_bytes"} == declared
-    assert lib.sc_abi_version() == 2
+    assert lib.sc_abi_version() == 3
     # the ctypes mirror of sc_gemm_args must have the C struct's size (8-byte fields, natural alignment; + drop_p, drop_seed; + tap_c, pad)
     assert ctypes.sizeof(_lib.GemmArgs) == 6 * 8 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 6 * 4 + 10 * 8 + 8 + 8 + 8
     # host twin of the kernels' dropout hash (lowbias32): known answers
