@@ -29,6 +29,7 @@ typedef uint16_t sc_bf16;
 
 const char* sc_last_error(void);
 int sc_abi_version(void);     /* 3 since round 3 (sc_gemm_args grew the LayerNorm-folding fields) */
+int64_t sc_sizeof(int32_t what);   /* sizeof of 0 sc_gemm_args, 1 sc_hubert_layer_args, 2 sc_rt_gemm_args, 3 sc_rt_ln_args, 4 sc_rt_ln_bwd_args */
 /* tuning switches for same-process A/B measurements (tools/); results never depend on them.  key 1: the 256-row GEMM uses
  * plain instead of non-temporal stores on tiles with a residual. */
 int sc_set_option(int32_t key, int32_t value);
@@ -222,15 +223,17 @@ int sc_wsum_lazy_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_par
  * backward (dm [B,H,D] fp32 given):
  *   dp = dm . X ; ds = p (dp - sum p dp) ; dX = sum_h p dm + ds a ; da_partial[b,h,:] = sum_s ds X
  * train-mode dropout of the attention weights (nn.MultiheadAttention dropout=): mult [B,H,R] fp32 (0 or 1/(1-p_drop),
- *   NULL = none): m = sum_s p*mult X ; backward takes dp already multiplied by mult and uses p*mult in the dX term.
+ *   NULL = none): m = sum_s p*mult X ; psum [B,H] (optional output) = sum_s p*mult, the weight of the value bias.  The backward
+ *   takes dp already multiplied by mult, or - cbias [B,H] given - the RAW dp = dm . X and forms (dp + cbias[b,h]) * mult itself
+ *   (cbias = the value-bias path, sc_rt_value_bias_bwd); it uses p*mult in the dX term.
  * ---------------------------------------------------------------------------------------------- */
 int sc_cls_scores(const sc_bf16* X, const float* vec, int64_t vec_bstride, float* scores, int32_t B, int32_t R,
                   int32_t D, int32_t H, void* stream);
 int sc_cls_pool_fwd(const sc_bf16* X, const float* scores, const int32_t* len, float* p, float* m, int32_t B,
-                    int32_t R, int32_t D, int32_t H, const float* mult, void* stream);
+                    int32_t R, int32_t D, int32_t H, const float* mult, float* psum, void* stream);
 int sc_cls_pool_bwd(const sc_bf16* X, const float* p, const float* dp, const float* dm, const float* a,
                     const int32_t* len, float* dX, float* da_partial, int32_t B, int32_t R, int32_t D, int32_t H,
-                    const float* mult, void* stream);
+                    const float* mult, const float* cbias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row softmax of the GEMM-based attention core (attention block of the cascaded+/hybrid+ branches,
@@ -399,6 +402,69 @@ int sc_infonce_fwd(const float* A, const float* B, int32_t Bg, int32_t E, const 
 int sc_infonce_grad(const float* logits, const int64_t* ids, const float* lse_row, const float* lse_col, int32_t Bg,
                     const float* gscale /*device scalar*/, const float* inv_temp /*device scalar*/, float margin, int32_t dcl,
                     int32_t a2b, int32_t b2a, float* G, float* dlogit_dot /*[Bg]*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row tail of the parallel head, round 3 (csrc/rowtail.hip): the B-row products of nn.TransformerEncoderLayer + final LayerNorm +
+ * Linear (avssl/module/kw_modules/TransformerModels.py:48-97, avssl/model/kw_branches.py:266-280) and the L2 normalisation of
+ * avssl/model/kwClip.py:857,913-915, fp32 on the master weights.
+ *   sc_rt_gemm: C[z] = epi(alpha A[z] . B[z]^T) on the matrix pipe in exact fp32, 64 x 64 tiles.  A [M, K] row-major (then it may be
+ *     given as a_ns partial slices that are added on load, plus a_bias[k] * a_rowscale[row][k / a_group]) or contraction-major
+ *     [K, M] (a_kmajor); B [N, K] or [K, N] (b_kmajor).  S > 1 splits the contraction: slice s writes its raw partial tile to
+ *     C + s * c_slice and the CONSUMER adds the slices (no reduce launch, no epilogue).  S = 1: v = alpha acc + bias[n]; act = 1:
+ *     U = v (if given), v = gelu_erf(v); dropout (keep bits = sc_dropout_mult_f32's on the index row * N + col); v += beta C; store.
+ *     gb (a_kmajor only): gb[m] += sum_k A[k][m] - the bias gradient as a by-product of a weight-gradient product.
+ *   sc_rt_gemm_slices: the S this library would pick for a few-row product (enough workgroups to cover the chip).
+ *   sc_rt_ln_fwd: z = (sum_s y_s + bias) * dropout + residual ; out1 = LN1(z) [; out2 = LN2(out1)], xhat / rstd kept.
+ *   sc_rt_ln_bwd: d = sum_s dy_s (+ add) ; dx = LayerNorm backward ; dx_masked = dx * dropout multiplier (optional) ; dgamma / dbeta +=.
+ *   sc_rt_l2norm_fwd / _bwd: x = sum_s y_s + bias ; e = x / |x| ; backward dx = (g - e <g, e>) / |x|.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* A; int64_t lda, a_slice, a_z; int32_t a_kmajor, a_ns;
+    const float* a_bias; const float* a_rowscale; int32_t a_group, a_nscale;
+    const float* B; int64_t ldb, b_z; int32_t b_kmajor, nbatch;
+    float* C; int64_t ldc, c_slice, c_z;
+    float* U;
+    int32_t M, N, K, S;
+    float alpha, beta;
+    const float* bias; int64_t bias_z;
+    int32_t act; float drop_p; uint32_t drop_seed; int32_t pad_;
+    float* gb; int64_t gb_z;
+} sc_rt_gemm_args;
+int sc_rt_gemm(const sc_rt_gemm_args* args, void* stream);
+int32_t sc_rt_gemm_slices(int32_t M, int32_t N, int32_t K, int32_t nbatch);
+typedef struct {
+    const float* y; int64_t y_slice; int32_t ns, rows;
+    const float* bias;
+    float drop_p; uint32_t drop_seed;
+    const float* res; int64_t res_stride;
+    const float *g1, *b1; float *out1, *xhat1, *rstd1;
+    const float *g2, *b2; float *out2, *xhat2, *rstd2;
+    float eps1, eps2; int32_t D, pad_;
+} sc_rt_ln_args;
+int sc_rt_ln_fwd(const sc_rt_ln_args* args, void* stream);
+typedef struct {
+    const float* dy; int64_t dy_slice; int32_t ns, rows;
+    const float* add;
+    const float *xhat, *gamma, *rstd;
+    float *dx, *dx_masked;
+    float drop_p; uint32_t drop_seed;
+    float *dgamma, *dbeta;
+    int32_t D, pad_;
+} sc_rt_ln_bwd_args;
+int sc_rt_ln_bwd(const sc_rt_ln_bwd_args* args, void* stream);
+int sc_rt_l2norm_fwd(const float* y, int64_t y_slice, int32_t ns, const float* bias, float* x /*or NULL*/, float* e, float* rnorm,
+                     int32_t rows, int32_t D, void* stream);
+int sc_rt_l2norm_bwd(const float* g, const float* e, const float* rnorm, float* dx, int32_t rows, int32_t D, void* stream);
+/* value-bias terms of the CLS head under attention-weight dropout (ctx_h = Wv_h m_h + bv_h * psum[b,h]):
+ *   cbias[b,h] = sum_j dctx[b, h dh + j] bv[h dh + j]   (d psum)      gbv[h dh + j] += sum_b dctx[b, h dh + j] psum[b,h] */
+int sc_rt_value_bias_bwd(const float* dctx, const float* bv, const float* psum, float* cbias, float* gbv, int32_t B, int32_t D, int32_t H,
+                         void* stream);
+/* end of the weighted-sum backward: d_soft[n] = sum_blk part[blk][n] ; out[n] = w[n] (d_soft[n] - sum_m w[m] d_soft[m])  (softmax backward) */
+int sc_rt_softmax_bwd_reduce(const float* part, int32_t nblk, int32_t NL, const float* w_soft, float* out, void* stream);
+/* elementwise over slices.  mode 0: out = sum_s y_s + bias[j] * rowscale[row][j / group] ; mode 1: u = sum_s y_s + bias, out = gelu_erf(u) *
+ * dropout ; mode 2: out = (sum_s y_s) * dropout * gelu_erf'(u)   (dropout keep bits as sc_dropout_mult_f32 on the index row * D + j) */
+int sc_rt_elem(const float* y, int64_t y_slice, int32_t ns, const float* bias, const float* rowscale, int32_t group, int32_t nscale, float* out,
+               float* u, int32_t rows, int32_t D, int32_t mode, float drop_p, uint32_t drop_seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused driver: ONE call enqueues a whole frozen HuBERT encoder layer (fairseq TransformerSentenceEncoderLayer as invoked at

@@ -35,6 +35,48 @@ class GemmArgs(ctypes.Structure):
     ]
 
 
+class RtGemmArgs(ctypes.Structure):
+    """Mirror of ``sc_rt_gemm_args``."""
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_i64), ("a_slice", c_i64), ("a_z", c_i64), ("a_kmajor", c_int), ("a_ns", c_int),
+        ("a_bias", c_void_p), ("a_rowscale", c_void_p), ("a_group", c_int), ("a_nscale", c_int),
+        ("B", c_void_p), ("ldb", c_i64), ("b_z", c_i64), ("b_kmajor", c_int), ("nbatch", c_int),
+        ("C", c_void_p), ("ldc", c_i64), ("c_slice", c_i64), ("c_z", c_i64),
+        ("U", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("S", c_int),
+        ("alpha", ctypes.c_float), ("beta", ctypes.c_float),
+        ("bias", c_void_p), ("bias_z", c_i64),
+        ("act", c_int), ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("pad_", c_int),
+        ("gb", c_void_p), ("gb_z", c_i64),
+    ]
+
+
+class RtLnArgs(ctypes.Structure):
+    """Mirror of ``sc_rt_ln_args``."""
+    _fields_ = [
+        ("y", c_void_p), ("y_slice", c_i64), ("ns", c_int), ("rows", c_int),
+        ("bias", c_void_p),
+        ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32),
+        ("res", c_void_p), ("res_stride", c_i64),
+        ("g1", c_void_p), ("b1", c_void_p), ("out1", c_void_p), ("xhat1", c_void_p), ("rstd1", c_void_p),
+        ("g2", c_void_p), ("b2", c_void_p), ("out2", c_void_p), ("xhat2", c_void_p), ("rstd2", c_void_p),
+        ("eps1", ctypes.c_float), ("eps2", ctypes.c_float), ("D", c_int), ("pad_", c_int),
+    ]
+
+
+class RtLnBwdArgs(ctypes.Structure):
+    """Mirror of ``sc_rt_ln_bwd_args``."""
+    _fields_ = [
+        ("dy", c_void_p), ("dy_slice", c_i64), ("ns", c_int), ("rows", c_int),
+        ("add", c_void_p),
+        ("xhat", c_void_p), ("gamma", c_void_p), ("rstd", c_void_p),
+        ("dx", c_void_p), ("dx_masked", c_void_p),
+        ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32),
+        ("dgamma", c_void_p), ("dbeta", c_void_p),
+        ("D", c_int), ("pad_", c_int),
+    ]
+
+
 class HubertLayerArgs(ctypes.Structure):
     """Mirror of ``sc_hubert_layer_args`` (include/speechclip_hip.h)."""
     _fields_ = [
@@ -104,8 +146,9 @@ SIGNATURES = {
     "sc_softmax_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint32, c_void_p],
     "sc_softmax_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint32, c_void_p],
     "sc_gemm_stats_strips": [ctypes.POINTER(GemmArgs)],
-    "sc_cls_pool_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
-    "sc_cls_pool_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sc_cls_pool_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "sc_cls_pool_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                        c_void_p, c_void_p],
     "sc_sgemm_f32": [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "sc_infonce_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p],
@@ -124,6 +167,16 @@ SIGNATURES = {
     "sc_gelu_f32": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "sc_colsum_f32": [c_void_p, c_i64, c_int, c_int, c_void_p, c_float, c_float, c_void_p],
     "sc_headmask_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_rt_gemm": [ctypes.POINTER(RtGemmArgs), c_void_p],
+    "sc_rt_gemm_slices": [c_int, c_int, c_int, c_int],
+    "sc_rt_ln_fwd": [ctypes.POINTER(RtLnArgs), c_void_p],
+    "sc_rt_ln_bwd": [ctypes.POINTER(RtLnBwdArgs), c_void_p],
+    "sc_rt_l2norm_fwd": [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "sc_rt_elem": [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, ctypes.c_uint32,
+                   c_void_p],
+    "sc_rt_value_bias_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "sc_rt_softmax_bwd_reduce": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "sc_rt_l2norm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "sc_sumsq_f32": [c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "sc_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p, c_int, c_float, c_void_p],
 }
@@ -149,6 +202,12 @@ def lib() -> ctypes.CDLL:
         cdll.sc_workspace_bytes.restype = ctypes.c_int64
         cdll.sc_infonce_workspace_floats.argtypes = [c_int]
         cdll.sc_infonce_workspace_floats.restype = ctypes.c_int64
+        cdll.sc_sizeof.argtypes = [c_int]
+        cdll.sc_sizeof.restype = ctypes.c_int64
+        for what, cls in enumerate((GemmArgs, HubertLayerArgs, RtGemmArgs, RtLnArgs, RtLnBwdArgs)):
+            if cdll.sc_sizeof(what) != ctypes.sizeof(cls):
+                raise RuntimeError(f"{cls.__name__}: ctypes mirror has {ctypes.sizeof(cls)} bytes, the library's struct {cdll.sc_sizeof(what)} "
+                                   "(include/speechclip_hip.h and _lib.py are out of step, or a stale .so)")
         cdll.sc_hash32.argtypes = [ctypes.c_uint32]
         cdll.sc_hash32.restype = ctypes.c_uint32
         _LIB = cdll

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void cls_pool_fwd_kernel(const uint16_t* __res
                                                            const float* __restrict__ scores,
                                                            const int32_t* __restrict__ len, float* __restrict__ p,
                                                            float* __restrict__ m, int R, int D, int H,
-                                                           const float* __restrict__ mult) {
+                                                           const float* __restrict__ mult, float* __restrict__ psum) {
     extern __shared__ float sm[];            // p[H][R] then red[4][H][64]
     float* ps = sm;
     float* red = sm + H * R;
@@ -126,11 +126,18 @@ __global__ __launch_bounds__(256) void cls_pool_fwd_kernel(const uint16_t* __res
         }
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
+        float kept = 0.f;
         for (int s = lane; s < R; s += 64) {
             const float v = s < n ? ps[h * R + s] * inv : 0.f;
             // attention-weight dropout (train mode): the pooling uses p * mult (mult = 0 or 1 / (1 - p_drop)), p itself is kept
-            ps[h * R + s] = mult ? v * mult[((int64_t)b * H + h) * R + s] : v;
+            const float w = mult ? v * mult[((int64_t)b * H + h) * R + s] : v;
+            ps[h * R + s] = w;
+            kept += w;
             if (blockIdx.x == 0) p[((int64_t)b * H + h) * R + s] = v;
+        }
+        if (psum) {                          // sum_s p mult: the weight of the value bias (dropped weights no longer sum to 1)
+            kept = wave_sum(kept);
+            if (blockIdx.x == 0 && lane == 0) psum[(int64_t)b * H + h] = kept;
         }
     }
     __syncthreads();
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void cls_pool_bwd_kernel(const uint16_t* __res
                                                            const float* __restrict__ a,
                                                            const int32_t* __restrict__ len, float* __restrict__ dX,
                                                            float* __restrict__ da_partial, int R, int D, int H,
-                                                           const float* __restrict__ mult) {
+                                                           const float* __restrict__ mult, const float* __restrict__ cbias) {
     extern __shared__ float sm[];            // ps[H][R] (p * mult: the weights the pooling used), dss[H][R], red[4][H][64]
     float* ps = sm;
     float* dss = sm + H * R;
@@ -193,13 +200,18 @@ __global__ __launch_bounds__(256) void cls_pool_bwd_kernel(const uint16_t* __res
     for (int h = wave; h < H; h += 4) {
         const float* pr = p + ((int64_t)b * H + h) * R;
         const float* dpr = dp + ((int64_t)b * H + h) * R;
+        const float* mr = mult ? mult + ((int64_t)b * H + h) * R : nullptr;
+        // cbias given: dp is the RAW score gradient X . dm; the gradient of the attention weight in front of the dropout is
+        // (dp + cbias[b,h]) * mult (cbias = the value-bias path through sum_s p mult).  Otherwise dp arrives already in that form.
+        const float cb = cbias ? cbias[(int64_t)b * H + h] : 0.f;
+        auto dpe = [&](int s) { return cbias ? (dpr[s] + cb) * (mr ? mr[s] : 1.f) : dpr[s]; };
         float dot = 0.f;
-        for (int s = lane; s < n; s += 64) dot += pr[s] * dpr[s];
+        for (int s = lane; s < n; s += 64) dot += pr[s] * dpe(s);
         dot = wave_sum(dot);
         for (int s = lane; s < R; s += 64) {
             const float pv = s < n ? pr[s] : 0.f;
-            ps[h * R + s] = mult ? pv * mult[((int64_t)b * H + h) * R + s] : pv;
-            dss[h * R + s] = s < n ? pv * (dpr[s] - dot) : 0.f;     // dp arrives already multiplied by mult
+            ps[h * R + s] = mr ? pv * mr[s] : pv;
+            dss[h * R + s] = s < n ? pv * (dpe(s) - dot) : 0.f;
         }
     }
     __syncthreads();
@@ -282,12 +294,12 @@ extern "C" int sc_cls_scores(const sc_bf16* X, const float* vec, int64_t vec_bst
 }
 
 extern "C" int sc_cls_pool_fwd(const sc_bf16* X, const float* scores, const int32_t* len, float* p, float* m,
-                               int32_t B, int32_t R, int32_t D, int32_t H, const float* mult, void* stream) {
+                               int32_t B, int32_t R, int32_t D, int32_t H, const float* mult, float* psum, void* stream) {
     SC_CHECK(X && scores && len && p && m, "sc_cls_pool_fwd: null pointer");
     SC_CHECK(D % 64 == 0 && H >= 1 && H <= MAXH && ((uintptr_t)X % 16) == 0, "sc_cls_pool_fwd: D %% 64, H <= 16, 16-byte aligned X required (D=%d H=%d)", D, H);
     const size_t lds = (size_t)(H * R + 4 * H * 64) * sizeof(float);
     SC_CHECK(lds <= 64 * 1024, "sc_cls_pool_fwd: H*R too large for LDS");
-    #define SC_CPF(NH) hipLaunchKernelGGL(cls_pool_fwd_kernel<NH>, dim3(D / 64, B), dim3(256), lds, (hipStream_t)stream, X, scores, len, p, m, R, D, H, mult)
+    #define SC_CPF(NH) hipLaunchKernelGGL(cls_pool_fwd_kernel<NH>, dim3(D / 64, B), dim3(256), lds, (hipStream_t)stream, X, scores, len, p, m, R, D, H, mult, psum)
     switch (H) {
         case 1: SC_CPF(1); break;
         case 2: SC_CPF(2); break;
@@ -303,13 +315,13 @@ extern "C" int sc_cls_pool_fwd(const sc_bf16* X, const float* scores, const int3
 
 extern "C" int sc_cls_pool_bwd(const sc_bf16* X, const float* p, const float* dp, const float* dm, const float* a,
                                const int32_t* len, float* dX, float* da_partial, int32_t B, int32_t R, int32_t D,
-                               int32_t H, const float* mult, void* stream) {
+                               int32_t H, const float* mult, const float* cbias, void* stream) {
     SC_CHECK(X && p && dp && dm && a && len && dX && da_partial, "sc_cls_pool_bwd: null pointer");
     SC_CHECK(D % 64 == 0 && H >= 1 && H <= MAXH, "sc_cls_pool_bwd: D %% 64, H <= 16 required");
     SC_CHECK(((uintptr_t)X % 8) == 0 && ((uintptr_t)dX % 16) == 0 && ((uintptr_t)dm % 16) == 0 && ((uintptr_t)a % 16) == 0, "sc_cls_pool_bwd: alignment");
     const size_t lds = (size_t)(2 * H * R + 4 * H * 64) * sizeof(float);
     SC_CHECK(lds <= 64 * 1024, "sc_cls_pool_bwd: H*R too large for LDS");
-    #define SC_CPB(NH) hipLaunchKernelGGL(cls_pool_bwd_kernel<NH>, dim3(D / 64, B), dim3(256), lds, (hipStream_t)stream, X, p, dp, dm, a, len, dX, da_partial, R, D, H, mult)
+    #define SC_CPB(NH) hipLaunchKernelGGL(cls_pool_bwd_kernel<NH>, dim3(D / 64, B), dim3(256), lds, (hipStream_t)stream, X, p, dp, dm, a, len, dX, da_partial, R, D, H, mult, cbias)
     switch (H) {
         case 1: SC_CPB(1); break;
         case 2: SC_CPB(2); break;

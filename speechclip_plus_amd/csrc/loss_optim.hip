@@ -148,24 +148,33 @@ __global__ __launch_bounds__(256) void infonce_fwd_kernel(const float* __restric
     float* prs = part + (int64_t)nt * Bg;                // row sum exp
     float* pcm = part + (int64_t)2 * nt * Bg;            // [nt][Bg] col max   (indexed by row tile)
     float* pcs = part + (int64_t)3 * nt * Bg;
+    // the tile's 64 row ids and 64 column ids once into LDS (the mask test below used to re-load them from global memory inside both
+    // inner loops: 256 dependent loads per thread on a kernel that is ONE workgroup at the per-GPU batch of the recipes)
+    __shared__ int64_t idl[2][64];
+    if (tid < 128) {
+        const int g = (tid < 64 ? i0 : j0) + (tid & 63);
+        idl[tid >> 6][tid & 63] = g < Bg ? (ids ? ids[g] : (int64_t)g) : (int64_t)-1 - g;
+    }
+    __syncthreads();
     if (tid < 128) {
         const bool is_row = tid < 64;
         const int o = tid & 63;
         const int gfix = (is_row ? i0 : j0) + o;
         if (gfix < Bg) {
-            const int64_t idf = ids ? ids[gfix] : (int64_t)gfix;
+            const int64_t idf = idl[is_row ? 0 : 1][o];
+            const int64_t* idv = idl[is_row ? 1 : 0];
             float m = -INFINITY;
             for (int q = 0; q < 64; ++q) {
                 const int gvar = (is_row ? j0 : i0) + q;
                 if (gvar >= Bg) break;
-                const bool neg = (ids ? ids[gvar] != idf : gvar != gfix) || (!dcl && gvar == gfix);
+                const bool neg = idv[q] != idf || (!dcl && gvar == gfix);
                 if (neg) m = fmaxf(m, is_row ? Ls[o][q] : Ls[q][o]);
             }
             float sum = 0.f;
             for (int q = 0; q < 64; ++q) {
                 const int gvar = (is_row ? j0 : i0) + q;
                 if (gvar >= Bg) break;
-                const bool neg = (ids ? ids[gvar] != idf : gvar != gfix) || (!dcl && gvar == gfix);
+                const bool neg = idv[q] != idf || (!dcl && gvar == gfix);
                 if (neg) sum += __expf((is_row ? Ls[o][q] : Ls[q][o]) - m);
             }
             if (is_row) { prm[(int64_t)tj * Bg + gfix] = m; prs[(int64_t)tj * Bg + gfix] = sum; }
@@ -254,7 +263,16 @@ __global__ __launch_bounds__(256) void infonce_grad_kernel(const float* __restri
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
     __shared__ float red[4];
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+    if (((uintptr_t)x % 16) == 0) {          // 16-byte loads over the aligned body, scalar tail
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            const f32x4 v = *(const f32x4*)(x + i * 4);
+            s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -268,10 +286,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float max_norm) {
     float clip = 1.f;
     if (gn_partial && max_norm > 0.f) {
-        float tot = 0.f;
-        for (int i = 0; i < nblk; ++i) tot += gn_partial[i];      // fixed order: deterministic
-        const float norm = sqrtf(tot);
-        clip = fminf(1.f, max_norm / (norm + 1e-6f));             // torch.nn.utils.clip_grad_norm_
+        // every workgroup re-derives the global norm from the partials: lanes of the first wave take them in a fixed interleave and
+        // add in a fixed order (deterministic), instead of every THREAD walking all of them
+        __shared__ float clip_s;
+        if (threadIdx.x < 64) {
+            float tot = 0.f;
+            for (int i = threadIdx.x; i < nblk; i += 64) tot += gn_partial[i];
+            tot = wave_sum(tot);
+            if (threadIdx.x == 0) clip_s = fminf(1.f, max_norm / (sqrtf(tot) + 1e-6f));      // torch.nn.utils.clip_grad_norm_
+        }
+        __syncthreads();
+        clip = clip_s;
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gi = g[i] * clip;

@@ -41,6 +41,18 @@ extern "C" uint32_t sc_hash32(uint32_t x) {
 extern "C" const char* sc_last_error(void) { return g_err; }
 extern "C" int sc_abi_version(void) { return 3; }
 
+// sizeof of the argument structs, for bindings that mirror them by hand (ctypes): a layout mismatch is caught before the first call
+extern "C" int64_t sc_sizeof(int32_t what) {
+    switch (what) {
+        case 0: return (int64_t)sizeof(sc_gemm_args);
+        case 1: return (int64_t)sizeof(sc_hubert_layer_args);
+        case 2: return (int64_t)sizeof(sc_rt_gemm_args);
+        case 3: return (int64_t)sizeof(sc_rt_ln_args);
+        case 4: return (int64_t)sizeof(sc_rt_ln_bwd_args);
+        default: return -1;
+    }
+}
+
 // tuning switches for same-process A/B measurements (tools/): not part of the computation's contract, results never depend on them
 static int g_options[8] = {1, 0, 0, 0, 0, 0, 0, 0};
 int sc_option(int key) { return (key >= 0 && key < 8) ? g_options[key] : 0; }

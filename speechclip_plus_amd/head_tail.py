@@ -36,7 +36,7 @@ def _gacc(p: torch.Tensor) -> torch.Tensor:
 
 
 def _lin(x, W, b):
-    """y[B,N] = x[B,K] W[N,K]^T + b"""
+    """y[B,N] = x[B,K] W[N,K]^T + b   (the one-row query path: M = 1 or H rows)"""
     Bn, K = x.shape
     N = W.shape[0]
     y = torch.empty(Bn, N, device=x.device, dtype=torch.float32)
@@ -44,25 +44,31 @@ def _lin(x, W, b):
     return y
 
 
-def _lin_bwd(dy, x, W, gW, gb, need_dx=True):
-    """gW += dy^T x ; gb += colsum(dy) ; returns dx = dy W"""
+def _wgrad(dy, x, gW, gb):
+    """gW [N, K] += dy[B, N]^T x[B, K] ; gb [N] += column sums of dy - ONE launch (sc_rt_gemm, weight-gradient form)"""
+    Bn, N = dy.shape
+    K = x.shape[1]
+    ops.rt_gemm(dy, x, N, K, Bn, a_kmajor=True, b_kmajor=True, lda=N, ldb=K, out=gW, beta=1.0, gb=gb)
+
+
+def _dgrad(dy, W):
+    """dx[B, K] = dy[B, N] W[N, K] as partial slices (the consumer adds them)"""
     Bn, N = dy.shape
     K = W.shape[1]
-    ops.sgemm_ex(dy, (1, N, 0), x, (1, K, 0), gW, K, N, K, Bn, beta=1.0)
-    if gb is not None:
-        ops.colsum(dy, N, Bn, N, gb, beta=1.0)
-    if not need_dx:
-        return None
-    dx = torch.empty(Bn, K, device=dy.device, dtype=torch.float32)
-    ops.sgemm_ex(dy, (N, 1, 0), W, (1, K, 0), dx, K, Bn, K, N)
-    return dx
+    return ops.rt_gemm(dy, W, Bn, K, N, b_kmajor=True, ldb=K, split=True)
 
 
 class ParallelHeadFn(torch.autograd.Function):
     """inputs : cls [1,1,D] fp32 (parameter), ws_weights (weighted-sum logits or None), feat (generic path or None),
                then constants: the TransformerEncoder module, the projection nn.Linear (or None), the encoder handle,
                src [B,R,D] bf16 (row 0 = CLS slot), lens int32 [B], B, R
-       output : [B, E] (or [B, D] without projection) fp32"""
+       output : [B, E] (or [B, D] without projection) fp32
+
+    Round 3: the B-row products are sc_rt_gemm launches whose contraction is split over the chip; their partial slices are added by
+    the consumer (the next product's operand load, a LayerNorm / activation row kernel) together with the bias, so no reduce
+    launch and no separate bias / GELU / dropout / residual launches exist; every weight-gradient product also emits its bias
+    gradient.  The dropout multipliers of the three B-row sites are hash bits evaluated inside the consumers (the same bits
+    ops.dropout_mult would materialise for the same seed)."""
 
     @staticmethod
     def forward(ctx, cls, ws_weights, feat, module, proj, handle, src, lens, B, R):
@@ -84,37 +90,38 @@ class ParallelHeadFn(torch.autograd.Function):
         ops.sgemm_ex(Qm, (D, 1, 0), Wk, (1, D, 0), a, D, H, D, D, alpha=dh ** -0.5)
         scores = ops.cls_scores(src, a, False, B, R, D, H)
         pd = float(module.dropout) if module.training else 0.0
-        mk = (lambda *shape: ops.dropout_mult(shape, pd, dev)) if pd > 0 else None      # one launch per mask (was rand / compare / cast / scale)
-        mult = mk(B, H, R) if mk else None
-        p, m = ops.cls_pool_fwd(src, scores, lens, B, R, D, H, mult)   # m [B, H, D]
-        # ---- value projection per head (softmax sums to 1 => + bv), out_proj, post-LN layer on B rows
-        cx = torch.empty(B, D, device=dev, dtype=torch.float32)
-        if mult is None:
-            ops.sgemm_ex(m, (H * D, 1, D), Wv, (D, 1, dh * D), cx, D, B, dh, D, nbatch=H, scz=dh, bias=bi[2 * D:], sbiasz=dh)
-            psum = None
-        else:       # dropped attention weights no longer sum to 1: ctx_h = Wv_h m_h + bv_h * sum_s(p mult)
-            ops.sgemm_ex(m, (H * D, 1, D), Wv, (D, 1, dh * D), cx, D, B, dh, D, nbatch=H, scz=dh)
-            psum = (p * mult).sum(-1)                               # [B, H]
-            cx.view(B, H, dh).addcmul_(psum[:, :, None], bi[2 * D:].view(1, H, dh))
-        attn = _lin(cx, att.out_proj.weight.detach(), att.out_proj.bias.detach())
-        k1, kf, k2 = (mk(B, D), mk(B, layer.linear1.out_features), mk(B, D)) if mk else (None, None, None)
-        if mk:
-            attn *= k1
-        x1, xh1, rs1 = ops.rowln_fwd(attn, x0, 0, layer.norm1.weight.detach(), layer.norm1.bias.detach(), module.layer_norm_eps)
-        u = _lin(x1, layer.linear1.weight.detach(), layer.linear1.bias.detach())
-        f = ops.gelu_f32(u)
-        if mk:
-            f *= kf
-        y2 = _lin(f, layer.linear2.weight.detach(), layer.linear2.bias.detach())
-        if mk:
-            y2 *= k2
-        x2, xh2, rs2 = ops.rowln_fwd(y2, x1, D, layer.norm2.weight.detach(), layer.norm2.bias.detach(), module.layer_norm_eps)
+        s_att, s1, sf, s2 = (ops.next_mult_seed() for _ in range(4)) if pd > 0 else (0, 0, 0, 0)   # order = the sites' order in the layer
+        mult = ops.dropout_mult((B, H, R), pd, dev, seed=s_att) if pd > 0 else None
+        # m [B, H, D]; psum [B, H] = sum_s(p mult): ctx_h = Wv_h m_h + bv_h * psum (the dropped weights no longer sum to 1; eval: 1)
+        if mult is not None:
+            p, m, psum = ops.cls_pool_fwd(src, scores, lens, B, R, D, H, mult, want_psum=True)
+        else:
+            (p, m), psum = ops.cls_pool_fwd(src, scores, lens, B, R, D, H, None), None
+        cxs = ops.rt_gemm(m, Wv, B, dh, D, nbatch=H, lda=H * D, a_z=D, ldb=D, b_z=dh * D, split=True, ldc=D, c_z=dh)
+        cx = ops.rt_elem(cxs, 0, bias=bi[2 * D:], rowscale=psum, group=dh)
+        # ---- out_proj -> dropout1 -> + cls -> LN1
+        attn_s = ops.rt_gemm(cx, att.out_proj.weight.detach(), B, D, D, split=True)
+        x1, xh1, rs1 = ops.rt_ln_fwd(attn_s, att.out_proj.bias.detach(), x0, 0, layer.norm1.weight.detach(), layer.norm1.bias.detach(),
+                                     module.layer_norm_eps, drop_p=pd, drop_seed=s1)
+        # ---- FFN: linear1 -> GELU -> dropout -> linear2 -> dropout2 -> + x1 -> LN2 -> final LN
+        F_ = layer.linear1.out_features
+        us = ops.rt_gemm(x1, layer.linear1.weight.detach(), B, F_, D, split=True)
+        u, f = ops.rt_elem(us, 1, bias=layer.linear1.bias.detach(), drop_p=pd, drop_seed=sf)
+        y2s = ops.rt_gemm(f, layer.linear2.weight.detach(), B, D, F_, split=True)
         fin = module.model.norm
-        x3, xh3, rs3 = ops.rowln_fwd(x2, None, 0, fin.weight.detach(), fin.bias.detach(), fin.eps)
-        out = _lin(x3, proj.weight.detach(), proj.bias.detach()) if proj is not None else x3
+        x2, xh2, rs2, x3, xh3, rs3 = ops.rt_ln_fwd(y2s, layer.linear2.bias.detach(), x1, D, layer.norm2.weight.detach(),
+                                                   layer.norm2.bias.detach(), module.layer_norm_eps, fin.weight.detach(),
+                                                   fin.bias.detach(), fin.eps, drop_p=pd, drop_seed=s2)
+        if proj is not None:
+            outs = ops.rt_gemm(x3, proj.weight.detach(), B, proj.weight.shape[0], D, split=True)
+            out, e, rn = ops.rt_l2norm_fwd(outs, proj.bias.detach())
+            out._sc_unit = (e, rn)           # UnitRowsFn (model.forward's L2 normalisation) re-uses these instead of a second launch
+        else:
+            out = x3
         ctx.mod, ctx.proj, ctx.handle, ctx.dims = module, proj, handle, (B, R, D, H)
         ctx.feat_meta = None if feat is None else (feat.shape, feat.dtype)
-        ctx.masks = (mult, k1, kf, k2, psum)
+        ctx.drop = (pd, s1, sf, s2)
+        ctx.masks = (mult, psum)
         ctx.save_for_backward(src, lens, x0, q, Qm, a, p, m, cx, xh1, rs1, x1, u, f, xh2, rs2, xh3, rs3, x3)
         return out
 
@@ -123,7 +130,8 @@ class ParallelHeadFn(torch.autograd.Function):
         src, lens, x0, q, Qm, a, p, m, cx, xh1, rs1, x1, u, f, xh2, rs2, xh3, rs3, x3 = ctx.saved_tensors
         module, proj = ctx.mod, ctx.proj
         B, R, D, H = ctx.dims
-        mult, k1, kf, k2, psum = ctx.masks
+        pd, s1, sf, s2 = ctx.drop
+        mult, psum = ctx.masks
         dh = D // H
         dev = src.device
         layer, fin = module.model.layers[0], module.model.norm
@@ -133,39 +141,39 @@ class ParallelHeadFn(torch.autograd.Function):
         gWi, gbi = _gacc(att.in_proj_weight), _gacc(att.in_proj_bias)
         d_out = d_out.float().contiguous()
         # ---- projection, final LN, LN2
-        dx3 = _lin_bwd(d_out, x3, proj.weight.detach(), _gacc(proj.weight), _gacc(proj.bias)) if proj is not None else d_out
-        dx2 = ops.rowln_bwd(dx3, xh3, fin.weight.detach(), rs3, _gacc(fin.weight), _gacc(fin.bias))
-        dy2 = ops.rowln_bwd(dx2, xh2, layer.norm2.weight.detach(), rs2, _gacc(layer.norm2.weight), _gacc(layer.norm2.bias))
-        # ---- FFN:  y2 = x1 + k2 * (W2 (kf * gelu(W1 x1 + b1)) + b2)      (k* = dropout multipliers, 1 in eval; f is saved masked)
-        dl2 = dy2 * k2 if k2 is not None else dy2
-        df = _lin_bwd(dl2, f, layer.linear2.weight.detach(), _gacc(layer.linear2.weight), _gacc(layer.linear2.bias))
-        if kf is not None:
-            df *= kf
-        du = ops.gelu_f32(u, df)
-        dx1 = _lin_bwd(du, x1, layer.linear1.weight.detach(), _gacc(layer.linear1.weight), _gacc(layer.linear1.bias))
-        dx1 += dy2
-        # ---- LN1 over (cls + attn): d attn = dy1, d cls += colsum(dy1)
-        dy1 = ops.rowln_bwd(dx1, xh1, layer.norm1.weight.detach(), rs1, _gacc(layer.norm1.weight), _gacc(layer.norm1.bias))
+        if proj is not None:
+            _wgrad(d_out, x3, _gacc(proj.weight), _gacc(proj.bias))
+            dx3 = _dgrad(d_out, proj.weight.detach())
+        else:
+            dx3 = ops.Slices(d_out.unsqueeze(0))
+        dx2 = ops.rt_ln_bwd(dx3, None, xh3, fin.weight.detach(), rs3, _gacc(fin.weight), _gacc(fin.bias))
+        # z2 = x1 + k2 * (W2 f + b2): dy2 flows to x1, dl2 = dy2 * k2 to the FFN output
+        dy2, dl2 = ops.rt_ln_bwd(ops.Slices(dx2.unsqueeze(0)), None, xh2, layer.norm2.weight.detach(), rs2, _gacc(layer.norm2.weight),
+                                 _gacc(layer.norm2.bias), want_masked=True, drop_p=pd, drop_seed=s2)
+        # ---- FFN (f is saved masked: f = kf * gelu(u))
+        _wgrad(dl2, f, _gacc(layer.linear2.weight), _gacc(layer.linear2.bias))
+        dfs = _dgrad(dl2, layer.linear2.weight.detach())
+        du = ops.rt_elem(dfs, 2, u=u, drop_p=pd, drop_seed=sf)
+        _wgrad(du, x1, _gacc(layer.linear1.weight), _gacc(layer.linear1.bias))
+        dx1s = _dgrad(du, layer.linear1.weight.detach())
+        # ---- LN1 over (cls + k1 * attn): incoming = FFN path + residual path; d attn = dy1 * k1, d cls += colsum(dy1)
+        dy1, dattn = ops.rt_ln_bwd(dx1s, dy2, xh1, layer.norm1.weight.detach(), rs1, _gacc(layer.norm1.weight), _gacc(layer.norm1.bias),
+                                   want_masked=True, drop_p=pd, drop_seed=s1)
         d_x0 = torch.empty(1, D, device=dev, dtype=torch.float32)
         ops.colsum(dy1, D, B, D, d_x0)
-        if k1 is not None:
-            dy1 = dy1 * k1
-        dcx = _lin_bwd(dy1, cx, att.out_proj.weight.detach(), _gacc(att.out_proj.weight), _gacc(att.out_proj.bias))
-        # ---- value projection: bv, Wv_h += dcx_h^T m_h, dm_h = dcx_h Wv_h
-        if psum is None:
-            ops.colsum(dcx, D, B, D, gbi[2 * D:], beta=1.0)
-        else:
-            gbi[2 * D:].view(H, dh).add_((dcx.view(B, H, dh) * psum[:, :, None]).sum(0))
-        ops.sgemm_ex(dcx, (1, D, dh), m, (1, H * D, D), gWi[2 * D:], D, dh, D, B, nbatch=H, scz=dh * D, beta=1.0)
+        _wgrad(dattn, cx, _gacc(att.out_proj.weight), _gacc(att.out_proj.bias))
+        dcx = ops.rt_elem(_dgrad(dattn, att.out_proj.weight.detach()), 0)
+        # ---- value projection: Wv_h += dcx_h^T m_h, bv_h += sum_b dcx_h psum, dm_h = dcx_h Wv_h
+        ops.rt_gemm(dcx, m, dh, D, B, a_kmajor=True, b_kmajor=True, lda=D, ldb=H * D, nbatch=H, a_z=dh, b_z=D, out=gWi[2 * D:], ldc=D,
+                    c_z=dh * D, beta=1.0, gb=gbi[2 * D:] if psum is None else None, gb_z=dh)
+        # train mode: the bias path through sum_s(p mult) - bv's gradient and the extra term of the attention-weight gradient
+        cbias = ops.rt_value_bias_bwd(dcx, att.in_proj_bias.detach()[2 * D:], psum, gbi[2 * D:], H) if psum is not None else None
         dm = torch.empty(B, H, D, device=dev, dtype=torch.float32)
-        ops.sgemm_ex(dcx, (D, 1, dh), Wv, (1, D, dh * D), dm, H * D, B, D, dh, nbatch=H, scz=D)
+        ops.rt_gemm(dcx, Wv, B, D, dh, nbatch=H, lda=D, a_z=dh, b_kmajor=True, ldb=D, b_z=dh * D, out=dm, ldc=H * D, c_z=D)
         # ---- attention pooling backward (two sweeps over X), gradient of the CLS slot and of a
         dp = ops.cls_scores(src, dm, True, B, R, D, H)
-        if mult is not None:                                        # + the bias path through sum_s(p mult), then the mask itself
-            dp += (dcx.view(B, H, dh) * att.in_proj_bias.detach()[2 * D:].view(1, H, dh)).sum(-1)[:, :, None]
-            dp *= mult
-        dX, da_part = ops.cls_pool_bwd(src, p, dp, dm, a, lens, B, R, D, H, mult)
-        ops.colsum(dX, R * D, B, D, d_x0, beta=1.0)              # row 0 of every utterance is the CLS token
+        dX, da_part = ops.cls_pool_bwd(src, p, dp, dm, a, lens, B, R, D, H, mult, cbias=cbias)    # (dp + cbias) * mult inside
+        ops.colsum(dX, R * D, B, D, d_x0, beta=1.0)             # row 0 of every utterance is the CLS token
         d_a = torch.empty(H, D, device=dev, dtype=torch.float32)
         ops.colsum(da_part, H * D, B, H * D, d_a)
         # ---- a = s Qm Wk ;  q = Wq cls + bq   (bk receives exactly zero)
@@ -184,11 +192,36 @@ class ParallelHeadFn(torch.autograd.Function):
         if hd is not None:
             hd.check_fresh()
         if hd is not None and ctx.needs_input_grad[1]:
-            d_soft = ops.wsum_bwd(hd.hidden, dX, B, R, D, 1, normalize=hd.normalize, lazy=hd.lazy)
-            d_ws = hd.w_soft * (d_soft - (hd.w_soft * d_soft).sum())
+            d_ws = ops.wsum_bwd_logits(hd.hidden, dX, hd.w_soft, B, R, D, 1, normalize=hd.normalize, lazy=hd.lazy)
         if hd is not None and hd.layers_bwd is not None:           # unfrozen HuBERT layers: continue the chain below the weighted sum
             hd.layers_bwd(dX, hd.w_soft)
         if ctx.feat_meta is not None and ctx.needs_input_grad[2]:
             shape, dtype = ctx.feat_meta
             d_feat = dX[:, 1: 1 + shape[1]].to(dtype)
         return d_cls, d_ws, d_feat, None, None, None, None, None, None, None
+
+
+class UnitRowsFn(torch.autograd.Function):
+    """e = x / |x| over the last dimension of a [B, E] fp32 matrix (avssl/model/kwClip.py:857,913-915) on the row kernels: one launch
+    forward (none when the producer already computed it, ParallelHeadFn), one backward - instead of norm / div and their autograd chain."""
+
+    @staticmethod
+    def forward(ctx, x):
+        cached = getattr(x, "_sc_unit", None)
+        if cached is not None:
+            e, rn = cached
+        else:
+            _, e, rn = ops.rt_l2norm_fwd(ops.Slices(x.detach().float().contiguous().unsqueeze(0)), None, keep_x=False)
+        ctx.save_for_backward(e, rn)
+        return e
+
+    @staticmethod
+    def backward(ctx, g):
+        e, rn = ctx.saved_tensors
+        return ops.rt_l2norm_bwd(g, e, rn)
+
+
+def unit_rows(x: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda or x.dim() != 2:
+        raise RuntimeError("unit_rows: [B, E] device tensors only (speechclip_plus_amd has no CPU path)")
+    return UnitRowsFn.apply(x)

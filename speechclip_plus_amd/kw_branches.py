@@ -132,7 +132,9 @@ class KW_ParallelBranch(GeneralBranch):
             audio_len = audio_feat_len
         output = defaultdict(lambda: None)
         # kw_branches.py:266-280: CLS + frames, key_padding_mask from audio_len + 1, row 0, projection
-        out = self.self_att.cls_forward(self.cls, audio_feat, audio_len + 1, proj=getattr(self, "linear_proj", None))
+        lens = getattr(audio_len, "_sc_p1_i32", None)           # audio_len + 1 as int32, uploaded with the batch's other integers
+        out = self.self_att.cls_forward(self.cls, audio_feat, audio_len + 1 if lens is None else lens,
+                                        proj=getattr(self, "linear_proj", None))
         output["parallel_audio_feat"] = out
         return output
 

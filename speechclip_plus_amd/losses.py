@@ -24,7 +24,7 @@ class _InfoNCEFn(torch.autograd.Function):
         ctx.save_for_backward(A, Bm, logits, lse_row, lse_col, it, ids if ids is not None else torch.empty(0))
         ctx.has_ids = ids is not None
         ctx.opts = (margin, dcl, a2b, b2a)
-        return loss[0].clone()
+        return loss.reshape(())            # (a fresh [1] buffer of this call: no copy)
 
     @staticmethod
     def backward(ctx, g):

@@ -18,6 +18,7 @@ from torch import nn
 
 from . import losses
 from .clip_text import ClipModel
+from .head_tail import unit_rows
 from .kw_branches import KW_CascadedBranchPlus, KW_HybridBranchPlus, KW_ParallelBranch
 from .speech_encoder import FairseqSpeechEncoder_Hubert
 
@@ -245,7 +246,7 @@ class KWClip_GeneralTransformer(nn.Module):
         wav, wav_len, image, id = batch["wav"], batch["wav_len"], batch["image"], batch["id"]
         audio_feat, audio_feat_len = self.forward_audio(wav, wav_len, return_hidden_states=False)
         image_feat = self.forward_image(image)
-        image_feat = image_feat / image_feat.norm(dim=-1, keepdim=True)
+        image_feat = unit_rows(image_feat.float())
         if self.cascaded_branch is not None:                                       # kwClip.py:859-880
             otherInputs = {"global_step": self.global_step}
             if getattr(self.cascaded_branch, "using_gt_len", False):
@@ -268,10 +269,10 @@ class KWClip_GeneralTransformer(nn.Module):
         id = id.to(self._device)
         losses_ = {"id": id, "image_feat": image_feat}
         if cascaded_audio_feat is not None:
-            cascaded_audio_feat = cascaded_audio_feat / cascaded_audio_feat.norm(dim=-1, keepdim=True)
+            cascaded_audio_feat = unit_rows(cascaded_audio_feat.float())
             losses_["cascaded_audio_feat"] = cascaded_audio_feat
         if parallel_audio_feat is not None:
-            parallel_audio_feat = parallel_audio_feat / parallel_audio_feat.norm(dim=-1, keepdim=True)
+            parallel_audio_feat = unit_rows(parallel_audio_feat.float())
             losses_["parallel_audio_feat"] = parallel_audio_feat
         if self.cascaded_branch is not None and getattr(self.cascaded_branch, "downsampling_type", None) == "cif":
             assert "target_len" in dsample_results and "quantity_out" in dsample_results, f"{dsample_results.keys()}"
@@ -294,7 +295,8 @@ class KWClip_GeneralTransformer(nn.Module):
         assert isinstance(inputDict, dict)
         required_keys = {"id", "image_feat"}
         assert required_keys.issubset(set(inputDict.keys())), f"required: {required_keys}, input: {inputDict.keys()}"
-        losses_ = {"loss": 0}
+        losses_ = {}
+        terms = []                                  # (weight, loss term): summed below without 0 + / 1.0 * launches
         image_feat = inputDict["image_feat"].float()
         id = inputDict["id"]
         for branchType in ["cascaded", "parallel"]:
@@ -304,10 +306,15 @@ class KWClip_GeneralTransformer(nn.Module):
                 assert feats_key in inputDict, f"{inputDict.keys()}"
                 losses_[f"{branchType[0]}_cl_loss"] = self.criterion(feat_A=inputDict[feats_key].float(),
                                                                      feat_B=image_feat, index=id)
-                losses_["loss"] += loss_weight * losses_[f"{branchType[0]}_cl_loss"]
+                terms.append((float(loss_weight), losses_[f"{branchType[0]}_cl_loss"]))
         if "cif_quantity_out" in inputDict and "cif_target_len" in inputDict and hasattr(self, "quantity_loss_criteria"):
             losses_["quantity_loss"] = self.quantity_loss_criteria(inputDict["cif_quantity_out"], inputDict["cif_target_len"])
-            losses_["loss"] += self.quantity_loss_weight * losses_["quantity_loss"]
+            terms.append((float(self.quantity_loss_weight), losses_["quantity_loss"]))
+        total = 0
+        for w, t in terms:
+            t = t if w == 1.0 else w * t
+            total = t if isinstance(total, int) else total + t
+        losses_["loss"] = total
         return losses_
 
     def training_step(self, batch: dict) -> dict:

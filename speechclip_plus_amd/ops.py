@@ -8,7 +8,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import GemmArgs, HubertLayerArgs, check, lib
+from ._lib import RtGemmArgs, RtLnArgs, RtLnBwdArgs, GemmArgs, HubertLayerArgs, check, lib
 
 
 def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
@@ -305,15 +305,22 @@ def dropout_bf16(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tenso
 _mult_calls = [0]
 
 
-def dropout_mult(shape, p: float, device) -> torch.Tensor:
-    """fp32 multiplier of F.dropout(., p) for a tensor of ``shape`` (numel a multiple of 8): keep ? 1 / (1 - p) : 0, one launch.  The
-    seed is a function of torch's seed and a call counter (reproducible under torch.manual_seed, no device RNG state)."""
+def next_mult_seed() -> int:
+    """Seed of the next fp32 dropout site: a function of torch's seed and a call counter (reproducible under torch.manual_seed, no
+    device RNG state).  A site is either materialised (``dropout_mult``) or evaluated inside its consumer kernel (rt_* ops below) -
+    the keep bit of element i is the same either way."""
+    _mult_calls[0] += 1
+    return ((torch.initial_seed() * 0x9E3779B1) ^ (_mult_calls[0] * 0x85EBCA6B)) & 0xffffffff
+
+
+def dropout_mult(shape, p: float, device, seed: Optional[int] = None) -> torch.Tensor:
+    """fp32 multiplier of F.dropout(., p) for a tensor of ``shape`` (numel a multiple of 8): keep ? 1 / (1 - p) : 0, one launch."""
     n = 1
     for d in shape:
         n *= int(d)
     out = torch.empty(n, device=device, dtype=torch.float32)
-    _mult_calls[0] += 1
-    seed = ((torch.initial_seed() * 0x9E3779B1) ^ (_mult_calls[0] * 0x85EBCA6B)) & 0xffffffff
+    if seed is None:
+        seed = next_mult_seed()
     check(lib().sc_dropout_mult_f32(_p(out), n, float(p), seed, _stream()), "sc_dropout_mult_f32")
     return out.view(*shape)
 
@@ -649,25 +656,26 @@ def cls_scores(X: torch.Tensor, vec: torch.Tensor, per_batch: bool, B: int, R: i
 
 
 def cls_pool_fwd(X: torch.Tensor, scores: torch.Tensor, lens: torch.Tensor, B: int, R: int, D: int, H: int,
-                 mult: Optional[torch.Tensor] = None):
-    """``mult`` [B,H,R] fp32 = dropout multipliers of the attention weights (0 or 1/(1-p)); p is returned un-masked."""
+                 mult: Optional[torch.Tensor] = None, want_psum: bool = False):
+    """``mult`` [B,H,R] fp32 = dropout multipliers of the attention weights (0 or 1/(1-p)); p is returned un-masked.  ``want_psum``:
+    also sum_s p mult [B,H] (the weight of the value bias when dropped weights no longer sum to 1)."""
     p = torch.empty(B, H, R, device=X.device, dtype=torch.float32)
     m = torch.empty(B, H, D, device=X.device, dtype=torch.float32)
+    psum = torch.empty(B, H, device=X.device, dtype=torch.float32) if want_psum else None
     if mult is not None:
         assert mult.shape == (B, H, R) and mult.dtype == torch.float32 and mult.is_contiguous()
-    check(lib().sc_cls_pool_fwd(_p(X), _p(scores), _p(lens), _p(p), _p(m), B, R, D, H, _p(mult) if mult is not None else None,
-                                _stream()), "sc_cls_pool_fwd")
-    return p, m
+    check(lib().sc_cls_pool_fwd(_p(X), _p(scores), _p(lens), _p(p), _p(m), B, R, D, H, _p(mult), _p(psum), _stream()), "sc_cls_pool_fwd")
+    return (p, m, psum) if want_psum else (p, m)
 
 
 def cls_pool_bwd(X: torch.Tensor, p: torch.Tensor, dp: torch.Tensor, dm: torch.Tensor, a: torch.Tensor, lens: torch.Tensor,
-                 B: int, R: int, D: int, H: int, mult: Optional[torch.Tensor] = None):
-    """with ``mult`` (see cls_pool_fwd) ``dp`` must already be multiplied by it."""
+                 B: int, R: int, D: int, H: int, mult: Optional[torch.Tensor] = None, cbias: Optional[torch.Tensor] = None):
+    """``cbias`` [B,H]: ``dp`` is the raw X . dm and the kernel forms (dp + cbias) * mult itself; otherwise dp arrives in that form."""
     dX = torch.empty(B, R, D, device=X.device, dtype=torch.float32)
-    da_part = torch.empty(B, H, D, device=X.device, dtype=torch.float32)
-    check(lib().sc_cls_pool_bwd(_p(X), _p(p), _p(dp), _p(dm), _p(a), _p(lens), _p(dX), _p(da_part), B, R, D, H,
-                                _p(mult) if mult is not None else None, _stream()), "sc_cls_pool_bwd")
-    return dX, da_part
+    da = torch.empty(B, H, D, device=X.device, dtype=torch.float32)
+    check(lib().sc_cls_pool_bwd(_p(X), _p(p), _p(dp), _p(dm), _p(a), _p(lens), _p(dX), _p(da), B, R, D, H, _p(mult), _p(cbias), _stream()),
+          "sc_cls_pool_bwd")
+    return dX, da
 
 
 def sgemm(A: torch.Tensor, sai: int, sak: int, Bm: torch.Tensor, sbj: int, sbk: int, M: int, N: int, K: int,
@@ -724,7 +732,7 @@ def infonce_grad(logits: torch.Tensor, ids: Optional[torch.Tensor], lse_row: tor
     return G, dot
 
 
-def sumsq(x: torch.Tensor, nblk: int = 256) -> torch.Tensor:
+def sumsq(x: torch.Tensor, nblk: int = 1024) -> torch.Tensor:
     part = torch.empty(nblk, device=x.device, dtype=torch.float32)
     check(lib().sc_sumsq_f32(_p(x), x.numel(), _p(part), nblk, _stream()), "sc_sumsq_f32")
     return part
@@ -789,3 +797,151 @@ def colsum(x: torch.Tensor, ld: int, rows: int, cols: int, out: torch.Tensor, al
 
 def headmask(q: torch.Tensor, Qm: torch.Tensor, H: int, D: int, dh: int, gather: bool) -> None:
     check(lib().sc_headmask_f32(_p(q), _p(Qm), H, D, dh, int(gather), _stream()), "sc_headmask_f32")
+
+
+# ---------------------------------------------------------------------------------------------- row tail of the head (csrc/rowtail.hip)
+class Slices:
+    """A [rows, cols] fp32 matrix given as ``ns`` partial slices [ns, rows, cols] that its consumer adds in order (a split product of
+    sc_rt_gemm; ns = 1: an ordinary matrix)."""
+
+    def __init__(self, t: torch.Tensor):
+        assert t.dim() == 3 and t.dtype == torch.float32 and t.is_contiguous()
+        self.t, self.ns, self.rows, self.cols = t, t.shape[0], t.shape[1], t.shape[2]
+
+    def total(self) -> torch.Tensor:          # (tests / debugging: the consumer kernels never materialise this)
+        return self.t.sum(0)
+
+
+def rt_gemm(A, Bm: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: bool = False, b_kmajor: bool = False, lda: Optional[int] = None,
+            ldb: Optional[int] = None, a_bias: Optional[torch.Tensor] = None, a_rowscale: Optional[torch.Tensor] = None, a_group: int = 1,
+            split: bool = False, out: Optional[torch.Tensor] = None, ldc: Optional[int] = None, alpha: float = 1.0, beta: float = 0.0,
+            bias: Optional[torch.Tensor] = None, act: int = 0, U: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
+            gb: Optional[torch.Tensor] = None, nbatch: int = 1, a_z: int = 0, b_z: int = 0, c_z: int = 0, bias_z: int = 0, gb_z: int = 0):
+    """C = epi(alpha A . B^T) (sc_rt_gemm).  ``A``: a tensor or ``Slices`` (row-major [M, K]; or [K, M] with a_kmajor), ``Bm`` [N, K] (or
+    [K, N] with b_kmajor).  ``split`` = True: the contraction is split over the chip and a ``Slices`` of raw partial products comes back
+    (its consumer adds them, with the bias); otherwise the epilogue runs and the [M, N] result (``out`` or a fresh tensor) is returned."""
+    a = RtGemmArgs()
+    if isinstance(A, Slices):
+        assert not a_kmajor
+        a.A, a.a_ns, a.a_slice = _p(A.t), A.ns, A.rows * A.cols
+        lda = A.cols if lda is None else lda
+    else:
+        assert A.dtype == torch.float32
+        a.A, a.a_ns, a.a_slice = _p(A), 1, 0
+        lda = A.stride(0) if lda is None else lda
+    assert Bm.dtype == torch.float32
+    a.lda, a.a_z, a.a_kmajor = int(lda), int(a_z), int(a_kmajor)
+    a.a_bias, a.a_rowscale, a.a_group = _p(a_bias), _p(a_rowscale), int(a_group)
+    a.a_nscale = int(a_rowscale.shape[-1]) if a_rowscale is not None else 0
+    a.B, a.ldb, a.b_z, a.b_kmajor, a.nbatch = _p(Bm), int(Bm.stride(0) if ldb is None else ldb), int(b_z), int(b_kmajor), int(nbatch)
+    a.M, a.N, a.K = int(M), int(N), int(K)
+    a.alpha, a.beta = float(alpha), float(beta)
+    dev = Bm.device
+    if split:
+        S = int(lib().sc_rt_gemm_slices(M, N, K, nbatch))
+        assert nbatch == 1 or c_z > 0
+        res = torch.empty(S, M, N if nbatch == 1 else ldc, device=dev, dtype=torch.float32)
+        a.C, a.ldc, a.c_slice, a.c_z, a.S = _p(res), res.shape[2], M * res.shape[2], int(c_z), S
+        check(lib().sc_rt_gemm(ctypes.byref(a), _stream()), "sc_rt_gemm")
+        return Slices(res)
+    if out is None:
+        out = torch.empty(M, N, device=dev, dtype=torch.float32)
+    a.C, a.ldc, a.c_slice, a.c_z, a.S = _p(out), int(out.stride(0) if ldc is None else ldc), 0, int(c_z), 1
+    a.U = _p(U)
+    a.bias, a.bias_z, a.act = _p(bias), int(bias_z), int(act)
+    a.drop_p, a.drop_seed = float(drop_p), int(drop_seed) & 0xffffffff
+    a.gb, a.gb_z = _p(gb), int(gb_z)
+    check(lib().sc_rt_gemm(ctypes.byref(a), _stream()), "sc_rt_gemm")
+    return out
+
+
+def rt_ln_fwd(y: Slices, bias, res, res_stride: int, g1, b1, eps1: float, g2=None, b2=None, eps2: float = 0.0, drop_p: float = 0.0,
+              drop_seed: int = 0):
+    """z = (sum_s y_s + bias) * dropout + res ; LN1 [; LN2] -> (out1, xhat1, rstd1[, out2, xhat2, rstd2])."""
+    rows, D = y.rows, y.cols
+    dev = y.t.device
+    f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+    a = RtLnArgs()
+    a.y, a.y_slice, a.ns, a.rows, a.D = _p(y.t), rows * D, y.ns, rows, D
+    a.bias, a.drop_p, a.drop_seed = _p(bias), float(drop_p), int(drop_seed) & 0xffffffff
+    a.res, a.res_stride = _p(res), int(res_stride)
+    o1, h1, r1 = f(rows, D), f(rows, D), f(rows)
+    a.g1, a.b1, a.eps1, a.out1, a.xhat1, a.rstd1 = _p(g1), _p(b1), float(eps1), _p(o1), _p(h1), _p(r1)
+    outs = (o1, h1, r1)
+    if g2 is not None:
+        o2, h2, r2 = f(rows, D), f(rows, D), f(rows)
+        a.g2, a.b2, a.eps2, a.out2, a.xhat2, a.rstd2 = _p(g2), _p(b2), float(eps2), _p(o2), _p(h2), _p(r2)
+        outs = outs + (o2, h2, r2)
+    check(lib().sc_rt_ln_fwd(ctypes.byref(a), _stream()), "sc_rt_ln_fwd")
+    return outs
+
+
+def rt_ln_bwd(dy: Slices, add, xhat, gamma, rstd, dgamma_acc, dbeta_acc, want_masked: bool = False, drop_p: float = 0.0, drop_seed: int = 0):
+    """LayerNorm backward over a sliced incoming gradient (+ ``add``); returns dx (and dx * dropout multiplier when asked)."""
+    rows, D = dy.rows, dy.cols
+    a = RtLnBwdArgs()
+    dx = torch.empty(rows, D, device=dy.t.device, dtype=torch.float32)
+    dxm = torch.empty_like(dx) if want_masked else None
+    a.dy, a.dy_slice, a.ns, a.rows, a.D = _p(dy.t), rows * D, dy.ns, rows, D
+    a.add, a.xhat, a.gamma, a.rstd, a.dx, a.dx_masked = _p(add), _p(xhat), _p(gamma), _p(rstd), _p(dx), _p(dxm)
+    a.drop_p, a.drop_seed, a.dgamma, a.dbeta = float(drop_p), int(drop_seed) & 0xffffffff, _p(dgamma_acc), _p(dbeta_acc)
+    check(lib().sc_rt_ln_bwd(ctypes.byref(a), _stream()), "sc_rt_ln_bwd")
+    return (dx, dxm) if want_masked else dx
+
+
+def rt_l2norm_fwd(y: Slices, bias, keep_x: bool = True):
+    """x = sum_s y_s + bias ; e = x / |x| -> (x or None, e, 1 / |x|)."""
+    rows, D = y.rows, y.cols
+    dev = y.t.device
+    x = torch.empty(rows, D, device=dev, dtype=torch.float32) if keep_x else None
+    e = torch.empty(rows, D, device=dev, dtype=torch.float32)
+    rn = torch.empty(rows, device=dev, dtype=torch.float32)
+    check(lib().sc_rt_l2norm_fwd(_p(y.t), rows * D, y.ns, _p(bias), _p(x), _p(e), _p(rn), rows, D, _stream()), "sc_rt_l2norm_fwd")
+    return x, e, rn
+
+
+def rt_l2norm_bwd(g: torch.Tensor, e: torch.Tensor, rn: torch.Tensor) -> torch.Tensor:
+    rows, D = e.shape
+    dx = torch.empty_like(e)
+    g = g.float().contiguous()
+    check(lib().sc_rt_l2norm_bwd(_p(g), _p(e), _p(rn), _p(dx), rows, D, _stream()), "sc_rt_l2norm_bwd")
+    return dx
+
+
+def rt_elem(y: Slices, mode: int, bias=None, rowscale=None, group: int = 1, u: Optional[torch.Tensor] = None, drop_p: float = 0.0,
+            drop_seed: int = 0):
+    """mode 0: sum_s y_s + bias * rowscale -> out ; 1: -> (u, gelu(u) * dropout) ; 2: (sum_s y_s) * dropout * gelu'(u) -> out."""
+    rows, D = y.rows, y.cols
+    out = torch.empty(rows, D, device=y.t.device, dtype=torch.float32)
+    if mode == 1:
+        u = torch.empty_like(out)
+    nscale = int(rowscale.shape[-1]) if rowscale is not None else 0
+    check(lib().sc_rt_elem(_p(y.t), rows * D, y.ns, _p(bias), _p(rowscale), int(group), nscale, _p(out), _p(u), rows, D, int(mode), float(drop_p),
+                           int(drop_seed) & 0xffffffff, _stream()), "sc_rt_elem")
+    return (u, out) if mode == 1 else out
+
+
+def rt_value_bias_bwd(dctx: torch.Tensor, bv: torch.Tensor, psum: torch.Tensor, gbv_acc: torch.Tensor, H: int) -> torch.Tensor:
+    """-> cbias [B,H] = sum_j dctx[b,h,j] bv[h,j] ; gbv_acc[h,j] += sum_b dctx[b,h,j] psum[b,h]  (one launch)"""
+    B, D = dctx.shape
+    cb = torch.empty(B, H, device=dctx.device, dtype=torch.float32)
+    check(lib().sc_rt_value_bias_bwd(_p(dctx), _p(bv), _p(psum), _p(cb), _p(gbv_acc), B, D, H, _stream()), "sc_rt_value_bias_bwd")
+    return cb
+
+
+def wsum_bwd_logits(h: torch.Tensor, g: torch.Tensor, w_soft: torch.Tensor, B: int, R: int, D: int, row_off: int, nblk: int = 1024,
+                    normalize: bool = False, lazy: Optional[LazyStates] = None) -> torch.Tensor:
+    """Gradient of the weighted-sum LOGITS in two launches: the partial sums <g, h_n - h_last> per block (sc_wsum_bwd) and their
+    reduction fused with the softmax backward w_n (d_n - sum_m w_m d_m) (sc_rt_softmax_bwd_reduce)."""
+    NL = h.shape[0]
+    assert g.dtype == torch.float32
+    part = torch.empty(nblk, NL, device=h.device, dtype=torch.float32)
+    if lazy is not None:
+        assert not normalize
+        check(lib().sc_wsum_lazy_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, _p(lazy.stats), _p(lazy.gamma), _p(lazy.beta),
+                                     lazy.first_lazy, lazy.ns, lazy.eps, _stream()), "sc_wsum_lazy_bwd")
+    else:
+        check(lib().sc_wsum_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, int(normalize), _stream()), "sc_wsum_bwd")
+    out = torch.empty(NL, device=h.device, dtype=torch.float32)
+    check(lib().sc_rt_softmax_bwd_reduce(_p(part), nblk, NL, _p(w_soft), _p(out), _stream()), "sc_rt_softmax_bwd_reduce")
+    return out

@@ -376,6 +376,9 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         ints = host.to(self._dev, non_blocking=True)
         pl.feat_len = ints[2]
         pl.feat_len._sc_host = list(feat_len)       # host twin (length-derived integers are known before any kernel runs)
+        # key count of the parallel head ([CLS ; frames]: feat_len + 1) as the int32 vector its kernels take: uploaded here too, so the
+        # head needs no add / cast launches
+        pl.feat_len._sc_p1_i32 = torch.tensor([f + 1 for f in feat_len], dtype=torch.int32).pin_memory().to(self._dev, non_blocking=True)
         pl.len_dev.copy_(ints[0])
         pl.valid.copy_(ints[1])
         # The frozen encoder is a fixed sequence of ~130 launches over the plan's resident buffers.  Opt-in (SC_ENCODER_GRAPH=1):

@@ -37,6 +37,7 @@ class ContrastiveTrainer:
         self.replicated = [p for p in model.criterion.parameters() if p.requires_grad]   # evaluated on the full batch by every rank
         self.side = torch.cuda.Stream() if self.opt.flat_g.is_cuda else None
         self._pending = False
+        self._one = None
         # unfrozen HuBERT layers (hubert_train.py): the slice of the flat gradient buffer that belongs to a layer is all-reduced
         # on the side stream as soon as that layer's backward has been enqueued, i.e. under the backward of the layers below it
         self._reduced = []                         # [start, end) ranges already summed across ranks in this step
@@ -99,7 +100,9 @@ class ContrastiveTrainer:
         loss = losses["loss"]
         if world > 1 and "quantity_loss" in losses:
             loss = loss - model.quantity_loss_weight * losses["quantity_loss"] * (1.0 - 1.0 / world)
-        loss.backward()
+        if self._one is None or self._one.device != loss.device:
+            self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        loss.backward(gradient=self._one)               # (a cached 1: no fill launch per step)
         lr = self.lr_at(model.global_step)
         if self.side is None:
             self._finish(lr)

@@ -53,9 +53,7 @@ class _WeightedSumFn(torch.autograd.Function):
     def backward(ctx, g):
         h, w_soft = ctx.saved_tensors
         B, R, D, normalize = ctx.dims
-        d_soft = ops.wsum_bwd(h, g.float().contiguous(), B, R, D, 0, normalize=normalize)
-        dw = w_soft * (d_soft - (w_soft * d_soft).sum())
-        return dw, None, None, None, None, None
+        return ops.wsum_bwd_logits(h, g.float().contiguous(), w_soft, B, R, D, 0, normalize=normalize), None, None, None, None, None
 
 
 class _WeightedSumSrcFn(torch.autograd.Function):
@@ -82,8 +80,8 @@ class _WeightedSumSrcFn(torch.autograd.Function):
         if ctx.plan is not None and ctx.plan.generation != ctx.generation:
             raise RuntimeError("the encoder ran another forward with the same batch geometry before this backward (its resident "
                                "hidden states were overwritten): one outstanding forward per (B, L) plan")
-        d_soft = ops.wsum_bwd(hidden, g.float().contiguous(), B, R, D, 1, normalize=normalize, lazy=ctx.lazy)
-        return w_soft * (d_soft - (w_soft * d_soft).sum()), None, None, None, None, None, None
+        return (ops.wsum_bwd_logits(hidden, g.float().contiguous(), w_soft, B, R, D, 1, normalize=normalize, lazy=ctx.lazy),
+                None, None, None, None, None, None)
 
 
 class WeightedSumLayer(nn.Module):

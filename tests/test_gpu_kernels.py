@@ -1079,3 +1079,98 @@ def test_gemm_layernorm_folding(dev, tile):
     # the 128-row tile family has no LayerNorm folding: asking for it there is an error, not a silent plain GEMM
     with pytest.raises(RuntimeError):
         ops.gemm_raw(C0, D, W1f, D, Y, F_, M, F_, D, bias=cvec, tile=1, ln_stats=st0, ln_ns=ns0, ln_colsum=colsum, ln_eps=1e-5)
+
+
+def test_rowtail_ops(dev):
+    """csrc/rowtail.hip (round 3: the head's B-row tail in ~40 launches): the skinny fp32 MFMA GEMM in all its forms - split slices
+    consumed by the next op, sliced A operand with row-scaled bias, epilogue (bias, GELU with kept pre-activation, hash dropout,
+    accumulate), weight-gradient form with the bias gradient as a by-product, batched per-head forms - LayerNorm forward / backward
+    over slices (single and chained, dropout, residual), the elementwise op and the unit-row op, against fp64 torch."""
+    import numpy as np
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(321)
+    R = lambda *s: torch.randn(*s, generator=g)
+    B, D, F_, E, H = 50, 384, 640, 72, 4            # awkward sizes on purpose (tails everywhere)
+    dh = D // H
+    x, W, b = R(B, D).to(dev), (R(F_, D) * D ** -0.5).to(dev), R(F_).to(dev)
+    d64 = lambda t: t.double().cpu()
+    rel_l2 = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / (b.double().cpu().norm() + 1e-30))
+    # split product + elementwise consumer (GELU + dropout)
+    ys = ops.rt_gemm(x, W, B, F_, D, split=True)
+    assert ys.ns > 1
+    ref = d64(x) @ d64(W).T
+    assert rel_l2(ys.total(), ref) < 1e-6
+    u, f = ops.rt_elem(ys, 1, bias=b, drop_p=0.25, drop_seed=99)
+    keep = torch.from_numpy(_keep_mask(np.arange(B * F_, dtype=np.int64), 99, 0.25)).view(B, F_)
+    assert rel_l2(u, ref + d64(b)) < 1e-6
+    assert rel_l2(f, torch.where(keep, F.gelu(ref + d64(b)) / 0.75, torch.zeros(()).double())) < 1e-6
+    # un-split epilogue: alpha, bias, GELU with U, dropout, beta
+    C0 = R(B, F_).to(dev)
+    C = C0.clone()
+    U = torch.empty_like(C)
+    ops.rt_gemm(x, W, B, F_, D, out=C, alpha=0.5, beta=2.0, bias=b, act=1, U=U, drop_p=0.25, drop_seed=99)
+    pre = 0.5 * ref + d64(b)
+    assert rel_l2(U, pre) < 1e-6
+    assert rel_l2(C, torch.where(keep, F.gelu(pre) / 0.75, torch.zeros(()).double()) + 2 * d64(C0)) < 1e-6
+    # sliced A with row-scaled bias, K-major B (the dgrad form): z = (sum_s ys + b * rs) W
+    rs = R(B, 10).to(dev)                                   # group = F_ / 10 = 64
+    zs = ops.rt_gemm(ys, W, B, D, F_, a_bias=b, a_rowscale=rs, a_group=64, b_kmajor=True, ldb=D, split=True)
+    a_full = ref + d64(b)[None, :] * d64(rs).repeat_interleave(64, dim=1)
+    assert rel_l2(zs.total(), a_full @ d64(W)) < 1e-6
+    assert rel_l2(ops.rt_elem(ys, 0, bias=b, rowscale=rs, group=64), a_full) < 1e-6
+    # weight-gradient form with bias gradient, accumulating
+    dy = R(B, F_).to(dev)
+    gW0, gb0 = R(F_, D).to(dev), R(F_).to(dev)
+    gW, gb = gW0.clone(), gb0.clone()
+    ops.rt_gemm(dy, x, F_, D, B, a_kmajor=True, b_kmajor=True, lda=F_, ldb=D, out=gW, beta=1.0, gb=gb)
+    assert rel_l2(gW, d64(gW0) + d64(dy).T @ d64(x)) < 1e-6 and rel_l2(gb, d64(gb0) + d64(dy).sum(0)) < 1e-6
+    # per-head batched forms: ctx_h = m_h Wv_h^T (split), dWv_h += dctx_h^T m_h with bias gradient, dm_h = dctx_h Wv_h
+    m, Wv = R(B, H, D).to(dev), (R(D, D) * D ** -0.5).to(dev)
+    cs = ops.rt_gemm(m, Wv, B, dh, D, nbatch=H, lda=H * D, a_z=D, ldb=D, b_z=dh * D, split=True, ldc=D, c_z=dh)
+    ref_c = torch.einsum("bhk,hjk->bhj", d64(m), d64(Wv).view(H, dh, D)).reshape(B, D)
+    assert rel_l2(cs.total(), ref_c) < 1e-6
+    dc = R(B, D).to(dev)
+    gWv, gbv = torch.zeros(D, D, device=dev), torch.zeros(D, device=dev)
+    ops.rt_gemm(dc, m, dh, D, B, a_kmajor=True, b_kmajor=True, lda=D, ldb=H * D, nbatch=H, a_z=dh, b_z=D, out=gWv, ldc=D, c_z=dh * D,
+                beta=1.0, gb=gbv, gb_z=dh)
+    assert rel_l2(gWv, torch.einsum("bhj,bhk->hjk", d64(dc).view(B, H, dh), d64(m)).reshape(D, D)) < 1e-6
+    assert rel_l2(gbv, d64(dc).sum(0)) < 1e-6
+    dm = torch.empty(B, H, D, device=dev)
+    ops.rt_gemm(dc, Wv, B, D, dh, nbatch=H, lda=D, a_z=dh, b_kmajor=True, ldb=D, b_z=dh * D, out=dm, ldc=H * D, c_z=D)
+    assert rel_l2(dm, torch.einsum("bhj,hjk->bhk", d64(dc).view(B, H, dh), d64(Wv).view(H, dh, D))) < 1e-6
+    # LayerNorm over slices: single (broadcast residual, dropout) and chained; backward with add, masked output, parameter gradients
+    g1, b1, g2, b2 = (1 + 0.1 * R(D)).to(dev), (0.1 * R(D)).to(dev), (1 + 0.1 * R(D)).to(dev), (0.1 * R(D)).to(dev)
+    bias_d, res0, resB = R(D).to(dev), R(1, D).to(dev), R(B, D).to(dev)
+    keepD = torch.from_numpy(_keep_mask(np.arange(B * D, dtype=np.int64), 7, 0.1)).view(B, D)
+    z_pre = torch.where(keepD, (zs.total().double().cpu() + d64(bias_d)) / 0.9, torch.zeros(()).double())
+    o1, h1, r1 = ops.rt_ln_fwd(zs, bias_d, res0, 0, g1, b1, 1e-5, drop_p=0.1, drop_seed=7)
+    zr = z_pre + d64(res0)
+    ln = lambda t, gg, bb: F.layer_norm(t, (D,), d64(gg), d64(bb), 1e-5)
+    assert rel_l2(o1, ln(zr, g1, b1)) < 1e-5 and rel_l2(h1, F.layer_norm(zr, (D,), None, None, 1e-5)) < 1e-5
+    o1b, h1b, r1b, o2, h2, r2 = ops.rt_ln_fwd(zs, bias_d, resB, D, g1, b1, 1e-5, g2, b2, 1e-6, drop_p=0.1, drop_seed=7)
+    z2 = (z_pre + d64(resB)).requires_grad_()
+    y1 = ln(z2, g1, b1)
+    y2 = F.layer_norm(y1, (D,), d64(g2), d64(b2), 1e-6)
+    assert rel_l2(o1b, y1) < 1e-5 and rel_l2(o2, y2) < 1e-5
+    dys = ops.Slices(R(3, B, D).to(dev))
+    add = R(B, D).to(dev)
+    dgam, dbet = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    dx, dxm = ops.rt_ln_bwd(dys, add, h1b, g1, r1b, dgam, dbet, want_masked=True, drop_p=0.1, drop_seed=7)
+    gin = d64(dys.total()) + d64(add)
+    g1p, b1p = d64(g1).requires_grad_(), d64(b1).requires_grad_()
+    y1p = F.layer_norm(z2, (D,), g1p, b1p, 1e-5)
+    y1p.backward(gin)
+    assert rel_l2(dx, z2.grad) < 1e-5 and rel_l2(dgam, g1p.grad) < 1e-5 and rel_l2(dbet, b1p.grad) < 1e-5
+    assert rel_l2(dxm, torch.where(keepD, z2.grad / 0.9, torch.zeros(()).double())) < 1e-5
+    # GELU backward over slices, unit rows
+    du = ops.rt_elem(ys, 2, u=u, drop_p=0.25, drop_seed=99)
+    up = (ref + d64(b)).requires_grad_()
+    F.gelu(up).backward(torch.where(keep, ref / 0.75, torch.zeros(()).double()))
+    assert rel_l2(du, up.grad) < 1e-5
+    xo, e, rn = ops.rt_l2norm_fwd(zs, bias_d)
+    xr = (d64(zs.total()) + d64(bias_d)).requires_grad_()
+    er = xr / xr.norm(dim=-1, keepdim=True)
+    assert rel_l2(xo, xr) < 1e-6 and rel_l2(e, er) < 1e-6
+    ge = R(B, D).to(dev)
+    er.backward(d64(ge))
+    assert rel_l2(ops.rt_l2norm_bwd(ge, e, rn), xr.grad) < 1e-5

@@ -17,15 +17,16 @@ def test_library_exports_every_declared_symbol():
     from speechclip_plus_amd import _lib
     header = open(os.path.join(ROOT, "include", "speechclip_hip.h")).read()
     declared = set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", header))
-    declared -= {"sc_gemm_args", "sc_hubert_layer_args"}
+    declared -= {"sc_gemm_args", "sc_hubert_layer_args", "sc_rt_gemm_args", "sc_rt_ln_args", "sc_rt_ln_bwd_args"}
     assert {"sc_gemm_bf16", "sc_attn_fwd_bf16", "sc_infonce_fwd", "sc_cls_pool_fwd"} <= declared
     lib = _lib.lib()                       # raises if the .so is missing (no fallback)
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/speechclip_hip.h but not exported"
-    assert set(_lib.SIGNATURES) | {"sc_last_error", "sc_hash32", "sc_infonce_workspace_floats", "sc_workspace_bytes"} == declared
+    assert set(_lib.SIGNATURES) | {"sc_last_error", "sc_hash32", "sc_infonce_workspace_floats", "sc_workspace_bytes", "sc_sizeof"} == declared
     assert lib.sc_abi_version() == 3
-    # the ctypes mirror of sc_gemm_args must have the C struct's size (8-byte fields, natural alignment; + drop_p, drop_seed; + tap_c, pad)
-    assert ctypes.sizeof(_lib.GemmArgs) == 6 * 8 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 6 * 4 + 10 * 8 + 8 + 8 + 8
+    # the ctypes mirrors of the argument structs have the C structs' sizes (checked again at every load: _lib.lib())
+    for what, cls in enumerate((_lib.GemmArgs, _lib.HubertLayerArgs, _lib.RtGemmArgs, _lib.RtLnArgs, _lib.RtLnBwdArgs)):
+        assert lib.sc_sizeof(what) == ctypes.sizeof(cls), cls.__name__
     # host twin of the kernels' dropout hash (lowbias32): known answers
     assert lib.sc_hash32(0) == 0 and lib.sc_hash32(1) == 0x688990C0
     ref = lambda x: ((((x ^ (x >> 16)) * 0x7feb352d & 0xffffffff) ^ ((((x ^ (x >> 16)) * 0x7feb352d & 0xffffffff)) >> 15)) * 0x846ca68b) & 0xffffffff
