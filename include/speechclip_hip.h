@@ -111,6 +111,8 @@ uint32_t sc_hash32(uint32_t x);   /* host twin of the kernels' dropout hash (low
  *   vt   [B, H, 64, R] bf16 : v transposed per head (written by sc_gemm_bf16's Ct path)
  *   valid_len [B] int32 : keys t >= valid_len[b] are masked (-inf)
  *   out  [B*R, ldo] bf16, columns h*64..h*64+63
+ *   causal (CLIP text tower): 1 = key t visible to query q iff t <= q ; 32 / 64 = causal INSIDE aligned segments of that many
+ *       rows (short sequences packed back to back into one 128-row block attend to their own segment only); same for the backward
  * ---------------------------------------------------------------------------------------------- */
 int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len,
                      sc_bf16* out, int64_t ldo, int32_t B, int32_t R, int32_t H, int32_t D, float scale,
@@ -402,6 +404,17 @@ int sc_infonce_fwd(const float* A, const float* B, int32_t Bg, int32_t E, const 
 int sc_infonce_grad(const float* logits, const int64_t* ids, const float* lse_row, const float* lse_col, int32_t Bg,
                     const float* gscale /*device scalar*/, const float* inv_temp /*device scalar*/, float margin, int32_t dcl,
                     int32_t a2b, int32_t b2a, float* G, float* dlogit_dot /*[Bg]*/, void* stream);
+
+/* CIF weight head (avssl/module/cif.py:106-129: ... Conv1d -> Dropout(0.5) -> ReLU -> Dropout(0.5) -> Linear(C, 1) -> Sigmoid): everything
+ * behind the conv GEMM in one row kernel, forward and backward.  y [rows, C] fp32 = the conv output (bias included), w [C], bias [1]:
+ *   alpha[row] = sigmoid(bias + sum_c w[c] m2 relu(m1 y[row, c]))     m1 / m2: dropout multipliers (p1 / p2, 0 in eval), keep bits =
+ *   sc_dropout_mult_f32's for the seed on the index row * C + c.   backward: dy, and per-block partial sums dw_partial [nblk, C],
+ *   db_partial [nblk] (reduce with sc_colsum_f32). */
+int sc_cif_head_fwd(const float* y, int64_t ldy, const float* w, const float* bias, float* alpha, int32_t rows, int32_t C, float p1,
+                    uint32_t seed1, float p2, uint32_t seed2, void* stream);
+int sc_cif_head_bwd(const float* y, int64_t ldy, const float* w, const float* alpha, const float* dalpha, float* dy, int64_t lddy,
+                    float* dw_partial, float* db_partial, int32_t nblk, int32_t rows, int32_t C, float p1, uint32_t seed1, float p2,
+                    uint32_t seed2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row tail of the parallel head, round 3 (csrc/rowtail.hip): the B-row products of nn.TransformerEncoderLayer + final LayerNorm +

@@ -167,6 +167,9 @@ SIGNATURES = {
     "sc_gelu_f32": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "sc_colsum_f32": [c_void_p, c_i64, c_int, c_int, c_void_p, c_float, c_float, c_void_p],
     "sc_headmask_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_cif_head_fwd": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_float, ctypes.c_uint32, c_void_p],
+    "sc_cif_head_bwd": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                        ctypes.c_uint32, c_float, ctypes.c_uint32, c_void_p],
     "sc_rt_gemm": [ctypes.POINTER(RtGemmArgs), c_void_p],
     "sc_rt_gemm_slices": [c_int, c_int, c_int, c_int],
     "sc_rt_ln_fwd": [ctypes.POINTER(RtLnArgs), c_void_p],

@@ -70,6 +70,29 @@ class _CifFn(torch.autograd.Function):
         return dx.to(ctx.dtypes[0]), da.to(ctx.dtypes[1]), None, None, None
 
 
+class _CifHeadFn(torch.autograd.Function):
+    """Dropout -> ReLU -> Dropout -> Linear(C, 1) -> Sigmoid of the weight generator on sc_cif_head_fwd / _bwd: y [B, S, C] fp32 (the conv
+    output), weight [1, C], bias [1] -> alpha [B, S]."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, p1, seed1, p2, seed2):
+        B, S, C = y.shape
+        w = ops.aligned16(weight.detach().float().reshape(C).contiguous())
+        b = bias.detach().float().reshape(1).contiguous()
+        y2 = y.detach().reshape(B * S, C)
+        alpha = ops.cif_head_fwd(y2, w, b, p1, seed1, p2, seed2)
+        ctx.save_for_backward(y2, w, alpha)
+        ctx.meta = (B, S, C, p1, seed1, p2, seed2, weight.shape)
+        return alpha.view(B, S)
+
+    @staticmethod
+    def backward(ctx, dalpha):
+        y2, w, alpha = ctx.saved_tensors
+        B, S, C, p1, seed1, p2, seed2, wshape = ctx.meta
+        dy, dw, db = ops.cif_head_bwd(y2, w, alpha, dalpha.float().contiguous().view(-1), p1, seed1, p2, seed2)
+        return dy.view(B, S, C), dw.view(wshape), db, None, None, None, None
+
+
 class CIF(nn.Module):
     def __init__(self, cif_threshold=1.0, cif_output_dim=768, encoder_embed_dim=768, produce_weight_type="conv",
                  num_layer=1, conv_cif_width=3, conv_cif_dropout=0.1, apply_scaling=True, apply_tail_handling=True,
@@ -117,8 +140,14 @@ class CIF(nn.Module):
             raise NotImplementedError(f"CIF kernels: at most 2048 frames per utterance and C % 4 == 0 (got S={S}, C={C})")
         if self.scaling_step >= 0 and self.apply_scaling and input_dict["global_step"] >= self.scaling_step:
             self.apply_scaling = False                         # cif.py:110-112: permanent once the step is reached
-        logits = self._weight_conv(feats)
-        alpha_raw = self.weight_proj(logits).float().squeeze(-1)          # sigmoid output; clip / masking: sc_cif_prepare
+        # conv output of the last weight-generator layer; Dropout -> ReLU -> Dropout -> Linear(C, 1) -> Sigmoid in one row kernel
+        # (sigmoid output; clip / masking: sc_cif_prepare)
+        y = self._weight_conv(feats)
+        lin = self.weight_proj[1]
+        p1 = float(self.conv[-2].p) if self.training else 0.0
+        p2 = float(self.weight_proj[0].p) if self.training else 0.0
+        alpha_raw = _CifHeadFn.apply(y.float().contiguous(), lin.weight, lin.bias, p1, ops.next_mult_seed() if p1 > 0 else 0, p2,
+                                     ops.next_mult_seed() if p2 > 0 else 0)
         scaled = bool(self.apply_scaling and target_lengths is not None)
         tail = bool(self.apply_tail_handling and target_lengths is None)
         target = target_lengths.to(device=feats.device, dtype=torch.int64).contiguous() if target_lengths is not None else None
@@ -164,5 +193,7 @@ class CIF(nn.Module):
             xp = torch.nn.functional.pad(x, (0, 0, p, p))                           # (B, T + 2 p, C)
             cols = torch.cat([xp[:, j: j + T + 2 * p - k + 1] for j in range(k)], dim=-1)   # (B, T', k C), tap-major
             w = conv.weight.permute(0, 2, 1).reshape(conv.out_channels, k * C)      # [C_out, k, C_in] flattened tap-major
-            x = act(drop(linear(cols, w, conv.bias)))
+            x = linear(cols, w, conv.bias)
+            if i + 3 < len(self.conv):                                              # not the last layer: its Dropout / ReLU follow here;
+                x = act(drop(x))                                                    # the last layer's are part of the weight-head kernel
         return x

@@ -185,7 +185,11 @@ class ClipModel(nn.Module):
         else:
             x = torch.cat([x[:, :1], keywords, x[:, 1 + keyword_num:]], dim=1)
         x = x + self.model.positional_embedding
-        x = self._transformer(x)
+        # the tower is causal and only the end-of-text row is read below: positions behind the LAST end-of-text token of the batch
+        # cannot influence any output.  keywords.shape[1] is the batch's largest keyword count (sized on the host), so the prefix
+        # [SOT, kw_1 .. kw_N, EOT] = N + 2 positions is all the transformer needs to see (clip_text_hip packs it densely).
+        n_pos = min(CONTEXT_LEN, (keywords.shape[1] if index is not None else int(keyword_num)) + 2)
+        x = self._transformer(x[:, :n_pos])
         # LayerNorm is per row: only the end-of-text row of every sample goes through ln_final and the projection
         rows = x[torch.arange(bsz, device=dev), index] if index is not None else x[:, 1 + keyword_num]
         ln = self.model.ln_final

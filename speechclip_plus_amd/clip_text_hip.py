@@ -2,8 +2,12 @@
 
 The cascaded branches push the keyword embeddings THROUGH the frozen text tower (avssl/module/clip_official.py:222-279 ->
 openai/CLIP ``Transformer``: pre-LN residual blocks, causal nn.MultiheadAttention with head_dim 64, QuickGELU MLP), so a
-train step needs the tower's forward and its input gradient but no weight gradient.  Per layer, on ``B * 128`` padded rows
-(77 tokens per sample, rows 77..127 scratch that stay finite and carry zero gradient):
+train step needs the tower's forward and its input gradient but no weight gradient.  Per layer, on ``B * SEG`` rows, SEG = 32 / 64 /
+128 = the prompt length T rounded up (rows T..SEG-1 scratch that stay finite and carry zero gradient).  The tower is CAUSAL and
+only the end-of-text row is read, so ``encode_keywords`` hands over the prompt PREFIX up to the last end-of-text position only
+(2 + the batch's largest keyword count, ~27 tokens for 10 s utterances instead of 77): with SEG < 128 the sequences lie back to
+back, 128 / SEG to an attention block, and the attention kernels mask causally inside aligned segments (``causal = SEG``) - the
+GEMMs, LayerNorms and activations then run on B * SEG dense rows instead of B * 128:
 
     forward   LN -> QKV GEMM -> causal attention (+ LSE) -> out-proj GEMM (+ residual) -> LN -> FC GEMM -> QuickGELU
               -> proj GEMM (+ residual)
@@ -20,7 +24,14 @@ import torch
 
 from . import ops
 
-ROWS = 128          # padded rows per sample (CONTEXT_LEN = 77 -> one 128-row attention block)
+BLOCK = 128         # rows of an attention block
+
+
+def _segment(T: int) -> int:
+    """rows per sample: the prompt length rounded up to 32 / 64 / 128"""
+    if T > BLOCK:
+        raise ValueError(f"text tower: {T} tokens (at most {BLOCK})")
+    return 32 if T <= 32 else 64 if T <= 64 else 128
 
 
 class _LayerW:
@@ -51,20 +62,25 @@ class TextTowerFn(torch.autograd.Function):
     def forward(ctx, x, weights, heads):
         B, T, W = x.shape
         dev = x.device
-        M = B * ROWS
-        X = torch.zeros(B, ROWS, W, device=dev, dtype=torch.bfloat16)
-        X[:, :T] = x.detach().to(torch.bfloat16)
+        SEG = _segment(T)
+        per = BLOCK // SEG                                   # sequences per attention block
+        Bp = -(-B // per) * per                              # padded up to whole blocks (pad sequences: zeros)
+        M = Bp * SEG
+        NB = M // BLOCK
+        causal = 1 if SEG == BLOCK else SEG
+        X = torch.zeros(Bp, SEG, W, device=dev, dtype=torch.bfloat16)
+        X[:B, :T] = x.detach().to(torch.bfloat16)
         X = X.view(M, W)
-        valid = torch.full((B,), T, device=dev, dtype=torch.int32)
+        valid = torch.full((NB,), BLOCK, device=dev, dtype=torch.int32)
         scale = (W // heads) ** -0.5
         saved = []
         for w in weights:
             h = ops.layernorm_bf16(X, w.g1, w.be1, eps=w.eps1)
             qkv = ops.linear_bf16(h, w.wqkv, w.bqkv)
-            vt = ops.head_transpose(qkv[:, 2 * W:], B, ROWS, heads)
+            vt = ops.head_transpose(qkv[:, 2 * W:], NB, BLOCK, heads)
             att = torch.empty(M, W, device=dev, dtype=torch.bfloat16)
-            lse2 = torch.empty(B, heads, ROWS, device=dev, dtype=torch.float32)
-            ops.attn_fwd(qkv[:, : 2 * W], vt, valid, att, B, ROWS, heads, W, scale, lse2=lse2, causal=True)
+            lse2 = torch.empty(NB, heads, BLOCK, device=dev, dtype=torch.float32)
+            ops.attn_fwd(qkv[:, : 2 * W], vt, valid, att, NB, BLOCK, heads, W, scale, lse2=lse2, causal=causal)
             X2 = ops.linear_bf16(att, w.wo, w.bo, residual=X)
             h2 = ops.layernorm_bf16(X2, w.g2, w.be2, eps=w.eps2)
             u = ops.linear_bf16(h2, w.w1, w.b1)
@@ -72,16 +88,17 @@ class TextTowerFn(torch.autograd.Function):
             Xn = ops.linear_bf16(f, w.w2, w.b2, residual=X2)
             saved.append((X, qkv, att, lse2, X2, u))
             X = Xn
-        ctx.weights, ctx.saved, ctx.valid, ctx.dims = weights, saved, valid, (B, T, W, heads, scale)
-        return X.view(B, ROWS, W)[:, :T].float()
+        ctx.weights, ctx.saved, ctx.valid, ctx.dims = weights, saved, valid, (B, T, W, heads, scale, SEG, Bp, causal)
+        return X.view(Bp, SEG, W)[:B, :T].float()
 
     @staticmethod
     def backward(ctx, dy):
-        B, T, W, heads, scale = ctx.dims
+        B, T, W, heads, scale, SEG, Bp, causal = ctx.dims
         dev = dy.device
-        M = B * ROWS
-        dX = torch.zeros(B, ROWS, W, device=dev, dtype=torch.bfloat16)
-        dX[:, :T] = dy.to(torch.bfloat16)
+        M = Bp * SEG
+        NB = M // BLOCK
+        dX = torch.zeros(Bp, SEG, W, device=dev, dtype=torch.bfloat16)
+        dX[:B, :T] = dy.to(torch.bfloat16)
         dX = dX.view(M, W)
         for w, (X, qkv, att, lse2, X2, u) in zip(reversed(ctx.weights), reversed(ctx.saved)):
             df = ops.linear_bf16(dX, w.w2T)
@@ -91,8 +108,8 @@ class TextTowerFn(torch.autograd.Function):
             datt = ops.linear_bf16(dX2, w.woT)
             dqkv = torch.empty(M, 3 * W, device=dev, dtype=torch.bfloat16)
             ops.attn_bwd(qkv[:, :W], qkv[:, W: 2 * W], qkv[:, 2 * W:], att, datt, lse2, ctx.valid, dqkv[:, :W], dqkv[:, W: 2 * W],
-                         dqkv[:, 2 * W:], B, ROWS, heads, scale, causal=True, q_rows=T)
+                         dqkv[:, 2 * W:], NB, BLOCK, heads, scale, causal=causal, q_rows=BLOCK if SEG < BLOCK else T)
             dh1 = ops.linear_bf16(dqkv, w.wqkvT)
             dX = ops.layernorm_bwd(X, dh1, w.g1, w.eps1, dres=dX2)
         ctx.saved = None
-        return dX.view(B, ROWS, W)[:, :T].float(), None, None
+        return dX.view(Bp, SEG, W)[:B, :T].float(), None, None

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -1e30f, l_run = 0.f;        // finite floor: a key block may be fully masked for a query (segment-causal packing)
 
     const int qrow = q0 + l31;                                       // this lane's query
     // attention-probability dropout (fairseq attention_dropout, train mode): P' = mask . P / (1 - p) with the row sum taken
@@ -115,11 +115,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
             }
         }
         auto softmax_block = [&](f32x16& sv, int kbase, bf16x8 (&pf)[2]) {
-            if (kbase + 32 > n_valid || (causal && kbase + 31 > q0)) {
+            // causal > 1: causal inside aligned segments of `causal` rows (32 / 64) - short sequences packed back to back into one
+            // 128-row block attend to their own segment only
+            if (kbase + 32 > n_valid || (causal && kbase + 31 > q0) || causal > 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kidx = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (kidx >= n_valid || (causal && kidx > qrow)) sv[r] = -INFINITY;
+                    if (kidx >= n_valid || (causal && kidx > qrow) || (causal > 1 && kidx < (qrow & ~(causal - 1)))) sv[r] = -INFINITY;
                 }
             }
             float mloc = sv[0];
@@ -232,6 +234,7 @@ extern "C" int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* 
     SC_CHECK(qk && vt && valid_len && out, "sc_attn_fwd_bf16: null pointer");
     SC_CHECK(B > 0 && H > 0 && R > 0 && R % 128 == 0, "sc_attn_fwd_bf16: R=%d must be a positive multiple of 128", R);
     SC_CHECK(D == H * 64, "sc_attn_fwd_bf16: head_dim must be 64 (D=%d, H=%d)", D, H);
+    SC_CHECK(causal == 0 || causal == 1 || causal == 32 || causal == 64, "sc_attn_fwd_bf16: causal=%d (0, 1, or a segment of 32 / 64 rows)", causal);
     SC_CHECK(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || (int64_t)B * H * R * R < ((int64_t)1 << 32)),
              "sc_attn_fwd_bf16: drop_p=%f (needs B*H*R*R < 2^32)", (double)drop_p);
     SC_CHECK(ldqk % 8 == 0 && ldo % 4 == 0 && ldqk >= 2 * D && ldo >= D, "sc_attn_fwd_bf16: bad leading dims");

@@ -1,4 +1,5 @@
-// Self-attention backward for gfx950, head_dim 64 (flash style, key padding by length, optional causal mask).
+// Self-attention backward for gfx950, head_dim 64 (flash style, key padding by length, optional causal mask; causal = 32 / 64:
+// causal inside aligned segments of that many rows - several short sequences packed into one 128-row block, see sc_attn_fwd_bf16).
 //
 // Same operand discipline as attention.hip: v_mfma_f32_32x32x16_bf16, every product arranged so that the accumulator of
 // one MFMA is, converted to bf16, the B operand of the next (no LDS round trip, no lane movement), which works when the next
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bwd_args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kidx = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const bool ok = kidx < n_valid && !(p.causal && kidx > qrow);
+                const bool ok = kidx < n_valid && !(p.causal && kidx > qrow) && !(p.causal > 1 && kidx < (qrow & ~(p.causal - 1)));
                 const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse)) : 0.f;
                 ds[r] = pr * (dp[r] - dl);
             }
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e, qidx = qt0 + ql + e;
-                    const bool ok = key_ok && !(p.causal && krow > qidx);
+                    const bool ok = key_ok && !(p.causal && krow > qidx) && !(p.causal > 1 && krow < (qidx & ~(p.causal - 1)));
                     const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e])) : 0.f;
                     if (DROP) {                                        // this lane's key, query qidx: one hash word per element
                         const uint32_t idx = (uint32_t)((b * H + h) * R + qidx) * (uint32_t)R + (uint32_t)krow;

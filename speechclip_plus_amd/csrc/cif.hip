@@ -321,6 +321,81 @@ __global__ __launch_bounds__(256) void cif_tail_kernel(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------ weight head (cif.py:106-129)
+// The reference's weight generator ends  Conv1d -> Dropout(0.5) -> ReLU -> Dropout(0.5) -> Linear(C, 1) -> Sigmoid.  Everything behind
+// the conv GEMM is one row kernel here (was: two dropout launches, a ReLU, a vendor GEMV, a sigmoid and casts, forward and backward):
+//   alpha[row] = sigmoid(b + sum_c w[c] m2(row, c) relu(m1(row, c) y[row, c]))
+// m1 / m2 = hash dropout multipliers (0 or 1 / (1 - p); keep bits = sc_keep8 on row * C + c, the library's stateless masks), p = 0 in eval.
+struct CifHead {
+    const float* y; int64_t ldy; const float* w; const float* bias; int rows, C;
+    float sc1, sc2; uint32_t thr1, thr2, seed1, seed2;
+};
+__device__ __forceinline__ f32x4 cif_head_mult(uint32_t idx, uint32_t seed, uint32_t thr, float sc) {      // idx % 4 == 0
+    if (!thr) return f32x4{1.f, 1.f, 1.f, 1.f};
+    const uint32_t k = sc_keep8(idx & ~7u, seed, thr) >> (idx & 4u);
+    return f32x4{(k & 1u) ? sc : 0.f, (k & 2u) ? sc : 0.f, (k & 4u) ? sc : 0.f, (k & 8u) ? sc : 0.f};
+}
+
+__global__ __launch_bounds__(256) void cif_head_fwd_kernel(const CifHead p, float* __restrict__ alpha) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= p.rows) return;
+    const float* yr = p.y + (int64_t)row * p.ldy;
+    float s = 0.f;
+    for (int c = lane * 4; c < p.C; c += 256) {
+        const f32x4 yv = *(const f32x4*)(yr + c), wv = *(const f32x4*)(p.w + c);
+        const uint32_t idx = (uint32_t)row * (uint32_t)p.C + (uint32_t)c;
+        const f32x4 m1 = cif_head_mult(idx, p.seed1, p.thr1, p.sc1), m2 = cif_head_mult(idx, p.seed2, p.thr2, p.sc2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += wv[e] * m2[e] * fmaxf(m1[e] * yv[e], 0.f);
+    }
+    s = wave_sum(s);
+    if (lane == 0) alpha[row] = 1.f / (1.f + __expf(-(s + p.bias[0])));
+}
+
+// g = dalpha a (1 - a) ; dy[row, c] = g w[c] m2 m1 [y > 0] ; dw_partial[blk][c] = sum over the block's rows of g m2 relu(m1 y) ;
+// db_partial[blk] = sum g     (rows blk * 4 + wave, + 4 gridDim.x, ... ; partials reduced in order by sc_colsum_f32)
+__global__ __launch_bounds__(256) void cif_head_bwd_kernel(const CifHead p, const float* __restrict__ alpha, const float* __restrict__ dalpha,
+                                                           float* __restrict__ dy, int64_t lddy, float* __restrict__ dw_partial,
+                                                           float* __restrict__ db_partial) {
+    __shared__ float red[4][1024];
+    __shared__ float redb[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x4 dw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < p.rows; row += 4 * gridDim.x) {
+        const float a = alpha[row];
+        const float g = dalpha[row] * a * (1.f - a);
+        db += g;
+        const float* yr = p.y + (int64_t)row * p.ldy;
+        float* dr = dy + (int64_t)row * lddy;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c >= p.C) break;
+            const f32x4 yv = *(const f32x4*)(yr + c), wv = *(const f32x4*)(p.w + c);
+            const uint32_t idx = (uint32_t)row * (uint32_t)p.C + (uint32_t)c;
+            const f32x4 m1 = cif_head_mult(idx, p.seed1, p.thr1, p.sc1), m2 = cif_head_mult(idx, p.seed2, p.thr2, p.sc2);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h = fmaxf(m1[e] * yv[e], 0.f);
+                dw[i][e] += g * m2[e] * h;
+                o[e] = h > 0.f ? g * wv[e] * m2[e] * m1[e] : 0.f;
+            }
+            *(f32x4*)(dr + c) = o;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)&red[wave][lane * 4 + i * 256] = dw[i];
+    if (lane == 0) redb[wave] = db;              // every lane of the wave carries the same per-row g: no wave reduction
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.C; c += 256)
+        dw_partial[(int64_t)blockIdx.x * p.C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (threadIdx.x == 0) db_partial[blockIdx.x] = (redb[0] + redb[1]) + (redb[2] + redb[3]);
+}
+
 }  // namespace
 
 extern "C" int sc_cif_fwd(const float* x, const float* alpha, const float* csum, float* out, int32_t B, int32_t S, int32_t C, int32_t T,
@@ -374,6 +449,38 @@ extern "C" int sc_cif_tail(const float* alpha, const float* csum, int32_t B, int
     SC_CHECK(B > 0 && S > 0 && C > 0 && T >= 0 && thr > 0.f, "sc_cif_tail: bad arguments");
     hipLaunchKernelGGL(cif_tail_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, alpha, csum, S, C, T, thr, tail_thr, max_feat, feat_len,
                        out, factor, extend);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+static CifHead cif_head_args(const float* y, int64_t ldy, const float* w, const float* bias, int32_t rows, int32_t C, float p1, uint32_t seed1,
+                             float p2, uint32_t seed2) {
+    CifHead a;
+    a.y = y; a.ldy = ldy; a.w = w; a.bias = bias; a.rows = rows; a.C = C;
+    a.thr1 = p1 > 0.f ? (uint32_t)(p1 * 65536.f + 0.5f) : 0u; a.sc1 = p1 > 0.f ? 1.f / (1.f - p1) : 1.f; a.seed1 = seed1;
+    a.thr2 = p2 > 0.f ? (uint32_t)(p2 * 65536.f + 0.5f) : 0u; a.sc2 = p2 > 0.f ? 1.f / (1.f - p2) : 1.f; a.seed2 = seed2;
+    return a;
+}
+
+extern "C" int sc_cif_head_fwd(const float* y, int64_t ldy, const float* w, const float* bias, float* alpha, int32_t rows, int32_t C, float p1,
+                               uint32_t seed1, float p2, uint32_t seed2, void* stream) {
+    SC_CHECK(y && w && bias && alpha && rows > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldy % 4 == 0, "sc_cif_head_fwd: C=%d (%% 4, <= 1024)", C);
+    SC_CHECK(((uintptr_t)y % 16) == 0 && ((uintptr_t)w % 16) == 0 && (int64_t)rows * C < ((int64_t)1 << 32) && p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f,
+             "sc_cif_head_fwd: alignment / size / p");
+    const CifHead a = cif_head_args(y, ldy, w, bias, rows, C, p1, seed1, p2, seed2);
+    hipLaunchKernelGGL(cif_head_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, alpha);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_cif_head_bwd(const float* y, int64_t ldy, const float* w, const float* alpha, const float* dalpha, float* dy, int64_t lddy,
+                               float* dw_partial, float* db_partial, int32_t nblk, int32_t rows, int32_t C, float p1, uint32_t seed1, float p2,
+                               uint32_t seed2, void* stream) {
+    SC_CHECK(y && w && alpha && dalpha && dy && dw_partial && db_partial && nblk > 0 && rows > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+             "sc_cif_head_bwd: bad args (C=%d)", C);
+    SC_CHECK(ldy % 4 == 0 && lddy % 4 == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)w % 16) == 0, "sc_cif_head_bwd: alignment");
+    const CifHead a = cif_head_args(y, ldy, w, nullptr, rows, C, p1, seed1, p2, seed2);
+    hipLaunchKernelGGL(cif_head_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a, alpha, dalpha, dy, lddy, dw_partial, db_partial);
     SC_LAUNCH_CHECK();
     return 0;
 }

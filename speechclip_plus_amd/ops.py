@@ -945,3 +945,28 @@ def wsum_bwd_logits(h: torch.Tensor, g: torch.Tensor, w_soft: torch.Tensor, B: i
     out = torch.empty(NL, device=h.device, dtype=torch.float32)
     check(lib().sc_rt_softmax_bwd_reduce(_p(part), nblk, NL, _p(w_soft), _p(out), _stream()), "sc_rt_softmax_bwd_reduce")
     return out
+
+
+def cif_head_fwd(y: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, p1: float, seed1: int, p2: float, seed2: int) -> torch.Tensor:
+    """alpha [rows] = sigmoid(bias + sum_c w[c] m2 relu(m1 y[row, c]))  (sc_cif_head_fwd; y [rows, C] fp32 contiguous)"""
+    rows, C = y.shape
+    alpha = torch.empty(rows, device=y.device, dtype=torch.float32)
+    check(lib().sc_cif_head_fwd(_p(y), y.stride(0), _p(w), _p(bias), _p(alpha), rows, C, float(p1), int(seed1) & 0xffffffff, float(p2),
+                                int(seed2) & 0xffffffff, _stream()), "sc_cif_head_fwd")
+    return alpha
+
+
+def cif_head_bwd(y: torch.Tensor, w: torch.Tensor, alpha: torch.Tensor, dalpha: torch.Tensor, p1: float, seed1: int, p2: float, seed2: int,
+                 nblk: int = 512):
+    """-> dy [rows, C], dw [C], db [1]"""
+    rows, C = y.shape
+    dy = torch.empty_like(y)
+    pw = torch.empty(nblk, C, device=y.device, dtype=torch.float32)
+    pb = torch.empty(nblk, device=y.device, dtype=torch.float32)
+    check(lib().sc_cif_head_bwd(_p(y), y.stride(0), _p(w), _p(alpha), _p(dalpha), _p(dy), dy.stride(0), _p(pw), _p(pb), nblk, rows, C, float(p1),
+                                int(seed1) & 0xffffffff, float(p2), int(seed2) & 0xffffffff, _stream()), "sc_cif_head_bwd")
+    dw = torch.empty(C, device=y.device, dtype=torch.float32)
+    db = torch.empty(1, device=y.device, dtype=torch.float32)
+    colsum(pw, C, nblk, C, dw)
+    colsum(pb.view(nblk, 1), 1, nblk, 1, db)
+    return dy, dw, db

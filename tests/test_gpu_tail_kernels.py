@@ -268,3 +268,31 @@ def test_cif_prepare_guards_all_zero_weights_and_clamps_to_the_allocated_slots()
     assert float(r["alpha"][1].abs().sum()) == 0.0 and float(r["ratio"][1]) == 0.0
     assert flags[0].item() == 2                            # two utterances with a positive weight sum
     assert flags[1].item() == 2                            # utterance 1 (1 != 3) and utterance 2 (6 != 9) disagree with their targets
+
+
+@pytest.mark.parametrize("p1,p2", [(0.0, 0.0), (0.5, 0.5)])
+def test_cif_weight_head_kernel(p1, p2):
+    """sc_cif_head_fwd / _bwd (Dropout -> ReLU -> Dropout -> Linear(C, 1) -> Sigmoid behind the weight-generator conv, cif.py:106-129, in
+    one row kernel each way) against torch autograd in fp64 with the same hash masks reconstructed on the host."""
+    import numpy as np
+    from speechclip_plus_amd import ops
+    from test_gpu_kernels import _keep_mask
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    rows, C = 777, 768
+    y = torch.randn(rows, C, generator=g)
+    w = torch.randn(C, generator=g) * C ** -0.5
+    b = torch.tensor([0.3])
+    da = torch.randn(rows, generator=g)
+    s1, s2 = 1234, 98765
+    alpha = ops.cif_head_fwd(y.to(dev), w.to(dev), b.to(dev), p1, s1, p2, s2)
+    idx = np.arange(rows * C, dtype=np.int64)
+    m1 = torch.from_numpy(_keep_mask(idx, s1, p1)).view(rows, C).double() / (1 - p1) if p1 > 0 else torch.ones(rows, C).double()
+    m2 = torch.from_numpy(_keep_mask(idx, s2, p2)).view(rows, C).double() / (1 - p2) if p2 > 0 else torch.ones(rows, C).double()
+    yd, wd, bd = y.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    ref = torch.sigmoid((torch.relu(yd * m1) * m2) @ wd + bd)
+    rel = lambda a, r: float((a.double().cpu() - r.double()).norm() / (r.double().norm() + 1e-30))
+    assert rel(alpha, ref.detach()) < 1e-5
+    ref.backward(da.double())
+    dy, dw, db = ops.cif_head_bwd(y.to(dev), w.to(dev), alpha, da.to(dev), p1, s1, p2, s2)
+    assert rel(dy, yd.grad) < 1e-5 and rel(dw, wd.grad) < 1e-5 and rel(db, bd.grad) < 1e-4      # (db: a cancelling fp32 sum over the rows)
