@@ -209,3 +209,88 @@ def test_cascaded_plus_full_size_properties():
     assert fl["count_mismatches"] == 0 and fl["positive_utterances"] >= B, fl
     torch.cuda.synchronize()
     assert torch.isfinite(trainer.opt.flat_g).all() and float(trainer.opt.flat_g.abs().sum()) > 0
+
+
+def test_hybrid_plus_large_full_size_properties():
+    """BASELINE configs[4] on one GPU at FULL size (HuBERT-large: 24 pre-LN layers, D = 1024; B = 64 x 10 s; ViT-L/14 text tower, 12
+    layers; coco-sized vocabulary): inference path - both embeddings, keyword counts and tokens of every utterance are independent of
+    its row in the batch and of junk beyond wav_len - then one train step (both InfoNCE terms + quantity loss through the flat-Adam
+    trainer): the loss is finite and does not go up on the same batch, the CIF output was sized from the host-side targets without a
+    count mismatch, every trainable parameter received a finite gradient.  """
+    from speechclip_plus_amd import KWClip_GeneralTransformer, hybrid_plus_large_config, set_dropout
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    torch.manual_seed(7122)
+    cfg = hybrid_plus_large_config()
+    cfg.audio_encoder.max_audio_len = -1
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0").eval()
+    assert model.audio_encoder.arch.layers == 24 and model.audio_encoder.arch.embed_dim == 1024
+    B, L, E = 64, 160000, int(cfg.clip.embed_dim)
+    g = torch.Generator().manual_seed(4)
+    wav = torch.randn(B, L, generator=g)
+    lens = torch.randint(32000, L + 1, (B,), generator=g)
+    lens[0] = L
+    wav = wav * (torch.arange(L)[None] < lens[:, None])
+    img = F.normalize(torch.randn(B, E, generator=g), dim=-1)
+    ids = torch.arange(B) // 5
+    batch = {"wav": wav.cuda(), "wav_len": lens, "image": img.cuda(), "id": ids.cuda()}
+    with torch.no_grad():
+        _, _, o1 = model(batch)
+        ec, ep = o1["cascaded_audio_feat"].clone(), o1["parallel_audio_feat"].clone()
+        n1, t1 = o1["keywords_len"].clone(), o1["vq_results"]["targets"].clone()
+        assert ec.shape == (B, E) and ep.shape == (B, E) and torch.isfinite(ec).all() and torch.isfinite(ep).all()
+        perm = torch.cat([torch.tensor([0]), 1 + torch.randperm(B - 1, generator=g)])
+        pc = perm.cuda()
+        _, _, o2 = model({"wav": batch["wav"][pc], "wav_len": lens[perm], "image": batch["image"][pc], "id": batch["id"][pc]})
+        assert torch.equal(o2["keywords_len"], n1[pc]) and torch.equal(o2["vq_results"]["targets"], t1[pc])
+        assert torch.equal(o2["parallel_audio_feat"], ep[pc]) and torch.equal(o2["cascaded_audio_feat"], ec[pc])
+        wav3 = batch["wav"].clone()
+        for b in range(1, B):
+            wav3[b, int(lens[b]):] = 3.0
+        _, _, o3 = model({**batch, "wav": wav3})
+        assert torch.equal(o3["cascaded_audio_feat"], ec) and torch.equal(o3["parallel_audio_feat"], ep) and torch.equal(o3["keywords_len"], n1)
+    set_dropout(model.train(), False)
+    trainer = ContrastiveTrainer(model)
+    l1 = float(trainer.step(batch))
+    l2 = float(trainer.step(batch))
+    assert l1 == l1 and l2 == l2 and l2 < l1 + 0.05, (l1, l2)
+    fl = model.cascaded_branch.downsampling.check_flags()
+    assert fl["count_mismatches"] == 0 and fl["positive_utterances"] >= B, fl
+    torch.cuda.synchronize()
+    assert torch.isfinite(trainer.opt.flat_g).all() and float(trainer.opt.flat_g.abs().sum()) > 0
+
+
+def test_cascaded_plus_full_size_train_step_with_dropout():
+    """BASELINE configs[2] at full size as the reference TRAINS it: every dropout site live (HuBERT p = 0.1 inside the frozen encoder,
+    the branch's attention block, the p = 0.5 pair of the CIF weight generator - all stateless hash masks).  Three steps on one batch:
+    finite losses, the keyword counts still pinned to the host-side targets (the target-length scaling makes them independent of the
+    masks), finite gradients; and the masks are a function of torch's seed and the call counters only: the same three steps from the
+    same state give bit-identical losses."""
+    import copy
+    from speechclip_plus_amd import KWClip_GeneralTransformer, cascaded_plus_base_config, mha_block, ops
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    B, L = 64, 160000
+    g = torch.Generator().manual_seed(5)
+    wav = torch.randn(B, L, generator=g)
+    lens = torch.randint(32000, L + 1, (B,), generator=g)
+    lens[0] = L
+    wav = wav * (torch.arange(L)[None] < lens[:, None])
+    batch = {"wav": wav.cuda(), "wav_len": lens, "image": F.normalize(torch.randn(B, 512, generator=g), dim=-1).cuda(),
+             "id": (torch.arange(B) // 5).cuda()}
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(7122)
+        ops._mult_calls[0] = 0
+        mha_block._calls = 0
+        cfg = cascaded_plus_base_config()
+        cfg.audio_encoder.max_audio_len = -1
+        model = KWClip_GeneralTransformer(cfg, device="cuda:0").train()
+        trainer = ContrastiveTrainer(model)
+        losses = [float(trainer.step(batch)) for _ in range(3)]
+        fl = model.cascaded_branch.downsampling.check_flags()
+        torch.cuda.synchronize()
+        assert all(l == l for l in losses), losses
+        assert fl["count_mismatches"] == 0, fl
+        assert torch.isfinite(trainer.opt.flat_g).all()
+        runs.append(losses)
+        del trainer, model
+    assert runs[0] == runs[1], runs
