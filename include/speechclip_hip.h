@@ -168,6 +168,13 @@ int sc_conv0_finalize(const double* partial, int32_t nchunk, const float* w0 /*[
                       float* shift, void* stream);
 int sc_conv0_gn_gelu(const float* wav, int64_t ldw, const float* w0, const float* scale, const float* shift,
                      sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream);
+/* backward of conv layer 0 + GroupNorm + GELU for the fully trainable encoder (speech_encoder_plus.py:556-562; the input is the
+ * waveform: parameter gradients only).  dy [B*R0, 512] bf16 = gradient of the layer's output, scale / shift / stats = the forward's
+ * (sc_conv0_finalize, sc_conv0_stats with nchunk chunks).  partial: scratch [B, nwc, 512, 12] fp32 (nwc % 4 == 0 wave chunks);
+ * contrib [B, 512, 12] fp32 = per utterance (dW[c][0..9], dgamma[c], dbeta[c]) - sum over B with sc_colsum_f32. */
+int sc_conv0_gn_bwd(const float* wav, int64_t ldw, const float* w0, const float* scale, const float* shift, const sc_bf16* dy,
+                    const double* stats, int32_t nchunk, const float* gamma, const float* beta, int32_t B, int32_t T0, int32_t R0,
+                    int32_t C, float eps, float* partial, int32_t nwc, float* contrib, void* stream);
 /* "layer_norm" extractor mode (HuBERT-large): conv0 (+bias) -> LayerNorm over the 512 channels -> GELU */
 int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma,
                      const float* beta, float eps, sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream);
@@ -357,6 +364,9 @@ int sc_dropout_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* out, int64_t ldo, in
 int sc_dropout_mult_f32(float* out, int64_t n, float p, uint32_t seed, void* stream);
 int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int64_t ldy, int32_t rows, int32_t cols,
                       float* colsum_partial /* NULL, or [ceil(rows / 64), cols] fp32: per-64-row-block column sums of x */, void* stream);
+/* input gradient of a channels-last Conv1d(k = 3, stride 2) run as a strided-row GEMM (fully trainable HuBERT, conv layers 1-4):
+ * dcols [M, 3C] = dy . W -> dx [2M, C]:  dx[2m] = dcols[m][0:C] + dcols[m-1][2C:3C],  dx[2m+1] = dcols[m][C:2C]   (one pass) */
+int sc_conv_overlap_add_bf16(const sc_bf16* dcols, sc_bf16* dx, int64_t M, int32_t C, void* stream);
 int sc_colsum_bf16(const sc_bf16* x, int64_t ldx, int64_t rows, int32_t cols, float* partial, int32_t nblk, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -300,6 +300,31 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
     partial[(int64_t)blockIdx.y * cols + c2 * 2 + 1] = s1;
 }
 
+// Input gradient of a channels-last Conv1d(k = 3, stride 2) that ran as a strided-row GEMM (window m = rows 2m, 2m + 1, 2m + 2 of the
+// input): dcols [M, 3 C] = dy . W holds the gradient of every window; the input row r collects the windows that contain it -
+//   dx[2m]     = dcols[m][0 : C] + dcols[m - 1][2C : 3C]        dx[2m + 1] = dcols[m][C : 2C]
+// one pass (was: three strided torch copies / adds over GB-sized tensors, 20 ms of the fully-trainable step).
+__global__ __launch_bounds__(256) void conv_overlap_add_kernel(const uint16_t* __restrict__ dcols, uint16_t* __restrict__ dx, int64_t M, int C) {
+    const int64_t chunks = C >> 3;                      // 8 bf16 per thread
+    const int64_t total = M * chunks;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = q / chunks;
+        const int c = (int)(q - m * chunks) * 8;
+        const uint16_t* row = dcols + m * 3 * C;
+        const uint4 t0 = *(const uint4*)(row + c), t1 = *(const uint4*)(row + C + c);
+        uint4 e = t0;
+        if (m > 0) {
+            const uint4 p2 = *(const uint4*)(row - 3 * (int64_t)C + 2 * C + c);
+            e.x = pack2bf(bflo(t0.x) + bflo(p2.x), bfhi(t0.x) + bfhi(p2.x));
+            e.y = pack2bf(bflo(t0.y) + bflo(p2.y), bfhi(t0.y) + bfhi(p2.y));
+            e.z = pack2bf(bflo(t0.z) + bflo(p2.z), bfhi(t0.z) + bfhi(p2.z));
+            e.w = pack2bf(bflo(t0.w) + bflo(p2.w), bfhi(t0.w) + bfhi(p2.w));
+        }
+        *(uint4*)(dx + (2 * m) * C + c) = e;
+        *(uint4*)(dx + (2 * m + 1) * C + c) = t1;
+    }
+}
+
 }  // namespace
 
 extern "C" int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int64_t ldy, int32_t rows, int32_t cols,
@@ -315,6 +340,15 @@ extern "C" int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int6
 extern "C" int sc_colsum_bf16(const sc_bf16* x, int64_t ldx, int64_t rows, int32_t cols, float* partial, int32_t nblk, void* stream) {
     SC_CHECK(x && partial && rows > 0 && cols > 0 && cols % 2 == 0 && nblk > 0 && ldx % 2 == 0, "sc_colsum_bf16: bad args");
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3((cols / 2 + 255) / 256, nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, partial);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv_overlap_add_bf16(const sc_bf16* dcols, sc_bf16* dx, int64_t M, int32_t C, void* stream) {
+    SC_CHECK(dcols && dx && M > 0 && C > 0 && C % 8 == 0 && ((uintptr_t)dcols % 16) == 0 && ((uintptr_t)dx % 16) == 0, "sc_conv_overlap_add_bf16: bad args");
+    const int64_t total = M * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(conv_overlap_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dcols, dx, M, C);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -246,6 +246,144 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------- conv layer 0: backward (GroupNorm form)
+// Fully trainable encoder (avssl/module/speech_encoder_plus.py:556-562), "default" extractor: y = gelu(n), n = gamma (u - mu) / sigma + beta,
+// u[b, t, c] = sum_j W[c][j] x[b, 5t + j], statistics over t < T0 per (b, c).  The input is the waveform: no input gradient, only
+// dW [C, 10], dgamma, dbeta.  With dn = dy gelu'(n) everything follows from 12 time sums per (b, c) -
+//   A1 = sum_t dn,  A2 = sum_t dn n,  V_j = sum_t dn x[5t + j]  (j = 0..9)
+// - and the forward's 10 x 10 Gram matrix G and sums S of the strided waveform (sc_conv0_stats):
+//   Q = sum_t dn uhat = (A2 - beta A1) / gamma ;  dgamma = sum_b Q ;  dbeta = sum_b A1 ;
+//   dW[c][j] = sum_b (gamma / sigma) [V_j - (A1 / T0) S_j - (Q / T0) (sum_i W[c][i] G_ij - mu S_j) / sigma]
+// One pass over dy (u is recomputed from the waveform, 10 FMAs per element), then a per-utterance finalisation in fp64.
+// Phi(x) + x phi(x) with the erfc of gelu_erf (A&S 7.1.28, one v_rcp) and one v_exp
+__device__ __forceinline__ float gelu_grad_as(float x) {
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752f;
+    float p = fmaf(0.0000430638f, z, 0.0002765672f);
+    p = fmaf(p, z, 0.0001520143f);
+    p = fmaf(p, z, 0.0092705272f);
+    p = fmaf(p, z, 0.0422820123f);
+    p = fmaf(p, z, 0.0705230784f);
+    p = fmaf(p, z, 1.0f);
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    const float he = 0.5f * __builtin_amdgcn_rcpf(p);                 // erfc(|z|) / 2
+    const float cdf = x >= 0.f ? 1.f - he : he;
+    return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
+}
+
+constexpr int C0_NS = 12;
+// grid (nblk, B), 4 waves per block; wave chunk wc = blockIdx.x * 4 + wave owns rows [wc * rpw, min(T0, (wc + 1) * rpw)); a lane owns
+// 8 channels (C = 512).  partial[((b * nwc + wc) * 512 + c) * 12 + e]
+__global__ __launch_bounds__(256) void conv0_gn_bwd_kernel(const float* __restrict__ wav, int64_t ldw, const float* __restrict__ w0,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const uint16_t* __restrict__ dy, int T0, int R0, int rpw, int nwc,
+                                                           float* __restrict__ partial) {
+    constexpr int C = 512;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wc = blockIdx.x * 4 + wave;
+    const float* x = wav + (int64_t)b * ldw;
+    const int c0 = lane * 8;
+    float w[8][10], sc[8], sh[8], acc[8][C0_NS];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[i][j] = w0[(c0 + i) * 10 + j];
+        sc[i] = scale[(int64_t)b * C + c0 + i];
+        sh[i] = shift[(int64_t)b * C + c0 + i];
+#pragma unroll
+        for (int e = 0; e < C0_NS; ++e) acc[i][e] = 0.f;
+    }
+    const int t_end = min(T0, (wc + 1) * rpw);
+    for (int t = wc * rpw; t < t_end; ++t) {
+        float v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];              // wave-uniform address: scalar loads
+        const uint4 d = *(const uint4*)(dy + ((int64_t)b * R0 + t) * C + c0);
+        const float g[8] = {bflo(d.x), bfhi(d.x), bflo(d.y), bfhi(d.y), bflo(d.z), bfhi(d.z), bflo(d.w), bfhi(d.w)};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float u = 0.f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) u = fmaf(w[i][j], v[j], u);
+            const float n = fmaf(u, sc[i], sh[i]);
+            const float dn = g[i] * gelu_grad_as(n);
+            acc[i][0] += dn;
+            acc[i][1] = fmaf(dn, n, acc[i][1]);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc[i][2 + j] = fmaf(dn, v[j], acc[i][2 + j]);
+        }
+    }
+    if (wc < nwc) {
+        float* pp = partial + (((int64_t)b * nwc + wc) * C + c0) * C0_NS;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < C0_NS; e += 4) *(f32x4*)(pp + i * C0_NS + e) = f32x4{acc[i][e], acc[i][e + 1], acc[i][e + 2], acc[i][e + 3]};
+    }
+}
+
+// one block per utterance, thread = channel (two rounds for 512): wave chunks added in order, then the per-(b, c) algebra in fp64;
+// contrib[b][c][12] = (dW[c][0..9], dgamma, dbeta) of utterance b (summed over b by sc_colsum_f32)
+__global__ __launch_bounds__(256) void conv0_gn_bwd_finalize_kernel(const float* __restrict__ partial, int nwc, const double* __restrict__ stats,
+                                                                    int nchunk, const float* __restrict__ w0, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int T0, float eps,
+                                                                    float* __restrict__ contrib) {
+    constexpr int C = 512;
+    __shared__ double st[SC_CONV0_NSTAT];
+    const int b = blockIdx.x;
+    if (threadIdx.x < 65) {
+        double sm = 0.0;
+        for (int c = 0; c < nchunk; ++c) sm += stats[((int64_t)b * nchunk + c) * SC_CONV0_NSTAT + threadIdx.x];
+        st[threadIdx.x] = sm;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double a[C0_NS];
+#pragma unroll
+        for (int e = 0; e < C0_NS; ++e) a[e] = 0.0;
+        for (int k = 0; k < nwc; ++k) {
+            const float* pp = partial + (((int64_t)b * nwc + k) * C + c) * C0_NS;
+#pragma unroll
+            for (int e = 0; e < C0_NS; ++e) a[e] += (double)pp[e];
+        }
+        double w[10], WG[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[j] = (double)w0[c * 10 + j];
+        // G is stored as its upper triangle (j <= k): e = index of (min, max)
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int lo = i < j ? i : j, hi = i < j ? j : i;
+                const int e = lo * 10 - lo * (lo - 1) / 2 + (hi - lo);
+                t += w[i] * st[e];
+            }
+            WG[j] = t;                                                   // sum_i W[c][i] G_ij
+            s1 += w[j] * st[55 + j];
+            s2 += w[j] * t;
+        }
+        const double T = (double)T0;
+        const double mu = s1 / T;
+        const double var = fmax(s2 / T - mu * mu, 0.0);
+        const double rs = 1.0 / sqrt(var + (double)eps);
+        const double g = (double)gamma[c], be = (double)beta[c];
+        const double A1 = a[0], Q = (a[1] - be * A1) / g;
+        float* out = contrib + ((int64_t)b * C + c) * C0_NS;
+#pragma unroll
+        for (int j = 0; j < 10; ++j)
+            out[j] = (float)(g * rs * (a[2 + j] - (A1 / T) * st[55 + j] - (Q / T) * rs * (WG[j] - mu * st[55 + j])));
+        out[10] = (float)Q;
+        out[11] = (float)A1;
+    }
+}
+
 }  // namespace
 
 extern "C" int sc_wav_prep(const float* wav, int64_t ldw_in, const int64_t* wav_len, float* out, int64_t ldw_out,
@@ -296,6 +434,23 @@ extern "C" int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, 
     const int rows_per_block = 128;
     dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
     hipLaunchKernelGGL(conv0_ln_gelu_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, out, R0, rows_per_block);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_gn_bwd(const float* wav, int64_t ldw, const float* w0, const float* scale, const float* shift, const sc_bf16* dy,
+                               const double* stats, int32_t nchunk, const float* gamma, const float* beta, int32_t B, int32_t T0, int32_t R0,
+                               int32_t C, float eps, float* partial, int32_t nwc, float* contrib, void* stream) {
+    SC_CHECK(wav && w0 && scale && shift && dy && stats && gamma && beta && partial && contrib, "sc_conv0_gn_bwd: null pointer");
+    SC_CHECK(C == 512 && B > 0 && T0 > 0 && T0 <= R0 && nwc > 0 && nwc % 4 == 0 && nchunk > 0 && ldw >= 5 * (int64_t)(T0 - 1) + 10,
+             "sc_conv0_gn_bwd: C must be 512 (got %d), nwc a multiple of 4", C);
+    SC_CHECK(((uintptr_t)dy % 16) == 0 && ((uintptr_t)partial % 16) == 0, "sc_conv0_gn_bwd: alignment");
+    const int rpw = (T0 + nwc - 1) / nwc;
+    hipLaunchKernelGGL(conv0_gn_bwd_kernel, dim3(nwc / 4, B), dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, scale, shift, dy, T0, R0, rpw, nwc,
+                       partial);
+    SC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv0_gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, nwc, stats, nchunk, w0, gamma, beta, T0,
+                       eps, contrib);
     SC_LAUNCH_CHECK();
     return 0;
 }

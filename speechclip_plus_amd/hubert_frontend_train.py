@@ -116,22 +116,27 @@ class TrainableFrontend(nn.Module):
         dev = pl.wav_pad.device
         st = pl.front = {"p_in": p_in, "p_res": p_res, "seed_in": seed_in, "seed_enc": seed_enc}
         ln_mode = a.extractor_mode == "layer_norm"
-        # ---- conv layer 0 (+ GroupNorm / LayerNorm, GELU): torch autograd on the fp32 waveform
-        with torch.enable_grad():
-            w0 = self.P("feature_extractor.conv_layers.0.0.weight")
-            b0 = self.P("feature_extractor.conv_layers.0.0.bias") if a.conv_bias else None
-            x0 = F.conv1d(pl.wav_pad[:, None, :L], w0, b0, stride=a.conv_strides[0])                 # [B, C, T0]
-            if ln_mode:
+        # ---- conv layer 0 (+ GroupNorm, GELU): the frozen path's kernels on the CURRENT parameters (analytic GroupNorm statistics from
+        # the waveform's Gram matrix, activation written once); the backward (sc_conv0_gn_bwd) recomputes the pre-activation from the
+        # waveform, so nothing but the per-(utterance, channel) scale / shift and the Gram partials is kept.  The "layer_norm"
+        # extractor (HuBERT-large) still takes torch autograd for this one layer.
+        T0 = pl.T_l[0]
+        if ln_mode:
+            with torch.enable_grad():
+                w0 = self.P("feature_extractor.conv_layers.0.0.weight")
+                b0 = self.P("feature_extractor.conv_layers.0.0.bias") if a.conv_bias else None
+                x0 = F.conv1d(pl.wav_pad[:, None, :L], w0, b0, stride=a.conv_strides[0])             # [B, C, T0]
                 n0 = F.layer_norm(x0.transpose(1, 2), (C,), self.P("feature_extractor.conv_layers.0.2.1.weight"),
                                   self.P("feature_extractor.conv_layers.0.2.1.bias"))
-            else:
-                n0 = F.group_norm(x0, C, self.P("feature_extractor.conv_layers.0.2.weight"),
-                                  self.P("feature_extractor.conv_layers.0.2.bias")).transpose(1, 2)
-            f0 = F.gelu(n0)                                                                              # [B, T0, C]
-        st["f0"] = f0
-        T0 = f0.shape[1]
-        assert T0 == pl.T_l[0]
-        pl.conv[0][: B * pl.R_l[0]].view(B, pl.R_l[0], C)[:, :T0] = f0.detach().to(torch.bfloat16)
+                f0 = F.gelu(n0)                                                                          # [B, T0, C]
+            st["f0"] = f0
+            assert f0.shape[1] == T0
+            pl.conv[0][: B * pl.R_l[0]].view(B, pl.R_l[0], C)[:, :T0] = f0.detach().to(torch.bfloat16)
+        else:
+            w0 = ops.aligned16(self.P("feature_extractor.conv_layers.0.0.weight").detach().float().reshape(C, a.conv_kernels[0]).contiguous())
+            g0 = ops.aligned16(self.P("feature_extractor.conv_layers.0.2.weight").detach().float().contiguous())
+            be0 = ops.aligned16(self.P("feature_extractor.conv_layers.0.2.bias").detach().float().contiguous())
+            st["conv0"] = (w0, g0, be0, ops.conv0_groupnorm_gelu(pl.wav_pad, w0, g0, be0, T0, pl.R_l[0], pl.conv[0]))
         # ---- conv layers 1 .. 6 on the strided-row GEMM, pre-activations kept
         st["u"], st["n"] = {}, {}
         for i in range(1, len(a.conv_kernels)):
@@ -265,14 +270,17 @@ class TrainableFrontend(nn.Module):
                 df = dcols.view(rows * s, C)
             else:
                 assert k == 3 and s == 2
-                df = torch.empty(rows, 2, C, device=dev, dtype=torch.bfloat16)
-                df[:, 0] = dcols[:, :C]
-                df[:, 1] = dcols[:, C: 2 * C]
-                df[1:, 0] += dcols[:-1, 2 * C:]                                              # tap 2 of window m = row 2 (m + 1)
-                df = df.view(rows * 2, C)
-        # ---- conv layer 0: torch autograd from the saved graph
-        f0 = st["f0"]
-        T0 = f0.shape[1]
-        g0 = df.view(B, pl.R_l[0], C)[:, :T0].float()
-        f0.backward(g0)
+                df = ops.conv_overlap_add(dcols, C)            # tap 2 of window m lands on row 2 (m + 1): one pass, one launch
+        # ---- conv layer 0: parameter gradients only (the input is the waveform)
+        T0 = pl.T_l[0]
+        if "conv0" in st:
+            w0, g0, be0, saved = st["conv0"]
+            dW0, dg0, db0 = ops.conv0_groupnorm_gelu_bwd(pl.wav_pad, w0, g0, be0, saved, df, T0, pl.R_l[0])
+            acc("feature_extractor.conv_layers.0.0.weight", dW0)
+            acc("feature_extractor.conv_layers.0.2.weight", dg0)
+            acc("feature_extractor.conv_layers.0.2.bias", db0)
+        else:                                  # "layer_norm" extractor: torch autograd from the saved graph
+            f0 = st["f0"]
+            g0 = df.view(B, pl.R_l[0], C)[:, :T0].float()
+            f0.backward(g0)
         pl.front = None

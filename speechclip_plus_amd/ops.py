@@ -567,8 +567,9 @@ def wav_prep(wav: torch.Tensor, wav_len: torch.Tensor, out: torch.Tensor, normal
 
 
 def conv0_groupnorm_gelu(wav_pad: torch.Tensor, w0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, T0: int,
-                         R0: int, out: torch.Tensor, eps: float = 1e-5, nchunk: int = 32) -> None:
-    """conv layer 0 + GroupNorm(C groups) over t < T0 + GELU -> out[B*R0, C] bf16 (channels-last)."""
+                         R0: int, out: torch.Tensor, eps: float = 1e-5, nchunk: int = 32):
+    """conv layer 0 + GroupNorm(C groups) over t < T0 + GELU -> out[B*R0, C] bf16 (channels-last).  Returns what the backward
+    (conv0_groupnorm_gelu_bwd) needs: (scale, shift, Gram statistics, nchunk)."""
     B = wav_pad.shape[0]
     C = w0.shape[0]
     partial = torch.empty(B * nchunk * 66, device=wav_pad.device, dtype=torch.float64)
@@ -580,6 +581,23 @@ def conv0_groupnorm_gelu(wav_pad: torch.Tensor, w0: torch.Tensor, gamma: torch.T
                               _p(shift), _stream()), "sc_conv0_finalize")
     check(L.sc_conv0_gn_gelu(_p(wav_pad), wav_pad.stride(0), _p(w0), _p(scale), _p(shift), _p(out), B, R0, C, _stream()),
           "sc_conv0_gn_gelu")
+    return scale, shift, partial, nchunk
+
+
+def conv0_groupnorm_gelu_bwd(wav_pad: torch.Tensor, w0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, saved, dy: torch.Tensor,
+                             T0: int, R0: int, eps: float = 1e-5, nwc: int = 32):
+    """Parameter gradients of conv layer 0 + GroupNorm + GELU (sc_conv0_gn_bwd): dy [B*R0, C] bf16 -> (dW0 [C, 10], dgamma [C], dbeta [C])."""
+    scale, shift, stats, nchunk = saved
+    B, C = wav_pad.shape[0], w0.shape[0]
+    dev = wav_pad.device
+    partial = torch.empty(B, nwc, C, 12, device=dev, dtype=torch.float32)
+    contrib = torch.empty(B, C * 12, device=dev, dtype=torch.float32)
+    check(lib().sc_conv0_gn_bwd(_p(wav_pad), wav_pad.stride(0), _p(w0), _p(scale), _p(shift), _p(dy), _p(stats), nchunk, _p(gamma), _p(beta),
+                                B, T0, R0, C, float(eps), _p(partial), nwc, _p(contrib), _stream()), "sc_conv0_gn_bwd")
+    tot = torch.empty(C * 12, device=dev, dtype=torch.float32)
+    colsum(contrib, C * 12, B, C * 12, tot)
+    tot = tot.view(C, 12)
+    return tot[:, :10], tot[:, 10], tot[:, 11]
 
 
 def conv0_layernorm_gelu(wav_pad: torch.Tensor, w0: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
@@ -970,3 +988,12 @@ def cif_head_bwd(y: torch.Tensor, w: torch.Tensor, alpha: torch.Tensor, dalpha: 
     colsum(pw, C, nblk, C, dw)
     colsum(pb.view(nblk, 1), 1, nblk, 1, db)
     return dy, dw, db
+
+
+def conv_overlap_add(dcols: torch.Tensor, C: int) -> torch.Tensor:
+    """dcols [M, 3C] bf16 (window gradients of a k = 3 / stride 2 conv) -> input-row gradients [2M, C] bf16 (sc_conv_overlap_add_bf16)"""
+    M = dcols.shape[0]
+    assert dcols.dtype == torch.bfloat16 and dcols.is_contiguous() and dcols.shape[1] == 3 * C
+    dx = torch.empty(2 * M, C, device=dcols.device, dtype=torch.bfloat16)
+    check(lib().sc_conv_overlap_add_bf16(_p(dcols), _p(dx), M, C, _stream()), "sc_conv_overlap_add_bf16")
+    return dx
