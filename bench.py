@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances in the CPU-baseline sample: BASELINE configs[0] = batch 8 (0 = skip)")
-    ap.add_argument("--cpu-iters", type=int, default=2, help="timed CPU iterations per thread setting (after 1 warm-up)")
+    ap.add_argument("--cpu-iters", type=int, default=3, help="timed CPU iterations per thread setting (after 1 warm-up)")
     ap.add_argument("--cpu-full", action="store_true", help="the CPU baseline exactly as SURVEY 8d states it: 3 warm-up + 10 timed "
                     "iterations, all host cores and 8 threads (several minutes; the default run is a bounded sample of the same workload)")
     ap.add_argument("--no-recall", action="store_true", help="skip the recall@k parity field (5000-utterance synthetic eval set)")
@@ -443,6 +443,26 @@ def recall_parity(dev):
     return recall_eval.hip_recall(recall_eval.build_model(str(dev)), fx)
 
 
+def physical_cores():
+    """Physical cores of the host from /proc/cpuinfo (distinct (physical id, core id) pairs); None if it cannot be told."""
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+        return len(pairs) or None
+    except OSError:
+        return None
+
+
 def cpu_baseline(sd, model, n_utts, L, iters, full=False):
     """The oracle (kind "port": torch-CPU fp32 restatement of the reference maths) on the host cores, BASELINE configs[0]:
     Parallel SpeechCLIP base, batch 8 (the reference's CPU-runnable case), same utterance length as the GPU workload.  Forward
@@ -489,7 +509,8 @@ def cpu_baseline(sd, model, n_utts, L, iters, full=False):
     best = max(runs.values(), key=lambda r: r["train_step_utt_per_s"])
     return {"value": best["train_step_utt_per_s"], "unit": "utterances/s", "cores": best["threads"], "kind": "port",
             "sample": f"BASELINE configs[0]: batch {n_utts} x {L} samples, {warm} warm-up + {timed} timed train steps per thread "
-                      f"setting, torch fp32 on {os.cpu_count()} logical CPUs",
+                      f"setting, torch fp32 on {os.cpu_count()} logical CPUs ({physical_cores()} physical cores)",
+            "host": {"logical_cpus": os.cpu_count(), "physical_cores": physical_cores(), "torch_default_threads": default_threads},
             "s_per_step": best["forward_backward_s"], "forward_utt_per_s": best["forward_utt_per_s"],
             "by_threads": list(runs.values())}
 
