@@ -98,6 +98,15 @@ typedef struct {
     float* stats_out;
     int32_t res_ns;
     float ln_eps;
+    /* ---- TN form (256 x 256 tiles only): tn = 1 reads BOTH operands with the reduction index as the row index,
+     *       C[m, n] = sum_r A[r, m] W[r, n],   A [K, M] row stride lda, W [K, N] row stride ldw  (K = number of rows r),
+     * i.e. a weight gradient dW = dY^T X straight from the row-major dY [rows, M] and X [rows, N] (rows may overlap: the im2col
+     * view of a strided conv input), no transposed copies.  Requirements: M % 256 == 0, N % 256 == 0, K % 64 == 0, no bias /
+     * activation / residual / dropout / transposed store / LayerNorm folding; split along r through the batch strides
+     * (sA1 = rows_per_slice * lda, sW1 = rows_per_slice * ldw) into fp32 partials (out_f32 = 1) or a single bf16 / fp32 result.
+     * k_total > 0: the slices are ragged - slice z1 covers rows [z1 K, min((z1 + 1) K, k_total)) (K, k_total multiples of 64). */
+    int32_t tn;
+    int32_t k_total;
 } sc_gemm_args;
 int32_t sc_gemm_stats_strips(const sc_gemm_args* args);   /* strips a producer launch with these args writes per row (0: not on the 256-row family) */
 int sc_gemm_bf16(const sc_gemm_args* args, void* stream);

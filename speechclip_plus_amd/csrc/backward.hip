@@ -284,20 +284,40 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restri
     }
 }
 
-// partial[blk][c] = sum over the block's rows of x[row, c]  (bf16 -> fp32; bias gradients).  Threads own 2 columns each.
+// partial[blk][c] = sum over the block's rows of x[row, c]  (bf16 -> fp32; bias gradients).  A thread owns 8 consecutive columns
+// (one 16-byte load per row); with fewer than 256 column chunks the block walks 256 / chunks rows at a time and adds its row lanes
+// through LDS in fixed order at the end.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, int64_t ldx, int64_t rows, int cols,
                                                           float* __restrict__ partial) {
-    const int c2 = blockIdx.x * 256 + threadIdx.x;           // column pair
-    if (c2 * 2 >= cols) return;
+    __shared__ float red[256 * 8];
+    const int chunks = cols >> 3;
+    const int cpb = chunks < 256 ? chunks : 256;            // column chunks per block
+    const int rpi = 256 / cpb;                              // rows per iteration
+    const int tc = threadIdx.x % cpb, tr = threadIdx.x / cpb;
+    const int c8 = blockIdx.x * cpb + tc;
+    const bool live = tr < rpi && c8 < chunks;
     const int64_t per = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
-    float s0 = 0.f, s1 = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-        const uint32_t u = *(const uint32_t*)(x + r * ldx + c2 * 2);
-        s0 += bflo(u);
-        s1 += bfhi(u);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live)
+        for (int64_t r = r0 + tr; r < r1; r += rpi) {
+            const uint4 u = *(const uint4*)(x + r * ldx + c8 * 8);
+            s[0] += bflo(u.x); s[1] += bfhi(u.x); s[2] += bflo(u.y); s[3] += bfhi(u.y);
+            s[4] += bflo(u.z); s[5] += bfhi(u.z); s[6] += bflo(u.w); s[7] += bfhi(u.w);
+        }
+    if (rpi > 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
+        __syncthreads();
+        if (live && tr == 0)
+            for (int j = 1; j < rpi; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += red[(j * cpb + tc) * 8 + e];
     }
-    partial[(int64_t)blockIdx.y * cols + c2 * 2] = s0;
-    partial[(int64_t)blockIdx.y * cols + c2 * 2 + 1] = s1;
+    if (live && tr == 0) {
+        float* o = partial + (int64_t)blockIdx.y * cols + c8 * 8;
+        *(f32x4*)o = f32x4{s[0], s[1], s[2], s[3]};
+        *(f32x4*)(o + 4) = f32x4{s[4], s[5], s[6], s[7]};
+    }
 }
 
 // Input gradient of a channels-last Conv1d(k = 3, stride 2) that ran as a strided-row GEMM (window m = rows 2m, 2m + 1, 2m + 2 of the
@@ -338,8 +358,10 @@ extern "C" int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int6
 }
 
 extern "C" int sc_colsum_bf16(const sc_bf16* x, int64_t ldx, int64_t rows, int32_t cols, float* partial, int32_t nblk, void* stream) {
-    SC_CHECK(x && partial && rows > 0 && cols > 0 && cols % 2 == 0 && nblk > 0 && ldx % 2 == 0, "sc_colsum_bf16: bad args");
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((cols / 2 + 255) / 256, nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, partial);
+    SC_CHECK(x && partial && rows > 0 && cols > 0 && cols % 8 == 0 && nblk > 0 && ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
+             ((uintptr_t)partial % 16) == 0, "sc_colsum_bf16: cols / ldx multiples of 8, 16-byte aligned operands");
+    const int chunks = cols / 8, cpb = chunks < 256 ? chunks : 256;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((chunks + cpb - 1) / cpb, nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, partial);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -61,7 +61,16 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 }
 
 // DIAG (diagnostic builds): 3 = no epilogue (timing only, results wrong), 4 = wall-clock stamps of each tile's sections
-// written to p.Ct (results right; tools/epi_stamps.py).  ACT = 1: erf-GELU in the epilogue (compile-time so the 128
+// written to p.Ct (results right; tools/epi_stamps.py).
+// DIAG = 5 is not a diagnostic but the TN form (p.tn): both operands are stored with the REDUCTION index as their row index,
+//   C[m, n] = sum_r A[r, m] W[r, n]        (a weight gradient dW = dY^T X read straight from the row-major activations),
+// so a K-tile is staged as [64 r][256 m] / [64 r][256 n] and the MFMA fragments (8 consecutive r per lane) are read with
+// ds_read_b64_tr_b16, the LDS transpose read of gfx950.  LDS image of a half-tile ([64 r][128 columns], 16 KiB, same ring
+// slots as the NT form): 8-row x 32-column subtiles of 512 B,
+//   off(r, ch) = 2048 (r >> 3) + 512 (ch >> 2) + 64 (r & 7) + 16 ((ch & 3) ^ ((r >> 2) & 3))      (ch = 16-byte chunk of the row),
+// conflict-free for the transposed reads of the 16x16x32 operand (cdna_hip_programming T10, image (a)); the LDS-DMA writes it
+// linearly (one wave instruction = two subtiles), the swizzle sits in the per-lane global source address.  Four base registers
+// serve all fragment reads, the rest are immediates.  ACT = 1: erf-GELU in the epilogue (compile-time so the 128
 // evaluations per lane form straight-line code).
 // BN = 256 or 192 output columns per tile (wave block 128 x 64 or 128 x 48).  The narrower tile exists for wave
 // quantisation: with M = 32768, N = 768 / 2304 give 384 / 1152 tiles of 256 x 256 (1.5 / 4.5 rounds over 256 CUs) but
@@ -112,9 +121,30 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     //      B: BN / 8 instr over the BN-row B region (wave w issues {w, w + 8, ...}) --------------------------------
     const uint16_t* a_src[2][2];
     const uint16_t* b_src[NBI];
+    constexpr bool TNM = (DIAG == 5);
     auto set_sources = [&](int m0, int n0) {
         int sl = lane;                           // opaque copy: keeps the lane-only terms from being hoisted out of the
         asm volatile("" : "+v"(sl));             // tile loop and living across the K loop
+        if constexpr (TNM) {
+            // wave instruction j of a half (16 per half): subtile row group j >> 1, column groups 2 (j & 1) + {0, 1}
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int j = i * 8 + wave;
+                    const int row = 8 * (j >> 1) + ((sl >> 2) & 7);
+                    const int ch = 4 * (2 * (j & 1) + (sl >> 5)) + ((sl & 3) ^ ((row >> 2) & 3));
+                    a_src[h][i] = A + (int64_t)row * p.lda + m0 + h * 128 + ch * 8;
+                }
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) {
+                const int j = (i * 8 + wave) & 15, hb = (i * 8 + wave) >> 4;
+                const int row = 8 * (j >> 1) + ((sl >> 2) & 7);
+                const int ch = 4 * (2 * (j & 1) + (sl >> 5)) + ((sl & 3) ^ ((row >> 2) & 3));
+                b_src[i] = W + (int64_t)row * p.ldw + n0 + hb * 128 + ch * 8;
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -131,16 +161,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         }
     };
     auto dma_A = [&](int par, int k0) {
+        const int64_t ko = TNM ? (int64_t)k0 * p.lda : (int64_t)k0;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                glds16(a_src[h][i] + k0, smem + par * BUF_BYTES + h * HALF_BYTES + (i * 8 + wave) * 1024);
+                glds16(a_src[h][i] + ko, smem + par * BUF_BYTES + h * HALF_BYTES + (i * 8 + wave) * 1024);
     };
     auto dma_B = [&](int par, int k0) {
+        const int64_t ko = TNM ? (int64_t)k0 * p.ldw : (int64_t)k0;
 #pragma unroll
         for (int i = 0; i < NBI; ++i)
-            glds16(b_src[i] + k0, smem + par * BUF_BYTES + 2 * HALF_BYTES + (i * 8 + wave) * 1024);
+            glds16(b_src[i] + ko, smem + par * BUF_BYTES + 2 * HALF_BYTES + (i * 8 + wave) * 1024);
     };
     // LN: statistics rows of the tile (consumer: of A's rows; producer: of the raw residual's rows) and the column constants
     // (consumer: s_n, c_n; producer: gamma, beta of the residual's LayerNorm) -> LDS.  One 16-byte piece per lane: wave w brings
@@ -169,8 +201,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
     const int frag_off0 = (lane & 15) * ROWB + (((lane >> 4)) ^ sw) * 16;          // kk = 0
     const int frag_off1 = (lane & 15) * ROWB + ((4 + (lane >> 4)) ^ sw) * 16;      // kk = 1
     const int a_base = wm * HALF_BYTES;                                             // wave's A half
-    const int b_base = 2 * HALF_BYTES + wn * TN * ROWB;                             // wave's TN rows of the B region
-    const int nk = p.K / BK;
+    // NT: wave's TN rows of the B region; TN form: half wn >> 1 of the B region, column groups 2 (wn & 1) + {0, 1} of it
+    const int b_base = TNM ? 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (wn & 1) * 1024 : 2 * HALF_BYTES + wn * TN * ROWB;
+    // TN form: a 16 x 32 operand fragment (16 columns f of the staged tile, 32 reduction rows kk) = two transposed reads, rows
+    // 32 kk + 8 g + 4 s + (0..3) for s = 0, 1: lane 4 q + pp of a 16-lane group supplies row q, chunk 2 f + (pp >> 1), byte 8 (pp & 1)
+    int tr_base[2][2];                                                              // [s][f & 1]
+    {
+        const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                tr_base[s2][e] = 2048 * g + 64 * (4 * s2 + q) + 16 * ((2 * e + (pp >> 1)) ^ ((2 * g + s2) & 3)) + 8 * (pp & 1);
+    }
+    auto ld_frag = [&](const char* base, int f, int kk) -> bf16x8 {                 // fragment f (16 columns) of a half-tile image
+        if constexpr (TNM) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+            const char* b0p = base + 512 * (f >> 1) + 8192 * kk;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(b0p + tr_base[0][f & 1]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(b0p + tr_base[1][f & 1]));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(bf16x8, v);
+        } else {
+            return *(const bf16x8*)(base + f * 16 * ROWB + (kk ? frag_off1 : frag_off0));
+        }
+    };
+    // TN form with ragged slices: slice z1 covers reduction rows [z1 K, min((z1 + 1) K, k_total))
+    const int nk = (TNM && p.k_total > 0 ? min(p.K, p.k_total - (int)(blockIdx.z / p.nb2) * p.K) : p.K) / BK;
     // K-tile kt -> first k of the tile.  Conv-shaped A (tap_c = C_in, K = 3 C_in, lda = 2 C_in): per 64-channel block visit tap 0,
     // tap 2, tap 1 - tap 2 of row r is tap 0 of row r + 1, so that tile is fetched again while the L2 still holds it.
     const int tap_c = p.tap_c;
@@ -256,13 +315,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             // ---------------- P0
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                b0[ni][0] = *(const bf16x8*)(bs + ni * 16 * ROWB + frag_off0);
-                b0[ni][1] = *(const bf16x8*)(bs + ni * 16 * ROWB + frag_off1);
+                b0[ni][0] = ld_frag(bs, ni, 0);
+                b0[ni][1] = ld_frag(bs, ni, 1);
             }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                af[mi][0] = *(const bf16x8*)(as + mi * 16 * ROWB + frag_off0);
-                af[mi][1] = *(const bf16x8*)(as + mi * 16 * ROWB + frag_off1);
+                af[mi][0] = ld_frag(as, mi, 0);
+                af[mi][1] = ld_frag(as, mi, 1);
             }
             SC_BAR();
             SC_MFMA_QUAD(0, 0, b0);
@@ -270,8 +329,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             // ---------------- P1
 #pragma unroll
             for (int ni = 0; ni < NB1; ++ni) {
-                b1[ni][0] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off0);
-                b1[ni][1] = *(const bf16x8*)(bs + (2 + ni) * 16 * ROWB + frag_off1);
+                b1[ni][0] = ld_frag(bs, 2 + ni, 0);
+                b1[ni][1] = ld_frag(bs, 2 + ni, 1);
             }
             if (LN != 0 && kt == 0) dma_ln(m0, n0);      // older than every later wait of this K loop: in LDS long before the epilogue
             if (kt + 1 < nk) dma_A(par ^ 1, koff(kt + 1));
@@ -281,8 +340,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             // ---------------- P2
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                af[mi][0] = *(const bf16x8*)(as + (4 + mi) * 16 * ROWB + frag_off0);
-                af[mi][1] = *(const bf16x8*)(as + (4 + mi) * 16 * ROWB + frag_off1);
+                af[mi][0] = ld_frag(as, 4 + mi, 0);
+                af[mi][1] = ld_frag(as, 4 + mi, 1);
             }
             SC_BAR();
             SC_MFMA_QUAD(1, 1, b1);
@@ -423,6 +482,7 @@ int sc_gemm256_launch(const sc_gemm_args& a_in, hipStream_t s) {
     // register-direct epilogue it must stay off: half-line non-temporal writes cost 25 % (75.7 vs 55.9 us on the out_proj shape).
     a.reserved = (a_in.reserved == 1 || (a_in.reserved == 0 && a_in.residual != nullptr)) ? 1 : 0;
     if (sc_option(1)) a.reserved = 0;      // A/B switch (tools/): plain stores everywhere
+    if (a.tn) return launch256_<5, 256, 0, 0>(a, s);     // TN operands (weight gradients): checked by sc_gemm_bf16
     if (a.tile == 32) return launch256<3, 256>(a, s);   // diagnostics only (tools/epi_probe.py, tools/epi_stamps.py)
     if (a.tile == 34) return launch256<4, 256>(a, s);
     if (a.tile == 7) return launch256<0, 192>(a, s);

@@ -295,6 +295,15 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     } else {
         a.n_split = -1;
     }
+    if (a.tn) {
+        SC_CHECK(a.M % 256 == 0 && a.N % 256 == 0 && !a.bias && !a.residual && a.act == 0 && a.drop_p == 0.f && a.n_split < 0 &&
+                 !a.ln_stats && !a.stats_out && !a.res_stats && a.tap_c == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0,
+                 "sc_gemm_bf16: the TN form needs M, N %% 256 == 0 and a plain epilogue (M=%d N=%d)", a.M, a.N);
+        SC_CHECK(a.tile == 0 || a.tile == 2 || a.tile == 8, "sc_gemm_bf16: the TN form is built on the 256 x 256 tile only");
+        SC_CHECK(a.k_total == 0 || (a.k_total % 64 == 0 && a.nb2 == 1 && (int64_t)(a.nb1 - 1) * a.K < a.k_total && (int64_t)a.nb1 * a.K >= a.k_total),
+                 "sc_gemm_bf16: ragged TN slices need k_total %% 64 == 0 and (nb1 - 1) K < k_total <= nb1 K");
+        return sc_gemm256_launch(a, (hipStream_t)stream);
+    }
     const bool ln = a.ln_stats || a.stats_out || a.res_stats;
     if (ln) {
         // LayerNorm folded into the GEMMs: built into the 256-row tile family only (csrc/gemm256_bf16.hip)

@@ -81,7 +81,8 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
              alg_rows: Optional[int] = None, tile: int = 0, drop_p: float = 0.0, drop_seed: int = 0, tap_c: int = 0,
              ln_stats: Optional[torch.Tensor] = None, ln_ns: int = 0, ln_colsum: Optional[torch.Tensor] = None,
              res_stats: Optional[torch.Tensor] = None, res_ns: int = 0, res_gamma: Optional[torch.Tensor] = None,
-             res_beta: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None, ln_eps: float = 0.0) -> int:
+             res_beta: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None, ln_eps: float = 0.0,
+             tn: bool = False, k_total: int = 0) -> int:
     """C = epi(A . W^T); see sc_gemm_args in include/speechclip_hip.h.  Pointers are the tensors' data_ptr()
     (pass a sliced view to offset).  ``alg_rows``: rows that are algorithmic work (excludes layout padding),
     used only by the optional KernelTimer.  ``ln_*`` / ``res_*`` / ``stats_out``: LayerNorm folded into the GEMM (row-statistics
@@ -108,6 +109,8 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     a.tile = tile
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed) & 0xffffffff
     a.tap_c = int(tap_c)
+    a.k_total = int(k_total)
+    a.tn = int(tn)          # C[m, n] = sum_r A[r, m] W[r, n]: both operands row-indexed by the reduction (weight gradients)
     strips = 0
     if ln_stats is not None or stats_out is not None:
         for t in (ln_stats, ln_colsum, res_stats, res_gamma, res_beta, stats_out):
@@ -261,16 +264,50 @@ def transpose_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None, colsum_p
     return out
 
 
+_cus = []
+
+
+def _num_cus() -> int:
+    if not _cus:
+        _cus.append(int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count))
+    return _cus[0]
+
+
+def colsum_bf16(x: torch.Tensor, out: torch.Tensor, beta: float = 0.0) -> None:
+    """out[c] = beta out[c] + sum_r x[r, c]  (bf16 rows -> fp32; bias gradients): row-block partials, then sc_colsum_f32 in block order."""
+    rows, cols = x.shape
+    assert x.dtype == torch.bfloat16 and x.stride(1) == 1 and out.dtype == torch.float32
+    nblk = max(1, min(512, rows // 64))
+    part = torch.empty(nblk, cols, device=x.device, dtype=torch.float32)
+    check(lib().sc_colsum_bf16(_p(x), x.stride(0), rows, cols, _p(part), nblk, _stream()), "sc_colsum_bf16")
+    colsum(part, cols, nblk, cols, out, beta=beta)
+
+
 def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional[torch.Tensor] = None, beta: float = 1.0) -> None:
     """gW[N, K] = beta gW + dy[rows, N]^T x[rows, K]  (fp32, contiguous) ;  gb[N] = beta gb + colsum(dy).
 
-    The contraction runs over the rows: both operands are transposed (HBM-bound) and the GEMM is split along K over its batch
-    dimension (few output tiles, tens of thousands of rows) into fp32 partials that sc_colsum_f32 adds in slice order."""
+    The contraction runs over the rows.  N, K multiples of 256: the TN form of sc_gemm_bf16 reads both operands in place (row-major,
+    any row stride - also the overlapping-row im2col view of a conv input), split along the rows into fp32 partials that
+    sc_colsum_f32 adds in slice order.  Other shapes (grouped pos_conv: 48 columns): both operands are transposed first."""
     rows, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == rows and rows % 64 == 0 and gW.dtype == torch.float32 and gW.is_contiguous() and tuple(gW.shape) == (N, K)
-    pb = torch.empty((rows + 63) // 64, N, device=dy.device, dtype=torch.float32) if gb is not None else None
+    assert dy.stride(1) == 1 and x.stride(1) == 1
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    if N % 256 == 0 and K % 256 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:
+        kt = rows // 64
+        S = max(1, min(_num_cus() // tiles, kt // 4))     # one round of workgroups; slices of whole K-tiles, the last one shorter
+        Kc = -(-kt // S) * 64
+        S = -(-rows // Kc)
+        part = gW if (S == 1 and beta == 0.0) else torch.empty(S, N, K, device=dy.device, dtype=torch.float32)
+        gemm_raw(dy, dy.stride(0), x, x.stride(0), part, K, N, K, Kc, out_f32=True, nb1=S, sA=(Kc * dy.stride(0), 0),
+                 sW=(Kc * x.stride(0), 0), sC=(N * K, 0), tn=True, k_total=rows)
+        if part is not gW:
+            colsum(part, N * K, S, N * K, gW, beta=beta)
+        if gb is not None:
+            colsum_bf16(dy, gb, beta=beta)
+        return
+    pb = torch.empty((rows + 63) // 64, N, device=dy.device, dtype=torch.float32) if gb is not None else None
     S = max(1, min(256 // max(tiles, 1), rows // 512))
     # the slices must be equal and multiples of 64 rows: the transposed operands are laid out with the row count padded up to
     # 64 * S and the pad columns zeroed (rows = B * 499 has no useful divisor; one un-split GEMM over 32k rows would leave most

@@ -1174,3 +1174,42 @@ def test_rowtail_ops(dev):
     ge = R(B, D).to(dev)
     er.backward(d64(ge))
     assert rel_l2(ops.rt_l2norm_bwd(ge, e, rn), xr.grad) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,rows,S", [(256, 256, 64, 1), (768, 768, 1024, 4), (512, 1536, 640, 2), (2304, 768, 512, 1)])
+def test_gemm_tn_form_reads_row_major_operands(dev, M, N, rows, S):
+    """sc_gemm_bf16 with tn = 1: C[m, n] = sum_r A[r, m] W[r, n] (the weight-gradient product dY^T X) straight from the row-major
+    operands - against an fp64 product of the same bf16 values, un-split and split along r into fp32 partials; the second case's
+    W operand is an overlapping-row (im2col) view as the conv layers' weight gradients use."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N + rows)
+    A = torch.randn(rows, M, generator=g).to(torch.bfloat16).to(dev)
+    ldw = N if N != 1536 else 1024                      # rows overlap: row r of W starts at element r * 1024, is 1536 long
+    Wflat = torch.randn(rows * ldw + N, generator=g).to(torch.bfloat16).to(dev)
+    Wv = torch.as_strided(Wflat, (rows, N), (ldw, 1))
+    ref = A.double().t() @ Wv.double()
+    Kc = rows // S
+    part = torch.empty(S, M, N, device=dev, dtype=torch.float32)
+    ops.gemm_raw(A, M, Wflat, ldw, part, N, M, N, Kc, out_f32=True, nb1=S, sA=(Kc * M, 0), sW=(Kc * ldw, 0), sC=(M * N, 0), tn=True)
+    got = part.double().sum(0)
+    assert float((got - ref).norm() / ref.norm()) < 1e-5
+    # the NT form on transposed copies gives the same numbers (same k order inside a tile): bitwise per slice
+    At, Wt = A.t().contiguous(), Wv.t().contiguous()
+    part2 = torch.empty_like(part)
+    ops.gemm_raw(At, rows, Wt, rows, part2, N, M, N, Kc, out_f32=True, nb1=S, sA=(Kc, 0), sW=(Kc, 0), sC=(M * N, 0), tile=8)
+    assert torch.equal(part, part2)
+    if rows >= 512:
+        # ragged slices (k_total): 3 slices of ceil(rows / 64 / 3) K-tiles, the last one shorter
+        Kr = -(-(rows // 64) // 3) * 64
+        Sr = -(-rows // Kr)
+        part3 = torch.empty(Sr, M, N, device=dev, dtype=torch.float32)
+        ops.gemm_raw(A, M, Wflat, ldw, part3, N, M, N, Kr, out_f32=True, nb1=Sr, sA=(Kr * M, 0), sW=(Kr * ldw, 0), sC=(M * N, 0), tn=True,
+                     k_total=rows)
+        assert float((part3.double().sum(0) - ref).norm() / ref.norm()) < 1e-5
+    # ops.wgrad_bf16 on top of it, with the bias gradient
+    gW = torch.zeros(M, N, device=dev)
+    gb = torch.zeros(M, device=dev)
+    ops.wgrad_bf16(A, Wv, gW, gb, beta=0.0)
+    assert float((gW.double() - ref).norm() / ref.norm()) < 1e-5
+    assert float((gb.double() - A.double().sum(0)).norm() / A.double().sum(0).norm()) < 1e-5
