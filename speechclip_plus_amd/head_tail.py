@@ -19,6 +19,7 @@ recipe): attention weights (a [B,H,R] multiplier consumed by the pooling kernel)
 dropout on the activation, dropout2 on the FFN output.  The masks come from torch's device generator (so
 ``torch.manual_seed`` makes a step reproducible) as 0 / (1/(1-p)) multipliers and are kept for the backward.
 """
+import os
 from typing import Optional
 
 import torch
@@ -58,6 +59,46 @@ def _dgrad(dy, W):
     return ops.rt_gemm(dy, W, Bn, K, N, b_kmajor=True, ldb=K, split=True)
 
 
+def cls_query(module, cls: torch.Tensor):
+    """(x0, q, Qm, a): the CLS query folded into the key projection, a_h = dh^-1/2 Wk_h^T (Wq cls + bq)_h.  It depends on
+    parameters only, so it is cached per parameter version (optim.param_generation() + the tensors' own versions) and the trainer
+    computes it on its SIDE stream right after the optimiser step (train.ContrastiveTrainer._finish -> prefetch), i.e. under the next
+    step's encoder forward: six small launches leave the critical path between the weighted sum and the score sweep."""
+    from .optim import param_generation
+    layer = module.model.layers[0]
+    att = layer.self_attn
+    key = (param_generation(), cls.data_ptr(), cls._version, att.in_proj_weight.data_ptr(), att.in_proj_weight._version,
+           att.in_proj_bias._version)
+    cache = getattr(module, "_sc_cls_query", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    D, H = module.d_model, module.nhead
+    dh = D // H
+    Wi, bi = att.in_proj_weight.detach(), att.in_proj_bias.detach()
+    x0 = cls.detach().reshape(1, D).float().contiguous()
+    q = _lin(x0, Wi[:D], bi[:D])                                  # [1, D]
+    Qm = torch.empty(H, D, device=x0.device, dtype=torch.float32)
+    ops.headmask(q, Qm, H, D, dh, gather=False)
+    a = torch.empty(H, D, device=x0.device, dtype=torch.float32)
+    ops.sgemm_ex(Qm, (D, 1, 0), Wi[D: 2 * D], (1, D, 0), a, D, H, D, D, alpha=dh ** -0.5)
+    x0b = x0.to(torch.bfloat16)
+    val = (x0, q, Qm, a, x0b)
+    module._sc_cls_query = (key, val)
+    return val
+
+
+_aux = {}
+_AUX_ON = os.environ.get("SC_HEAD_AUX_STREAM", "1") == "1"
+
+
+def _aux_stream(dev) -> "torch.cuda.Stream":
+    """A second stream for the parameter-only half of the head's backward (it runs beside the weighted-sum sweep)."""
+    st = _aux.get(dev)
+    if st is None:
+        st = _aux[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class ParallelHeadFn(torch.autograd.Function):
     """inputs : cls [1,1,D] fp32 (parameter), ws_weights (weighted-sum logits or None), feat (generic path or None),
                then constants: the TransformerEncoder module, the projection nn.Linear (or None), the encoder handle,
@@ -79,15 +120,10 @@ class ParallelHeadFn(torch.autograd.Function):
         att = layer.self_attn
         Wi, bi = att.in_proj_weight.detach(), att.in_proj_bias.detach()
         Wq, Wk, Wv = Wi[:D], Wi[D: 2 * D], Wi[2 * D:]
-        x0 = cls.detach().reshape(1, D).float().contiguous()
+        # ---- CLS query folded into the key projection: a_h = dh^-1/2 Wk_h^T q_h (bk shifts all scores alike: cancels); cached
+        x0, q, Qm, a, x0b = cls_query(module, cls)
         src = src.detach()
-        src[:, 0] = x0.to(torch.bfloat16)                       # CLS slot of the padded [CLS ; frames] buffer
-        # ---- CLS query folded into the key projection: a_h = dh^-1/2 Wk_h^T q_h (bk shifts all scores alike: cancels)
-        q = _lin(x0, Wq, bi[:D])                                  # [1, D]
-        Qm = torch.empty(H, D, device=dev, dtype=torch.float32)
-        ops.headmask(q, Qm, H, D, dh, gather=False)
-        a = torch.empty(H, D, device=dev, dtype=torch.float32)
-        ops.sgemm_ex(Qm, (D, 1, 0), Wk, (1, D, 0), a, D, H, D, D, alpha=dh ** -0.5)
+        src[:, 0] = x0b                                         # CLS slot of the padded [CLS ; frames] buffer
         scores = ops.cls_scores(src, a, False, B, R, D, H)
         pd = float(module.dropout) if module.training else 0.0
         s_att, s1, sf, s2 = (ops.next_mult_seed() for _ in range(4)) if pd > 0 else (0, 0, 0, 0)   # order = the sites' order in the layer
@@ -173,24 +209,38 @@ class ParallelHeadFn(torch.autograd.Function):
         # ---- attention pooling backward (two sweeps over X), gradient of the CLS slot and of a
         dp = ops.cls_scores(src, dm, True, B, R, D, H)
         dX, da_part = ops.cls_pool_bwd(src, p, dp, dm, a, lens, B, R, D, H, mult, cbias=cbias)    # (dp + cbias) * mult inside
-        ops.colsum(dX, R * D, B, D, d_x0, beta=1.0)             # row 0 of every utterance is the CLS token
+        # The rest splits in two independent halves: the sweep over the 13 hidden states that needs dX (weighted-sum logits, unfrozen
+        # layers) and ~10 small launches on parameter-sized tensors (CLS slot, a, q).  The small half goes to a second stream and
+        # runs beside the sweep; the main stream waits for it before this node returns (autograd accumulates d_cls there).
         d_a = torch.empty(H, D, device=dev, dtype=torch.float32)
-        ops.colsum(da_part, H * D, B, H * D, d_a)
-        # ---- a = s Qm Wk ;  q = Wq cls + bq   (bk receives exactly zero)
-        s = dh ** -0.5
-        ops.sgemm_ex(Qm, (1, D, 0), d_a, (1, D, 0), gWi[D: 2 * D], D, D, D, H, alpha=s, beta=1.0)
         dQm = torch.empty(H, D, device=dev, dtype=torch.float32)
-        ops.sgemm_ex(d_a, (D, 1, 0), Wk, (D, 1, 0), dQm, D, H, D, D, alpha=s)
         dq = torch.empty(1, D, device=dev, dtype=torch.float32)
-        ops.headmask(dq, dQm, H, D, dh, gather=True)
-        ops.sgemm_ex(dq, (1, 1, 0), x0, (1, 1, 0), gWi[:D], D, D, D, 1, beta=1.0)
-        ops.colsum(dq, D, 1, D, gbi[:D], beta=1.0)
-        ops.sgemm_ex(dq, (D, 1, 0), Wq, (1, D, 0), d_x0, D, 1, D, D, beta=1.0)
-        d_cls = d_x0.reshape(1, 1, D)
-        d_ws, d_feat = None, None
         hd = ctx.handle
         if hd is not None:
             hd.check_fresh()
+        main = torch.cuda.current_stream()
+        side = _aux_stream(dev) if (hd is not None and ctx.needs_input_grad[1] and _AUX_ON) else None
+
+        def small_half():
+            ops.colsum(dX, R * D, B, D, d_x0, beta=1.0)             # row 0 of every utterance is the CLS token
+            ops.colsum(da_part, H * D, B, H * D, d_a)
+            # ---- a = s Qm Wk ;  q = Wq cls + bq   (bk receives exactly zero)
+            s = dh ** -0.5
+            ops.sgemm_ex(Qm, (1, D, 0), d_a, (1, D, 0), gWi[D: 2 * D], D, D, D, H, alpha=s, beta=1.0)
+            ops.sgemm_ex(d_a, (D, 1, 0), Wk, (D, 1, 0), dQm, D, H, D, D, alpha=s)
+            ops.headmask(dq, dQm, H, D, dh, gather=True)
+            ops.sgemm_ex(dq, (1, 1, 0), x0, (1, 1, 0), gWi[:D], D, D, D, 1, beta=1.0)
+            ops.colsum(dq, D, 1, D, gbi[:D], beta=1.0)
+            ops.sgemm_ex(dq, (D, 1, 0), Wq, (1, D, 0), d_x0, D, 1, D, D, beta=1.0)
+
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                small_half()
+        else:
+            small_half()
+        d_cls = d_x0.reshape(1, 1, D)
+        d_ws, d_feat = None, None
         if hd is not None and ctx.needs_input_grad[1]:
             d_ws = ops.wsum_bwd_logits(hd.hidden, dX, hd.w_soft, B, R, D, 1, normalize=hd.normalize, lazy=hd.lazy)
         if hd is not None and hd.layers_bwd is not None:           # unfrozen HuBERT layers: continue the chain below the weighted sum
@@ -198,6 +248,8 @@ class ParallelHeadFn(torch.autograd.Function):
         if ctx.feat_meta is not None and ctx.needs_input_grad[2]:
             shape, dtype = ctx.feat_meta
             d_feat = dX[:, 1: 1 + shape[1]].to(dtype)
+        if side is not None:
+            main.wait_stream(side)
         return d_cls, d_ws, d_feat, None, None, None, None, None, None, None
 
 

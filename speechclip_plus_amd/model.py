@@ -211,6 +211,15 @@ class KWClip_GeneralTransformer(nn.Module):
         return self._device
 
     # ---------------------------------------------------------------------------------------------
+    def prefetch_after_step(self) -> None:
+        """Called by the trainer on its side stream right after the optimiser step: computes what the next forward needs from the
+        parameters alone (head_tail.cls_query, cached per parameter version), off the critical path."""
+        pb = self.parallel_branch
+        if pb is not None and getattr(pb, "self_att", None) is not None and hasattr(pb.self_att, "cls_forward"):
+            from .head_tail import cls_query
+            with torch.no_grad():
+                cls_query(pb.self_att, pb.cls)
+
     def getTrainableParams(self) -> list:
         """kwClip.py:620-644 + :812-837."""
         _params = []

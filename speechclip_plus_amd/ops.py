@@ -805,10 +805,12 @@ _SPLITK_WS = {}
 
 
 def _splitk_workspace(device) -> torch.Tensor:
-    """Per-device scratch for split-K partial sums (8 Mi floats; calls on one stream are serialised, so one buffer serves)."""
-    ws = _SPLITK_WS.get(device)
+    """Scratch for split-K partial sums, one buffer per (device, stream): calls on one stream are serialised, calls on different
+    streams (the head's parameter-only backward half, the trainer's prefetch) must not share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
     if ws is None:
-        ws = _SPLITK_WS[device] = torch.empty(8 << 20, device=device, dtype=torch.float32)
+        ws = _SPLITK_WS[key] = torch.empty(8 << 20, device=device, dtype=torch.float32)
     return ws
 
 

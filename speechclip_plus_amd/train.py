@@ -10,6 +10,7 @@ of the next step (the weighted sum at the end of the encoder).  The collective a
 encoder forward instead of extending the step.  With unfrozen HuBERT layers (hubert_train.py) that premise does not hold - the
 encoder reads trainable parameters from its first unfrozen layer on - so the encoder joins at the top of its forward instead
 (speech_encoder.forward) and only the per-layer gradient all-reduces overlap (with the backward of the layers below)."""
+import os
 from typing import Optional
 
 import torch
@@ -139,3 +140,8 @@ class ContrastiveTrainer:
                 pos = max(pos, hi)
             self._reduced = []
         self.opt.step(lr=lr)
+        # parameter-only pieces of the next forward (the CLS query of the parallel head) go here too: on the side stream, right
+        # behind the optimiser, under the next step's encoder forward
+        pre = getattr(self.model, "prefetch_after_step", None)
+        if pre is not None and os.environ.get("SC_PREFETCH", "1") == "1":
+            pre()
