@@ -206,6 +206,15 @@ int sc_posconv_prep(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_
 int sc_posconv_bf16(const sc_bf16* xg, const sc_bf16* w, const float* bias, const sc_bf16* residual, sc_bf16* out, int32_t B,
                     int32_t R, int32_t D, int32_t G, int32_t Kp, int32_t Rp, void* stream);
 
+/* Weight gradient of that convolution (fully trainable HuBERT; speech_encoder_plus.py:29-40 under trainable: true):
+ *   part[z][g][co][tap*Dg + ci] = sum over the z-th slice of slab rows m of  du[g][m][co] * xg[g][m + tap][ci]
+ * du, xg [G, rows, Dg] bf16 (rows = B * Rp, the slab row pitch; du must be ZERO on rows whose window straddles two utterances, i.e.
+ * laid out like the slab with the frames at row offset 0: pass the du slab advanced by `halo` rows), Dg in {48, 64}, Kp % 16 == 0,
+ * rows % (128 * Z) == 0; xg rows past the end of the buffer are never dereferenced (clamped; they meet du = 0).
+ * part [Z, G, Dg, Kp*Dg] fp32: reduce over z with sc_colsum_f32. */
+int sc_posconv_wgrad_bf16(const sc_bf16* du, const sc_bf16* xg, float* part, int32_t G, int64_t rows, int32_t Dg, int32_t Kp,
+                          int32_t Z, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weighted sum over hidden states (avssl/module/weighted_sum.py:26-45).
  *   h    [NL, B*R, D] bf16 ; w [NL] fp32 = softmax(weights) (host computes the 13-element softmax)

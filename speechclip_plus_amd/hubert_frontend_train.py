@@ -198,25 +198,17 @@ class TrainableFrontend(nn.Module):
         # slab of du (group-major, halo-padded, frames of every utterance kept: the mask argument is "all R frames valid")
         all_valid = torch.full((B,), R, device=dev, dtype=torch.int32)
         du_z = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-        dug = torch.zeros(G, B, Rp, Dg, device=dev, dtype=torch.bfloat16)
+        # + (halo + 1) slab rows of zero slack behind the last group: the weight gradient reads the slab advanced by `halo` rows, the
+        # input gradient advanced by one row
+        dug_buf = torch.zeros((G * B * Rp + halo + 1) * Dg, device=dev, dtype=torch.bfloat16)
+        dug = dug_buf[: G * B * Rp * Dg].view(G, B, Rp, Dg)
         ops.posconv_prep(du, all_valid, du_z, dug, B, R, D, G, halo)
-        # weight gradient per group: du_g^T [Dg, B Rp] . Toeplitz view of the forward slab [B Rp, Kp Dg] (row m starts at slab row m).
-        # du rows are laid out with the slab's row pitch (Rp per utterance): the halo rows multiply windows that straddle two
-        # utterances and must be zero - they are (dug's halos), shifted by `halo` rows against the window index.
-        gw = torch.empty(G, Dg, Kp * Dg, device=dev, dtype=torch.float32)
+        # weight gradient: gw[g][co][tap Dg + ci] = sum_m du[g][m][co] xg[g][m + tap][ci] over the slab rows m = b Rp + t (window index),
+        # du laid out with the frames at row offset 0 = the du slab advanced by `halo` rows; its halo rows (zero) meet the windows that
+        # straddle two utterances.  One kernel for all groups and taps (csrc/posconv_bwd.hip).
+        gw = ops.posconv_wgrad(dug_buf[halo * Dg:], pl.xg, G, B * Rp, Dg, Kp)
         gb = torch.empty(D, device=dev, dtype=torch.float32)
-        rows_p = B * Rp
-        xg_flat = pl.xg.view(G, -1)
-        du_rows = torch.zeros(G, rows_p, Dg, device=dev, dtype=torch.bfloat16)      # window index m = b Rp + t  <->  du[b, t]
-        du_rows.view(G, B, Rp, Dg)[:, :, :R] = dug[:, :, halo: halo + R]
-        slack = torch.zeros(Kp * Dg, device=dev, dtype=torch.bfloat16)
-        for g in range(G):
-            # the last windows of the last utterance read past this group's slab: give the view its own zero slack
-            src = torch.cat([xg_flat[g], slack])
-            cols = torch.as_strided(src, (rows_p, Kp * Dg), (Dg, 1))
-            gbg = torch.empty(Dg, device=dev, dtype=torch.float32)
-            ops.wgrad_bf16(du_rows[g], cols, gw[g], gbg, beta=0.0)
-            gb[g * Dg: (g + 1) * Dg] = gbg
+        ops.colsum_bf16(du, gb)
         acc("encoder.pos_conv.0.bias", gb)
         # chain rule to weight_g / weight_v through the fold (small tensors: torch autograd)
         dW = gw.view(G, Dg, Kp, Dg).permute(0, 1, 3, 2).reshape(D, Dg, Kp)             # [co][ci][tap]
@@ -227,8 +219,7 @@ class TrainableFrontend(nn.Module):
         acc("encoder.pos_conv.0.weight_v", gv)
         # input gradient: dx[s] = sum_tap' du_slab[s + 1 + tap'] . W_flip[tap']  (+ the residual path dpre in the epilogue)
         dxz = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-        dug_flat = torch.cat([dug.view(-1), torch.zeros(Dg, device=dev, dtype=torch.bfloat16)])   # + one slab row of slack
-        ops.gemm_raw(dug_flat[Dg:], Dg, c["pos_w_flip"], Kp * Dg, dxz, D, R, Dg, Kp * Dg, residual=dpre, ldr=D, nb1=G, nb2=B,
+        ops.gemm_raw(dug_buf[Dg:], Dg, c["pos_w_flip"], Kp * Dg, dxz, D, R, Dg, Kp * Dg, residual=dpre, ldr=D, nb1=G, nb2=B,
                      sA=(B * Rp * Dg, Rp * Dg), sW=(Dg * Kp * Dg, 0), sC=(Dg, R * D), sR=(Dg, R * D), alg_rows=T)
         # padded frames were zeroed in the forward (x[padding_mask] = 0): no gradient to them
         dx_proj = torch.empty(M, D, device=dev, dtype=torch.bfloat16)

@@ -328,6 +328,23 @@ def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional
         colsum(pb, N, pb.shape[0], N, gb, beta=beta)
 
 
+def posconv_wgrad(du: torch.Tensor, xg: torch.Tensor, G: int, rows: int, Dg: int, Kp: int) -> torch.Tensor:
+    """gw [G, Dg, Kp Dg] fp32 = the grouped pos_conv weight gradient (sc_posconv_wgrad_bf16): du / xg are [G, rows, Dg] slabs given by
+    their first element (du advanced by the halo, see the header); row slices reduced in order by sc_colsum_f32."""
+    assert du.dtype == torch.bfloat16 and xg.dtype == torch.bfloat16 and rows % 128 == 0
+    Z = 4
+    while (rows // 128) % Z:
+        Z -= 1
+    n = G * Dg * Kp * Dg
+    part = torch.empty(Z, n, device=du.device, dtype=torch.float32)
+    check(lib().sc_posconv_wgrad_bf16(_p(du), _p(xg), _p(part), G, rows, Dg, Kp, Z, _stream()), "sc_posconv_wgrad_bf16")
+    if Z == 1:
+        return part.view(G, Dg, Kp * Dg)
+    gw = torch.empty(G, Dg, Kp * Dg, device=du.device, dtype=torch.float32)
+    colsum(part, n, Z, n, gw)
+    return gw
+
+
 def dropout_bf16(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """F.dropout(x, p) on bf16 rows with the stateless hash mask (element row * D + col); in place when out is x."""
     rows, D = x.shape

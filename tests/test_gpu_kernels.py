@@ -1213,3 +1213,28 @@ def test_gemm_tn_form_reads_row_major_operands(dev, M, N, rows, S):
     ops.wgrad_bf16(A, Wv, gW, gb, beta=0.0)
     assert float((gW.double() - ref).norm() / ref.norm()) < 1e-5
     assert float((gb.double() - A.double().sum(0)).norm() / A.double().sum(0).norm()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Dg,G,B,R", [(48, 2, 2, 128), (64, 3, 3, 256)])
+def test_posconv_weight_gradient_kernel(dev, Dg, G, B, R):
+    """sc_posconv_wgrad_bf16: gw[g][co][tap Dg + ci] = sum_m du[g][m][co] xg[g][m + tap][ci] over the halo-padded slab rows, against an
+    fp64 correlation of the same bf16 values (and thereby against F.conv1d's weight gradient, which is that sum)."""
+    ops = _ops()
+    Kp, halo = 128, 64
+    Rp = R + 2 * halo
+    g = torch.Generator(device="cpu").manual_seed(Dg + R)
+    xg = torch.zeros(G, B, Rp, Dg)
+    xg[:, :, halo: halo + R] = torch.randn(G, B, R, Dg, generator=g)
+    du_buf = torch.zeros((G * B * Rp + halo + 1) * Dg)
+    dug = du_buf[: G * B * Rp * Dg].view(G, B, Rp, Dg)
+    dug[:, :, halo: halo + R] = torch.randn(G, B, R, Dg, generator=g)
+    xg_d, du_d = xg.to(torch.bfloat16).to(dev), du_buf.to(torch.bfloat16).to(dev)
+    gw = ops.posconv_wgrad(du_d[halo * Dg:], xg_d, G, B * Rp, Dg, Kp)
+    xr = xg_d.double().cpu()
+    dr = du_d[: G * B * Rp * Dg].view(G, B, Rp, Dg).double().cpu()[:, :, halo: halo + R]      # du[g][b][t][co]
+    ref = torch.empty(G, Dg, Kp, Dg, dtype=torch.float64)
+    for tap in range(Kp):
+        ref[:, :, tap] = torch.einsum("gbtc,gbti->gci", dr, xr[:, :, tap: tap + R])
+    got = gw.double().cpu().view(G, Dg, Kp, Dg)
+    assert float((got - ref).norm() / ref.norm()) < 1e-5
