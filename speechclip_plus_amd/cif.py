@@ -93,6 +93,61 @@ class _CifHeadFn(torch.autograd.Function):
         return dy.view(B, S, C), dw.view(wshape), db, None, None, None, None
 
 
+class _ConvRowsBf16Fn(torch.autograd.Function):
+    """Conv1d(C, N, k, stride 1, padding p) over channels-last frames as ONE strided-row GEMM per pass (training: bf16 operands, fp32
+    accumulation), without materialising the k shifted copies of the input.
+
+    x [B, T, C] -> rows.  The frames are copied once into a zero-padded bf16 row buffer xp [B, T + 2p, C] (row pitch Tp = T + 2p per
+    utterance); output row m = b Tp + t reads the k consecutive rows m .. m + k - 1 of xp (lda = C, K = k C, weights tap-major), so
+    y_full [rows, N] carries the outputs at the same pitch and 2p rows of no meaning after every utterance (the caller slices
+    [:, :T]; their incoming gradient is zero by construction).  Backward: the input gradient is the same kind of GEMM over the
+    zero-padded output gradient with the tap-reversed weights (the 2p meaningless rows between utterances ARE its padding), the weight
+    gradient reads dy and the overlapping-row view of xp in place (ops.wgrad_bf16, TN form).  Returns y_full fp32 [rows_pad, N]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad):
+        B, T, C = x.shape
+        N, _, k = weight.shape
+        Tp = T + 2 * pad
+        rows = B * Tp
+        rows_pad = (rows + 63) // 64 * 64
+        dev = x.device
+        xp = torch.zeros(rows_pad + k, C, device=dev, dtype=torch.bfloat16)
+        xp[:rows].view(B, Tp, C)[:, pad: pad + T] = x.detach()
+        wt = weight.detach().permute(0, 2, 1).reshape(N, k * C).to(torch.bfloat16)            # [N, k C] tap-major
+        y = torch.empty(rows_pad, N, device=dev, dtype=torch.float32)
+        ops.gemm_raw(xp, C, wt, k * C, y, N, rows_pad, N, k * C, bias=None if bias is None else bias.detach().float().contiguous(),
+                     out_f32=True)
+        ctx.save_for_backward(xp, weight)
+        ctx.meta = (B, T, C, N, k, pad, Tp, rows, rows_pad, x.dtype, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight = ctx.saved_tensors
+        B, T, C, N, k, pad, Tp, rows, rows_pad, xdtype, has_bias = ctx.meta
+        dev = dy.device
+        # k zero rows in front (the first utterance's left padding), k behind (the last window of the input-gradient GEMM)
+        dyb = torch.zeros(rows_pad + 2 * k, N, device=dev, dtype=torch.bfloat16)
+        dyb[k: k + rows_pad] = dy
+        dx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            # dx[m] = sum_j dy[m + p - j] W_j = sum_jj dyb_row[m + p + 1 + jj] . W_{k-1-jj}     (dyb rows are shifted by k)
+            wd = weight.detach().flip(2).permute(1, 2, 0).reshape(C, k * N).to(torch.bfloat16)      # [C, (jj, n)]
+            dxf = torch.empty(rows_pad, C, device=dev, dtype=torch.bfloat16)
+            ops.gemm_raw(dyb[pad + 1:], N, wd, k * N, dxf, C, rows_pad, C, k * N)
+            dx = dxf[:rows].view(B, Tp, C)[:, :T].to(xdtype)
+        if ctx.needs_input_grad[1]:
+            cols = torch.as_strided(xp, (rows_pad, k * C), (C, 1))                                 # im2col VIEW: rows overlap
+            g2 = torch.empty(N, k * C, device=dev, dtype=torch.float32)
+            gb = torch.empty(N, device=dev, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
+            ops.wgrad_bf16(dyb[k: k + rows_pad], cols, g2, gb, beta=0.0)
+            gW = g2.view(N, k, C).permute(0, 2, 1)
+        elif has_bias and ctx.needs_input_grad[2]:
+            gb = dy[:rows].sum(0)
+        return dx, gW, gb, None
+
+
 class CIF(nn.Module):
     def __init__(self, cif_threshold=1.0, cif_output_dim=768, encoder_embed_dim=768, produce_weight_type="conv",
                  num_layer=1, conv_cif_width=3, conv_cif_dropout=0.1, apply_scaling=True, apply_tail_handling=True,
@@ -142,12 +197,23 @@ class CIF(nn.Module):
             self.apply_scaling = False                         # cif.py:110-112: permanent once the step is reached
         # conv output of the last weight-generator layer; Dropout -> ReLU -> Dropout -> Linear(C, 1) -> Sigmoid in one row kernel
         # (sigmoid output; clip / masking: sc_cif_prepare)
-        y = self._weight_conv(feats)
         lin = self.weight_proj[1]
         p1 = float(self.conv[-2].p) if self.training else 0.0
         p2 = float(self.weight_proj[0].p) if self.training else 0.0
-        alpha_raw = _CifHeadFn.apply(y.float().contiguous(), lin.weight, lin.bias, p1, ops.next_mult_seed() if p1 > 0 else 0, p2,
-                                     ops.next_mult_seed() if p2 > 0 else 0)
+        seed1 = ops.next_mult_seed() if p1 > 0 else 0
+        seed2 = ops.next_mult_seed() if p2 > 0 else 0
+        last = self.conv[-3]
+        if self.training and last.stride[0] == 1 and last.kernel_size[0] == 2 * last.padding[0] + 1:
+            # training: the last conv layer as a strided-row GEMM over the zero-padded frames; the weight head runs over the GEMM's row
+            # layout (pitch S + 2p per utterance, the extra rows are dropped from alpha)
+            x = self._weight_conv(feats, upto=len(self.conv) - 3)
+            pd = last.padding[0]
+            y_full = _ConvRowsBf16Fn.apply(x, last.weight, last.bias, pd)
+            a_full = _CifHeadFn.apply(y_full.unsqueeze(0), lin.weight, lin.bias, p1, seed1, p2, seed2)
+            alpha_raw = a_full.view(-1)[: B * (S + 2 * pd)].view(B, S + 2 * pd)[:, :S]
+        else:
+            y = self._weight_conv(feats)
+            alpha_raw = _CifHeadFn.apply(y.float().contiguous(), lin.weight, lin.bias, p1, seed1, p2, seed2)
         scaled = bool(self.apply_scaling and target_lengths is not None)
         tail = bool(self.apply_tail_handling and target_lengths is None)
         target = target_lengths.to(device=feats.device, dtype=torch.int64).contiguous() if target_lengths is not None else None
@@ -177,7 +243,7 @@ class CIF(nn.Module):
                 "target_len": target_lengths, "dsample_feats_pad_mask": out_pad, "dsample_feats": output,
                 "dsample_feats_length": feat_lengths, "alpha": st["alpha"], "fired_marks": fired, "input_feats_pad_mask": pad}
 
-    def _weight_conv(self, feats: torch.Tensor) -> torch.Tensor:
+    def _weight_conv(self, feats: torch.Tensor, upto: Optional[int] = None) -> torch.Tensor:
         """``self.conv(feats^T)^T`` (Conv1d k, stride 1, 'same' padding -> Dropout -> ReLU per layer) evaluated channels-last as ONE
         GEMM per layer over the k shifted copies of the input.  Training: bf16 operands / fp32 accumulation on the library's MFMA
         GEMM (the reference trains under precision-16 autocast, and the keyword COUNT is pinned by the target-length scaling, so
@@ -186,7 +252,7 @@ class CIF(nn.Module):
         from .linear_fn import linear_bf16_autograd, linear_f32_autograd
         linear = linear_bf16_autograd if self.training else linear_f32_autograd
         x = feats
-        for i in range(0, len(self.conv), 3):
+        for i in range(0, len(self.conv) if upto is None else upto, 3):
             conv, drop, act = self.conv[i], self.conv[i + 1], self.conv[i + 2]
             k, p = conv.kernel_size[0], conv.padding[0]
             B, T, C = x.shape
