@@ -177,6 +177,8 @@ int sc_conv0_finalize(const double* partial, int32_t nchunk, const float* w0 /*[
                       float* shift, void* stream);
 int sc_conv0_gn_gelu(const float* wav, int64_t ldw, const float* w0, const float* scale, const float* shift,
                      sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream);
+int sc_conv0_gn_gelu_f32(const float* wav, int64_t ldw, const float* w0, const float* scale, const float* shift,
+                         float* out, int32_t B, int32_t R0, int32_t C, void* stream);      /* fp32 debug mode: unrounded stores */
 /* backward of conv layer 0 + GroupNorm + GELU for the fully trainable encoder (speech_encoder_plus.py:556-562; the input is the
  * waveform: parameter gradients only).  dy [B*R0, 512] bf16 = gradient of the layer's output, scale / shift / stats = the forward's
  * (sc_conv0_finalize, sc_conv0_stats with nchunk chunks).  partial: scratch [B, nwc, 512, 12] fp32 (nwc % 4 == 0 wave chunks);
@@ -187,6 +189,8 @@ int sc_conv0_gn_bwd(const float* wav, int64_t ldw, const float* w0, const float*
 /* "layer_norm" extractor mode (HuBERT-large): conv0 (+bias) -> LayerNorm over the 512 channels -> GELU */
 int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma,
                      const float* beta, float eps, sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream);
+int sc_conv0_ln_gelu_f32(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma,
+                         const float* beta, float eps, float* out, int32_t B, int32_t R0, int32_t C, void* stream);   /* fp32 debug mode */
 
 /* ------------------------------------------------------------------------------------------------
  * pos_conv input: zero padded frames (speech_encoder_plus.py:32-33 index_put(x, padding_mask, 0)) and
@@ -275,6 +279,11 @@ int sc_softmax_fwd(const float* scores, const uint8_t* key_mask, sc_bf16* P, sc_
                    int32_t rows_per_batch, float scale, float drop_p, uint32_t drop_seed, void* stream);
 int sc_softmax_bwd(const float* dP, const sc_bf16* P, sc_bf16* dS, int64_t rows, int32_t n, float scale, float drop_p,
                    uint32_t drop_seed, void* stream);
+/* fp32 DEBUG mode (SURVEY 8d "fp32 kernel mode (for debugging)"; host side speechclip_plus_amd/debug_fp32.py): the same kernels with
+ * unrounded fp32 outputs - softmax probabilities here, the conv layer 0 activations below (sc_conv0_gn_gelu_f32, sc_conv0_ln_gelu_f32);
+ * every product of that mode runs on sc_sgemm_mfma_f32 / sc_sgemm_f32_ex, the norms on sc_rowln_f32_fwd, GELU on sc_gelu_f32. */
+int sc_softmax_fwd_f32(const float* scores, const uint8_t* key_mask, float* P, int64_t rows, int32_t n, int32_t rows_per_batch,
+                       float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Continuous integrate-and-fire accumulation (avssl/module/cif.py:157-240; the downsampler of the cascaded+/hybrid+ branches).

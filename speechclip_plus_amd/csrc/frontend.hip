@@ -141,12 +141,14 @@ __global__ __launch_bounds__(256) void conv0_finalize_kernel(const double* __res
 
 // out[b*R0 + t, c] = gelu(conv0(x)[t, c] * scale[b, c] + shift[b, c]); one wave = one output row per step
 // (64 lanes x 8 channels = 512 channels = 1 KiB contiguous store).
+template <bool F32OUT>      // F32OUT: the fp32 debug mode of the encoder (speechclip_plus_amd/debug_fp32.py) - same arithmetic, unrounded stores
 __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int64_t ldw,
                                                             const float* __restrict__ w0,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
-                                                            uint16_t* __restrict__ out, int R0, int C,
+                                                            void* __restrict__ out_, int R0, int C,
                                                             int rows_per_block) {
+    uint16_t* out = (uint16_t*)out_;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     // wave id made provably uniform: the 10-sample window x[5t .. 5t+9] is then fetched with scalar loads (SMEM,
@@ -181,23 +183,31 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
                 o[2 * i] = g.x;
                 o[2 * i + 1] = g.y;
             }
-            uint4 u;
-            u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
-            u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
-            *(uint4*)(out + ((int64_t)b * R0 + t) * C + c0) = u;
+            if constexpr (F32OUT) {
+                float* of = (float*)out_ + ((int64_t)b * R0 + t) * C + c0;
+                *(f32x4*)of = f32x4{o[0], o[1], o[2], o[3]};
+                *(f32x4*)(of + 4) = f32x4{o[4], o[5], o[6], o[7]};
+            } else {
+                uint4 u;
+                u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
+                u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+                *(uint4*)(out + ((int64_t)b * R0 + t) * C + c0) = u;
+            }
         }
     }
 }
 
 // "layer_norm" extractor mode (HuBERT-large): out[b*R0 + t, :] = gelu(LayerNorm_c(conv0(x)[t, :] + bias)), C = 512:
 // one wave per output row, 8 channels per lane, wavefront reductions for the channel statistics.
+template <bool F32OUT>
 __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ wav, int64_t ldw,
                                                             const float* __restrict__ w0,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
-                                                            uint16_t* __restrict__ out, int R0, int rows_per_block) {
+                                                            void* __restrict__ out_, int R0, int rows_per_block) {
     constexpr int C = 512;
+    uint16_t* out = (uint16_t*)out_;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -239,10 +249,16 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
             o[i] = g.x;
             o[i + 1] = g.y;
         }
-        uint4 u;
-        u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
-        u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
-        *(uint4*)(out + ((int64_t)b * R0 + t) * C + c0) = u;
+        if constexpr (F32OUT) {
+            float* of = (float*)out_ + ((int64_t)b * R0 + t) * C + c0;
+            *(f32x4*)of = f32x4{o[0], o[1], o[2], o[3]};
+            *(f32x4*)(of + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        } else {
+            uint4 u;
+            u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
+            u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+            *(uint4*)(out + ((int64_t)b * R0 + t) * C + c0) = u;
+        }
     }
 }
 
@@ -421,7 +437,19 @@ extern "C" int sc_conv0_gn_gelu(const float* wav, int64_t ldw, const float* w0, 
     SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_gn_gelu: alignment");
     const int rows_per_block = 128;
     dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
-    hipLaunchKernelGGL(conv0_gn_gelu_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, scale, shift, out, R0, C, rows_per_block);
+    hipLaunchKernelGGL(conv0_gn_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, scale, shift, (void*)out, R0, C, rows_per_block);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_gn_gelu_f32(const float* wav, int64_t ldw, const float* w0, const float* scale, const float* shift,
+                                    float* out, int32_t B, int32_t R0, int32_t C, void* stream) {
+    SC_CHECK(wav && w0 && scale && shift && out, "sc_conv0_gn_gelu_f32: null pointer");
+    SC_CHECK(C % 512 == 0 && ldw >= 5 * (int64_t)(R0 - 1) + 10, "sc_conv0_gn_gelu_f32: C=%d must be a multiple of 512; ldw too small", C);
+    SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_gn_gelu_f32: alignment");
+    const int rows_per_block = 128;
+    dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
+    hipLaunchKernelGGL(conv0_gn_gelu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, scale, shift, (void*)out, R0, C, rows_per_block);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -433,7 +461,19 @@ extern "C" int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, 
     SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_ln_gelu: alignment");
     const int rows_per_block = 128;
     dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
-    hipLaunchKernelGGL(conv0_ln_gelu_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, out, R0, rows_per_block);
+    hipLaunchKernelGGL(conv0_ln_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, (void*)out, R0, rows_per_block);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_ln_gelu_f32(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma,
+                                    const float* beta, float eps, float* out, int32_t B, int32_t R0, int32_t C, void* stream) {
+    SC_CHECK(wav && w0 && gamma && beta && out, "sc_conv0_ln_gelu_f32: null pointer");
+    SC_CHECK(C == 512 && ldw >= 5 * (int64_t)(R0 - 1) + 10, "sc_conv0_ln_gelu_f32: C must be 512 (got %d); ldw too small", C);
+    SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_ln_gelu_f32: alignment");
+    const int rows_per_block = 128;
+    dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
+    hipLaunchKernelGGL(conv0_ln_gelu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, (void*)out, R0, rows_per_block);
     SC_LAUNCH_CHECK();
     return 0;
 }

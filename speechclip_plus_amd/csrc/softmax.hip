@@ -18,7 +18,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ scores, const uint8_t* __restrict__ mask,
                                                           uint16_t* __restrict__ P, uint16_t* __restrict__ Pd, int64_t rows, int n,
                                                           int rows_per_batch, float scale_log2e, uint32_t thr, float drop_scale,
-                                                          uint32_t seed) {
+                                                          uint32_t seed, float* __restrict__ P32) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t row = wave0; row < rows; row += nwaves) {
@@ -58,6 +58,10 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
             const int c = (i * 64 + lane) * 4;
             if (c >= n) continue;
             float p[4] = {v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv};
+            if (P32) {                                   // fp32 debug mode: unrounded probabilities, nothing else
+                *(float4*)(P32 + row * n + c) = float4{p[0], p[1], p[2], p[3]};
+                continue;
+            }
             uint2 o;
             o.x = pack2bf(p[0], p[1]);
             o.y = pack2bf(p[2], p[3]);
@@ -137,7 +141,23 @@ extern "C" int sc_softmax_fwd(const float* scores, const uint8_t* key_mask, sc_b
     const int nv = (n / 4 + 63) / 64;
     hipStream_t s = (hipStream_t)stream;
 #define SC_SMF(N) hipLaunchKernelGGL((softmax_fwd_kernel<N>), dim3(grid_for(rows)), dim3(256), 0, s, scores, key_mask, P, Pd, rows, n, \
-                                     rows_per_batch, sl, thr, ds, drop_seed)
+                                     rows_per_batch, sl, thr, ds, drop_seed, (float*)nullptr)
+    if (nv <= 1) SC_SMF(1); else if (nv <= 2) SC_SMF(2); else SC_SMF(4);
+#undef SC_SMF
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+// fp32 debug mode of the encoder (speechclip_plus_amd/debug_fp32.py): the same row kernel with unrounded fp32 probabilities
+extern "C" int sc_softmax_fwd_f32(const float* scores, const uint8_t* key_mask, float* P, int64_t rows, int32_t n, int32_t rows_per_batch,
+                                  float scale, void* stream) {
+    SC_CHECK(scores && key_mask && P && rows > 0 && rows_per_batch > 0, "sc_softmax_fwd_f32: bad args");
+    SC_CHECK(n > 0 && n % 4 == 0 && n <= MAXN && ((uintptr_t)P % 16) == 0, "sc_softmax_fwd_f32: n=%d must be a multiple of 4, <= %d", n, MAXN);
+    const float sl = scale * 1.4426950408889634f;
+    const int nv = (n / 4 + 63) / 64;
+    hipStream_t s = (hipStream_t)stream;
+#define SC_SMF(N) hipLaunchKernelGGL((softmax_fwd_kernel<N>), dim3(grid_for(rows)), dim3(256), 0, s, scores, key_mask, (uint16_t*)nullptr, \
+                                     (uint16_t*)nullptr, rows, n, rows_per_batch, sl, 0u, 1.f, 0u, P)
     if (nv <= 1) SC_SMF(1); else if (nv <= 2) SC_SMF(2); else SC_SMF(4);
 #undef SC_SMF
     SC_LAUNCH_CHECK();

@@ -910,3 +910,40 @@ def test_long_utterance_geometry_vs_oracle():
     for n in range(4):
         for b, v in enumerate(valid):
             assert rel_l2(hs[n][b, :v], hs_o[n][b, :v]) < 2e-2, (n, b)
+
+
+@pytest.mark.parametrize("which", ["base", "large"])
+def test_fp32_debug_mode_matches_the_oracle(which):
+    """SURVEY 8d's "fp32 kernel mode (for debugging) <= 1e-4 rel": the encoder run with every tensor in fp32 on the library's exact-fp32
+    kernels (speechclip_plus_amd/debug_fp32.py - same algorithm, masks and row layouts as the production path) must reproduce the fp32
+    oracle's hidden states to ~1e-5, ragged batch, padded frames and key masks included.  What the bf16 production path differs by
+    beyond that is storage precision (cf. tests/test_gpu_recall.py's bf16-storage-emulated oracle)."""
+    import dataclasses
+    import oracle
+    from speechclip_plus_amd import random_hubert_state_dict
+    from speechclip_plus_amd.debug_fp32 import hubert_hidden_states_fp32
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    if which == "base":
+        arch = dataclasses.replace(ARCHS["hubert"], layers=4)
+        o_arch = oracle.HubertArch.base()
+        o_arch.layers = 4
+    else:
+        arch = dataclasses.replace(ARCHS["hubert_large_ll60k"], layers=3)
+        o_arch = oracle.HubertArch.large()
+        o_arch.layers = 3
+    sd = random_hubert_state_dict(arch, seed=11)
+    g = torch.Generator().manual_seed(5)
+    lens = [16000, 9000, 12345]
+    wavs = [torch.randn(l, generator=g) * 0.3 + 0.05 for l in lens]
+    with torch.no_grad():
+        hs, fl = hubert_hidden_states_fp32(sd, arch, wavs, device="cuda:0")
+        hs_o, fl_o = oracle.speech_encoder_forward(sd, o_arch, wavs)
+    assert fl == fl_o.tolist()
+    assert len(hs) == len(hs_o) == arch.layers + 1
+    worst = 0.0
+    for n in range(len(hs)):
+        for b, f in enumerate(fl):                      # valid frames (the oracle's padded frames hold unmasked values too: compare all T)
+            e = rel_l2(hs[n][b], hs_o[n][b])
+            worst = max(worst, e)
+    print(which, "fp32 debug mode: worst hidden-state rel-L2 vs the fp32 oracle", worst)
+    assert worst < 1e-4, worst
