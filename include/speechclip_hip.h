@@ -186,6 +186,11 @@ int sc_conv0_gn_gelu_f32(const float* wav, int64_t ldw, const float* w0, const f
 int sc_conv0_gn_bwd(const float* wav, int64_t ldw, const float* w0, const float* scale, const float* shift, const sc_bf16* dy,
                     const double* stats, int32_t nchunk, const float* gamma, const float* beta, int32_t B, int32_t T0, int32_t R0,
                     int32_t C, float eps, float* partial, int32_t nwc, float* contrib, void* stream);
+/* the same for the "layer_norm" extractor (HuBERT-large: conv 0 (+bias) -> LayerNorm over the 512 channels -> GELU): per wave chunk of
+ * rows 13 sums per channel - partial [B, nwc, 512, 16] fp32 with (dW[c][0..9], dbias[c], dgamma[c], dbeta[c], 3 unused); sum over
+ * B * nwc with sc_colsum_f32 (nwc % 4 == 0). */
+int sc_conv0_ln_bwd(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma, const float* beta, float eps,
+                    const sc_bf16* dy, int32_t B, int32_t T0, int32_t R0, int32_t C, float* partial, int32_t nwc, void* stream);
 /* "layer_norm" extractor mode (HuBERT-large): conv0 (+bias) -> LayerNorm over the 512 channels -> GELU */
 int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma,
                      const float* beta, float eps, sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream);

@@ -116,6 +116,7 @@ SIGNATURES = {
     "sc_conv0_gn_gelu_f32": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "sc_conv0_ln_gelu_f32": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p],
     "sc_softmax_fwd_f32": [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, ctypes.c_float, c_void_p],
+    "sc_conv0_ln_bwd": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p],
     "sc_posconv_prep": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "sc_dropout_mult_f32": [c_void_p, c_i64, c_float, ctypes.c_uint32, c_void_p],
     "sc_posconv_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

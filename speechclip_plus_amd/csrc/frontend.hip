@@ -343,6 +343,89 @@ __global__ __launch_bounds__(256) void conv0_gn_bwd_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------- conv layer 0: backward (LayerNorm form)
+// "layer_norm" extractor (HuBERT-large): y = gelu(n), n = gamma xhat + beta, xhat = (u - mean_c u) rstd, u[t, c] = b[c] + sum_j W[c][j] x[5t + j]
+// with the statistics over the 512 channels of a row.  Per row: dn = dy gelu'(n); dgamma += dn xhat; dbeta += dn;
+//   g = dn gamma;  du = rstd (g - mean_c g - xhat mean_c(g xhat));  db += du;  dW[c][j] += du[c] x[5t + j].
+// Same walk as conv0_gn_bwd_kernel (wave chunk of rows, 8 channels per lane, u recomputed from the waveform), 13 sums per channel:
+// partial[((b * nwc + wc) * 512 + c) * 16 + e], e = 0..9 dW, 10 db, 11 dgamma, 12 dbeta (13..15 unused).
+constexpr int C0L_NS = 16;
+__global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const float* __restrict__ wav, int64_t ldw, const float* __restrict__ w0,
+                                                           const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, const uint16_t* __restrict__ dy,
+                                                           int T0, int R0, int rpw, int nwc, float* __restrict__ partial) {
+    constexpr int C = 512;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wc = blockIdx.x * 4 + wave;
+    const float* x = wav + (int64_t)b * ldw;
+    const int c0 = lane * 8;
+    float w[8][10], bs[8], gm[8], bt[8], acc[8][13];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[i][j] = w0[(c0 + i) * 10 + j];
+        bs[i] = bias ? bias[c0 + i] : 0.f;
+        gm[i] = gamma[c0 + i];
+        bt[i] = beta[c0 + i];
+#pragma unroll
+        for (int e = 0; e < 13; ++e) acc[i][e] = 0.f;
+    }
+    const int t_end = min(T0, (wc + 1) * rpw);
+    for (int t = wc * rpw; t < t_end; ++t) {
+        float v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];              // wave-uniform address: scalar loads
+        const uint4 d = *(const uint4*)(dy + ((int64_t)b * R0 + t) * C + c0);
+        const float gy[8] = {bflo(d.x), bfhi(d.x), bflo(d.y), bfhi(d.y), bflo(d.z), bfhi(d.z), bflo(d.w), bfhi(d.w)};
+        float a[8], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float u = bs[i];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) u = fmaf(w[i][j], v[j], u);
+            a[i] = u;
+            s += u;
+        }
+        const float mean = wave_sum(s) * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sq += (a[i] - mean) * (a[i] - mean);
+        const float rstd = rsqrtf(wave_sum(sq) * (1.0f / C) + eps);
+        float g[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (a[i] - mean) * rstd;
+            const float dn = gy[i] * gelu_grad_as(fmaf(xh, gm[i], bt[i]));
+            acc[i][11] = fmaf(dn, xh, acc[i][11]);
+            acc[i][12] += dn;
+            a[i] = xh;
+            g[i] = dn * gm[i];
+            s1 += g[i];
+            s2 = fmaf(g[i], xh, s2);
+        }
+        const float m1 = wave_sum(s1) * (1.0f / C), m2 = wave_sum(s2) * (1.0f / C);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float du = rstd * (g[i] - m1 - a[i] * m2);
+            acc[i][10] += du;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc[i][j] = fmaf(du, v[j], acc[i][j]);
+        }
+    }
+    if (wc < nwc) {
+        float* pp = partial + (((int64_t)b * nwc + wc) * C + c0) * C0L_NS;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            *(f32x4*)(pp + i * C0L_NS) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+            *(f32x4*)(pp + i * C0L_NS + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+            *(f32x4*)(pp + i * C0L_NS + 8) = f32x4{acc[i][8], acc[i][9], acc[i][10], acc[i][11]};
+            *(f32x4*)(pp + i * C0L_NS + 12) = f32x4{acc[i][12], 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 // one block per utterance, thread = channel (two rounds for 512): wave chunks added in order, then the per-(b, c) algebra in fp64;
 // contrib[b][c][12] = (dW[c][0..9], dgamma, dbeta) of utterance b (summed over b by sc_colsum_f32)
 __global__ __launch_bounds__(256) void conv0_gn_bwd_finalize_kernel(const float* __restrict__ partial, int nwc, const double* __restrict__ stats,
@@ -491,6 +574,20 @@ extern "C" int sc_conv0_gn_bwd(const float* wav, int64_t ldw, const float* w0, c
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv0_gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, nwc, stats, nchunk, w0, gamma, beta, T0,
                        eps, contrib);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_ln_bwd(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma, const float* beta,
+                               float eps, const sc_bf16* dy, int32_t B, int32_t T0, int32_t R0, int32_t C, float* partial, int32_t nwc,
+                               void* stream) {
+    SC_CHECK(wav && w0 && gamma && beta && dy && partial, "sc_conv0_ln_bwd: null pointer");
+    SC_CHECK(C == 512 && B > 0 && T0 > 0 && T0 <= R0 && nwc > 0 && nwc % 4 == 0 && ldw >= 5 * (int64_t)(T0 - 1) + 10,
+             "sc_conv0_ln_bwd: C must be 512 (got %d), nwc a multiple of 4", C);
+    SC_CHECK(((uintptr_t)dy % 16) == 0 && ((uintptr_t)partial % 16) == 0, "sc_conv0_ln_bwd: alignment");
+    const int rpw = (T0 + nwc - 1) / nwc;
+    hipLaunchKernelGGL(conv0_ln_bwd_kernel, dim3(nwc / 4, B), dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps,
+                       (const uint16_t*)dy, T0, R0, rpw, nwc, partial);
     SC_LAUNCH_CHECK();
     return 0;
 }

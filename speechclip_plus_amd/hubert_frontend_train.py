@@ -12,8 +12,8 @@ TrainableLayers.backward with the gradient of ``hidden[0]``:
     ->  conv layers 6 .. 1: GELU' (large: + LayerNorm'), weight gradient = dy^T . (strided im2col VIEW of the layer input, no copy
         of the windows), input gradient = dy . W followed by the overlap-add of the k = 3 / stride 2 windows (k = 2 windows do
         not overlap: a reshape)
-    ->  conv layer 0 (C_in = 1, k = 10) with its GroupNorm (base) / LayerNorm (large): the one piece left to torch autograd
-        (``F.conv1d`` + ``F.group_norm`` / ``F.layer_norm`` + GELU on the fp32 waveform; 1 input channel, 0.3 % of the conv flops).
+    ->  conv layer 0 (C_in = 1, k = 10) with its GroupNorm (base) / LayerNorm (large): own forward / backward kernel pairs
+        (csrc/frontend.hip: sc_conv0_gn_gelu / sc_conv0_gn_bwd, sc_conv0_ln_gelu / sc_conv0_ln_bwd); parameter gradients only.
 
 pos_conv is weight-normalised in fairseq (``weight_g``, ``weight_v``, norm over dims 0, 1): those two tensors are the
 parameters; the folded weight and the chain rule back to them are a few small torch ops on 4.7 M elements.
@@ -119,19 +119,15 @@ class TrainableFrontend(nn.Module):
         # ---- conv layer 0 (+ GroupNorm, GELU): the frozen path's kernels on the CURRENT parameters (analytic GroupNorm statistics from
         # the waveform's Gram matrix, activation written once); the backward (sc_conv0_gn_bwd) recomputes the pre-activation from the
         # waveform, so nothing but the per-(utterance, channel) scale / shift and the Gram partials is kept.  The "layer_norm"
-        # extractor (HuBERT-large) still takes torch autograd for this one layer.
+        # extractor (HuBERT-large) has the same pair of kernels (sc_conv0_ln_gelu / sc_conv0_ln_bwd): statistics per row, nothing kept.
         T0 = pl.T_l[0]
         if ln_mode:
-            with torch.enable_grad():
-                w0 = self.P("feature_extractor.conv_layers.0.0.weight")
-                b0 = self.P("feature_extractor.conv_layers.0.0.bias") if a.conv_bias else None
-                x0 = F.conv1d(pl.wav_pad[:, None, :L], w0, b0, stride=a.conv_strides[0])             # [B, C, T0]
-                n0 = F.layer_norm(x0.transpose(1, 2), (C,), self.P("feature_extractor.conv_layers.0.2.1.weight"),
-                                  self.P("feature_extractor.conv_layers.0.2.1.bias"))
-                f0 = F.gelu(n0)                                                                          # [B, T0, C]
-            st["f0"] = f0
-            assert f0.shape[1] == T0
-            pl.conv[0][: B * pl.R_l[0]].view(B, pl.R_l[0], C)[:, :T0] = f0.detach().to(torch.bfloat16)
+            w0 = ops.aligned16(self.P("feature_extractor.conv_layers.0.0.weight").detach().float().reshape(C, a.conv_kernels[0]).contiguous())
+            b0 = ops.aligned16(self.P("feature_extractor.conv_layers.0.0.bias").detach().float().contiguous()) if a.conv_bias else None
+            g0 = ops.aligned16(self.P("feature_extractor.conv_layers.0.2.1.weight").detach().float().contiguous())
+            be0 = ops.aligned16(self.P("feature_extractor.conv_layers.0.2.1.bias").detach().float().contiguous())
+            ops.conv0_layernorm_gelu(pl.wav_pad, w0, b0, g0, be0, pl.R_l[0], pl.conv[0])
+            st["conv0_ln"] = (w0, b0, g0, be0)
         else:
             w0 = ops.aligned16(self.P("feature_extractor.conv_layers.0.0.weight").detach().float().reshape(C, a.conv_kernels[0]).contiguous())
             g0 = ops.aligned16(self.P("feature_extractor.conv_layers.0.2.weight").detach().float().contiguous())
@@ -270,8 +266,12 @@ class TrainableFrontend(nn.Module):
             acc("feature_extractor.conv_layers.0.0.weight", dW0)
             acc("feature_extractor.conv_layers.0.2.weight", dg0)
             acc("feature_extractor.conv_layers.0.2.bias", db0)
-        else:                                  # "layer_norm" extractor: torch autograd from the saved graph
-            f0 = st["f0"]
-            g0 = df.view(B, pl.R_l[0], C)[:, :T0].float()
-            f0.backward(g0)
+        else:                                  # "layer_norm" extractor (HuBERT-large): sc_conv0_ln_bwd
+            w0, b0, g0, be0 = st["conv0_ln"]
+            dW0, db0, dg0, dbe0 = ops.conv0_layernorm_gelu_bwd(pl.wav_pad, w0, b0, g0, be0, df, T0, pl.R_l[0])
+            acc("feature_extractor.conv_layers.0.0.weight", dW0)
+            if a.conv_bias:
+                acc("feature_extractor.conv_layers.0.0.bias", db0)
+            acc("feature_extractor.conv_layers.0.2.1.weight", dg0)
+            acc("feature_extractor.conv_layers.0.2.1.bias", dbe0)
         pl.front = None

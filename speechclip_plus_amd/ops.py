@@ -662,6 +662,21 @@ def conv0_layernorm_gelu(wav_pad: torch.Tensor, w0: torch.Tensor, bias: Optional
                                  B, R0, C, _stream()), "sc_conv0_ln_gelu")
 
 
+def conv0_layernorm_gelu_bwd(wav_pad: torch.Tensor, w0: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                             dy: torch.Tensor, T0: int, R0: int, eps: float = 1e-5, nwc: int = 32):
+    """Parameter gradients of conv layer 0 (+bias) + LayerNorm + GELU (sc_conv0_ln_bwd): dy [B*R0, 512] bf16 ->
+    (dW0 [C, 10], dbias [C], dgamma [C], dbeta [C])."""
+    B, C = wav_pad.shape[0], w0.shape[0]
+    dev = wav_pad.device
+    partial = torch.empty(B * nwc, C * 16, device=dev, dtype=torch.float32)
+    check(lib().sc_conv0_ln_bwd(_p(wav_pad), wav_pad.stride(0), _p(w0), _p(bias), _p(gamma), _p(beta), float(eps), _p(dy), B, T0, R0, C,
+                                _p(partial), nwc, _stream()), "sc_conv0_ln_bwd")
+    tot = torch.empty(C * 16, device=dev, dtype=torch.float32)
+    colsum(partial, C * 16, B * nwc, C * 16, tot)
+    tot = tot.view(C, 16)
+    return tot[:, :10], tot[:, 10], tot[:, 11], tot[:, 12]
+
+
 def posconv_prep(x: torch.Tensor, valid_len: torch.Tensor, xz: torch.Tensor, xg: torch.Tensor, B: int, R: int, D: int,
                  G: int, halo: int) -> None:
     check(lib().sc_posconv_prep(_p(x), _p(valid_len), _p(xz), _p(xg), B, R, D, G, halo, _stream()), "sc_posconv_prep")
