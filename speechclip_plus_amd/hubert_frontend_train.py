@@ -22,7 +22,6 @@ No shipped recipe trains HuBERT (SURVEY F3); parity: tests/test_gpu_model.py::te
 from typing import Dict
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops
