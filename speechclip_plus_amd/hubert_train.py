@@ -192,10 +192,7 @@ class TrainableLayers(nn.Module):
             gname = "self_attn_layer_norm" if which == 1 else "final_layer_norm"
             if not train:
                 return ops.layernorm_bwd(xin, dy, c[f"ln{which}_g"], 1e-5, dres=dres)
-            dx, dg, db = ops.layernorm_bwd(xin, dy, c[f"ln{which}_g"], 1e-5, dres=dres, want_param_grads=True)
-            P(gname + ".weight").add_(dg)
-            P(gname + ".bias").add_(db)
-            return dx
+            return ops.layernorm_bwd(xin, dy, c[f"ln{which}_g"], 1e-5, dres=dres, acc=(P(gname + ".weight"), P(gname + ".bias")))
 
         def wgrad(dy, xin, name):
             if train:
@@ -229,11 +226,11 @@ class TrainableLayers(nn.Module):
                      dqkv[:, 2 * D:], B, R, H, (D // H) ** -0.5, q_rows=T, drop_p=p_att, drop_seed=sd_a)
         attn_in = s["x1"] if pre_ln else x
         if train:
-            gW = torch.empty(3 * D, D, device=x.device, dtype=torch.float32)
             gb = torch.empty(3 * D, device=x.device, dtype=torch.float32)
-            ops.wgrad_bf16(dqkv, attn_in, gW, gb, beta=0.0)
+            # the fused QKV product's slice reduction adds each D-row block straight into its projection's gradient
+            ops.wgrad_bf16(dqkv, attn_in, [P(f"self_attn.{n}.weight") for n in ("q_proj", "k_proj", "v_proj")], None, beta=1.0)
+            ops.colsum_bf16(dqkv, gb)
             for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
-                P(f"self_attn.{n}.weight").add_(gW[j * D: (j + 1) * D])
                 P(f"self_attn.{n}.bias").add_(gb[j * D: (j + 1) * D])
         if pre_ln:                       # LN1 sits in front of the attention: its parameters need the gradient even at the lowest layer
             if not (need_dx or train):

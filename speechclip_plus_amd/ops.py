@@ -229,8 +229,11 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
 
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float, dres: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None, want_param_grads: bool = False):
-    """dx = LN'(x)(dy) (+ dres) for bf16 rows; with ``want_param_grads`` also returns (dgamma, dbeta) fp32."""
+                  out: Optional[torch.Tensor] = None, want_param_grads: bool = False, acc=None):
+    """dx = LN'(x)(dy) (+ dres) for bf16 rows; with ``want_param_grads`` also returns (dgamma, dbeta) fp32.
+    ``acc`` = (dgamma_target, dbeta_target): the parameter gradients are ADDED to these fp32 [D] tensors by the reduction itself (no
+    temporaries, no add launches); returns dx only."""
+    want_param_grads = want_param_grads or acc is not None
     rows, D = x.shape
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and gamma.dtype == torch.float32
     if out is None:
@@ -245,6 +248,10 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
                                       _p(out), out.stride(0), rows, D, float(eps), _p(dg), _p(db), n_part, _stream()),
           "sc_layernorm_bwd_bf16")
     if not want_param_grads:
+        return out
+    if acc is not None:
+        colsum(dg, D, n_part, D, acc[0], beta=1.0)
+        colsum(db, D, n_part, D, acc[1], beta=1.0)
         return out
     g, b = torch.empty(D, device=x.device, dtype=torch.float32), torch.empty(D, device=x.device, dtype=torch.float32)
     colsum(dg, D, n_part, D, g)
@@ -283,26 +290,55 @@ def colsum_bf16(x: torch.Tensor, out: torch.Tensor, beta: float = 0.0) -> None:
     colsum(part, cols, nblk, cols, out, beta=beta)
 
 
-def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional[torch.Tensor] = None, beta: float = 1.0) -> None:
+def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, gW, gb: Optional[torch.Tensor] = None, beta: float = 1.0) -> None:
     """gW[N, K] = beta gW + dy[rows, N]^T x[rows, K]  (fp32, contiguous) ;  gb[N] = beta gb + colsum(dy).
+    ``gW`` may be a LIST of fp32 contiguous tensors that together hold the N rows in order (q / k / v projection weights of one fused
+    QKV product): the slice reduction writes each block straight into its tensor.
 
     The contraction runs over the rows.  N, K multiples of 256: the TN form of sc_gemm_bf16 reads both operands in place (row-major,
     any row stride - also the overlapping-row im2col view of a conv input), split along the rows into fp32 partials that
     sc_colsum_f32 adds in slice order.  Other shapes (grouped pos_conv: 48 columns): both operands are transposed first."""
     rows, N = dy.shape
     K = x.shape[1]
-    assert x.shape[0] == rows and rows % 64 == 0 and gW.dtype == torch.float32 and gW.is_contiguous() and tuple(gW.shape) == (N, K)
+    blocks = None
+    if isinstance(gW, (list, tuple)):
+        blocks = list(gW)
+        assert all(t.dtype == torch.float32 and t.is_contiguous() and t.shape[1] == K for t in blocks) and sum(t.shape[0] for t in blocks) == N
+        gW = None
+    else:
+        assert gW.dtype == torch.float32 and gW.is_contiguous() and tuple(gW.shape) == (N, K)
+    assert x.shape[0] == rows and rows % 64 == 0
     assert dy.stride(1) == 1 and x.stride(1) == 1
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
-    if N % 256 == 0 and K % 256 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:
+    tn_ok = N % 256 == 0 and K % 256 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+    if blocks is not None and not tn_ok:                     # generic shapes: one temporary, then block adds
+        tmp = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+        wgrad_bf16(dy, x, tmp, None, beta=0.0)
+        r = 0
+        for t in blocks:
+            if beta == 0.0:
+                t.copy_(tmp[r: r + t.shape[0]])
+            else:
+                t.mul_(beta).add_(tmp[r: r + t.shape[0]])
+            r += t.shape[0]
+        if gb is not None:
+            colsum_bf16(dy, gb, beta=beta)
+        return
+    if tn_ok:
         kt = rows // 64
         S = max(1, min(_num_cus() // tiles, kt // 4))     # one round of workgroups; slices of whole K-tiles, the last one shorter
         Kc = -(-kt // S) * 64
         S = -(-rows // Kc)
-        part = gW if (S == 1 and beta == 0.0) else torch.empty(S, N, K, device=dy.device, dtype=torch.float32)
+        part = gW if (S == 1 and beta == 0.0 and gW is not None) else torch.empty(S, N, K, device=dy.device, dtype=torch.float32)
         gemm_raw(dy, dy.stride(0), x, x.stride(0), part, K, N, K, Kc, out_f32=True, nb1=S, sA=(Kc * dy.stride(0), 0),
                  sW=(Kc * x.stride(0), 0), sC=(N * K, 0), tn=True, k_total=rows)
-        if part is not gW:
+        if blocks is not None:
+            r = 0
+            for t in blocks:                                   # rows r .. r + n of every slice are one contiguous run of n K floats
+                n = t.shape[0]
+                colsum(part.view(S, N * K)[:, r * K:], N * K, S, n * K, t, beta=beta)
+                r += n
+        elif part is not gW:
             colsum(part, N * K, S, N * K, gW, beta=beta)
         if gb is not None:
             colsum_bf16(dy, gb, beta=beta)
