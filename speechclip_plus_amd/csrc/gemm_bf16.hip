@@ -17,13 +17,18 @@ namespace {
 constexpr int BK = 64;
 constexpr int ROWB = BK * 2;   // bytes per LDS tile row
 
-template <int BM, int BN>
+// NS = LDS stages.  2: the next K-tile is staged while the current one is multiplied, one __syncthreads (which drains the DMA) per
+// K-tile - two workgroups per CU cover each other's waits.  4 (small problems, at most one workgroup per CU anyway: the text tower's
+// 2048 packed rows): K-tiles are staged THREE ahead, raw barrier + one counted s_waitcnt vmcnt per K-tile: 23.3 -> 18.2 us on the
+// K = 2048 products (tools/bench_small_gemm.py).  Six stages measured the same: past the round-trip latency a 128 x 64 tile is bound by
+// the LDS-DMA rate of its CU (24 KiB per K-tile at ~21 B/clk, the same per-CU rate the 256-row kernel stages at).
+template <int BM, int BN, int NS = 2>
 struct GemmCfg {
     static constexpr int WM = 2, WN = 2;
     static constexpr int TM = BM / WM, TN = BN / WN;
     static constexpr int FM = TM / 16, FN = TN / 16;
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    static constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES);
+    static constexpr int STAGE_BYTES = NS * (A_BYTES + B_BYTES);
     static constexpr int EPI_BYTES = BM * BN * 4;
     static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
@@ -33,9 +38,9 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
-    using Cfg = GemmCfg<BM, BN>;
+    using Cfg = GemmCfg<BM, BN, NS>;
     constexpr int FM = Cfg::FM, FN = Cfg::FN, TM = Cfg::TM, TN = Cfg::TN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
         b_src[i] = W + (int64_t)gn_row * p.ldw + c * 8;
     }
     char* const As = smem;
-    char* const Bs = smem + 2 * Cfg::A_BYTES;
+    char* const Bs = smem + NS * Cfg::A_BYTES;
 
     auto stage = [&](int buf, int k0) {
 #pragma unroll
@@ -132,11 +137,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
         const int c = kt / 3, j = kt - 3 * c;
         return (j == 0 ? 0 : (3 - j) * tap_c) + c * BK;
     };
-    stage(0, 0);
-    __syncthreads();   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, koff(kt + 1));
+    auto mma_tile = [&](int buf) {
         const char* as = As + buf * Cfg::A_BYTES;
         const char* bs = Bs + buf * Cfg::B_BYTES;
 #pragma unroll
@@ -152,7 +153,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
                 for (int ni = 0; ni < FN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
         }
-        __syncthreads();
+    };
+    if constexpr (NS == 2) {
+        stage(0, 0);
+        __syncthreads();   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) stage(buf ^ 1, koff(kt + 1));
+            mma_tile(buf);
+            __syncthreads();
+        }
+    } else {
+        // K-tiles kt .. kt + NS - 2 in flight.  Per K-tile: wait until tile kt has landed (all but the NS - 2 newest stages of THIS
+        // wave), barrier (every wave's share has landed, and every wave is done with tile kt - 1), re-stage tile kt - 1's buffer
+        // with tile kt + NS - 1, multiply.
+        constexpr int IPW = A_INST + B_INST;                  // LDS-DMA instructions per wave and stage
+#pragma unroll
+        for (int j = 0; j < NS - 1; ++j)
+            if (j < nk) stage(j, koff(j));
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, koff(kt + NS - 1));
+            mma_tile(kt % NS);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // the epilogue reuses the ring
+        asm volatile("" ::: "memory");
     }
 
     // ---- epilogue --------------------------------------------------------------------------------------
@@ -239,17 +269,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NS = 2>
 int launch(const sc_gemm_args& a, hipStream_t s) {
-    using Cfg = GemmCfg<BM, BN>;
+    using Cfg = GemmCfg<BM, BN, NS>;
     static sc_lds_attr_once attr;
-    if (hipError_t e = sc_set_max_lds_once(attr, gemm_bf16_kernel<BM, BN>, Cfg::LDS_BYTES); e != hipSuccess) {
+    if (hipError_t e = sc_set_max_lds_once(attr, gemm_bf16_kernel<BM, BN, NS>, Cfg::LDS_BYTES); e != hipSuccess) {
         sc_set_error("hipFuncSetAttribute(gemm %dx%d): %s", BM, BN, hipGetErrorString(e));
         return -3;
     }
     const int nM = (a.M + BM - 1) / BM, nN = (a.N + BN - 1) / BN;
     dim3 grid(nM * nN, 1, a.nb1 * a.nb2);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, NS>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -342,9 +372,13 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
             SC_CHECK(a.n_split < 0 || a.n_split % 192 == 0 || a.n_split % 256 == 0,
                      "sc_gemm_bf16: 256-row tiles need n_split %% 192 == 0 or %% 256 == 0");
             return sc_gemm256_launch(a, s);
-        case 3:
+        case 3: case 13: {
             SC_CHECK(a.n_split < 0, "sc_gemm_bf16: 128x64 tile has no transposed store");
+            // at most one workgroup per CU anyway: the 4-stage ring hides the operand round trips the second workgroup would have
+            const int64_t wgs = (int64_t)((a.M + 127) / 128) * ((a.N + 63) / 64) * a.nb1 * a.nb2;
+            if (tile == 13 || (a.tile == 0 && wgs <= (int64_t)sc_num_cus() && a.K >= 1024)) return launch<128, 64, 4>(a, s);
             return launch<128, 64>(a, s);
+        }
         default: sc_set_error("sc_gemm_bf16: tile=%d", a.tile); return -1;
     }
 }

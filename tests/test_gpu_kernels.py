@@ -1238,3 +1238,28 @@ def test_posconv_weight_gradient_kernel(dev, Dg, G, B, R):
         ref[:, :, tap] = torch.einsum("gbtc,gbti->gci", dr, xr[:, :, tap: tap + R])
     got = gw.double().cpu().view(G, Dg, Kp, Dg)
     assert float((got - ref).norm() / ref.norm()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_gemm_small_tile_ring_variants_agree_bitwise(dev):
+    """128 x 64 tiles, 2-stage and 4-stage LDS ring (tile 3 / 13; the dispatcher picks the deep ring for small grids with long K):
+    same K order, same epilogue - identical bits, with bias, GELU and residual."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for (M, N, K, act, res) in ((2048, 512, 2048, 0, True), (1000, 192, 1088, 1, False), (128, 64, 64, 0, False)):
+        A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        R = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev) if res else None
+        outs = []
+        for t in (3, 13, 0):
+            C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            ops.gemm_raw(A, K, W, K, C, N, M, N, K, bias=bias, residual=R, ldr=N, act=act, tile=t)
+            outs.append(C)
+        ref = A.float() @ W.float().t() + bias
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        if res:
+            ref = ref + R.float()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert rel_l2(outs[0], ref) < 6e-3

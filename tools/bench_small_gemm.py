@@ -16,7 +16,7 @@ for name, m, n, k in shapes:
     bias = torch.randn(n, device=dev)
     C = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
     row = {}
-    for t in (1, 3, 2):
+    for t in (1, 3, 13, 2):
         if t == 2 and (m < 512 or n < 192):
             continue
         ts = []
@@ -30,4 +30,7 @@ for name, m, n, k in shapes:
             if r:
                 ts.append(e0.elapsed_time(e1) / 10 * 1e3)
         row[t] = round(sorted(ts)[len(ts) // 2], 1)
-    print(name, m, n, k, row, flush=True)
+    C3 = torch.empty_like(C); C13 = torch.empty_like(C)
+    ops.gemm_raw(A, k, W, k, C3, n, m, n, k, bias=bias, tile=3)
+    ops.gemm_raw(A, k, W, k, C13, n, m, n, k, bias=bias, tile=13)
+    print(name, m, n, k, row, "bitwise 3 == 13:", bool(torch.equal(C3, C13)), flush=True)
