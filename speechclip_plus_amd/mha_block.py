@@ -63,7 +63,9 @@ class MhaNormFn(torch.autograd.Function):
         xb[:, :S] = x.detach()
         xb = xb.view(M, Dm)
         if dh == dh_true:
-            Wi_b, Wo_b, bi_f = Wi.detach().to(bf).contiguous(), Wo.detach().to(bf).contiguous(), bi.detach().float().contiguous()
+            Wi_b = ops.derived(Wi, "bf16", lambda t: t.to(bf).contiguous())
+            Wo_b = ops.derived(Wo, "bf16", lambda t: t.to(bf).contiguous())
+            bi_f = bi.detach().float().contiguous()
         else:
             Wi_b = torch.zeros(3, H, dh, Dm, device=dev, dtype=bf)
             Wi_b[:, :, :dh_true] = Wi.detach().view(3, H, dh_true, Dm)
@@ -94,6 +96,9 @@ class MhaNormFn(torch.autograd.Function):
         out = ops.layernorm_bf16(pre, g32, b32, eps=eps)
         ctx.save_for_backward(xb, Wi_b, Wo_b, qkv, P, Pd if p_drop > 0.0 else None, cx, pre, g32)
         ctx.meta = (B, S, Sp, D, H, dh, eps, p_drop, seed, x.dtype, Dm, dh_true, p_res, seed_res)
+        # transposed bf16 copies for the input-gradient products: per parameter version when the weights are used as they are
+        ctx.wT = (ops.derived(Wi, "bf16T", lambda t: t.to(bf).t().contiguous()), ops.derived(Wo, "bf16T", lambda t: t.to(bf).t().contiguous())) \
+            if dh == dh_true else None
         return out.view(B, Sp, Dm)[:, :S].to(x.dtype)
 
     @staticmethod
@@ -113,7 +118,8 @@ class MhaNormFn(torch.autograd.Function):
         gbo = torch.empty(Dm, device=dev, dtype=torch.float32)
         dbr = ops.dropout_bf16(dpre, p_res, seed_res) if p_res > 0.0 else dpre                # the dropped branch's gradient
         ops.wgrad_bf16(dbr, cx, gWo, gbo, beta=0.0)
-        dcx = ops.linear_bf16(dbr, Wo_b.t().contiguous())                                     # [M, D]
+        WiT, WoT = ctx.wT if ctx.wT is not None else (Wi_b.t().contiguous(), Wo_b.t().contiguous())
+        dcx = ops.linear_bf16(dbr, WoT)                                                        # [M, D]
         # ---- core: dP = dctx V^T ; dS = P (dP - rowsum(P dP)) scale
         dP = torch.empty(B, H, Sp, Sp, device=dev, dtype=torch.float32)
         ops.gemm_raw(dcx, D, qkv[:, 2 * D:], 3 * D, dP, Sp, Sp, Sp, dh, out_f32=True, nb1=B, nb2=H,
@@ -121,25 +127,34 @@ class MhaNormFn(torch.autograd.Function):
         dS = ops.softmax_bwd(dP, P, dh_true ** -0.5, p_drop, seed)
         del dP
         dqkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
-        # dV = Pd^T dctx   (A = Pd^T from one 2-D transpose [Sp, B H Sp]; W = dctx^T [D, M])
-        PT = ops.transpose_bf16(Pd.view(B * H * Sp, Sp))
-        dcxT = ops.transpose_bf16(dcx)
-        ops.gemm_raw(PT, B * H * Sp, dcxT, M, dqkv[:, 2 * D:], 3 * D, Sp, dh, Sp, nb1=B, nb2=H,
-                     sA=(H * Sp, Sp), sW=(Sp, dh * M), sC=(Sp * 3 * D, dh))
+        tn = Sp % 256 == 0 and dh % 256 == 0                # the TN form reads Pd / dS and dctx / Q in place (sum over their rows)
+        # dV = Pd^T dctx
+        if tn:
+            ops.gemm_raw(Pd, Sp, dcx, D, dqkv[:, 2 * D:], 3 * D, Sp, dh, Sp, nb1=B, nb2=H,
+                         sA=(H * Sp * Sp, Sp * Sp), sW=(Sp * D, dh), sC=(Sp * 3 * D, dh), tn=True)
+        else:               # A = Pd^T from one 2-D transpose [Sp, B H Sp]; W = dctx^T [D, M]
+            PT = ops.transpose_bf16(Pd.view(B * H * Sp, Sp))
+            dcxT = ops.transpose_bf16(dcx)
+            ops.gemm_raw(PT, B * H * Sp, dcxT, M, dqkv[:, 2 * D:], 3 * D, Sp, dh, Sp, nb1=B, nb2=H,
+                         sA=(H * Sp, Sp), sW=(Sp, dh * M), sC=(Sp * 3 * D, dh))
         # dQ = dS K   (W = K^T [D, M])
         kT = ops.transpose_bf16(qkv[:, D: 2 * D])
         ops.gemm_raw(dS, Sp, kT, M, dqkv, 3 * D, Sp, dh, Sp, nb1=B, nb2=H,
                      sA=(H * Sp * Sp, Sp * Sp), sW=(Sp, dh * M), sC=(Sp * 3 * D, dh))
-        # dK = dS^T Q  (A = dS^T, W = Q^T)
-        dST = ops.transpose_bf16(dS.view(B * H * Sp, Sp))
-        qT = ops.transpose_bf16(qkv[:, :D])
-        ops.gemm_raw(dST, B * H * Sp, qT, M, dqkv[:, D: 2 * D], 3 * D, Sp, dh, Sp, nb1=B, nb2=H,
-                     sA=(H * Sp, Sp), sW=(Sp, dh * M), sC=(Sp * 3 * D, dh))
+        # dK = dS^T Q
+        if tn:
+            ops.gemm_raw(dS, Sp, qkv, 3 * D, dqkv[:, D: 2 * D], 3 * D, Sp, dh, Sp, nb1=B, nb2=H,
+                         sA=(H * Sp * Sp, Sp * Sp), sW=(Sp * 3 * D, dh), sC=(Sp * 3 * D, dh), tn=True)
+        else:               # A = dS^T, W = Q^T
+            dST = ops.transpose_bf16(dS.view(B * H * Sp, Sp))
+            qT = ops.transpose_bf16(qkv[:, :D])
+            ops.gemm_raw(dST, B * H * Sp, qT, M, dqkv[:, D: 2 * D], 3 * D, Sp, dh, Sp, nb1=B, nb2=H,
+                         sA=(H * Sp, Sp), sW=(Sp, dh * M), sC=(Sp * 3 * D, dh))
         # ---- in_proj (+ the residual branch's gradient)
         gWi = torch.empty(3 * D, Dm, device=dev, dtype=torch.float32)
         gbi = torch.empty(3 * D, device=dev, dtype=torch.float32)
         ops.wgrad_bf16(dqkv, xb, gWi, gbi, beta=0.0)
-        dx = ops.linear_bf16(dqkv, Wi_b.t().contiguous(), residual=dpre)
+        dx = ops.linear_bf16(dqkv, WiT, residual=dpre)
         dx = dx.view(B, Sp, Dm)[:, :S].to(xdtype)
         if dh != dh_true:                                   # drop the gradients of the zero padding
             gWi = gWi.view(3, H, dh, Dm)[:, :, :dh_true].reshape(3 * Dm, Dm)

@@ -280,6 +280,24 @@ def _num_cus() -> int:
     return _cus[0]
 
 
+_derived = {}
+
+
+def derived(param: torch.Tensor, tag: str, fn):
+    """``fn(param.detach())`` cached per parameter VERSION (bf16 working copies, transposed copies of trainable weights: computed once
+    per optimiser step instead of once per call).  The key carries optim.param_generation() because the fused Adam kernel writes the
+    masters through a raw pointer (no ``_version`` bump)."""
+    from .optim import param_generation
+    key = (id(param), tag)
+    ver = (param.data_ptr(), param._version, param_generation(), tuple(param.shape))
+    hit = _derived.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    val = fn(param.detach())
+    _derived[key] = (ver, val)
+    return val
+
+
 def colsum_bf16(x: torch.Tensor, out: torch.Tensor, beta: float = 0.0) -> None:
     """out[c] = beta out[c] + sum_r x[r, c]  (bf16 rows -> fp32; bias gradients): row-block partials, then sc_colsum_f32 in block order."""
     rows, cols = x.shape
