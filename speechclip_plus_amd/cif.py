@@ -114,7 +114,7 @@ class _ConvRowsBf16Fn(torch.autograd.Function):
         dev = x.device
         xp = torch.zeros(rows_pad + k, C, device=dev, dtype=torch.bfloat16)
         xp[:rows].view(B, Tp, C)[:, pad: pad + T] = x.detach()
-        wt = weight.detach().permute(0, 2, 1).reshape(N, k * C).to(torch.bfloat16)            # [N, k C] tap-major
+        wt = ops.derived(weight, "conv_rows", lambda t: t.permute(0, 2, 1).reshape(N, k * C).to(torch.bfloat16))   # [N, k C] tap-major
         y = torch.empty(rows_pad, N, device=dev, dtype=torch.float32)
         ops.gemm_raw(xp, C, wt, k * C, y, N, rows_pad, N, k * C, bias=None if bias is None else bias.detach().float().contiguous(),
                      out_f32=True)
@@ -133,7 +133,7 @@ class _ConvRowsBf16Fn(torch.autograd.Function):
         dx = gW = gb = None
         if ctx.needs_input_grad[0]:
             # dx[m] = sum_j dy[m + p - j] W_j = sum_jj dyb_row[m + p + 1 + jj] . W_{k-1-jj}     (dyb rows are shifted by k)
-            wd = weight.detach().flip(2).permute(1, 2, 0).reshape(C, k * N).to(torch.bfloat16)      # [C, (jj, n)]
+            wd = ops.derived(weight, "conv_rows_T", lambda t: t.flip(2).permute(1, 2, 0).reshape(C, k * N).to(torch.bfloat16))   # [C, (jj, n)]
             dxf = torch.empty(rows_pad, C, device=dev, dtype=torch.bfloat16)
             ops.gemm_raw(dyb[pad + 1:], N, wd, k * N, dxf, C, rows_pad, C, k * N)
             dx = dxf[:rows].view(B, Tp, C)[:, :T].to(xdtype)

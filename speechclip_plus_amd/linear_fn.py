@@ -23,9 +23,10 @@ class LinearBf16Fn(torch.autograd.Function):
         rp = (rows + 63) // 64 * 64
         xb = torch.zeros(rp, K, device=x.device, dtype=torch.bfloat16)
         xb[:rows] = x.reshape(rows, K)
-        wb = weight.detach().to(torch.bfloat16).contiguous()
+        wb = ops.derived(weight, "bf16", lambda t: t.to(torch.bfloat16).contiguous())     # once per parameter version
         y = ops.linear_bf16(xb, wb, None if bias is None else bias.detach().float().contiguous())
         ctx.save_for_backward(xb, wb)
+        ctx.wT = ops.derived(weight, "bf16T", lambda t: t.to(torch.bfloat16).t().contiguous()) if weight.dim() == 2 else None
         ctx.meta = (shape, rows, rp, K, N, x.dtype, bias is not None)
         return y[:rows].to(x.dtype).reshape(*shape[:-1], N)
 
@@ -37,7 +38,7 @@ class LinearBf16Fn(torch.autograd.Function):
         dyb[:rows] = dy.reshape(rows, N)
         dx = gW = gb = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear_bf16(dyb, wb.t().contiguous())[:rows].to(dtype).reshape(shape)
+            dx = ops.linear_bf16(dyb, ctx.wT if ctx.wT is not None else wb.t().contiguous())[:rows].to(dtype).reshape(shape)
         if ctx.needs_input_grad[1]:
             gW = torch.empty(N, K, device=dy.device, dtype=torch.float32)
             if has_bias and ctx.needs_input_grad[2]:

@@ -288,6 +288,8 @@ def derived(param: torch.Tensor, tag: str, fn):
     per optimiser step instead of once per call).  The key carries optim.param_generation() because the fused Adam kernel writes the
     masters through a raw pointer (no ``_version`` bump)."""
     from .optim import param_generation
+    if not isinstance(param, torch.nn.Parameter):       # a temporary: its id / address can be recycled for different contents
+        return fn(param.detach())
     key = (id(param), tag)
     ver = (param.data_ptr(), param._version, param_generation(), tuple(param.shape))
     hit = _derived.get(key)
@@ -296,6 +298,11 @@ def derived(param: torch.Tensor, tag: str, fn):
     val = fn(param.detach())
     _derived[key] = (ver, val)
     return val
+
+
+def invalidate_derived() -> None:
+    """Forget every cached derived copy (after writing parameters through ``.data``, which bumps no version counter)."""
+    _derived.clear()
 
 
 def colsum_bf16(x: torch.Tensor, out: torch.Tensor, beta: float = 0.0) -> None:
