@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--ragged", action="store_true", help="SURVEY 8d's variable-length run: utterance lengths U{32000 .. --seconds * 16000} "
+                    "(seeded) instead of all-equal; algorithmic flops then count every utterance at ITS OWN length (padding is not work)")
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances in the CPU-baseline sample: BASELINE configs[0] = batch 8 (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=3, help="timed CPU iterations per thread setting (after 1 warm-up)")
     ap.add_argument("--cpu-full", action="store_true", help="the CPU baseline exactly as SURVEY 8d states it: 3 warm-up + 10 timed "
@@ -116,6 +118,10 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(7122 + rank)
     wav = torch.randn(B, L, generator=g).to(dev)
     wav_len = torch.full((B,), L, dtype=torch.long)
+    if args.ragged:
+        wav_len = torch.randint(min(32000, L), L + 1, (B,), generator=g)
+        wav_len[0] = L                                   # the batch is padded to its longest utterance: keep the geometry
+        wav = wav * (torch.arange(L).unsqueeze(0) < wav_len.unsqueeze(1)).to(dev)
     img = torch.nn.functional.normalize(torch.randn(B, E, generator=g), dim=-1).to(dev)
     ids = (torch.arange(B) + rank * B) // 5            # Flickr8k shape: 5 captions per image id
     batch = {"wav": wav, "wav_len": wav_len, "image": img, "id": ids.to(dev)}
@@ -226,7 +232,9 @@ def main():
                                     "hybrid_plus_large": "Hybrid+ large train step (HuBERT-large frozen fwd + weighted sum + shared attention "
                                                          "block: CLS row -> parallel embedding, frames -> CIF / VQ / frozen CLIP ViT-L/14 text "
                                                          "tower, fwd/bwd + both InfoNCE losses + quantity loss + Adam)"}[args.model] +
-                                   f", {B} utt/GPU x {args.seconds:g} s (L={L}, T={T}), CLIP image embeddings given",
+                                   f", {B} utt/GPU x {args.seconds:g} s (L={L}, T={T})" +
+                                   (f", RAGGED lengths U{{32000..{L}}} (mean {float(wav_len.float().mean()) / 16000:.2f} s)" if args.ragged else "") +
+                                   ", CLIP image embeddings given",
                        "global_batch": B * world, "per_gpu_batch": B, "audio_samples": L, "frames": T,
                        "parallelism": f"dp{world}", "dropout": ("off (--no-dropout)" if args.no_dropout else
                                    "on, as the reference's train step: HuBERT in train mode (base: input / residual / attention "
@@ -234,8 +242,8 @@ def main():
             "rccl_ranks": rccl_ranks, "dist_backend": (os.environ.get("SC_DIST_BACKEND", "nccl") if dist is not None else None),
             "collectives": collectives,
             "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,
-            "forward": None if fwd_ms is None else forward_summary(fwd_ms, B, L, T),
-            "forward_train_mode": None if fwd_train_ms is None else forward_summary(fwd_train_ms, B, L, T),
+            "forward": None if fwd_ms is None else forward_summary(fwd_ms, B, L, T, wav_len.tolist() if args.ragged else None),
+            "forward_train_mode": None if fwd_train_ms is None else forward_summary(fwd_train_ms, B, L, T, wav_len.tolist() if args.ragged else None),
             "recall": recall,
         }
         print(json.dumps(result), flush=True)
@@ -345,22 +353,25 @@ def rehearse_launch(args, world: int) -> None:
         dist.destroy_process_group()
 
 
-def forward_summary(fwd_ms, B, L, T):
+def forward_summary(fwd_ms, B, L, T, lens=None):
     """Algorithmic flops of the HuBERT-base + CLS-pool forward (SURVEY 8d formulae, conv extractor included; the
-    collapsed CLS head is ~0.013 GFLOP/utt) over the measured forward time."""
-    conv_T, t, cin = [], L, 1
-    ks, ss = (10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)
-    flop = 0.0
-    for k, s_ in zip(ks, ss):
-        t = (t - k) // s_ + 1
-        flop += 2.0 * t * 512 * cin * k
-        cin = 512
-    D, F, NL = 768, 3072, 12
-    flop += 2.0 * T * 512 * D                                  # post_extract_proj
-    flop += 2.0 * T * D * (D // 16) * 128                      # pos_conv
-    flop += NL * T * 2.0 * (4 * D * D + 2 * D * F)             # linear layers
-    flop += NL * 4.0 * T * T * D                               # attention
-    flop += 0.013e9
+    collapsed CLS head is ~0.013 GFLOP/utt) over the measured forward time.  ``lens``: per-utterance sample counts of a ragged
+    batch - every utterance then counts at its own length (mean reported)."""
+    def one(Lb):
+        t, cin, flop = Lb, 1, 0.0
+        ks, ss = (10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)
+        for k, s_ in zip(ks, ss):
+            t = (t - k) // s_ + 1
+            flop += 2.0 * t * 512 * cin * k
+            cin = 512
+        Tb = t
+        D, F, NL = 768, 3072, 12
+        flop += 2.0 * Tb * 512 * D                                  # post_extract_proj
+        flop += 2.0 * Tb * D * (D // 16) * 128                      # pos_conv
+        flop += NL * Tb * 2.0 * (4 * D * D + 2 * D * F)             # linear layers
+        flop += NL * 4.0 * Tb * Tb * D                              # attention
+        return flop + 0.013e9
+    flop = one(L) if lens is None else sum(one(int(l)) for l in lens) / len(lens)
     tfl = flop * B / (fwd_ms * 1e-3) / 1e12
     return {"ms": round(fwd_ms, 3), "utterances_per_s": round(B / fwd_ms * 1e3, 1), "alg_gflop_per_utt": round(flop / 1e9, 2),
             "alg_tflops": round(tfl, 1), "frac_of_mfma_bf16_peak": round(tfl / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
