@@ -362,35 +362,37 @@ __global__ __launch_bounds__(256) void vq_norm_bwd_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------ keyword BatchNorm (kw_bn.py:167-228)
 // nn.BatchNorm1d over the keyword positions: x [N, E] fp32 (N = batch x keyword slots, padded slots included, as the reference's
-// permute(0, 2, 1) view feeds them), statistics per channel.  One workgroup per 32 channels (8 row lanes x 32 columns: every
-// load instruction reads whole 128-byte segments); two-pass mean / variance, then the normalisation, all out of the L2.
-__device__ __forceinline__ float col_reduce8(float v, float (*red)[33]) {       // sum over the 8 row lanes of a column
+// permute(0, 2, 1) view feeds them), statistics per channel.  One workgroup per 32 channels, 1024 threads = 32 row lanes x 32 columns
+// (every load instruction reads whole 128-byte segments; 8 row lanes left each thread a 200-row serial walk per pass: 102 -> ~30 us);
+// two-pass mean / variance, then the normalisation, all out of the L2.  The row lanes are added in fixed order.
+constexpr int BN_RL = 32;                                                         // row lanes
+__device__ __forceinline__ float col_reduce8(float v, float (*red)[33]) {       // sum over the row lanes of a column
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
     __syncthreads();
     red[r][c] = v;
     __syncthreads();
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += red[i][c];
+    for (int i = 0; i < BN_RL; ++i) s += red[i][c];
     return s;
 }
 
-__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x, int64_t ldx, int N, int E, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void bn_fwd_kernel(const float* __restrict__ x, int64_t ldx, int N, int E, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ run_mean,
                                                      float* __restrict__ run_var, int training, float momentum, float eps,
                                                      float* __restrict__ y, int64_t ldy, float* __restrict__ save_mean,
                                                      float* __restrict__ save_rstd) {
-    __shared__ float red[8][33];
+    __shared__ float red[BN_RL][33];
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + c;
     const bool ok = e < E;
     float mean, rstd;
     if (training) {
         float s = 0.f;
-        for (int n = r; n < N; n += 8) s += ok ? x[(int64_t)n * ldx + e] : 0.f;
+        for (int n = r; n < N; n += BN_RL) s += ok ? x[(int64_t)n * ldx + e] : 0.f;
         mean = col_reduce8(s, red) / (float)N;
         float q = 0.f;
-        for (int n = r; n < N; n += 8) {
+        for (int n = r; n < N; n += BN_RL) {
             const float d = ok ? x[(int64_t)n * ldx + e] - mean : 0.f;
             q = fmaf(d, d, q);
         }
@@ -408,21 +410,21 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x
     }
     if (!ok) return;
     const float g = gamma[e] * rstd, b = beta[e] - mean * gamma[e] * rstd;
-    for (int n = r; n < N; n += 8) y[(int64_t)n * ldy + e] = fmaf(x[(int64_t)n * ldx + e], g, b);
+    for (int n = r; n < N; n += BN_RL) y[(int64_t)n * ldy + e] = fmaf(x[(int64_t)n * ldx + e], g, b);
 }
 
 // dx = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)) ; dgamma = sum dy xhat ; dbeta = sum dy       (training statistics)
-__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t ldg,
+__global__ __launch_bounds__(1024) void bn_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t ldg,
                                                      int N, int E, const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                                      const float* __restrict__ save_rstd, float* __restrict__ dx, int64_t ldd,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float red[8][33];
+    __shared__ float red[BN_RL][33];
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + c;
     const bool ok = e < E;
     const float mean = ok ? save_mean[e] : 0.f, rstd = ok ? save_rstd[e] : 0.f;
     float sb = 0.f, sg = 0.f;
-    for (int n = r; n < N; n += 8) {
+    for (int n = r; n < N; n += BN_RL) {
         const float g = ok ? dy[(int64_t)n * ldg + e] : 0.f;
         const float xh = ok ? (x[(int64_t)n * ldx + e] - mean) * rstd : 0.f;
         sb += g;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ x
         dbeta[e] = sb;
     }
     const float k = gamma[e] * rstd, mb = sb / (float)N, mg = sg / (float)N;
-    for (int n = r; n < N; n += 8) {
+    for (int n = r; n < N; n += BN_RL) {
         const float xh = (x[(int64_t)n * ldx + e] - mean) * rstd;
         dx[(int64_t)n * ldd + e] = k * (dy[(int64_t)n * ldg + e] - mb - xh * mg);
     }
@@ -537,7 +539,7 @@ extern "C" int sc_bn_rows_fwd(const float* x, int64_t ldx, int32_t N, int32_t E,
                               float* save_rstd, void* stream) {
     SC_CHECK(x && gamma && beta && run_mean && run_var && y, "sc_bn_rows_fwd: null pointer");
     SC_CHECK(N > 0 && E > 0 && (!training || (save_mean && save_rstd)), "sc_bn_rows_fwd: bad arguments");
-    hipLaunchKernelGGL(bn_fwd_kernel, dim3((E + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, N, E, gamma, beta, run_mean, run_var,
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3((E + 31) / 32), dim3(32 * BN_RL), 0, (hipStream_t)stream, x, ldx, N, E, gamma, beta, run_mean, run_var,
                        training, momentum, eps, y, ldy, save_mean, save_rstd);
     SC_LAUNCH_CHECK();
     return 0;
@@ -548,7 +550,7 @@ extern "C" int sc_bn_rows_bwd(const float* x, int64_t ldx, const float* dy, int6
                               void* stream) {
     SC_CHECK(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta, "sc_bn_rows_bwd: null pointer");
     SC_CHECK(N > 0 && E > 0, "sc_bn_rows_bwd: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3((E + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, ldg, N, E, gamma, save_mean,
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3((E + 31) / 32), dim3(32 * BN_RL), 0, (hipStream_t)stream, x, ldx, dy, ldg, N, E, gamma, save_mean,
                        save_rstd, dx, ldd, dgamma, dbeta);
     SC_LAUNCH_CHECK();
     return 0;
