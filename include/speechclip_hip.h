@@ -146,6 +146,13 @@ int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k, int64_t ld
                      int32_t q_rows /* query rows t >= q_rows carry dout = 0 (layout padding) */, float scale, int32_t causal,
                      float drop_p, uint32_t drop_seed /* the forward's probability dropout: same mask, regenerated */,
                      void* stream);
+/* the same with the operand preparation inside: qT / kT / doT are scratch [B, H, 64, R] the call fills in ONE launch (three head
+ * transposes + delta), followed by the dq and dk/dv kernels - 3 launches instead of 6 */
+int sc_attn_bwd_fused_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k, int64_t ldk, const sc_bf16* v, int64_t ldv,
+                           const sc_bf16* out, int64_t ldo, const sc_bf16* dout, int64_t lddo, sc_bf16* qT, sc_bf16* kT,
+                           sc_bf16* doT, const float* lse2, float* delta, const int32_t* valid_len, sc_bf16* dq,
+                           int64_t lddq, sc_bf16* dk, int64_t lddk, sc_bf16* dv, int64_t lddv, int32_t B, int32_t R,
+                           int32_t H, int32_t q_rows, float scale, int32_t causal, float drop_p, uint32_t drop_seed, void* stream);
 int sc_head_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* xT, int32_t B, int32_t R, int32_t H, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -360,6 +360,50 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const uint16_t* __r
     }
 }
 
+// The backward's operand preparation in ONE launch (was four: three head transposes + the delta kernel): blockIdx.z = 3 b + which,
+// which = 0 / 1 / 2 transposes the (b, h) tile of q / k / dO into qT / kT / dOT ([b, h, d, t]); the dO blocks also emit
+// delta[b, h, t] = sum_d dO[t, d] O[t, d] for their 64 rows (8 consecutive threads hold one row: three xor-shuffles).
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ k,
+                                                            int64_t ldk, const uint16_t* __restrict__ dout, int64_t lddo,
+                                                            const uint16_t* __restrict__ out, int64_t ldo, uint16_t* __restrict__ qT,
+                                                            uint16_t* __restrict__ kT, uint16_t* __restrict__ doT,
+                                                            float* __restrict__ delta, int R, int H) {
+    __shared__ uint16_t tile[64][66];
+    const int tb = blockIdx.x, h = blockIdx.y, b = blockIdx.z / 3, which = blockIdx.z % 3, tid = threadIdx.x;
+    const uint16_t* x = which == 0 ? q : which == 1 ? k : dout;
+    const int64_t ldx = which == 0 ? ldq : which == 1 ? ldk : lddo;
+    uint16_t* xT = which == 0 ? qT : which == 1 ? kT : doT;
+    const int t0 = tb * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 256, row = id >> 3, ch = id & 7;
+        const uint4 v = *(const uint4*)(x + ((int64_t)b * R + t0 + row) * ldx + h * 64 + ch * 8);
+        uint16_t* d = &tile[row][ch * 8];
+        d[0] = v.x & 0xffff; d[1] = v.x >> 16; d[2] = v.y & 0xffff; d[3] = v.y >> 16;
+        d[4] = v.z & 0xffff; d[5] = v.z >> 16; d[6] = v.w & 0xffff; d[7] = v.w >> 16;
+        if (which == 2) {
+            const uint4 o = *(const uint4*)(out + ((int64_t)b * R + t0 + row) * ldo + h * 64 + ch * 8);
+            float s = bflo(v.x) * bflo(o.x) + bfhi(v.x) * bfhi(o.x) + bflo(v.y) * bflo(o.y) + bfhi(v.y) * bfhi(o.y) +
+                      bflo(v.z) * bflo(o.z) + bfhi(v.z) * bfhi(o.z) + bflo(v.w) * bflo(o.w) + bfhi(v.w) * bfhi(o.w);
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            if (ch == 0) delta[((int64_t)b * H + h) * R + t0 + row] = s;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 256, d = id >> 3, ch = id & 7;
+        uint4 o;
+        o.x = tile[ch * 8 + 0][d] | ((uint32_t)tile[ch * 8 + 1][d] << 16);
+        o.y = tile[ch * 8 + 2][d] | ((uint32_t)tile[ch * 8 + 3][d] << 16);
+        o.z = tile[ch * 8 + 4][d] | ((uint32_t)tile[ch * 8 + 5][d] << 16);
+        o.w = tile[ch * 8 + 6][d] | ((uint32_t)tile[ch * 8 + 7][d] << 16);
+        *(uint4*)(xT + (((int64_t)b * H + h) * 64 + d) * R + t0 + ch * 8) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int sc_head_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* xT, int32_t B, int32_t R, int32_t H, void* stream) {
@@ -369,9 +413,9 @@ extern "C" int sc_head_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* xT
     return 0;
 }
 
-extern "C" int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k, int64_t ldk, const sc_bf16* v, int64_t ldv,
-                                const sc_bf16* out, int64_t ldo, const sc_bf16* dout, int64_t lddo, const sc_bf16* qT,
-                                const sc_bf16* kT, const sc_bf16* doT, const float* lse2, float* delta,
+static int attn_bwd_launch(int fused_prep, const sc_bf16* q, int64_t ldq, const sc_bf16* k, int64_t ldk, const sc_bf16* v, int64_t ldv,
+                           const sc_bf16* out, int64_t ldo, const sc_bf16* dout, int64_t lddo, const sc_bf16* qT,
+                           const sc_bf16* kT, const sc_bf16* doT, const float* lse2, float* delta,
                                 const int32_t* valid_len, sc_bf16* dq, int64_t lddq, sc_bf16* dk, int64_t lddk, sc_bf16* dv,
                                 int64_t lddv, int32_t B, int32_t R, int32_t H, int32_t q_rows, float scale, int32_t causal,
                                 float drop_p, uint32_t drop_seed, void* stream) {
@@ -383,9 +427,15 @@ extern "C" int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k,
              "sc_attn_bwd_bf16: drop_p=%f (needs B*H*R*R < 2^32)", (double)drop_p);
     SC_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 &&
                  lddv % 4 == 0, "sc_attn_bwd_bf16: leading dims");
-    const int64_t total = (int64_t)B * R * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, lddo, out,
-                       ldo, delta, R, H, total);
+    if (fused_prep) {        // qT / kT / doT are OUTPUTS here: the three transposes and delta in one launch
+        hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(R / 64, H, 3 * B), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
+                           (const uint16_t*)k, ldk, (const uint16_t*)dout, lddo, (const uint16_t*)out, ldo, (uint16_t*)qT, (uint16_t*)kT,
+                           (uint16_t*)doT, delta, R, H);
+    } else {
+        const int64_t total = (int64_t)B * R * H;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, lddo, out,
+                           ldo, delta, R, H, total);
+    }
     SC_LAUNCH_CHECK();
     bwd_args a;
     a.q = q; a.k = k; a.v = v; a.dout = dout;
@@ -404,4 +454,25 @@ extern "C" int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k,
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
     SC_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sc_attn_bwd_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k, int64_t ldk, const sc_bf16* v, int64_t ldv,
+                                const sc_bf16* out, int64_t ldo, const sc_bf16* dout, int64_t lddo, const sc_bf16* qT,
+                                const sc_bf16* kT, const sc_bf16* doT, const float* lse2, float* delta,
+                                const int32_t* valid_len, sc_bf16* dq, int64_t lddq, sc_bf16* dk, int64_t lddk, sc_bf16* dv,
+                                int64_t lddv, int32_t B, int32_t R, int32_t H, int32_t q_rows, float scale, int32_t causal,
+                                float drop_p, uint32_t drop_seed, void* stream) {
+    return attn_bwd_launch(0, q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, qT, kT, doT, lse2, delta, valid_len, dq, lddq, dk, lddk, dv, lddv,
+                           B, R, H, q_rows, scale, causal, drop_p, drop_seed, stream);
+}
+
+// same, but qT / kT / doT [B, H, 64, R] are scratch the call fills itself (one preparation launch: transposes + delta)
+extern "C" int sc_attn_bwd_fused_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k, int64_t ldk, const sc_bf16* v, int64_t ldv,
+                                      const sc_bf16* out, int64_t ldo, const sc_bf16* dout, int64_t lddo, sc_bf16* qT, sc_bf16* kT,
+                                      sc_bf16* doT, const float* lse2, float* delta, const int32_t* valid_len, sc_bf16* dq,
+                                      int64_t lddq, sc_bf16* dk, int64_t lddk, sc_bf16* dv, int64_t lddv, int32_t B, int32_t R,
+                                      int32_t H, int32_t q_rows, float scale, int32_t causal, float drop_p, uint32_t drop_seed,
+                                      void* stream) {
+    return attn_bwd_launch(1, q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, qT, kT, doT, lse2, delta, valid_len, dq, lddq, dk, lddk, dv, lddv,
+                           B, R, H, q_rows, scale, causal, drop_p, drop_seed, stream);
 }

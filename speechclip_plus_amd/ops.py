@@ -216,16 +216,18 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     (default R) must carry dout = 0.  ``drop_p`` / ``drop_seed``: those of the forward (attn_fwd) when it dropped probabilities."""
     for t in (q, k, v, out, dout, dq, dk, dv):
         assert t.dtype == torch.bfloat16 and t.stride(1) == 1
-    qT = head_transpose(q, B, R, H)
-    if kT is None:
-        kT = head_transpose(k, B, R, H)
-    doT = head_transpose(dout, B, R, H)
     delta = torch.empty(B, H, R, device=q.device, dtype=torch.float32)
-    check(lib().sc_attn_bwd_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), _p(dout),
-                                 dout.stride(0), _p(qT), _p(kT), _p(doT), _p(lse2), _p(delta), _p(valid_len), _p(dq), dq.stride(0),
-                                 _p(dk), dk.stride(0), _p(dv), dv.stride(0), B, R, H, R if q_rows is None else q_rows, float(scale),
-                                 int(causal), float(drop_p), int(drop_seed) & 0xffffffff, _stream()),
-          "sc_attn_bwd_bf16")
+    args = lambda qT, kT, doT: (_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), _p(dout), dout.stride(0),
+                                _p(qT), _p(kT), _p(doT), _p(lse2), _p(delta), _p(valid_len), _p(dq), dq.stride(0), _p(dk), dk.stride(0),
+                                _p(dv), dv.stride(0), B, R, H, R if q_rows is None else q_rows, float(scale), int(causal), float(drop_p),
+                                int(drop_seed) & 0xffffffff, _stream())
+    if kT is None:          # the three per-head transposes and delta in one preparation launch inside the call
+        T3 = torch.empty(3, B, H, 64, R, device=q.device, dtype=torch.bfloat16)
+        check(lib().sc_attn_bwd_fused_bf16(*args(T3[0], T3[1], T3[2])), "sc_attn_bwd_fused_bf16")
+        return
+    qT = head_transpose(q, B, R, H)
+    doT = head_transpose(dout, B, R, H)
+    check(lib().sc_attn_bwd_bf16(*args(qT, kT, doT)), "sc_attn_bwd_bf16")
 
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float, dres: Optional[torch.Tensor] = None,
