@@ -288,17 +288,21 @@ _derived = {}
 def derived(param: torch.Tensor, tag: str, fn):
     """``fn(param.detach())`` cached per parameter VERSION (bf16 working copies, transposed copies of trainable weights: computed once
     per optimiser step instead of once per call).  The key carries optim.param_generation() because the fused Adam kernel writes the
-    masters through a raw pointer (no ``_version`` bump)."""
+    masters through a raw pointer (no ``_version`` bump).  Entries hold only a weak reference to their parameter and die with it."""
+    import weakref
     from .optim import param_generation
     if not isinstance(param, torch.nn.Parameter):       # a temporary: its id / address can be recycled for different contents
         return fn(param.detach())
     key = (id(param), tag)
     ver = (param.data_ptr(), param._version, param_generation(), tuple(param.shape))
     hit = _derived.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
+    if hit is not None and hit[0]() is param and hit[1] == ver:
+        return hit[2]
     val = fn(param.detach())
-    _derived[key] = (ver, val)
+    if len(_derived) > 512:                             # drop the entries of parameters that no longer exist
+        for k in [k for k, v in _derived.items() if v[0]() is None]:
+            del _derived[k]
+    _derived[key] = (weakref.ref(param), ver, val)
     return val
 
 
