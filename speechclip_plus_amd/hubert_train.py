@@ -89,14 +89,34 @@ class TrainableLayers(nn.Module):
         if ver == self._versions:
             return
         bf = lambda t: t.detach().to(torch.bfloat16).contiguous()
+        # Trainable parameters managed by optim.FlatAdam are contiguous views of ONE flat fp32 buffer: cast the span they cover in a
+        # single launch and hand out views of that bf16 mirror, instead of one cast launch per weight matrix (113 per step)
+        mirror, lo = None, 0
+        ps = [q for q in self.p.values()]
+        if ps and all(q.is_contiguous() and q.dtype == torch.float32 and
+                      q.data.untyped_storage().data_ptr() == ps[0].data.untyped_storage().data_ptr() for q in ps):
+            lo = min(q.storage_offset() for q in ps)
+            hi = max(q.storage_offset() + q.numel() for q in ps)
+            if hi - lo <= 2 * sum(q.numel() for q in ps):          # a compact span (other modules' parameters may sit in between)
+                flat = torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(ps[0].data.untyped_storage(), lo, (hi - lo,))
+                mirror = flat.to(torch.bfloat16)
+
+        def bfp(i, name):                                          # bf16 working copy of a layer parameter
+            t = self.get(i, name)
+            if mirror is not None and i in self.ids:
+                off = t.storage_offset() - lo
+                if off % 8 == 0:                                   # the kernels read operands in 16-byte pieces
+                    return mirror[off: off + t.numel()].view(t.shape)
+            return bf(t)
+
         for i in self.ids + [j for j in self.pass_ids if j not in self._copies]:
             c = {}
-            qkv = torch.cat([self.get(i, f"self_attn.{n}.weight").detach() for n in ("q_proj", "k_proj", "v_proj")], 0)
-            c["qkv_w"], c["qkv_wT"] = bf(qkv), bf(qkv.t())
+            qkv_b16 = torch.cat([bfp(i, f"self_attn.{n}.weight") for n in ("q_proj", "k_proj", "v_proj")], 0)
+            c["qkv_w"], c["qkv_wT"] = qkv_b16, qkv_b16.t().contiguous()
             c["qkv_b"] = torch.cat([self.get(i, f"self_attn.{n}.bias").detach() for n in ("q_proj", "k_proj", "v_proj")], 0).contiguous()
             for short, name in (("o", "self_attn.out_proj"), ("fc1", "fc1"), ("fc2", "fc2")):
-                wt = self.get(i, name + ".weight").detach()
-                c[short + "_w"], c[short + "_wT"], c[short + "_b"] = bf(wt), bf(wt.t()), self.get(i, name + ".bias").detach()
+                wb = bfp(i, name + ".weight")
+                c[short + "_w"], c[short + "_wT"], c[short + "_b"] = wb, wb.t().contiguous(), self.get(i, name + ".bias").detach()
             c["ln1_g"], c["ln1_b"] = self.get(i, "self_attn_layer_norm.weight").detach(), self.get(i, "self_attn_layer_norm.bias").detach()
             c["ln2_g"], c["ln2_b"] = self.get(i, "final_layer_norm.weight").detach(), self.get(i, "final_layer_norm.bias").detach()
             self._copies[i] = c
