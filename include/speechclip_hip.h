@@ -60,7 +60,7 @@ typedef struct {
     int32_t M, N, K;
     const float* bias;            /* [N] fp32 or NULL */
     const sc_bf16* residual; int64_t ldr;   /* [M, N] bf16 or NULL */
-    int32_t act;                  /* 0 none, 1 gelu(erf) */
+    int32_t act;                  /* 0 none, 1 gelu(erf) (fused epilogue of every tile family); 2 QuickGELU only with aux_mode */
     int32_t out_f32;              /* 0: C is bf16, 1: C is fp32 */
     sc_bf16* Ct; int32_t n_split; int32_t R; int32_t dh;   /* transposed-store region; n_split < 0 disables */
     int32_t nb1, nb2;             /* batch = nb1*nb2 (>= 1 each) */
@@ -107,6 +107,14 @@ typedef struct {
      * k_total > 0: the slices are ragged - slice z1 covers rows [z1 K, min((z1 + 1) K, k_total)) (K, k_total multiples of 64). */
     int32_t tn;
     int32_t k_total;
+    /* ---- activation fused with a second operand (128-row tile family only; Ct doubles as the aux pointer [M, N] bf16, row stride ldc;
+     * act = 1 erf-GELU or 2 QuickGELU; no transposed store, bf16 output):
+     *   aux_mode 1  dual store:  Ct <- u = bf16(acc + bias) (the pre-activation the backward needs),  C <- act(u)   (FFN fc1 of a layer
+     *               that is differentiated: one launch instead of GEMM + sc_act_bf16)
+     *   aux_mode 2  C <- bf16(acc) * act'(Ct)   (the input-gradient GEMM of fc2 followed by the activation's backward: Ct = the saved u)
+     * Both reproduce the two-launch sequence bit for bit (the activation reads the ROUNDED values the first kernel would have stored). */
+    int32_t aux_mode;
+    int32_t reserved3;
 } sc_gemm_args;
 int32_t sc_gemm_stats_strips(const sc_gemm_args* args);   /* strips a producer launch with these args writes per row (0: not on the 256-row family) */
 int sc_gemm_bf16(const sc_gemm_args* args, void* stream);

@@ -32,7 +32,7 @@ class GemmArgs(ctypes.Structure):
         ("tap_c", c_int), ("ln_ns", c_int),
         ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("res_stats", c_void_p), ("res_gamma", c_void_p), ("res_beta", c_void_p),
         ("stats_out", c_void_p), ("res_ns", c_int), ("ln_eps", ctypes.c_float),
-        ("tn", c_int), ("k_total", c_int),
+        ("tn", c_int), ("k_total", c_int), ("aux_mode", c_int), ("reserved3", c_int),
     ]
 
 

@@ -83,8 +83,8 @@ class TextTowerFn(torch.autograd.Function):
             ops.attn_fwd(qkv[:, : 2 * W], vt, valid, att, NB, BLOCK, heads, W, scale, lse2=lse2, causal=causal)
             X2 = ops.linear_bf16(att, w.wo, w.bo, residual=X)
             h2 = ops.layernorm_bf16(X2, w.g2, w.be2, eps=w.eps2)
-            u = ops.linear_bf16(h2, w.w1, w.b1)
-            f = ops.act_bf16(u, 2)
+            u = torch.empty(M, w.w1.shape[0], device=dev, dtype=torch.bfloat16)
+            f = ops.linear_bf16(h2, w.w1, w.b1, act=2, aux=u, aux_mode=1)          # u = fc1 pre-activation (kept), f = QuickGELU(u)
             Xn = ops.linear_bf16(f, w.w2, w.b2, residual=X2)
             saved.append((X, qkv, att, lse2, X2, u))
             X = Xn
@@ -101,8 +101,7 @@ class TextTowerFn(torch.autograd.Function):
         dX[:B, :T] = dy.to(torch.bfloat16)
         dX = dX.view(M, W)
         for w, (X, qkv, att, lse2, X2, u) in zip(reversed(ctx.weights), reversed(ctx.saved)):
-            df = ops.linear_bf16(dX, w.w2T)
-            du = ops.act_bf16(u, 2, df=df)
+            du = ops.linear_bf16(dX, w.w2T, act=2, aux=u, aux_mode=2)                 # (dX W2) * QuickGELU'(u) in the GEMM's epilogue
             dh2 = ops.linear_bf16(du, w.w1T)
             dX2 = ops.layernorm_bwd(X2, dh2, w.g2, w.eps2, dres=dX)
             datt = ops.linear_bf16(dX2, w.woT)

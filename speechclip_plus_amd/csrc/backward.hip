@@ -113,19 +113,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
     }
 }
 
-__device__ __forceinline__ float act_fwd(float u, int act) {
-    if (act == 1) return gelu_erf(u);
-    const float sg = 1.f / (1.f + __expf(-1.702f * u));            // QuickGELU (CLIP): u * sigmoid(1.702 u)
-    return u * sg;
-}
-__device__ __forceinline__ float act_grad(float u, int act) {
-    if (act == 1) {                                                  // Phi(u) + u phi(u)
-        const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
-        return cdf + u * 0.3989422804014327f * __expf(-0.5f * u * u);
-    }
-    const float sg = 1.f / (1.f + __expf(-1.702f * u));
-    return sg * (1.f + 1.702f * u * (1.f - sg));
-}
+// act_fwd / act_grad: sc_common.h (shared with the GEMM epilogue that fuses them, gemm_bf16.hip aux_mode)
 // out = act(u)  (df == nullptr)   or   out = df * act'(u);   8 bf16 per thread
 __global__ void act_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ df, uint16_t* __restrict__ out, int64_t n8,
                            int act) {

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
         for (int mi = 0; mi < FM; ++mi) {
             const int ml = wm * TM + mi * 16 + 4 * (lane >> 4);
             f32x4 v = acc[mi][ni];
-            if (p.act == 1) {
+            if (p.act == 1 && p.aux_mode == 0) {
                 const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
                 v = f32x4{g0.x, g0.y, g1.x, g1.y};
             }
@@ -232,6 +232,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
                     const uint4 rv = *(const uint4*)(Rs + (int64_t)m * p.ldr + n);
                     v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
                     v[4] += bflo(rv.z); v[5] += bfhi(rv.z); v[6] += bflo(rv.w); v[7] += bfhi(rv.w);
+                }
+                if (p.aux_mode) {        // activation fused with the aux operand Ct (see sc_gemm_args.aux_mode): bit-identical to GEMM + sc_act_bf16
+                    uint16_t* X = p.Ct + coff + (int64_t)m * p.ldc + n;
+                    uint4 r;             // the values the plain GEMM would have stored
+                    r.x = pack2bf(v[0], v[1]); r.y = pack2bf(v[2], v[3]); r.z = pack2bf(v[4], v[5]); r.w = pack2bf(v[6], v[7]);
+                    const float rr[8] = {bflo(r.x), bfhi(r.x), bflo(r.y), bfhi(r.y), bflo(r.z), bfhi(r.z), bflo(r.w), bfhi(r.w)};
+                    if (p.aux_mode == 1) {
+                        *(uint4*)X = r;                                              // u
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = act_fwd(rr[e], p.act);   // act(u)
+                    } else {
+                        const uint4 uu = *(const uint4*)X;                           // saved u
+                        const float u8[8] = {bflo(uu.x), bfhi(uu.x), bflo(uu.y), bfhi(uu.y), bflo(uu.z), bfhi(uu.z), bflo(uu.w), bfhi(uu.w)};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = rr[e] * act_grad(u8[e], p.act);
+                    }
                 }
                 if (p.out_f32) {
                     float* C = (float*)p.C + coff + (int64_t)m * p.ldc + n;
@@ -305,7 +321,7 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     SC_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0, "sc_gemm_bf16: leading dims must be multiples of 8");
     SC_CHECK(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0 && ((uintptr_t)a.C % 16) == 0,
              "sc_gemm_bf16: operands must be 16-byte aligned");
-    SC_CHECK(a.act == 0 || a.act == 1, "sc_gemm_bf16: act=%d", a.act);
+    SC_CHECK(a.act == 0 || a.act == 1 || (a.act == 2 && a.aux_mode != 0), "sc_gemm_bf16: act=%d", a.act);
     SC_CHECK(a.drop_p >= 0.f && a.drop_p < 1.f, "sc_gemm_bf16: drop_p=%f", (double)a.drop_p);
     SC_CHECK(a.tap_c == 0 || (a.tap_c > 0 && a.tap_c % 64 == 0 && a.K == 3 * a.tap_c),
              "sc_gemm_bf16: tap_c=%d needs tap_c %% 64 == 0 and K == 3 * tap_c (K=%d)", a.tap_c, a.K);
@@ -334,6 +350,14 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
                  "sc_gemm_bf16: ragged TN slices need k_total %% 64 == 0 and (nb1 - 1) K < k_total <= nb1 K");
         return sc_gemm256_launch(a, (hipStream_t)stream);
     }
+    if (a.aux_mode) {
+        SC_CHECK((a.aux_mode == 1 || a.aux_mode == 2) && (a.act == 1 || a.act == 2) && a.Ct && a.n_split < 0 && !a.out_f32 && !a.tn &&
+                 a.drop_p == 0.f && !a.ln_stats && !a.stats_out && !a.res_stats && ((uintptr_t)a.Ct % 16) == 0,
+                 "sc_gemm_bf16: aux_mode needs act 1 / 2, the aux pointer in Ct (16-byte aligned), bf16 output and a plain epilogue");
+        SC_CHECK(a.tile == 0 || a.tile == 1 || a.tile == 3 || a.tile == 13, "sc_gemm_bf16: aux_mode is built into the 128-row tiles");
+    } else {
+        SC_CHECK(a.act == 0 || a.act == 1, "sc_gemm_bf16: act=%d (2 = QuickGELU needs aux_mode)", a.act);
+    }
     const bool ln = a.ln_stats || a.stats_out || a.res_stats;
     if (ln) {
         // LayerNorm folded into the GEMMs: built into the 256-row tile family only (csrc/gemm256_bf16.hip)
@@ -358,7 +382,7 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     if (tile == 0) {
         const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.nb1 * a.nb2;
         if (a.N <= 64 && a.n_split < 0) tile = 3;            // narrow outputs (grouped pos_conv, N = 48)
-        else if (a.M >= 512 && a.N >= 192 && tiles256 >= 192 && (a.n_split < 0 || a.n_split % 64 == 0)) tile = 2;
+        else if (!a.aux_mode && a.M >= 512 && a.N >= 192 && tiles256 >= 192 && (a.n_split < 0 || a.n_split % 64 == 0)) tile = 2;
         else {
             // small problems (the text tower's 2048 packed rows): 128 x 64 tiles give twice the workgroups, 10-20 % faster up to two
             // waves of 128 x 128 tiles per CU (tools/bench_small_gemm.py)

@@ -60,6 +60,21 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return fmaf(-ah, r, h + ah);
 }
 
+// activation codes of sc_act_bf16 / sc_gemm_args.act: 1 = erf-GELU (fairseq FFN), 2 = QuickGELU (CLIP MLP)
+__device__ __forceinline__ float act_fwd(float u, int act) {
+    if (act == 1) return gelu_erf(u);
+    const float sg = 1.f / (1.f + __expf(-1.702f * u));            // QuickGELU (CLIP): u * sigmoid(1.702 u)
+    return u * sg;
+}
+__device__ __forceinline__ float act_grad(float u, int act) {
+    if (act == 1) {                                                  // Phi(u) + u phi(u)
+        const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+        return cdf + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+    }
+    const float sg = 1.f / (1.f + __expf(-1.702f * u));
+    return sg * (1.f + 1.702f * u * (1.f - sg));
+}
+
 // two elements at a time: the polynomial, squarings and scalings become packed fp32 ops (v_pk_fma_f32 / v_pk_mul_f32,
 // two lanes' worth of work per issue slot); only the rcp stays scalar (transcendental unit).  Same operation order as
 // gelu_erf => bitwise identical results.

@@ -82,7 +82,7 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
              ln_stats: Optional[torch.Tensor] = None, ln_ns: int = 0, ln_colsum: Optional[torch.Tensor] = None,
              res_stats: Optional[torch.Tensor] = None, res_ns: int = 0, res_gamma: Optional[torch.Tensor] = None,
              res_beta: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None, ln_eps: float = 0.0,
-             tn: bool = False, k_total: int = 0) -> int:
+             tn: bool = False, k_total: int = 0, aux: Optional[torch.Tensor] = None, aux_mode: int = 0) -> int:
     """C = epi(A . W^T); see sc_gemm_args in include/speechclip_hip.h.  Pointers are the tensors' data_ptr()
     (pass a sliced view to offset).  ``alg_rows``: rows that are algorithmic work (excludes layout padding),
     used only by the optional KernelTimer.  ``ln_*`` / ``res_*`` / ``stats_out``: LayerNorm folded into the GEMM (row-statistics
@@ -110,6 +110,9 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed) & 0xffffffff
     a.tap_c = int(tap_c)
     a.k_total = int(k_total)
+    if aux_mode:            # activation fused with a second [M, N] bf16 operand of C's row stride (sc_gemm_args.aux_mode)
+        assert aux is not None and aux.dtype == torch.bfloat16 and Ct is None and aux.stride(0) == ldc and aux.stride(1) == 1
+        a.Ct, a.aux_mode = _p(aux), int(aux_mode)
     a.tn = int(tn)          # C[m, n] = sum_r A[r, m] W[r, n]: both operands row-indexed by the reduction (weight gradients)
     strips = 0
     if ln_stats is not None or stats_out is not None:
@@ -170,8 +173,10 @@ def gemm_stats_strips(M: int, N: int) -> int:
 
 def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, act: int = 0, out_f32: bool = False,
-                alg_rows: Optional[int] = None, tile: int = 0, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
-    """y[M, N] = epi(x[M, K] . w[N, K]^T) for contiguous 2-D operands."""
+                alg_rows: Optional[int] = None, tile: int = 0, drop_p: float = 0.0, drop_seed: int = 0,
+                aux: Optional[torch.Tensor] = None, aux_mode: int = 0) -> torch.Tensor:
+    """y[M, N] = epi(x[M, K] . w[N, K]^T) for contiguous 2-D operands.  ``aux`` / ``aux_mode`` (small problems, 128-row tiles):
+    1 = also store the pre-activation into ``aux`` and return act(it); 2 = return (x . w^T) * act'(aux)."""
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
@@ -179,7 +184,7 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         out = torch.empty(M, N, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     gemm_raw(x, x.stride(0), w, w.stride(0), out, out.stride(0), M, N, K, bias=bias, residual=residual,
              ldr=residual.stride(0) if residual is not None else 0, act=act, out_f32=out_f32, alg_rows=alg_rows, tile=tile,
-             drop_p=drop_p, drop_seed=drop_seed)
+             drop_p=drop_p, drop_seed=drop_seed, aux=aux, aux_mode=aux_mode)
     return out
 
 

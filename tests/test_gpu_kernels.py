@@ -1263,3 +1263,27 @@ def test_gemm_small_tile_ring_variants_agree_bitwise(dev):
             ref = ref + R.float()
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
         assert rel_l2(outs[0], ref) < 6e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", [1, 2])
+def test_gemm_fused_activation_with_aux_operand(dev, act):
+    """sc_gemm_args.aux_mode (128-row tiles): 1 = dual store (pre-activation + activation), 2 = product times act'(aux) - both must
+    reproduce the two-launch sequences GEMM -> sc_act_bf16 bit for bit (erf-GELU and QuickGELU)."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(act)
+    M, N, K = 2048, 2048, 512
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    u_ref = ops.linear_bf16(x, w, b, tile=3)
+    f_ref = ops.act_bf16(u_ref, act)
+    u = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    f = ops.linear_bf16(x, w, b, act=act, aux=u, aux_mode=1)
+    assert torch.equal(u, u_ref) and torch.equal(f, f_ref)
+    dy = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)           # gradient of an [M, K] output through W2 [K, N]
+    w2T = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+    df_ref = ops.linear_bf16(dy, w2T, tile=3)
+    du_ref = ops.act_bf16(u_ref, act, df=df_ref)
+    du = ops.linear_bf16(dy, w2T, act=act, aux=u_ref, aux_mode=2)
+    assert torch.equal(du, du_ref)
