@@ -78,7 +78,7 @@ struct bwd_args {
 
 // ------------------------------------------------------------------------------------------------------------ dQ
 template <int DROP>   // DROP: the forward dropped its probabilities (same stateless hash mask, regenerated here)
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bwd_args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_kernel(const bwd_args p) {
     __shared__ __attribute__((aligned(16))) char Ks[TT * 128];
     __shared__ __attribute__((aligned(16))) char Vs[TT * 128];
     __shared__ __attribute__((aligned(16))) char KTs[64 * 128];
