@@ -164,3 +164,20 @@ audio_encoder: {type: FairseqHubert, name: hubert_large_ll60k, trainable: false,
         c = load_config(f, reference_root="/root/reference")
         assert c.audio_encoder.type == "FairseqHubert" and c.cl_loss.type == "MaskedContrastiveLoss"
         assert c.clip.embed_dim in (512, 768)
+
+
+def test_bench_host_helpers():
+    """bench.py's host-side accounting: physical cores are counted from /proc/cpuinfo, and the algorithmic flops of a ragged batch
+    count every utterance at its own length (padding is not achieved work)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pc = bench.physical_cores()
+    assert pc is None or (isinstance(pc, int) and 1 <= pc <= (os.cpu_count() or 1))
+    full = bench.forward_summary(12.0, 64, 160000, 499)
+    assert abs(full["alg_gflop_per_utt"] - 148.14) < 0.05                      # SURVEY 8d: 148.1 GFLOP per 10 s utterance
+    ragged = bench.forward_summary(12.0, 64, 160000, 499, lens=[160000] + [80000] * 63)
+    assert ragged["alg_gflop_per_utt"] < 0.55 * full["alg_gflop_per_utt"]      # shorter utterances count less than linearly (attention ~ T^2)
+    same = bench.forward_summary(12.0, 64, 160000, 499, lens=[160000] * 64)
+    assert abs(same["alg_gflop_per_utt"] - full["alg_gflop_per_utt"]) < 1e-6
