@@ -14,7 +14,8 @@
  *     global state.  Re-entrant per stream.
  *   - return 0 on success, <0 on error; sc_last_error() gives a thread-local message.
  *   - bf16 tensors are raw uint16 storage (`sc_bf16`); "rows" of activations live in the padded layout
- *     described in DESIGN.md: utterance b, frame t  ->  row  b*R + t,  R % 128 == 0.
+ *     described in DESIGN.md: utterance b, frame t  ->  row  b*R + t (uniform pitch R), or - round 4, the `_seg` entry points -
+ *     row  row0[b] + t  with a pitch per utterance (`sc_segments`): work follows the real lengths of a ragged batch.
  */
 #ifndef SPEECHCLIP_HIP_H
 #define SPEECHCLIP_HIP_H
@@ -28,11 +29,29 @@ extern "C" {
 typedef uint16_t sc_bf16;
 
 const char* sc_last_error(void);
-int sc_abi_version(void);     /* 3 since round 3 (sc_gemm_args grew the LayerNorm-folding fields) */
-int64_t sc_sizeof(int32_t what);   /* sizeof of 0 sc_gemm_args, 1 sc_hubert_layer_args, 2 sc_rt_gemm_args, 3 sc_rt_ln_args, 4 sc_rt_ln_bwd_args */
+int sc_abi_version(void);     /* 4 since round 4 (sc_segments; sc_gemm_args / sc_hubert_layer_args grew the segment fields) */
+int64_t sc_sizeof(int32_t what);   /* sizeof of 0 sc_gemm_args, 1 sc_hubert_layer_args, 2 sc_rt_gemm_args, 3 sc_rt_ln_args, 4 sc_rt_ln_bwd_args, 5 sc_segments */
 /* tuning switches for same-process A/B measurements (tools/); results never depend on them.  key 1: the 256-row GEMM uses
  * plain instead of non-temporal stores on tiles with a residual. */
 int sc_set_option(int32_t key, int32_t value);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ragged row layout (round 4).  The reference pads every batch to its longest utterance and computes all of it
+ * (avssl/module/speech_encoder_plus.py:506-518, 548-552); here utterance b owns rows [row0[b], row0[b + 1]) of every
+ * [rows, C] activation buffer - its own pitch, a multiple of 32 rows, sized by its own number of frames - so GEMM rows,
+ * attention blocks and row kernels follow the real lengths.  Down the conv stack layer l has the same table scaled by
+ * 2^(6-l) (row0 * 64 at conv layer 0), the waveform by `samples_per_row` (320): a strided Conv1d stays ONE flat GEMM.
+ *   row0   device [B + 1] int32, multiples of 32, row0[0] = 0, row0[B] = rows
+ *   chunk  device [rows / 32][4] int32: for every 32-row chunk (first row of its utterance, pitch of its utterance, utterance, 0)
+ *          - the reverse lookup of the flat kernels (one 16-byte load)
+ *   max_pitch = max_b (row0[b + 1] - row0[b])   (grid sizing on the host)
+ * The struct itself lives in HOST memory (passed by pointer), its two tables in device memory.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const int32_t* row0;
+    const int32_t* chunk;
+    int32_t B, rows, max_pitch, reserved;
+} sc_segments;
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 MFMA GEMM with fused epilogue:  C = epi(A . W^T)      (every Linear / Conv1d on the path)
@@ -115,6 +134,10 @@ typedef struct {
      * Both reproduce the two-launch sequence bit for bit (the activation reads the ROUNDED values the first kernel would have stored). */
     int32_t aux_mode;
     int32_t reserved3;
+    /* ---- ragged rows (round 4): seg_chunk != NULL replaces the uniform `R` of the transposed store - row m belongs to the
+     * utterance of chunk m / 32 = (first row r0, pitch Rb, ...) (sc_segments.chunk) and goes to
+     *       Ct[(N - n_split) * r0 + (n - n_split) * Rb + (m - r0)]          (V^T [H, dh, Rb] per utterance, utterances back to back) */
+    const int32_t* seg_chunk;
 } sc_gemm_args;
 int32_t sc_gemm_stats_strips(const sc_gemm_args* args);   /* strips a producer launch with these args writes per row (0: not on the 256-row family) */
 int sc_gemm_bf16(const sc_gemm_args* args, void* stream);
@@ -137,6 +160,16 @@ int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const i
                      int32_t causal /* 1: key t' > query t masked too (CLIP text tower) */,
                      float drop_p, uint32_t drop_seed /* attention-probability dropout (train mode): P' = mask . P / (1 - p), element
                      ((b*H + h)*R + q)*R + k hashed as in sc_gemm_args; 0 = off */, void* stream);
+
+/* The same over ragged rows (sc_segments): q / k rows of utterance b at row0[b] + t, vt = per utterance [H, 64, Rb] at element offset
+ * D * row0[b] (what sc_gemm_bf16 writes with seg_chunk), out rows likewise; lse2 [H][rows].  One workgroup = 128 queries of one
+ * (utterance, head); a last block of 32 / 64 / 96 queries is computed by that many waves.  work (optional, device [nwork] int32):
+ * the (utterance | q-block << 16) pairs to run, in launch order - the host sorts them longest first (an utterance's cost grows with
+ * its key count); NULL = every (b, q-block < max_pitch / 128), blocks past an utterance's pitch exit.  Dropout element index:
+ * ((h * rows + row0[b] + q) * max_pitch + k).  Bit-identical to the uniform call on the rows they share. */
+int sc_attn_fwd_seg_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len, sc_bf16* out, int64_t ldo,
+                         const sc_segments* seg, const int32_t* work, int32_t nwork, int32_t H, int32_t D, float scale, float* lse2,
+                         int32_t causal, float drop_p, uint32_t drop_seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Self-attention backward, head_dim 64 (fairseq MultiheadAttention / nn.MultiheadAttention / CLIP ResidualAttentionBlock
@@ -206,6 +239,21 @@ int sc_conv0_gn_bwd(const float* wav, int64_t ldw, const float* w0, const float*
  * B * nwc with sc_colsum_f32 (nwc % 4 == 0). */
 int sc_conv0_ln_bwd(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma, const float* beta, float eps,
                     const sc_bf16* dy, int32_t B, int32_t T0, int32_t R0, int32_t C, float* partial, int32_t nwc, void* stream);
+/* Ragged rows (sc_segments; round 4).  The prepared waveform is ONE flat buffer, utterance b at sample samples_per_row * row0[b]
+ * (320 = 5 * 64: conv layer 0 then reads x[5 r + j] for its flat output row r = 64 * row0[b] + t, like every later conv layer reads
+ * rows 2 r ..), zero from wav_len[b] to the end of its region; out needs samples_per_row * rows + 16 floats.
+ *   sc_wav_prep_seg    : as sc_wav_prep into that layout
+ *   sc_conv0_stats_len : GroupNorm statistics straight from the caller's [B, ldw] batch, samples >= wav_len[b] read as 0 (the
+ *                        statistics run over the PADDED batch length T0 - fairseq semantics - whatever the row layout)
+ *   sc_conv0_gn_gelu_seg / sc_conv0_ln_gelu_seg : conv layer 0 on the flat waveform, out row 64 * row0[b] + t for t < 64 * pitch_b */
+int sc_wav_prep_seg(const float* wav, int64_t ldw_in, const int64_t* wav_len, float* out, const sc_segments* seg,
+                    int32_t samples_per_row, int32_t L, int32_t normalize, void* stream);
+int sc_conv0_stats_len(const float* wav, int64_t ldw, const int64_t* wav_len, int32_t B, int32_t T0, int32_t nchunk, double* partial,
+                       void* stream);
+int sc_conv0_gn_gelu_seg(const float* wav_flat, const sc_segments* seg, int32_t samples_per_row, const float* w0, const float* scale,
+                         const float* shift, sc_bf16* out, int32_t C, void* stream);
+int sc_conv0_ln_gelu_seg(const float* wav_flat, const sc_segments* seg, int32_t samples_per_row, const float* w0, const float* bias,
+                         const float* gamma, const float* beta, float eps, sc_bf16* out, int32_t C, void* stream);
 /* "layer_norm" extractor mode (HuBERT-large): conv0 (+bias) -> LayerNorm over the 512 channels -> GELU */
 int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma,
                      const float* beta, float eps, sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream);
@@ -221,6 +269,10 @@ int sc_conv0_ln_gelu_f32(const float* wav, int64_t ldw, const float* w0, const f
 int sc_posconv_prep(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_bf16* xg, int32_t B, int32_t R,
                     int32_t D, int32_t G, int32_t halo, void* stream);
 
+/* ragged rows: xg [G][rows + 2 * halo * B][D / G], utterance b's slab at row  row0[b] + 2 * halo * b  (its frames at + halo) */
+int sc_posconv_prep_seg(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_bf16* xg, const sc_segments* seg, int32_t D,
+                        int32_t G, int32_t halo, void* stream);
+
 /* HuBERT positional convolution on the slab layout above + bias + GELU + residual (speech_encoder_plus.py:32-37: grouped Conv1d,
  * kernel Kp = 128, padding 64, SamePad drops the last frame):
  *   out[b*R + t, g*Dg + n] = gelu(bias[g*Dg + n] + sum_j sum_ci w[g][n][j*Dg + ci] * xg[g][b][t + j][ci]) + residual[b*R + t, g*Dg + n]
@@ -229,6 +281,10 @@ int sc_posconv_prep(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_
  * formulation (lda = Dg, K = Kp*Dg, act = 1, residual): bit-identical results. */
 int sc_posconv_bf16(const sc_bf16* xg, const sc_bf16* w, const float* bias, const sc_bf16* residual, sc_bf16* out, int32_t B,
                     int32_t R, int32_t D, int32_t G, int32_t Kp, int32_t Rp, void* stream);
+
+/* ragged rows: the slab layout of sc_posconv_prep_seg (halo = Kp / 2), out / residual rows row0[b] + t */
+int sc_posconv_seg_bf16(const sc_bf16* xg, const sc_bf16* w, const float* bias, const sc_bf16* residual, sc_bf16* out,
+                        const sc_segments* seg, int32_t D, int32_t G, int32_t Kp, void* stream);
 
 /* Weight gradient of that convolution (fully trainable HuBERT; speech_encoder_plus.py:29-40 under trainable: true):
  *   part[z][g][co][tap*Dg + ci] = sum over the z-th slice of slab rows m of  du[g][m][co] * xg[g][m + tap][ci]
@@ -255,6 +311,13 @@ int sc_wsum_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, int3
                 int32_t row_off, int32_t normalize, void* stream);
 int sc_wsum_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial /*[nblk, NL]*/, int32_t nblk,
                 int32_t B, int32_t R, int32_t D, int32_t row_off, int32_t normalize, void* stream);
+/* Ragged hidden states -> uniform-pitch output (round 4): h [NL, seg->rows, D] in the segment layout; out / g [B, Rout, D] with
+ * utterance b's frame t at out[b, t + row_off] for t + row_off < min(pitch_b + row_off, Rout), every other row of out is ZEROED (the
+ * consumers - the CLS pooling kernels, the cascaded+/hybrid+ branches - keep a uniform [B, Rout, D] view and mask by length). */
+int sc_wsum_fwd_seg(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, const sc_segments* seg, int32_t Rout, int32_t D,
+                    int32_t row_off, int32_t normalize, void* stream);
+int sc_wsum_bwd_seg(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial /*[nblk, NL]*/, int32_t nblk,
+                    const sc_segments* seg, int32_t Rout, int32_t D, int32_t row_off, int32_t normalize, void* stream);
 /* The same sums over RAW hidden states (LayerNorm folded into the encoder GEMMs, see sc_gemm_args): layers n >= first_lazy of h hold
  * the rows in FRONT of the layer's final LayerNorm; stats [NL][B*R][8][2] fp32 their row statistics (ns valid strips), gamma / beta
  * [NL][D] the LayerNorm affines (rows < first_lazy unused): the summed state is (raw - mean) rstd gamma_n + beta_n in fp32. */
@@ -564,6 +627,11 @@ typedef struct {
     const float *x_ln_g, *x_ln_b;
     const float *qkv_colsum, *fc1_colsum;
     float *stats1, *out_stats;
+    /* ---- ragged rows (round 4): seg != NULL (host pointer, seg->row0 device) - x / out / scratch hold seg->rows rows in the
+     * segment layout (R, T are then ignored; vt = per utterance [H, 64, pitch]); attn_work / n_attn_work as in sc_attn_fwd_seg_bf16 */
+    const sc_segments* seg;
+    const int32_t* attn_work;
+    int32_t n_attn_work, reserved2;
 } sc_hubert_layer_args;
 int sc_hubert_layer_fwd(const sc_hubert_layer_args* args, void* stream);
 #define SC_WS_INFONCE 0       /* a = Bg */

@@ -33,7 +33,13 @@ class GemmArgs(ctypes.Structure):
         ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("res_stats", c_void_p), ("res_gamma", c_void_p), ("res_beta", c_void_p),
         ("stats_out", c_void_p), ("res_ns", c_int), ("ln_eps", ctypes.c_float),
         ("tn", c_int), ("k_total", c_int), ("aux_mode", c_int), ("reserved3", c_int),
+        ("seg_chunk", c_void_p),
     ]
+
+
+class Segments(ctypes.Structure):
+    """Mirror of ``sc_segments``: the ragged row layout (device tables row0 [B + 1], chunk [rows / 32][4])."""
+    _fields_ = [("row0", c_void_p), ("chunk", c_void_p), ("B", c_int), ("rows", c_int), ("max_pitch", c_int), ("reserved", c_int)]
 
 
 class RtGemmArgs(ctypes.Structure):
@@ -91,6 +97,7 @@ class HubertLayerArgs(ctypes.Structure):
         ("qk", c_void_p), ("vt", c_void_p), ("ctx", c_void_p), ("pre", c_void_p), ("x1", c_void_p), ("ffn", c_void_p),
         ("fused_ln", c_int), ("x_ns", c_int), ("x_stats", c_void_p), ("x_ln_g", c_void_p), ("x_ln_b", c_void_p),
         ("qkv_colsum", c_void_p), ("fc1_colsum", c_void_p), ("stats1", c_void_p), ("out_stats", c_void_p),
+        ("seg", ctypes.POINTER(Segments)), ("attn_work", c_void_p), ("n_attn_work", c_int), ("reserved2", c_int),
     ]
 
 
@@ -103,6 +110,16 @@ SIGNATURES = {
     "sc_gemm_bf16": [ctypes.POINTER(GemmArgs), c_void_p],
     "sc_attn_fwd_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
                          c_float, ctypes.c_uint32, c_void_p],
+    "sc_attn_fwd_seg_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, ctypes.POINTER(Segments), c_void_p, c_int, c_int, c_int,
+                             c_float, c_void_p, c_int, c_float, ctypes.c_uint32, c_void_p],
+    "sc_wav_prep_seg": [c_void_p, c_i64, c_void_p, c_void_p, ctypes.POINTER(Segments), c_int, c_int, c_int, c_void_p],
+    "sc_conv0_stats_len": [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sc_conv0_gn_gelu_seg": [c_void_p, ctypes.POINTER(Segments), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "sc_conv0_ln_gelu_seg": [c_void_p, ctypes.POINTER(Segments), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p],
+    "sc_posconv_prep_seg": [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Segments), c_int, c_int, c_int, c_void_p],
+    "sc_posconv_seg_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Segments), c_int, c_int, c_int, c_void_p],
+    "sc_wsum_fwd_seg": [c_void_p, c_void_p, c_int, c_void_p, ctypes.POINTER(Segments), c_int, c_int, c_int, c_int, c_void_p],
+    "sc_wsum_bwd_seg": [c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.POINTER(Segments), c_int, c_int, c_int, c_int, c_void_p],
     "sc_attn_bwd_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int,
                          c_int, c_int, c_float, c_int, c_float, ctypes.c_uint32, c_void_p],
@@ -219,7 +236,7 @@ def lib() -> ctypes.CDLL:
         cdll.sc_infonce_workspace_floats.restype = ctypes.c_int64
         cdll.sc_sizeof.argtypes = [c_int]
         cdll.sc_sizeof.restype = ctypes.c_int64
-        for what, cls in enumerate((GemmArgs, HubertLayerArgs, RtGemmArgs, RtLnArgs, RtLnBwdArgs)):
+        for what, cls in enumerate((GemmArgs, HubertLayerArgs, RtGemmArgs, RtLnArgs, RtLnBwdArgs, Segments)):
             if cdll.sc_sizeof(what) != ctypes.sizeof(cls):
                 raise RuntimeError(f"{cls.__name__}: ctypes mirror has {ctypes.sizeof(cls)} bytes, the library's struct {cdll.sc_sizeof(what)} "
                                    "(include/speechclip_hip.h and _lib.py are out of step, or a stale .so)")

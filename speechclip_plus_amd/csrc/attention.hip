@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                                                         const int32_t* __restrict__ valid_len,
                                                         uint16_t* __restrict__ out, int64_t ldo, int R, int H, int D,
                                                         float c /* scale * log2(e) */, float* __restrict__ lse2, int causal,
-                                                        float drop_p, uint32_t drop_seed) {
+                                                        float drop_p, uint32_t drop_seed, const int32_t* __restrict__ row0,
+                                                        const int32_t* __restrict__ work, int npairs, int rows_total, int max_pitch) {
     __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
     __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
 
@@ -30,22 +31,47 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     // 1-D grid, XCD-aware decode: blocks bid, bid + 8, ... share an XCD (and its L2); give each XCD a contiguous
     // range of (utterance, head, q-block) triples with the q-block fastest, so the R/128 workgroups that re-read the
     // same K / V^T of one (utterance, head) hit in that XCD's L2 instead of fetching it once per XCD.
-    const int nqb = R >> 7;
+    const int nqb = (R + 127) >> 7;
     int logical;
     {
         const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int qblk = logical % nqb, bh = logical / nqb;
-    const int h = bh % H, b = bh / H;
-    const int q0 = qblk * 128 + wave * 32;
+    // uniform rows: utterance b at row b R.  Ragged rows (row0 != NULL, sc_segments): utterance b at row0[b] with its own pitch; the
+    // (utterance, q-block) pairs come from the host's work list (longest first) or, without one, from the (B x max q-blocks) rectangle
+    int qblk, h, b, r0;
+    if (row0) {
+        const int pair = logical % npairs;
+        h = logical / npairs;
+        if (work) {
+            const int code = work[pair];
+            b = code & 0xffff;
+            qblk = code >> 16;
+        } else {
+            b = pair / nqb;
+            qblk = pair % nqb;
+        }
+        r0 = row0[b];
+        R = row0[b + 1] - r0;                                        // this utterance's pitch (a multiple of 32)
+        if (qblk * 128 >= R) return;                                 // uniform for the workgroup, before any barrier
+    } else {
+        qblk = logical % nqb;
+        const int bh = logical / nqb;
+        h = bh % H;
+        b = bh / H;
+        r0 = b * R;
+    }
+    // a last block of 32 / 64 / 96 queries: the waves past the pitch still stage K / V^T and meet the barriers, but neither multiply
+    // nor store (their rows belong to the next utterance)
+    const bool wave_on = qblk * 128 + wave * 32 < R;
+    const int q0 = wave_on ? qblk * 128 + wave * 32 : 0;
     int n_valid = valid_len[b];
     n_valid = max(1, min(n_valid, R));
 
     // Q fragments (B operand): Q[q0 + l31][ks*16 + 8*half + j]
     bf16x8 qf[4];
     {
-        const uint16_t* qp = qk + ((int64_t)b * R + q0 + l31) * ldqk + h * 64 + 8 * half;
+        const uint16_t* qp = qk + ((int64_t)r0 + q0 + l31) * ldqk + h * 64 + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
     }
@@ -57,8 +83,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int id = tid + i * 256, row = id >> 3, ch = id & 7;
-        kg[i] = qk + ((int64_t)b * R + row) * ldqk + D + h * 64 + ch * 8;
-        vg[i] = vt + (((int64_t)b * H + h) * 64 + row) * R + ch * 8;
+        kg[i] = qk + ((int64_t)r0 + row) * ldqk + D + h * 64 + ch * 8;
+        vg[i] = vt + (int64_t)D * r0 + (int64_t)(h * 64 + row) * R + ch * 8;      // V^T of the utterance: [H, 64, pitch] at D * r0
         k_lds[i] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
         v_lds0[i] = row * 128 + (((2 * ch) ^ ((row >> 1) & 15)) << 3);
         v_lds1[i] = row * 128 + (((2 * ch + 1) ^ ((row >> 1) & 15)) << 3);
@@ -73,7 +99,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     // attention-probability dropout (fairseq attention_dropout, train mode): P' = mask . P / (1 - p) with the row sum taken
     // over the un-masked P; element (b, h, q, k) -> sc_hash32 lane as in sc_common.h
     const uint32_t drop_thr = DROP ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
-    const uint32_t drop_row = (uint32_t)(((b * H + h) * R + qrow)) * (uint32_t)R;
+    const uint32_t drop_row = row0 ? (uint32_t)(h * rows_total + r0 + qrow) * (uint32_t)max_pitch
+                                   : (uint32_t)(((b * H + h) * R + qrow)) * (uint32_t)R;
     if (causal) n_valid = min(n_valid, qblk * 128 + 128);           // keys beyond the block's last query are all masked
     const int ntiles = (n_valid + KT - 1) / KT;
     // prefetch registers as named scalars: arrays indexed across the tile loop were being placed in scratch
@@ -98,6 +125,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         // Two 32-key blocks per tile, software-pipelined inside the wave: both S^T blocks are issued first, so the
         // matrix pipe works on block 1 while the VALU runs block 0's softmax, and on P.V of block 0 during block 1's.
         const bool blk1 = key0 + 32 < n_valid;                       // wave-uniform
+        if (wave_on) {
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
@@ -206,14 +234,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
             softmax_block(s1, key0 + 32, pf1);
             pv_block(1, pf1);
         }
+        }
         __syncthreads();
     }
+    if (!wave_on) return;
 
     const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
     const float inv = DROP ? 1.0f / (l_tot * (1.0f - drop_p)) : 1.0f / l_tot;
-    if (lse2 && half == 0) lse2[((int64_t)b * H + h) * R + qrow] = m_run * c + __builtin_amdgcn_logf(l_tot);   // log2 domain
-    uint16_t* op = out + ((int64_t)b * R + q0 + l31) * ldo + h * 64 + 4 * half;
+    if (lse2 && half == 0)
+        lse2[row0 ? (int64_t)h * rows_total + r0 + qrow : ((int64_t)b * H + h) * R + qrow] = m_run * c + __builtin_amdgcn_logf(l_tot);   // log2 domain
+    uint16_t* op = out + ((int64_t)r0 + q0 + l31) * ldo + h * 64 + 4 * half;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         uint2 w0, w1;
@@ -232,7 +263,10 @@ extern "C" int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* 
                                 sc_bf16* out, int64_t ldo, int32_t B, int32_t R, int32_t H, int32_t D, float scale,
                                 float* lse2, int32_t causal, float drop_p, uint32_t drop_seed, void* stream) {
     SC_CHECK(qk && vt && valid_len && out, "sc_attn_fwd_bf16: null pointer");
-    SC_CHECK(B > 0 && H > 0 && R > 0 && R % 128 == 0, "sc_attn_fwd_bf16: R=%d must be a positive multiple of 128", R);
+    // R % 128 != 0 (round 4): a last q-block of 32 / 64 / 96 rows; the K / V^T tiles of 64 keys may then read up to 32 rows / 64
+    // elements past an utterance (into the next one, or - behind the last - into slack the caller provides: 64 rows of qk, 64
+    // elements of vt); what they read there is masked
+    SC_CHECK(B > 0 && H > 0 && R > 0 && R % 32 == 0, "sc_attn_fwd_bf16: R=%d must be a positive multiple of 32", R);
     SC_CHECK(D == H * 64, "sc_attn_fwd_bf16: head_dim must be 64 (D=%d, H=%d)", D, H);
     SC_CHECK(causal == 0 || causal == 1 || causal == 32 || causal == 64, "sc_attn_fwd_bf16: causal=%d (0, 1, or a segment of 32 / 64 rows)", causal);
     SC_CHECK(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || (int64_t)B * H * R * R < ((int64_t)1 << 32)),
@@ -240,13 +274,38 @@ extern "C" int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* 
     SC_CHECK(ldqk % 8 == 0 && ldo % 4 == 0 && ldqk >= 2 * D && ldo >= D, "sc_attn_fwd_bf16: bad leading dims");
     SC_CHECK(((uintptr_t)qk % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0,
              "sc_attn_fwd_bf16: alignment");
-    dim3 grid((R / 128) * H * B);
+    dim3 grid(((R + 127) / 128) * H * B);
     if (drop_p > 0.f)
         hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R,
-                           H, D, scale * 1.4426950408889634f, lse2, causal, drop_p, drop_seed);
+                           H, D, scale * 1.4426950408889634f, lse2, causal, drop_p, drop_seed, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, 0, 0);
     else
         hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R,
-                           H, D, scale * 1.4426950408889634f, lse2, causal, drop_p, drop_seed);
+                           H, D, scale * 1.4426950408889634f, lse2, causal, drop_p, drop_seed, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, 0, 0);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_attn_fwd_seg_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len, sc_bf16* out, int64_t ldo,
+                                    const sc_segments* seg, const int32_t* work, int32_t nwork, int32_t H, int32_t D, float scale,
+                                    float* lse2, int32_t causal, float drop_p, uint32_t drop_seed, void* stream) {
+    SC_CHECK(qk && vt && valid_len && out && seg && seg->row0, "sc_attn_fwd_seg_bf16: null pointer");
+    SC_CHECK(seg->B > 0 && seg->B < 65536 && H > 0 && seg->rows > 0 && seg->max_pitch > 0 && seg->max_pitch % 32 == 0 && (!work || nwork > 0),
+             "sc_attn_fwd_seg_bf16: B=%d rows=%d max_pitch=%d", seg->B, seg->rows, seg->max_pitch);
+    SC_CHECK(D == H * 64, "sc_attn_fwd_seg_bf16: head_dim must be 64 (D=%d, H=%d)", D, H);
+    SC_CHECK(causal == 0 || causal == 1, "sc_attn_fwd_seg_bf16: causal=%d", causal);
+    SC_CHECK(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || (int64_t)H * seg->rows * seg->max_pitch < ((int64_t)1 << 32)),
+             "sc_attn_fwd_seg_bf16: drop_p=%f (needs H*rows*max_pitch < 2^32)", (double)drop_p);
+    SC_CHECK(ldqk % 8 == 0 && ldo % 4 == 0 && ldqk >= 2 * D && ldo >= D, "sc_attn_fwd_seg_bf16: bad leading dims");
+    SC_CHECK(((uintptr_t)qk % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0, "sc_attn_fwd_seg_bf16: alignment");
+    const int nqb = (seg->max_pitch + 127) / 128;
+    const int npairs = work ? nwork : seg->B * nqb;
+    dim3 grid(npairs * H);
+    if (drop_p > 0.f)
+        hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, seg->max_pitch,
+                           H, D, scale * 1.4426950408889634f, lse2, causal, drop_p, drop_seed, seg->row0, work, npairs, seg->rows, seg->max_pitch);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, seg->max_pitch,
+                           H, D, scale * 1.4426950408889634f, lse2, causal, drop_p, drop_seed, seg->row0, work, npairs, seg->rows, seg->max_pitch);
     SC_LAUNCH_CHECK();
     return 0;
 }

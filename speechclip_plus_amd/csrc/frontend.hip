@@ -14,15 +14,21 @@ namespace {
 // one block per utterance: optional layer_norm over the utterance's own samples, zero padding to ldw_out
 // (normalise: 1024 threads, four independent fp64 accumulator pairs per thread - the statistics pass is a latency-bound
 // serial loop otherwise: 328 us at 10 s / 256 threads)
+// row0 != NULL (ragged rows, sc_segments): utterance b's region is [spr * row0[b], spr * row0[b + 1]) of ONE flat buffer
 __global__ __launch_bounds__(1024) void wav_prep_kernel(const float* __restrict__ wav, int64_t ldw_in,
                                                         const int64_t* __restrict__ wav_len, float* __restrict__ out,
-                                                        int64_t ldw_out, int L, int normalize) {
+                                                        int64_t ldw_out, int L, int normalize, const int32_t* __restrict__ row0, int spr) {
     __shared__ double red[2][16];
     const int b = blockIdx.x;
     int len = (int)wav_len[b];
     len = max(0, min(len, L));
     const float* x = wav + (int64_t)b * ldw_in;
     float* o = out + (int64_t)b * ldw_out;
+    if (row0) {
+        const int r0 = row0[b];
+        o = out + (int64_t)r0 * spr;
+        ldw_out = (int64_t)(row0[b + 1] - r0) * spr;
+    }
     float mean = 0.f, rstd = 1.f;
     if (normalize) {
         double a[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -67,12 +73,15 @@ __global__ __launch_bounds__(1024) void wav_prep_kernel(const float* __restrict_
 }
 
 // partial[(b*nchunk + chunk)*66 + e]: e < 55 Gram (j <= j'), 55..64 sums
+// wav_len != NULL: the caller's un-prepared batch - samples at and past wav_len[b] read as 0 (windows that lie wholly behind the
+// utterance add nothing and are skipped); the sums are those of the zero-padded waveform, term for term
 __global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ wav, int64_t ldw, int T0,
-                                                          int nchunk, double* __restrict__ partial) {
+                                                          int nchunk, double* __restrict__ partial, const int64_t* __restrict__ wav_len) {
     __shared__ double red[4][SC_CONV0_NSTAT];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int per = (T0 + nchunk - 1) / nchunk;
-    const int t_begin = chunk * per, t_end = min(T0, t_begin + per);
+    const int len = wav_len ? (int)wav_len[b] : 0x7fffffff;
+    const int t_begin = chunk * per, t_end = min(min(T0, t_begin + per), wav_len ? (len + 4) / 5 : 0x7fffffff);
     const float* x = wav + (int64_t)b * ldw;
     double acc[65];
 #pragma unroll
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restric
     for (int t = t_begin + threadIdx.x; t < t_end; t += blockDim.x) {
         float v[10];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];
+        for (int j = 0; j < 10; ++j) v[j] = (5 * t + j < len) ? x[5 * t + j] : 0.f;
         int e = 0;
 #pragma unroll
         for (int j = 0; j < 10; ++j)
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             void* __restrict__ out_, int R0, int C,
-                                                            int rows_per_block) {
+                                                            int rows_per_block, const int32_t* __restrict__ row0, int spr) {
     uint16_t* out = (uint16_t*)out_;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -156,7 +165,15 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cgroups = C / 512;   // C is a multiple of 512 (checked on the host)
     const float* x = wav + (int64_t)b * ldw;
+    int64_t orow = (int64_t)b * R0;                 // first output row of the utterance
+    if (row0) {                                     // ragged rows: flat waveform, utterance at sample spr * row0[b], spr / 5 rows per row
+        const int r0 = row0[b];
+        x = wav + (int64_t)r0 * spr;
+        orow = (int64_t)r0 * (spr / 5);
+        R0 = (row0[b + 1] - r0) * (spr / 5);
+    }
     const int t_begin = blockIdx.x * rows_per_block;
+    if (t_begin >= R0) return;
     const int t_end = min(R0, t_begin + rows_per_block);
     for (int cg = 0; cg < cgroups; ++cg) {
         const int c0 = cg * 512 + lane * 8;
@@ -184,14 +201,14 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
                 o[2 * i + 1] = g.y;
             }
             if constexpr (F32OUT) {
-                float* of = (float*)out_ + ((int64_t)b * R0 + t) * C + c0;
+                float* of = (float*)out_ + (orow + t) * C + c0;
                 *(f32x4*)of = f32x4{o[0], o[1], o[2], o[3]};
                 *(f32x4*)(of + 4) = f32x4{o[4], o[5], o[6], o[7]};
             } else {
                 uint4 u;
                 u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
                 u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
-                *(uint4*)(out + ((int64_t)b * R0 + t) * C + c0) = u;
+                *(uint4*)(out + (orow + t) * C + c0) = u;
             }
         }
     }
@@ -205,14 +222,23 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
-                                                            void* __restrict__ out_, int R0, int rows_per_block) {
+                                                            void* __restrict__ out_, int R0, int rows_per_block,
+                                                            const int32_t* __restrict__ row0, int spr) {
     constexpr int C = 512;
     uint16_t* out = (uint16_t*)out_;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* x = wav + (int64_t)b * ldw;
+    int64_t orow = (int64_t)b * R0;
+    if (row0) {                                     // ragged rows: see conv0_gn_gelu_kernel
+        const int r0 = row0[b];
+        x = wav + (int64_t)r0 * spr;
+        orow = (int64_t)r0 * (spr / 5);
+        R0 = (row0[b + 1] - r0) * (spr / 5);
+    }
     const int t_begin = blockIdx.x * rows_per_block;
+    if (t_begin >= R0) return;
     const int t_end = min(R0, t_begin + rows_per_block);
     const int c0 = lane * 8;
     float w[8][10], bs[8], gm[8], bt[8];
@@ -250,14 +276,14 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
             o[i + 1] = g.y;
         }
         if constexpr (F32OUT) {
-            float* of = (float*)out_ + ((int64_t)b * R0 + t) * C + c0;
+            float* of = (float*)out_ + (orow + t) * C + c0;
             *(f32x4*)of = f32x4{o[0], o[1], o[2], o[3]};
             *(f32x4*)(of + 4) = f32x4{o[4], o[5], o[6], o[7]};
         } else {
             uint4 u;
             u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
             u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
-            *(uint4*)(out + ((int64_t)b * R0 + t) * C + c0) = u;
+            *(uint4*)(out + (orow + t) * C + c0) = u;
         }
     }
 }
@@ -490,7 +516,17 @@ extern "C" int sc_wav_prep(const float* wav, int64_t ldw_in, const int64_t* wav_
     SC_CHECK(wav && wav_len && out, "sc_wav_prep: null pointer");
     SC_CHECK(B > 0 && L > 0 && ldw_out >= L && ldw_in >= L, "sc_wav_prep: bad sizes");
     // without normalisation the kernel is a pure copy: spread each utterance over 32 blocks
-    hipLaunchKernelGGL(wav_prep_kernel, dim3(B, normalize ? 4 : 32), dim3(normalize ? 1024 : 256), 0, (hipStream_t)stream, wav, ldw_in, wav_len, out, ldw_out, L, normalize);
+    hipLaunchKernelGGL(wav_prep_kernel, dim3(B, normalize ? 4 : 32), dim3(normalize ? 1024 : 256), 0, (hipStream_t)stream, wav, ldw_in, wav_len, out, ldw_out, L, normalize, (const int32_t*)nullptr, 0);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_wav_prep_seg(const float* wav, int64_t ldw_in, const int64_t* wav_len, float* out, const sc_segments* seg,
+                               int32_t samples_per_row, int32_t L, int32_t normalize, void* stream) {
+    SC_CHECK(wav && wav_len && out && seg && seg->row0, "sc_wav_prep_seg: null pointer");
+    SC_CHECK(seg->B > 0 && L > 0 && ldw_in >= L && samples_per_row > 0 && samples_per_row % 5 == 0, "sc_wav_prep_seg: bad sizes");
+    hipLaunchKernelGGL(wav_prep_kernel, dim3(seg->B, normalize ? 4 : 32), dim3(normalize ? 1024 : 256), 0, (hipStream_t)stream, wav, ldw_in, wav_len,
+                       out, (int64_t)0, L, normalize, seg->row0, samples_per_row);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -499,7 +535,16 @@ extern "C" int sc_conv0_stats(const float* wav, int64_t ldw, int32_t B, int32_t 
                               void* stream) {
     SC_CHECK(wav && partial, "sc_conv0_stats: null pointer");
     SC_CHECK(B > 0 && T0 > 0 && nchunk > 0 && ldw >= 5 * (int64_t)(T0 - 1) + 10, "sc_conv0_stats: bad sizes");
-    hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, wav, ldw, T0, nchunk, partial);
+    hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, wav, ldw, T0, nchunk, partial, (const int64_t*)nullptr);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_stats_len(const float* wav, int64_t ldw, const int64_t* wav_len, int32_t B, int32_t T0, int32_t nchunk,
+                                  double* partial, void* stream) {
+    SC_CHECK(wav && wav_len && partial, "sc_conv0_stats_len: null pointer");
+    SC_CHECK(B > 0 && T0 > 0 && nchunk > 0, "sc_conv0_stats_len: bad sizes");
+    hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, wav, ldw, T0, nchunk, partial, wav_len);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -520,7 +565,23 @@ extern "C" int sc_conv0_gn_gelu(const float* wav, int64_t ldw, const float* w0, 
     SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_gn_gelu: alignment");
     const int rows_per_block = 128;
     dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
-    hipLaunchKernelGGL(conv0_gn_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, scale, shift, (void*)out, R0, C, rows_per_block);
+    hipLaunchKernelGGL(conv0_gn_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, scale, shift, (void*)out, R0, C, rows_per_block,
+                       (const int32_t*)nullptr, 0);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_gn_gelu_seg(const float* wav_flat, const sc_segments* seg, int32_t samples_per_row, const float* w0, const float* scale,
+                                    const float* shift, sc_bf16* out, int32_t C, void* stream) {
+    SC_CHECK(wav_flat && seg && seg->row0 && w0 && scale && shift && out, "sc_conv0_gn_gelu_seg: null pointer");
+    SC_CHECK(C % 512 == 0 && samples_per_row > 0 && samples_per_row % 5 == 0 && seg->B > 0 && seg->max_pitch > 0,
+             "sc_conv0_gn_gelu_seg: C=%d must be a multiple of 512, samples_per_row a multiple of 5", C);
+    SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_gn_gelu_seg: alignment");
+    const int rows_per_block = 128;
+    const int R0max = seg->max_pitch * (samples_per_row / 5);
+    dim3 grid((R0max + rows_per_block - 1) / rows_per_block, seg->B);
+    hipLaunchKernelGGL(conv0_gn_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav_flat, (int64_t)0, w0, scale, shift, (void*)out, 0, C,
+                       rows_per_block, seg->row0, samples_per_row);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -532,7 +593,8 @@ extern "C" int sc_conv0_gn_gelu_f32(const float* wav, int64_t ldw, const float* 
     SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_gn_gelu_f32: alignment");
     const int rows_per_block = 128;
     dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
-    hipLaunchKernelGGL(conv0_gn_gelu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, scale, shift, (void*)out, R0, C, rows_per_block);
+    hipLaunchKernelGGL(conv0_gn_gelu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, scale, shift, (void*)out, R0, C, rows_per_block,
+                       (const int32_t*)nullptr, 0);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -544,7 +606,23 @@ extern "C" int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, 
     SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_ln_gelu: alignment");
     const int rows_per_block = 128;
     dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
-    hipLaunchKernelGGL(conv0_ln_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, (void*)out, R0, rows_per_block);
+    hipLaunchKernelGGL(conv0_ln_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, (void*)out, R0, rows_per_block,
+                       (const int32_t*)nullptr, 0);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_ln_gelu_seg(const float* wav_flat, const sc_segments* seg, int32_t samples_per_row, const float* w0, const float* bias,
+                                    const float* gamma, const float* beta, float eps, sc_bf16* out, int32_t C, void* stream) {
+    SC_CHECK(wav_flat && seg && seg->row0 && w0 && gamma && beta && out, "sc_conv0_ln_gelu_seg: null pointer");
+    SC_CHECK(C == 512 && samples_per_row > 0 && samples_per_row % 5 == 0 && seg->B > 0 && seg->max_pitch > 0,
+             "sc_conv0_ln_gelu_seg: C must be 512 (got %d), samples_per_row a multiple of 5", C);
+    SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_ln_gelu_seg: alignment");
+    const int rows_per_block = 128;
+    const int R0max = seg->max_pitch * (samples_per_row / 5);
+    dim3 grid((R0max + rows_per_block - 1) / rows_per_block, seg->B);
+    hipLaunchKernelGGL(conv0_ln_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav_flat, (int64_t)0, w0, bias, gamma, beta, eps, (void*)out, 0,
+                       rows_per_block, seg->row0, samples_per_row);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -556,7 +634,8 @@ extern "C" int sc_conv0_ln_gelu_f32(const float* wav, int64_t ldw, const float* 
     SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_ln_gelu_f32: alignment");
     const int rows_per_block = 128;
     dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
-    hipLaunchKernelGGL(conv0_ln_gelu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, (void*)out, R0, rows_per_block);
+    hipLaunchKernelGGL(conv0_ln_gelu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, (void*)out, R0, rows_per_block,
+                       (const int32_t*)nullptr, 0);
     SC_LAUNCH_CHECK();
     return 0;
 }

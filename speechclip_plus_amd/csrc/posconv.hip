@@ -22,7 +22,8 @@ namespace {
 template <int DG, int NW>                         // channels per group; waves per workgroup (8: one workgroup per CU, 4: two)
 __global__ __launch_bounds__(NW * 64) void posconv_kernel(const uint16_t* __restrict__ xg, const uint16_t* __restrict__ w,
                                                       const float* __restrict__ bias, const uint16_t* __restrict__ res,
-                                                      uint16_t* __restrict__ out, int B, int R, int D, int G, int Kp, int Rp) {
+                                                      uint16_t* __restrict__ out, int B, int R, int D, int G, int Kp, int Rp,
+                                                      const int32_t* __restrict__ row0, int seg_rows) {
     constexpr int FN = DG / 16;                   // channel fragments per wave
     constexpr int KS = 2 * DG / 32;               // MFMA k-steps per tap pair
     constexpr int APR = DG / 8;                   // 16-byte atoms per frame
@@ -55,6 +56,16 @@ __global__ __launch_bounds__(NW * 64) void posconv_kernel(const uint16_t* __rest
         m0 = (L % mb) * PC_ROWS;
     }
     const uint16_t* xs = xg + ((int64_t)g * B + bi) * Rp * DG;            // padded frames of this (group, utterance): [Rp, DG]
+    int64_t orow = (int64_t)bi * R;                                       // first output row of the utterance
+    if (row0) {
+        // ragged rows (sc_segments): R = the longest pitch (grid sizing); the utterance's own pitch decides what this workgroup does
+        const int r0 = row0[bi];
+        R = row0[bi + 1] - r0;
+        if (m0 >= R) return;                                              // uniform for the workgroup, before any barrier
+        Rp = R + Kp;
+        xs = xg + ((int64_t)g * (seg_rows + (int64_t)Kp * B) + r0 + (int64_t)Kp * bi) * DG;
+        orow = r0;
+    }
     const uint16_t* wg = w + (int64_t)g * DG * Kp * DG;                   // [DG out, Kp * DG] tap-major
     const int ldw = Kp * DG;
     const int ntp = Kp / 2;                                               // tap pairs
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(NW * 64) void posconv_kernel(const uint16_t* __rest
     for (int mi = 0; mi < 4; ++mi) {
         const int t = m0 + wave * 64 + 16 * mi + l15;
         if (t >= R) continue;
-        const int64_t o = ((int64_t)bi * R + t) * D + g * DG + 4 * q;
+        const int64_t o = (orow + t) * D + g * DG + 4 * q;
 #pragma unroll
         for (int ni = 0; ni < FN; ++ni) {
             const f32x4 v = acc[mi][ni];
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void posconv_kernel(const uint16_t* __rest
 
 template <int DG, int NW>
 static int launch_posconv(const uint16_t* xg, const uint16_t* w, const float* bias, const uint16_t* res, uint16_t* out, int B, int R,
-                          int D, int G, int Kp, int Rp, hipStream_t s) {
+                          int D, int G, int Kp, int Rp, hipStream_t s, const int32_t* row0 = nullptr, int seg_rows = 0) {
     constexpr int PC_ROWS = NW * 64;
     constexpr int LDS = (PC_ROWS + 128) * 128 + 3 * (2 * DG / 32) * DG * 64;
     static sc_lds_attr_once attr;
@@ -189,7 +200,7 @@ static int launch_posconv(const uint16_t* xg, const uint16_t* w, const float* bi
         return -3;
     }
     const int mb = (R + PC_ROWS - 1) / PC_ROWS;
-    hipLaunchKernelGGL((posconv_kernel<DG, NW>), dim3(G * B * mb), dim3(NW * 64), LDS, s, xg, w, bias, res, out, B, R, D, G, Kp, Rp);
+    hipLaunchKernelGGL((posconv_kernel<DG, NW>), dim3(G * B * mb), dim3(NW * 64), LDS, s, xg, w, bias, res, out, B, R, D, G, Kp, Rp, row0, seg_rows);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -213,4 +224,22 @@ extern "C" int sc_posconv_bf16(const sc_bf16* xg, const sc_bf16* w, const float*
     // fall under the other's MFMAs: 283 vs 306 us at the step's shape); Dg = 64: its 96 KiB allow one workgroup per CU, 8 waves x 512 frames
     // (396 vs 514 us)
     return DG == 48 ? launch_posconv<48, 4>(xp, wp, bias, rp, op, B, R, D, G, Kp, Rp, s) : launch_posconv<64, 8>(xp, wp, bias, rp, op, B, R, D, G, Kp, Rp, s);
+}
+
+extern "C" int sc_posconv_seg_bf16(const sc_bf16* xg, const sc_bf16* w, const float* bias, const sc_bf16* residual, sc_bf16* out,
+                                   const sc_segments* seg, int32_t D, int32_t G, int32_t Kp, void* stream) {
+    SC_CHECK(xg && w && out && seg && seg->row0, "sc_posconv_seg_bf16: null pointer");
+    SC_CHECK(seg->B > 0 && seg->max_pitch > 0 && seg->rows > 0 && G > 0 && D % G == 0, "sc_posconv_seg_bf16: bad shape B=%d D=%d G=%d", seg->B, D, G);
+    const int DG = D / G;
+    SC_CHECK(DG == 48 || DG == 64, "sc_posconv_seg_bf16: channels per group must be 48 or 64 (D=%d, G=%d)", D, G);
+    SC_CHECK(Kp == 128, "sc_posconv_seg_bf16: kernel must be 128 taps (Kp=%d)", Kp);
+    SC_CHECK(((uintptr_t)xg % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 8) == 0 &&
+                 (!residual || ((uintptr_t)residual % 8) == 0) && (!bias || ((uintptr_t)bias % 16) == 0),
+             "sc_posconv_seg_bf16: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const uint16_t *xp = (const uint16_t*)xg, *wp = (const uint16_t*)w, *rp = (const uint16_t*)residual;
+    uint16_t* op = (uint16_t*)out;
+    const int R = seg->max_pitch;
+    return DG == 48 ? launch_posconv<48, 4>(xp, wp, bias, rp, op, seg->B, R, D, G, Kp, R + Kp, s, seg->row0, seg->rows)
+                    : launch_posconv<64, 8>(xp, wp, bias, rp, op, seg->B, R, D, G, Kp, R + Kp, s, seg->row0, seg->rows);
 }

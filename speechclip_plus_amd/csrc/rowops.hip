@@ -484,6 +484,209 @@ __global__ __launch_bounds__(256) void posconv_prep_kernel(const uint16_t* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------- ragged rows (sc_segments, round 4)
+// Weighted sum from the segment layout (utterance b's frames at rows row0[b] + t of every h[n]) into a UNIFORM [B, Rout, D] buffer:
+// out[b, s] = sum_n w[n] h[n, row0[b] + s - row_off] for 0 <= s - row_off < pitch_b, zero elsewhere (every row of out is written).
+__global__ __launch_bounds__(256) void wsum_fwd_seg_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w, int NL,
+                                                           uint16_t* __restrict__ out, const int32_t* __restrict__ row0, int B, int Rout,
+                                                           int D, int row_off, int64_t plane) {
+    const int64_t chunks_per_row = D >> 3;
+    const int64_t total = (int64_t)B * Rout * chunks_per_row;
+    float wl[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) wl[n] = n < NL ? w[n] : 0.f;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t orow = q / chunks_per_row;
+        const int cc = (int)(q % chunks_per_row);
+        const int b = (int)(orow / Rout), t = (int)(orow % Rout) - row_off;
+        const int r0 = row0[b], pitch = row0[b + 1] - r0;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t >= 0 && t < pitch) {
+            const uint16_t* src = h + (int64_t)(r0 + t) * D + cc * 8;
+#pragma unroll 4
+            for (int n = 0; n < NL; ++n) {
+                const uint4 u = *(const uint4*)(src + n * plane);
+                const float wn = wl[n];
+                acc[0] += wn * bflo(u.x); acc[1] += wn * bfhi(u.x); acc[2] += wn * bflo(u.y); acc[3] += wn * bfhi(u.y);
+                acc[4] += wn * bflo(u.z); acc[5] += wn * bfhi(u.z); acc[6] += wn * bflo(u.w); acc[7] += wn * bfhi(u.w);
+            }
+        }
+        uint4 o;
+        o.x = pack2bf(acc[0], acc[1]); o.y = pack2bf(acc[2], acc[3]);
+        o.z = pack2bf(acc[4], acc[5]); o.w = pack2bf(acc[6], acc[7]);
+        *(uint4*)(out + orow * D + cc * 8) = o;
+    }
+}
+
+// as wsum_bwd_kernel, g in the uniform [B, Rout, D] layout, h in the segment layout
+__global__ __launch_bounds__(256) void wsum_bwd_seg_kernel(const uint16_t* __restrict__ h, const float* __restrict__ g, int NL,
+                                                           float* __restrict__ dw_partial, const int32_t* __restrict__ row0, int B, int Rout,
+                                                           int D, int row_off, int64_t plane) {
+    __shared__ float red[4][32];
+    const int64_t chunks_per_row = D >> 3;
+    const int64_t total = (int64_t)B * Rout * chunks_per_row;
+    float acc[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) acc[n] = 0.f;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t orow = q / chunks_per_row;
+        const int cc = (int)(q % chunks_per_row);
+        const int b = (int)(orow / Rout), t = (int)(orow % Rout) - row_off;
+        const int r0 = row0[b], pitch = row0[b + 1] - r0;
+        if (t < 0 || t >= pitch) continue;
+        const float* gp = g + orow * D + cc * 8;
+        const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+        const uint16_t* src = h + (int64_t)(r0 + t) * D + cc * 8;
+        const uint4 r = *(const uint4*)(src + (int64_t)(NL - 1) * plane);
+#pragma unroll
+        for (int n = 0; n < 31; ++n) {
+            if (n < NL - 1) {
+                const uint4 u = *(const uint4*)(src + n * plane);
+                acc[n] += g0[0] * (bflo(u.x) - bflo(r.x)) + g0[1] * (bfhi(u.x) - bfhi(r.x)) + g0[2] * (bflo(u.y) - bflo(r.y)) +
+                          g0[3] * (bfhi(u.y) - bfhi(r.y)) + g1[0] * (bflo(u.z) - bflo(r.z)) + g1[1] * (bfhi(u.z) - bfhi(r.z)) +
+                          g1[2] * (bflo(u.w) - bflo(r.w)) + g1[3] * (bfhi(u.w) - bfhi(r.w));
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        const float s = wave_sum(acc[n]);
+        if (lane == 0) red[wave][n] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NL)
+        dw_partial[(int64_t)blockIdx.x * NL + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <int NE>
+__global__ __launch_bounds__(256) void wsum_norm_fwd_seg_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w, int NL,
+                                                                uint16_t* __restrict__ out, const int32_t* __restrict__ row0, int B, int Rout,
+                                                                int D, int row_off, int64_t plane) {
+    const int lane = threadIdx.x & 63;
+    const int nchunks = D >> 3;
+    const int64_t orows = (int64_t)B * Rout;
+    for (int64_t orow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); orow < orows; orow += (int64_t)gridDim.x * 4) {
+        const int b = (int)(orow / Rout), t = (int)(orow % Rout) - row_off;
+        const int r0 = row0[b], pitch = row0[b + 1] - r0;
+        float acc[NE][8];
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+        if (t >= 0 && t < pitch) {
+            for (int n = 0; n < NL; ++n) {
+                float xh[NE][8];
+                load_row_norm<NE>(h + n * plane + (int64_t)(r0 + t) * D, lane, nchunks, D, 1e-5f, xh);
+                const float wn = w[n];
+#pragma unroll
+                for (int i = 0; i < NE; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i][j] += wn * xh[i][j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunks) {
+                uint4 o;
+                o.x = pack2bf(acc[i][0], acc[i][1]); o.y = pack2bf(acc[i][2], acc[i][3]);
+                o.z = pack2bf(acc[i][4], acc[i][5]); o.w = pack2bf(acc[i][6], acc[i][7]);
+                *(uint4*)(out + orow * D + ch * 8) = o;
+            }
+        }
+    }
+}
+
+template <int NE>
+__global__ __launch_bounds__(256) void wsum_norm_bwd_seg_kernel(const uint16_t* __restrict__ h, const float* __restrict__ g, int NL,
+                                                                float* __restrict__ dw_partial, const int32_t* __restrict__ row0, int B,
+                                                                int Rout, int D, int row_off, int64_t plane) {
+    __shared__ float red[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = D >> 3;
+    const int64_t orows = (int64_t)B * Rout;
+    float accn[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) accn[n] = 0.f;
+    for (int64_t orow = (int64_t)blockIdx.x * 4 + wave; orow < orows; orow += (int64_t)gridDim.x * 4) {
+        const int b = (int)(orow / Rout), t = (int)(orow % Rout) - row_off;
+        const int r0 = row0[b], pitch = row0[b + 1] - r0;
+        if (t < 0 || t >= pitch) continue;
+        const int64_t row = r0 + t;
+        float gv[NE][8];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunks) {
+                const float* gp = g + orow * D + ch * 8;
+                const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+                gv[i][0] = g0[0]; gv[i][1] = g0[1]; gv[i][2] = g0[2]; gv[i][3] = g0[3];
+                gv[i][4] = g1[0]; gv[i][5] = g1[1]; gv[i][6] = g1[2]; gv[i][7] = g1[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gv[i][j] = 0.f;
+            }
+        }
+        float xr[NE][8];
+        load_row_norm<NE>(h + (int64_t)(NL - 1) * plane + row * D, lane, nchunks, D, 1e-5f, xr);
+#pragma unroll
+        for (int n = 0; n < 31; ++n) {
+            if (n < NL - 1) {
+                float xh[NE][8];
+                load_row_norm<NE>(h + n * plane + row * D, lane, nchunks, D, 1e-5f, xh);
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < NE; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d += gv[i][j] * (xh[i][j] - xr[i][j]);
+                accn[n] += d;
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        const float s = wave_sum(accn[n]);
+        if (lane == 0) red[wave][n] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NL)
+        dw_partial[(int64_t)blockIdx.x * NL + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// pos_conv input on ragged rows: xz[row] = masked x[row]; slab xg[g][row0[b] + 2 halo b + halo + t] = the same.  The slab layout moves
+// with the batch's lengths, so the halo rows are re-zeroed here: the rows t < halo of an utterance also clear its leading halo, the
+// last `halo` rows its trailing one (strided by the pitch when an utterance is shorter than a halo).
+__global__ __launch_bounds__(256) void posconv_prep_seg_kernel(const uint16_t* __restrict__ x, const int32_t* __restrict__ valid_len,
+                                                               uint16_t* __restrict__ xz, uint16_t* __restrict__ xg,
+                                                               const int32_t* __restrict__ chunk, int rows, int B, int D, int G, int halo) {
+    const int Dg = D / G;
+    const int cpg = Dg >> 3;
+    const int64_t chunks_per_row = D >> 3;
+    const int64_t total = (int64_t)rows * chunks_per_row;
+    const int64_t slab_rows = (int64_t)rows + 2 * halo * B;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(q / chunks_per_row);
+        const int cc = (int)(q % chunks_per_row);
+        const int4 sg = *(const int4*)(chunk + 4 * (row >> 5));       // (first row, pitch, utterance, -)
+        const int t = row - sg.x, pitch = sg.y, b = sg.z;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (t < valid_len[b]) u = *(const uint4*)(x + (int64_t)row * D + cc * 8);
+        *(uint4*)(xz + (int64_t)row * D + cc * 8) = u;
+        const int g = cc / cpg, cg = cc % cpg;
+        uint16_t* slab = xg + ((int64_t)g * slab_rows + sg.x + 2 * halo * b) * Dg + cg * 8;     // leading halo row 0 of (g, b)
+        *(uint4*)(slab + (int64_t)(halo + t) * Dg) = u;
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int v = t; v < halo; v += pitch) {
+            *(uint4*)(slab + (int64_t)v * Dg) = z;
+            *(uint4*)(slab + (int64_t)(halo + pitch + v) * Dg) = z;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sc_layernorm_bf16(const sc_bf16* x, int64_t ldx, const float* gamma, const float* beta, sc_bf16* y,
@@ -582,6 +785,61 @@ extern "C" int sc_posconv_prep(const sc_bf16* x, const int32_t* valid_len, sc_bf
     const int64_t total = (int64_t)B * R * (D / 8);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(posconv_prep_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, valid_len, xz, xg, B, R, D, G, halo);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_wsum_fwd_seg(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, const sc_segments* seg, int32_t Rout, int32_t D,
+                               int32_t row_off, int32_t normalize, void* stream) {
+    SC_CHECK(h && w && out && seg && seg->row0, "sc_wsum_fwd_seg: null pointer");
+    SC_CHECK(NL >= 1 && NL <= 32 && D % 8 == 0 && row_off >= 0 && Rout > row_off && seg->B > 0 && seg->rows > 0, "sc_wsum_fwd_seg: bad NL/D/row_off");
+    const int B = seg->B;
+    const int64_t plane = (int64_t)seg->rows * D;
+    hipStream_t s = (hipStream_t)stream;
+    if (normalize) {
+        SC_CHECK(D <= 1024, "sc_wsum_fwd_seg: normalised variant needs D <= 1024 (got %d)", D);
+        const int64_t rows = (int64_t)B * Rout;
+        const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+        if (D <= 512) hipLaunchKernelGGL(wsum_norm_fwd_seg_kernel<1>, dim3(grid), dim3(256), 0, s, h, w, NL, out, seg->row0, B, Rout, D, row_off, plane);
+        else hipLaunchKernelGGL(wsum_norm_fwd_seg_kernel<2>, dim3(grid), dim3(256), 0, s, h, w, NL, out, seg->row0, B, Rout, D, row_off, plane);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
+    const int64_t total = (int64_t)B * Rout * (D / 8);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wsum_fwd_seg_kernel, dim3(grid), dim3(256), 0, s, h, w, NL, out, seg->row0, B, Rout, D, row_off, plane);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_wsum_bwd_seg(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial, int32_t nblk, const sc_segments* seg,
+                               int32_t Rout, int32_t D, int32_t row_off, int32_t normalize, void* stream) {
+    SC_CHECK(h && g && dw_partial && seg && seg->row0, "sc_wsum_bwd_seg: null pointer");
+    SC_CHECK(NL >= 1 && NL <= 32 && D % 8 == 0 && nblk >= 1 && row_off >= 0 && Rout > row_off && seg->B > 0 && seg->rows > 0, "sc_wsum_bwd_seg: bad args");
+    const int B = seg->B;
+    const int64_t plane = (int64_t)seg->rows * D;
+    hipStream_t s = (hipStream_t)stream;
+    if (normalize) {
+        SC_CHECK(D <= 1024, "sc_wsum_bwd_seg: normalised variant needs D <= 1024 (got %d)", D);
+        if (D <= 512) hipLaunchKernelGGL(wsum_norm_bwd_seg_kernel<1>, dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+        else hipLaunchKernelGGL(wsum_norm_bwd_seg_kernel<2>, dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
+    hipLaunchKernelGGL(wsum_bwd_seg_kernel, dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_posconv_prep_seg(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_bf16* xg, const sc_segments* seg, int32_t D,
+                                   int32_t G, int32_t halo, void* stream) {
+    SC_CHECK(x && valid_len && xz && xg && seg && seg->chunk, "sc_posconv_prep_seg: null pointer");
+    SC_CHECK(G > 0 && D % G == 0 && (D / G) % 8 == 0 && seg->rows > 0 && seg->rows % 32 == 0 && seg->B > 0 && halo > 0,
+             "sc_posconv_prep_seg: D/G=%d must be a multiple of 8, rows a multiple of 32", D / G);
+    SC_CHECK(((uintptr_t)seg->chunk % 16) == 0, "sc_posconv_prep_seg: chunk table must be 16-byte aligned");
+    const int64_t total = (int64_t)seg->rows * (D / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(posconv_prep_seg_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, valid_len, xz, xg, seg->chunk, seg->rows, seg->B, D, G, halo);
     SC_LAUNCH_CHECK();
     return 0;
 }

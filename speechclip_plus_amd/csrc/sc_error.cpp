@@ -39,7 +39,7 @@ extern "C" uint32_t sc_hash32(uint32_t x) {
 }
 
 extern "C" const char* sc_last_error(void) { return g_err; }
-extern "C" int sc_abi_version(void) { return 3; }
+extern "C" int sc_abi_version(void) { return 4; }
 
 // sizeof of the argument structs, for bindings that mirror them by hand (ctypes): a layout mismatch is caught before the first call
 extern "C" int64_t sc_sizeof(int32_t what) {
@@ -49,6 +49,7 @@ extern "C" int64_t sc_sizeof(int32_t what) {
         case 2: return (int64_t)sizeof(sc_rt_gemm_args);
         case 3: return (int64_t)sizeof(sc_rt_ln_args);
         case 4: return (int64_t)sizeof(sc_rt_ln_bwd_args);
+        case 5: return (int64_t)sizeof(sc_segments);
         default: return -1;
     }
 }

@@ -242,7 +242,7 @@ class ParallelHeadFn(torch.autograd.Function):
         d_cls = d_x0.reshape(1, 1, D)
         d_ws, d_feat = None, None
         if hd is not None and ctx.needs_input_grad[1]:
-            d_ws = ops.wsum_bwd_logits(hd.hidden, dX, hd.w_soft, B, R, D, 1, normalize=hd.normalize, lazy=hd.lazy)
+            d_ws = ops.wsum_bwd_logits(hd.hidden, dX, hd.w_soft, B, R, D, 1, normalize=hd.normalize, lazy=hd.lazy, seg=hd.seg)
         if hd is not None and hd.layers_bwd is not None:           # unfrozen HuBERT layers: continue the chain below the weighted sum
             hd.layers_bwd(dX, hd.w_soft)
         if ctx.feat_meta is not None and ctx.needs_input_grad[2]:

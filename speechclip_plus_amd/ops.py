@@ -8,7 +8,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import RtGemmArgs, RtLnArgs, RtLnBwdArgs, GemmArgs, HubertLayerArgs, check, lib
+from ._lib import RtGemmArgs, RtLnArgs, RtLnBwdArgs, GemmArgs, HubertLayerArgs, Segments, check, lib
 
 
 def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
@@ -27,6 +27,59 @@ def aligned16(t: torch.Tensor) -> torch.Tensor:
 
 def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class RowSegments:
+    """Ragged row layout of one batch (``sc_segments``, include/speechclip_hip.h): utterance b owns rows [row0[b], row0[b + 1]) -
+    its own pitch, a multiple of 32 rows - of every activation buffer of the encoder.  Built on the host from the batch's lengths
+    (``host_tables``: pure python, tested on the CPU) and uploaded in one pinned, asynchronous copy.
+
+    ``pitch`` [B] rows per utterance; ``keys`` [B] the key count that sorts the attention work list (longest first)."""
+
+    def __init__(self, pitch, keys, device, storage: Optional[torch.Tensor] = None):
+        host, self.row0_host, self.n_work = self.host_tables(pitch, keys)
+        self.pitch = [int(p) for p in pitch]
+        self.B, self.rows, self.max_pitch = len(self.pitch), self.row0_host[-1], max(self.pitch)
+        n = host.numel()
+        if storage is not None:
+            assert storage.dtype == torch.int32 and storage.numel() >= n and storage.data_ptr() % 16 == 0
+            dev = storage[:n]
+            dev.copy_(host.pin_memory(), non_blocking=True)
+        else:
+            dev = host.pin_memory().to(device, non_blocking=True)
+        nch = self.rows // 32
+        self.chunk = dev[: 4 * nch]                              # first: the 16-byte entries stay 16-byte aligned
+        self.row0 = dev[4 * nch: 4 * nch + self.B + 1]
+        self.work = dev[4 * nch + self.B + 1:]
+        self._dev = dev
+        self.c = Segments()
+        self.c.row0, self.c.chunk = _p(self.row0), _p(self.chunk)
+        self.c.B, self.c.rows, self.c.max_pitch = self.B, self.rows, self.max_pitch
+
+    @staticmethod
+    def table_ints(B: int, max_rows: int) -> int:
+        """upper bound of the table size in int32 (storage for a plan: B utterances, at most ``max_rows`` rows)"""
+        return 4 * (max_rows // 32) + B + 1 + B * ((max_rows + 127) // 128 + 1)
+
+    @staticmethod
+    def host_tables(pitch, keys):
+        """-> (int32 tensor [chunk table | row0 | attention work list], row0 as a python list, number of work items).
+        chunk[c] = (first row, pitch, utterance, 0) of the utterance that owns rows 32 c .. 32 c + 31; work = (utterance | q-block << 16)
+        for every 128-query block, longest utterance first (its workgroups run longest: start them first)."""
+        B = len(pitch)
+        assert B < 65536 and all(int(p) > 0 and int(p) % 32 == 0 for p in pitch)
+        row0 = [0]
+        for p in pitch:
+            row0.append(row0[-1] + int(p))
+        chunk = []
+        for b, p in enumerate(pitch):
+            chunk.extend([row0[b], int(p), b, 0] * (int(p) // 32))
+        order = sorted(range(B), key=lambda b: (-int(keys[b]), b))
+        work = [b | (qb << 16) for b in order for qb in range((int(pitch[b]) + 127) // 128)]
+        return torch.tensor(chunk + row0 + work, dtype=torch.int32), row0, len(work)
+
+    def ref(self):
+        return ctypes.byref(self.c)
 
 
 class KernelTimer:
@@ -82,7 +135,8 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
              ln_stats: Optional[torch.Tensor] = None, ln_ns: int = 0, ln_colsum: Optional[torch.Tensor] = None,
              res_stats: Optional[torch.Tensor] = None, res_ns: int = 0, res_gamma: Optional[torch.Tensor] = None,
              res_beta: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None, ln_eps: float = 0.0,
-             tn: bool = False, k_total: int = 0, aux: Optional[torch.Tensor] = None, aux_mode: int = 0) -> int:
+             tn: bool = False, k_total: int = 0, aux: Optional[torch.Tensor] = None, aux_mode: int = 0,
+             seg: Optional["RowSegments"] = None) -> int:
     """C = epi(A . W^T); see sc_gemm_args in include/speechclip_hip.h.  Pointers are the tensors' data_ptr()
     (pass a sliced view to offset).  ``alg_rows``: rows that are algorithmic work (excludes layout padding),
     used only by the optional KernelTimer.  ``ln_*`` / ``res_*`` / ``stats_out``: LayerNorm folded into the GEMM (row-statistics
@@ -114,6 +168,9 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
         assert aux is not None and aux.dtype == torch.bfloat16 and Ct is None and aux.stride(0) == ldc and aux.stride(1) == 1
         a.Ct, a.aux_mode = _p(aux), int(aux_mode)
     a.tn = int(tn)          # C[m, n] = sum_r A[r, m] W[r, n]: both operands row-indexed by the reduction (weight gradients)
+    if seg is not None:     # ragged rows: the transposed (V^T) store looks its utterance up per 32-row chunk
+        assert M == seg.rows
+        a.seg_chunk = _p(seg.chunk)
     strips = 0
     if ln_stats is not None or stats_out is not None:
         for t in (ln_stats, ln_colsum, res_stats, res_gamma, res_beta, stats_out):
@@ -138,7 +195,8 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
 
 
 def hubert_layer_fwd(x: torch.Tensor, out: torch.Tensor, valid_len: torch.Tensor, w: dict, i: int, pl, B: int, R: int, T: int, D: int,
-                     F_: int, H: int, pre_ln: bool, p_attn: float = 0.0, p_res: float = 0.0, seeds=(0, 0, 0), fused=None) -> None:
+                     F_: int, H: int, pre_ln: bool, p_attn: float = 0.0, p_res: float = 0.0, seeds=(0, 0, 0), fused=None,
+                     seg: Optional["RowSegments"] = None) -> None:
     """One frozen HuBERT encoder layer in ONE C-ABI call (sc_hubert_layer_fwd: QKV -> attention -> out_proj -> LN -> FC1 -> FC2 ->
     LN on the caller's stream).  ``w``: the encoder's weight dict (keys l{i}_*), ``pl``: its plan (scratch buffers).
     ``fused`` = (x_stats or None, x_ns, out_stats): the LayerNorm-free form (the LayerNorms folded into the GEMMs; ``out`` receives
@@ -152,6 +210,9 @@ def hubert_layer_fwd(x: torch.Tensor, out: torch.Tensor, valid_len: torch.Tensor
     a.eps, a.p_attn, a.p_res = 1e-5, float(p_attn), float(p_res)
     a.seed_attn, a.seed_o, a.seed_fc2 = (int(s) & 0xffffffff for s in seeds)
     a.qk, a.vt, a.ctx, a.pre, a.x1, a.ffn = _p(pl.qk), _p(pl.vt), _p(pl.ctx), _p(pl.pre), _p(pl.x1), _p(pl.ffn)
+    if seg is not None:
+        a.seg = ctypes.pointer(seg.c)
+        a.attn_work, a.n_attn_work = _p(seg.work), seg.n_work
     if fused is not None:
         x_stats, x_ns, out_stats = fused
         a.fused_ln = 1
@@ -190,15 +251,21 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
 
 def attn_fwd(qk: torch.Tensor, vt: torch.Tensor, valid_len: torch.Tensor, out: torch.Tensor, B: int, R: int, H: int,
              D: int, scale: float, alg_flops: float = 0.0, lse2: Optional[torch.Tensor] = None, causal: bool = False,
-             drop_p: float = 0.0, drop_seed: int = 0) -> None:
+             drop_p: float = 0.0, drop_seed: int = 0, seg: Optional["RowSegments"] = None, use_work: bool = True) -> None:
+    """``seg``: ragged rows (B / R are then ignored; vt = per utterance [H, 64, pitch] back to back, as gemm_raw(seg=...) writes it)."""
     assert qk.dtype == torch.bfloat16 and vt.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
     assert valid_len.dtype == torch.int32
     if _timer is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib().sc_attn_fwd_bf16(_p(qk), qk.stride(0), _p(vt), _p(valid_len), _p(out), out.stride(0), B, R, H, D,
-                                 float(scale), _p(lse2), int(causal), float(drop_p), int(drop_seed) & 0xffffffff, _stream()),
-          "sc_attn_fwd_bf16")
+    if seg is not None:
+        check(lib().sc_attn_fwd_seg_bf16(_p(qk), qk.stride(0), _p(vt), _p(valid_len), _p(out), out.stride(0), seg.ref(),
+                                         _p(seg.work) if use_work else _p(None), seg.n_work if use_work else 0, H, D, float(scale), _p(lse2),
+                                         int(causal), float(drop_p), int(drop_seed) & 0xffffffff, _stream()), "sc_attn_fwd_seg_bf16")
+    else:
+        check(lib().sc_attn_fwd_bf16(_p(qk), qk.stride(0), _p(vt), _p(valid_len), _p(out), out.stride(0), B, R, H, D,
+                                     float(scale), _p(lse2), int(causal), float(drop_p), int(drop_seed) & 0xffffffff, _stream()),
+              "sc_attn_fwd_bf16")
     if _timer is not None:
         ev1.record()
         _timer.add("attn_fwd", ev0, ev1, float(alg_flops))
@@ -692,6 +759,40 @@ def wav_prep(wav: torch.Tensor, wav_len: torch.Tensor, out: torch.Tensor, normal
           "sc_wav_prep")
 
 
+def wav_prep_seg(wav: torch.Tensor, wav_len: torch.Tensor, out_flat: torch.Tensor, seg: "RowSegments", samples_per_row: int,
+                 normalize: bool) -> None:
+    """waveform into the ragged layout: utterance b at sample samples_per_row * row0[b] of ONE flat fp32 buffer (sc_wav_prep_seg)"""
+    assert wav.dtype == torch.float32 and wav_len.dtype == torch.int64 and out_flat.dtype == torch.float32
+    assert out_flat.numel() >= samples_per_row * seg.rows + 16
+    B, L = wav.shape
+    check(lib().sc_wav_prep_seg(_p(wav), wav.stride(0), _p(wav_len), _p(out_flat), seg.ref(), samples_per_row, L, int(normalize), _stream()),
+          "sc_wav_prep_seg")
+
+
+def conv0_groupnorm_gelu_seg(wav: torch.Tensor, wav_len: torch.Tensor, wav_flat: torch.Tensor, seg: "RowSegments", samples_per_row: int,
+                             w0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, T0: int, out: torch.Tensor, eps: float = 1e-5,
+                             nchunk: int = 32) -> None:
+    """conv layer 0 + GroupNorm + GELU on ragged rows.  The GroupNorm statistics run over the PADDED batch length T0 (fairseq feeds the
+    zero-padded batch, speech_encoder_plus.py:75) and come straight from the caller's [B, L] batch masked by wav_len; the activation is
+    written for the rows of the segment layout only."""
+    B, C = wav.shape[0], w0.shape[0]
+    partial = torch.empty(B * nchunk * 66, device=wav.device, dtype=torch.float64)
+    scale = torch.empty(B, C, device=wav.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    L = lib()
+    check(L.sc_conv0_stats_len(_p(wav), wav.stride(0), _p(wav_len), B, T0, nchunk, _p(partial), _stream()), "sc_conv0_stats_len")
+    check(L.sc_conv0_finalize(_p(partial), nchunk, _p(w0), _p(gamma), _p(beta), B, C, T0, float(eps), _p(scale), _p(shift), _stream()),
+          "sc_conv0_finalize")
+    check(L.sc_conv0_gn_gelu_seg(_p(wav_flat), seg.ref(), samples_per_row, _p(w0), _p(scale), _p(shift), _p(out), C, _stream()),
+          "sc_conv0_gn_gelu_seg")
+
+
+def conv0_layernorm_gelu_seg(wav_flat: torch.Tensor, seg: "RowSegments", samples_per_row: int, w0: torch.Tensor, bias: Optional[torch.Tensor],
+                             gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float = 1e-5) -> None:
+    check(lib().sc_conv0_ln_gelu_seg(_p(wav_flat), seg.ref(), samples_per_row, _p(w0), _p(bias), _p(gamma), _p(beta), float(eps), _p(out),
+                                     w0.shape[0], _stream()), "sc_conv0_ln_gelu_seg")
+
+
 def conv0_groupnorm_gelu(wav_pad: torch.Tensor, w0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, T0: int,
                          R0: int, out: torch.Tensor, eps: float = 1e-5, nchunk: int = 32):
     """conv layer 0 + GroupNorm(C groups) over t < T0 + GELU -> out[B*R0, C] bf16 (channels-last).  Returns what the backward
@@ -754,6 +855,25 @@ def posconv_prep(x: torch.Tensor, valid_len: torch.Tensor, xz: torch.Tensor, xg:
     check(lib().sc_posconv_prep(_p(x), _p(valid_len), _p(xz), _p(xg), B, R, D, G, halo, _stream()), "sc_posconv_prep")
 
 
+def posconv_prep_seg(x: torch.Tensor, valid_len: torch.Tensor, xz: torch.Tensor, xg: torch.Tensor, seg: "RowSegments", D: int, G: int,
+                     halo: int) -> None:
+    """ragged rows: xg = flat [G, rows + 2 halo B, D / G] slab buffer (numel at least that), utterance b at slab row row0[b] + 2 halo b"""
+    assert xg.numel() >= (seg.rows + 2 * halo * seg.B) * D
+    check(lib().sc_posconv_prep_seg(_p(x), _p(valid_len), _p(xz), _p(xg), seg.ref(), D, G, halo, _stream()), "sc_posconv_prep_seg")
+
+
+def posconv_seg(xg: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor], out: torch.Tensor,
+                seg: "RowSegments", D: int, G: int, Kp: int, alg_rows: Optional[int] = None) -> None:
+    assert xg.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+    if _timer is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().sc_posconv_seg_bf16(_p(xg), _p(w), _p(bias), _p(residual), _p(out), seg.ref(), D, G, Kp, _stream()), "sc_posconv_seg_bf16")
+    if _timer is not None:
+        ev1.record()
+        _timer.add("posconv", ev0, ev1, 2.0 * (seg.rows if alg_rows is None else alg_rows) * D * Kp * (D // G))
+
+
 def posconv(xg: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor], out: torch.Tensor,
             B: int, R: int, D: int, G: int, Kp: int, alg_rows: Optional[int] = None) -> None:
     """HuBERT positional convolution + bias + GELU + residual on the slab layout of ``posconv_prep`` (sc_posconv_bf16):
@@ -780,8 +900,14 @@ class LazyStates:
 
 
 def wsum_fwd(h: torch.Tensor, w_softmax: torch.Tensor, out: torch.Tensor, B: int, R: int, D: int, row_off: int,
-             normalize: bool = False, lazy: Optional[LazyStates] = None) -> None:
+             normalize: bool = False, lazy: Optional[LazyStates] = None, seg: Optional["RowSegments"] = None) -> None:
+    """``seg``: h [NL, seg.rows, D] in the ragged layout -> out [B, R, D] uniform (every row written, zero outside the utterances)"""
     NL = h.shape[0]
+    if seg is not None:
+        assert lazy is None and h.shape[1] == seg.rows and B == seg.B
+        assert h.dtype == torch.bfloat16 and w_softmax.dtype == torch.float32 and out.dtype == torch.bfloat16
+        check(lib().sc_wsum_fwd_seg(_p(h), _p(w_softmax), NL, _p(out), seg.ref(), R, D, row_off, int(normalize), _stream()), "sc_wsum_fwd_seg")
+        return
     if lazy is not None:
         assert not normalize
         check(lib().sc_wsum_lazy_fwd(_p(h), _p(w_softmax), NL, _p(out), B, R, D, row_off, _p(lazy.stats), _p(lazy.gamma), _p(lazy.beta),
@@ -1091,13 +1217,16 @@ def rt_value_bias_bwd(dctx: torch.Tensor, bv: torch.Tensor, psum: torch.Tensor, 
 
 
 def wsum_bwd_logits(h: torch.Tensor, g: torch.Tensor, w_soft: torch.Tensor, B: int, R: int, D: int, row_off: int, nblk: int = 1024,
-                    normalize: bool = False, lazy: Optional[LazyStates] = None) -> torch.Tensor:
+                    normalize: bool = False, lazy: Optional[LazyStates] = None, seg: Optional["RowSegments"] = None) -> torch.Tensor:
     """Gradient of the weighted-sum LOGITS in two launches: the partial sums <g, h_n - h_last> per block (sc_wsum_bwd) and their
     reduction fused with the softmax backward w_n (d_n - sum_m w_m d_m) (sc_rt_softmax_bwd_reduce)."""
     NL = h.shape[0]
     assert g.dtype == torch.float32
     part = torch.empty(nblk, NL, device=h.device, dtype=torch.float32)
-    if lazy is not None:
+    if seg is not None:
+        assert lazy is None and h.shape[1] == seg.rows and B == seg.B
+        check(lib().sc_wsum_bwd_seg(_p(h), _p(g), NL, _p(part), nblk, seg.ref(), R, D, row_off, int(normalize), _stream()), "sc_wsum_bwd_seg")
+    elif lazy is not None:
         assert not normalize
         check(lib().sc_wsum_lazy_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, _p(lazy.stats), _p(lazy.gamma), _p(lazy.beta),
                                      lazy.first_lazy, lazy.ns, lazy.eps, _stream()), "sc_wsum_lazy_bwd")

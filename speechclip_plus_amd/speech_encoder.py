@@ -4,11 +4,13 @@ libspeechclip_hip.so.  Same constructor keywords, ``forward(wav, wav_len, feat_s
 return_hidden_states) -> (feat, feat_len[, hidden_states])``, ``out_dim``, ``downsample_rate``,
 ``trainable_params()``.
 
-Data layout in HBM: channels-last bf16 activations in a padded row layout, utterance b / frame t
--> row b*R_l + t with R_6 = R = roundup(T + 2, 128) and R_{l-1} = 2 R_l down the conv stack (R_wav = 5 R_0).
-With that layout every strided Conv1d of the feature extractor is ONE flat GEMM whose A rows overlap
-(lda = stride*C, K = k*C), the transformer GEMMs see M = B*R rows, and attention / pooling index utterances
-by b*R.  Rows t >= T_l are scratch: finite, never read as keys, never returned.
+Data layout in HBM: channels-last bf16 activations in a row layout with a pitch PER UTTERANCE (round 4): utterance b /
+frame t -> row row0[b] + t, pitch_b = row0[b + 1] - row0[b] = roundup(n_b + 1, 32) with n_b the frames anything downstream reads
+(``_Plan.bind``), and 2^(6-l) times that table down the conv stack (the waveform: 320 samples per row).  With that layout every
+strided Conv1d of the feature extractor is ONE flat GEMM whose A rows overlap (lda = stride*C, K = k*C), the transformer GEMMs see
+M = sum_b pitch_b rows - the work follows the real lengths of a ragged batch instead of its padded length - and attention /
+pos_conv / the weighted sum find their utterance through ``ops.RowSegments``.  Rows t >= n_b of an utterance are scratch: finite,
+never read as keys, never returned.  Unfrozen layers (hubert_train.py) keep the uniform pitch R = roundup(T + 2, 128) of rounds 1-3.
 
 There is no pretrained checkpoint offline (the reference downloads hubert_base_ls960.pt,
 speech_encoder_plus.py:327-331,382): weights come from ``state_dict`` (fairseq key names, pos_conv weight-norm
@@ -157,44 +159,61 @@ def _roundup(x: int, m: int) -> int:
 
 
 class _Plan:
-    """Shapes + resident workspaces for one (B, L) batch geometry."""
+    """Shapes + resident workspaces for one (B, L) batch geometry.
 
-    def __init__(self, arch: HubertArch, B: int, L: int, device):
+    ``seg_mode`` (the frozen encoder, round 4): buffers are sized for the uniform worst case (every utterance L samples long,
+    pitch ``R = roundup(T + 1, 32)``) and ``bind`` lays the CURRENT batch out in them by its real lengths - per-utterance pitches,
+    ``ops.RowSegments`` tables uploaded with the batch's other integers - so ``M``, ``hidden`` and the row buffers below are views
+    that change from forward to forward.  Otherwise (unfrozen layers: their backward kernels index utterances by ``b * R``) the
+    uniform layout of rounds 1-3 with ``R = roundup(T + 2, 128)``."""
+
+    SLACK = 64           # rows behind the last utterance that a 64-key attention tile / a conv window may read (never written)
+
+    def __init__(self, arch: HubertArch, B: int, L: int, device, seg_mode: bool = False):
         self.B, self.L = B, L
         self.T_l = conv_out_lengths(L, arch)
         self.T = self.T_l[-1]
         if self.T < 1:
             raise ValueError(f"waveform too short for the conv stack: L={L}")
-        self.R = _roundup(self.T + 2, 128)
+        self.seg_mode = seg_mode
         nl = len(arch.conv_kernels)
+        self.spr = 1                                    # waveform samples per row of the last conv layer (320)
+        for s_ in arch.conv_strides:
+            self.spr *= s_
+        # seg_mode: the frames < n of an utterance need conv rows < 2^(6-l) n + c_l (c_0 = 15) of layer l and samples < 320 n + 80,
+        # all inside a pitch of n + 1 rows (tests/test_host_cpu.py::test_segment_geometry); the legacy layout stores every padded row
+        self.R = _roundup(self.T + 1, 32) if seg_mode else _roundup(self.T + 2, 128)
         self.R_l = [self.R * (2 ** (nl - 1 - i)) for i in range(nl)]
-        assert all(r >= t for r, t in zip(self.R_l, self.T_l))
+        if not seg_mode:
+            assert all(r >= t for r, t in zip(self.R_l, self.T_l))
         self.ldw = _roundup(max(L, arch.conv_strides[0] * self.R_l[0] + 16), 64)
         C, D, F = arch.conv_dim, arch.embed_dim, arch.ffn_dim
         bf, dev = torch.bfloat16, device
         z = lambda *s, dtype=bf: torch.zeros(*s, device=dev, dtype=dtype)
-        self.wav_pad = z(B, self.ldw, dtype=torch.float32)
-        # conv activations, channels-last, +8 slack rows (the last GEMM row's window runs one row past the end)
-        self.conv = [z(B * r + 8, C) for r in self.R_l]
         M = B * self.R
         self.M = M
-        self.feat_ln = z(M, C)
-        self.x_proj = z(M, D)
-        self.xz = z(M, D)
+        S = self.SLACK if seg_mode else 0
         G, halo = arch.pos_conv_groups, arch.pos_conv_kernel // 2
         self.halo = halo
-        self.xg = z(G, B, self.R + 2 * halo, D // G)
-        self.pre = z(M, D)           # pre-LayerNorm / residual scratch
-        self.x1 = z(M, D)
-        self.qk = z(M, 2 * D)
-        self.vt = z(B, arch.heads, D // arch.heads, self.R)
-        self.ctx = z(M, D)
-        self.ffn = z(M, F)
-        self.hidden = z(arch.layers + 1, M, D)
+        if seg_mode:
+            self.wav_pad = z(self.spr * M + 64, dtype=torch.float32)           # ONE flat waveform, utterance b at sample 320 row0[b]
+            self.xg = z(G * (M + 2 * halo * B) * (D // G))                     # flat slab buffer (sc_posconv_prep_seg)
+            self.vt = z(D * (M + S))
+            self.tables = torch.zeros(ops.RowSegments.table_ints(B, self.R * B), device=dev, dtype=torch.int32)
+        else:
+            self.wav_pad = z(B, self.ldw, dtype=torch.float32)
+            self.xg = z(G, B, self.R + 2 * halo, D // G)
+            self.vt = z(B, arch.heads, D // arch.heads, self.R)
+        # conv activations, channels-last, +8 slack rows (the last GEMM row's window runs one row past the end)
+        self._conv = [z(B * r + 8 + S, C) for r in self.R_l]
+        self._rows = dict(feat_ln=z(M + S, C), x_proj=z(M + S, D), xz=z(M + S, D), pre=z(M + S, D), x1=z(M + S, D),
+                          qk=z(M + S, 2 * D), ctx=z(M + S, D), ffn=z(M + S, F))
+        self._hidden = z((arch.layers + 1) * M * D + S * D)
+        self.NL, self.D = arch.layers + 1, D
         # LayerNorm-free layers: hidden[n >= 1] then hold the rows in FRONT of layer n's final LayerNorm, stats[n] their (sum, sum of
         # squares) strips, stats1 the scratch for the rows in front of LN1; lazy = how consumers read such states (ops.LazyStates)
-        self.stats = z(arch.layers + 1, M, 8, 2, dtype=torch.float32)
-        self.stats1 = z(M, 8, 2, dtype=torch.float32)
+        self.stats = z(arch.layers + 1, M, 8, 2, dtype=torch.float32) if (_FUSED_LN and not seg_mode) else None
+        self.stats1 = z(M, 8, 2, dtype=torch.float32) if (_FUSED_LN and not seg_mode) else None
         self.lazy = None
         self.valid = torch.zeros(B, device=dev, dtype=torch.int32)
         self.len_dev = torch.zeros(B, device=dev, dtype=torch.int64)
@@ -202,6 +221,20 @@ class _Plan:
         self.graph, self.graph_warm = None, 0        # hipGraph of the frozen encoder forward for this geometry
         self.train = {}              # per unfrozen layer: activations kept for the backward (hubert_train.TrainableLayers)
         self.generation = 0          # forwards run on this plan (weighted_sum.PaddedFeatHandle.check_fresh)
+        self.seg = None
+        self.bind(None)
+
+    def bind(self, seg) -> None:
+        """Lay the current batch out: ``seg`` = its ops.RowSegments (seg_mode) or None = the uniform B x R rows."""
+        self.seg = seg
+        M = seg.rows if seg is not None else self.B * self.R
+        self.M = M
+        nl = len(self.R_l)
+        self.conv = self._conv if seg is None else [c[: M * (2 ** (nl - 1 - i)) + 8] for i, c in enumerate(self._conv)]
+        for k, v in self._rows.items():
+            setattr(self, k, v[:M])
+        self.hidden = self._hidden[: self.NL * M * self.D].view(self.NL, M, self.D)
+        self.Rout = seg.max_pitch if seg is not None else self.R      # uniform pitch of what leaves the encoder ([B, Rout, D])
 
 
 class FairseqSpeechEncoder_Hubert(nn.Module):
@@ -234,6 +267,12 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             raise ValueError(f"layer_drop = {layer_drop} is not supported.")
         self.feat_select_idx = feat_select_idx
         self.hubert_dropout = True              # False: keep the frozen encoder deterministic in train mode (not the reference)
+        # Round 4: rows follow the real lengths.  ``ragged`` False = every utterance at the batch's padded length (the reference's
+        # amount of work; also what ``return_hidden_states`` uses: those tensors carry every padded row, like the reference's).
+        # ``tail_rows``: frames behind feat_len that a consumer still reads - the CIF weight conv of the cascaded+/hybrid+ branches
+        # (conv_cif_width 3 or 5, avssl/module/cif.py:44-52) looks one / two frames past the last valid one.
+        self.ragged = os.environ.get("SC_RAGGED", "1") == "1"
+        self.tail_rows = 2
         self._drop_calls = 0
         self.before_trainable = None            # optional callable invoked right before the first trainable module (train.py)
         self.max_audio_len = max_audio_len
@@ -262,7 +301,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             from .hubert_frontend_train import TrainableFrontend
             self.frontend = TrainableFrontend(self.arch, state_dict, self._dev)
             self.train_layers.frontend = self.frontend
-        self._plans: Dict[Tuple[int, int], _Plan] = {}
+        self._plans: Dict[Tuple[int, int, bool], _Plan] = {}
         if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             self.weightedsum_layer = WeightedSumLayer(
                 n_weights=self.upstream_model_hiddenstates_len,
@@ -347,16 +386,30 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         return layer_params if len(self.reinit_layers) > 0 else layer_params + ws
 
     # ------------------------------------------------------------------------------------------ forward
+    def _seg_mode(self) -> bool:
+        """Per-utterance row pitches (ops.RowSegments) for the frozen encoder; unfrozen layers / the LayerNorm-folded experiment keep
+        the uniform layout their kernels index."""
+        return self.train_layers is None and not _FUSED_LN
+
     def _plan(self, B: int, L: int) -> _Plan:
-        key = (B, L)
+        key = (B, L, self._seg_mode())
         if key not in self._plans:
             if len(self._plans) >= 4:          # keep HBM bounded when lengths vary
                 self._plans.pop(next(iter(self._plans)))
-            self._plans[key] = _Plan(self.arch, B, L, self._dev)
+            self._plans[key] = _Plan(self.arch, B, L, self._dev, seg_mode=key[2])
         return self._plans[key]
 
+    def segment_pitches(self, T: int, valid: Sequence[int], feat_len: Sequence[int], ragged: bool) -> Tuple[List[int], List[int]]:
+        """-> (rows needed per utterance, pitch per utterance).  An utterance needs the frames the HuBERT key mask admits
+        (``valid``, fairseq forward_padding_mask) and the frames the head / branches read (``feat_len`` + ``tail_rows``), never
+        more than the padded length T; its pitch is that + 1 (the conv stack's last row of a segment is scratch) rounded to 32."""
+        if not ragged:
+            return [T] * len(valid), [_roundup(T + 1, 32)] * len(valid)
+        need = [max(1, min(T, max(int(v), int(f) + self.tail_rows))) for v, f in zip(valid, feat_len)]
+        return need, [_roundup(n + 1, 32) for n in need]
+
     @torch.no_grad()
-    def _encode(self, padded: torch.Tensor, wav_len: List[int], save: bool = False) -> _Plan:
+    def _encode(self, padded: torch.Tensor, wav_len: List[int], save: bool = False, ragged: Optional[bool] = None) -> _Plan:
         """customHubertForward + patched extract_features (speech_encoder_plus.py:29-107) on the device."""
         a, w = self.arch, self._w
         B, L = padded.shape
@@ -372,6 +425,17 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         chunk = L // T
         valid = [min(T, -(-int(l) // chunk)) for l in wav_len]
         feat_len = [min(round(int(l) / self.downsample_rate), T) for l in wav_len]
+        if pl.seg_mode:
+            # the row layout of THIS batch: pitches from the lengths, tables into the plan's resident int32 storage (same stream, so
+            # the previous forward's kernels are done with them)
+            need, pitch = self.segment_pitches(T, valid, feat_len, self.ragged if ragged is None else ragged)
+            pl.bind(ops.RowSegments(pitch, valid, self._dev, storage=pl.tables))
+            pl.need = need
+            R, M = pl.R, pl.M
+            # algorithmic work of this batch: every utterance at its OWN length (padding is not work)
+            own = [conv_out_lengths(max(int(l), 400), a) for l in wav_len]
+            pl.alg_rows_l = [sum(o[i] for o in own) for i in range(len(a.conv_kernels))]
+            pl.alg_attn_flops = 4.0 * D * sum(float(o[-1]) ** 2 for o in own)
         host = torch.tensor([list(map(int, wav_len)), valid, feat_len], dtype=torch.int64).pin_memory()
         ints = host.to(self._dev, non_blocking=True)
         pl.feat_len = ints[2]
@@ -387,7 +451,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # gaps between kernels are the hardware's dispatch, not the host's), so it stays off by default; not used with
         # unfrozen layers nor while bench.py's per-kernel event timer is attached.
         use_graph = (_USE_GRAPH and self._dev.type == "cuda" and self.train_layers is None and ops._timer is None
-                     and not self._dropout_active())
+                     and not self._dropout_active() and not pl.seg_mode)
         if not use_graph:
             self._encode_kernels(pl, padded, save)
             return pl
@@ -433,43 +497,61 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         R, M, T = pl.R, pl.M, pl.T
         len_dev = pl.len_dev
         # a1: (optional) utterance layer-norm + zero pad                                (:506-518)
-        ops.wav_prep(padded, len_dev, pl.wav_pad, a.normalize_wav)
+        if pl.seg is not None:
+            ops.wav_prep_seg(padded, len_dev, pl.wav_pad, pl.seg, pl.spr, a.normalize_wav)
+        else:
+            ops.wav_prep(padded, len_dev, pl.wav_pad, a.normalize_wav)
         scale = (D // H) ** -0.5
         train_front = self.frontend is not None      # (also in eval: the frozen copies in self._w are the INITIAL weights)
         if train_front:           # fully trainable encoder: the front end keeps its activations (hubert_frontend_train.py)
             self.frontend.refresh()
             self.frontend.forward_frontend(pl, L, p_in, p_res, sd(0), sd(1))
         else:
-            self._frontend_frozen(pl, w, seeds, sd, p_in, p_res)
+            self._frontend_frozen(pl, w, seeds, sd, p_in, p_res, padded)
         self._layers(pl, w, seeds, sd, p_res, p_att, save, scale, first_hidden_done=train_front)
 
     @torch.no_grad()
-    def _frontend_frozen(self, pl, w, seeds, sd, p_in, p_res) -> None:
+    def _frontend_frozen(self, pl, w, seeds, sd, p_in, p_res, padded=None) -> None:
         a = self.arch
         B, L = pl.B, pl.L
         C, D, F, H = a.conv_dim, a.embed_dim, a.ffn_dim, a.heads
         R, M, T = pl.R, pl.M, pl.T
+        seg = pl.seg
+        nl = len(a.conv_kernels)
         # a2: conv feature extractor                                                    (:75)
         ln_mode = a.extractor_mode == "layer_norm"
-        if ln_mode:       # large: conv (+bias) -> LayerNorm(512) -> GELU after every layer
+        if seg is not None:
+            # ragged rows: conv 0 writes the rows of the segment layout only; the GroupNorm statistics still run over the padded
+            # batch length T_0 (fairseq feeds the zero-padded batch) and come from the caller's batch masked by its lengths
+            if ln_mode:
+                ops.conv0_layernorm_gelu_seg(pl.wav_pad, seg, pl.spr, w["conv0_w"], w["conv0_bias"], w["conv0_ln_g"], w["conv0_ln_b"], pl.conv[0])
+            else:
+                ops.conv0_groupnorm_gelu_seg(padded, pl.len_dev, pl.wav_pad, seg, pl.spr, w["conv0_w"], w["gn_g"], w["gn_b"], pl.T_l[0], pl.conv[0])
+        elif ln_mode:       # large: conv (+bias) -> LayerNorm(512) -> GELU after every layer
             ops.conv0_layernorm_gelu(pl.wav_pad, w["conv0_w"], w["conv0_bias"], w["conv0_ln_g"], w["conv0_ln_b"],
                                      pl.R_l[0], pl.conv[0])
         else:             # base: GroupNorm(512, 512) over time after conv 0 only, no conv bias
             ops.conv0_groupnorm_gelu(pl.wav_pad, w["conv0_w"], w["gn_g"], w["gn_b"], pl.T_l[0], pl.R_l[0], pl.conv[0])
-        for i in range(1, len(a.conv_kernels)):
+        alg = pl.alg_rows_l if seg is not None else [B * t for t in pl.T_l]     # rows that are algorithmic work (bench.py's timer)
+        for i in range(1, nl):
             k, s = a.conv_kernels[i], a.conv_strides[i]
-            rows = B * pl.R_l[i]
+            rows = M * (2 ** (nl - 1 - i)) if seg is not None else B * pl.R_l[i]
             ops.gemm_raw(pl.conv[i - 1], s * C, w[f"conv{i}_w"], k * C, pl.conv[i], C, rows, C, k * C,
-                         bias=w[f"conv{i}_bias"], act=0 if ln_mode else 1, alg_rows=B * pl.T_l[i],
+                         bias=w[f"conv{i}_bias"], act=0 if ln_mode else 1, alg_rows=alg[i],
                          tap_c=C if (k == 3 and s == 2) else 0)      # shared-tap K order: see sc_gemm_args.tap_c
             if ln_mode:
                 ops.layernorm_bf16(pl.conv[i][:rows], w[f"conv{i}_ln_g"], w[f"conv{i}_ln_b"], out=pl.conv[i][:rows], act=1)
         # a3: LayerNorm(512) -> post_extract_proj                                       (:78, :84-85)
         ops.layernorm_bf16(pl.conv[-1][:M], w["ln_feat_g"], w["ln_feat_b"], out=pl.feat_ln)
-        ops.linear_bf16(pl.feat_ln, w["proj_w"], w["proj_b"], out=pl.x_proj, alg_rows=B * T, drop_p=p_in, drop_seed=sd(0))   # dropout_input (:87)
+        ops.linear_bf16(pl.feat_ln, w["proj_w"], w["proj_b"], out=pl.x_proj, alg_rows=alg[-1], drop_p=p_in, drop_seed=sd(0))   # dropout_input (:87)
         # a4: zero padded frames, grouped pos_conv + GELU, residual, LayerNorm          (:32-40)
         G, Kp = a.pos_conv_groups, a.pos_conv_kernel
         Dg, Rp = D // G, R + 2 * pl.halo
+        if seg is not None:
+            assert Dg in (48, 64) and Kp == 128, "the segment layout runs pos_conv on the slab kernel (48 / 64 channels per group, 128 taps)"
+            ops.posconv_prep_seg(pl.x_proj, pl.valid, pl.xz, pl.xg, seg, D, G, pl.halo)
+            ops.posconv_seg(pl.xg, w["pos_w"], w["pos_b"], pl.xz, pl.pre, seg, D, G, Kp, alg_rows=alg[-1])
+            return
         ops.posconv_prep(pl.x_proj, pl.valid, pl.xz, pl.xg, B, R, D, G, pl.halo)
         if Dg in (48, 64) and Kp == 128:
             # the input slab of a (group, utterance) stays in LDS for all 128 taps (csrc/posconv.hip); same arithmetic as the GEMM below
@@ -486,11 +568,15 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         C, D, F, H = a.conv_dim, a.embed_dim, a.ffn_dim, a.heads
         R, M, T = pl.R, pl.M, pl.T
 
+        seg = pl.seg
+        alg_M = pl.alg_rows_l[-1] if seg is not None else B * T                       # rows / flops that are algorithmic work
+        alg_att = pl.alg_attn_flops if seg is not None else 4.0 * B * T * T * D
+
         def qkv_attn(x, i):
             ops.gemm_raw(x, D, w[f"l{i}_qkv_w"], D, pl.qk, 2 * D, M, 3 * D, D, bias=w[f"l{i}_qkv_b"], Ct=pl.vt,
-                         n_split=2 * D, R=R, dh=D // H, alg_rows=B * T)
-            ops.attn_fwd(pl.qk, pl.vt, pl.valid, pl.ctx, B, R, H, D, scale, alg_flops=4.0 * B * T * T * D,
-                         drop_p=p_att, drop_seed=sd(3 * i + 2))
+                         n_split=2 * D, R=R, dh=D // H, alg_rows=alg_M, seg=seg)
+            ops.attn_fwd(pl.qk, pl.vt, pl.valid, pl.ctx, B, R, H, D, scale, alg_flops=alg_att,
+                         drop_p=p_att, drop_seed=sd(3 * i + 2), seg=seg)
 
         if not a.layer_norm_first:
             # a5: post-LN layers (base): x = LN1(x + attn(x)); x = LN2(x + ffn(x))       (:39-40, :49-53)
@@ -513,16 +599,16 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                     continue
                 if ops._timer is None:          # one C-ABI call per frozen layer (sc_hubert_layer_fwd); the per-op path below is
                     ops.hubert_layer_fwd(x, pl.hidden[i + 1], pl.valid, w, i, pl, B, R, T, D, F, H, False, p_att, p_res,
-                                         (sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)))   # kept for bench.py's per-kernel timer
+                                         (sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)), seg=seg)   # kept for bench.py's per-kernel timer
                     continue
                 qkv_attn(x, i)
                 # train mode: dropout1 / dropout3 of fairseq's TransformerSentenceEncoderLayer in the GEMM epilogues (before the
                 # residual add), attention dropout inside the attention kernel
-                ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T,
+                ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=alg_M,
                                 drop_p=p_res, drop_seed=sd(3 * i + 3))
                 ops.layernorm_bf16(pl.pre, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
-                ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1, alg_rows=B * T)
-                ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.pre, residual=pl.x1, alg_rows=B * T,
+                ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1, alg_rows=alg_M)
+                ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.pre, residual=pl.x1, alg_rows=alg_M,
                                 drop_p=p_res, drop_seed=sd(3 * i + 4))
                 ops.layernorm_bf16(pl.pre, w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"], out=pl.hidden[i + 1])
         else:
@@ -543,16 +629,16 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                     continue
                 if ops._timer is None:
                     ops.hubert_layer_fwd(x, pl.hidden[i + 1], pl.valid, w, i, pl, B, R, T, D, F, H, True, p_att, p_res,
-                                         (sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)))
+                                         (sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)), seg=seg)
                     continue
                 ops.layernorm_bf16(x, w[f"l{i}_ln1_g"], w[f"l{i}_ln1_b"], out=pl.x1)
                 qkv_attn(pl.x1, i)
-                ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=B * T,
+                ops.linear_bf16(pl.ctx, w[f"l{i}_o_w"], w[f"l{i}_o_b"], out=pl.pre, residual=x, alg_rows=alg_M,
                                 drop_p=p_res, drop_seed=sd(3 * i + 3))
                 ops.layernorm_bf16(pl.pre, w[f"l{i}_ln2_g"], w[f"l{i}_ln2_b"], out=pl.x1)
-                ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1, alg_rows=B * T)
+                ops.linear_bf16(pl.x1, w[f"l{i}_fc1_w"], w[f"l{i}_fc1_b"], out=pl.ffn, act=1, alg_rows=alg_M)
                 ops.linear_bf16(pl.ffn, w[f"l{i}_fc2_w"], w[f"l{i}_fc2_b"], out=pl.hidden[i + 1], residual=pl.pre,
-                                alg_rows=B * T, drop_p=p_res, drop_seed=sd(3 * i + 4))
+                                alg_rows=alg_M, drop_p=p_res, drop_seed=sd(3 * i + 4))
 
     @torch.no_grad()
     def _layers_fused(self, pl, w, sd, p_res, p_att, scale) -> None:
@@ -589,9 +675,13 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         pl.lazy = ops.LazyStates(pl.stats, w["lazy_gamma"], w["lazy_beta"], first_lazy=1, ns=ns, eps=1e-5)
 
     def _materialised_states(self, pl) -> tuple:
-        """Hidden states as the reference returns them (fresh tensors).  With the LayerNorm-free layers states 1.. are raw rows: their
-        LayerNorm runs here, on request only (the weighted sum normalises on the fly)."""
+        """Hidden states as the reference returns them (fresh [B, T, D] tensors).  With the LayerNorm-free layers states 1.. are raw
+        rows: their LayerNorm runs here, on request only (the weighted sum normalises on the fly).  Segment layout: one row gather
+        per state; frames t >= rows-needed of an utterance (``_Plan.need``; all T when the forward ran un-ragged) are zero."""
         B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
+        if pl.seg is not None:
+            idx, keep = self._gather_index(pl)
+            return tuple(pl.hidden[n].index_select(0, idx).view(B, T, D) * keep for n in range(self.arch.layers + 1))
         if pl.lazy is None:
             return tuple(pl.hidden[n].view(B, R, D)[:, :T].clone() for n in range(self.arch.layers + 1))
         out = [pl.hidden[0].view(B, R, D)[:, :T].clone()]
@@ -599,6 +689,17 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             y = ops.layernorm_bf16(pl.hidden[n], self._w[f"l{n - 1}_ln2_g"], self._w[f"l{n - 1}_ln2_b"])
             out.append(y.view(B, R, D)[:, :T].clone())
         return tuple(out)
+
+    def _gather_index(self, pl):
+        """row index [B * T] of frame (b, t) in the segment layout (row 0 for frames the layout does not hold) + their 0 / 1 mask"""
+        T, seg = pl.T, pl.seg
+        t = torch.arange(T).unsqueeze(0)
+        need = torch.tensor(pl.need).unsqueeze(1)
+        r0 = torch.tensor(seg.row0_host[:-1]).unsqueeze(1)
+        keep = t < need
+        idx = torch.where(keep, r0 + t, torch.zeros_like(t)).reshape(-1)
+        return (idx.to(self._dev, non_blocking=True),
+                keep.reshape(pl.B, T, 1).to(device=self._dev, dtype=torch.bfloat16, non_blocking=True))
 
     def forward(self, wav: Union[torch.Tensor, list], wav_len: Union[torch.Tensor, list] = [],
                 feat_select_idx: Union[str, list] = None, return_hidden_states: bool = False) -> Tuple:
@@ -634,14 +735,15 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             # unfrozen layers read their parameters (refresh(): bf16 copies; LayerNorm affine and biases alias the masters) inside
             # the encoder: join the optimiser's side stream BEFORE the first kernel, not at the weighted sum
             self.before_trainable()
-        pl = self._encode(padded, lens, save)
-        B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
         # views of the plan's resident workspace; every PUBLIC return path below hands out clones (the reference returns fresh
         # tensors: holding encoder outputs across calls must be safe), the weighted-sum fast path reads the workspace in place
         want_states = return_hidden_states or (feat_select_idx or self.feat_select_idx) != FEAT_SELECT_IDX_WEIGHTED_SUM_MODE
+        # returned hidden states carry every padded row, as the reference's do: that forward runs un-ragged (all B x T frames)
+        pl = self._encode(padded, lens, save, ragged=False if want_states else None)
+        B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
         # (without want_states the tuple is only a placeholder: the weighted sum reads the plan's workspace, raw or not, in place)
-        hidden_states = self._materialised_states(pl) if want_states else tuple(pl.hidden[n].view(B, R, D)[:, :T]
-                                                                                 for n in range(self.arch.layers + 1))
+        hidden_states = self._materialised_states(pl) if want_states else ((None,) * (self.arch.layers + 1) if pl.seg is not None else tuple(
+            pl.hidden[n].view(B, R, D)[:, :T] for n in range(self.arch.layers + 1)))
         feat = {"last_hidden_state": hidden_states[-1], "hidden_states": hidden_states}
         feat_len = pl.feat_len                                                          # :604-611 (uploaded in _encode)
         if feat_select_idx is None:
@@ -652,7 +754,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         elif feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             if self.before_trainable is not None:
                 self.before_trainable()                 # train.ContrastiveTrainer: join the optimiser's side stream here
-            ws_feat = self.weightedsum_layer.forward_padded(pl.hidden, B, R, T, D, plan=pl)
+            ws_feat = self.weightedsum_layer.forward_padded(pl.hidden, B, pl.Rout, T, D, plan=pl)
             if save:                                    # the head's backward hands dX to the unfrozen layers (hubert_train.py)
                 tl = self.train_layers
                 ws_feat._sc_handle.layers_bwd = lambda dX, w_soft, _pl=pl: tl.backward(

@@ -29,6 +29,7 @@ class PaddedFeatHandle:
         # plan has been re-used must fail loudly instead of differentiating against the wrong states.
         self.plan, self.generation = plan, (plan.generation if plan is not None else None)
         self.lazy = getattr(plan, "lazy", None)      # ops.LazyStates: the hidden states are raw rows + row statistics
+        self.seg = getattr(plan, "seg", None)        # ops.RowSegments: ``hidden`` is in the ragged row layout, ``src`` uniform [B, R, D]
 
     def check_fresh(self) -> None:
         if self.plan is not None and self.plan.generation != self.generation:
@@ -66,9 +67,12 @@ class _WeightedSumSrcFn(torch.autograd.Function):
         ctx.plan, ctx.generation = plan, (plan.generation if plan is not None else None)
         w_soft = torch.softmax(weights.detach().float(), dim=0).contiguous()
         src = torch.empty(B, R, D, device=hidden.device, dtype=torch.bfloat16)
-        src[:, 0].zero_()                    # rows 1 .. R - 1 are written by the kernel; row 0 is the CLS slot
         ctx.lazy = getattr(plan, "lazy", None)
-        ops.wsum_fwd(hidden, w_soft, src, B, R, D, 1, normalize, lazy=ctx.lazy)
+        ctx.seg = getattr(plan, "seg", None)
+        if ctx.seg is None:
+            src[:, 0].zero_()                # rows 1 .. R - 1 are written by the kernel; row 0 is the CLS slot
+        # (segment layout: the kernel writes EVERY row of src - frames at row t + 1, zeros in the CLS slot and behind an utterance)
+        ops.wsum_fwd(hidden, w_soft, src, B, R, D, 1, normalize, lazy=ctx.lazy, seg=ctx.seg)
         ctx.save_for_backward(hidden, w_soft)
         ctx.dims = (B, R, D, normalize)
         return src
@@ -80,7 +84,7 @@ class _WeightedSumSrcFn(torch.autograd.Function):
         if ctx.plan is not None and ctx.plan.generation != ctx.generation:
             raise RuntimeError("the encoder ran another forward with the same batch geometry before this backward (its resident "
                                "hidden states were overwritten): one outstanding forward per (B, L) plan")
-        return (ops.wsum_bwd_logits(hidden, g.float().contiguous(), w_soft, B, R, D, 1, normalize=normalize, lazy=ctx.lazy),
+        return (ops.wsum_bwd_logits(hidden, g.float().contiguous(), w_soft, B, R, D, 1, normalize=normalize, lazy=ctx.lazy, seg=ctx.seg),
                 None, None, None, None, None, None)
 
 

@@ -87,12 +87,20 @@ def test_layernorm_free_layers_match_the_layernorm_kernels(setup):
     finally:
         se._FUSED_LN = default
         enc.eval()
+    # (train mode: since round 4 the two forms lay their rows out differently - the LayerNorm-free form keeps the uniform pitch of
+    # rounds 1-3, the default form the segment layout - so their hash masks hit different elements: eval is compared element-wise,
+    # train mode only for being finite and different from eval)
     for train in (False, True):
         f1, h1 = res[(True, train)]
         f0, h0 = res[(False, train)]
         for n in range(13):
-            assert rel_l2(h1[n], h0[n]) < 1.2e-2, (train, n, rel_l2(h1[n], h0[n]))
-        assert rel_l2(f1, f0) < 1.2e-2, (train, rel_l2(f1, f0))
+            if not train:
+                assert rel_l2(h1[n], h0[n]) < 1.2e-2, (train, n, rel_l2(h1[n], h0[n]))
+            assert torch.isfinite(h1[n]).all() and torch.isfinite(h0[n]).all()
+        if not train:
+            assert rel_l2(f1, f0) < 1.2e-2, (train, rel_l2(f1, f0))
+        else:
+            assert rel_l2(f1, res[(True, False)][0]) > 0.02
     # both against the oracle (eval): the LayerNorm-free form is not further away than the LayerNorm kernels were
     hs_o, _ = oracle.speech_encoder_forward(sd, o_arch, [w.cpu() for w in wavs])
     e1 = max(rel_l2(res[(True, False)][1][n], hs_o[n]) for n in range(13))
@@ -793,9 +801,11 @@ def test_edge_batches_single_utterance_and_very_short_utterance(setup):
         assert float(F.cosine_similarity(out, e, dim=-1).min()) > 0.999, lens
 
 
-def _encoder_mask_hook(seed_of, B, T, D, H, R, p=0.1):
+def _encoder_mask_hook(seed_of, B, T, D, H, R, p=0.1, seg=False):
     """oracle ``drop`` hook that rebuilds the kernels' stateless hash masks on the host (site numbering of
-    speech_encoder._encode_kernels: 0 input, 1 encoder, 3 i + 2 attention, 3 i + 3 out_proj, 3 i + 4 fc2 of layer i)."""
+    speech_encoder._encode_kernels: 0 input, 1 encoder, 3 i + 2 attention, 3 i + 3 out_proj, 3 i + 4 fc2 of layer i).
+    ``seg``: the frozen encoder's segment layout with every utterance at pitch R (an un-ragged forward): the attention kernel then
+    numbers a probability ((h rows + row0[b] + q) max_pitch + k), sc_attn_fwd_seg_bf16."""
     from test_gpu_kernels import _keep_mask
     site_of = {"input": lambda i: 0, "encoder": lambda i: 1, "attn": lambda i: 3 * i + 2, "dropout1": lambda i: 3 * i + 3,
                "dropout3": lambda i: 3 * i + 4}
@@ -803,6 +813,8 @@ def _encoder_mask_hook(seed_of, B, T, D, H, R, p=0.1):
     row_idx = ((b_ * R + t_) * D + d_).astype(np.int64)
     bb, hh, qq, kk = np.meshgrid(np.arange(B), np.arange(H), np.arange(T), np.arange(T), indexing="ij")
     att_idx = (((bb * H + hh) * R + qq) * R + kk).astype(np.int64)
+    if seg:
+        att_idx = (((hh * (B * R) + bb * R + qq)) * R + kk).astype(np.int64)
 
     def drop(site, layer, t):
         keep = _keep_mask(att_idx if site == "attn" else row_idx, seed_of(site_of[site](layer)), p)
@@ -838,10 +850,10 @@ def test_encoder_train_mode_dropout_vs_oracle(setup):
     finally:
         enc.eval()
     B, T, D = hs[0].shape
-    H, R = 12, (T + 2 + 127) // 128 * 128
+    H, R = 12, (T + 1 + 31) // 32 * 32          # returned hidden states: the un-ragged segment layout, pitch roundup(T + 1, 32)
     a = enc.arch
     assert (a.dropout, a.attention_dropout, a.dropout_input) == (0.1, 0.1, 0.1)
-    drop = _encoder_mask_hook(seed_of, B, T, D, H, R)
+    drop = _encoder_mask_hook(seed_of, B, T, D, H, R, seg=True)
     hs_o, _ = oracle.speech_encoder_forward(sd, o_arch, wavs, drop=drop)
     valid = oracle.fairseq_valid_frames(lens, max(lens), T)
     zero_frac = float((hs[0][0, : valid[0]] == 0).float().mean())

@@ -1,0 +1,236 @@
+"""GPU: the ragged row layout of round 4 (ops.RowSegments / sc_segments; speech_encoder._Plan.bind) - every utterance at its own
+row pitch, so the work of a batch follows its real lengths instead of the padded length the reference computes
+(avssl/module/speech_encoder_plus.py:506-518 pads to the longest utterance).
+
+What must hold: frames < feat_len are BIT-IDENTICAL to the un-ragged path (same kernels, same k order, same
+32-query waves in the attention kernel - only the row addresses differ), the assembled path still matches the oracle, and the rows the
+layout does not hold come back as zeros."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import oracle
+    from speechclip_plus_amd import KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict, HubertArch
+    arch = HubertArch()
+    sd = random_hubert_state_dict(arch, seed=7122)
+    torch.manual_seed(7122)
+    cfg = base_parallel_config()
+    cfg.audio_encoder.max_audio_len = -1
+    model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd).eval()
+    with torch.no_grad():
+        model.audio_encoder.weightedsum_layer.weights.copy_(torch.linspace(-1, 1, 13))
+    return model, sd, oracle
+
+
+# lengths that exercise: pitch 32 (a 10-frame utterance), 64 / 96-row last attention blocks, a 128-multiple, the batch maximum,
+# feat_len > valid frames (round(len / 320) vs ceil(len / chunk)), feat_len == valid
+LENS = [48000, 3300, 20000, 30500, 40960, 9000, 47999, 16000, 25000]
+
+
+def _batch(lens, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    L = max(lens)
+    wav = torch.zeros(len(lens), L)
+    for b, l in enumerate(lens):
+        wav[b, :l] = torch.randn(l, generator=g)
+    return wav
+
+
+def test_segment_layout_of_the_batch(setup):
+    model, sd, oracle = setup
+    enc = model.audio_encoder
+    wav = _batch(LENS)
+    with torch.no_grad():
+        enc(wav.cuda(), torch.tensor(LENS))
+    pl = enc._plan(len(LENS), max(LENS))
+    seg = pl.seg
+    T = pl.T
+    valid = oracle.fairseq_valid_frames(LENS, max(LENS), T)
+    feat_len = [min(round(l / 320), T) for l in LENS]
+    assert seg is not None and seg.rows == sum(seg.pitch) and seg.rows < len(LENS) * pl.R        # fewer rows than the padded batch
+    for b in range(len(LENS)):
+        assert seg.pitch[b] % 32 == 0 and seg.pitch[b] >= max(valid[b], feat_len[b]) + 1
+        assert seg.pitch[b] <= max(valid[b], feat_len[b]) + enc.tail_rows + 32
+    assert min(seg.pitch) == 32 and max(seg.pitch) == pl.Rout
+
+
+def test_ragged_rows_are_bit_identical_to_the_padded_computation(setup):
+    """weighted-sum features (what the head and the branches read) and the pooled embedding, ragged vs every utterance at the
+    batch's padded length: equal bit for bit on the frames < feat_len (+ tail_rows), zero behind them."""
+    model, sd, oracle = setup
+    enc = model.audio_encoder
+    wav, lens = _batch(LENS).cuda(), torch.tensor(LENS)
+    out = {}
+    try:
+        for ragged in (True, False):
+            enc.ragged = ragged
+            with torch.no_grad():
+                feat, feat_len = enc(wav, lens)
+                out[ragged] = (feat.float().clone(), feat_len.clone(), enc._plan(len(LENS), max(LENS)).M)
+    finally:
+        enc.ragged = True
+    (f1, l1, m1), (f0, l0, m0) = out[True], out[False]
+    assert torch.equal(l1, l0) and m1 < 0.75 * m0, (m1, m0)
+    T = f1.shape[1]
+    for b, n in enumerate(l1.tolist()):
+        keep = min(T, n + enc.tail_rows)
+        assert torch.equal(f1[b, :keep], f0[b, :keep]), b
+        assert float(f1[b, keep + 32:].abs().max() if keep + 32 < T else 0.0) == 0.0, b       # rows the layout does not hold: zeros
+
+
+def test_ragged_batch_against_the_oracle(setup):
+    """the ragged encoder + head against the fp32 oracle run utterance by utterance in ONE padded batch (the reference's forward)"""
+    model, sd, oracle = setup
+    enc = model.audio_encoder
+    lens = LENS[:6]
+    wav = _batch(lens, seed=5)
+    with torch.no_grad():
+        feat, feat_len = enc(wav.cuda(), torch.tensor(lens))
+    hs_o, fl_o = oracle.speech_encoder_forward(sd, oracle.HubertArch.base(), [wav[b, :l] for b, l in enumerate(lens)])
+    assert feat_len.cpu().tolist() == fl_o.tolist()
+    w = enc.weightedsum_layer.weights.detach().cpu()
+    ws_o = oracle.weighted_sum(w, hs_o)
+    for b, n in enumerate(fl_o.tolist()):
+        assert rel_l2(feat[b, :n], ws_o[b, :n]) < 1.5e-2, (b, rel_l2(feat[b, :n], ws_o[b, :n]))
+    head_W = {k: v.detach().cpu().float() for k, v in model.parallel_branch.state_dict().items()}
+    e_o = oracle.parallel_branch_forward(head_W, ws_o, fl_o, nhead=8)
+    batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": torch.randn(len(lens), 512).cuda(), "id": torch.arange(len(lens)).cuda()}
+    with torch.no_grad():
+        _, _, o = model(batch)
+    cos = torch.nn.functional.cosine_similarity(o["parallel_audio_feat"].float().cpu(), e_o, dim=-1)
+    assert float(cos.min()) > 0.999, cos
+
+
+def test_ragged_train_step_equals_the_padded_train_step(setup):
+    """loss and every trainable gradient of one train step (dropout off: the masks are hashes of layout positions), ragged vs padded"""
+    from speechclip_plus_amd import set_dropout
+    model, sd, oracle = setup
+    enc = model.audio_encoder
+    lens = LENS[:7]
+    wav = _batch(lens, seed=9)
+    g = torch.Generator().manual_seed(2)
+    batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": torch.randn(len(lens), 512, generator=g).cuda(),
+             "id": torch.tensor([0, 1, 1, 2, 3, 3, 4]).cuda()}
+    res = {}
+    model.train()
+    set_dropout(model, False)
+    try:
+        for ragged in (True, False):
+            enc.ragged = ragged
+            model.zero_grad(set_to_none=True)
+            losses, _, _ = model(batch)
+            loss = model.compute_loss(losses)["loss"]
+            loss.backward()
+            res[ragged] = (loss.item(), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        enc.ragged = True
+        set_dropout(model, True)
+        model.eval()
+        model.zero_grad(set_to_none=True)
+    (l1, g1), (l0, g0) = res[True], res[False]
+    assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0)), (l1, l0)
+    assert set(g1) == set(g0) and len(g1) > 10
+    for n in g0:
+        # the weighted-sum logits' gradient is a sum over rows in a different block order: fp32 round-off; the head's are exact
+        assert rel_l2(g1[n], g0[n]) < 1e-5, (n, rel_l2(g1[n], g0[n]))
+
+
+def test_segment_attention_and_vt_store_against_torch():
+    """sc_gemm_bf16 with a segment table (V^T per utterance [H, 64, pitch]) + sc_attn_fwd_seg_bf16, pitches 32 .. 160 (last q-blocks of
+    32 / 64 / 96 / 128 rows, a K tile that crosses into the next utterance), with and without the host's work list, against fp32 torch."""
+    from speechclip_plus_amd import ops
+    torch.manual_seed(0)
+    H, D = 2, 128
+    pitch = [32, 160, 64, 96, 128, 32]
+    valid = [7, 150, 64, 65, 100, 32]
+    seg = ops.RowSegments(pitch, valid, "cuda")
+    M = seg.rows
+    x = torch.randn(M + 64, D, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(3 * D, D, device="cuda") * D ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(3 * D, device="cuda") * 0.1
+    y = torch.zeros(M, 3 * D, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_raw(x, D, w, D, y, 3 * D, M, 3 * D, D, bias=bias)                    # the same product, stored row-major
+    assert rel_l2(y, x[:M].float() @ w.float().T + bias) < 5e-3
+    for tile in (1, 2):                                                           # 128-row and 256-row tile families
+        qk = torch.zeros(M + 64, 2 * D, device="cuda", dtype=torch.bfloat16)
+        vt = torch.zeros(D * (M + 64), device="cuda", dtype=torch.bfloat16)
+        ops.gemm_raw(x, D, w, D, qk, 2 * D, M, 3 * D, D, bias=bias, Ct=vt, n_split=2 * D, dh=64, seg=seg, tile=tile)
+        assert torch.equal(qk[:M], y[:, : 2 * D]), tile
+        for b, p in enumerate(pitch):
+            r0b = seg.row0_host[b]
+            v_b = vt[D * r0b: D * r0b + D * p].view(H, 64, p)
+            assert torch.equal(v_b.permute(2, 0, 1).reshape(p, D), y[r0b: r0b + p, 2 * D:]), (tile, b)   # V^T of the utterance, transposed back
+    vl = torch.tensor(valid, dtype=torch.int32, device="cuda")
+    outs = []
+    for use_work in (True, False):
+        out = torch.zeros(M + 64, D, device="cuda", dtype=torch.bfloat16)
+        ops.attn_fwd(qk, vt, vl, out, 0, 0, H, D, 0.125, seg=seg, use_work=use_work)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[0][M:].abs().max()) == 0.0                      # nothing is written behind the last utterance
+    r0 = seg.row0_host
+    for b, (p, n) in enumerate(zip(pitch, valid)):
+        rows = slice(r0[b], r0[b] + p)
+        q = y[rows, :D].float().view(p, H, 64).transpose(0, 1)
+        k = y[rows, D: 2 * D].float().view(p, H, 64).transpose(0, 1)[:, :n]
+        v = y[rows, 2 * D:].float().view(p, H, 64).transpose(0, 1)[:, :n]
+        ref = (torch.softmax(q @ k.transpose(1, 2) * 0.125, -1) @ v).transpose(0, 1).reshape(p, D)
+        assert rel_l2(outs[0][rows], ref) < 1.5e-2, (b, rel_l2(outs[0][rows], ref))
+
+
+def test_segment_posconv_and_weighted_sum_match_the_uniform_kernels():
+    """sc_posconv_prep_seg + sc_posconv_seg_bf16 and sc_wsum_fwd_seg / sc_wsum_bwd_seg against the uniform-pitch kernels run per
+    utterance on the same data: bit-identical rows; the slab halos are re-zeroed when the layout moves."""
+    from speechclip_plus_amd import ops
+    torch.manual_seed(1)
+    D, G, Kp, halo = 768, 16, 128, 64
+    Dg = D // G
+    w = (torch.randn(G, Dg, Kp * Dg, device="cuda") * (Kp * Dg) ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(D, device="cuda") * 0.1
+    xg = torch.full((G * (512 + 64 + 2 * halo * 4) * Dg,), 7.0, device="cuda", dtype=torch.bfloat16)      # stale, non-zero halos
+    for pitch, valid in (([96, 288, 32, 160], [80, 280, 31, 160]), ([64, 32, 320, 128], [64, 5, 300, 127])):
+        seg = ops.RowSegments(pitch, valid, "cuda")
+        M, B = seg.rows, seg.B
+        x = torch.randn(M, D, device="cuda").to(torch.bfloat16)
+        vl = torch.tensor(valid, dtype=torch.int32, device="cuda")
+        xz, out = torch.empty_like(x), torch.empty_like(x)
+        ops.posconv_prep_seg(x, vl, xz, xg, seg, D, G, halo)
+        ops.posconv_seg(xg, w, bias, xz, out, seg, D, G, Kp)
+        r0 = seg.row0_host
+        for b, p in enumerate(pitch):
+            R = (p + 127) // 128 * 128
+            xb = torch.zeros(R, D, device="cuda", dtype=torch.bfloat16)
+            xb[:p] = x[r0[b]: r0[b] + p]
+            xzb, xgb, ob = torch.empty_like(xb), torch.zeros(G, 1, R + 2 * halo, Dg, device="cuda", dtype=torch.bfloat16), torch.empty_like(xb)
+            ops.posconv_prep(xb, vl[b: b + 1], xzb, xgb, 1, R, D, G, halo)
+            ops.posconv(xgb, w, bias, xzb, ob, 1, R, D, G, Kp)
+            # rows whose 128-tap window stays inside the utterance's own pitch see the same zero-padded frames in both layouts
+            assert torch.equal(xz[r0[b]: r0[b] + p], xzb[:p]), b
+            assert torch.equal(out[r0[b]: r0[b] + p], ob[:p]), b
+        # weighted sum: ragged states -> uniform [B, Rout, D] with the frames at row 1.., zeros elsewhere; backward against torch
+        NL, Rout = 5, seg.max_pitch
+        h = torch.randn(NL, M, D, device="cuda").to(torch.bfloat16)
+        ws = torch.softmax(torch.randn(NL, device="cuda"), 0)
+        src = torch.full((B, Rout, D), 3.0, device="cuda", dtype=torch.bfloat16)
+        ops.wsum_fwd(h, ws, src, B, Rout, D, 1, seg=seg)
+        gsum = torch.randn(B, Rout, D, device="cuda")
+        ref_d = torch.zeros(NL, device="cuda", dtype=torch.float64)
+        for b, p in enumerate(pitch):
+            n = min(p, Rout - 1)
+            ref = (ws.view(NL, 1, 1) * h[:, r0[b]: r0[b] + n].float()).sum(0)
+            assert float(src[b, 0].abs().max()) == 0.0 and float(src[b, 1 + n:].abs().max() if 1 + n < Rout else 0.0) == 0.0
+            assert rel_l2(src[b, 1: 1 + n], ref) < 4e-3
+            ref_d += (gsum[b, 1: 1 + n].double().unsqueeze(0) * h[:, r0[b]: r0[b] + n].double()).sum((1, 2))
+        d = ops.wsum_bwd_logits(h, gsum, ws, B, Rout, D, 1, seg=seg).double()
+        wd = ws.double()
+        ref_logit = wd * (ref_d - (wd * ref_d).sum())
+        assert rel_l2(d, ref_logit) < 1e-3, rel_l2(d, ref_logit)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/speechclip_hip.h but not exported"
     assert set(_lib.SIGNATURES) | {"sc_last_error", "sc_hash32", "sc_infonce_workspace_floats", "sc_workspace_bytes", "sc_sizeof"} == declared
-    assert lib.sc_abi_version() == 3
+    assert lib.sc_abi_version() == 4
     # the ctypes mirrors of the argument structs have the C structs' sizes (checked again at every load: _lib.lib())
     for what, cls in enumerate((_lib.GemmArgs, _lib.HubertLayerArgs, _lib.RtGemmArgs, _lib.RtLnArgs, _lib.RtLnBwdArgs)):
         assert lib.sc_sizeof(what) == ctypes.sizeof(cls), cls.__name__
@@ -53,6 +53,40 @@ def test_plan_geometry_matches_oracle_lengths():
         R_l = [R * 2 ** (6 - i) for i in range(7)]
         assert all(r >= tt for r, tt in zip(R_l, t)), (L, R_l, t)      # every valid conv row is stored
     assert conv_out_lengths(160000, arch)[-1] == 499 and conv_out_lengths(102400, arch)[-1] == 319
+
+
+def test_segment_geometry():
+    """Round 4, ragged rows (speech_encoder._Plan.bind / ops.RowSegments): an utterance that needs its first n frames gets a pitch of
+    roundup(n + 1, 32) rows at the last conv layer and 2^(6-l) times that at layer l.  Walk the conv stack's receptive fields
+    backwards: every row / sample those n frames depend on lies INSIDE the utterance's own segment, for every n."""
+    from speechclip_plus_amd.speech_encoder import HubertArch, FairseqSpeechEncoder_Hubert
+    from speechclip_plus_amd.ops import RowSegments
+    arch = HubertArch()
+    ks, ss = arch.conv_kernels, arch.conv_strides
+    for n in list(range(1, 70)) + [99, 127, 128, 129, 319, 320, 499, 511, 512]:
+        pitch = (n + 1 + 31) // 32 * 32
+        need = n                                   # rows needed at layer l (walking from the last layer down)
+        for l in range(len(ks) - 1, 0, -1):
+            assert need <= pitch * 2 ** (len(ks) - 1 - l)
+            need = (need - 1) * ss[l] + ks[l]      # rows of layer l - 1 that rows < need of layer l read
+        assert need <= pitch * 64                  # conv layer 0 rows
+        samples = (need - 1) * ss[0] + ks[0]
+        assert samples <= pitch * 320, (n, samples)
+    # pitches of a batch: frames the key mask admits, frames the head reads + the CIF conv's tail, never more than T
+    enc = FairseqSpeechEncoder_Hubert.__new__(FairseqSpeechEncoder_Hubert)
+    enc.tail_rows = 2
+    need, pitch = enc.segment_pitches(499, [499, 100, 7, 300], [499, 101, 6, 301], ragged=True)
+    assert need == [499, 103, 8, 303] and pitch == [512, 128, 32, 320]
+    need, pitch = enc.segment_pitches(319, [319, 100], [319, 99], ragged=False)
+    assert need == [319, 319] and pitch == [320, 320]            # the reference's 6.4 s training crop: 320 rows for 319 frames
+    # host tables: chunk entries (first row, pitch, utterance, 0) per 32 rows; work list = q-blocks, longest key count first
+    tab, row0, nwork = RowSegments.host_tables([64, 32, 160], [50, 20, 140])
+    assert row0 == [0, 64, 96, 256] and nwork == 1 + 1 + 2
+    t = tab.tolist()
+    chunk, r0, work = t[: 4 * 8], t[32: 36], t[36:]
+    assert chunk[:8] == [0, 64, 0, 0, 0, 64, 0, 0] and chunk[8:12] == [64, 32, 1, 0] and chunk[12:16] == [96, 160, 2, 0]
+    assert r0 == row0 and work == [2, 2 | (1 << 16), 0, 1]
+    assert RowSegments.table_ints(3, 512 * 3) >= len(t)
 
 
 def test_retrieval_matches_golden(golden):
