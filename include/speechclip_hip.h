@@ -38,15 +38,16 @@ int sc_set_option(int32_t key, int32_t value);
 /* ------------------------------------------------------------------------------------------------
  * Ragged row layout (round 4).  The reference pads every batch to its longest utterance and computes all of it
  * (avssl/module/speech_encoder_plus.py:506-518, 548-552); here utterance b owns rows [row0[b], row0[b + 1]) of every
- * [rows, C] activation buffer - its own pitch, a multiple of 32 rows, sized by its own number of frames - so GEMM rows,
+ * [rows, C] activation buffer - its own pitch, a multiple of SC_SEG_ROWS = 8 rows, sized by its own number of frames - so GEMM rows,
  * attention blocks and row kernels follow the real lengths.  Down the conv stack layer l has the same table scaled by
  * 2^(6-l) (row0 * 64 at conv layer 0), the waveform by `samples_per_row` (320): a strided Conv1d stays ONE flat GEMM.
- *   row0   device [B + 1] int32, multiples of 32, row0[0] = 0, row0[B] = rows
- *   chunk  device [rows / 32][4] int32: for every 32-row chunk (first row of its utterance, pitch of its utterance, utterance, 0)
+ *   row0   device [B + 1] int32, multiples of 8, row0[0] = 0, row0[B] = rows
+ *   chunk  device [rows / 8][4] int32: for every 8-row chunk (first row of its utterance, pitch of its utterance, utterance, 0)
  *          - the reverse lookup of the flat kernels (one 16-byte load)
  *   max_pitch = max_b (row0[b + 1] - row0[b])   (grid sizing on the host)
  * The struct itself lives in HOST memory (passed by pointer), its two tables in device memory.
  * ---------------------------------------------------------------------------------------------- */
+#define SC_SEG_ROWS 8
 typedef struct {
     const int32_t* row0;
     const int32_t* chunk;
@@ -135,7 +136,7 @@ typedef struct {
     int32_t aux_mode;
     int32_t reserved3;
     /* ---- ragged rows (round 4): seg_chunk != NULL replaces the uniform `R` of the transposed store - row m belongs to the
-     * utterance of chunk m / 32 = (first row r0, pitch Rb, ...) (sc_segments.chunk) and goes to
+     * utterance of chunk m / 8 = (first row r0, pitch Rb, ...) (sc_segments.chunk) and goes to
      *       Ct[(N - n_split) * r0 + (n - n_split) * Rb + (m - r0)]          (V^T [H, dh, Rb] per utterance, utterances back to back) */
     const int32_t* seg_chunk;
 } sc_gemm_args;
@@ -163,7 +164,7 @@ int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const i
 
 /* The same over ragged rows (sc_segments): q / k rows of utterance b at row0[b] + t, vt = per utterance [H, 64, Rb] at element offset
  * D * row0[b] (what sc_gemm_bf16 writes with seg_chunk), out rows likewise; lse2 [H][rows].  One workgroup = 128 queries of one
- * (utterance, head); a last block of 32 / 64 / 96 queries is computed by that many waves.  work (optional, device [nwork] int32):
+ * (utterance, head); in a last, shorter block the waves (32 queries each) past the pitch idle and the rows past it are not stored.  work (optional, device [nwork] int32):
  * the (utterance | q-block << 16) pairs to run, in launch order - the host sorts them longest first (an utterance's cost grows with
  * its key count); NULL = every (b, q-block < max_pitch / 128), blocks past an utterance's pitch exit.  Dropout element index:
  * ((h * rows + row0[b] + q) * max_pitch + k).  Bit-identical to the uniform call on the rows they share. */

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
             qblk = pair % nqb;
         }
         r0 = row0[b];
-        R = row0[b + 1] - r0;                                        // this utterance's pitch (a multiple of 32)
+        R = row0[b + 1] - r0;                                        // this utterance's pitch (a multiple of 8)
         if (qblk * 128 >= R) return;                                 // uniform for the workgroup, before any barrier
     } else {
         qblk = logical % nqb;
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         b = bh / H;
         r0 = b * R;
     }
-    // a last block of 32 / 64 / 96 queries: the waves past the pitch still stage K / V^T and meet the barriers, but neither multiply
-    // nor store (their rows belong to the next utterance)
+    // a last, shorter block: the waves past the pitch still stage K / V^T and meet the barriers, but neither multiply nor store;
+    // inside the wave that straddles the pitch the lanes past it compute on the next utterance's rows and skip their store
     const bool wave_on = qblk * 128 + wave * 32 < R;
     const int q0 = wave_on ? qblk * 128 + wave * 32 : 0;
     int n_valid = valid_len[b];
@@ -160,15 +160,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                 mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
             // deferred rescale: keep the running max stale while it would grow by < 2^6 in the exponent domain
-            // (p stays <= 64, harmless for the fp32 sums and the bf16 P operand); when any lane of the wave needs
-            // it, O, l and the max are brought to the new scale together, before this block's P is formed
+            // (p stays <= 64, harmless for the fp32 sums and the bf16 P operand).  The DECISION is per query (round 4): when some
+            // lane of the wave needs it the rescale code runs, but a query that does not need it multiplies by exp2(0) = 1 exactly
+            // and keeps its max - so a query's bits do not depend on which other queries share its wave (ragged vs padded rows)
             const float m_cand = fmaxf(m_run, mloc);
-            if (__any((m_cand - m_run) * c > 6.0f)) {
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * c);
+            const bool grow = (m_cand - m_run) * c > 6.0f;
+            if (__any(grow)) {
+                const float m_new = grow ? m_cand : m_run;
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
                 l_run *= alpha;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-                m_run = m_cand;
+                m_run = m_new;
             }
             const float mc = m_run * c;
             float psum = 0.f;
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
     const float inv = DROP ? 1.0f / (l_tot * (1.0f - drop_p)) : 1.0f / l_tot;
+    if (qrow >= R) return;                                          // lanes past the pitch: the next utterance's rows
     if (lse2 && half == 0)
         lse2[row0 ? (int64_t)h * rows_total + r0 + qrow : ((int64_t)b * H + h) * R + qrow] = m_run * c + __builtin_amdgcn_logf(l_tot);   // log2 domain
     uint16_t* op = out + ((int64_t)r0 + q0 + l31) * ldo + h * 64 + 4 * half;
@@ -266,7 +270,7 @@ extern "C" int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* 
     // R % 128 != 0 (round 4): a last q-block of 32 / 64 / 96 rows; the K / V^T tiles of 64 keys may then read up to 32 rows / 64
     // elements past an utterance (into the next one, or - behind the last - into slack the caller provides: 64 rows of qk, 64
     // elements of vt); what they read there is masked
-    SC_CHECK(B > 0 && H > 0 && R > 0 && R % 32 == 0, "sc_attn_fwd_bf16: R=%d must be a positive multiple of 32", R);
+    SC_CHECK(B > 0 && H > 0 && R > 0 && R % 8 == 0, "sc_attn_fwd_bf16: R=%d must be a positive multiple of 8", R);
     SC_CHECK(D == H * 64, "sc_attn_fwd_bf16: head_dim must be 64 (D=%d, H=%d)", D, H);
     SC_CHECK(causal == 0 || causal == 1 || causal == 32 || causal == 64, "sc_attn_fwd_bf16: causal=%d (0, 1, or a segment of 32 / 64 rows)", causal);
     SC_CHECK(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || (int64_t)B * H * R * R < ((int64_t)1 << 32)),
@@ -289,7 +293,7 @@ extern "C" int sc_attn_fwd_seg_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf
                                     const sc_segments* seg, const int32_t* work, int32_t nwork, int32_t H, int32_t D, float scale,
                                     float* lse2, int32_t causal, float drop_p, uint32_t drop_seed, void* stream) {
     SC_CHECK(qk && vt && valid_len && out && seg && seg->row0, "sc_attn_fwd_seg_bf16: null pointer");
-    SC_CHECK(seg->B > 0 && seg->B < 65536 && H > 0 && seg->rows > 0 && seg->max_pitch > 0 && seg->max_pitch % 32 == 0 && (!work || nwork > 0),
+    SC_CHECK(seg->B > 0 && seg->B < 65536 && H > 0 && seg->rows > 0 && seg->max_pitch > 0 && seg->max_pitch % SC_SEG_ROWS == 0 && (!work || nwork > 0),
              "sc_attn_fwd_seg_bf16: B=%d rows=%d max_pitch=%d", seg->B, seg->rows, seg->max_pitch);
     SC_CHECK(D == H * 64, "sc_attn_fwd_seg_bf16: head_dim must be 64 (D=%d, H=%d)", D, H);
     SC_CHECK(causal == 0 || causal == 1, "sc_attn_fwd_seg_bf16: causal=%d", causal);

@@ -83,6 +83,10 @@ __global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restric
     const int len = wav_len ? (int)wav_len[b] : 0x7fffffff;
     const int t_begin = chunk * per, t_end = min(min(T0, t_begin + per), wav_len ? (len + 4) / 5 : 0x7fffffff);
     const float* x = wav + (int64_t)b * ldw;
+    if (t_begin >= t_end) {                      // a chunk wholly behind the utterance (ragged batches): its sums are zero
+        if (threadIdx.x < 65) partial[((int64_t)b * nchunk + chunk) * SC_CONV0_NSTAT + threadIdx.x] = 0.0;
+        return;
+    }
     double acc[65];
 #pragma unroll
     for (int e = 0; e < 65; ++e) acc[e] = 0.0;

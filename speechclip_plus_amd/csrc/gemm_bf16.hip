@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
                 const f32x4 hi = *(const f32x4*)(Cs + nrow * BM + mc * 8 + 4);
                 const int nn = n - p.n_split, hh = nn / p.dh, d = nn % p.dh;
                 uint16_t* dst;
-                if (p.seg_chunk) {       // ragged rows: (first row, pitch) of the utterance that owns this 32-row chunk
-                    const int2 sg = *(const int2*)(p.seg_chunk + 4 * (m >> 5));
+                if (p.seg_chunk) {       // ragged rows: (first row, pitch) of the utterance that owns this 8-row chunk
+                    const int2 sg = *(const int2*)(p.seg_chunk + 4 * (m >> 3));
                     dst = p.Ct + (int64_t)(p.N - p.n_split) * sg.x + (int64_t)nn * sg.y + (m - sg.x);
                 } else {
                     const int b = m / p.R, t = m % p.R;
@@ -342,10 +342,10 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     if (a.n_split >= 0) {
         SC_CHECK(a.Ct != nullptr && a.dh > 0 && (a.R > 0 || a.seg_chunk), "sc_gemm_bf16: transposed store needs Ct, dh, R (or seg_chunk)");
         if (a.seg_chunk)
-            SC_CHECK(a.M % 32 == 0 && ((uintptr_t)a.seg_chunk % 16) == 0 && a.nb1 * a.nb2 == 1,
-                     "sc_gemm_bf16: a segment table needs M %% 32 == 0, a 16-byte aligned table and no batch");
+            SC_CHECK(a.M % SC_SEG_ROWS == 0 && ((uintptr_t)a.seg_chunk % 16) == 0 && a.nb1 * a.nb2 == 1,
+                     "sc_gemm_bf16: a segment table needs M %% 8 == 0, a 16-byte aligned table and no batch");
         else
-            SC_CHECK(a.R % 32 == 0 && a.M % a.R == 0, "sc_gemm_bf16: transposed store needs R %% 32 == 0, M %% R == 0");
+            SC_CHECK(a.R % 8 == 0 && a.M % a.R == 0, "sc_gemm_bf16: transposed store needs R %% 8 == 0, M %% R == 0");
         SC_CHECK(a.n_split % 128 == 0 && (a.N - a.n_split) % a.dh == 0, "sc_gemm_bf16: transposed store needs n_split %% 128 == 0, (N - n_split) %% dh == 0");
         SC_CHECK(a.out_f32 == 0, "sc_gemm_bf16: transposed store is bf16 only");
     } else {

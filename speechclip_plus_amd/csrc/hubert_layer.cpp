@@ -43,11 +43,11 @@ extern "C" int sc_hubert_layer_fwd(const sc_hubert_layer_args* p, void* stream) 
              "sc_hubert_layer_fwd: null pointer");
     const sc_segments* seg = p->seg;
     if (seg) {
-        SC_CHECK(seg->row0 && seg->chunk && seg->B > 0 && seg->rows > 0 && seg->rows % 32 == 0 && p->H > 0 && p->D == p->H * 64 && p->F > 0,
+        SC_CHECK(seg->row0 && seg->chunk && seg->B > 0 && seg->rows > 0 && seg->rows % SC_SEG_ROWS == 0 && p->H > 0 && p->D == p->H * 64 && p->F > 0,
                  "sc_hubert_layer_fwd: segment table B=%d rows=%d D=%d (= 64 H) F=%d", seg->B, seg->rows, p->D, p->F);
     } else {
-        SC_CHECK(p->B > 0 && p->R > 0 && p->R % 32 == 0 && p->H > 0 && p->D == p->H * 64 && p->F > 0 && p->T > 0 && p->T <= p->R,
-                 "sc_hubert_layer_fwd: B=%d R=%d (%% 32) T=%d D=%d (= 64 H) F=%d", p->B, p->R, p->T, p->D, p->F);
+        SC_CHECK(p->B > 0 && p->R > 0 && p->R % 8 == 0 && p->H > 0 && p->D == p->H * 64 && p->F > 0 && p->T > 0 && p->T <= p->R,
+                 "sc_hubert_layer_fwd: B=%d R=%d (%% 8) T=%d D=%d (= 64 H) F=%d", p->B, p->R, p->T, p->D, p->F);
     }
     const int M = seg ? seg->rows : p->B * p->R, D = p->D, F = p->F, H = p->H;
     const float scale = 0.125f;       // head_dim 64

@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void posconv_prep_seg_kernel(const uint16_t* _
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
         const int row = (int)(q / chunks_per_row);
         const int cc = (int)(q % chunks_per_row);
-        const int4 sg = *(const int4*)(chunk + 4 * (row >> 5));       // (first row, pitch, utterance, -)
+        const int4 sg = *(const int4*)(chunk + 4 * (row >> 3));       // (first row, pitch, utterance, -)
         const int t = row - sg.x, pitch = sg.y, b = sg.z;
         uint4 u = make_uint4(0, 0, 0, 0);
         if (t < valid_len[b]) u = *(const uint4*)(x + (int64_t)row * D + cc * 8);
@@ -834,8 +834,8 @@ extern "C" int sc_wsum_bwd_seg(const sc_bf16* h, const float* g, int32_t NL, flo
 extern "C" int sc_posconv_prep_seg(const sc_bf16* x, const int32_t* valid_len, sc_bf16* xz, sc_bf16* xg, const sc_segments* seg, int32_t D,
                                    int32_t G, int32_t halo, void* stream) {
     SC_CHECK(x && valid_len && xz && xg && seg && seg->chunk, "sc_posconv_prep_seg: null pointer");
-    SC_CHECK(G > 0 && D % G == 0 && (D / G) % 8 == 0 && seg->rows > 0 && seg->rows % 32 == 0 && seg->B > 0 && halo > 0,
-             "sc_posconv_prep_seg: D/G=%d must be a multiple of 8, rows a multiple of 32", D / G);
+    SC_CHECK(G > 0 && D % G == 0 && (D / G) % 8 == 0 && seg->rows > 0 && seg->rows % SC_SEG_ROWS == 0 && seg->B > 0 && halo > 0,
+             "sc_posconv_prep_seg: D/G=%d must be a multiple of 8, rows a multiple of 8", D / G);
     SC_CHECK(((uintptr_t)seg->chunk % 16) == 0, "sc_posconv_prep_seg: chunk table must be 16-byte aligned");
     const int64_t total = (int64_t)seg->rows * (D / 8);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

@@ -200,6 +200,14 @@ class KWClip_GeneralTransformer(nn.Module):
             logger.info("Create Parallel Branch")
             self.parallel_branch = KW_ParallelBranch(config=config, audio_dim=self.audio_embd_dim,
                                                      text_dim=self.subword_embd_dim)
+        # frames behind feat_len the encoder still has to compute (speech_encoder.segment_pitches): the CIF weight conv of the plus
+        # branches looks conv_cif_width // 2 frames past the last valid one (avssl/module/cif.py:44-52); the CLS head reads none
+        if self.cascaded_branch is None:
+            self.audio_encoder.tail_rows = 0
+        else:
+            ds = ms.cascaded_branch.get("downsampling", None)
+            width = ds.cif.get("conv_cif_width", 5) if (ds is not None and ds.type == "cif") else 5
+            self.audio_encoder.tail_rows = max(1, int(width) // 2)
         self.img_enc_proj_net = None
         self.p_branch_proj_net = None
         self.c_branch_proj_net = None

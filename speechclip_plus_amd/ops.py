@@ -31,10 +31,12 @@ def _stream() -> ctypes.c_void_p:
 
 class RowSegments:
     """Ragged row layout of one batch (``sc_segments``, include/speechclip_hip.h): utterance b owns rows [row0[b], row0[b + 1]) -
-    its own pitch, a multiple of 32 rows - of every activation buffer of the encoder.  Built on the host from the batch's lengths
+    its own pitch, a multiple of 8 rows - of every activation buffer of the encoder.  Built on the host from the batch's lengths
     (``host_tables``: pure python, tested on the CPU) and uploaded in one pinned, asynchronous copy.
 
     ``pitch`` [B] rows per utterance; ``keys`` [B] the key count that sorts the attention work list (longest first)."""
+
+    GRAN = 8             # SC_SEG_ROWS: pitches are multiples of this; one chunk-table entry per GRAN rows
 
     def __init__(self, pitch, keys, device, storage: Optional[torch.Tensor] = None):
         host, self.row0_host, self.n_work = self.host_tables(pitch, keys)
@@ -47,7 +49,7 @@ class RowSegments:
             dev.copy_(host.pin_memory(), non_blocking=True)
         else:
             dev = host.pin_memory().to(device, non_blocking=True)
-        nch = self.rows // 32
+        nch = self.rows // self.GRAN
         self.chunk = dev[: 4 * nch]                              # first: the 16-byte entries stay 16-byte aligned
         self.row0 = dev[4 * nch: 4 * nch + self.B + 1]
         self.work = dev[4 * nch + self.B + 1:]
@@ -56,27 +58,27 @@ class RowSegments:
         self.c.row0, self.c.chunk = _p(self.row0), _p(self.chunk)
         self.c.B, self.c.rows, self.c.max_pitch = self.B, self.rows, self.max_pitch
 
-    @staticmethod
-    def table_ints(B: int, max_rows: int) -> int:
+    @classmethod
+    def table_ints(cls, B: int, max_rows: int) -> int:
         """upper bound of the table size in int32 (storage for a plan: B utterances, at most ``max_rows`` rows)"""
-        return 4 * (max_rows // 32) + B + 1 + B * ((max_rows + 127) // 128 + 1)
+        return 4 * (max_rows // cls.GRAN) + B + 1 + B * ((max_rows + 127) // 128 + 1)
 
-    @staticmethod
-    def host_tables(pitch, keys):
+    @classmethod
+    def host_tables(cls, pitch, keys):
         """-> (int32 tensor [chunk table | row0 | attention work list], row0 as a python list, number of work items).
-        chunk[c] = (first row, pitch, utterance, 0) of the utterance that owns rows 32 c .. 32 c + 31; work = (utterance | q-block << 16)
+        chunk[c] = (first row, pitch, utterance, 0) of the utterance that owns rows 8 c .. 8 c + 7; work = (utterance | q-block << 16)
         for every 128-query block, longest utterance first (its workgroups run longest: start them first)."""
-        B = len(pitch)
-        assert B < 65536 and all(int(p) > 0 and int(p) % 32 == 0 for p in pitch)
-        row0 = [0]
-        for p in pitch:
-            row0.append(row0[-1] + int(p))
-        chunk = []
-        for b, p in enumerate(pitch):
-            chunk.extend([row0[b], int(p), b, 0] * (int(p) // 32))
+        import numpy as np
+        B, G = len(pitch), cls.GRAN
+        p = np.asarray([int(x) for x in pitch], dtype=np.int64)
+        assert B < 65536 and (p > 0).all() and (p % G == 0).all()
+        row0 = np.concatenate([[0], np.cumsum(p)])
+        per = np.stack([row0[:-1], p, np.arange(B), np.zeros(B, dtype=np.int64)], axis=1)         # one entry per utterance
+        chunk = np.repeat(per, p // G, axis=0).reshape(-1)
         order = sorted(range(B), key=lambda b: (-int(keys[b]), b))
-        work = [b | (qb << 16) for b in order for qb in range((int(pitch[b]) + 127) // 128)]
-        return torch.tensor(chunk + row0 + work, dtype=torch.int32), row0, len(work)
+        work = [b | (qb << 16) for b in order for qb in range((int(p[b]) + 127) // 128)]
+        tab = np.concatenate([chunk, row0, np.asarray(work, dtype=np.int64)]).astype(np.int32)
+        return torch.from_numpy(tab), [int(x) for x in row0], len(work)
 
     def ref(self):
         return ctypes.byref(self.c)

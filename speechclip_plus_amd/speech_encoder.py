@@ -5,7 +5,7 @@ return_hidden_states) -> (feat, feat_len[, hidden_states])``, ``out_dim``, ``dow
 ``trainable_params()``.
 
 Data layout in HBM: channels-last bf16 activations in a row layout with a pitch PER UTTERANCE (round 4): utterance b /
-frame t -> row row0[b] + t, pitch_b = row0[b + 1] - row0[b] = roundup(n_b + 1, 32) with n_b the frames anything downstream reads
+frame t -> row row0[b] + t, pitch_b = row0[b + 1] - row0[b] = roundup(n_b + 1, 8) with n_b the frames anything downstream reads
 (``_Plan.bind``), and 2^(6-l) times that table down the conv stack (the waveform: 320 samples per row).  With that layout every
 strided Conv1d of the feature extractor is ONE flat GEMM whose A rows overlap (lda = stride*C, K = k*C), the transformer GEMMs see
 M = sum_b pitch_b rows - the work follows the real lengths of a ragged batch instead of its padded length - and attention /
@@ -162,7 +162,7 @@ class _Plan:
     """Shapes + resident workspaces for one (B, L) batch geometry.
 
     ``seg_mode`` (the frozen encoder, round 4): buffers are sized for the uniform worst case (every utterance L samples long,
-    pitch ``R = roundup(T + 1, 32)``) and ``bind`` lays the CURRENT batch out in them by its real lengths - per-utterance pitches,
+    pitch ``R = roundup(T + 1, 8)``) and ``bind`` lays the CURRENT batch out in them by its real lengths - per-utterance pitches,
     ``ops.RowSegments`` tables uploaded with the batch's other integers - so ``M``, ``hidden`` and the row buffers below are views
     that change from forward to forward.  Otherwise (unfrozen layers: their backward kernels index utterances by ``b * R``) the
     uniform layout of rounds 1-3 with ``R = roundup(T + 2, 128)``."""
@@ -182,7 +182,7 @@ class _Plan:
             self.spr *= s_
         # seg_mode: the frames < n of an utterance need conv rows < 2^(6-l) n + c_l (c_0 = 15) of layer l and samples < 320 n + 80,
         # all inside a pitch of n + 1 rows (tests/test_host_cpu.py::test_segment_geometry); the legacy layout stores every padded row
-        self.R = _roundup(self.T + 1, 32) if seg_mode else _roundup(self.T + 2, 128)
+        self.R = _roundup(self.T + 1, ops.RowSegments.GRAN) if seg_mode else _roundup(self.T + 2, 128)
         self.R_l = [self.R * (2 ** (nl - 1 - i)) for i in range(nl)]
         if not seg_mode:
             assert all(r >= t for r, t in zip(self.R_l, self.T_l))
@@ -402,11 +402,11 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
     def segment_pitches(self, T: int, valid: Sequence[int], feat_len: Sequence[int], ragged: bool) -> Tuple[List[int], List[int]]:
         """-> (rows needed per utterance, pitch per utterance).  An utterance needs the frames the HuBERT key mask admits
         (``valid``, fairseq forward_padding_mask) and the frames the head / branches read (``feat_len`` + ``tail_rows``), never
-        more than the padded length T; its pitch is that + 1 (the conv stack's last row of a segment is scratch) rounded to 32."""
+        more than the padded length T; its pitch is that + 1 (the conv stack's last row of a segment is scratch) rounded to 8."""
         if not ragged:
-            return [T] * len(valid), [_roundup(T + 1, 32)] * len(valid)
+            return [T] * len(valid), [_roundup(T + 1, ops.RowSegments.GRAN)] * len(valid)
         need = [max(1, min(T, max(int(v), int(f) + self.tail_rows))) for v, f in zip(valid, feat_len)]
-        return need, [_roundup(n + 1, 32) for n in need]
+        return need, [_roundup(n + 1, ops.RowSegments.GRAN) for n in need]
 
     @torch.no_grad()
     def _encode(self, padded: torch.Tensor, wav_len: List[int], save: bool = False, ragged: Optional[bool] = None) -> _Plan:

@@ -850,7 +850,7 @@ def test_encoder_train_mode_dropout_vs_oracle(setup):
     finally:
         enc.eval()
     B, T, D = hs[0].shape
-    H, R = 12, (T + 1 + 31) // 32 * 32          # returned hidden states: the un-ragged segment layout, pitch roundup(T + 1, 32)
+    H, R = 12, (T + 1 + 7) // 8 * 8             # returned hidden states: the un-ragged segment layout, pitch roundup(T + 1, 8)
     a = enc.arch
     assert (a.dropout, a.attention_dropout, a.dropout_input) == (0.1, 0.1, 0.1)
     drop = _encoder_mask_hook(seed_of, B, T, D, H, R, seg=True)

@@ -31,7 +31,7 @@ def setup():
     return model, sd, oracle
 
 
-# lengths that exercise: pitch 32 (a 10-frame utterance), 64 / 96-row last attention blocks, a 128-multiple, the batch maximum,
+# lengths that exercise: pitch 16 (a 10-frame utterance), short last attention blocks, a 128-multiple, the batch maximum,
 # feat_len > valid frames (round(len / 320) vs ceil(len / chunk)), feat_len == valid
 LENS = [48000, 3300, 20000, 30500, 40960, 9000, 47999, 16000, 25000]
 
@@ -58,9 +58,9 @@ def test_segment_layout_of_the_batch(setup):
     feat_len = [min(round(l / 320), T) for l in LENS]
     assert seg is not None and seg.rows == sum(seg.pitch) and seg.rows < len(LENS) * pl.R        # fewer rows than the padded batch
     for b in range(len(LENS)):
-        assert seg.pitch[b] % 32 == 0 and seg.pitch[b] >= max(valid[b], feat_len[b]) + 1
-        assert seg.pitch[b] <= max(valid[b], feat_len[b]) + enc.tail_rows + 32
-    assert min(seg.pitch) == 32 and max(seg.pitch) == pl.Rout
+        assert seg.pitch[b] % 8 == 0 and seg.pitch[b] >= max(valid[b], feat_len[b]) + 1
+        assert seg.pitch[b] <= max(valid[b], feat_len[b]) + enc.tail_rows + 8
+    assert min(seg.pitch) == 16 and max(seg.pitch) == pl.Rout
 
 
 def test_ragged_rows_are_bit_identical_to_the_padded_computation(setup):
@@ -84,7 +84,7 @@ def test_ragged_rows_are_bit_identical_to_the_padded_computation(setup):
     for b, n in enumerate(l1.tolist()):
         keep = min(T, n + enc.tail_rows)
         assert torch.equal(f1[b, :keep], f0[b, :keep]), b
-        assert float(f1[b, keep + 32:].abs().max() if keep + 32 < T else 0.0) == 0.0, b       # rows the layout does not hold: zeros
+        assert float(f1[b, keep + 8:].abs().max() if keep + 8 < T else 0.0) == 0.0, b       # rows the layout does not hold: zeros
 
 
 def test_ragged_batch_against_the_oracle(setup):
@@ -145,13 +145,13 @@ def test_ragged_train_step_equals_the_padded_train_step(setup):
 
 
 def test_segment_attention_and_vt_store_against_torch():
-    """sc_gemm_bf16 with a segment table (V^T per utterance [H, 64, pitch]) + sc_attn_fwd_seg_bf16, pitches 32 .. 160 (last q-blocks of
-    32 / 64 / 96 / 128 rows, a K tile that crosses into the next utterance), with and without the host's work list, against fp32 torch."""
+    """sc_gemm_bf16 with a segment table (V^T per utterance [H, 64, pitch]) + sc_attn_fwd_seg_bf16, pitches 8 .. 160 (last q-blocks of
+    8 / 24 / 32 / 64 / 104 / 128 rows, a K tile that crosses into the next utterance), with and without the host's work list, against fp32 torch."""
     from speechclip_plus_amd import ops
     torch.manual_seed(0)
     H, D = 2, 128
-    pitch = [32, 160, 64, 96, 128, 32]
-    valid = [7, 150, 64, 65, 100, 32]
+    pitch = [24, 160, 64, 104, 128, 8]
+    valid = [7, 150, 64, 65, 100, 8]
     seg = ops.RowSegments(pitch, valid, "cuda")
     M = seg.rows
     x = torch.randn(M + 64, D, device="cuda").to(torch.bfloat16)
@@ -197,7 +197,7 @@ def test_segment_posconv_and_weighted_sum_match_the_uniform_kernels():
     w = (torch.randn(G, Dg, Kp * Dg, device="cuda") * (Kp * Dg) ** -0.5).to(torch.bfloat16)
     bias = torch.randn(D, device="cuda") * 0.1
     xg = torch.full((G * (512 + 64 + 2 * halo * 4) * Dg,), 7.0, device="cuda", dtype=torch.bfloat16)      # stale, non-zero halos
-    for pitch, valid in (([96, 288, 32, 160], [80, 280, 31, 160]), ([64, 32, 320, 128], [64, 5, 300, 127])):
+    for pitch, valid in (([88, 288, 8, 168], [80, 280, 7, 160]), ([64, 32, 320, 128], [64, 5, 300, 127])):
         seg = ops.RowSegments(pitch, valid, "cuda")
         M, B = seg.rows, seg.B
         x = torch.randn(M, D, device="cuda").to(torch.bfloat16)

@@ -57,14 +57,14 @@ def test_plan_geometry_matches_oracle_lengths():
 
 def test_segment_geometry():
     """Round 4, ragged rows (speech_encoder._Plan.bind / ops.RowSegments): an utterance that needs its first n frames gets a pitch of
-    roundup(n + 1, 32) rows at the last conv layer and 2^(6-l) times that at layer l.  Walk the conv stack's receptive fields
+    roundup(n + 1, 8) rows at the last conv layer and 2^(6-l) times that at layer l.  Walk the conv stack's receptive fields
     backwards: every row / sample those n frames depend on lies INSIDE the utterance's own segment, for every n."""
     from speechclip_plus_amd.speech_encoder import HubertArch, FairseqSpeechEncoder_Hubert
     from speechclip_plus_amd.ops import RowSegments
     arch = HubertArch()
     ks, ss = arch.conv_kernels, arch.conv_strides
     for n in list(range(1, 70)) + [99, 127, 128, 129, 319, 320, 499, 511, 512]:
-        pitch = (n + 1 + 31) // 32 * 32
+        pitch = (n + 1 + 7) // 8 * 8
         need = n                                   # rows needed at layer l (walking from the last layer down)
         for l in range(len(ks) - 1, 0, -1):
             assert need <= pitch * 2 ** (len(ks) - 1 - l)
@@ -76,15 +76,15 @@ def test_segment_geometry():
     enc = FairseqSpeechEncoder_Hubert.__new__(FairseqSpeechEncoder_Hubert)
     enc.tail_rows = 2
     need, pitch = enc.segment_pitches(499, [499, 100, 7, 300], [499, 101, 6, 301], ragged=True)
-    assert need == [499, 103, 8, 303] and pitch == [512, 128, 32, 320]
+    assert need == [499, 103, 8, 303] and pitch == [504, 104, 16, 304]
     need, pitch = enc.segment_pitches(319, [319, 100], [319, 99], ragged=False)
     assert need == [319, 319] and pitch == [320, 320]            # the reference's 6.4 s training crop: 320 rows for 319 frames
-    # host tables: chunk entries (first row, pitch, utterance, 0) per 32 rows; work list = q-blocks, longest key count first
-    tab, row0, nwork = RowSegments.host_tables([64, 32, 160], [50, 20, 140])
-    assert row0 == [0, 64, 96, 256] and nwork == 1 + 1 + 2
+    # host tables: chunk entries (first row, pitch, utterance, 0) per 8 rows; work list = q-blocks, longest key count first
+    tab, row0, nwork = RowSegments.host_tables([16, 8, 160], [13, 2, 140])
+    assert row0 == [0, 16, 24, 184] and nwork == 1 + 1 + 2
     t = tab.tolist()
-    chunk, r0, work = t[: 4 * 8], t[32: 36], t[36:]
-    assert chunk[:8] == [0, 64, 0, 0, 0, 64, 0, 0] and chunk[8:12] == [64, 32, 1, 0] and chunk[12:16] == [96, 160, 2, 0]
+    chunk, r0, work = t[: 4 * 23], t[92: 96], t[96:]
+    assert chunk[:8] == [0, 16, 0, 0, 0, 16, 0, 0] and chunk[8:12] == [16, 8, 1, 0] and chunk[12:16] == [24, 160, 2, 0] and chunk[-4:] == [24, 160, 2, 0]
     assert r0 == row0 and work == [2, 2 | (1 << 16), 0, 1]
     assert RowSegments.table_ints(3, 512 * 3) >= len(t)
 
