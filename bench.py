@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--model", choices=["base", "large", "cascaded_plus", "hybrid_plus_large"], default="base",
                     help="base = BASELINE configs[1] (headline); large = Parallel large; cascaded_plus = configs[2]; "
                          "hybrid_plus_large = configs[4] recipe on one GPU")
+    ap.add_argument("--no-recipes", action="store_true", help="skip the `recipes` object of the default N = 1 run (BASELINE configs[2] "
+                    "cascaded+ base and configs[4] hybrid+ large on one GPU, the ragged batch and the 6.4 s training crop: 10 steps each)")
     ap.add_argument("--rehearse-launch", action="store_true", help="launch plumbing only, no GPU: the ranks rendezvous, issue the "
                     "step's two collectives (packed all-gather, flat all-reduce) on CPU tensors and rank 0 prints the JSON line "
                     "with value null (tests/test_dp_gloo.py runs this with SC_DIST_BACKEND=gloo)")
@@ -89,42 +91,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     rccl_ranks = count_ranks(dist, dev)
 
-    from speechclip_plus_amd import (KWClip_GeneralTransformer, base_parallel_config, cascaded_plus_base_config,
-                                     hybrid_plus_large_config, large_parallel_config, ops, random_hubert_state_dict)
-    from speechclip_plus_amd.speech_encoder import ARCHS
-    from speechclip_plus_amd.train import ContrastiveTrainer
+    from speechclip_plus_amd import ops
 
     B, L = args.batch, int(round(args.seconds * 16000))
-    torch.manual_seed(7122)
-    large = args.model in ("large", "hybrid_plus_large")
-    sd = random_hubert_state_dict(ARCHS["hubert_large_ll60k" if large else "hubert"], seed=7122)
-    cfg = {"base": base_parallel_config, "large": large_parallel_config, "cascaded_plus": cascaded_plus_base_config,
-           "hybrid_plus_large": hybrid_plus_large_config}[args.model]()
-    E = int(cfg.clip.embed_dim)
-    cfg.audio_encoder.max_audio_len = -1          # 10 s utterances, no 6.4 s training crop (BASELINE configs[1])
-    if args.unfreeze > 0:
-        nl = 24 if large else 12
-        cfg.audio_encoder.trainable = True
-        cfg.audio_encoder.unfreeze_layers = list(range(nl - args.unfreeze, nl))
-    if args.trainable:
-        cfg.audio_encoder.trainable = True
-    model = KWClip_GeneralTransformer(cfg, device=str(dev), hubert_state_dict=sd)
-    model.train()
-    if args.no_dropout:
-        from speechclip_plus_amd import set_dropout
-        set_dropout(model, False)
-    trainer = ContrastiveTrainer(model)
-
-    g = torch.Generator(device="cpu").manual_seed(7122 + rank)
-    wav = torch.randn(B, L, generator=g).to(dev)
-    wav_len = torch.full((B,), L, dtype=torch.long)
-    if args.ragged:
-        wav_len = torch.randint(min(32000, L), L + 1, (B,), generator=g)
-        wav_len[0] = L                                   # the batch is padded to its longest utterance: keep the geometry
-        wav = wav * (torch.arange(L).unsqueeze(0) < wav_len.unsqueeze(1)).to(dev)
-    img = torch.nn.functional.normalize(torch.randn(B, E, generator=g), dim=-1).to(dev)
-    ids = (torch.arange(B) + rank * B) // 5            # Flickr8k shape: 5 captions per image id
-    batch = {"wav": wav, "wav_len": wav_len, "image": img, "id": ids.to(dev)}
+    model, trainer, batch, sd, wav_len = make_workload(args.model, B, L, args.ragged, rank, dev, unfreeze=args.unfreeze,
+                                                       trainable=args.trainable, no_dropout=args.no_dropout)
 
     def sync():
         torch.cuda.synchronize()
@@ -157,20 +128,11 @@ def main():
     if dist is not None:
         collectives = collective_report(dist, dev, args.steps, elapsed / args.steps * 1e3, lambda: trainer.step(batch))
     # ---- forward only (north_star: fraction of the MFMA bf16 peak on the HuBERT + attention-pool forward) ---------
-    fwd_ms = fwd_train_ms = None
+    fwd_ms = fwd_train_ms = conv_ms = conv_train_ms = None
     if rank == 0 and args.model == "base":
-        def time_forward():
-            with torch.no_grad():
-                model(batch)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    model(batch)
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t1) / args.steps * 1e3
-        fwd_train_ms = time_forward()                            # as the train step runs it: HuBERT + head dropout live
-        model.eval()                                             # inference forward: no dropout
-        fwd_ms = time_forward()
+        fwd_train_ms, conv_train_ms = time_forward(model, batch, args.steps)     # as the train step runs it: HuBERT + head dropout live
+        model.eval()                                                             # inference forward: no dropout
+        fwd_ms, conv_ms = time_forward(model, batch, args.steps)
         model.train()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -242,14 +204,120 @@ def main():
             "rccl_ranks": rccl_ranks, "dist_backend": (os.environ.get("SC_DIST_BACKEND", "nccl") if dist is not None else None),
             "collectives": collectives,
             "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,
-            "forward": None if fwd_ms is None else forward_summary(fwd_ms, B, L, T, wav_len.tolist() if args.ragged else None),
-            "forward_train_mode": None if fwd_train_ms is None else forward_summary(fwd_train_ms, B, L, T, wav_len.tolist() if args.ragged else None),
+            "forward": None if fwd_ms is None else forward_summary(fwd_ms, B, L, T, wav_len.tolist() if args.ragged else None, conv_ms),
+            "forward_train_mode": None if fwd_train_ms is None else forward_summary(fwd_train_ms, B, L, T, wav_len.tolist() if args.ragged else None,
+                                                                                    conv_train_ms),
             "recall": recall,
         }
+        default_run = (world == 1 and args.model == "base" and not args.ragged and not args.unfreeze and not args.trainable
+                       and not args.no_dropout and abs(args.seconds - 10.0) < 1e-9)
+        if default_run and not args.no_recipes:
+            del trainer, model, batch
+            torch.cuda.empty_cache()
+            result["recipes"] = run_recipes(args, dev)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def make_workload(kind, B, L, ragged, rank, dev, unfreeze=0, trainable=False, no_dropout=False):
+    """model (random-init weights of the named architecture, seeded), trainer and one synthetic batch resident in HBM:
+    B utterances of L samples N(0, 1) (``ragged``: lengths U{32000 .. L}, zero behind), unit-norm "CLIP image embeddings", 5 captions per id."""
+    from speechclip_plus_amd import (KWClip_GeneralTransformer, base_parallel_config, cascaded_plus_base_config,
+                                     hybrid_plus_large_config, large_parallel_config, random_hubert_state_dict)
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    torch.manual_seed(7122)
+    large = kind in ("large", "hybrid_plus_large")
+    sd = random_hubert_state_dict(ARCHS["hubert_large_ll60k" if large else "hubert"], seed=7122)
+    cfg = {"base": base_parallel_config, "large": large_parallel_config, "cascaded_plus": cascaded_plus_base_config,
+           "hybrid_plus_large": hybrid_plus_large_config}[kind]()
+    E = int(cfg.clip.embed_dim)
+    cfg.audio_encoder.max_audio_len = -1          # the batch is given at its length (no second crop inside the model)
+    if unfreeze > 0:
+        nl = 24 if large else 12
+        cfg.audio_encoder.trainable = True
+        cfg.audio_encoder.unfreeze_layers = list(range(nl - unfreeze, nl))
+    if trainable:
+        cfg.audio_encoder.trainable = True
+    model = KWClip_GeneralTransformer(cfg, device=str(dev), hubert_state_dict=sd)
+    model.train()
+    if no_dropout:
+        from speechclip_plus_amd import set_dropout
+        set_dropout(model, False)
+    trainer = ContrastiveTrainer(model)
+    g = torch.Generator(device="cpu").manual_seed(7122 + rank)
+    wav = torch.randn(B, L, generator=g).to(dev)
+    wav_len = torch.full((B,), L, dtype=torch.long)
+    if ragged:
+        wav_len = torch.randint(min(32000, L), L + 1, (B,), generator=g)
+        wav_len[0] = L                                   # the batch is padded to its longest utterance: keep the geometry
+        wav = wav * (torch.arange(L).unsqueeze(0) < wav_len.unsqueeze(1)).to(dev)
+    img = torch.nn.functional.normalize(torch.randn(B, E, generator=g), dim=-1).to(dev)
+    ids = (torch.arange(B) + rank * B) // 5            # Flickr8k shape: 5 captions per image id
+    batch = {"wav": wav, "wav_len": wav_len, "image": img, "id": ids.to(dev)}
+    return model, trainer, batch, sd, wav_len
+
+
+def time_forward(model, batch, steps):
+    """-> (ms per forward, ms of it inside the conv feature extractor): the model's forward under no_grad, wall clock over ``steps``
+    back-to-back calls; the conv share from three event records per call (speech_encoder._section_ev: start, conv stack done, end)."""
+    enc = model.audio_encoder
+    with torch.no_grad():
+        model(batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            model(batch)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) / steps * 1e3
+        conv = []
+        for _ in range(min(steps, 5)):
+            enc._section_ev = {}
+            model(batch)
+            torch.cuda.synchronize()
+            ev = enc._section_ev
+            if "start" in ev and "conv_done" in ev:
+                conv.append(ev["start"].elapsed_time(ev["conv_done"]))
+        enc._section_ev = None
+    return ms, (sum(conv) / len(conv) if conv else None)
+
+
+def run_recipes(args, dev):
+    """The other shapes and recipes on the driver's clock: 3 warm-up + 10 timed train steps each, same protocol as
+    the headline (barrier-free at N = 1: synchronize on both sides), models built and released one at a time."""
+    import gc
+    out = {}
+    B = args.batch
+    for name, kind, seconds, ragged in (("ragged_base", "base", args.seconds, True), ("crop_6p4s_base", "base", 6.4, False),
+                                        ("cascaded_plus_base", "cascaded_plus", args.seconds, False),
+                                        ("hybrid_plus_large", "hybrid_plus_large", args.seconds, False)):
+        L = int(round(seconds * 16000))
+        model, trainer, batch, _, wav_len = make_workload(kind, B, L, ragged, 0, dev)
+        for _ in range(3):
+            trainer.step(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            loss = trainer.step(batch)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        rec = {"ms_per_step": round(ms, 3), "utterances_per_s": round(B / ms * 1e3, 1), "steps": 10, "warmup": 3, "batch": B,
+               "seconds": seconds, "loss": round(float(loss.item()), 5)}
+        if ragged:
+            rec["mean_seconds"] = round(float(wav_len.float().mean()) / 16000, 2)
+        if kind == "base":
+            T = model.audio_encoder._plan(B, L).T
+            model.eval()
+            fwd_ms, conv_ms = time_forward(model, batch, 10)
+            rec["forward"] = forward_summary(fwd_ms, B, L, T, wav_len.tolist() if ragged else None, conv_ms)
+            rec["rows"] = {"layout": int(model.audio_encoder._plan(B, L).M), "padded_batch": B * T}
+        out[name] = rec
+        del model, trainer, batch
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 def launch_ranks(n: int) -> int:
@@ -353,28 +421,39 @@ def rehearse_launch(args, world: int) -> None:
         dist.destroy_process_group()
 
 
-def forward_summary(fwd_ms, B, L, T, lens=None):
+def forward_summary(fwd_ms, B, L, T, lens=None, conv_ms=None):
     """Algorithmic flops of the HuBERT-base + CLS-pool forward (SURVEY 8d formulae, conv extractor included; the
     collapsed CLS head is ~0.013 GFLOP/utt) over the measured forward time.  ``lens``: per-utterance sample counts of a ragged
-    batch - every utterance then counts at its own length (mean reported)."""
+    batch - every utterance then counts at its own length (mean reported).  ``conv_ms``: the part of the forward spent in the conv
+    feature extractor (event records around it): SURVEY 8d asks for the "transformer + head only" fraction next to the one that
+    includes the extractor - its flops (projection, pos_conv, 12 layers, head) over the forward time without the extractor."""
     def one(Lb):
-        t, cin, flop = Lb, 1, 0.0
+        t, cin, conv = Lb, 1, 0.0
         ks, ss = (10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)
         for k, s_ in zip(ks, ss):
             t = (t - k) // s_ + 1
-            flop += 2.0 * t * 512 * cin * k
+            conv += 2.0 * t * 512 * cin * k
             cin = 512
         Tb = t
         D, F, NL = 768, 3072, 12
-        flop += 2.0 * Tb * 512 * D                                  # post_extract_proj
-        flop += 2.0 * Tb * D * (D // 16) * 128                      # pos_conv
-        flop += NL * Tb * 2.0 * (4 * D * D + 2 * D * F)             # linear layers
-        flop += NL * 4.0 * Tb * Tb * D                              # attention
-        return flop + 0.013e9
-    flop = one(L) if lens is None else sum(one(int(l)) for l in lens) / len(lens)
+        rest = 2.0 * Tb * 512 * D                                   # post_extract_proj
+        rest += 2.0 * Tb * D * (D // 16) * 128                      # pos_conv
+        rest += NL * Tb * 2.0 * (4 * D * D + 2 * D * F)             # linear layers
+        rest += NL * 4.0 * Tb * Tb * D                              # attention
+        return conv, rest + 0.013e9
+    pairs = [one(L)] if lens is None else [one(int(l)) for l in lens]
+    conv = sum(p[0] for p in pairs) / len(pairs)
+    rest = sum(p[1] for p in pairs) / len(pairs)
+    flop = conv + rest
     tfl = flop * B / (fwd_ms * 1e-3) / 1e12
-    return {"ms": round(fwd_ms, 3), "utterances_per_s": round(B / fwd_ms * 1e3, 1), "alg_gflop_per_utt": round(flop / 1e9, 2),
-            "alg_tflops": round(tfl, 1), "frac_of_mfma_bf16_peak": round(tfl / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+    out = {"ms": round(fwd_ms, 3), "utterances_per_s": round(B / fwd_ms * 1e3, 1), "alg_gflop_per_utt": round(flop / 1e9, 2),
+           "alg_tflops": round(tfl, 1), "frac_of_mfma_bf16_peak": round(tfl / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+    if conv_ms is not None and 0 < conv_ms < fwd_ms:
+        t_rest = rest * B / ((fwd_ms - conv_ms) * 1e-3) / 1e12
+        out.update({"conv_extractor_ms": round(conv_ms, 3), "alg_gflop_per_utt_transformer_head_only": round(rest / 1e9, 2),
+                    "frac_transformer_head_only": round(t_rest / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                    "frac_conv_extractor_only": round(conv * B / (conv_ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)})
+    return out
 
 
 def pmc_traffic(kernel_substr):
@@ -519,7 +598,8 @@ def cpu_baseline(sd, model, n_utts, L, iters, full=False):
     torch.set_num_threads(default_threads)
     best = max(runs.values(), key=lambda r: r["train_step_utt_per_s"])
     return {"value": best["train_step_utt_per_s"], "unit": "utterances/s", "cores": best["threads"], "kind": "port",
-            "sample": f"BASELINE configs[0]: batch {n_utts} x {L} samples, {warm} warm-up + {timed} timed train steps per thread "
+            "sample": ("SURVEY 8d protocol, " if full else "bounded sample (the driver's time limit; --cpu-full runs SURVEY 8d's 3 + 10): ") +
+                      f"BASELINE configs[0]: batch {n_utts} x {L} samples, {warm} warm-up + {timed} timed train steps per thread "
                       f"setting, torch fp32 on {os.cpu_count()} logical CPUs ({physical_cores()} physical cores)",
             "host": {"logical_cpus": os.cpu_count(), "physical_cores": physical_cores(), "torch_default_threads": default_threads},
             "s_per_step": best["forward_backward_s"], "forward_utt_per_s": best["forward_utt_per_s"],

@@ -271,6 +271,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # amount of work; also what ``return_hidden_states`` uses: those tensors carry every padded row, like the reference's).
         # ``tail_rows``: frames behind feat_len that a consumer still reads - the CIF weight conv of the cascaded+/hybrid+ branches
         # (conv_cif_width 3 or 5, avssl/module/cif.py:44-52) looks one / two frames past the last valid one.
+        self._section_ev = None                 # bench.py: a dict that receives event records (start / conv stack done) of one forward
         self.ragged = os.environ.get("SC_RAGGED", "1") == "1"
         self.tail_rows = 2
         self._drop_calls = 0
@@ -496,6 +497,9 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         C, D, F, H = a.conv_dim, a.embed_dim, a.ffn_dim, a.heads
         R, M, T = pl.R, pl.M, pl.T
         len_dev = pl.len_dev
+        if self._section_ev is not None:
+            self._section_ev["start"] = torch.cuda.Event(enable_timing=True)
+            self._section_ev["start"].record()
         # a1: (optional) utterance layer-norm + zero pad                                (:506-518)
         if pl.seg is not None:
             ops.wav_prep_seg(padded, len_dev, pl.wav_pad, pl.seg, pl.spr, a.normalize_wav)
@@ -541,6 +545,9 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                          tap_c=C if (k == 3 and s == 2) else 0)      # shared-tap K order: see sc_gemm_args.tap_c
             if ln_mode:
                 ops.layernorm_bf16(pl.conv[i][:rows], w[f"conv{i}_ln_g"], w[f"conv{i}_ln_b"], out=pl.conv[i][:rows], act=1)
+        if self._section_ev is not None:
+            self._section_ev["conv_done"] = torch.cuda.Event(enable_timing=True)
+            self._section_ev["conv_done"].record()
         # a3: LayerNorm(512) -> post_extract_proj                                       (:78, :84-85)
         ops.layernorm_bf16(pl.conv[-1][:M], w["ln_feat_g"], w["ln_feat_b"], out=pl.feat_ln)
         ops.linear_bf16(pl.feat_ln, w["proj_w"], w["proj_b"], out=pl.x_proj, alg_rows=alg[-1], drop_p=p_in, drop_seed=sd(0))   # dropout_input (:87)
