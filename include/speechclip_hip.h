@@ -386,8 +386,10 @@ int sc_cif_bwd(const float* x, const float* alpha, const float* csum, const floa
  *   sc_cif_prepare: a = clip(alpha_raw, 0, 1), padded frames (pad != 0) zeroed -> a_clip [B,S] ("orig_alpha") ; quantity = sum a ;
  *     if target && apply_scaling: a *= (thr * target + eps) / quantity (ratio [B] kept for the backward) ; alpha [B,S] ;
  *     csum = inclusive scan [B,S] ; feat_len = clip(floor(sum alpha / thr), 1, max_feat) ; fired [B,S] = slot index advances at the
- *     frame (indices clipped at T) ; flags[0] += (quantity > 0) (the reference asserts that not ALL utterances are zero) ;
- *     flags[1] += (feat_len != clip(target, 1, max_feat)) when scaling (the caller sized the output from target).  fp64 sums.
+ *     frame (indices clipped at T) ; flags (8 int32, zeroed once by the caller): [0] += (quantity > 0) ; [1] += (feat_len !=
+ *     clip(target, 1, max_feat)) when scaling (the caller sized the output from target) ; [3] += 1 when NO utterance of this call had
+ *     a positive quantity (the reference asserts that on every call, cif.py:121) ; [6] += utterances whose zero quantity could not
+ *     be rescaled ; [4], [5] scratch of the per-call check (left at 0) ; [2], [7] the caller's.  fp64 sums.
  *   sc_cif_prepare_bwd: pa / pb of sc_cif_bwd + d quantity (gq, may be NULL) -> d alpha_raw [B,S] (suffix sum of d csum, scaling).
  *   sc_cif_tail (inference): tail weight of slot feat_len >= tail_thr -> that row *= thr / weight, feat_len += 1 (clip max_feat),
  *     rows >= feat_len zeroed in out [B,T+1,C]; factor / extend [B] returned for the caller's backward / diagnostics.    S <= 2048. */

@@ -174,16 +174,20 @@ class CIF(nn.Module):
                                  padding=int(conv_cif_width / 2)), nn.Dropout(), nn.ReLU()]
         self.conv = nn.Sequential(*layers)
         self.weight_proj = nn.Sequential(nn.Dropout(), nn.Linear(encoder_embed_dim, 1), nn.Sigmoid())
-        # [0] utterances with a positive weight sum (the reference asserts that there is at least one per call),
-        # [1] keyword counts that differ from clip(target, 1, 75) while the output was sized from the host-side targets, [2] calls
-        self.register_buffer("consistency_flags", torch.zeros(4, dtype=torch.int32), persistent=False)
+        # sc_cif_prepare's counters (include/speechclip_hip.h): [0] utterances with a positive weight sum, [1] keyword counts that differ
+        # from clip(target, 1, 75) while the output was sized from the host-side targets, [2] calls, [3] CALLS in which no utterance
+        # had a positive weight sum (the reference asserts on every call that there is one), [6] utterances whose all-zero weights could
+        # not be rescaled to the target, [4] / [5] the kernel's scratch
+        self.register_buffer("consistency_flags", torch.zeros(8, dtype=torch.int32), persistent=False)
 
     def check_flags(self) -> dict:
-        """Synchronises.  Raises like the reference's assertion if some call saw only all-zero weights cannot be told apart
-        per call without a read per call, so the counters are cumulative: ``positive`` utterances over ``calls`` calls."""
-        pos, mism, calls, _ = self.consistency_flags.tolist()
-        assert calls == 0 or pos > 0, "alphas are all zero"
-        return {"positive_utterances": pos, "count_mismatches": mism, "calls": calls}
+        """Synchronises.  Raises like the reference's per-call assertion (avssl/module/cif.py:121) if ANY call since the last reset saw
+        only all-zero weights: the kernel keeps that indicator per call (a cumulative "some utterance was positive once"
+        let one early healthy call mask a collapsed weight generator for ever)."""
+        pos, mism, calls, zero_calls, _, _, zero_utts, _ = self.consistency_flags.tolist()
+        assert zero_calls == 0, f"alphas are all zero in {zero_calls} of {calls} CIF calls"
+        return {"positive_utterances": pos, "count_mismatches": mism, "calls": calls, "all_zero_calls": zero_calls,
+                "zero_quantity_utterances": zero_utts}
 
     def forward(self, input_dict, target_lengths=None, eps=1e-5, target_lengths_host: Optional[List[int]] = None):
         feats = input_dict["audio_feat"]                       # B x S x C

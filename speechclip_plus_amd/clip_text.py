@@ -113,6 +113,8 @@ class ClipModel(nn.Module):
         self.text_encoder_trainable = text_encoder_trainable
         self.model = _ClipTextCore(CLIP_VOCAB, a["width"], a["heads"], a["layers"], a["embed_dim"], seed)
         self.out_dim = a["width"]
+        # keyword counts that pointed behind the keyword tensor and were clamped by encode_keywords (device counter, read on request)
+        self.register_buffer("eot_clamped", torch.zeros((), dtype=torch.int64), persistent=False)
         self.selected_text_emb_ids = None
         if reduce_subword_embbedding is not None:
             # clip_official.py:63-108: keep only the sub-words seen in the captions.  Accepts the reference's .npy path
@@ -191,6 +193,15 @@ class ClipModel(nn.Module):
         n_pos = min(CONTEXT_LEN, (keywords.shape[1] if index is not None else int(keyword_num)) + 2)
         x = self._transformer(x[:, :n_pos])
         # LayerNorm is per row: only the end-of-text row of every sample goes through ln_final and the projection
-        rows = x[torch.arange(bsz, device=dev), index] if index is not None else x[:, 1 + keyword_num]
+        # (index = keyword count + 1 <= n_pos - 1 by construction - the CIF kernel caps every count at the slots the host sized,
+        # min(max_feat, T); the clamp makes the gather safe whatever a caller hands in: a count beyond the keyword tensor is an error
+        # the reference reports as a shape mismatch on the host, here it is clamped and counted in ``eot_clamped`` instead of
+        # indexing out of bounds on the device, which would poison the context)
+        if index is not None:
+            over = index > n_pos - 1
+            self.eot_clamped += over.sum()
+            rows = x[torch.arange(bsz, device=dev), torch.where(over, torch.full_like(index, n_pos - 1), index)]
+        else:
+            rows = x[:, 1 + keyword_num]
         ln = self.model.ln_final
         return _EotHeadFn.apply(rows, ln.weight, ln.bias, ln.eps, self.model.text_projection)

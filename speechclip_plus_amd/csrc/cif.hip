@@ -229,11 +229,26 @@ __global__ __launch_bounds__(256) void cif_prepare_kernel(const float* __restric
         feat_len[b] = fl;
         quantity[b] = q;
         ratio_out[b] = ratio;
-        if (q > 0.f) atomicAdd(&flags[0], 1);               // the reference asserts (alpha_sum > 0).any()
+        if (q > 0.f) {
+            atomicAdd(&flags[0], 1);                        // cumulative count of utterances with a positive weight sum
+            atomicAdd(&flags[5], 1);                        // ... of THIS call
+        } else if (scale) {
+            atomicAdd(&flags[6], 1);                        // an utterance that could not be rescaled (ratio forced to 0, see above)
+        }
         if (scale) {
             int64_t t = target[b];
             t = t < 1 ? 1 : (t > max_feat ? max_feat : t);
             if (t != fl) atomicAdd(&flags[1], 1);           // the host sized the output from target_len
+        }
+        // the reference asserts (alpha_sum > 0).any() on EVERY call (avssl/module/cif.py:121): the last utterance of the call to arrive
+        // (ticket in flags[4]) looks at the call's own count and records a call without any positive utterance in flags[3]; both
+        // scratch words are left at 0 for the next call (calls on one stream are ordered)
+        __threadfence();
+        if (atomicAdd(&flags[4], 1) + 1 == (int)gridDim.x) {
+            __threadfence();
+            const int pos = atomicExch(&flags[5], 0);
+            atomicExch(&flags[4], 0);
+            if (pos == 0) atomicAdd(&flags[3], 1);
         }
     }
 }

@@ -548,7 +548,7 @@ def cif_prepare(alpha_raw: torch.Tensor, pad: torch.Tensor, target: Optional[tor
     """CIF bookkeeping of one batch on the device (sc_cif_prepare): alpha_raw [B,S] fp32 (row stride free), pad [B,S] uint8 / bool."""
     B, S = alpha_raw.shape
     assert alpha_raw.dtype == torch.float32 and alpha_raw.stride(1) == 1 and pad.element_size() == 1 and pad.stride(1) == 1
-    assert flags.dtype == torch.int32 and flags.numel() >= 2
+    assert flags.dtype == torch.int32 and flags.numel() >= 8
     if target is not None:
         assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == B
     dev = alpha_raw.device

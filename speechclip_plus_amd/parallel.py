@@ -159,8 +159,12 @@ class GradAllReduce:
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
+            # synchronous form ON the side stream: with the NCCL / RCCL backend the collective runs on the process group's own
+            # stream and a blocking call makes the CURRENT (= side) stream wait for it - so the closing event of the bracket sits
+            # behind the collective and `all_reduce_us` measures it, not just its launch; the host does not block
             with torch.cuda.stream(self.stream), comm_span("all_reduce", True):
-                self.work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.work = None
         else:
             with comm_span("all_reduce", False):
                 self.work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -174,3 +178,26 @@ class GradAllReduce:
             self.work = None
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class AccumulationSchedule:
+    """``trainer.accumulate_grad_batches`` (config/speechCLIP+/model_large/coco/spchclip_h+.yaml:138; Lightning semantics): every
+    micro-step back-propagates loss / n into the SAME gradient buffer; the gradient collective, the clip + optimiser step, the
+    learning-rate schedule and ``global_step`` advance only on every n-th micro-step (the boundary).  No collective is issued on
+    the micro-steps in between - their gradients are partial sums that only this rank needs."""
+
+    def __init__(self, n: int = 1):
+        self.n = max(1, int(n))
+        self.micro = 0                       # micro-steps taken since the last boundary
+
+    @property
+    def loss_scale(self) -> float:
+        return 1.0 / self.n
+
+    def advance(self) -> bool:
+        """count one micro-step -> True when it is a boundary (collectives + optimiser run now)"""
+        self.micro += 1
+        if self.micro >= self.n:
+            self.micro = 0
+            return True
+        return False

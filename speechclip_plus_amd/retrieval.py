@@ -3,8 +3,13 @@
 
 The reference sorts every score row and looks the answers up in rank order.  Here no row is sorted: a query hits at k iff fewer
 than k candidates score strictly above its best-scoring correct candidate, so one masked row maximum and one comparison count per
-direction give every k at once (on the device the scores live on).  Exact float ties between a correct and a wrong candidate
-count for the query; the reference leaves them to the order of an unstable ``argsort``, i.e. undefined."""
+direction give every k at once (on the device the scores live on).
+
+Degenerate scores: the reference leaves exact float ties between a correct and a wrong candidate to the order of an
+unstable ``argsort`` - collapsed embeddings (all scores equal) then score about chance - and sorts NaN first.  Here a tie counts
+AGAINST the query (a wrong candidate with the same score as the best correct one is ahead of it), a NaN candidate is ahead of
+everything (where the reference's sort puts it) and a query whose best correct score is not finite is a miss at every k: a
+diverged or collapsed model reports recall near 0, never 100, so a "keep the best validation recall" monitor cannot latch onto it."""
 from typing import Dict, Sequence, Tuple
 
 import torch
@@ -14,9 +19,13 @@ def _recall(score: torch.Tensor, query_ids: torch.Tensor, cand_ids: torch.Tensor
     """score [Q, C]; a candidate c is correct for query q iff cand_ids[c] == query_ids[q] (an image with several captions has
     several correct candidates; one of them inside the top k is a hit)."""
     correct = cand_ids.unsqueeze(0) == query_ids.unsqueeze(1)
-    best = score.masked_fill(~correct, float("-inf")).amax(dim=1, keepdim=True)
-    ahead = (score > best).sum(dim=1)                    # a query without any correct candidate has best = -inf: never a hit
-    ahead = torch.where(correct.any(dim=1), ahead, torch.full_like(ahead, score.shape[1]))
+    nan = torch.isnan(score)
+    best = score.masked_fill(~correct | nan, float("-inf")).amax(dim=1, keepdim=True)
+    # wrong candidates ahead of the best correct one: higher score, equal score (ties count against the query), or NaN
+    ahead = (score > best).sum(dim=1) + (((score == best) | nan) & ~correct).sum(dim=1)
+    # a query without a correct candidate, or whose best correct score is not finite (-inf: none / all NaN; +inf: overflow): never a hit
+    ok = correct.any(dim=1) & torch.isfinite(best.squeeze(1))
+    ahead = torch.where(ok, ahead, torch.full_like(ahead, score.shape[1]))
     out = {}
     for k in ks:
         if k > score.shape[1]:

@@ -424,26 +424,44 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # fairseq forward_padding_mask: frame t valid iff t*(L//T) < len                (:81-82)
         # feat_len = min(round(len / 320), T), python round = half to even              (:604-611)
         chunk = L // T
-        valid = [min(T, -(-int(l) // chunk)) for l in wav_len]
-        feat_len = [min(round(int(l) / self.downsample_rate), T) for l in wav_len]
-        if pl.seg_mode:
-            # the row layout of THIS batch: pitches from the lengths, tables into the plan's resident int32 storage (same stream, so
-            # the previous forward's kernels are done with them)
-            need, pitch = self.segment_pitches(T, valid, feat_len, self.ragged if ragged is None else ragged)
-            pl.bind(ops.RowSegments(pitch, valid, self._dev, storage=pl.tables))
-            pl.need = need
-            R, M = pl.R, pl.M
-            # algorithmic work of this batch: every utterance at its OWN length (padding is not work)
-            own = [conv_out_lengths(max(int(l), 400), a) for l in wav_len]
-            pl.alg_rows_l = [sum(o[i] for o in own) for i in range(len(a.conv_kernels))]
-            pl.alg_attn_flops = 4.0 * D * sum(float(o[-1]) ** 2 for o in own)
-        host = torch.tensor([list(map(int, wav_len)), valid, feat_len], dtype=torch.int64).pin_memory()
-        ints = host.to(self._dev, non_blocking=True)
-        pl.feat_len = ints[2]
-        pl.feat_len._sc_host = list(feat_len)       # host twin (length-derived integers are known before any kernel runs)
-        # key count of the parallel head ([CLS ; frames]: feat_len + 1) as the int32 vector its kernels take: uploaded here too, so the
-        # head needs no add / cast launches
-        pl.feat_len._sc_p1_i32 = torch.tensor([f + 1 for f in feat_len], dtype=torch.int32).pin_memory().to(self._dev, non_blocking=True)
+        if isinstance(wav_len, torch.Tensor):
+            # lengths that exist on the DEVICE only (the reference's batch after Lightning moved it, DP scatter): no host read - the
+            # length arithmetic runs in a few launches on B integers and the rows keep the uniform pitch (a ragged layout needs the
+            # lengths on the host before the first launch; hand ``wav_len`` over as a CPU tensor / list for that, as collate does)
+            l64 = wav_len.to(device=self._dev, dtype=torch.int64).clamp(min=0, max=L)
+            valid_d = torch.clamp((l64 + (chunk - 1)) // chunk, max=T)
+            feat_d = torch.clamp(torch.round(l64.double() / self.downsample_rate).long(), max=T)       # torch.round: half to even
+            if pl.seg_mode:
+                need, pitch = self.segment_pitches(T, [T] * B, [T] * B, False)
+                pl.bind(ops.RowSegments(pitch, [T] * B, self._dev, storage=pl.tables))
+                pl.need = need
+                R, M = pl.R, pl.M
+                pl.alg_rows_l = [B * t for t in pl.T_l]
+                pl.alg_attn_flops = 4.0 * D * B * float(T) ** 2
+            pl.feat_len = feat_d
+            pl.feat_len._sc_p1_i32 = (feat_d + 1).to(torch.int32)
+            ints = (l64, valid_d.to(torch.int32))
+        else:
+            valid = [min(T, -(-int(l) // chunk)) for l in wav_len]
+            feat_len = [min(round(int(l) / self.downsample_rate), T) for l in wav_len]
+            if pl.seg_mode:
+                # the row layout of THIS batch: pitches from the lengths, tables into the plan's resident int32 storage (same stream, so
+                # the previous forward's kernels are done with them)
+                need, pitch = self.segment_pitches(T, valid, feat_len, self.ragged if ragged is None else ragged)
+                pl.bind(ops.RowSegments(pitch, valid, self._dev, storage=pl.tables))
+                pl.need = need
+                R, M = pl.R, pl.M
+                # algorithmic work of this batch: every utterance at its OWN length (padding is not work)
+                own = [conv_out_lengths(max(int(l), 400), a) for l in wav_len]
+                pl.alg_rows_l = [sum(o[i] for o in own) for i in range(len(a.conv_kernels))]
+                pl.alg_attn_flops = 4.0 * D * sum(float(o[-1]) ** 2 for o in own)
+            host = torch.tensor([list(map(int, wav_len)), valid, feat_len], dtype=torch.int64).pin_memory()
+            ints = host.to(self._dev, non_blocking=True)
+            pl.feat_len = ints[2]
+            pl.feat_len._sc_host = list(feat_len)       # host twin (length-derived integers are known before any kernel runs)
+            # key count of the parallel head ([CLS ; frames]: feat_len + 1) as the int32 vector its kernels take: uploaded here too, so the
+            # head needs no add / cast launches
+            pl.feat_len._sc_p1_i32 = torch.tensor([f + 1 for f in feat_len], dtype=torch.int32).pin_memory().to(self._dev, non_blocking=True)
         pl.len_dev.copy_(ints[0])
         pl.valid.copy_(ints[1])
         # The frozen encoder is a fixed sequence of ~130 launches over the plan's resident buffers.  Opt-in (SC_ENCODER_GRAPH=1):
@@ -714,11 +732,17 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # (sc_wav_prep re-applies the zero padding from wav_len); otherwise un-pad / crop / re-pad like the reference.
         crop = self.training and self.max_audio_len >= 0
         if isinstance(wav, torch.Tensor) and wav.dim() == 2 and not (crop and wav.shape[1] > self.max_audio_len):
-            if len(wav_len) > 0:
-                lens = [int(l) for l in (wav_len.tolist() if isinstance(wav_len, torch.Tensor) else wav_len)]
+            if isinstance(wav_len, torch.Tensor) and wav_len.is_cuda and wav_len.numel() > 0:
+                # device-resident lengths: not read back (no host synchronisation); the batch's second dimension
+                # is then taken as its padded length (what collate_general produces: padded to the longest utterance)
+                lens = getattr(wav_len, "_sc_host", None) or wav_len
+                L = wav.shape[1] if isinstance(lens, torch.Tensor) else max(lens)
             else:
-                lens = [wav.shape[1]] * wav.shape[0]
-            L = max(lens)
+                if len(wav_len) > 0:
+                    lens = [int(l) for l in (wav_len.tolist() if isinstance(wav_len, torch.Tensor) else wav_len)]
+                else:
+                    lens = [wav.shape[1]] * wav.shape[0]
+                L = max(lens)
             padded = wav[:, :L].to(self._dev, torch.float32).contiguous()
         else:
             if isinstance(wav, torch.Tensor):

@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from .optim import FlatAdam, linear_warmup_decay
-from .parallel import GradAllReduce, comm_span, dp_world, gather_loss_feats, scale_replicated_grads
+from .parallel import AccumulationSchedule, GradAllReduce, comm_span, dp_world, gather_loss_feats, scale_replicated_grads
 
 
 class ContrastiveTrainer:
@@ -34,6 +34,10 @@ class ContrastiveTrainer:
         self.sched = cfg.audio_encoder.get("scheduler", None)
         self.opt = FlatAdam(model.getTrainableParams(), lr=self.base_lr, weight_decay=float(oc.args.get("weight_decay", 0.0)),
                             max_grad_norm=float(cfg.trainer.get("gradient_clip_val", 0.0)))
+        # trainer.accumulate_grad_batches (spchclip_h+.yaml:138): gradients of n micro-steps add up in the flat buffer, collectives and
+        # optimiser on the boundary micro-step only
+        self.accum = AccumulationSchedule(int(cfg.trainer.get("accumulate_grad_batches", 1) or 1))
+        self._boundary = self.accum.n == 1          # is the micro-step in flight the one that ends with the optimiser step?
         self.allreduce = GradAllReduce(self.opt.flat_g, group)
         self.replicated = [p for p in model.criterion.parameters() if p.requires_grad]   # evaluated on the full batch by every rank
         self.side = torch.cuda.Stream() if self.opt.flat_g.is_cuda else None
@@ -56,7 +60,7 @@ class ContrastiveTrainer:
         return dp_world(self.group)
 
     def _layer_ready(self, i: int) -> None:
-        if self._world() == 1:
+        if self._world() == 1 or not self._boundary:       # (a micro-step inside an accumulation window: nothing to exchange yet)
             return
         lo, hi = self._layer_span[i]
         if self.side is not None:
@@ -102,8 +106,11 @@ class ContrastiveTrainer:
         if world > 1 and "quantity_loss" in losses:
             loss = loss - model.quantity_loss_weight * losses["quantity_loss"] * (1.0 - 1.0 / world)
         if self._one is None or self._one.device != loss.device:
-            self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
-        loss.backward(gradient=self._one)               # (a cached 1: no fill launch per step)
+            self._one = torch.full((), self.accum.loss_scale, device=loss.device, dtype=loss.dtype)
+        self._boundary = self.accum.micro + 1 >= self.accum.n          # read by the per-layer hooks during this backward
+        loss.backward(gradient=self._one)               # (a cached 1 / accumulate_grad_batches: no fill launch per step)
+        if not self.accum.advance():
+            return loss.detach()                        # inside an accumulation window: no collective, no optimiser, gradients stay
         lr = self.lr_at(model.global_step)
         if self.side is None:
             self._finish(lr)

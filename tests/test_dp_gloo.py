@@ -59,6 +59,72 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_accumulate(rank, world, port, q):
+    """accumulate_grad_batches = 2 over two ranks (spchclip_h+.yaml:138): each rank back-propagates loss / 2 of two micro-batches into
+    ONE flat buffer and the SUM all-reduce runs on the boundary micro-step only; the result must be the mean over the micro-batches of
+    the single-process global-batch gradients, and exactly one collective per window may be issued."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from speechclip_plus_amd import parallel
+    from speechclip_plus_amd.parallel import AccumulationSchedule, GradAllReduce, gather_loss_feats
+    torch.manual_seed(0)
+    Bg, E, D, n_acc = 8, 16, 12, 2
+    W = torch.nn.Parameter(torch.randn(E, D) * 0.3)
+    data = [(torch.randn(Bg, D), torch.nn.functional.normalize(torch.randn(Bg, E), dim=-1), torch.arange(Bg) // 2) for _ in range(2 * n_acc)]
+    calls = [0]
+    real = dist.all_reduce
+
+    def counted(*a, **k):
+        calls[0] += 1
+        return real(*a, **k)
+    parallel.dist.all_reduce = counted
+    sched = AccumulationSchedule(n_acc)
+    flat = torch.zeros(W.numel())
+    ar = GradAllReduce(flat)
+    n = Bg // world
+    sl = slice(rank * n, (rank + 1) * n)
+    ok, worst = True, 0.0
+    for step, (X, img, ids) in enumerate(data):
+        a_loc = torch.nn.functional.normalize(X[sl] @ W.t(), dim=-1)
+        a_all, i_all, id_all = gather_loss_feats(a_loc, img[sl], ids[sl])
+        loss = oracle.masked_contrastive_loss(a_all, i_all, id_all)
+        (g,) = torch.autograd.grad(loss * sched.loss_scale, [W])
+        flat += g.reshape(-1)
+        before = calls[0]
+        if sched.advance():
+            ar.launch()
+            ar.wait()
+            ref = torch.zeros_like(W)
+            for Xr, imr, idr in data[step + 1 - n_acc: step + 1]:
+                ar_ = torch.nn.functional.normalize(Xr @ W.t(), dim=-1)
+                ref += torch.autograd.grad(oracle.masked_contrastive_loss(ar_, imr, idr), [W])[0] / n_acc
+            worst = max(worst, float((flat.view_as(W) - ref).abs().max()))
+            ok = ok and calls[0] == before + 1
+            flat.zero_()
+        else:
+            ok = ok and calls[0] == before                   # inside the window: no gradient collective
+    parallel.dist.all_reduce = real
+    q.put((rank, bool(ok and worst < 1e-6 and calls[0] == 2), worst, calls[0]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_accumulate_grad_batches_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_accumulate, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] for r in res), res
+
+
 @pytest.mark.timeout(120)
 def test_gather_and_allreduce_world2():
     ctx = mp.get_context("spawn")

@@ -304,6 +304,56 @@ def test_trainer_side_stream_schedule_matches_synchronous():
     assert finals[0][0][2] < finals[0][0][0]
 
 
+def test_accumulate_grad_batches_two_micro_steps_make_one_optimiser_step():
+    """trainer.accumulate_grad_batches: 2 (config/speechCLIP+/model_large/coco/spchclip_h+.yaml:138, Lightning semantics): the first
+    micro-step only back-propagates loss / 2 (no optimiser step, parameters and global_step unchanged), the second adds its loss / 2
+    and steps once - with the gradient a plain trainer accumulates from the same two batches by hand."""
+    import dataclasses
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    arch = dataclasses.replace(ARCHS["hubert"], layers=2)
+    sd = random_hubert_state_dict(arch, seed=3)
+    g = torch.Generator().manual_seed(13)
+    B, L = 6, 9000
+    mk = lambda: {"wav": torch.randn(B, L, generator=g).cuda(), "wav_len": torch.tensor([9000, 7000, 9000, 5000, 8000, 9000]),
+                  "image": torch.randn(B, 512, generator=g).cuda(), "id": torch.tensor([0, 1, 1, 2, 3, 4]).cuda()}
+    b1, b2 = mk(), mk()
+
+    def build(acc):
+        torch.manual_seed(3)
+        cfg = base_parallel_config()
+        cfg.audio_encoder.max_audio_len = -1
+        cfg.trainer.accumulate_grad_batches = acc
+        model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
+        return model, ContrastiveTrainer(model)
+    model, tr = build(2)
+    p0 = tr.opt.flat_p.clone()
+    tr.step(b1)
+    torch.cuda.synchronize()
+    assert model.global_step == 0 and torch.equal(tr.opt.flat_p, p0)           # inside the window: nothing stepped
+    g_half = tr.opt.flat_g.clone()
+    assert float(g_half.abs().sum()) > 0
+    tr.step(b2)
+    torch.cuda.synchronize()
+    assert model.global_step == 1 and not torch.equal(tr.opt.flat_p, p0)
+    g_acc = tr.opt.flat_g.clone()
+    # by hand: the two gradients of a plain trainer at the SAME (initial) parameters, halved and added
+    grads = []
+    for b in (b1, b2):
+        m1, t1 = build(1)
+        t1.step(b)
+        torch.cuda.synchronize()
+        grads.append(t1.opt.flat_g.clone())
+    ref = 0.5 * grads[0] + 0.5 * grads[1]
+    assert rel_l2(g_half, 0.5 * grads[0]) < 1e-6
+    assert rel_l2(g_acc, ref) < 1e-5, rel_l2(g_acc, ref)
+    # and the window closes: the next micro-step starts from a zeroed buffer
+    tr.step(b1)
+    torch.cuda.synchronize()
+    assert model.global_step == 1 and rel_l2(tr.opt.flat_g, g_half) < 0.2      # (parameters moved one Adam step: close, not equal)
+
+
 def test_unfrozen_layers_follow_the_optimiser_and_side_stream_matches_synchronous():
     """Unfrozen HuBERT layers over several optimiser steps: (1) the bf16 working copies the forward / dgrad kernels read are the
     CURRENT fp32 masters after every step (sc_adam_f32 writes through a raw pointer: no tensor version changes, the copies key on

@@ -234,3 +234,31 @@ def test_segment_posconv_and_weighted_sum_match_the_uniform_kernels():
         wd = ws.double()
         ref_logit = wd * (ref_d - (wd * ref_d).sum())
         assert rel_l2(d, ref_logit) < 1e-3, rel_l2(d, ref_logit)
+
+
+def test_device_resident_lengths_need_no_host_read(setup):
+    """``wav_len`` on the device (the reference's batch after Lightning moved it to the GPU / DP scattered it,
+    avssl/model/kwClip.py:149-189): the encoder does not read it back - length arithmetic on the device, uniform row pitch - and the
+    result equals the host-length (ragged) forward on every frame the head reads.  torch's sync debug mode turns any synchronising
+    call inside the forward into an error."""
+    model, sd, oracle = setup
+    enc = model.audio_encoder
+    wav, lens = _batch(LENS).cuda(), torch.tensor(LENS)
+    img = torch.nn.functional.normalize(torch.randn(len(LENS), 512), dim=-1).cuda()
+    ids = torch.arange(len(LENS)).cuda()
+    with torch.no_grad():
+        f_h, l_h = enc(wav, lens)
+        _, _, o_h = model({"wav": wav, "wav_len": lens, "image": img, "id": ids})
+        lens_d = lens.cuda()
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            f_d, l_d = enc(wav, lens_d)
+            _, _, o_d = model({"wav": wav, "wav_len": lens_d, "image": img, "id": ids})
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    assert getattr(l_d, "_sc_host", None) is None and torch.equal(l_d.cpu(), l_h.cpu())
+    assert enc._plan(len(LENS), max(LENS)).M == len(LENS) * enc._plan(len(LENS), max(LENS)).R          # uniform pitch: nothing was read
+    for b, n in enumerate(l_h.tolist()):
+        assert torch.equal(f_d[b, :n], f_h[b, :n]), b
+    assert torch.equal(o_d["parallel_audio_feat"], o_h["parallel_audio_feat"])

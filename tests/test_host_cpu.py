@@ -55,6 +55,25 @@ def test_plan_geometry_matches_oracle_lengths():
     assert conv_out_lengths(160000, arch)[-1] == 499 and conv_out_lengths(102400, arch)[-1] == 319
 
 
+def test_retrieval_degenerate_scores_are_misses():
+    """NaN or collapsed embeddings must not read as recall 100 (the counting formulation compared against a NaN
+    / tied best score and found nobody ahead).  Non-finite rows are misses, exact ties count against the query."""
+    from speechclip_plus_amd import mutualRetrieval
+    nA, nB = 12, 4
+    a_ids, b_ids = torch.arange(nA) // 3, torch.arange(nB)
+    for S in (torch.full((nA, nB), float("nan")), torch.zeros(nA, nB), torch.full((nA, nB), float("inf"))):
+        AB, BA, mean = mutualRetrieval(S, S.t().contiguous(), a_ids, b_ids, [1, 2])
+        assert AB["recall@1"] == 0.0 and BA["recall@1"] == 0.0 and mean["recall@2"] == 0.0, (S[0, 0], AB, BA)
+    # one NaN row does not poison the others; a healthy matrix still scores 100
+    S = torch.eye(nB)[a_ids] + 0.01 * torch.arange(nA * nB).view(nA, nB) / (nA * nB)
+    AB, BA, _ = mutualRetrieval(S, S.t().contiguous(), a_ids, b_ids, [1])
+    assert AB["recall@1"] == 100.0 and BA["recall@1"] == 100.0
+    S[5] = float("nan")
+    AB, BA, _ = mutualRetrieval(S, S.t().contiguous(), a_ids, b_ids, [1])
+    # audio -> image: the NaN row misses; image -> audio: the NaN candidate (a caption of image 1) sorts ahead of every other image's captions
+    assert abs(AB["recall@1"] - 100.0 * 11 / 12) < 1e-4 and BA["recall@1"] == 25.0, (AB, BA)
+
+
 def test_segment_geometry():
     """Round 4, ragged rows (speech_encoder._Plan.bind / ops.RowSegments): an utterance that needs its first n frames gets a pitch of
     roundup(n + 1, 8) rows at the last conv layer and 2^(6-l) times that at layer l.  Walk the conv stack's receptive fields

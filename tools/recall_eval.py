@@ -177,6 +177,25 @@ def build_gallery(a_o: torch.Tensor, ids: torch.Tensor, n_ids: int, seed: int = 
     return img, role
 
 
+def natural_gallery(a_o: torch.Tensor, ids: torch.Tensor, n_ids: int, noise: float, seed: int = SEED_DATA + 177) -> torch.Tensor:
+    """Image embeddings with NATURAL margins (the second fixture, tests/golden/make_recall_natural_fixture.py): class centre of the
+    three gallery captions + isotropic noise of relative size ``noise``, orthogonal to the mean embedding, unit norm.  Nothing is
+    planted: the own-minus-best-other margins pass continuously through zero, as they did in round 2's set."""
+    N, E = a_o.shape
+    cap = torch.arange(N) % PER_ID
+    gal = cap < GALLERY
+    mu = a_o.mean(0)
+    d = a_o - mu
+    muh = mu / mu.norm()
+    C = torch.stack([d[(ids == k) & gal].mean(0) for k in range(n_ids)])
+    C = C / C.norm(dim=-1, keepdim=True)
+    g = torch.Generator().manual_seed(seed)
+    eps = torch.randn(n_ids, E, generator=g) / E ** 0.5
+    img = C + noise * eps
+    img = img - (img @ muh)[:, None] * muh
+    return img / img.norm(dim=-1, keepdim=True)
+
+
 def rank_stats(a_unit: torch.Tensor, image: torch.Tensor, ids: torch.Tensor) -> dict:
     """Scores as the validation epoch computes them (kwClip.py:467-471: plain dot products of unit vectors) -> for every utterance
     the number of images above its own (A->I rank), for every image the number of foreign captions above its best own caption
