@@ -530,7 +530,13 @@ def recall_parity(dev):
     if not os.path.exists(recall_eval.FIXTURE):
         return None
     fx = dict(np.load(recall_eval.FIXTURE))
-    return recall_eval.hip_recall(recall_eval.build_model(str(dev)), fx)
+    model = recall_eval.build_model(str(dev))
+    emb = recall_eval.hip_embeddings(model, int(fx["n_ids"]), int(fx["batch"]))
+    out = recall_eval.hip_recall(model, fx, emb=emb)
+    out["set"] = "planted margins (every confusion >= 30 sigma of the bf16 margin noise): parity holds by construction for any bf16-storage implementation"
+    if os.path.exists(recall_eval.FIXTURE_NATURAL):       # the same utterances against a gallery with natural margins (nothing planted)
+        out["natural_margins"] = recall_eval.natural_margin_report(emb, dict(np.load(recall_eval.FIXTURE_NATURAL)))
+    return out
 
 
 def physical_cores():

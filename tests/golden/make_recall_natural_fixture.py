@@ -58,6 +58,7 @@ def main():
     held = (torch.arange(len(ids)) % PER_ID) >= GALLERY
     noise_ai = (sem["own"].unsqueeze(1) - sem["scores"].gather(1, s32["kth_idx"])) - s32["margin_ai"]
     sigma = float(noise_ai.std())
+    sigma_ia = float((sem["margin_ia"] - s32["margin_ia"]).std())      # image -> audio: own-best minus k-th foreign, each at its own ranks
     flips = lambda a, b: [int(((a < k) != (b < k)).sum()) for k in (1, 5, 10)]
     summary = {
         "protocol": {"ids": args.ids, "captions_per_id": PER_ID, "gallery_captions": GALLERY, "batch": BATCH, "noise_level": s,
@@ -68,11 +69,15 @@ def main():
                     "image_to_audio": recalls(sem["rank_ia"]),
                     "rank_flips_vs_fp32_audio_to_image": flips(s32["rank_ai"], sem["rank_ai"]),
                     "rank_flips_vs_fp32_image_to_audio": flips(s32["rank_ia"], sem["rank_ia"]),
-                    "margin_noise_sigma": sigma, "margin_noise_max": float(noise_ai.abs().max())},
+                    "margin_noise_sigma": sigma, "margin_noise_max": float(noise_ai.abs().max()),
+                    "margin_noise_sigma_image_to_audio": sigma_ia},
         "fraction_of_queries_within_3_sigma_at_1_5_10": [float((s32["margin_ai"][:, i].abs() < 3 * sigma).float().mean()) for i in range(3)],
         "largest_fp32_margin_of_an_emulation_flip_in_sigma": [
             float((s32["margin_ai"][:, i].abs()[(s32["rank_ai"] < k) != (sem["rank_ai"] < k)].max() / sigma)
                   if ((s32["rank_ai"] < k) != (sem["rank_ai"] < k)).any() else 0.0) for i, k in enumerate((1, 5, 10))],
+        "largest_fp32_margin_of_an_emulation_flip_in_sigma_image_to_audio": [
+            float((s32["margin_ia"][:, i].abs()[(s32["rank_ia"] < k) != (sem["rank_ia"] < k)].max() / sigma_ia)
+                  if ((s32["rank_ia"] < k) != (sem["rank_ia"] < k)).any() else 0.0) for i, k in enumerate((1, 5, 10))],
     }
     print(json.dumps(summary, indent=1))
     json.dump(summary, open(os.path.join(HERE, "recall_eval_natural_margins.json"), "w"), indent=1)
@@ -81,7 +86,7 @@ def main():
         rank_ai_fp32=s32["rank_ai"].numpy().astype(np.int16), rank_ia_fp32=s32["rank_ia"].numpy().astype(np.int16),
         rank_ai_bf16emu=sem["rank_ai"].numpy().astype(np.int16), rank_ia_bf16emu=sem["rank_ia"].numpy().astype(np.int16),
         margin_ai_fp32=s32["margin_ai"].numpy().astype(np.float32), kth_idx_fp32=s32["kth_idx"].numpy().astype(np.int16),
-        margin_ia_fp32=s32["margin_ia"].numpy().astype(np.float32), sigma_bf16emu=np.float64(sigma),
+        margin_ia_fp32=s32["margin_ia"].numpy().astype(np.float32), sigma_bf16emu=np.float64(sigma), sigma_ia_bf16emu=np.float64(sigma_ia),
         emb_head_fp32=e32[:64].numpy(), emb_head_bf16emu=eem[:64].numpy())
     print("wrote", args.out, os.path.getsize(args.out), "bytes")
 

@@ -31,10 +31,48 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def test_recall_at_k_matches_the_oracle_on_5000_utterances(golden):
+@pytest.fixture(scope="module")
+def hip_emb():
+    """the product model's embeddings of the 5000 utterances (one pass, shared by the two galleries)"""
+    import recall_eval
+    model = recall_eval.build_model()
+    return model, recall_eval.hip_embeddings(model, 1000, recall_eval.BATCH)
+
+
+def test_recall_on_natural_margins(golden, hip_emb):
+    """Round 4: the same utterances against a gallery with NATURAL margins - class centre +
+    isotropic noise, nothing planted, fp32 recall@1 = 50.02 %, 14.8 % of the rank-1 decisions within 3 sigma of the margin noise that
+    bf16 STORAGE alone causes (the bf16-emulated oracle flips 79 / 66 / 61 of the 5000 rank-1 / 5 / 10 decisions against fp32).  On such
+    a set no bf16 implementation can match recall@1 to 0.1; what is required instead:
+      * every decision the HIP model takes differently from the fp32 oracle sits at an fp32 margin below 4 sigma of the emulation's
+        margin noise (the emulation's own flips reach 2.1 sigma) - a flip at a resolvable margin would be a defect;
+      * the HIP model flips no more decisions against the emulated oracle than the emulated oracle flips against fp32, x 1.25
+        (+ 3 for the small image -> audio counts);
+      * the recalls themselves stay within the band those flip counts allow."""
+    import recall_eval
+    model, emb = hip_emb
+    fx = golden("recall_eval_natural.npz")
+    r = recall_eval.natural_margin_report(emb, fx)
+    print("natural-margin recall:", r)
+    assert r["queries"] == 5000 and r["images"] == 1000
+    for d in ("audio_to_image", "image_to_audio"):
+        assert max(r["largest_fp32_margin_of_a_flip_in_sigma"][d]) < 4.0, r["largest_fp32_margin_of_a_flip_in_sigma"]
+        for k in range(3):
+            emu = r["emulation_flips_vs_fp32"][d][k]
+            mine = r["oracle_bf16emu"]["rank_flips_" + d][k]
+            assert mine <= max(1.25 * emu, emu + 3), (d, k, mine, emu)
+            assert r["oracle_fp32"]["rank_flips_" + d][k] <= max(1.25 * emu, emu + 3), (d, k, r["oracle_fp32"], emu)
+    n = {"audio_to_image": 5000, "image_to_audio": 1000}
+    for d in ("audio_to_image", "image_to_audio"):
+        for k in range(3):
+            band = 100.0 * r["oracle_fp32"]["rank_flips_" + d][k] / n[d]
+            assert abs(r["hip"][d][k] - r["oracle_fp32"][d][k]) <= band + 1e-9
+
+
+def test_recall_at_k_matches_the_oracle_on_5000_utterances(golden, hip_emb):
     import recall_eval
     fx = golden("recall_eval.npz")
-    r = recall_eval.hip_recall(recall_eval.build_model(), fx)
+    r = recall_eval.hip_recall(hip_emb[0], fx, emb=hip_emb[1])
     print("recall parity:", r)
     assert r["queries"] == 5000 and r["images"] == 1000 and r["batch"] == recall_eval.BATCH
     hip = r["hip"]

@@ -234,3 +234,21 @@ def test_bench_host_helpers():
     assert ragged["alg_gflop_per_utt"] < 0.55 * full["alg_gflop_per_utt"]      # shorter utterances count less than linearly (attention ~ T^2)
     same = bench.forward_summary(12.0, 64, 160000, 499, lens=[160000] * 64)
     assert abs(same["alg_gflop_per_utt"] - full["alg_gflop_per_utt"]) < 1e-6
+
+
+def test_natural_margin_recall_fixture_is_consistent():
+    """tests/golden/recall_eval_natural.npz (make_recall_natural_fixture.py): the stored ranks give the recalls of its summary, the
+    gallery is unit-norm and orthogonal to nothing planted (role-free), and the report code reproduces the emulation's own flip counts
+    when it is fed the fixture's references."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import recall_eval
+    fx = dict(np.load(recall_eval.FIXTURE_NATURAL))
+    summ = json.load(open(os.path.join(ROOT, "tests", "golden", "recall_eval_natural_margins.json")))
+    r32, rem = torch.from_numpy(fx["rank_ai_fp32"]).long(), torch.from_numpy(fx["rank_ai_bf16emu"]).long()
+    assert recall_eval.recalls(r32) == summ["fp32"]["audio_to_image"] and recall_eval.recalls(rem) == summ["bf16emu"]["audio_to_image"]
+    assert 45.0 < summ["fp32"]["audio_to_image"][0] < 55.0                       # natural margins: recall@1 tuned to ~50 %
+    assert [int(((r32 < k) != (rem < k)).sum()) for k in (1, 5, 10)] == summ["bf16emu"]["rank_flips_vs_fp32_audio_to_image"]
+    img = torch.from_numpy(fx["image"])
+    assert torch.allclose(img.norm(dim=-1), torch.ones(1000), atol=1e-5)
+    assert max(summ["largest_fp32_margin_of_an_emulation_flip_in_sigma"]) < 4.0 and summ["fraction_of_queries_within_3_sigma_at_1_5_10"][0] > 0.05

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 FIXTURE = os.path.join(ROOT, "tests", "golden", "recall_eval.npz")
+FIXTURE_NATURAL = os.path.join(ROOT, "tests", "golden", "recall_eval_natural.npz")    # the same utterances against a gallery with natural margins
 SEED_W, SEED_HEAD, SEED_DATA = 7122, 7123, 20261
 PER_ID = 5
 GALLERY = 3      # captions 0..2 of every id build its image; captions 3, 4 are held out of the construction
@@ -254,7 +255,52 @@ def embed_all(encode, wavs, dim: int, batch: int = BATCH) -> torch.Tensor:
     return emb
 
 
-def hip_recall(model, fixture: dict, dump: str = None) -> dict:
+def hip_embeddings(model, n_ids: int, batch: int = BATCH) -> torch.Tensor:
+    """the product model's [5 n_ids, E] embeddings of the eval set (length-sorted batches of ``batch``: part of the protocol)"""
+    dev = next(model.parameters()).device
+    wavs, _ = eval_set(n_ids)
+    with torch.no_grad():
+        return embed_all(lambda ws: model.encode_speech([w.to(dev) for w in ws])["parallel_audio_feat"], wavs,
+                         model.parallel_branch.linear_proj.out_features if hasattr(model.parallel_branch, "linear_proj") else 512, batch)
+
+
+def natural_margin_report(emb: torch.Tensor, fixture: dict) -> dict:
+    """The HIP embeddings on the NATURAL-margin gallery (tests/golden/recall_eval_natural.npz: class centre + isotropic noise, nothing
+    planted, fp32 recall@1 = 50 %): recalls, rank flips against both references and - per boundary k and direction - the largest fp32
+    margin among the decisions the HIP model takes differently from the fp32 oracle, in units of the bf16-emulation's margin noise."""
+    import numpy as np
+    T = lambda k: torch.from_numpy(np.asarray(fixture[k]))
+    n_ids = int(fixture["n_ids"])
+    image = T("image")
+    ids = torch.arange(n_ids).repeat_interleave(PER_ID)
+    held = (torch.arange(len(ids)) % PER_ID) >= GALLERY
+    st = rank_stats(F.normalize(emb, dim=-1), image, ids)
+    sig_ai, sig_ia = float(fixture["sigma_bf16emu"]), float(fixture["sigma_ia_bf16emu"])
+    out = {"queries": len(ids), "images": n_ids, "recall_at": [1, 5, 10], "noise_level": float(fixture["noise_level"]),
+           "hip": {"audio_to_image": recalls(st["rank_ai"]), "audio_to_image_heldout": recalls(st["rank_ai"], held),
+                   "image_to_audio": recalls(st["rank_ia"])},
+           "emulation_margin_noise_sigma": {"audio_to_image": sig_ai, "image_to_audio": sig_ia}}
+    for ref in ("fp32", "bf16emu"):
+        r_ai, r_ia = T(f"rank_ai_{ref}").long(), T(f"rank_ia_{ref}").long()
+        out["oracle_" + ref] = {"audio_to_image": recalls(r_ai), "audio_to_image_heldout": recalls(r_ai, held), "image_to_audio": recalls(r_ia),
+                                "rank_flips_audio_to_image": [int(((st["rank_ai"] < k) != (r_ai < k)).sum()) for k in (1, 5, 10)],
+                                "rank_flips_image_to_audio": [int(((st["rank_ia"] < k) != (r_ia < k)).sum()) for k in (1, 5, 10)]}
+    out["emulation_flips_vs_fp32"] = {
+        "audio_to_image": [int(((T("rank_ai_bf16emu").long() < k) != (T("rank_ai_fp32").long() < k)).sum()) for k in (1, 5, 10)],
+        "image_to_audio": [int(((T("rank_ia_bf16emu").long() < k) != (T("rank_ia_fp32").long() < k)).sum()) for k in (1, 5, 10)]}
+    worst = {}
+    for name, rank, ref, margin, sig in (("audio_to_image", st["rank_ai"], T("rank_ai_fp32").long(), T("margin_ai_fp32"), sig_ai),
+                                         ("image_to_audio", st["rank_ia"], T("rank_ia_fp32").long(), T("margin_ia_fp32"), sig_ia)):
+        w = []
+        for i, k in enumerate((1, 5, 10)):
+            flip = (rank < k) != (ref < k)
+            w.append(round(float(margin[:, i].abs()[flip].max() / sig), 3) if flip.any() else 0.0)
+        worst[name] = w
+    out["largest_fp32_margin_of_a_flip_in_sigma"] = worst
+    return out
+
+
+def hip_recall(model, fixture: dict, dump: str = None, emb: torch.Tensor = None) -> dict:
     """Embeds the 5000 utterances with ``model`` (the product, on the GPU) and compares recall@{1,5,10}, both directions, all
     queries and the 2000 held-out ones, with BOTH references held by the fixture: the fp32 oracle and the bf16-storage-emulated
     oracle (oracle.bf16_store / bf16_weights: the control that separates storage precision from kernel defects)."""
@@ -263,10 +309,9 @@ def hip_recall(model, fixture: dict, dump: str = None) -> dict:
     n_ids = int(fixture["n_ids"])
     image = torch.from_numpy(np.asarray(fixture["image"]))
     dev = next(model.parameters()).device
-    wavs, ids = eval_set(n_ids)
-    with torch.no_grad():
-        emb = embed_all(lambda ws: model.encode_speech([w.to(dev) for w in ws])["parallel_audio_feat"], wavs, image.shape[1],
-                        int(fixture["batch"]))
+    ids = torch.arange(n_ids).repeat_interleave(PER_ID)
+    if emb is None:
+        emb = hip_embeddings(model, n_ids, int(fixture["batch"]))
     if dump:
         np.save(dump, emb.numpy())
     a = F.normalize(emb, dim=-1)
