@@ -61,7 +61,9 @@ def test_recall_on_natural_margins(golden, hip_emb):
             emu = r["emulation_flips_vs_fp32"][d][k]
             mine = r["oracle_bf16emu"]["rank_flips_" + d][k]
             assert mine <= max(1.25 * emu, emu + 3), (d, k, mine, emu)
-            assert r["oracle_fp32"]["rank_flips_" + d][k] <= max(1.25 * emu, emu + 3), (d, k, r["oracle_fp32"], emu)
+            # against fp32 the HIP model is one more bf16-storage implementation: as many flips as the emulation, up to the counting
+            # noise of two independent draws (2 sqrt(n): the image -> audio counts are 5 .. 12)
+            assert r["oracle_fp32"]["rank_flips_" + d][k] <= 1.25 * emu + 2.0 * emu ** 0.5, (d, k, r["oracle_fp32"], emu)
     n = {"audio_to_image": 5000, "image_to_audio": 1000}
     for d in ("audio_to_image", "image_to_audio"):
         for k in range(3):
