@@ -164,8 +164,9 @@ int sc_attn_fwd_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const i
 
 /* The same over ragged rows (sc_segments): q / k rows of utterance b at row0[b] + t, vt = per utterance [H, 64, Rb] at element offset
  * D * row0[b] (what sc_gemm_bf16 writes with seg_chunk), out rows likewise; lse2 [H][rows].  One workgroup = 128 queries of one
- * (utterance, head); in a last, shorter block the waves (32 queries each) past the pitch idle and the rows past it are not stored.  work (optional, device [nwork] int32):
- * the (utterance | q-block << 16) pairs to run, in launch order - the host sorts them longest first (an utterance's cost grows with
+ * (utterance, head); in a last, shorter block the waves (32 queries each) past the pitch idle and the rows past it are not stored.  work (optional, device
+ * [nwork][4] int32, 16-byte aligned): the 128-query blocks to run, in launch order, one item = (utterance | q-block << 16, row0 of the
+ * utterance, its pitch, its key count or -1 = read valid_len) - the host sorts them longest first (an utterance's cost grows with
  * its key count); NULL = every (b, q-block < max_pitch / 128), blocks past an utterance's pitch exit.  Dropout element index:
  * ((h * rows + row0[b] + q) * max_pitch + k).  Bit-identical to the uniform call on the rows they share. */
 int sc_attn_fwd_seg_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len, sc_bf16* out, int64_t ldo,

@@ -39,20 +39,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     }
     // uniform rows: utterance b at row b R.  Ragged rows (row0 != NULL, sc_segments): utterance b at row0[b] with its own pitch; the
     // (utterance, q-block) pairs come from the host's work list (longest first) or, without one, from the (B x max q-blocks) rectangle
-    int qblk, h, b, r0;
+    int qblk, h, b, r0, n_valid_item = -1;
     if (row0) {
         const int pair = logical % npairs;
         h = logical / npairs;
         if (work) {
-            const int code = work[pair];
-            b = code & 0xffff;
-            qblk = code >> 16;
+            // one 16-byte item = (utterance | q-block << 16, first row, pitch, key count or -1): everything the workgroup needs to
+            // form its addresses after ONE load (three dependent loads - item, row0[b], row0[b + 1] - cost 5 us per launch)
+            const int4 it = *(const int4*)(work + 4 * pair);
+            b = it.x & 0xffff;
+            qblk = it.x >> 16;
+            r0 = it.y;
+            R = it.z;
+            n_valid_item = it.w;
         } else {
             b = pair / nqb;
             qblk = pair % nqb;
+            r0 = row0[b];
+            R = row0[b + 1] - r0;                                    // this utterance's pitch (a multiple of 8)
         }
-        r0 = row0[b];
-        R = row0[b + 1] - r0;                                        // this utterance's pitch (a multiple of 8)
         if (qblk * 128 >= R) return;                                 // uniform for the workgroup, before any barrier
     } else {
         qblk = logical % nqb;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     // inside the wave that straddles the pitch the lanes past it compute on the next utterance's rows and skip their store
     const bool wave_on = qblk * 128 + wave * 32 < R;
     const int q0 = wave_on ? qblk * 128 + wave * 32 : 0;
-    int n_valid = valid_len[b];
+    int n_valid = n_valid_item >= 0 ? n_valid_item : valid_len[b];
     n_valid = max(1, min(n_valid, R));
 
     // Q fragments (B operand): Q[q0 + l31][ks*16 + 8*half + j]
@@ -293,6 +298,7 @@ extern "C" int sc_attn_fwd_seg_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf
                                     const sc_segments* seg, const int32_t* work, int32_t nwork, int32_t H, int32_t D, float scale,
                                     float* lse2, int32_t causal, float drop_p, uint32_t drop_seed, void* stream) {
     SC_CHECK(qk && vt && valid_len && out && seg && seg->row0, "sc_attn_fwd_seg_bf16: null pointer");
+    SC_CHECK(!work || ((uintptr_t)work % 16) == 0, "sc_attn_fwd_seg_bf16: the work list must be 16-byte aligned");
     SC_CHECK(seg->B > 0 && seg->B < 65536 && H > 0 && seg->rows > 0 && seg->max_pitch > 0 && seg->max_pitch % SC_SEG_ROWS == 0 && (!work || nwork > 0),
              "sc_attn_fwd_seg_bf16: B=%d rows=%d max_pitch=%d", seg->B, seg->rows, seg->max_pitch);
     SC_CHECK(D == H * 64, "sc_attn_fwd_seg_bf16: head_dim must be 64 (D=%d, H=%d)", D, H);

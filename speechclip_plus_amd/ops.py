@@ -38,8 +38,8 @@ class RowSegments:
 
     GRAN = 8             # SC_SEG_ROWS: pitches are multiples of this; one chunk-table entry per GRAN rows
 
-    def __init__(self, pitch, keys, device, storage: Optional[torch.Tensor] = None):
-        host, self.row0_host, self.n_work = self.host_tables(pitch, keys)
+    def __init__(self, pitch, keys, device, storage: Optional[torch.Tensor] = None, keys_known: bool = True):
+        host, self.row0_host, self.n_work = self.host_tables(pitch, keys, keys_known)
         self.pitch = [int(p) for p in pitch]
         self.B, self.rows, self.max_pitch = len(self.pitch), self.row0_host[-1], max(self.pitch)
         n = host.numel()
@@ -50,9 +50,9 @@ class RowSegments:
         else:
             dev = host.pin_memory().to(device, non_blocking=True)
         nch = self.rows // self.GRAN
-        self.chunk = dev[: 4 * nch]                              # first: the 16-byte entries stay 16-byte aligned
-        self.row0 = dev[4 * nch: 4 * nch + self.B + 1]
-        self.work = dev[4 * nch + self.B + 1:]
+        self.chunk = dev[: 4 * nch]                              # 16-byte entries first: they stay 16-byte aligned
+        self.work = dev[4 * nch: 4 * nch + 4 * self.n_work]
+        self.row0 = dev[4 * nch + 4 * self.n_work:]
         self._dev = dev
         self.c = Segments()
         self.c.row0, self.c.chunk = _p(self.row0), _p(self.chunk)
@@ -61,13 +61,14 @@ class RowSegments:
     @classmethod
     def table_ints(cls, B: int, max_rows: int) -> int:
         """upper bound of the table size in int32 (storage for a plan: B utterances, at most ``max_rows`` rows)"""
-        return 4 * (max_rows // cls.GRAN) + B + 1 + B * ((max_rows + 127) // 128 + 1)
+        return 4 * (max_rows // cls.GRAN) + B + 1 + 4 * B * ((max_rows + 127) // 128 + 1)
 
     @classmethod
-    def host_tables(cls, pitch, keys):
-        """-> (int32 tensor [chunk table | row0 | attention work list], row0 as a python list, number of work items).
-        chunk[c] = (first row, pitch, utterance, 0) of the utterance that owns rows 8 c .. 8 c + 7; work = (utterance | q-block << 16)
-        for every 128-query block, longest utterance first (its workgroups run longest: start them first)."""
+    def host_tables(cls, pitch, keys, keys_known: bool = True):
+        """-> (int32 tensor [chunk table | attention work list | row0], row0 as a python list, number of work items).
+        chunk[c] = (first row, pitch, utterance, 0) of the utterance that owns rows 8 c .. 8 c + 7; work = one int4 item per
+        128-query block, (utterance | q-block << 16, first row, pitch, key count or -1), longest utterance first (its workgroups run
+        longest: start them first).  ``keys_known`` False: the key counts only order the list (the kernel reads valid_len)."""
         import numpy as np
         B, G = len(pitch), cls.GRAN
         p = np.asarray([int(x) for x in pitch], dtype=np.int64)
@@ -76,8 +77,9 @@ class RowSegments:
         per = np.stack([row0[:-1], p, np.arange(B), np.zeros(B, dtype=np.int64)], axis=1)         # one entry per utterance
         chunk = np.repeat(per, p // G, axis=0).reshape(-1)
         order = sorted(range(B), key=lambda b: (-int(keys[b]), b))
-        work = [b | (qb << 16) for b in order for qb in range((int(p[b]) + 127) // 128)]
-        tab = np.concatenate([chunk, row0, np.asarray(work, dtype=np.int64)]).astype(np.int32)
+        work = [(b | (qb << 16), int(row0[b]), int(p[b]), int(keys[b]) if keys_known else -1)
+                for b in order for qb in range((int(p[b]) + 127) // 128)]
+        tab = np.concatenate([chunk, np.asarray(work, dtype=np.int64).reshape(-1), row0]).astype(np.int32)
         return torch.from_numpy(tab), [int(x) for x in row0], len(work)
 
     def ref(self):

@@ -199,7 +199,7 @@ class _Plan:
             self.wav_pad = z(self.spr * M + 64, dtype=torch.float32)           # ONE flat waveform, utterance b at sample 320 row0[b]
             self.xg = z(G * (M + 2 * halo * B) * (D // G))                     # flat slab buffer (sc_posconv_prep_seg)
             self.vt = z(D * (M + S))
-            self.tables = torch.zeros(ops.RowSegments.table_ints(B, self.R * B), device=dev, dtype=torch.int32)
+            self._seg_cache = (None, None)
         else:
             self.wav_pad = z(B, self.ldw, dtype=torch.float32)
             self.xg = z(G, B, self.R + 2 * halo, D // G)
@@ -223,6 +223,14 @@ class _Plan:
         self.generation = 0          # forwards run on this plan (weighted_sum.PaddedFeatHandle.check_fresh)
         self.seg = None
         self.bind(None)
+
+    def segments(self, pitch, keys, device, keys_known: bool = True):
+        """ops.RowSegments of a batch; the tables of the previous batch are re-used when the layout and the work order are the same
+        (read-only on the device: a fresh upload per change, never an overwrite of tables a kernel in flight may read)"""
+        key = (tuple(pitch), tuple(keys), keys_known)
+        if self._seg_cache[0] != key:
+            self._seg_cache = (key, ops.RowSegments(pitch, keys, device, keys_known=keys_known))
+        return self._seg_cache[1]
 
     def bind(self, seg) -> None:
         """Lay the current batch out: ``seg`` = its ops.RowSegments (seg_mode) or None = the uniform B x R rows."""
@@ -433,7 +441,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             feat_d = torch.clamp(torch.round(l64.double() / self.downsample_rate).long(), max=T)       # torch.round: half to even
             if pl.seg_mode:
                 need, pitch = self.segment_pitches(T, [T] * B, [T] * B, False)
-                pl.bind(ops.RowSegments(pitch, [T] * B, self._dev, storage=pl.tables))
+                pl.bind(pl.segments(pitch, [T] * B, self._dev, keys_known=False))
                 pl.need = need
                 R, M = pl.R, pl.M
                 pl.alg_rows_l = [B * t for t in pl.T_l]
@@ -445,10 +453,10 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             valid = [min(T, -(-int(l) // chunk)) for l in wav_len]
             feat_len = [min(round(int(l) / self.downsample_rate), T) for l in wav_len]
             if pl.seg_mode:
-                # the row layout of THIS batch: pitches from the lengths, tables into the plan's resident int32 storage (same stream, so
-                # the previous forward's kernels are done with them)
+                # the row layout of THIS batch: pitches from the lengths, tables uploaded with the batch's other integers (a batch with
+                # the layout of the previous one - every equal-length batch - re-uses its tables: _Plan.segments)
                 need, pitch = self.segment_pitches(T, valid, feat_len, self.ragged if ragged is None else ragged)
-                pl.bind(ops.RowSegments(pitch, valid, self._dev, storage=pl.tables))
+                pl.bind(pl.segments(pitch, valid, self._dev))
                 pl.need = need
                 R, M = pl.R, pl.M
                 # algorithmic work of this batch: every utterance at its OWN length (padding is not work)

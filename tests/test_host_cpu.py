@@ -102,9 +102,10 @@ def test_segment_geometry():
     tab, row0, nwork = RowSegments.host_tables([16, 8, 160], [13, 2, 140])
     assert row0 == [0, 16, 24, 184] and nwork == 1 + 1 + 2
     t = tab.tolist()
-    chunk, r0, work = t[: 4 * 23], t[92: 96], t[96:]
+    chunk, work, r0 = t[: 4 * 23], t[92: 92 + 16], t[108:]
     assert chunk[:8] == [0, 16, 0, 0, 0, 16, 0, 0] and chunk[8:12] == [16, 8, 1, 0] and chunk[12:16] == [24, 160, 2, 0] and chunk[-4:] == [24, 160, 2, 0]
-    assert r0 == row0 and work == [2, 2 | (1 << 16), 0, 1]
+    assert r0 == row0 and work == [2, 24, 160, 140, 2 | (1 << 16), 24, 160, 140, 0, 0, 16, 13, 1, 16, 8, 2]
+    assert RowSegments.host_tables([16, 8], [9, 9], keys_known=False)[0].tolist()[12:20] == [0, 0, 16, -1, 1, 16, 8, -1]
     assert RowSegments.table_ints(3, 512 * 3) >= len(t)
 
 

@@ -8,7 +8,7 @@ from speechclip_plus_amd import ops
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-B, R, D, F, C = 64, 512, 768, 3072, 512
+B, R, D, F, C = 64, int(os.environ.get("SC_BENCH_R", "512")), 768, 3072, 512
 M = B * R
 shapes = [  # name, M, N, K, lda(None = K), act, residual
     ("qkv", M, 3 * D, D, None, 0, False), ("oproj", M, D, D, None, 0, True), ("fc1", M, F, D, None, 1, False),

@@ -9,3 +9,5 @@ rm -rf /tmp/p_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$tag -o st -- python3 bench.py --steps 10 --warmup 2 --cpu-utts 0 --no-recall --no-kernel-timer "$@" > $out/${tag}_run.json 2> /tmp/p_$tag.err
 cp "$(find /tmp/p_$tag -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats.csv
 python3 $root/tools/trace_top.py $out/${tag}_kernel_stats.csv 1 45 | cut -c1-190
+python3 $root/tools/step_timeline.py "$(find /tmp/p_$tag -name '*kernel_trace.csv' | head -1)" 1 > $out/${tag}_timeline.txt 2>&1 || true
+head -3 $out/${tag}_timeline.txt
