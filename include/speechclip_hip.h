@@ -30,6 +30,9 @@ typedef uint16_t sc_bf16;
 
 const char* sc_last_error(void);
 int sc_abi_version(void);     /* 4 since round 4 (sc_segments; sc_gemm_args / sc_hubert_layer_args grew the segment fields) */
+int sc_is_diag_build(void);   /* 1: libspeechclip_hip_diag.so - the same sources built with SC_DIAG_BUILD: also holds the diagnostic kernels
+                                 (sc_gemm_args.tile 32 = timing only, RESULTS WRONG; 34 = stamped) and the LayerNorm-folded GEMMs; the
+                                 product library refuses both */
 int64_t sc_sizeof(int32_t what);   /* sizeof of 0 sc_gemm_args, 1 sc_hubert_layer_args, 2 sc_rt_gemm_args, 3 sc_rt_ln_args, 4 sc_rt_ln_bwd_args, 5 sc_segments */
 /* tuning switches for same-process A/B measurements (tools/); results never depend on them.  key 1: the 256-row GEMM uses
  * plain instead of non-temporal stores on tiles with a residual. */
@@ -87,7 +90,8 @@ typedef struct {
     int64_t sA1, sA2, sW1, sW2, sC1, sC2, sBias1, sBias2, sR1, sR2;
     int32_t tile;                 /* 0 auto | 1: 128x128 (4 waves) | 2: 256-row tile, 8 waves, width 256 or 192 by wave quantisation
                                      (7 / 8 force 192 / 256) | 3: 128x64.  Every tile family accumulates k in the same order and
-                                     shares the epilogue arithmetic: results do not depend on the choice */
+                                     shares the epilogue arithmetic: results do not depend on the choice.  (32 / 34: diagnostic
+                                     kernels of libspeechclip_hip_diag.so only; the product library returns an error) */
     int32_t reserved;             /* store policy of the bf16 C tile (256-row kernels): 0 auto = non-temporal stores when a residual
                                      is given (the output is the next residual stream, not re-read by this kernel; measured
                                      -3.5 % GEMM time per step), 1 always non-temporal, 2 never */

@@ -105,6 +105,7 @@ class HubertLayerArgs(ctypes.Structure):
 # library exports every symbol the header declares.
 SIGNATURES = {
     "sc_abi_version": [],
+    "sc_is_diag_build": [],
     "sc_set_option": [c_int, c_int],
     "sc_hubert_layer_fwd": [ctypes.POINTER(HubertLayerArgs), c_void_p],
     "sc_gemm_bf16": [ctypes.POINTER(GemmArgs), c_void_p],
@@ -213,17 +214,38 @@ SIGNATURES = {
     "sc_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p, c_int, c_float, c_void_p],
 }
 
+DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libspeechclip_hip_diag.so")
 _LIB = None
+_DIAG = None
 
 
 def lib() -> ctypes.CDLL:
+    """The product library."""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
+        _LIB = _load(LIB_PATH)
+    return _LIB
+
+
+def diag_lib() -> ctypes.CDLL:
+    """libspeechclip_hip_diag.so: the same ABI built with SC_DIAG_BUILD - additionally the timing-only / stamped kernels (GEMM tile ids
+    32 / 34, the attention section stamps) and the opt-in LayerNorm-folded GEMMs.  Loaded by tools/, bench.py's in-kernel clock probe
+    and the SC_FUSED_LN experiment; the product path (lib()) cannot reach those kernels."""
+    global _DIAG
+    if _DIAG is None:
+        _DIAG = _load(DIAG_LIB_PATH)
+        if _DIAG.sc_is_diag_build() != 1:
+            raise RuntimeError(f"{DIAG_LIB_PATH} is not a diagnostics build")
+    return _DIAG
+
+
+def _load(path: str) -> ctypes.CDLL:
+    if True:
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} not found: the HIP extension is not built (python -m speechclip_plus_amd.build). "
+                f"{path} not found: the HIP extension is not built (python -m speechclip_plus_amd.build). "
                 "speechclip_plus_amd has no CPU / eager fallback.")
-        cdll = ctypes.CDLL(LIB_PATH)
+        cdll = ctypes.CDLL(path)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(cdll, name)            # AttributeError if the symbol is missing: loud
             fn.argtypes = argtypes
@@ -242,10 +264,9 @@ def lib() -> ctypes.CDLL:
                                    "(include/speechclip_hip.h and _lib.py are out of step, or a stale .so)")
         cdll.sc_hash32.argtypes = [ctypes.c_uint32]
         cdll.sc_hash32.restype = ctypes.c_uint32
-        _LIB = cdll
-    return _LIB
+        return cdll
 
 
-def check(rc: int, what: str = "") -> None:
+def check(rc: int, what: str = "", library=None) -> None:
     if rc != 0:
-        raise RuntimeError(f"libspeechclip_hip {what} failed ({rc}): {lib().sc_last_error().decode()}")
+        raise RuntimeError(f"libspeechclip_hip {what} failed ({rc}): {(library or lib()).sc_last_error().decode()}")

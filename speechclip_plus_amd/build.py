@@ -7,6 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(HERE, "..", "include"))
 LIB = os.path.join(CSRC, "libspeechclip_hip.so")
+DIAG_LIB = os.path.join(CSRC, "libspeechclip_hip_diag.so")    # same sources + -DSC_DIAG_BUILD: diagnostic kernels, LayerNorm-folded GEMMs
+DIAG_SOURCES = ["sc_error.cpp", "gemm256_bf16.hip", "attention.hip"]    # the files whose contents depend on SC_DIAG_BUILD
 SOURCES = ["sc_error.cpp", "hubert_layer.cpp", "gemm_bf16.hip", "gemm256_bf16.hip", "attention.hip", "attention_bwd.hip", "rowops.hip", "frontend.hip", "posconv.hip", "posconv_bwd.hip", "clspool.hip",
            "loss_optim.hip", "headtail.hip", "rowtail.hip", "backward.hip", "softmax.hip", "cif.hip", "vq.hip"]
 
@@ -18,32 +20,42 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, diag: bool = True) -> str:
+    """-> path of the product library.  ``diag``: also build libspeechclip_hip_diag.so (tools/, bench.py's in-kernel clock probe and
+    the opt-in SC_FUSED_LN path load it through _lib.diag_lib(); the product path never does)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))] + [os.path.join(INCLUDE, "speechclip_hip.h")]
-    objs = []
-    procs = []
+    # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has a unified register file); otherwise every VALU touch
+    # of an accumulator (softmax, epilogues) pays v_accvgpr_read/write moves
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-x", "hip", "-I", INCLUDE, "-I", CSRC]
+    objs, diag_objs, procs = [], [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        stem = os.path.splitext(src)[0]
+        obj = os.path.join(CSRC, stem + ".o")
         objs.append(obj)
-        if force or _stale(obj, [sp] + headers):
-            # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has a unified register file); otherwise every VALU touch
-            # of an accumulator (softmax, epilogues) pays v_accvgpr_read/write moves
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-x", "hip",
-                   "-I", INCLUDE, "-I", CSRC,
-                   "-c", sp, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd)))
+        variants = [(obj, [])]
+        if diag and src in DIAG_SOURCES:
+            dobj = os.path.join(CSRC, stem + "_diag.o")
+            diag_objs.append(dobj)
+            variants.append((dobj, ["-DSC_DIAG_BUILD=1"]))
+        elif diag:
+            diag_objs.append(obj)
+        for o, flags in variants:
+            if force or _stale(o, [sp] + headers):
+                cmd = base + flags + ["-c", sp, "-o", o]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                procs.append((src, subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    for lib, parts in ((LIB, objs),) + (((DIAG_LIB, diag_objs),) if diag else ()):
+        if force or _stale(lib, parts):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + parts
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return LIB
 
 

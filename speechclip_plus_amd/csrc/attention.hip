@@ -15,14 +15,20 @@ namespace {
 
 constexpr int KT = 64;   // keys per LDS tile
 
-template <int DROP>   // train-mode probability dropout as a compile-time variant: the eval kernel carries none of its registers
+// STAMP (diagnostics build only, sc_diag_attn_fwd_stamps): per wave, the shader-clock cycles spent between the landmarks of a key
+// tile, summed over the tiles -> stamps[wg / 32][wave][8]: 0 staging writes + barrier, 1 next-tile loads + S^T MFMAs issued, 2 softmax
+// of block 0 (waits for its S^T), 3 P.V of block 0 issued, 4 softmax of block 1, 5 P.V of block 1 issued, 6 closing barrier, 7 total.
+// s_memtime needs an s_waitcnt lgkmcnt(0), i.e. the LDS reads in flight at a landmark are drained there: the stamped kernel is slower
+// than the production one (tools/attn_stamps.py prints both) - the SPLIT between the sections is what it is for.
+template <int DROP, int STAMP = 0>   // DROP: train-mode probability dropout as a compile-time variant: the eval kernel carries none of its registers
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qk, int64_t ldqk,
                                                         const uint16_t* __restrict__ vt,
                                                         const int32_t* __restrict__ valid_len,
                                                         uint16_t* __restrict__ out, int64_t ldo, int R, int H, int D,
                                                         float c /* scale * log2(e) */, float* __restrict__ lse2, int causal,
                                                         float drop_p, uint32_t drop_seed, const int32_t* __restrict__ row0,
-                                                        const int32_t* __restrict__ work, int npairs, int rows_total, int max_pitch) {
+                                                        const int32_t* __restrict__ work, int npairs, int rows_total, int max_pitch,
+                                                        long long* __restrict__ stamps = nullptr) {
     __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
     __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
 
@@ -111,6 +117,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     // prefetch registers as named scalars: arrays indexed across the tile loop were being placed in scratch
     uint4 kreg0 = *(const uint4*)(kg[0]), kreg1 = *(const uint4*)(kg[1]);
     uint4 vreg0 = *(const uint4*)(vg[0]), vreg1 = *(const uint4*)(vg[1]);
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_first = 0;
+#define SC_ST(K)                                         \
+    do {                                                 \
+        if (STAMP) {                                     \
+            const long long now_ = clock64();            \
+            st_acc[K] += now_ - st_prev;                 \
+            st_prev = now_;                              \
+        }                                                \
+    } while (0)
+    if (STAMP) st_first = st_prev = clock64();
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
         // write the prefetched tile
@@ -121,6 +137,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         *(uint2*)(Vs + v_lds0[1]) = make_uint2(vreg1.x, vreg1.y);
         *(uint2*)(Vs + v_lds1[1]) = make_uint2(vreg1.z, vreg1.w);
         __syncthreads();
+        SC_ST(0);
         if (t + 1 < ntiles) {
             kreg0 = *(const uint4*)(kg[0] + (int64_t)(key0 + KT) * ldqk);
             kreg1 = *(const uint4*)(kg[1] + (int64_t)(key0 + KT) * ldqk);
@@ -236,15 +253,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
             }
         };
         bf16x8 pf0[2], pf1[2];
+        SC_ST(1);
         softmax_block(s0, key0, pf0);
+        SC_ST(2);
         pv_block(0, pf0);
+        SC_ST(3);
         if (blk1) {
             softmax_block(s1, key0 + 32, pf1);
+            SC_ST(4);
             pv_block(1, pf1);
+            SC_ST(5);
         }
         }
         __syncthreads();
+        SC_ST(6);
     }
+    if (STAMP && stamps && (blockIdx.x & 31) == 0 && lane == 0) {
+        st_acc[7] = clock64() - st_first;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) stamps[((blockIdx.x >> 5) * 4 + wave) * 8 + k] = st_acc[k];
+    }
+#undef SC_ST
     if (!wave_on) return;
 
     const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
@@ -319,3 +348,21 @@ extern "C" int sc_attn_fwd_seg_bf16(const sc_bf16* qk, int64_t ldqk, const sc_bf
     SC_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef SC_DIAG_BUILD
+// diagnostics library only (not declared in include/speechclip_hip.h): the uniform-pitch forward with per-section cycle stamps
+extern "C" int sc_diag_attn_fwd_stamps(const sc_bf16* qk, int64_t ldqk, const sc_bf16* vt, const int32_t* valid_len, sc_bf16* out, int64_t ldo,
+                                       int32_t B, int32_t R, int32_t H, int32_t D, float scale, float drop_p, uint32_t drop_seed,
+                                       long long* stamps /* [ceil(grid / 32)][4][8] */, void* stream) {
+    SC_CHECK(qk && vt && valid_len && out && stamps && D == H * 64 && R % 8 == 0, "sc_diag_attn_fwd_stamps: bad arguments");
+    dim3 grid(((R + 127) / 128) * H * B);
+    if (drop_p > 0.f)
+        hipLaunchKernelGGL((attn_fwd_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R, H, D,
+                           scale * 1.4426950408889634f, (float*)nullptr, 0, drop_p, drop_seed, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, 0, 0, stamps);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<0, 1>), grid, dim3(256), 0, (hipStream_t)stream, qk, ldqk, vt, valid_len, out, ldo, R, H, D,
+                           scale * 1.4426950408889634f, (float*)nullptr, 0, drop_p, drop_seed, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, 0, 0, stamps);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+#endif

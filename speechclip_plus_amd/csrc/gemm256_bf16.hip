@@ -432,18 +432,26 @@ static int launch256__(const sc_gemm_args& a, hipStream_t s) {
     return 0;
 }
 
+// SC_DIAG_BUILD (libspeechclip_hip_diag.so, speechclip_plus_amd/build.py): the build that ALSO holds the timing-only / stamped kernels
+// (DIAG 3 / 4: tile ids 32 / 34) and the opt-in LayerNorm-folded instantiations (LN 1 / 2; measured no faster).
+// The product library carries neither - 8 instead of 24 instantiations of this kernel - and sc_gemm_bf16 refuses the tile ids / LN
+// arguments with a message instead of running a kernel whose results are wrong by design (VERDICT r03 "weak" 9).
 template <int DIAG, int BN, int ACT, int DROP>
 static int launch256_(const sc_gemm_args& a, hipStream_t s) {
     if constexpr (DIAG == 0) {          // the residual epilogue is its own instantiation (its prefetch registers)
         if (a.residual) {
+#ifdef SC_DIAG_BUILD
             if constexpr (ACT == 0) {   // statistics producer: residual GEMMs without an activation (out_proj, fc2)
                 if (a.stats_out) return launch256__<DIAG, BN, ACT, DROP, 1, 2>(a, s);
             }
+#endif
             return launch256__<DIAG, BN, ACT, DROP, 1, 0>(a, s);
         }
+#ifdef SC_DIAG_BUILD
         if constexpr (DROP == 0) {      // LayerNorm-folded consumer (QKV, fc1): no dropout site there
             if (a.ln_stats) return launch256__<DIAG, BN, ACT, DROP, 0, 1>(a, s);
         }
+#endif
     }
     return launch256__<DIAG, BN, ACT, DROP, 0, 0>(a, s);
 }
@@ -483,8 +491,16 @@ int sc_gemm256_launch(const sc_gemm_args& a_in, hipStream_t s) {
     a.reserved = (a_in.reserved == 1 || (a_in.reserved == 0 && a_in.residual != nullptr)) ? 1 : 0;
     if (sc_option(1)) a.reserved = 0;      // A/B switch (tools/): plain stores everywhere
     if (a.tn) return launch256_<5, 256, 0, 0>(a, s);     // TN operands (weight gradients): checked by sc_gemm_bf16
+#ifdef SC_DIAG_BUILD
     if (a.tile == 32) return launch256<3, 256>(a, s);   // diagnostics only (tools/epi_probe.py, tools/epi_stamps.py)
     if (a.tile == 34) return launch256<4, 256>(a, s);
+#else
+    if (a.tile == 32 || a.tile == 34 || a.ln_stats || a.stats_out || a.res_stats) {
+        sc_set_error("sc_gemm_bf16: tile ids 32 / 34 (timing-only / stamped kernels) and the LayerNorm-folded GEMMs are built into "
+                     "libspeechclip_hip_diag.so only (speechclip_plus_amd/build.py; _lib.diag_lib())");
+        return -1;
+    }
+#endif
     if (a.tile == 7) return launch256<0, 192>(a, s);
     if (a.tile == 8) return launch256<0, 256>(a, s);
     if (sc_gemm256_bn(a) == 192) return launch256<0, 192>(a, s);

@@ -40,6 +40,14 @@ extern "C" uint32_t sc_hash32(uint32_t x) {
 
 extern "C" const char* sc_last_error(void) { return g_err; }
 extern "C" int sc_abi_version(void) { return 4; }
+// 1 = the diagnostics build (timing-only / stamped kernels + the LayerNorm-folded GEMMs), 0 = the product library
+extern "C" int sc_is_diag_build(void) {
+#ifdef SC_DIAG_BUILD
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 // sizeof of the argument structs, for bindings that mirror them by hand (ctypes): a layout mismatch is caught before the first call
 extern "C" int64_t sc_sizeof(int32_t what) {

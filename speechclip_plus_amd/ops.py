@@ -8,7 +8,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import RtGemmArgs, RtLnArgs, RtLnBwdArgs, GemmArgs, HubertLayerArgs, Segments, check, lib
+from ._lib import RtGemmArgs, RtLnArgs, RtLnBwdArgs, GemmArgs, HubertLayerArgs, Segments, check, diag_lib, lib
 
 
 def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
@@ -184,13 +184,15 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
         a.stats_out, a.ln_eps = _p(stats_out), float(ln_eps)
         if stats_out is not None:
             assert stats_out.numel() >= M * 16
-            strips = int(lib().sc_gemm_stats_strips(ctypes.byref(a)))
+            strips = int(diag_lib().sc_gemm_stats_strips(ctypes.byref(a)))
+    # diagnostic tile ids and the opt-in LayerNorm-folded GEMMs exist in the diagnostics library only (the product library refuses them)
+    L = diag_lib() if (tile in (32, 34) or ln_stats is not None or stats_out is not None) else lib()
     if _timer is None:
-        check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
+        check(L.sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16", L)
         return strips
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
-    check(lib().sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16")
+    check(L.sc_gemm_bf16(ctypes.byref(a), _stream()), "sc_gemm_bf16", L)
     ev1.record()
     rows = (M if alg_rows is None else alg_rows) * nb1 * nb2
     _timer.add("gemm_bf16_" + gemm_tile_name(M, N, K, n_split, nb1 * nb2, 2 if (tile == 0 and strips + ln_ns > 0) else tile), ev0, ev1,
@@ -226,14 +228,15 @@ def hubert_layer_fwd(x: torch.Tensor, out: torch.Tensor, valid_len: torch.Tensor
             a.x_stats, a.x_ns = _p(x_stats), int(x_ns)
             a.x_ln_g, a.x_ln_b = _p(w[f"l{i - 1}_ln2_g"]), _p(w[f"l{i - 1}_ln2_b"])
             a.qkv_w, a.qkv_b, a.qkv_colsum = _p(w[f"l{i}_qkv_wf"]), _p(w[f"l{i}_qkv_cf"]), _p(w[f"l{i}_qkv_sf"])
-    check(lib().sc_hubert_layer_fwd(ctypes.byref(a), _stream()), "sc_hubert_layer_fwd")
+    L = diag_lib() if fused is not None else lib()       # the LayerNorm-free form runs on the diagnostics library's GEMMs (opt-in)
+    check(L.sc_hubert_layer_fwd(ctypes.byref(a), _stream()), "sc_hubert_layer_fwd", L)
 
 
 def gemm_stats_strips(M: int, N: int) -> int:
     """Row-statistics strips a producer GEMM [M, N] writes (one per N-tile of the width the dispatcher picks)."""
     a = GemmArgs()
     a.M, a.N, a.K, a.n_split, a.nb1, a.nb2 = int(M), int(N), 64, -1, 1, 1
-    return int(lib().sc_gemm_stats_strips(ctypes.byref(a)))
+    return int(diag_lib().sc_gemm_stats_strips(ctypes.byref(a)))
 
 
 def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,

