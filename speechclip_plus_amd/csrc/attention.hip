@@ -15,6 +15,22 @@ namespace {
 
 constexpr int KT = 64;   // keys per LDS tile
 
+// XOR swizzle of the V^T tile image ([64 d rows][64 keys] bf16, 128-byte rows, 8-byte units): unit u of row r lives at unit u ^ vsw(r).
+//   (r >> 1) & 15 : the 32 rows a ds_read_b64 lane group touches cover all 64 banks once (rows 2j / 2j + 1 sit in the two 128-byte halves
+//                   of the 256-byte bank row);
+//   ^ (r & 1)     : the staging stores are ds_write_b64 - 16 contiguous lanes = rows r, r + 1, banks mod 32: without this bit both rows
+//                   wrote the same banks (2-way);
+//   ^ (r >> 5)    : round 4 - rows r and r + 32 used to sit exactly 4096 bytes apart, so the compiler fused the two fragment reads of a
+//                   step into ds_read2st64_b64: 16-lane groups on 32 banks = half the rate of ds_read_b64 AND 2-way conflicts
+//                   (rocprofv3: SQ_LDS_BANK_CONFLICT = 38 % of SQ_LDS_IDX_ACTIVE, profiles/r04_attn_pmc.json); with this bit the
+//                   distance depends on the lane and the reads stay ds_read_b64.
+// (sc_common.h: sc_tr_swizzle - shared with the backward kernels' transposed tiles)
+#ifdef SC_AB_OLD_VSW
+__device__ __forceinline__ int vsw(int row) { return (row >> 1) & 15; }
+#else
+__device__ __forceinline__ int vsw(int row) { return sc_tr_swizzle(row); }
+#endif
+
 // STAMP (diagnostics build only, sc_diag_attn_fwd_stamps): per wave, the shader-clock cycles spent between the landmarks of a key
 // tile, summed over the tiles -> stamps[wg / 32][wave][8]: 0 staging writes + barrier, 1 next-tile loads + S^T MFMAs issued, 2 softmax
 // of block 0 (waits for its S^T), 3 P.V of block 0 issued, 4 softmax of block 1, 5 P.V of block 1 issued, 6 closing barrier, 7 total.
@@ -97,8 +113,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         kg[i] = qk + ((int64_t)r0 + row) * ldqk + D + h * 64 + ch * 8;
         vg[i] = vt + (int64_t)D * r0 + (int64_t)(h * 64 + row) * R + ch * 8;      // V^T of the utterance: [H, 64, pitch] at D * r0
         k_lds[i] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
-        v_lds0[i] = row * 128 + (((2 * ch) ^ ((row >> 1) & 15)) << 3);
-        v_lds1[i] = row * 128 + (((2 * ch + 1) ^ ((row >> 1) & 15)) << 3);
+        v_lds0[i] = row * 128 + (((2 * ch) ^ vsw(row)) << 3);
+        v_lds1[i] = row * 128 + (((2 * ch + 1) ^ vsw(row)) << 3);
     }
 
     f32x16 o0, o1;
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     const int vrow = dt * 32 + l31;
-                    const int sw = (vrow >> 1) & 15;
+                    const int sw = vsw(vrow);
                     const uint2 lo = *(const uint2*)(Vs + vrow * 128 + ((u0 ^ sw) << 3));
                     const uint2 hi = *(const uint2*)(Vs + vrow * 128 + (((u0 + 2) ^ sw) << 3));
                     const uint4 v4 = make_uint4(lo.x, lo.y, hi.x, hi.y);

@@ -139,6 +139,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// XOR swizzle (in 8-byte units) of a transposed [64 rows][64 x bf16] LDS tile with 128-byte rows, read as MFMA fragments with
+// ds_read_b64 and staged with ds_write_b64 (csrc/attention.hip explains the three terms)
+__device__ __forceinline__ int sc_tr_swizzle(int row) { return ((row >> 1) & 15) ^ (row & 1) ^ ((row >> 5) & 1); }
+
 // host side
 void sc_set_error(const char* fmt, ...);
 int sc_num_cus();   // compute units of the current device (immutable cache; 256 on MI355X)
