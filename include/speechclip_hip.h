@@ -131,8 +131,8 @@ typedef struct {
      * k_total > 0: the slices are ragged - slice z1 covers rows [z1 K, min((z1 + 1) K, k_total)) (K, k_total multiples of 64). */
     int32_t tn;
     int32_t k_total;
-    /* ---- activation fused with a second operand (128-row tile family only; Ct doubles as the aux pointer [M, N] bf16, row stride ldc;
-     * act = 1 erf-GELU or 2 QuickGELU; no transposed store, bf16 output):
+    /* ---- activation fused with a second operand (Ct doubles as the aux pointer [M, N] bf16, row stride ldc; act = 1 erf-GELU - every
+     * tile family, the 256-row one without a residual (round 4) - or 2 QuickGELU - 128-row tiles; no transposed store, bf16 output):
      *   aux_mode 1  dual store:  Ct <- u = bf16(acc + bias) (the pre-activation the backward needs),  C <- act(u)   (FFN fc1 of a layer
      *               that is differentiated: one launch instead of GEMM + sc_act_bf16)
      *   aux_mode 2  C <- bf16(acc) * act'(Ct)   (the input-gradient GEMM of fc2 followed by the activation's backward: Ct = the saved u)
@@ -485,6 +485,9 @@ int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int64_t ldy, in
 /* input gradient of a channels-last Conv1d(k = 3, stride 2) run as a strided-row GEMM (fully trainable HuBERT, conv layers 1-4):
  * dcols [M, 3C] = dy . W -> dx [2M, C]:  dx[2m] = dcols[m][0:C] + dcols[m-1][2C:3C],  dx[2m+1] = dcols[m][C:2C]   (one pass) */
 int sc_conv_overlap_add_bf16(const sc_bf16* dcols, sc_bf16* dx, int64_t M, int32_t C, void* stream);
+/* the same followed by the backward of the activation that produced the conv's input (u [2M, C] = its kept pre-activation):
+ * dx <- bf16(dx) * act'(u), bit-identical to sc_conv_overlap_add_bf16 + sc_act_bf16(u, dx) in one pass */
+int sc_conv_overlap_add_act_bf16(const sc_bf16* dcols, const sc_bf16* u, sc_bf16* dx, int64_t M, int32_t C, int32_t act, void* stream);
 int sc_colsum_bf16(const sc_bf16* x, int64_t ldx, int64_t rows, int32_t cols, float* partial, int32_t nblk, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -185,6 +185,7 @@ SIGNATURES = {
     "sc_conv0_gn_bwd": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                         c_float, c_void_p, c_int, c_void_p, c_void_p],
     "sc_conv_overlap_add_bf16": [c_void_p, c_void_p, c_i64, c_int, c_void_p],
+    "sc_conv_overlap_add_act_bf16": [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p],
     "sc_posconv_wgrad_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_int, c_int, c_void_p],
     "sc_transpose_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p],
     "sc_colsum_bf16": [c_void_p, c_i64, c_i64, c_int, c_void_p, c_int, c_void_p],

@@ -312,7 +312,11 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
 // input): dcols [M, 3 C] = dy . W holds the gradient of every window; the input row r collects the windows that contain it -
 //   dx[2m]     = dcols[m][0 : C] + dcols[m - 1][2C : 3C]        dx[2m + 1] = dcols[m][C : 2C]
 // one pass (was: three strided torch copies / adds over GB-sized tensors, 20 ms of the fully-trainable step).
-__global__ __launch_bounds__(256) void conv_overlap_add_kernel(const uint16_t* __restrict__ dcols, uint16_t* __restrict__ dx, int64_t M, int C) {
+// u != NULL (round 4): the layer below ends in an activation whose pre-activation u [2M, C] was kept - the gradient leaves already
+// multiplied by act'(u), i.e. dx <- bf16(dx) * act'(u), the same values as this kernel followed by sc_act_bf16(u, dx) (two passes over
+// GB-sized tensors less per conv layer of the fully trainable encoder).
+__global__ __launch_bounds__(256) void conv_overlap_add_kernel(const uint16_t* __restrict__ dcols, uint16_t* __restrict__ dx, int64_t M, int C,
+                                                               const uint16_t* __restrict__ u, int act) {
     const int64_t chunks = C >> 3;                      // 8 bf16 per thread
     const int64_t total = M * chunks;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
@@ -328,8 +332,20 @@ __global__ __launch_bounds__(256) void conv_overlap_add_kernel(const uint16_t* _
             e.z = pack2bf(bflo(t0.z) + bflo(p2.z), bfhi(t0.z) + bfhi(p2.z));
             e.w = pack2bf(bflo(t0.w) + bflo(p2.w), bfhi(t0.w) + bfhi(p2.w));
         }
+        uint4 o1 = t1;
+        if (u) {
+            const uint4 u0 = *(const uint4*)(u + (2 * m) * C + c), u1 = *(const uint4*)(u + (2 * m + 1) * C + c);
+            e.x = pack2bf(bflo(e.x) * act_grad(bflo(u0.x), act), bfhi(e.x) * act_grad(bfhi(u0.x), act));
+            e.y = pack2bf(bflo(e.y) * act_grad(bflo(u0.y), act), bfhi(e.y) * act_grad(bfhi(u0.y), act));
+            e.z = pack2bf(bflo(e.z) * act_grad(bflo(u0.z), act), bfhi(e.z) * act_grad(bfhi(u0.z), act));
+            e.w = pack2bf(bflo(e.w) * act_grad(bflo(u0.w), act), bfhi(e.w) * act_grad(bfhi(u0.w), act));
+            o1.x = pack2bf(bflo(t1.x) * act_grad(bflo(u1.x), act), bfhi(t1.x) * act_grad(bfhi(u1.x), act));
+            o1.y = pack2bf(bflo(t1.y) * act_grad(bflo(u1.y), act), bfhi(t1.y) * act_grad(bfhi(u1.y), act));
+            o1.z = pack2bf(bflo(t1.z) * act_grad(bflo(u1.z), act), bfhi(t1.z) * act_grad(bfhi(u1.z), act));
+            o1.w = pack2bf(bflo(t1.w) * act_grad(bflo(u1.w), act), bfhi(t1.w) * act_grad(bfhi(u1.w), act));
+        }
         *(uint4*)(dx + (2 * m) * C + c) = e;
-        *(uint4*)(dx + (2 * m + 1) * C + c) = t1;
+        *(uint4*)(dx + (2 * m + 1) * C + c) = o1;
     }
 }
 
@@ -358,7 +374,18 @@ extern "C" int sc_conv_overlap_add_bf16(const sc_bf16* dcols, sc_bf16* dx, int64
     SC_CHECK(dcols && dx && M > 0 && C > 0 && C % 8 == 0 && ((uintptr_t)dcols % 16) == 0 && ((uintptr_t)dx % 16) == 0, "sc_conv_overlap_add_bf16: bad args");
     const int64_t total = M * (C / 8);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(conv_overlap_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dcols, dx, M, C);
+    hipLaunchKernelGGL(conv_overlap_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dcols, dx, M, C, (const uint16_t*)nullptr, 0);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv_overlap_add_act_bf16(const sc_bf16* dcols, const sc_bf16* u, sc_bf16* dx, int64_t M, int32_t C, int32_t act, void* stream) {
+    SC_CHECK(dcols && u && dx && M > 0 && C > 0 && C % 8 == 0 && ((uintptr_t)dcols % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)u % 16) == 0,
+             "sc_conv_overlap_add_act_bf16: bad args");
+    SC_CHECK(act == 1 || act == 2, "sc_conv_overlap_add_act_bf16: act=%d (1 erf-GELU, 2 QuickGELU)", act);
+    const int64_t total = M * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(conv_overlap_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dcols, dx, M, C, u, act);
     SC_LAUNCH_CHECK();
     return 0;
 }

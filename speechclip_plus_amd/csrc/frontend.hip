@@ -301,25 +301,7 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
 //   Q = sum_t dn uhat = (A2 - beta A1) / gamma ;  dgamma = sum_b Q ;  dbeta = sum_b A1 ;
 //   dW[c][j] = sum_b (gamma / sigma) [V_j - (A1 / T0) S_j - (Q / T0) (sum_i W[c][i] G_ij - mu S_j) / sigma]
 // One pass over dy (u is recomputed from the waveform, 10 FMAs per element), then a per-utterance finalisation in fp64.
-// Phi(x) + x phi(x) with the erfc of gelu_erf (A&S 7.1.28, one v_rcp) and one v_exp
-__device__ __forceinline__ float gelu_grad_as(float x) {
-    const float ax = fabsf(x);
-    const float z = ax * 0.70710678118654752f;
-    float p = fmaf(0.0000430638f, z, 0.0002765672f);
-    p = fmaf(p, z, 0.0001520143f);
-    p = fmaf(p, z, 0.0092705272f);
-    p = fmaf(p, z, 0.0422820123f);
-    p = fmaf(p, z, 0.0705230784f);
-    p = fmaf(p, z, 1.0f);
-    p = p * p;
-    p = p * p;
-    p = p * p;
-    p = p * p;
-    const float he = 0.5f * __builtin_amdgcn_rcpf(p);                 // erfc(|z|) / 2
-    const float cdf = x >= 0.f ? 1.f - he : he;
-    return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
-}
-
+// gelu_grad_as: sc_common.h
 constexpr int C0_NS = 12;
 // grid (nblk, B), 4 waves per block; wave chunk wc = blockIdx.x * 4 + wave owns rows [wc * rpw, min(T0, (wc + 1) * rpw)); a lane owns
 // 8 channels (C = 512).  partial[((b * nwc + wc) * 512 + c) * 12 + e]

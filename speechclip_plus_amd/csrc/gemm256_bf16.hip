@@ -459,6 +459,8 @@ static int launch256_(const sc_gemm_args& a, hipStream_t s) {
 template <int DIAG, int BN>
 static int launch256(const sc_gemm_args& a, hipStream_t s) {
     if constexpr (DIAG == 0) {          // the diagnostic builds have no dropout variant
+        if (a.aux_mode == 1) return launch256__<DIAG, BN, 3, 0, 0, 0>(a, s);      // erf-GELU fused with the aux operand (checked by sc_gemm_bf16:
+        if (a.aux_mode == 2) return launch256__<DIAG, BN, 4, 0, 0, 0>(a, s);      // act = 1, no residual / dropout / transposed store / LN)
         if (a.drop_p > 0.f) return a.act == 1 ? launch256_<DIAG, BN, 1, 1>(a, s) : launch256_<DIAG, BN, 0, 1>(a, s);
     }
     return a.act == 1 ? launch256_<DIAG, BN, 1, 0>(a, s) : launch256_<DIAG, BN, 0, 0>(a, s);

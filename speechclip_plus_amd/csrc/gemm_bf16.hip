@@ -364,7 +364,9 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
         SC_CHECK((a.aux_mode == 1 || a.aux_mode == 2) && (a.act == 1 || a.act == 2) && a.Ct && a.n_split < 0 && !a.out_f32 && !a.tn &&
                  a.drop_p == 0.f && !a.ln_stats && !a.stats_out && !a.res_stats && ((uintptr_t)a.Ct % 16) == 0,
                  "sc_gemm_bf16: aux_mode needs act 1 / 2, the aux pointer in Ct (16-byte aligned), bf16 output and a plain epilogue");
-        SC_CHECK(a.tile == 0 || a.tile == 1 || a.tile == 3 || a.tile == 13, "sc_gemm_bf16: aux_mode is built into the 128-row tiles");
+        // 128-row tiles: both activations; 256-row tiles (round 4): erf-GELU, plain epilogue (no residual)
+        SC_CHECK(a.tile == 0 || a.tile == 1 || a.tile == 3 || a.tile == 13 || ((a.tile == 2 || a.tile == 7 || a.tile == 8) && a.act == 1 && !a.residual),
+                 "sc_gemm_bf16: aux_mode on the 256-row tiles needs act = 1 (erf-GELU) and no residual");
     } else {
         SC_CHECK(a.act == 0 || a.act == 1, "sc_gemm_bf16: act=%d (2 = QuickGELU needs aux_mode)", a.act);
     }
@@ -392,7 +394,7 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     if (tile == 0) {
         const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.nb1 * a.nb2;
         if (a.N <= 64 && a.n_split < 0) tile = 3;            // narrow outputs (grouped pos_conv, N = 48)
-        else if (!a.aux_mode && a.M >= 512 && a.N >= 192 && tiles256 >= 192 && (a.n_split < 0 || a.n_split % 64 == 0)) tile = 2;
+        else if ((!a.aux_mode || (a.act == 1 && !a.residual)) && a.M >= 512 && a.N >= 192 && tiles256 >= 192 && (a.n_split < 0 || a.n_split % 64 == 0)) tile = 2;
         else {
             // small problems (the text tower's 2048 packed rows): 128 x 64 tiles give twice the workgroups, 10-20 % faster up to two
             // waves of 128 x 128 tiles per CU (tools/bench_small_gemm.py)

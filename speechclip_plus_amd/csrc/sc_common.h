@@ -60,6 +60,25 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return fmaf(-ah, r, h + ah);
 }
 
+// Phi(x) + x phi(x) with the erfc of gelu_erf (A&S 7.1.28, one v_rcp) and one v_exp
+__device__ __forceinline__ float gelu_grad_as(float x) {
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752f;
+    float p = fmaf(0.0000430638f, z, 0.0002765672f);
+    p = fmaf(p, z, 0.0001520143f);
+    p = fmaf(p, z, 0.0092705272f);
+    p = fmaf(p, z, 0.0422820123f);
+    p = fmaf(p, z, 0.0705230784f);
+    p = fmaf(p, z, 1.0f);
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    const float he = 0.5f * __builtin_amdgcn_rcpf(p);                 // erfc(|z|) / 2
+    const float cdf = x >= 0.f ? 1.f - he : he;
+    return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
+}
+
 // activation codes of sc_act_bf16 / sc_gemm_args.act: 1 = erf-GELU (fairseq FFN), 2 = QuickGELU (CLIP MLP)
 __device__ __forceinline__ float act_fwd(float u, int act) {
     if (act == 1) return gelu_erf(u);
@@ -67,10 +86,8 @@ __device__ __forceinline__ float act_fwd(float u, int act) {
     return u * sg;
 }
 __device__ __forceinline__ float act_grad(float u, int act) {
-    if (act == 1) {                                                  // Phi(u) + u phi(u)
-        const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
-        return cdf + u * 0.3989422804014327f * __expf(-0.5f * u * u);
-    }
+    if (act == 1) return gelu_grad_as(u);                            // Phi(u) + u phi(u): ONE definition for sc_act_bf16 and both GEMM
+                                                                     // tile families (round 4: libm erff cost 40 instructions per element)
     const float sg = 1.f / (1.f + __expf(-1.702f * u));
     return sg * (1.f + 1.702f * u * (1.f - sg));
 }

@@ -138,15 +138,16 @@ class TrainableFrontend(nn.Module):
             k, s = a.conv_kernels[i], a.conv_strides[i]
             rows = B * pl.R_l[i]
             u = torch.empty(rows, C, device=dev, dtype=torch.bfloat16)
-            ops.gemm_raw(pl.conv[i - 1], s * C, c[f"conv{i}_w"], k * C, u, C, rows, C, k * C, bias=c[f"conv{i}_b"], alg_rows=B * pl.T_l[i],
-                         tap_c=C if (k == 3 and s == 2) else 0)
             st["u"][i] = u
             if ln_mode:
+                ops.gemm_raw(pl.conv[i - 1], s * C, c[f"conv{i}_w"], k * C, u, C, rows, C, k * C, bias=c[f"conv{i}_b"], alg_rows=B * pl.T_l[i],
+                             tap_c=C if (k == 3 and s == 2) else 0)
                 n = ops.layernorm_bf16(u, c[f"conv{i}_g"], c[f"conv{i}_beta"])
                 st["n"][i] = n
                 ops.act_bf16(n, 1, out=pl.conv[i][:rows])
-            else:
-                ops.act_bf16(u, 1, out=pl.conv[i][:rows])
+            else:     # one launch: the pre-activation u (kept) and gelu(u) (sc_gemm_args.aux_mode 1)
+                ops.gemm_raw(pl.conv[i - 1], s * C, c[f"conv{i}_w"], k * C, pl.conv[i], C, rows, C, k * C, bias=c[f"conv{i}_b"], act=1,
+                             alg_rows=B * pl.T_l[i], tap_c=C if (k == 3 and s == 2) else 0, aux=u, aux_mode=1)
         # ---- feature LayerNorm, projection (+ dropout_input)
         ops.layernorm_bf16(pl.conv[-1][:M], c["ln_feat_g"], c["ln_feat_b"], out=pl.feat_ln)
         ops.linear_bf16(pl.feat_ln, c["proj_w"], c["proj_b"], out=pl.x_proj, alg_rows=B * T, drop_p=p_in, drop_seed=seed_in)
@@ -230,16 +231,22 @@ class TrainableFrontend(nn.Module):
         fgm = float(getattr(a, "feature_grad_mult", 1.0))
         if fgm != 1.0:                       # fairseq GradMultiply on the extractor's output
             df = (df.float() * fgm).to(torch.bfloat16)
-        # ---- conv layers 6 .. 1
+        # ---- conv layers 6 .. 1.  "default" extractor (conv -> GELU): the GELU' of the layer BELOW rides on the step that produces its
+        # output gradient - the epilogue of the input-gradient GEMM (k = stride: its windows are a reshape) or the overlap-add pass
+        # (k = 3, stride 2) - so du of the next iteration arrives ready (no activation-sized pass of its own)
+        du_ready = None
         for i in range(len(a.conv_kernels) - 1, 0, -1):
             k, s = a.conv_kernels[i], a.conv_strides[i]
             rows = B * pl.R_l[i]
             u = st["u"][i]
+            fuse_below = (not ln_mode) and i >= 2
             if ln_mode:
                 dn = ops.act_bf16(st["n"][i], 1, df=df)
                 du, dg, db = ops.layernorm_bwd(u, dn, c[f"conv{i}_g"], 1e-5, want_param_grads=True)
                 acc(f"feature_extractor.conv_layers.{i}.2.1.weight", dg)
                 acc(f"feature_extractor.conv_layers.{i}.2.1.bias", db)
+            elif du_ready is not None:
+                du, du_ready = du_ready, None
             else:
                 du = ops.act_bf16(u, 1, df=df)
             # weight gradient: dy^T . im2col VIEW of the layer input (rows overlap in memory: lda = s C < K = k C)
@@ -251,12 +258,19 @@ class TrainableFrontend(nn.Module):
             if a.conv_bias:
                 acc(f"feature_extractor.conv_layers.{i}.0.bias", gbias)
             # input gradient: windows of dcols = du . W back onto the rows they were cut from
-            dcols = ops.linear_bf16(du, c[f"conv{i}_wT"])                                   # [rows, k C]
             if k == s:                                                                     # non-overlapping windows: a reshape
-                df = dcols.view(rows * s, C)
+                if fuse_below:
+                    du_ready = ops.linear_bf16(du, c[f"conv{i}_wT"], act=1, aux=st["u"][i - 1].view(rows, k * C), aux_mode=2).view(rows * s, C)
+                else:
+                    df = ops.linear_bf16(du, c[f"conv{i}_wT"]).view(rows * s, C)
             else:
                 assert k == 3 and s == 2
-                df = ops.conv_overlap_add(dcols, C)            # tap 2 of window m lands on row 2 (m + 1): one pass, one launch
+                dcols = ops.linear_bf16(du, c[f"conv{i}_wT"])                               # [rows, k C]
+                # tap 2 of window m lands on row 2 (m + 1): one pass, one launch
+                if fuse_below:
+                    du_ready = ops.conv_overlap_add(dcols, C, u=st["u"][i - 1])
+                else:
+                    df = ops.conv_overlap_add(dcols, C)
         # ---- conv layer 0: parameter gradients only (the input is the waveform)
         T0 = pl.T_l[0]
         if "conv0" in st:

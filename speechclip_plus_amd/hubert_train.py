@@ -160,9 +160,8 @@ class TrainableLayers(nn.Module):
             ops.layernorm_bf16(s["pre1"], c["ln2_g"], c["ln2_b"], out=s["pre2"])
         else:
             ops.layernorm_bf16(s["pre1"], c["ln1_g"], c["ln1_b"], out=s["x1"])
-        if save:
-            ops.linear_bf16(ffn_in, c["fc1_w"], c["fc1_b"], out=s["u"], alg_rows=B * T)
-            ops.act_bf16(s["u"], 1, out=s["f"])
+        if save:      # one launch: u = fc1 pre-activation (kept for the backward) and f = gelu(u) (sc_gemm_args.aux_mode 1)
+            ops.linear_bf16(ffn_in, c["fc1_w"], c["fc1_b"], out=s["f"], act=1, aux=s["u"], aux_mode=1, alg_rows=B * T)
         else:
             ops.linear_bf16(ffn_in, c["fc1_w"], c["fc1_b"], out=s["f"], act=1, alg_rows=B * T)
         if pre_ln:
@@ -227,8 +226,7 @@ class TrainableLayers(nn.Module):
         # gradient of the dropped branch = the same mask on the sum's gradient; the residual path keeps the un-masked one
         dfc2 = ops.dropout_bf16(dffn_out, p_res, sd_f) if p_res > 0.0 else dffn_out
         wgrad(dfc2, s["f"], "fc2")
-        df = ops.linear_bf16(dfc2, c["fc2_wT"])
-        du = ops.act_bf16(s["u"], 1, df=df, out=df)
+        du = ops.linear_bf16(dfc2, c["fc2_wT"], act=1, aux=s["u"], aux_mode=2)          # (dfc2 W2) * gelu'(u) in the GEMM's epilogue
         wgrad(du, ffn_in, "fc1")
         if pre_ln:
             dx2n = ops.linear_bf16(du, c["fc1_wT"])

@@ -1269,10 +1269,15 @@ def cif_head_bwd(y: torch.Tensor, w: torch.Tensor, alpha: torch.Tensor, dalpha: 
     return dy, dw, db
 
 
-def conv_overlap_add(dcols: torch.Tensor, C: int) -> torch.Tensor:
-    """dcols [M, 3C] bf16 (window gradients of a k = 3 / stride 2 conv) -> input-row gradients [2M, C] bf16 (sc_conv_overlap_add_bf16)"""
+def conv_overlap_add(dcols: torch.Tensor, C: int, u: Optional[torch.Tensor] = None, act: int = 1) -> torch.Tensor:
+    """dcols [M, 3C] bf16 (window gradients of a k = 3 / stride 2 conv) -> input-row gradients [2M, C] bf16 (sc_conv_overlap_add_bf16);
+    ``u`` [2M, C] bf16: also through the activation below, dx * act'(u) (sc_conv_overlap_add_act_bf16)"""
     M = dcols.shape[0]
     assert dcols.dtype == torch.bfloat16 and dcols.is_contiguous() and dcols.shape[1] == 3 * C
     dx = torch.empty(2 * M, C, device=dcols.device, dtype=torch.bfloat16)
-    check(lib().sc_conv_overlap_add_bf16(_p(dcols), _p(dx), M, C, _stream()), "sc_conv_overlap_add_bf16")
+    if u is not None:
+        assert u.dtype == torch.bfloat16 and u.is_contiguous() and u.numel() >= 2 * M * C
+        check(lib().sc_conv_overlap_add_act_bf16(_p(dcols), _p(u), _p(dx), M, C, int(act), _stream()), "sc_conv_overlap_add_act_bf16")
+    else:
+        check(lib().sc_conv_overlap_add_bf16(_p(dcols), _p(dx), M, C, _stream()), "sc_conv_overlap_add_bf16")
     return dx

@@ -1311,3 +1311,48 @@ def test_product_library_refuses_the_diagnostic_kernels():
     dbg = torch.zeros(4 * 8 * 8 * 8, device="cuda", dtype=torch.int64)
     ops.gemm_raw(A, K, W, K, C, N, M, N, K, tile=34, Ct=dbg.view(torch.bfloat16))
     assert rel_l2(C, A.float() @ W.float().T) < 1e-2
+
+
+@pytest.mark.parametrize("tile", [2, 7, 8])
+def test_gemm256_fused_gelu_with_aux_operand(dev, tile):
+    """Round 4: sc_gemm_args.aux_mode on the 256-row tile family (erf-GELU; the fc1 / conv GEMMs of a differentiated HuBERT): the dual
+    store and the product-times-gelu'(aux) epilogues reproduce GEMM -> sc_act_bf16 bit for bit, on both tile widths, also when M is not
+    a multiple of the tile and for a conv-shaped (overlapping-row) A operand."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(tile)
+    M, N, K = 2048 + 40, 768, 512
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    u_ref = ops.linear_bf16(x, w, b, tile=tile)
+    f_ref = ops.act_bf16(u_ref, 1)
+    u = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    f = ops.linear_bf16(x, w, b, act=1, aux=u, aux_mode=1, tile=tile)
+    assert torch.equal(u, u_ref) and torch.equal(f, f_ref)
+    assert torch.equal(f, ops.linear_bf16(x, w, b, act=1, tile=tile))                  # and equals the plain fused-GELU epilogue
+    dy = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w2T = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+    df_ref = ops.linear_bf16(dy, w2T, tile=tile)
+    du_ref = ops.act_bf16(u_ref, 1, df=df_ref)
+    du = ops.linear_bf16(dy, w2T, act=1, aux=u_ref, aux_mode=2, tile=tile)
+    assert torch.equal(du, du_ref)
+    # conv-shaped A (k = 3, stride 2: lda = 2 C < K = 3 C) with the shared-tap K order
+    C, rows = 256, 1024
+    xin = torch.randn(2 * rows + 8, C, generator=g).to(torch.bfloat16).to(dev)
+    wc = (torch.randn(C, 3 * C, generator=g) * (3 * C) ** -0.5).to(torch.bfloat16).to(dev)
+    uc_ref = torch.empty(rows, C, device=dev, dtype=torch.bfloat16)
+    ops.gemm_raw(xin, 2 * C, wc, 3 * C, uc_ref, C, rows, C, 3 * C, tap_c=C, tile=tile)
+    uc, fc = torch.empty_like(uc_ref), torch.empty_like(uc_ref)
+    ops.gemm_raw(xin, 2 * C, wc, 3 * C, fc, C, rows, C, 3 * C, act=1, tap_c=C, aux=uc, aux_mode=1, tile=tile)
+    assert torch.equal(uc, uc_ref) and torch.equal(fc, ops.act_bf16(uc_ref, 1))
+
+
+def test_conv_overlap_add_with_activation_backward(dev):
+    """sc_conv_overlap_add_act_bf16 = sc_conv_overlap_add_bf16 followed by sc_act_bf16(u, dx), in one pass, bit for bit"""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, C = 4096, 512
+    dcols = torch.randn(M, 3 * C, generator=g).to(torch.bfloat16).to(dev)
+    u = torch.randn(2 * M, C, generator=g).to(torch.bfloat16).to(dev)
+    ref = ops.act_bf16(u, 1, df=ops.conv_overlap_add(dcols, C))
+    assert torch.equal(ops.conv_overlap_add(dcols, C, u=u), ref)
