@@ -98,16 +98,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
 
     const int nM = (p.M + 255) >> 8, nN = (p.N + BN - 1) / BN;
     const int n_tiles = nM * nN;
-    // ---- virtual block -> tile (XCD-aware, banded; see gemm_bf16.hip) --------------------------------------
-    auto tile_of = [&](int vb, int& m0, int& n0) {
+    // ---- virtual block -> tile.  Blocks b, b + 8, ... share an XCD and its L2.  Round 4: the M-tiles are split among the XCDs
+    // FIRST (XCD x owns M-tiles [nM x / 8, nM (x + 1) / 8)) and each XCD walks its own rows in bands of 8 M-tiles x all N-tiles, so an A
+    // row-tile is only ever filled into ONE L2, whatever M is.  The round-1..3 map cut the band-major tile list into 8 equal runs:
+    // aligned with the bands only when nM was a multiple of 64 (B x 512 rows), and with the ragged layout's arbitrary row counts a
+    // band straddled two XCDs most of the time (PMC: 487 MB per launch at M = 64 x 504 against 434 MB at M = 64 x 512).  An XCD's list
+    // may be one row of tiles shorter than its neighbour's; a virtual block past its XCD's list has no tile (returns false).
+    const bool xcd_rows = (gridDim.x & 7) == 0 && nM >= 8 && !p.reserved3;      // reserved3: A/B switch (sc_set_option(3, 1): round-3 map)
+    auto tile_of = [&](int vb, int& m0, int& n0) -> bool {
+        constexpr int GM = 8;
+        if (xcd_rows) {
+            const int xcd = vb & 7, idx = vb >> 3;
+            const int m_lo = (nM * xcd) >> 3, m_hi = (nM * (xcd + 1)) >> 3;
+            if (idx >= (m_hi - m_lo) * nN) return false;
+            const int band = idx / (GM * nN), first_m = m_lo + band * GM;
+            const int gm = min(GM, m_hi - first_m);
+            const int within = idx - band * GM * nN;
+            m0 = (first_m + within % gm) << 8;
+            n0 = (within / gm) * BN;
+            return true;
+        }
+        if (vb >= n_tiles) return false;
         const int xcd = vb & 7, q = n_tiles >> 3, r = n_tiles & 7;
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-        constexpr int GM = 8;
         const int band = L / (GM * nN), first_m = band * GM;
         const int gm = min(GM, nM - first_m);
         const int within = L - band * GM * nN;
         m0 = (first_m + within % gm) << 8;
         n0 = (within / gm) * BN;
+        return true;
     };
 
     const int z = blockIdx.z, z1 = z / p.nb2, z2 = z % p.nb2;
@@ -269,7 +288,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
 
     // ---- first tile: K-tile 0 into buffer 0 -------------------------------------------------------------------
     int vb = blockIdx.x, m0, n0, base = 0;
-    tile_of(vb, m0, n0);
+    if (!tile_of(vb, m0, n0)) return;             // (a slot past its XCD's list: uniform for the workgroup, before any barrier / DMA)
     set_sources(m0, n0);
     dma_B(0, 0);
     dma_A(0, 0);
@@ -365,9 +384,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
         const int last_par = (nk - 1 + base) & 1;
         const int cm0 = m0, cn0 = n0;
         vb += gridDim.x;
-        const bool has_next = vb < n_tiles;
+        const bool has_next = tile_of(vb, m0, n0);
         if (has_next) {
-            tile_of(vb, m0, n0);
             set_sources(m0, n0);
             base = last_par ^ 1;
             dma_B(base, 0);
@@ -492,6 +510,7 @@ int sc_gemm256_launch(const sc_gemm_args& a_in, hipStream_t s) {
     // register-direct epilogue it must stay off: half-line non-temporal writes cost 25 % (75.7 vs 55.9 us on the out_proj shape).
     a.reserved = (a_in.reserved == 1 || (a_in.reserved == 0 && a_in.residual != nullptr)) ? 1 : 0;
     if (sc_option(1)) a.reserved = 0;      // A/B switch (tools/): plain stores everywhere
+    a.reserved3 = sc_option(3);            // A/B switch (tools/): 1 = the round-3 block -> tile map (band-major list cut into 8 runs)
     if (a.tn) return launch256_<5, 256, 0, 0>(a, s);     // TN operands (weight gradients): checked by sc_gemm_bf16
 #ifdef SC_DIAG_BUILD
     if (a.tile == 32) return launch256<3, 256>(a, s);   // diagnostics only (tools/epi_probe.py, tools/epi_stamps.py)

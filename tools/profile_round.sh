@@ -7,7 +7,7 @@ set -e -o pipefail
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/profiles; mkdir -p $out
-cmd="bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-recall $*"
+cmd="bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-recall --no-recipes $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o st -- python3 $cmd > $out/${tag}_bench_n1_profiled_run.json 2> /tmp/p_stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_fetch -o f -- python3 $cmd > /dev/null 2> /tmp/p_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_write -o w -- python3 $cmd > /dev/null 2> /tmp/p_write.err

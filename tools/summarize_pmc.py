@@ -31,7 +31,7 @@ _h = hashlib.sha256()
 for _n in ("gemm256_bf16.hip", "gemm_epilogue.inc"):
     _h.update(open(os.path.join(_csrc, _n), "rb").read())
 res["_meta"] = {"kernel_source_sha256": _h.hexdigest(),
-                "command": "python3 bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-recall"}
+                "command": "python3 bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-recall --no-recipes"}
 json.dump(res, open(out + "_traffic.json", "w"), indent=1, sort_keys=True)
 rows = list(csv.DictReader(open(stats_csv)))
 with open(out + "_kernel_stats.csv", "w") as fo:
