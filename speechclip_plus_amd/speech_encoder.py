@@ -170,7 +170,12 @@ class _Plan:
     SLACK = 64           # rows behind the last utterance that a 64-key attention tile / a conv window may read (never written)
 
     def __init__(self, arch: HubertArch, B: int, L: int, device, seg_mode: bool = False):
+        # seg_mode: L is the plan's CAPACITY (the longest padded batch it can hold, speech_encoder._plan buckets the batch length);
+        # the geometry of the batch in flight (L, T_l, T) is set per forward by set_length - real data changes its longest
+        # utterance from batch to batch, and a fresh 7 GB of zeroed workspaces per distinct length would cost more than the step
+        self.arch = arch
         self.B, self.L = B, L
+        self.L_cap = L
         self.T_l = conv_out_lengths(L, arch)
         self.T = self.T_l[-1]
         if self.T < 1:
@@ -223,6 +228,16 @@ class _Plan:
         self.generation = 0          # forwards run on this plan (weighted_sum.PaddedFeatHandle.check_fresh)
         self.seg = None
         self.bind(None)
+
+    def set_length(self, L: int) -> None:
+        """geometry of the batch in flight: padded length L <= the plan's capacity (segment layout only)"""
+        if L == self.L:
+            return
+        assert self.seg_mode and L <= self.L_cap, (L, self.L_cap)
+        T_l = conv_out_lengths(L, self.arch)
+        if T_l[-1] < 1:
+            raise ValueError(f"waveform too short for the conv stack: L={L}")
+        self.L, self.T_l, self.T = L, T_l, T_l[-1]
 
     def segments(self, pitch, keys, device, keys_known: bool = True):
         """ops.RowSegments of a batch; the tables of the previous batch are re-used when the layout and the work order are the same
@@ -400,13 +415,24 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         the uniform layout their kernels index."""
         return self.train_layers is None and not _FUSED_LN
 
+    LENGTH_BUCKET = 32000        # samples: plans of the segment layout are sized for the batch length rounded up to 2 s
+
     def _plan(self, B: int, L: int) -> _Plan:
-        key = (B, L, self._seg_mode())
+        seg_mode = self._seg_mode()
+        if conv_out_lengths(L, self.arch)[-1] < 1:
+            raise ValueError(f"waveform too short for the conv stack: L={L}")
+        # segment layout: the workspaces are views into capacity-sized buffers, so one plan serves every padded length of its 2 s
+        # bucket (real batches change their longest utterance all the time); the uniform layout of unfrozen layers is per length
+        cap = _roundup(L, self.LENGTH_BUCKET) if seg_mode else L
+        key = (B, cap, seg_mode)
         if key not in self._plans:
             if len(self._plans) >= 4:          # keep HBM bounded when lengths vary
                 self._plans.pop(next(iter(self._plans)))
-            self._plans[key] = _Plan(self.arch, B, L, self._dev, seg_mode=key[2])
-        return self._plans[key]
+            self._plans[key] = _Plan(self.arch, B, cap, self._dev, seg_mode=seg_mode)
+        pl = self._plans[key]
+        if seg_mode:
+            pl.set_length(L)
+        return pl
 
     def segment_pitches(self, T: int, valid: Sequence[int], feat_len: Sequence[int], ragged: bool) -> Tuple[List[int], List[int]]:
         """-> (rows needed per utterance, pitch per utterance).  An utterance needs the frames the HuBERT key mask admits

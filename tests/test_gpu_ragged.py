@@ -258,7 +258,42 @@ def test_device_resident_lengths_need_no_host_read(setup):
         finally:
             torch.cuda.set_sync_debug_mode("default")
     assert getattr(l_d, "_sc_host", None) is None and torch.equal(l_d.cpu(), l_h.cpu())
-    assert enc._plan(len(LENS), max(LENS)).M == len(LENS) * enc._plan(len(LENS), max(LENS)).R          # uniform pitch: nothing was read
+    pl = enc._plan(len(LENS), max(LENS))
+    assert pl.M == len(LENS) * ((pl.T + 1 + 7) // 8 * 8)                                                # uniform pitch: nothing was read
     for b, n in enumerate(l_h.tolist()):
         assert torch.equal(f_d[b, :n], f_h[b, :n]), b
     assert torch.equal(o_d["parallel_audio_feat"], o_h["parallel_audio_feat"])
+
+
+def test_one_plan_serves_every_batch_length_of_its_bucket(setup):
+    """Real batches change their longest utterance from batch to batch: the segment layout's workspaces are capacity-sized (the
+    batch length rounded up to 2 s) with the batch's geometry set per forward, so no new plan (7 GB of zeroed buffers at B = 64) is
+    built per distinct length - and a batch's result does not depend on what ran in the plan before it."""
+    model, sd, oracle = setup
+    enc = model.audio_encoder
+    lens_a = [47000, 30000, 12000, 40000]
+    lens_b = [33000, 41500, 8000, 39990]              # another padded length (41500) of the same 64000-sample bucket, other T
+    wa, wb = _batch(lens_a, seed=21).cuda(), _batch(lens_b, seed=22).cuda()
+    with torch.no_grad():
+        fa, la = enc(wa, torch.tensor(lens_a))
+        fa = fa.float().clone()
+        n_plans = len(enc._plans)
+        pl = enc._plan(4, 47000)
+        fb, lb = enc(wb, torch.tensor(lens_b))
+        fb = fb.float().clone()
+        assert enc._plan(4, 41500) is pl and len(enc._plans) == n_plans and pl.L == 41500
+        fa2, _ = enc(wa, torch.tensor(lens_a))
+        assert torch.equal(fa2.float(), fa)
+        # the same batch on a fresh encoder (fresh plan): identical
+        from speechclip_plus_amd.speech_encoder import FairseqSpeechEncoder_Hubert
+        enc2 = FairseqSpeechEncoder_Hubert(name="hubert", device="cuda:0", feat_select_idx="weighted_sum", state_dict=sd).eval()
+        enc2.tail_rows = enc.tail_rows
+        enc2.weightedsum_layer.weights.data.copy_(enc.weightedsum_layer.weights.data)
+        fb2, _ = enc2(wb, torch.tensor(lens_b))
+    for b, n in enumerate(lb.tolist()):
+        assert torch.equal(fb2[b, :n].float(), fb[b, :n]), b
+    hs_o, fl_o = oracle.speech_encoder_forward(sd, oracle.HubertArch.base(), [wb[b, :l].cpu() for b, l in enumerate(lens_b)])
+    assert lb.cpu().tolist() == fl_o.tolist()
+    ws_o = oracle.weighted_sum(enc.weightedsum_layer.weights.detach().cpu(), hs_o)
+    for b, n in enumerate(fl_o.tolist()):
+        assert rel_l2(fb[b, :n], ws_o[b, :n]) < 1.5e-2
