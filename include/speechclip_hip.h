@@ -89,7 +89,8 @@ typedef struct {
     int32_t nb1, nb2;             /* batch = nb1*nb2 (>= 1 each) */
     int64_t sA1, sA2, sW1, sW2, sC1, sC2, sBias1, sBias2, sR1, sR2;
     int32_t tile;                 /* 0 auto | 1: 128x128 (4 waves) | 2: 256-row tile, 8 waves, width 256 or 192 by wave quantisation
-                                     (7 / 8 force 192 / 256) | 3: 128x64.  Every tile family accumulates k in the same order and
+                                     (7 / 8 force 192 / 256) | 3: 128x64 (13: four LDS stages) | 14 / 15: 64x64 with two / four stages
+                                     (few rows, narrow output, long K).  Every tile family accumulates k in the same order and
                                      shares the epilogue arithmetic: results do not depend on the choice.  (32 / 34: diagnostic
                                      kernels of libspeechclip_hip_diag.so only; the product library returns an error) */
     int32_t reserved;             /* store policy of the bf16 C tile (256-row kernels): 0 auto = non-temporal stores when a residual
@@ -658,6 +659,27 @@ int sc_sumsq_f32(const float* x, int64_t n, float* partial, int32_t nblk, void* 
 int sc_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int32_t step, const float* gnorm_sq_partial, int32_t nblk,
                 float max_norm, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Keyword prompt of the cascaded branches in the text tower's packed rows (round 4; replaces the ~35 element-wise torch launches of
+ * ClipModel.encode_keywords, avssl/module/clip_official.py:222-279, and of the padding around the tower).
+ *   sc_prompt_assemble: X [Bp*SEG, W] bf16 <- per sample b < B the prefix t < n_pos of
+ *       [SOT, kw_1 .. kw_n, EOT, token 0 ...] + positional_embedding  (n = count[b]; keyword t-1 read from keywords[b*ldb + (t-1)*W],
+ *       zero past the N keywords given), every other row (t >= n_pos, pad samples b >= B) zero.  tok [3, W] = the embeddings of SOT,
+ *       EOT and token 0; pos [>= n_pos, W].  eot_row[b] <- b*SEG + min(count[b] + 1, n_pos - 1): the row the head reads; counts that
+ *       pointed behind the prefix are clamped and added to *clamped (device counter, may be NULL).
+ *   sc_prompt_assemble_bwd: dkeywords[b, j] <- float(dX[b*SEG + j + 1]) for j + 1 < min(count[b] + 1, n_pos), else 0 (every element
+ *       of the [B, N, W] gradient is written).
+ *   sc_rows_gather_bf16: out[b] <- float(X[row[b]]);   sc_rows_scatter_bf16: dX [M, W] <- 0 except dX[row[b]] = bf16(d[b]) (the row of
+ *       sample b lies in its own segment b*SEG .. b*SEG + SEG - 1; every row of dX is written).
+ * ---------------------------------------------------------------------------------------------- */
+int sc_prompt_assemble(const float* keywords, int64_t ldb, const int64_t* count, const float* tok, const float* pos, sc_bf16* X,
+                       int32_t* eot_row, int64_t* clamped, int32_t B, int32_t Bp, int32_t N, int32_t W, int32_t SEG, int32_t n_pos,
+                       void* stream);
+int sc_prompt_assemble_bwd(const sc_bf16* dX, const int64_t* count, float* dkeywords, int64_t ldb, int32_t B, int32_t N, int32_t W,
+                           int32_t SEG, int32_t n_pos, void* stream);
+int sc_rows_gather_bf16(const sc_bf16* X, const int32_t* row, float* out, int32_t B, int32_t W, void* stream);
+int sc_rows_scatter_bf16(const float* d, const int32_t* row, sc_bf16* dX, int32_t M, int32_t B, int32_t W, int32_t SEG, void* stream);
 
 #ifdef __cplusplus
 }

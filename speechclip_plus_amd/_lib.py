@@ -198,6 +198,10 @@ SIGNATURES = {
     "sc_gelu_f32": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "sc_colsum_f32": [c_void_p, c_i64, c_int, c_int, c_void_p, c_float, c_float, c_void_p],
     "sc_headmask_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_prompt_assemble": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_prompt_assemble_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_rows_gather_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "sc_rows_scatter_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "sc_cif_head_fwd": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_float, ctypes.c_uint32, c_void_p],
     "sc_cif_head_bwd": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                         ctypes.c_uint32, c_float, ctypes.c_uint32, c_void_p],

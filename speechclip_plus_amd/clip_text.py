@@ -135,23 +135,32 @@ class ClipModel(nn.Module):
                 p.requires_grad = False
         self.to(device)
 
-    def _transformer(self, x: torch.Tensor) -> torch.Tensor:
-        """(B, 77, W) -> (B, 77, W) on the library's bf16 kernels, forward and input gradient (clip_text_hip.TextTowerFn).  The
-        tower is frozen in every shipped recipe (clip_official.py:113-134) and both published towers have head_dim 64."""
+    def _check_tower(self) -> None:
         core = self.model
         heads = core.transformer.resblocks[0].attn.num_heads
-        if not x.is_cuda:
-            raise RuntimeError("the CLIP text tower runs on the HIP kernels: device tensors only")
         if self.text_encoder_trainable:
             raise NotImplementedError("text_encoder_trainable: no shipped recipe trains the CLIP text tower; only the frozen tower "
                                       "(forward + input gradient) is built")
         if core.transformer.width != 64 * heads:
             raise NotImplementedError(f"text tower head_dim {core.transformer.width // heads}: the attention kernels are built for 64")
-        from .clip_text_hip import TextTowerFn, prepare_weights
-        key = (x.device, tuple((p.data_ptr(), p._version) for p in core.transformer.parameters()))
-        if getattr(self, "_hip_key", None) != key:              # (re)converted when a checkpoint is loaded or the module moves
-            self._hip_weights, self._hip_key = prepare_weights(core.transformer, x.device), key
-        return TextTowerFn.apply(x, self._hip_weights, heads)
+
+    def _tower_weights(self, dev):
+        """bf16 (+ transposed) copies of the frozen tower's weights, (re)converted when a checkpoint is loaded or the module moves"""
+        from .clip_text_hip import prepare_weights
+        core = self.model
+        key = (dev, tuple((p.data_ptr(), p._version) for p in core.transformer.parameters()))
+        if getattr(self, "_hip_key", None) != key:
+            self._hip_weights, self._hip_key = prepare_weights(core.transformer, dev), key
+        return self._hip_weights
+
+    def _transformer(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, T <= 77, W) -> (B, T, W) on the library's bf16 kernels, forward and input gradient (clip_text_hip.TextTowerFn).  The
+        tower is frozen in every shipped recipe (clip_official.py:113-134) and both published towers have head_dim 64."""
+        if not x.is_cuda:
+            raise RuntimeError("the CLIP text tower runs on the HIP kernels: device tensors only")
+        self._check_tower()
+        from .clip_text_hip import TextTowerFn
+        return TextTowerFn.apply(x, self._tower_weights(x.device), self.model.transformer.resblocks[0].attn.num_heads)
 
     def update_device(self, device):
         self.device = device
@@ -161,47 +170,48 @@ class ClipModel(nn.Module):
         self.device = self.model.token_embedding.weight.device
         return self
 
+    def _prompt_constants(self, dev):
+        """(tok [3, W] = embeddings of SOT, EOT and token 0; pos [77, W]) as fp32 device tensors, per parameter version"""
+        emb, posp = self.model.token_embedding.weight, self.model.positional_embedding
+        key = (str(dev), emb.data_ptr(), emb._version, posp.data_ptr(), posp._version)
+        if getattr(self, "_prompt_key", None) != key:
+            sot, eot = (SOT_TOKEN, EOT_TOKEN) if self.selected_text_emb_ids is None else (self.startOfTxt_reduced, self.endOfTxt_reduced)
+            tok = emb.detach()[torch.tensor([sot, eot, 0], device=emb.device)].to(device=dev, dtype=torch.float32).contiguous()
+            self._prompt_const = (tok, posp.detach().to(device=dev, dtype=torch.float32).contiguous())
+            self._prompt_key = key
+        return self._prompt_const
+
     def encode_keywords(self, keywords: torch.Tensor, keyword_num: Union[int, torch.Tensor]) -> torch.Tensor:
         """clip_official.py:222-279: [SOT, kw_1 .. kw_n, EOT, 0 ...] -> text transformer -> EOT row @ text_projection."""
         if not isinstance(keywords, torch.Tensor):
             raise TypeError(f"Unknown keywords type {type(keywords)}")
         bsz = keywords.size(0)
         dev = keywords.device
+        ln = self.model.ln_final
+        if isinstance(keyword_num, torch.Tensor):
+            # per-sample keyword counts (the CIF branches): prompt assembly, the tower's padding and the end-of-text gather are
+            # single launches around the tower (clip_text_hip.KeywordTowerFn, csrc/prompt.hip).  The tower is causal and only the
+            # end-of-text row is read: positions behind the LAST end-of-text token of the batch cannot influence any output, and
+            # keywords.shape[1] is the batch's largest keyword count (sized on the host), so the prefix [SOT, kw_1 .. kw_N, EOT] =
+            # N + 2 positions is all the transformer sees.  A count that points behind the keyword tensor (a caller error the
+            # reference reports as a shape mismatch on the host) is clamped into the prefix and counted in ``eot_clamped`` instead of
+            # indexing out of bounds on the device.
+            if not keywords.is_cuda:
+                raise RuntimeError("the CLIP text tower runs on the HIP kernels: device tensors only")
+            self._check_tower()
+            from .clip_text_hip import KeywordTowerFn
+            n_pos = min(CONTEXT_LEN, keywords.shape[1] + 2)
+            tok, pos = self._prompt_constants(dev)
+            heads = self.model.transformer.resblocks[0].attn.num_heads
+            rows = KeywordTowerFn.apply(keywords, keyword_num.to(dev), tok, pos, self._tower_weights(dev), heads, n_pos, self.eot_clamped)
+            return _EotHeadFn.apply(rows, ln.weight, ln.bias, ln.eps, self.model.text_projection)
         sot, eot = (SOT_TOKEN, EOT_TOKEN) if self.selected_text_emb_ids is None else (self.startOfTxt_reduced, self.endOfTxt_reduced)
         text = torch.zeros([bsz, CONTEXT_LEN], device=dev, dtype=torch.long)
         text[:, 0] = sot
-        if isinstance(keyword_num, torch.Tensor):
-            index = keyword_num.to(dev) + 1
-            text = text.scatter(1, index.unsqueeze(1), eot)
-        else:
-            index = None
-            text[:, keyword_num + 1] = eot
+        text[:, keyword_num + 1] = eot
         x = self.model.token_embedding(text)
-        if index is not None:
-            pos = torch.arange(CONTEXT_LEN, device=dev).unsqueeze(0)
-            is_kw = (pos >= 1) & (pos < index.unsqueeze(1))                        # rows 1 .. n of every sample
-            n_kw = keywords.shape[1]
-            src = torch.zeros(bsz, CONTEXT_LEN, x.shape[-1], device=dev, dtype=x.dtype)
-            src[:, 1: 1 + n_kw] = keywords[:, : CONTEXT_LEN - 1]
-            x = torch.where(is_kw.unsqueeze(-1), src, x)
-        else:
-            x = torch.cat([x[:, :1], keywords, x[:, 1 + keyword_num:]], dim=1)
+        x = torch.cat([x[:, :1], keywords, x[:, 1 + keyword_num:]], dim=1)
         x = x + self.model.positional_embedding
-        # the tower is causal and only the end-of-text row is read below: positions behind the LAST end-of-text token of the batch
-        # cannot influence any output.  keywords.shape[1] is the batch's largest keyword count (sized on the host), so the prefix
-        # [SOT, kw_1 .. kw_N, EOT] = N + 2 positions is all the transformer needs to see (clip_text_hip packs it densely).
-        n_pos = min(CONTEXT_LEN, (keywords.shape[1] if index is not None else int(keyword_num)) + 2)
+        n_pos = min(CONTEXT_LEN, int(keyword_num) + 2)          # the causal prefix up to the end-of-text position
         x = self._transformer(x[:, :n_pos])
-        # LayerNorm is per row: only the end-of-text row of every sample goes through ln_final and the projection
-        # (index = keyword count + 1 <= n_pos - 1 by construction - the CIF kernel caps every count at the slots the host sized,
-        # min(max_feat, T); the clamp makes the gather safe whatever a caller hands in: a count beyond the keyword tensor is an error
-        # the reference reports as a shape mismatch on the host, here it is clamped and counted in ``eot_clamped`` instead of
-        # indexing out of bounds on the device, which would poison the context)
-        if index is not None:
-            over = index > n_pos - 1
-            self.eot_clamped += over.sum()
-            rows = x[torch.arange(bsz, device=dev), torch.where(over, torch.full_like(index, n_pos - 1), index)]
-        else:
-            rows = x[:, 1 + keyword_num]
-        ln = self.model.ln_final
-        return _EotHeadFn.apply(rows, ln.weight, ln.bias, ln.eps, self.model.text_projection)
+        return _EotHeadFn.apply(x[:, 1 + keyword_num], ln.weight, ln.bias, ln.eps, self.model.text_projection)

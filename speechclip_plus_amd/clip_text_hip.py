@@ -55,60 +55,122 @@ def prepare_weights(transformer, device) -> List[_LayerW]:
     return out
 
 
+_valid_cache = {}
+
+
+def _full_blocks(NB: int, dev) -> torch.Tensor:
+    """valid_len of the attention launch: every 128-row block is full (the causal mask does the rest); one resident vector per size"""
+    key = (NB, str(dev))
+    if key not in _valid_cache:
+        _valid_cache[key] = torch.full((NB,), BLOCK, device=dev, dtype=torch.int32)
+    return _valid_cache[key]
+
+
+def _geometry(B: int, T: int):
+    SEG = _segment(T)
+    per = BLOCK // SEG                                   # sequences per attention block
+    Bp = -(-B // per) * per                              # padded up to whole blocks (pad sequences: zeros)
+    return SEG, Bp, Bp * SEG, 1 if SEG == BLOCK else SEG
+
+
+def tower_forward(X: torch.Tensor, weights, heads: int, causal: int):
+    """X [M, W] bf16 packed rows -> (output rows [M, W] bf16, what the backward needs)"""
+    M, W = X.shape
+    dev = X.device
+    NB = M // BLOCK
+    valid = _full_blocks(NB, dev)
+    scale = (W // heads) ** -0.5
+    saved = []
+    for w in weights:
+        h = ops.layernorm_bf16(X, w.g1, w.be1, eps=w.eps1)
+        qkv = ops.linear_bf16(h, w.wqkv, w.bqkv)
+        vt = ops.head_transpose(qkv[:, 2 * W:], NB, BLOCK, heads)
+        att = torch.empty(M, W, device=dev, dtype=torch.bfloat16)
+        lse2 = torch.empty(NB, heads, BLOCK, device=dev, dtype=torch.float32)
+        ops.attn_fwd(qkv[:, : 2 * W], vt, valid, att, NB, BLOCK, heads, W, scale, lse2=lse2, causal=causal)
+        X2 = ops.linear_bf16(att, w.wo, w.bo, residual=X)
+        h2 = ops.layernorm_bf16(X2, w.g2, w.be2, eps=w.eps2)
+        u = torch.empty(M, w.w1.shape[0], device=dev, dtype=torch.bfloat16)
+        f = ops.linear_bf16(h2, w.w1, w.b1, act=2, aux=u, aux_mode=1)          # u = fc1 pre-activation (kept), f = QuickGELU(u)
+        Xn = ops.linear_bf16(f, w.w2, w.b2, residual=X2)
+        saved.append((X, qkv, att, lse2, X2, u))
+        X = Xn
+    return X, saved
+
+
+def tower_backward(dX: torch.Tensor, weights, saved, heads: int, causal: int, q_rows: int) -> torch.Tensor:
+    """dX [M, W] bf16 (rows that carry no gradient: zero) -> gradient w.r.t. the tower's input rows"""
+    M, W = dX.shape
+    dev = dX.device
+    NB = M // BLOCK
+    valid = _full_blocks(NB, dev)
+    scale = (W // heads) ** -0.5
+    for w, (X, qkv, att, lse2, X2, u) in zip(reversed(weights), reversed(saved)):
+        du = ops.linear_bf16(dX, w.w2T, act=2, aux=u, aux_mode=2)                 # (dX W2) * QuickGELU'(u) in the GEMM's epilogue
+        dh2 = ops.linear_bf16(du, w.w1T)
+        dX2 = ops.layernorm_bwd(X2, dh2, w.g2, w.eps2, dres=dX)
+        datt = ops.linear_bf16(dX2, w.woT)
+        dqkv = torch.empty(M, 3 * W, device=dev, dtype=torch.bfloat16)
+        ops.attn_bwd(qkv[:, :W], qkv[:, W: 2 * W], qkv[:, 2 * W:], att, datt, lse2, valid, dqkv[:, :W], dqkv[:, W: 2 * W],
+                     dqkv[:, 2 * W:], NB, BLOCK, heads, scale, causal=causal, q_rows=q_rows)
+        dh1 = ops.linear_bf16(dqkv, w.wqkvT)
+        dX = ops.layernorm_bwd(X, dh1, w.g1, w.eps1, dres=dX2)
+    return dX
+
+
 class TextTowerFn(torch.autograd.Function):
     """x [B, T <= 128, W] (any float dtype) -> transformer(x) [B, T, W] fp32; gradient w.r.t. x only."""
 
     @staticmethod
     def forward(ctx, x, weights, heads):
         B, T, W = x.shape
-        dev = x.device
-        SEG = _segment(T)
-        per = BLOCK // SEG                                   # sequences per attention block
-        Bp = -(-B // per) * per                              # padded up to whole blocks (pad sequences: zeros)
-        M = Bp * SEG
-        NB = M // BLOCK
-        causal = 1 if SEG == BLOCK else SEG
-        X = torch.zeros(Bp, SEG, W, device=dev, dtype=torch.bfloat16)
+        SEG, Bp, M, causal = _geometry(B, T)
+        X = torch.zeros(Bp, SEG, W, device=x.device, dtype=torch.bfloat16)
         X[:B, :T] = x.detach().to(torch.bfloat16)
-        X = X.view(M, W)
-        valid = torch.full((NB,), BLOCK, device=dev, dtype=torch.int32)
-        scale = (W // heads) ** -0.5
-        saved = []
-        for w in weights:
-            h = ops.layernorm_bf16(X, w.g1, w.be1, eps=w.eps1)
-            qkv = ops.linear_bf16(h, w.wqkv, w.bqkv)
-            vt = ops.head_transpose(qkv[:, 2 * W:], NB, BLOCK, heads)
-            att = torch.empty(M, W, device=dev, dtype=torch.bfloat16)
-            lse2 = torch.empty(NB, heads, BLOCK, device=dev, dtype=torch.float32)
-            ops.attn_fwd(qkv[:, : 2 * W], vt, valid, att, NB, BLOCK, heads, W, scale, lse2=lse2, causal=causal)
-            X2 = ops.linear_bf16(att, w.wo, w.bo, residual=X)
-            h2 = ops.layernorm_bf16(X2, w.g2, w.be2, eps=w.eps2)
-            u = torch.empty(M, w.w1.shape[0], device=dev, dtype=torch.bfloat16)
-            f = ops.linear_bf16(h2, w.w1, w.b1, act=2, aux=u, aux_mode=1)          # u = fc1 pre-activation (kept), f = QuickGELU(u)
-            Xn = ops.linear_bf16(f, w.w2, w.b2, residual=X2)
-            saved.append((X, qkv, att, lse2, X2, u))
-            X = Xn
-        ctx.weights, ctx.saved, ctx.valid, ctx.dims = weights, saved, valid, (B, T, W, heads, scale, SEG, Bp, causal)
+        X, saved = tower_forward(X.view(M, W), weights, heads, causal)
+        ctx.weights, ctx.saved, ctx.dims = weights, saved, (B, T, W, heads, SEG, Bp, causal)
         return X.view(Bp, SEG, W)[:B, :T].float()
 
     @staticmethod
     def backward(ctx, dy):
-        B, T, W, heads, scale, SEG, Bp, causal = ctx.dims
-        dev = dy.device
+        B, T, W, heads, SEG, Bp, causal = ctx.dims
         M = Bp * SEG
-        NB = M // BLOCK
-        dX = torch.zeros(Bp, SEG, W, device=dev, dtype=torch.bfloat16)
+        dX = torch.zeros(Bp, SEG, W, device=dy.device, dtype=torch.bfloat16)
         dX[:B, :T] = dy.to(torch.bfloat16)
-        dX = dX.view(M, W)
-        for w, (X, qkv, att, lse2, X2, u) in zip(reversed(ctx.weights), reversed(ctx.saved)):
-            du = ops.linear_bf16(dX, w.w2T, act=2, aux=u, aux_mode=2)                 # (dX W2) * QuickGELU'(u) in the GEMM's epilogue
-            dh2 = ops.linear_bf16(du, w.w1T)
-            dX2 = ops.layernorm_bwd(X2, dh2, w.g2, w.eps2, dres=dX)
-            datt = ops.linear_bf16(dX2, w.woT)
-            dqkv = torch.empty(M, 3 * W, device=dev, dtype=torch.bfloat16)
-            ops.attn_bwd(qkv[:, :W], qkv[:, W: 2 * W], qkv[:, 2 * W:], att, datt, lse2, ctx.valid, dqkv[:, :W], dqkv[:, W: 2 * W],
-                         dqkv[:, 2 * W:], NB, BLOCK, heads, scale, causal=causal, q_rows=BLOCK if SEG < BLOCK else T)
-            dh1 = ops.linear_bf16(dqkv, w.wqkvT)
-            dX = ops.layernorm_bwd(X, dh1, w.g1, w.eps1, dres=dX2)
+        dX = tower_backward(dX.view(M, W), ctx.weights, ctx.saved, heads, causal, BLOCK if SEG < BLOCK else T)
         ctx.saved = None
         return dX.view(Bp, SEG, W)[:B, :T].float(), None, None
+
+
+class KeywordTowerFn(torch.autograd.Function):
+    """The whole keyword path of ``ClipModel.encode_keywords`` (clip_official.py:222-279) around the frozen tower:
+    keywords [B, N, W] fp32, count [B] int64 -> the B end-of-text rows of transformer([SOT, kw_1 .. kw_n, EOT, 0 ..] + pos), fp32 [B, W].
+
+    One launch assembles the tower's packed bf16 rows (csrc/prompt.hip), one reads the end-of-text rows back; the backward scatters
+    the rows' gradient into a zero [M, W] buffer, runs the tower's input gradient and extracts d(keywords) - four launches around the
+    tower where the element-wise formulation took ~35 (zeros / scatter / embedding / where / add / pad / cast / advanced index and
+    their autograd nodes).  Same arithmetic: fp32 embedding + position sums rounded once to bf16, gradients rounded to bf16 where the
+    tower takes them."""
+
+    @staticmethod
+    def forward(ctx, keywords, count, tok, pos, weights, heads, n_pos, clamped):
+        B, N, W = keywords.shape
+        SEG, Bp, M, causal = _geometry(B, n_pos)
+        kw = keywords.detach()
+        if kw.dtype != torch.float32 or kw.stride(2) != 1 or (N > 0 and kw.stride(1) != W) or kw.data_ptr() % 16:
+            kw = kw.float().contiguous()
+        count = count.detach().to(dtype=torch.int64).contiguous()
+        X, eot_row = ops.prompt_assemble(kw, count, tok, pos, Bp, SEG, n_pos, clamped)
+        X, saved = tower_forward(X, weights, heads, causal)
+        ctx.weights, ctx.saved, ctx.dims = weights, saved, (B, N, W, heads, SEG, M, causal, n_pos, keywords.dtype)
+        ctx.count, ctx.eot_row = count, eot_row
+        return ops.rows_gather(X, eot_row)
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        B, N, W, heads, SEG, M, causal, n_pos, dtype = ctx.dims
+        dX = ops.rows_scatter(d_rows.float().contiguous(), ctx.eot_row, M, SEG)
+        dX = tower_backward(dX, ctx.weights, ctx.saved, heads, causal, BLOCK if SEG < BLOCK else n_pos)
+        ctx.saved = None
+        dk = ops.prompt_assemble_bwd(dX, ctx.count, B, N, SEG, n_pos)
+        return (dk if dtype == torch.float32 else dk.to(dtype)), None, None, None, None, None, None, None

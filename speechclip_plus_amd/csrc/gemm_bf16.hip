@@ -365,7 +365,7 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
                  a.drop_p == 0.f && !a.ln_stats && !a.stats_out && !a.res_stats && ((uintptr_t)a.Ct % 16) == 0,
                  "sc_gemm_bf16: aux_mode needs act 1 / 2, the aux pointer in Ct (16-byte aligned), bf16 output and a plain epilogue");
         // 128-row tiles: both activations; 256-row tiles (round 4): erf-GELU, plain epilogue (no residual)
-        SC_CHECK(a.tile == 0 || a.tile == 1 || a.tile == 3 || a.tile == 13 || ((a.tile == 2 || a.tile == 7 || a.tile == 8) && a.act == 1 && !a.residual),
+        SC_CHECK(a.tile == 0 || a.tile == 1 || a.tile == 3 || a.tile == 13 || a.tile == 14 || a.tile == 15 || ((a.tile == 2 || a.tile == 7 || a.tile == 8) && a.act == 1 && !a.residual),
                  "sc_gemm_bf16: aux_mode on the 256-row tiles needs act = 1 (erf-GELU) and no residual");
     } else {
         SC_CHECK(a.act == 0 || a.act == 1, "sc_gemm_bf16: act=%d (2 = QuickGELU needs aux_mode)", a.act);
@@ -399,7 +399,11 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
             // small problems (the text tower's 2048 packed rows): 128 x 64 tiles give twice the workgroups, 10-20 % faster up to two
             // waves of 128 x 128 tiles per CU (tools/bench_small_gemm.py)
             const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.nb1 * a.nb2;
-            tile = (tiles128 <= 2 * (int64_t)sc_num_cus() && a.n_split < 0) ? 3 : 1;
+            const int64_t tiles64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.nb1 * a.nb2;
+            // long-K products with a narrow output (text tower: fc2, the input gradients of fc1 / QKV): 64 x 64 tiles put them on
+            // 2-3 times the CUs, each streaming half the A rows: 18.4 -> 13.1 us (2048 x 512 x 2048), 20.2 -> 16.3 (2048 x 768 x 2304)
+            if (a.n_split < 0 && a.K >= 1024 && tiles64 <= 2 * (int64_t)sc_num_cus()) tile = 15;
+            else tile = (tiles128 <= 2 * (int64_t)sc_num_cus() && a.n_split < 0) ? 3 : 1;
         }
     }
     switch (tile) {
@@ -415,6 +419,9 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
             if (tile == 13 || (a.tile == 0 && wgs <= (int64_t)sc_num_cus() && a.K >= 1024)) return launch<128, 64, 4>(a, s);
             return launch<128, 64>(a, s);
         }
+        case 14: case 15:                                      // 64 x 64 (2 / 4 stages): few-row problems with narrow outputs
+            SC_CHECK(a.n_split < 0, "sc_gemm_bf16: 64x64 tile has no transposed store");
+            return tile == 15 ? launch<64, 64, 4>(a, s) : launch<64, 64>(a, s);
         default: sc_set_error("sc_gemm_bf16: tile=%d", a.tile); return -1;
     }
 }

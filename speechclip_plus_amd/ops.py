@@ -1281,3 +1281,46 @@ def conv_overlap_add(dcols: torch.Tensor, C: int, u: Optional[torch.Tensor] = No
     else:
         check(lib().sc_conv_overlap_add_bf16(_p(dcols), _p(dx), M, C, _stream()), "sc_conv_overlap_add_bf16")
     return dx
+
+
+# ---- keyword prompt of the cascaded branches in the text tower's packed rows (csrc/prompt.hip) ------------------------------------------
+def prompt_assemble(keywords: torch.Tensor, count: torch.Tensor, tok: torch.Tensor, pos: torch.Tensor, Bp: int, SEG: int, n_pos: int,
+                    clamped: Optional[torch.Tensor] = None):
+    """keywords [B, N, W] fp32 (last two dims dense), count [B] int64, tok [3, W] (SOT, EOT, token 0), pos [>= n_pos, W] ->
+    X [Bp * SEG, W] bf16 (prefix rows of [SOT, kw.., EOT, 0..] + pos; zero elsewhere), eot_row [B] int32 (rows of X)"""
+    B, N, W = keywords.shape
+    assert keywords.dtype == torch.float32 and keywords.stride(2) == 1 and (N == 0 or keywords.stride(1) == W)
+    assert count.dtype == torch.int64 and count.is_contiguous() and tok.dtype == torch.float32 and tok.is_contiguous() and tuple(tok.shape) == (3, W)
+    assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[0] >= n_pos and pos.shape[1] == W
+    X = torch.empty(Bp * SEG, W, device=keywords.device, dtype=torch.bfloat16)
+    eot_row = torch.empty(B, device=keywords.device, dtype=torch.int32)
+    check(lib().sc_prompt_assemble(_p(keywords), keywords.stride(0) if B > 1 else N * W, _p(count), _p(tok), _p(pos), _p(X), _p(eot_row),
+                                   _p(clamped), B, Bp, N, W, SEG, n_pos, _stream()), "sc_prompt_assemble")
+    return X, eot_row
+
+
+def prompt_assemble_bwd(dX: torch.Tensor, count: torch.Tensor, B: int, N: int, SEG: int, n_pos: int) -> torch.Tensor:
+    """dX [>= B * SEG, W] bf16 -> dkeywords [B, N, W] fp32 (rows behind a sample's keyword count: zero)"""
+    W = dX.shape[1]
+    assert dX.dtype == torch.bfloat16 and dX.is_contiguous()
+    dk = torch.empty(B, N, W, device=dX.device, dtype=torch.float32)
+    if N > 0:
+        check(lib().sc_prompt_assemble_bwd(_p(dX), _p(count), _p(dk), N * W, B, N, W, SEG, n_pos, _stream()), "sc_prompt_assemble_bwd")
+    return dk
+
+
+def rows_gather(X: torch.Tensor, row: torch.Tensor) -> torch.Tensor:
+    """out[b] = float(X[row[b]]): X [M, W] bf16 contiguous, row [B] int32"""
+    assert X.dtype == torch.bfloat16 and X.is_contiguous() and row.dtype == torch.int32
+    out = torch.empty(row.numel(), X.shape[1], device=X.device, dtype=torch.float32)
+    check(lib().sc_rows_gather_bf16(_p(X), _p(row), _p(out), row.numel(), X.shape[1], _stream()), "sc_rows_gather_bf16")
+    return out
+
+
+def rows_scatter(d: torch.Tensor, row: torch.Tensor, M: int, SEG: int) -> torch.Tensor:
+    """dX [M, W] bf16: zero except dX[row[b]] = bf16(d[b]) (row[b] inside segment b of SEG rows)"""
+    B, W = d.shape
+    assert d.dtype == torch.float32 and d.is_contiguous() and row.dtype == torch.int32
+    dX = torch.empty(M, W, device=d.device, dtype=torch.bfloat16)
+    check(lib().sc_rows_scatter_bf16(_p(d), _p(row), _p(dX), M, B, W, SEG, _stream()), "sc_rows_scatter_bf16")
+    return dX

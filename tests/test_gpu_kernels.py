@@ -1242,17 +1242,18 @@ def test_posconv_weight_gradient_kernel(dev, Dg, G, B, R):
 
 @pytest.mark.gpu
 def test_gemm_small_tile_ring_variants_agree_bitwise(dev):
-    """128 x 64 tiles, 2-stage and 4-stage LDS ring (tile 3 / 13; the dispatcher picks the deep ring for small grids with long K):
-    same K order, same epilogue - identical bits, with bias, GELU and residual."""
+    """128 x 64 tiles, 2-stage and 4-stage LDS ring (tile 3 / 13; the dispatcher picks the deep ring for small grids with long K) and the
+    64 x 64 tiles (14 / 15; chosen for few rows x narrow output x long K): same K order, same epilogue - identical bits, with bias,
+    GELU and residual; M with a tail in every tile size."""
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(4)
-    for (M, N, K, act, res) in ((2048, 512, 2048, 0, True), (1000, 192, 1088, 1, False), (128, 64, 64, 0, False)):
+    for (M, N, K, act, res) in ((2048, 512, 2048, 0, True), (1000, 192, 1088, 1, False), (128, 64, 64, 0, False), (1733, 776, 1536, 1, True)):
         A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
         W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
         bias = torch.randn(N, generator=g).to(dev)
         R = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev) if res else None
         outs = []
-        for t in (3, 13, 0):
+        for t in (3, 13, 0, 14, 15):
             C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             ops.gemm_raw(A, K, W, K, C, N, M, N, K, bias=bias, residual=R, ldr=N, act=act, tile=t)
             outs.append(C)
@@ -1261,7 +1262,7 @@ def test_gemm_small_tile_ring_variants_agree_bitwise(dev):
             ref = torch.nn.functional.gelu(ref)
         if res:
             ref = ref + R.float()
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
         assert rel_l2(outs[0], ref) < 6e-3
 
 

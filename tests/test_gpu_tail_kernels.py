@@ -296,3 +296,49 @@ def test_cif_weight_head_kernel(p1, p2):
     ref.backward(da.double())
     dy, dw, db = ops.cif_head_bwd(y.to(dev), w.to(dev), alpha, da.to(dev), p1, s1, p2, s2)
     assert rel(dy, yd.grad) < 1e-5 and rel(dw, wd.grad) < 1e-5 and rel(db, bd.grad) < 1e-4      # (db: a cancelling fp32 sum over the rows)
+
+
+@pytest.mark.gpu
+def test_prompt_assembly_kernels_match_the_elementwise_formulation():
+    """csrc/prompt.hip against the torch formulation it replaces (clip_official.py:233-262 written with zeros / scatter / where / add):
+    bit-identical rows, the end-of-text row index incl. a count that points behind the keyword tensor (clamped + counted), pad
+    samples and rows behind the prefix zero, and the two adjoints (gather / scatter of the end-of-text rows, keyword gradient)."""
+    from speechclip_plus_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, N, W, SEG, Bp = 5, 6, 512, 32, 8
+    n_pos = N + 2
+    kw = (torch.randn(B, N, W, generator=g) * 0.02).to(dev)
+    count = torch.tensor([6, 1, 4, 0, 9], dtype=torch.int64, device=dev)           # the last one points behind the tensor
+    tok = torch.randn(3, W, generator=g).to(dev)
+    pos = (torch.randn(77, W, generator=g) * 0.01).to(dev)
+    clamped = torch.zeros((), dtype=torch.int64, device=dev)
+    X, eot_row = ops.prompt_assemble(kw, count, tok, pos, Bp, SEG, n_pos, clamped)
+    torch.cuda.synchronize()
+    # the element-wise formulation
+    index = count + 1
+    t = torch.arange(n_pos, device=dev).unsqueeze(0)
+    e = tok[2].expand(B, n_pos, W).clone()
+    e[:, 0] = tok[0]
+    src = torch.zeros(B, n_pos, W, device=dev)
+    src[:, 1: 1 + N] = kw
+    e = torch.where(((t >= 1) & (t < index.unsqueeze(1))).unsqueeze(-1), src, e)
+    e = torch.where((t == index.unsqueeze(1)).unsqueeze(-1), tok[1].expand(B, n_pos, W), e)
+    ref = torch.zeros(Bp, SEG, W, device=dev, dtype=torch.bfloat16)
+    ref[:B, :n_pos] = (e + pos[:n_pos]).to(torch.bfloat16)
+    assert torch.equal(X.view(Bp, SEG, W), ref)
+    want_row = torch.arange(B, device=dev) * SEG + torch.clamp(index, max=n_pos - 1)
+    assert torch.equal(eot_row.long(), want_row) and int(clamped) == 1
+    # gather / scatter of the selected rows
+    rows = ops.rows_gather(X, eot_row)
+    assert torch.equal(rows, X[eot_row.long()].float())
+    d = torch.randn(B, W, generator=g).to(dev)
+    dX = ops.rows_scatter(d, eot_row, Bp * SEG, SEG)
+    want = torch.zeros(Bp * SEG, W, device=dev, dtype=torch.bfloat16)
+    want[eot_row.long()] = d.to(torch.bfloat16)
+    assert torch.equal(dX, want)
+    # keyword gradient: row j + 1 of every sample for j < its count (inside the prefix), zero behind
+    dXr = torch.randn(Bp * SEG, W, generator=g).to(torch.bfloat16).to(dev)
+    dk = ops.prompt_assemble_bwd(dXr, count, B, N, SEG, n_pos)
+    live = (torch.arange(N, device=dev).unsqueeze(0) + 1 < torch.clamp(index, max=n_pos).unsqueeze(1)).unsqueeze(-1)
+    assert torch.equal(dk, torch.where(live, dXr.view(Bp, SEG, W)[:B, 1: 1 + N].float(), torch.zeros((), device=dev)))

@@ -9,14 +9,14 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 shapes = [("b_qkv", 2048, 1536, 512), ("b_out", 2048, 512, 512), ("b_fc1", 2048, 2048, 512), ("b_fc2", 2048, 512, 2048),
           ("l_qkv", 2048, 2304, 768), ("l_out", 2048, 768, 768), ("l_fc1", 2048, 3072, 768), ("l_fc2", 2048, 768, 3072),
-          ("b_out_1k", 1024, 512, 512), ("b_fc2_1k", 1024, 512, 2048)]
+          ("b_out_1k", 1024, 512, 512), ("b_fc2_1k", 1024, 512, 2048), ("b_dqkv", 2048, 512, 1536), ("l_dqkv", 2048, 768, 2304)]
 for name, m, n, k in shapes:
     A = torch.randn(m, k, device=dev).to(torch.bfloat16)
     W = (torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16)
     bias = torch.randn(n, device=dev)
     C = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
     row = {}
-    for t in (1, 3, 13, 2):
+    for t in (1, 3, 13, 14, 15, 2):
         if t == 2 and (m < 512 or n < 192):
             continue
         ts = []
