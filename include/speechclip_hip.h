@@ -417,6 +417,10 @@ int sc_cif_tail(const float* alpha, const float* csum, int32_t B, int32_t S, int
  *                      decide an argmax over the vocabulary and the CIF weights a floor(), so no reduced-precision operand.
  *                      A: [M][K] row-major (a_kmajor 0) or [K][M] (a_kmajor 1); B: [N][K] (the nn.Linear layout) or [K][N].
  *                      any M, N, K (16-byte loads when base and leading dimension allow, element loads otherwise)
+ *   sc_sgemm_mfma_f32_split  the same product with the contraction cut into S slices of whole 16-wide K-tiles (partials [S, M, N] fp32:
+ *                      the caller's workspace), added in slice order with the bias by a second launch - for products with few output
+ *                      tiles and a long K (the keyword projection's 64- and 1600-row products and their weight gradients), which the
+ *                      one-slice kernel walks with a handful of workgroups.  sc_sgemm_mfma_slices(M, N, K) = the S to use (1: do not split)
  *   sc_vq_rowstats     x [Nk, ldx] fp32, V columns: columns listed in mask_cols_host (<= 4, host array: the special tokens 0, 2, 3) are
  *                      set to -inf IN PLACE (the reference's x[:, i] += -inf), idx = first argmax, lse_t = LSE(x / temp),
  *                      lse_1 = LSE(x), ent = - sum p log(p + 1e-9) with p = softmax(x)       (my_vector_quantizer.py:80-116)
@@ -431,6 +435,9 @@ int sc_cif_tail(const float* alpha, const float* csum, int32_t B, int32_t S, int
 int sc_vq_prep_f32(const float* kw, int64_t ldk, int32_t Nk, int32_t Et, float eps, float* kwn_T, int64_t ldt, float* rnorm, void* stream);
 int sc_sgemm_mfma_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc,
                       int32_t M, int32_t N, int32_t K, const float* bias, void* stream);
+int sc_sgemm_mfma_f32_split(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, int32_t b_kmajor, float* C,
+                            int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, float* partials, int32_t S, void* stream);
+int32_t sc_sgemm_mfma_slices(int32_t M, int32_t N, int32_t K);
 int sc_vq_rowstats(float* x, int64_t ldx, int32_t Nk, int32_t V, float temp, const int32_t* mask_cols_host, int32_t n_mask, int64_t* idx,
                    float* lse_t, float* lse_1, float* ent, void* stream);
 int sc_vq_perplexity(const float* x, int64_t ldx, int32_t Nk, int32_t V, const int64_t* idx, const float* lse_1, float* partial,

@@ -128,7 +128,9 @@ __device__ __forceinline__ void sg_stage(const float4 (&r)[2], float (*S)[LDT], 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256, 2) void sgemm_mfma_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
                                                            int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                           const float* __restrict__ bias, int vec_a, int vec_b) {
+                                                           const float* __restrict__ bias, int vec_a, int vec_b, int Kc, int64_t c_slice) {
+    // blockIdx.z = slice of the contraction (k in [z Kc, min(K, (z + 1) Kc)), Kc a multiple of 16); with more than one slice the
+    // raw partial tile goes to C + z c_slice (no bias) and sgemm_reduce_kernel adds the slices in order
     __shared__ float As[2][16][LDT];
     __shared__ float Bs[2][16][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -139,18 +141,21 @@ __global__ __launch_bounds__(256, 2) void sgemm_mfma_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
     float4 ra[2], rb[2];
-    sg_load<A_KMAJOR>(ra, A, lda, M, K, m0, 0, tid, vec_a);
-    sg_load<B_KMAJOR>(rb, Bm, ldb, N, K, n0, 0, tid, vec_b);
+    const int kb = blockIdx.z * Kc;
+    K = min(K, kb + Kc);
+    C += blockIdx.z * c_slice;
+    sg_load<A_KMAJOR>(ra, A, lda, M, K, m0, kb, tid, vec_a);
+    sg_load<B_KMAJOR>(rb, Bm, ldb, N, K, n0, kb, tid, vec_b);
     sg_stage<A_KMAJOR>(ra, As[0], tid);
     sg_stage<B_KMAJOR>(rb, Bs[0], tid);
     __syncthreads();
-    const int nk = (K + 15) >> 4;
+    const int nk = (K - kb + 15) >> 4;
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         const bool more = t + 1 < nk;
         if (more) {
-            sg_load<A_KMAJOR>(ra, A, lda, M, K, m0, (t + 1) * 16, tid, vec_a);
-            sg_load<B_KMAJOR>(rb, Bm, ldb, N, K, n0, (t + 1) * 16, tid, vec_b);
+            sg_load<A_KMAJOR>(ra, A, lda, M, K, m0, kb + (t + 1) * 16, tid, vec_a);
+            sg_load<B_KMAJOR>(rb, Bm, ldb, N, K, n0, kb + (t + 1) * 16, tid, vec_b);
         }
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) {
@@ -184,6 +189,17 @@ __global__ __launch_bounds__(256, 2) void sgemm_mfma_kernel(const float* __restr
     store(acc01, 0, 1);
     store(acc10, 1, 0);
     store(acc11, 1, 1);
+}
+
+// C[m, n] = part[0][m, n] + part[1][m, n] + ... + part[S - 1][m, n] (+ bias[n]): the slices of a split product, added in slice order
+__global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restrict__ part, int64_t slice, int S, int M, int N,
+                                                           const float* __restrict__ bias, float* __restrict__ C, int64_t ldc) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)M * N) return;
+    const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
+    float a = part[e];
+    for (int s2 = 1; s2 < S; ++s2) a += part[s2 * slice + e];
+    C[(int64_t)m * ldc + n] = a + (bias ? bias[n] : 0.f);
 }
 
 // ------------------------------------------------------------------------------------------ row statistics
@@ -455,22 +471,60 @@ extern "C" int sc_vq_prep_f32(const float* kw, int64_t ldk, int32_t Nk, int32_t 
     return 0;
 }
 
-extern "C" int sc_sgemm_mfma_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* Bm, int64_t ldb, int32_t b_kmajor,
-                                 float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, void* stream) {
+// slices the split entry point wants for this shape (1 = the product already fills the chip): a few workgroups walking a long K
+// one 16-wide tile at a time are latency-bound (64 rows x 768 columns x K = 1024: 6 workgroups, 100 us)
+extern "C" int32_t sc_sgemm_mfma_slices(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 1;
+    const int64_t wgs = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+    const int cus = sc_num_cus();
+    if (wgs > cus || K < 256) return 1;
+    int64_t S = 2 * cus / wgs;                       // two workgroups per CU are resident (launch bounds)
+    if (S > K / 64) S = K / 64;
+    if (S > 16) S = 16;
+    return S < 1 ? 1 : (int32_t)S;
+}
+
+static int sgemm_launch(const float* A, int64_t lda, int32_t a_kmajor, const float* Bm, int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc,
+                        int32_t M, int32_t N, int32_t K, const float* bias, float* partials, int32_t S, void* stream) {
     SC_CHECK(A && Bm && C, "sc_sgemm_mfma_f32: null pointer");
     SC_CHECK(M > 0 && N > 0 && K > 0, "sc_sgemm_mfma_f32: M=%d N=%d K=%d", M, N, K);
     SC_CHECK(ldc >= N, "sc_sgemm_mfma_f32: ldc");
+    SC_CHECK(S >= 1 && S <= 64 && (S == 1 || partials), "sc_sgemm_mfma_f32: S=%d slices need a [S, M, N] workspace", S);
     // 16-byte loads when the base and the leading dimension allow it, element loads otherwise (tiny / ragged operands)
     const int vec_a = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0), vec_b = (ldb % 4 == 0) && (((uintptr_t)Bm & 15) == 0);
-    const dim3 grid((N + 127) / 128, (M + 127) / 128);
-#define SG_LAUNCH(AK, BK) hipLaunchKernelGGL((sgemm_mfma_kernel<AK, BK>), grid, dim3(256), 0, (hipStream_t)stream, A, lda, Bm, ldb, C, ldc, M, N, K, bias, vec_a, vec_b)
+    int Kc = K;
+    if (S > 1) {
+        Kc = ((K + S - 1) / S + 15) / 16 * 16;
+        S = (K + Kc - 1) / Kc;                           // no empty slice
+    }
+    const dim3 grid((N + 127) / 128, (M + 127) / 128, S);
+    float* out = S > 1 ? partials : C;
+    const int64_t ldo = S > 1 ? N : ldc, slice = S > 1 ? (int64_t)M * N : 0;
+    const float* kb = S > 1 ? nullptr : bias;
+#define SG_LAUNCH(AK, BK) hipLaunchKernelGGL((sgemm_mfma_kernel<AK, BK>), grid, dim3(256), 0, (hipStream_t)stream, A, lda, Bm, ldb, out, ldo, M, N, K, kb, vec_a, vec_b, Kc, slice)
     if (a_kmajor && b_kmajor) SG_LAUNCH(true, true);
     else if (a_kmajor) SG_LAUNCH(true, false);
     else if (b_kmajor) SG_LAUNCH(false, true);
     else SG_LAUNCH(false, false);
 #undef SG_LAUNCH
     SC_LAUNCH_CHECK();
+    if (S > 1) {
+        const int64_t n = (int64_t)M * N;
+        hipLaunchKernelGGL(sgemm_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, slice, S, M, N, bias, C, ldc);
+        SC_LAUNCH_CHECK();
+    }
     return 0;
+}
+
+extern "C" int sc_sgemm_mfma_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* Bm, int64_t ldb, int32_t b_kmajor,
+                                 float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, void* stream) {
+    return sgemm_launch(A, lda, a_kmajor, Bm, ldb, b_kmajor, C, ldc, M, N, K, bias, nullptr, 1, stream);
+}
+
+extern "C" int sc_sgemm_mfma_f32_split(const float* A, int64_t lda, int32_t a_kmajor, const float* Bm, int64_t ldb, int32_t b_kmajor,
+                                       float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, float* partials,
+                                       int32_t S, void* stream) {
+    return sgemm_launch(A, lda, a_kmajor, Bm, ldb, b_kmajor, C, ldc, M, N, K, bias, partials, S, stream);
 }
 
 extern "C" int sc_vq_rowstats(float* x, int64_t ldx, int32_t Nk, int32_t V, float temp, const int32_t* mask_cols_host, int32_t n_mask,

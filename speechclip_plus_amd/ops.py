@@ -618,8 +618,14 @@ def sgemm_mfma(A: torch.Tensor, Bm: torch.Tensor, a_kmajor: bool = False, b_kmaj
     if _timer is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib().sc_sgemm_mfma_f32(_p(A), A.stride(0), int(a_kmajor), _p(Bm), Bm.stride(0), int(b_kmajor), _p(out), out.stride(0), M, N, K,
-                                  _p(bias), _stream()), "sc_sgemm_mfma_f32")
+    S = int(lib().sc_sgemm_mfma_slices(M, N, K))          # few output tiles x long K: slices of the contraction, added in order
+    if S > 1:
+        part = torch.empty(S, M, N, device=A.device, dtype=torch.float32)
+        check(lib().sc_sgemm_mfma_f32_split(_p(A), A.stride(0), int(a_kmajor), _p(Bm), Bm.stride(0), int(b_kmajor), _p(out), out.stride(0),
+                                            M, N, K, _p(bias), _p(part), S, _stream()), "sc_sgemm_mfma_f32_split")
+    else:
+        check(lib().sc_sgemm_mfma_f32(_p(A), A.stride(0), int(a_kmajor), _p(Bm), Bm.stride(0), int(b_kmajor), _p(out), out.stride(0), M, N, K,
+                                      _p(bias), _stream()), "sc_sgemm_mfma_f32")
     if _timer is not None:
         ev1.record()
         _timer.add("sgemm_mfma_f32", ev0, ev1, 2.0 * M * N * K)
