@@ -316,15 +316,17 @@ int sc_posconv_wgrad_bf16(const sc_bf16* du, const sc_bf16* xg, float* part, int
  * ---------------------------------------------------------------------------------------------- */
 int sc_wsum_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, int32_t B, int32_t R, int32_t D,
                 int32_t row_off, int32_t normalize, void* stream);
-int sc_wsum_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial /*[nblk, NL]*/, int32_t nblk,
-                int32_t B, int32_t R, int32_t D, int32_t row_off, int32_t normalize, void* stream);
+/* bwd `flags`: bit 0 = normalize, bit 1 = g is bf16 [B, R, D] instead of fp32 (the attention block of the cascaded+/hybrid+ branches
+ * returns its input gradient as the bf16 rows its GEMM wrote; g 16-byte aligned either way) */
+int sc_wsum_bwd(const sc_bf16* h, const void* g, int32_t NL, float* dw_partial /*[nblk, NL]*/, int32_t nblk,
+                int32_t B, int32_t R, int32_t D, int32_t row_off, int32_t flags, void* stream);
 /* Ragged hidden states -> uniform-pitch output (round 4): h [NL, seg->rows, D] in the segment layout; out / g [B, Rout, D] with
  * utterance b's frame t at out[b, t + row_off] for t + row_off < min(pitch_b + row_off, Rout), every other row of out is ZEROED (the
  * consumers - the CLS pooling kernels, the cascaded+/hybrid+ branches - keep a uniform [B, Rout, D] view and mask by length). */
 int sc_wsum_fwd_seg(const sc_bf16* h, const float* w, int32_t NL, sc_bf16* out, const sc_segments* seg, int32_t Rout, int32_t D,
                     int32_t row_off, int32_t normalize, void* stream);
-int sc_wsum_bwd_seg(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial /*[nblk, NL]*/, int32_t nblk,
-                    const sc_segments* seg, int32_t Rout, int32_t D, int32_t row_off, int32_t normalize, void* stream);
+int sc_wsum_bwd_seg(const sc_bf16* h, const void* g, int32_t NL, float* dw_partial /*[nblk, NL]*/, int32_t nblk,
+                    const sc_segments* seg, int32_t Rout, int32_t D, int32_t row_off, int32_t flags, void* stream);
 /* The same sums over RAW hidden states (LayerNorm folded into the encoder GEMMs, see sc_gemm_args): layers n >= first_lazy of h hold
  * the rows in FRONT of the layer's final LayerNorm; stats [NL][B*R][8][2] fp32 their row statistics (ns valid strips), gamma / beta
  * [NL][D] the LayerNorm affines (rows < first_lazy unused): the summed state is (raw - mean) rstd gamma_n + beta_n in fp32. */

@@ -170,12 +170,27 @@ __global__ __launch_bounds__(256) void wsum_fwd_kernel(const uint16_t* __restric
     }
 }
 
+// 8 consecutive gradient elements as fp32: the gradient arrives either as fp32 (autograd's default) or as bf16 rows (the attention
+// block of the cascaded+/hybrid+ branches hands its input gradient over as it leaves the GEMM: no activation-sized cast in between)
+template <typename GT>
+__device__ __forceinline__ void load_g8(const GT* gp, f32x4& g0, f32x4& g1) {
+    if constexpr (sizeof(GT) == 4) {
+        g0 = *(const f32x4*)gp;
+        g1 = *(const f32x4*)(gp + 4);
+    } else {
+        const uint4 u = *(const uint4*)gp;
+        g0 = f32x4{bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y)};
+        g1 = f32x4{bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+    }
+}
+
 // dw_partial[blk, n] = sum over this block's elements of g[b, t + row_off, d] * (h[n, b, t, d] - h[NL - 1, b, t, d])
 // The caller only uses the softmax-projected combination w_n (d_n - sum_m w_m d_m), which is invariant under a common shift of
 // the d_n: subtracting the LAST layer element-wise BEFORE the accumulation removes the large common part <g, h> that the
 // projection would cancel afterwards (the differences between layers of a residual stream are one to two orders of magnitude
 // smaller than the states themselves: summing first and subtracting later costs that many digits of the fp32 accumulators).
-__global__ __launch_bounds__(256) void wsum_bwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ g,
+template <typename GT>
+__global__ __launch_bounds__(256) void wsum_bwd_kernel(const uint16_t* __restrict__ h, const GT* __restrict__ g,
                                                        int NL, float* __restrict__ dw_partial, int B, int R, int D,
                                                        int row_off) {
     __shared__ float red[4][32];
@@ -190,8 +205,8 @@ __global__ __launch_bounds__(256) void wsum_bwd_kernel(const uint16_t* __restric
         const int cc = (int)(q % chunks_per_row);
         const int t = (int)(row % R);
         if (t + row_off >= R) continue;
-        const float* gp = g + (row + row_off) * D + cc * 8;
-        const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+        f32x4 g0, g1;
+        load_g8(g + (row + row_off) * D + cc * 8, g0, g1);
         const uint16_t* src = h + row * D + cc * 8;
         const uint4 r = *(const uint4*)(src + (int64_t)(NL - 1) * plane);
 #pragma unroll
@@ -303,8 +318,8 @@ __global__ __launch_bounds__(256) void wsum_lazy_bwd_kernel(const uint16_t* __re
         const int cc = (int)(q % chunks_per_row);
         const int t = (int)(row % R);
         if (t + row_off >= R) continue;
-        const float* gp = g + (row + row_off) * D + cc * 8;
-        const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+        f32x4 g0, g1;
+        load_g8(g + (row + row_off) * D + cc * 8, g0, g1);
         const uint16_t* src = h + row * D + cc * 8;
         float r[8];
         lazy_load8(z, src + (int64_t)(NL - 1) * plane, NL - 1, rows_total, row, D, cc, r);
@@ -407,8 +422,8 @@ __global__ __launch_bounds__(256) void wsum_norm_fwd_kernel(const uint16_t* __re
     }
 }
 
-template <int NE>
-__global__ __launch_bounds__(256) void wsum_norm_bwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ g,
+template <int NE, typename GT>
+__global__ __launch_bounds__(256) void wsum_norm_bwd_kernel(const uint16_t* __restrict__ h, const GT* __restrict__ g,
                                                             int NL, float* __restrict__ dw_partial, int B, int R, int D,
                                                             int row_off) {
     __shared__ float red[4][32];
@@ -425,8 +440,8 @@ __global__ __launch_bounds__(256) void wsum_norm_bwd_kernel(const uint16_t* __re
         for (int i = 0; i < NE; ++i) {
             const int ch = lane + i * 64;
             if (ch < nchunks) {
-                const float* gp = g + (row + row_off) * D + ch * 8;
-                const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+                f32x4 g0, g1;
+                load_g8(g + (row + row_off) * D + ch * 8, g0, g1);
                 gv[i][0] = g0[0]; gv[i][1] = g0[1]; gv[i][2] = g0[2]; gv[i][3] = g0[3];
                 gv[i][4] = g1[0]; gv[i][5] = g1[1]; gv[i][6] = g1[2]; gv[i][7] = g1[3];
             } else {
@@ -520,7 +535,8 @@ __global__ __launch_bounds__(256) void wsum_fwd_seg_kernel(const uint16_t* __res
 }
 
 // as wsum_bwd_kernel, g in the uniform [B, Rout, D] layout, h in the segment layout
-__global__ __launch_bounds__(256) void wsum_bwd_seg_kernel(const uint16_t* __restrict__ h, const float* __restrict__ g, int NL,
+template <typename GT>
+__global__ __launch_bounds__(256) void wsum_bwd_seg_kernel(const uint16_t* __restrict__ h, const GT* __restrict__ g, int NL,
                                                            float* __restrict__ dw_partial, const int32_t* __restrict__ row0, int B, int Rout,
                                                            int D, int row_off, int64_t plane) {
     __shared__ float red[4][32];
@@ -535,8 +551,8 @@ __global__ __launch_bounds__(256) void wsum_bwd_seg_kernel(const uint16_t* __res
         const int b = (int)(orow / Rout), t = (int)(orow % Rout) - row_off;
         const int r0 = row0[b], pitch = row0[b + 1] - r0;
         if (t < 0 || t >= pitch) continue;
-        const float* gp = g + orow * D + cc * 8;
-        const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+        f32x4 g0, g1;
+        load_g8(g + orow * D + cc * 8, g0, g1);
         const uint16_t* src = h + (int64_t)(r0 + t) * D + cc * 8;
         const uint4 r = *(const uint4*)(src + (int64_t)(NL - 1) * plane);
 #pragma unroll
@@ -600,8 +616,8 @@ __global__ __launch_bounds__(256) void wsum_norm_fwd_seg_kernel(const uint16_t* 
     }
 }
 
-template <int NE>
-__global__ __launch_bounds__(256) void wsum_norm_bwd_seg_kernel(const uint16_t* __restrict__ h, const float* __restrict__ g, int NL,
+template <int NE, typename GT>
+__global__ __launch_bounds__(256) void wsum_norm_bwd_seg_kernel(const uint16_t* __restrict__ h, const GT* __restrict__ g, int NL,
                                                                 float* __restrict__ dw_partial, const int32_t* __restrict__ row0, int B,
                                                                 int Rout, int D, int row_off, int64_t plane) {
     __shared__ float red[4][32];
@@ -621,8 +637,8 @@ __global__ __launch_bounds__(256) void wsum_norm_bwd_seg_kernel(const uint16_t* 
         for (int i = 0; i < NE; ++i) {
             const int ch = lane + i * 64;
             if (ch < nchunks) {
-                const float* gp = g + orow * D + ch * 8;
-                const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+                f32x4 g0, g1;
+                load_g8(g + orow * D + ch * 8, g0, g1);
                 gv[i][0] = g0[0]; gv[i][1] = g0[1]; gv[i][2] = g0[2]; gv[i][3] = g0[3];
                 gv[i][4] = g1[0]; gv[i][5] = g1[1]; gv[i][6] = g1[2]; gv[i][7] = g1[3];
             } else {
@@ -736,18 +752,29 @@ extern "C" int sc_wsum_fwd(const sc_bf16* h, const float* w, int32_t NL, sc_bf16
     return 0;
 }
 
-extern "C" int sc_wsum_bwd(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial, int32_t nblk, int32_t B,
-                           int32_t R, int32_t D, int32_t row_off, int32_t normalize, void* stream) {
-    SC_CHECK(h && g && dw_partial, "sc_wsum_bwd: null pointer");
+extern "C" int sc_wsum_bwd(const sc_bf16* h, const void* gv, int32_t NL, float* dw_partial, int32_t nblk, int32_t B,
+                           int32_t R, int32_t D, int32_t row_off, int32_t flags, void* stream) {
+    SC_CHECK(h && gv && dw_partial, "sc_wsum_bwd: null pointer");
     SC_CHECK(NL >= 1 && NL <= 32 && D % 8 == 0 && nblk >= 1 && row_off >= 0 && row_off < R, "sc_wsum_bwd: bad args");
+    SC_CHECK(((uintptr_t)gv % 16) == 0, "sc_wsum_bwd: g must be 16-byte aligned");
+    const bool normalize = flags & 1, g16 = flags & 2;         // bit 1: g is bf16
+    const float* g = (const float*)gv;
+    const uint16_t* gh = (const uint16_t*)gv;
+    hipStream_t s = (hipStream_t)stream;
     if (normalize) {
         SC_CHECK(D <= 1024, "sc_wsum_bwd: normalised variant needs D <= 1024 (got %d)", D);
-        if (D <= 512) hipLaunchKernelGGL(wsum_norm_bwd_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, h, g, NL, dw_partial, B, R, D, row_off);
-        else hipLaunchKernelGGL(wsum_norm_bwd_kernel<2>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, h, g, NL, dw_partial, B, R, D, row_off);
+        if (D <= 512) {
+            if (g16) hipLaunchKernelGGL((wsum_norm_bwd_kernel<1, uint16_t>), dim3(nblk), dim3(256), 0, s, h, gh, NL, dw_partial, B, R, D, row_off);
+            else hipLaunchKernelGGL((wsum_norm_bwd_kernel<1, float>), dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, B, R, D, row_off);
+        } else {
+            if (g16) hipLaunchKernelGGL((wsum_norm_bwd_kernel<2, uint16_t>), dim3(nblk), dim3(256), 0, s, h, gh, NL, dw_partial, B, R, D, row_off);
+            else hipLaunchKernelGGL((wsum_norm_bwd_kernel<2, float>), dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, B, R, D, row_off);
+        }
         SC_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(wsum_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, h, g, NL, dw_partial, B, R, D, row_off);
+    if (g16) hipLaunchKernelGGL(wsum_bwd_kernel<uint16_t>, dim3(nblk), dim3(256), 0, s, h, gh, NL, dw_partial, B, R, D, row_off);
+    else hipLaunchKernelGGL(wsum_bwd_kernel<float>, dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, B, R, D, row_off);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -812,21 +839,31 @@ extern "C" int sc_wsum_fwd_seg(const sc_bf16* h, const float* w, int32_t NL, sc_
     return 0;
 }
 
-extern "C" int sc_wsum_bwd_seg(const sc_bf16* h, const float* g, int32_t NL, float* dw_partial, int32_t nblk, const sc_segments* seg,
-                               int32_t Rout, int32_t D, int32_t row_off, int32_t normalize, void* stream) {
-    SC_CHECK(h && g && dw_partial && seg && seg->row0, "sc_wsum_bwd_seg: null pointer");
+extern "C" int sc_wsum_bwd_seg(const sc_bf16* h, const void* gv, int32_t NL, float* dw_partial, int32_t nblk, const sc_segments* seg,
+                               int32_t Rout, int32_t D, int32_t row_off, int32_t flags, void* stream) {
+    SC_CHECK(h && gv && dw_partial && seg && seg->row0, "sc_wsum_bwd_seg: null pointer");
+    SC_CHECK(((uintptr_t)gv % 16) == 0, "sc_wsum_bwd_seg: g must be 16-byte aligned");
+    const bool normalize = flags & 1, g16 = flags & 2;         // bit 1: g is bf16
+    const float* g = (const float*)gv;
+    const uint16_t* gh = (const uint16_t*)gv;
     SC_CHECK(NL >= 1 && NL <= 32 && D % 8 == 0 && nblk >= 1 && row_off >= 0 && Rout > row_off && seg->B > 0 && seg->rows > 0, "sc_wsum_bwd_seg: bad args");
     const int B = seg->B;
     const int64_t plane = (int64_t)seg->rows * D;
     hipStream_t s = (hipStream_t)stream;
     if (normalize) {
         SC_CHECK(D <= 1024, "sc_wsum_bwd_seg: normalised variant needs D <= 1024 (got %d)", D);
-        if (D <= 512) hipLaunchKernelGGL(wsum_norm_bwd_seg_kernel<1>, dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
-        else hipLaunchKernelGGL(wsum_norm_bwd_seg_kernel<2>, dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+        if (D <= 512) {
+            if (g16) hipLaunchKernelGGL((wsum_norm_bwd_seg_kernel<1, uint16_t>), dim3(nblk), dim3(256), 0, s, h, gh, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+            else hipLaunchKernelGGL((wsum_norm_bwd_seg_kernel<1, float>), dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+        } else {
+            if (g16) hipLaunchKernelGGL((wsum_norm_bwd_seg_kernel<2, uint16_t>), dim3(nblk), dim3(256), 0, s, h, gh, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+            else hipLaunchKernelGGL((wsum_norm_bwd_seg_kernel<2, float>), dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+        }
         SC_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(wsum_bwd_seg_kernel, dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+    if (g16) hipLaunchKernelGGL(wsum_bwd_seg_kernel<uint16_t>, dim3(nblk), dim3(256), 0, s, h, gh, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+    else hipLaunchKernelGGL(wsum_bwd_seg_kernel<float>, dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -7,6 +7,7 @@ keyword at kwClip.py:881-884; ``audio_len`` accepted as the positional name the 
 """
 import logging
 from collections import defaultdict
+from types import SimpleNamespace
 from typing import Optional, Tuple
 
 import torch
@@ -210,6 +211,23 @@ class KW_CascadedBranchPlus(GeneralBranch):
         return tuple(self.self_att.extract_hidden_states(src=audio_feat, key_padding_mask=pad))
 
 
+class _ClsSlotFn(torch.autograd.Function):
+    """Writes the CLS token into row 0 of every utterance of the encoder's output buffer [B, R, D] (in place: that slot is free,
+    weighted_sum._WeightedSumSrcFn) and returns the buffer; the CLS gradient is the batch sum of row 0's."""
+
+    @staticmethod
+    def forward(ctx, buf, cls):
+        buf[:, 0] = cls.detach().reshape(-1)
+        ctx.mark_dirty(buf)
+        ctx.cls = (cls.shape, cls.dtype)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype = ctx.cls
+        return g, g[:, 0].float().sum(0).reshape(shape).to(dtype)
+
+
 class KW_HybridBranchPlus(KW_CascadedBranchPlus):
     """kw_branches.py:780-891: one shared self-attention block over [CLS ; frames]; the CLS row is the parallel
     embedding, the frame rows feed the cascaded tail."""
@@ -227,7 +245,16 @@ class KW_HybridBranchPlus(KW_CascadedBranchPlus):
         bsz, T = audio_feat.shape[:2]
         lens = audio_feat_len.to(audio_feat.device)
         pad = get_keypadding_mask(T + 1, lens + 1)
-        src = torch.cat([self.cls.expand(bsz, -1, -1).to(audio_feat.dtype), audio_feat], dim=1)
+        from .mha_block import resident_rows
+        res = resident_rows(audio_feat)
+        if res is not None and res[1] == 1:
+            # the encoder's output rows keep a free slot in front of every utterance (weighted_sum.forward_padded): the CLS token
+            # goes there and the attention block reads [CLS ; frames] in place - no concatenated copy of the features
+            buf = _ClsSlotFn.apply(res[0], self.cls)
+            src = buf[:, : T + 1]
+            src._sc_handle = SimpleNamespace(src=buf, inplace_ok=True)
+        else:
+            src = torch.cat([self.cls.expand(bsz, -1, -1).to(audio_feat.dtype), audio_feat], dim=1)
         post = self.self_att(src=src, key_padding_mask=pad)
         output["parallel_audio_feat"] = linear_f32_autograd(post[:, :1].reshape(-1, self.audio_dim).float(), self.parallel_proj.weight,
                                                             self.parallel_proj.bias)

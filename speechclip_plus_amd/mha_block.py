@@ -50,18 +50,30 @@ class MhaNormFn(torch.autograd.Function):
     LayerNorm weight / bias [D]; constants: key_padding_mask [B, S] bool (True = padding), H, eps, p_drop (0 in eval)."""
 
     @staticmethod
-    def forward(ctx, x, Wi, bi, Wo, bo, g, beta, kpm, H, eps, p_drop, seed, p_res=0.0, seed_res=0):
-        B, S, Dm = x.shape
+    def forward(ctx, x, Wi, bi, Wo, bo, g, beta, kpm, H, eps, p_drop, seed, p_res=0.0, seed_res=0, rows=None, out_dtype=None):
+        """``rows`` = (off, S): ``x`` is the encoder's resident bf16 row buffer [B, R, Dm] (R a multiple of 64, at least ``off``
+        finite rows behind its end) and the sequence of utterance b is its rows off .. off + S - 1 - the block then reads that buffer
+        in place (row pitch R, the rows behind a sequence are masked keys) and returns the gradient in the same layout, so neither a
+        padded copy of the input nor a slice / cast of its gradient is made."""
+        dev, bf = x.device, torch.bfloat16
+        if rows is None:
+            B, S, Dm = x.shape
+            Sp = _roundup(S, 64)
+        else:
+            off, S = rows
+            B, Sp, Dm = x.shape
+            assert x.dtype == bf and x.is_contiguous() and Sp % 64 == 0 and off + S <= Sp
         dh_true = Dm // H
         assert Dm % H == 0 and Dm % 64 == 0, "d_model must be a multiple of 64 and of the head count"
-        dev, bf = x.device, torch.bfloat16
         dh = _roundup(dh_true, 64)                       # padded head dim; D = width of q, k, v and of the context
         D = H * dh
-        Sp = _roundup(S, 64)
         M = B * Sp
-        xb = torch.zeros(B, Sp, Dm, device=dev, dtype=bf)
-        xb[:, :S] = x.detach()
-        xb = xb.view(M, Dm)
+        if rows is None:
+            xb = torch.zeros(B, Sp, Dm, device=dev, dtype=bf)
+            xb[:, :S] = x.detach()
+            xb = xb.view(M, Dm)
+        else:
+            xb = torch.as_strided(x.detach(), (M, Dm), (Dm, 1), x.storage_offset() + off * Dm)
         if dh == dh_true:
             Wi_b = ops.derived(Wi, "bf16", lambda t: t.to(bf).contiguous())
             Wo_b = ops.derived(Wo, "bf16", lambda t: t.to(bf).contiguous())
@@ -95,16 +107,16 @@ class MhaNormFn(torch.autograd.Function):
         g32, b32 = g.detach().float().clone(), beta.detach().float().clone()
         out = ops.layernorm_bf16(pre, g32, b32, eps=eps)
         ctx.save_for_backward(xb, Wi_b, Wo_b, qkv, P, Pd if p_drop > 0.0 else None, cx, pre, g32)
-        ctx.meta = (B, S, Sp, D, H, dh, eps, p_drop, seed, x.dtype, Dm, dh_true, p_res, seed_res)
+        ctx.meta = (B, S, Sp, D, H, dh, eps, p_drop, seed, x.dtype, Dm, dh_true, p_res, seed_res, rows)
         # transposed bf16 copies for the input-gradient products: per parameter version when the weights are used as they are
         ctx.wT = (ops.derived(Wi, "bf16T", lambda t: t.to(bf).t().contiguous()), ops.derived(Wo, "bf16T", lambda t: t.to(bf).t().contiguous())) \
             if dh == dh_true else None
-        return out.view(B, Sp, Dm)[:, :S].to(x.dtype)
+        return out.view(B, Sp, Dm)[:, :S].to(x.dtype if out_dtype is None else out_dtype)
 
     @staticmethod
     def backward(ctx, dout):
         xb, Wi_b, Wo_b, qkv, P, Pd, cx, pre, g = ctx.saved_tensors
-        B, S, Sp, D, H, dh, eps, p_drop, seed, xdtype, Dm, dh_true, p_res, seed_res = ctx.meta
+        B, S, Sp, D, H, dh, eps, p_drop, seed, xdtype, Dm, dh_true, p_res, seed_res, rows = ctx.meta
         dev, bf = dout.device, torch.bfloat16
         M = B * Sp
         if Pd is None:
@@ -154,24 +166,57 @@ class MhaNormFn(torch.autograd.Function):
         gWi = torch.empty(3 * D, Dm, device=dev, dtype=torch.float32)
         gbi = torch.empty(3 * D, device=dev, dtype=torch.float32)
         ops.wgrad_bf16(dqkv, xb, gWi, gbi, beta=0.0)
-        dx = ops.linear_bf16(dqkv, WiT, residual=dpre)
-        dx = dx.view(B, Sp, Dm)[:, :S].to(xdtype)
+        if rows is None:
+            dx = ops.linear_bf16(dqkv, WiT, residual=dpre)
+            dx = dx.view(B, Sp, Dm)[:, :S].to(xdtype)
+        else:
+            # the gradient in the input's own layout: row m of the GEMM is row m + off of the buffer; the first ``off`` rows (the CLS
+            # slot of the cascaded layout) get no gradient, the rows behind a sequence are exact zeros (dy = 0 there and pad keys
+            # have P = 0), and the last ``off`` GEMM rows (padding of the last utterance) land behind the returned view
+            off = rows[0]
+            flat = torch.empty(M + off, Dm, device=dev, dtype=bf)
+            if off:
+                flat[:off].zero_()
+            ops.linear_bf16(dqkv, WiT, residual=dpre, out=flat[off:])
+            dx = flat[:M].view(B, Sp, Dm)
         if dh != dh_true:                                   # drop the gradients of the zero padding
             gWi = gWi.view(3, H, dh, Dm)[:, :, :dh_true].reshape(3 * Dm, Dm)
             gbi = gbi.view(3, H, dh)[:, :, :dh_true].reshape(3 * Dm)
             gWo = gWo.view(Dm, H, dh)[:, :, :dh_true].reshape(Dm, Dm)
-        return dx, gWi, gbi, gWo, gbo, dg, dbeta, None, None, None, None, None, None, None
+        return dx, gWi, gbi, gWo, gbo, dg, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def resident_rows(x: torch.Tensor):
+    """(buffer [B, R, D] bf16, off) if ``x`` is the [B, S, D] view at row offset ``off`` of an encoder output buffer the attention
+    block may read in place (weighted_sum.PaddedFeatHandle: pitch a multiple of 64, finite rows behind every sequence and behind the
+    buffer's end), else None."""
+    h = getattr(x, "_sc_handle", None)
+    if h is None or not getattr(h, "inplace_ok", False):
+        return None
+    src = h.src
+    D = src.shape[2]
+    if x.dtype != torch.bfloat16 or x.dim() != 3 or x.shape[2] != D or x.stride() != src.stride() or x.shape[0] != src.shape[0]:
+        return None
+    delta = x.storage_offset() - src.storage_offset()
+    if x.untyped_storage().data_ptr() != src.untyped_storage().data_ptr() or delta < 0 or delta % D or delta // D + x.shape[1] > src.shape[1]:
+        return None
+    return src, delta // D
 
 
 def mha_norm(x: torch.Tensor, mha: torch.nn.MultiheadAttention, norm: torch.nn.LayerNorm, key_padding_mask: torch.Tensor,
-             training: bool, p_res: float = 0.0) -> torch.Tensor:
+             training: bool, p_res: float = 0.0, out_dtype=None) -> torch.Tensor:
     """``norm(x + dropout_res(MHA(x, x, x, key_padding_mask)))``; ``p_res`` = nn.TransformerEncoderLayer's dropout1 (the bare
-    MultiheadAttentionAndNorm block has none)."""
+    MultiheadAttentionAndNorm block has none).  An ``x`` that is a view of the encoder's resident output rows is read in place."""
     p = float(mha.dropout) if training else 0.0
     p_res = float(p_res) if training else 0.0
+    res = resident_rows(x)
+    rows = None
+    if res is not None:
+        src, off = res
+        x, rows = src, (off, x.shape[1])
     return MhaNormFn.apply(x, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, norm.weight,
                            norm.bias, key_padding_mask, mha.num_heads, norm.eps, p, _next_seed() if p > 0.0 else 0,
-                           p_res, _next_seed() if p_res > 0.0 else 0)
+                           p_res, _next_seed() if p_res > 0.0 else 0, rows, out_dtype)
 
 
 class FfnNormFn(torch.autograd.Function):

@@ -208,6 +208,7 @@ class KWClip_GeneralTransformer(nn.Module):
             ds = ms.cascaded_branch.get("downsampling", None)
             width = ds.cif.get("conv_cif_width", 5) if (ds is not None and ds.type == "cif") else 5
             self.audio_encoder.tail_rows = max(1, int(width) // 2)
+            self.audio_encoder.branch_inplace = True      # the branch's attention block reads the encoder's output rows in place
         self.img_enc_proj_net = None
         self.p_branch_proj_net = None
         self.c_branch_proj_net = None

@@ -1234,17 +1234,20 @@ def wsum_bwd_logits(h: torch.Tensor, g: torch.Tensor, w_soft: torch.Tensor, B: i
     """Gradient of the weighted-sum LOGITS in two launches: the partial sums <g, h_n - h_last> per block (sc_wsum_bwd) and their
     reduction fused with the softmax backward w_n (d_n - sum_m w_m d_m) (sc_rt_softmax_bwd_reduce)."""
     NL = h.shape[0]
-    assert g.dtype == torch.float32
+    assert g.dtype in (torch.float32, torch.bfloat16) and g.is_contiguous()      # bf16: as the attention block's GEMM wrote it
+    flags = int(normalize) | (2 if g.dtype == torch.bfloat16 else 0)
     part = torch.empty(nblk, NL, device=h.device, dtype=torch.float32)
     if seg is not None:
         assert lazy is None and h.shape[1] == seg.rows and B == seg.B
-        check(lib().sc_wsum_bwd_seg(_p(h), _p(g), NL, _p(part), nblk, seg.ref(), R, D, row_off, int(normalize), _stream()), "sc_wsum_bwd_seg")
+        check(lib().sc_wsum_bwd_seg(_p(h), _p(g), NL, _p(part), nblk, seg.ref(), R, D, row_off, flags, _stream()), "sc_wsum_bwd_seg")
     elif lazy is not None:
         assert not normalize
+        if g.dtype != torch.float32:
+            g = g.float()
         check(lib().sc_wsum_lazy_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, _p(lazy.stats), _p(lazy.gamma), _p(lazy.beta),
                                      lazy.first_lazy, lazy.ns, lazy.eps, _stream()), "sc_wsum_lazy_bwd")
     else:
-        check(lib().sc_wsum_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, int(normalize), _stream()), "sc_wsum_bwd")
+        check(lib().sc_wsum_bwd(_p(h), _p(g), NL, _p(part), nblk, B, R, D, row_off, flags, _stream()), "sc_wsum_bwd")
     out = torch.empty(NL, device=h.device, dtype=torch.float32)
     check(lib().sc_rt_softmax_bwd_reduce(_p(part), nblk, NL, _p(w_soft), _p(out), _stream()), "sc_rt_softmax_bwd_reduce")
     return out

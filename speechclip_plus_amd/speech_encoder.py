@@ -169,6 +169,8 @@ class _Plan:
 
     SLACK = 64           # rows behind the last utterance that a 64-key attention tile / a conv window may read (never written)
 
+    out_align, branch_rows = 8, 0          # set per call by the encoder (_plan): output pitch granularity, zero rows behind the output
+
     def __init__(self, arch: HubertArch, B: int, L: int, device, seg_mode: bool = False):
         # seg_mode: L is the plan's CAPACITY (the longest padded batch it can hold, speech_encoder._plan buckets the batch length);
         # the geometry of the batch in flight (L, T_l, T) is set per forward by set_length - real data changes its longest
@@ -257,7 +259,8 @@ class _Plan:
         for k, v in self._rows.items():
             setattr(self, k, v[:M])
         self.hidden = self._hidden[: self.NL * M * self.D].view(self.NL, M, self.D)
-        self.Rout = seg.max_pitch if seg is not None else self.R      # uniform pitch of what leaves the encoder ([B, Rout, D])
+        # uniform pitch of what leaves the encoder ([B, Rout, D]); a multiple of 64 when a cascaded+/hybrid+ attention block reads it in place
+        self.Rout = -(-seg.max_pitch // self.out_align) * self.out_align if seg is not None else self.R
 
 
 class FairseqSpeechEncoder_Hubert(nn.Module):
@@ -297,6 +300,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self._section_ev = None                 # bench.py: a dict that receives event records (start / conv stack done) of one forward
         self.ragged = os.environ.get("SC_RAGGED", "1") == "1"
         self.tail_rows = 2
+        self.branch_inplace = False             # model.py: True when a cascaded+/hybrid+ branch consumes the output rows (see _plan)
         self._drop_calls = 0
         self.before_trainable = None            # optional callable invoked right before the first trainable module (train.py)
         self.max_audio_len = max_audio_len
@@ -430,6 +434,9 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = _Plan(self.arch, B, cap, self._dev, seg_mode=seg_mode)
         pl = self._plans[key]
+        # a cascaded+/hybrid+ attention block reads the encoder's output rows in place (mha_block.resident_rows): output pitch a
+        # multiple of 64, a few zero rows behind the buffer
+        pl.out_align, pl.branch_rows = (64, 8) if self.branch_inplace else (ops.RowSegments.GRAN, 0)
         if seg_mode:
             pl.set_length(L)
         return pl

@@ -114,7 +114,10 @@ class MultiheadAttentionAndNorm(nn.Module):
             raise RuntimeError("MultiheadAttentionAndNorm runs on the HIP kernels: device tensors only (CPU restatement: "
                                "oracle/head_ref.py)")
         from .mha_block import mha_norm
-        return mha_norm(src.float(), self.multihead_attn_layer, self.attentionBlock_Norm, key_padding_mask, self.training)
+        # (no cast of the input: the block rounds its operands to bf16 itself and reads a view of the encoder's output rows in place;
+        # the result leaves in fp32 like the reference's)
+        return mha_norm(src, self.multihead_attn_layer, self.attentionBlock_Norm, key_padding_mask, self.training,
+                        out_dtype=torch.float32)
 
     def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
         return tuple([src, self.forward(src, key_padding_mask)])

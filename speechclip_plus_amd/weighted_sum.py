@@ -30,6 +30,9 @@ class PaddedFeatHandle:
         self.plan, self.generation = plan, (plan.generation if plan is not None else None)
         self.lazy = getattr(plan, "lazy", None)      # ops.LazyStates: the hidden states are raw rows + row statistics
         self.seg = getattr(plan, "seg", None)        # ops.RowSegments: ``hidden`` is in the ragged row layout, ``src`` uniform [B, R, D]
+        # the attention block of the cascaded+/hybrid+ branches may read ``src`` in place (mha_block.resident_rows): pitch a multiple
+        # of 64, every row finite, and a few zero rows allocated behind the buffer (the cascaded layout starts one row in)
+        self.inplace_ok = bool(getattr(plan, "branch_rows", 0)) and R % 64 == 0 and src.dtype == torch.bfloat16
 
     def check_fresh(self) -> None:
         if self.plan is not None and self.plan.generation != self.generation:
@@ -66,7 +69,15 @@ class _WeightedSumSrcFn(torch.autograd.Function):
     def forward(ctx, weights, hidden, B, R, D, normalize, plan):
         ctx.plan, ctx.generation = plan, (plan.generation if plan is not None else None)
         w_soft = torch.softmax(weights.detach().float(), dim=0).contiguous()
-        src = torch.empty(B, R, D, device=hidden.device, dtype=torch.bfloat16)
+        extra = int(getattr(plan, "branch_rows", 0))       # zero rows behind the buffer for a consumer that reads it in place, shifted
+        if extra:
+            flat = torch.empty((B * R + extra) * D, device=hidden.device, dtype=torch.bfloat16)
+            flat[B * R * D:].zero_()
+            # (a tensor of its own over the front of that storage - not a view, which autograd would refuse to see modified in place
+            # when the hybrid branch writes its CLS token into row 0)
+            src = torch.empty(0, device=hidden.device, dtype=torch.bfloat16).set_(flat.untyped_storage(), 0, (B, R, D), (R * D, D, 1))
+        else:
+            src = torch.empty(B, R, D, device=hidden.device, dtype=torch.bfloat16)
         ctx.lazy = getattr(plan, "lazy", None)
         ctx.seg = getattr(plan, "seg", None)
         if ctx.seg is None:
@@ -84,7 +95,9 @@ class _WeightedSumSrcFn(torch.autograd.Function):
         if ctx.plan is not None and ctx.plan.generation != ctx.generation:
             raise RuntimeError("the encoder ran another forward with the same batch geometry before this backward (its resident "
                                "hidden states were overwritten): one outstanding forward per (B, L) plan")
-        return (ops.wsum_bwd_logits(hidden, g.float().contiguous(), w_soft, B, R, D, 1, normalize=normalize, lazy=ctx.lazy, seg=ctx.seg),
+        if not (g.is_contiguous() and g.dtype in (torch.float32, torch.bfloat16)):      # (bf16 rows as the attention block returns them)
+            g = g.float().contiguous()
+        return (ops.wsum_bwd_logits(hidden, g, w_soft, B, R, D, 1, normalize=normalize, lazy=ctx.lazy, seg=ctx.seg),
                 None, None, None, None, None, None)
 
 

@@ -341,3 +341,50 @@ def test_hybrid_plus_large_at_the_recipe_batch_of_128_with_accumulation():
         del trainer, model
         torch.cuda.empty_cache()
     assert runs[0][:2] == runs[1][:2] and torch.equal(runs[0][2], runs[1][2]), (runs[0][:2], runs[1][:2])
+
+
+@pytest.mark.parametrize("kind", ["hybrid_large", "cascaded_base"])
+def test_branch_reads_the_encoder_rows_in_place_with_identical_results(kind):
+    """The attention block of the plus branches reads the encoder's output rows in place (mha_block.resident_rows: pitch a multiple
+    of 64, the CLS token of the hybrid branch written into the free slot in front of every utterance, the gradient returned in the
+    same layout as bf16 rows): same loss, same tokens and the same gradients as the padded-copy formulation, bit for bit."""
+    from speechclip_plus_amd import mha_block
+    model, sd, o_arch, oracle = _make(kind)
+    E = 768 if kind == "hybrid_large" else 512
+    g = torch.Generator().manual_seed(11)
+    lens = [40000, 26000, 33000, 17000, 39000, 22000]
+    B = len(lens)
+    wav = torch.zeros(B, max(lens))
+    for b, l in enumerate(lens):
+        wav[b, :l] = torch.randn(l, generator=g) * 0.5
+    batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": torch.randn(B, E, generator=g).cuda(),
+             "id": torch.tensor([0, 0, 1, 2, 2, 3]).cuda()}
+    seen = []
+    real = mha_block.MhaNormFn.forward
+
+    def spy(ctx, *a):
+        seen.append(a[14] if len(a) > 14 else None)
+        return real(ctx, *a)
+
+    results = []
+    for inplace in (True, False):
+        model.audio_encoder.branch_inplace = inplace
+        model.zero_grad(set_to_none=True)
+        seen.clear()
+        mha_block.MhaNormFn.forward = staticmethod(spy)
+        try:
+            losses_, _, others = model(batch)
+        finally:
+            mha_block.MhaNormFn.forward = staticmethod(real)
+        assert (seen[0] is not None) == inplace, seen                 # (off, S) when the rows are read in place
+        if inplace:
+            assert seen[0] == ((0, 125) if kind == "hybrid_large" else (1, 124))
+        out = model.compute_loss(losses_)
+        out["loss"].backward()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        results.append((out["loss"].detach().clone(), others["vq_results"]["targets"].clone(), grads))
+    (l0, t0, g0), (l1, t1, g1) = results
+    assert torch.equal(l0, l1) and torch.equal(t0, t1)
+    assert g0.keys() == g1.keys() and len(g0) > 10
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
