@@ -389,6 +389,18 @@ int sc_cif_fwd(const float* x, const float* alpha, const float* csum, float* out
                float thr, void* stream);
 int sc_cif_bwd(const float* x, const float* alpha, const float* csum, const float* g, float* dx, float* pa, float* pb, int32_t B,
                int32_t S, int32_t C, int32_t T, float thr, void* stream);
+/* The same kernels on the ROWS of the attention block in front of CIF (round 4): x = frame 0 of utterance 0, fp32 or bf16 (x_bf16), with
+ * `xbs` elements between utterances (the block's row pitch x C) - no fp32 copy of the activations.  The gradient leaves in the dtype
+ * the frames came in, frame s of utterance b at dx + b dxbs + s C; the zlo rows in front of an utterance's frames and the zhi rows
+ * behind them are zero-filled (CLS slot / padding rows of the block's buffer). */
+int sc_cif_fwd_rows(const void* x, int32_t x_bf16, int64_t xbs, const float* alpha, const float* csum, float* out, int32_t B, int32_t S,
+                    int32_t C, int32_t T, float thr, void* stream);
+int sc_cif_bwd_rows(const void* x, int32_t x_bf16, int64_t xbs, const float* alpha, const float* csum, const float* g, void* dx,
+                    int32_t dx_bf16, int64_t dxbs, int32_t zlo, int32_t zhi, float* pa, float* pb, int32_t B, int32_t S, int32_t C, int32_t T,
+                    float thr, void* stream);
+/* buf [lead + B*P + trail, D] bf16: the rows that are not frames <- 0 (the `lead` rows in front, per utterance rows [0, head) and
+ * [stop, P), the `trail` rows behind): the zero padding a k-tap conv GEMM reads in place between utterances.  B = 0: lead + trail only. */
+int sc_rows_zero_pad_bf16(sc_bf16* buf, int32_t lead, int32_t B, int32_t P, int32_t head, int32_t stop, int32_t trail, int32_t D, void* stream);
 
 /* CIF bookkeeping on the device (avssl/module/cif.py:106-175, 244-297), one workgroup per utterance, no host round trip.
  *   sc_cif_prepare: a = clip(alpha_raw, 0, 1), padded frames (pad != 0) zeroed -> a_clip [B,S] ("orig_alpha") ; quantity = sum a ;
@@ -556,6 +568,10 @@ int sc_cif_head_fwd(const float* y, int64_t ldy, const float* w, const float* bi
 int sc_cif_head_bwd(const float* y, int64_t ldy, const float* w, const float* alpha, const float* dalpha, float* dy, int64_t lddy,
                     float* dw_partial, float* db_partial, int32_t nblk, int32_t rows, int32_t C, float p1, uint32_t seed1, float p2,
                     uint32_t seed2, void* stream);
+/* dy as bf16 rows (dy_bf16 != 0: what the input-gradient GEMM of the weight conv reads) or fp32 */
+int sc_cif_head_bwd_rows(const float* y, int64_t ldy, const float* w, const float* alpha, const float* dalpha, void* dy, int32_t dy_bf16,
+                         int64_t lddy, float* dw_partial, float* db_partial, int32_t nblk, int32_t rows, int32_t C, float p1, uint32_t seed1,
+                         float p2, uint32_t seed2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row tail of the parallel head, round 3 (csrc/rowtail.hip): the B-row products of nn.TransformerEncoderLayer + final LayerNorm +

@@ -148,6 +148,12 @@ SIGNATURES = {
     "sc_wsum_lazy_bwd": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                          c_float, c_void_p],
     "sc_cls_scores": [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_cif_fwd_rows": [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p],
+    "sc_cif_bwd_rows": [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                        c_int, c_int, ctypes.c_float, c_void_p],
+    "sc_rows_zero_pad_bf16": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "sc_cif_head_bwd_rows": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                             ctypes.c_uint32, c_float, ctypes.c_uint32, c_void_p],
     "sc_cif_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p],
     "sc_cif_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p],
     "sc_cif_prepare": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_void_p, c_void_p,

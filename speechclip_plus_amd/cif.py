@@ -34,12 +34,15 @@ class _CifFn(torch.autograd.Function):
     """(feats [B,S,C], alpha_raw [B,S]) -> (slots [B,Tc+1,C] fp32, quantity [B]); everything else rides on ``st`` (plain dict)."""
 
     @staticmethod
-    def forward(ctx, feats, alpha_raw, pad, target, st: dict):
-        x = feats.detach().float().contiguous()
+    def forward(ctx, feats, alpha_raw, pad, target, st: dict, rows=None):
+        # ``rows`` = (head, S): ``feats`` is the attention block's bf16 row buffer [B, P, C] (mha_block.BranchRows.full) and the frames
+        # of utterance b are its rows head .. head + S - 1 - read in place, gradient returned in the same layout (zero elsewhere)
+        x = feats.detach() if rows is not None else feats.detach().float().contiguous()
         a = alpha_raw.detach().float().contiguous()
         thr, Tc = st["thr"], st["T_clip"]
         r = ops.cif_prepare(a, pad, target, st["apply_scaling"], thr, st["eps"], MAX_FEAT_LEN, Tc, st["flags"])
-        out = ops.cif_fwd(x, r["alpha"], r["csum"], Tc, thr)
+        out = ops.cif_fwd(x, r["alpha"], r["csum"], Tc, thr) if rows is None else ops.cif_fwd_rows(x, rows[0], rows[1], r["alpha"], r["csum"], Tc, thr)
+        ctx.rows = rows
         st.update(r)
         if st["tail"]:                                         # inference-time tail handling
             st["feat_len_pre"] = r["feat_len"].clone()
@@ -64,10 +67,13 @@ class _CifFn(torch.autograd.Function):
             scale = torch.where((rows == fl_old) & st["extend"].bool().unsqueeze(1), st["factor"].unsqueeze(1),
                                 torch.ones((), device=g.device))
             g = g * (scale * (rows < fl_new)).unsqueeze(-1)
-        dx, pa, pb = ops.cif_bwd(x, alpha, csum, g, Tc, thr)
+        if ctx.rows is None:
+            dx, pa, pb = ops.cif_bwd(x, alpha, csum, g, Tc, thr)
+        else:
+            dx, pa, pb = ops.cif_bwd_rows(x, ctx.rows[0], ctx.rows[1], alpha, csum, g, Tc, thr)
         gq = g_q.float().contiguous() if g_q is not None else None
         da = ops.cif_prepare_bwd(pa, pb, a_clip, pad, ratio, quantity, gq, st["scaled"])
-        return dx.to(ctx.dtypes[0]), da.to(ctx.dtypes[1]), None, None, None
+        return dx.to(ctx.dtypes[0]), da.to(ctx.dtypes[1]), None, None, None, None
 
 
 class _CifHeadFn(torch.autograd.Function):
@@ -148,6 +154,64 @@ class _ConvRowsBf16Fn(torch.autograd.Function):
         return dx, gW, gb, None
 
 
+class _WeightHeadRowsFn(torch.autograd.Function):
+    """The CIF weight generator (Conv1d(C, C, k, 'same') -> Dropout -> ReLU -> Dropout -> Linear(C, 1) -> Sigmoid, cif.py:44-60) over
+    the attention block's bf16 output rows READ IN PLACE: ``full`` [B, P, C] (mha_block.BranchRows: frames of utterance b at rows
+    head .. head + S - 1, every other row of the surrounding flat buffer zero - that IS the conv's zero padding) -> alpha [B, S].
+
+    forward   y[b P + t] = sum_j x[b, t + j - p] W_j + bias : ONE strided-row GEMM (lda = C, K = k C) whose A operand starts p rows in
+              front of frame 0; the weight-head row kernel on y.
+    backward  the head kernel writes d y as bf16 rows between k zero rows; the conv's input gradient is the same kind of GEMM over
+              them with the tap-reversed weights, stored ``head`` rows further down so that it lands in the layout of ``full``
+              (rows that are not frames zeroed by one small launch); weight gradient in place (TN form) from the same views.
+    No padded copy of the frames, no fp32 copy, no cast or slice of a gradient."""
+
+    @staticmethod
+    def forward(ctx, full, conv_w, conv_b, lin_w, lin_b, head, S, pd, p1, seed1, p2, seed2):
+        B, P, C = full.shape
+        N, _, k = conv_w.shape
+        M = B * P
+        dev = full.device
+        A = torch.as_strided(full.detach(), (M, C), (C, 1), full.storage_offset() + (head - pd) * C)
+        wt = ops.derived(conv_w, "conv_rows", lambda t: t.permute(0, 2, 1).reshape(N, k * C).to(torch.bfloat16))   # [N, k C] tap-major
+        y = torch.empty(M, N, device=dev, dtype=torch.float32)
+        ops.gemm_raw(A, C, wt, k * C, y, N, M, N, k * C, bias=None if conv_b is None else conv_b.detach().float().contiguous(), out_f32=True)
+        w = ops.aligned16(lin_w.detach().float().reshape(N).contiguous())
+        b = lin_b.detach().float().reshape(1).contiguous()
+        alpha = ops.cif_head_fwd(y, w, b, p1, seed1, p2, seed2)
+        ctx.save_for_backward(full, conv_w, y, w, alpha)
+        ctx.meta = (B, P, C, N, k, pd, head, S, p1, seed1, p2, seed2, lin_w.shape, conv_b is not None)
+        return alpha.view(B, P)[:, :S]
+
+    @staticmethod
+    def backward(ctx, dalpha):
+        full, conv_w, y, w, alpha = ctx.saved_tensors
+        B, P, C, N, k, pd, head, S, p1, seed1, p2, seed2, wshape, has_bias = ctx.meta
+        M = B * P
+        dev = y.device
+        da = torch.zeros(B, P, device=dev, dtype=torch.float32)
+        da[:, :S] = dalpha
+        # d y as bf16 rows, k zero rows in front (the first utterance's left padding) and behind (the last window of the GEMM below)
+        dyb = torch.empty(M + 2 * k, N, device=dev, dtype=torch.bfloat16)
+        ops.rows_zero_pad(dyb, k, 1, M, 0, M, k)
+        _, dw, db = ops.cif_head_bwd(y, w, alpha, da.view(-1), p1, seed1, p2, seed2, dy_out=dyb[k: k + M])
+        dfull = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            # dx[m] = sum_jj dyb_row[m + p + 1 + jj] . W_{k-1-jj}; row m = b P + t is frame t, i.e. row head + t of ``full``
+            wd = ops.derived(conv_w, "conv_rows_T", lambda t: t.flip(2).permute(1, 2, 0).reshape(C, k * N).to(torch.bfloat16))
+            flat = torch.empty(M + head, C, device=dev, dtype=torch.bfloat16)
+            ops.gemm_raw(dyb[pd + 1:], N, wd, k * N, flat[head:], C, M, C, k * N)
+            ops.rows_zero_pad(flat, 0, B, P, head, head + S, head)
+            dfull = flat[:M].view(B, P, C)
+        if ctx.needs_input_grad[1]:
+            cols = torch.as_strided(full, (M, k * C), (C, 1), full.storage_offset() + (head - pd) * C)       # im2col VIEW: rows overlap
+            g2 = torch.empty(N, k * C, device=dev, dtype=torch.float32)
+            gb = torch.empty(N, device=dev, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
+            ops.wgrad_bf16(dyb[k: k + M], cols, g2, gb, beta=0.0)
+            gW = g2.view(N, k, C).permute(0, 2, 1)
+        return dfull, gW, gb, dw.view(wshape), db, None, None, None, None, None, None, None
+
+
 class CIF(nn.Module):
     def __init__(self, cif_threshold=1.0, cif_output_dim=768, encoder_embed_dim=768, produce_weight_type="conv",
                  num_layer=1, conv_cif_width=3, conv_cif_dropout=0.1, apply_scaling=True, apply_tail_handling=True,
@@ -189,12 +253,25 @@ class CIF(nn.Module):
         return {"positive_utterances": pos, "count_mismatches": mism, "calls": calls, "all_zero_calls": zero_calls,
                 "zero_quantity_utterances": zero_utts}
 
+    def rows_usable(self, br) -> bool:
+        """Can this call read the attention block's output rows (mha_block.BranchRows) in place?  Training, ONE weight-conv layer with
+        'same' padding over the block's width, and enough zero rows around the buffer for the conv's reach."""
+        last = self.conv[-3]
+        k, pd = last.kernel_size[0], last.padding[0]
+        return (br is not None and self.training and len(self.conv) == 3 and last.stride[0] == 1 and k == 2 * pd + 1 and
+                last.in_channels == br.D == last.out_channels and br.D % 64 == 0 and br.lead + br.head >= pd and br.trail >= k and
+                br.P - br.head - br.S >= pd and br.S <= 2048)
+
     def forward(self, input_dict, target_lengths=None, eps=1e-5, target_lengths_host: Optional[List[int]] = None):
-        feats = input_dict["audio_feat"]                       # B x S x C
+        br = input_dict.get("audio_feat_rows", None)           # mha_block.BranchRows: the frames as the attention block left them
+        if br is not None and not self.rows_usable(br):
+            input_dict = dict(input_dict, audio_feat=br.full[:, br.head: br.head + br.S].float())
+            br = None
+        feats = br.full if br is not None else input_dict["audio_feat"]                       # B x S x C
         if not feats.is_cuda:
             raise RuntimeError("CIF runs on the HIP kernels: device tensors only (CPU restatement: oracle/cascaded_ref.py)")
         pad = input_dict["audio_feat_pad_mask"].bool().contiguous()      # B x S, True = padding
-        B, S, C = feats.shape
+        B, S, C = (br.B, br.S, br.D) if br is not None else feats.shape
         if S > 2048 or C % 4 != 0:
             raise NotImplementedError(f"CIF kernels: at most 2048 frames per utterance and C % 4 == 0 (got S={S}, C={C})")
         if self.scaling_step >= 0 and self.apply_scaling and input_dict["global_step"] >= self.scaling_step:
@@ -207,7 +284,11 @@ class CIF(nn.Module):
         seed1 = ops.next_mult_seed() if p1 > 0 else 0
         seed2 = ops.next_mult_seed() if p2 > 0 else 0
         last = self.conv[-3]
-        if self.training and last.stride[0] == 1 and last.kernel_size[0] == 2 * last.padding[0] + 1:
+        if br is not None:
+            # the block's rows read in place: conv GEMM + weight head, forward and backward, in one autograd node
+            alpha_raw = _WeightHeadRowsFn.apply(feats, last.weight, last.bias, lin.weight, lin.bias, br.head, S, last.padding[0], p1, seed1, p2,
+                                                seed2)
+        elif self.training and last.stride[0] == 1 and last.kernel_size[0] == 2 * last.padding[0] + 1:
             # training: the last conv layer as a strided-row GEMM over the zero-padded frames; the weight head runs over the GEMM's row
             # layout (pitch S + 2p per utterance, the extra rows are dropped from alpha)
             x = self._weight_conv(feats, upto=len(self.conv) - 3)
@@ -228,12 +309,12 @@ class CIF(nn.Module):
               "tail_thr": float(self.tail_handling_firing_threshold), "flags": self.consistency_flags,
               "T_clip": T_known if T_known is not None else MAX_FEAT_LEN}
         self.consistency_flags[2:3] += 1
-        slots, quantity, feat_lengths = _CifFn.apply(feats, alpha_raw, pad, target, st)
+        slots, quantity, feat_lengths = _CifFn.apply(feats, alpha_raw, pad, target, st, (br.head, S) if br is not None else None)
         if T_known is not None:
             T = T_known
         else:
             T = int(feat_lengths.max())                        # the one host read: the returned tensor's shape is data
-        output = slots[:, :T].to(feats.dtype)
+        output = slots[:, :T].to(torch.float32 if br is not None else feats.dtype)
         fired = st["fired"].bool()
         if tail:
             # cif.py:281-283 marks, for EVERY row, the columns feat_len_j - 1 of the utterances j that fired their tail (diagnostic)

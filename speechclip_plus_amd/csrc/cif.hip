@@ -43,19 +43,31 @@ __device__ __forceinline__ void stage_meta(frame_meta* sm, const float* __restri
 
 constexpr int UNROLL = 8;
 
-__device__ __forceinline__ void load_batch(float4 (&xv)[UNROLL], const float* __restrict__ xb, int s0, int S, int C, bool active) {
+// the frames arrive as fp32 [B, S, C] or as the bf16 rows the attention block's LayerNorm wrote (round 4: row pitch of the block's
+// buffer, no fp32 copy of the activations in between); the gradient leaves the same way
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float4 ld4(const uint16_t* p) {
+    const uint2 u = *(const uint2*)p;
+    return float4{bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y)};
+}
+__device__ __forceinline__ void st4(float* p, const float4& v) { *(float4*)p = v; }
+__device__ __forceinline__ void st4(uint16_t* p, const float4& v) { *(uint2*)p = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w)); }
+
+template <typename XT>
+__device__ __forceinline__ void load_batch(float4 (&xv)[UNROLL], const XT* __restrict__ xb, int s0, int S, int C, bool active) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
-        xv[u] = (active && s0 + u < S) ? *(const float4*)(xb + (int64_t)(s0 + u) * C) : float4{0.f, 0.f, 0.f, 0.f};
+        xv[u] = (active && s0 + u < S) ? ld4(xb + (int64_t)(s0 + u) * C) : float4{0.f, 0.f, 0.f, 0.f};
 }
 
 // frames are consumed in batches of UNROLL rows; the next batch's loads are issued before the current one is processed
-__global__ __launch_bounds__(64) void cif_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+template <typename XT>
+__global__ __launch_bounds__(64) void cif_fwd_kernel(const XT* __restrict__ x, int64_t xbs, const float* __restrict__ alpha,
                                                      const float* __restrict__ csum, float* __restrict__ out, int S, int C, int T,
                                                      float thr) {
     const int b = blockIdx.y, c0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const bool active = c0 < C;
-    const float* xb = x + (int64_t)b * S * C + (active ? c0 : 0);
+    const XT* xb = x + (int64_t)b * xbs + (active ? c0 : 0);
     float* ob = out + (int64_t)b * (T + 1) * C + (active ? c0 : 0);
     __shared__ frame_meta sm[MAXS];
     float4 xv[UNROLL], xn[UNROLL];
@@ -94,14 +106,21 @@ __global__ __launch_bounds__(64) void cif_fwd_kernel(const float* __restrict__ x
     }
 }
 
-__global__ __launch_bounds__(64) void cif_bwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+// dx: frame s of utterance b at dx + b dxbs + s C; the zlo rows in front of an utterance's frames and the zhi rows behind them are
+// zero-filled (the rows of the attention block's buffer that are not frames: CLS slot, padding)
+template <typename XT, typename DT>
+__global__ __launch_bounds__(64) void cif_bwd_kernel(const XT* __restrict__ x, int64_t xbs, const float* __restrict__ alpha,
                                                      const float* __restrict__ csum, const float* __restrict__ g,
-                                                     float* __restrict__ dx, float* __restrict__ pa, float* __restrict__ pb, int B, int S,
-                                                     int C, int T, float thr) {
+                                                     DT* __restrict__ dx, int64_t dxbs, int zlo, int zhi, float* __restrict__ pa,
+                                                     float* __restrict__ pb, int B, int S, int C, int T, float thr) {
     const int b = blockIdx.y, lane = threadIdx.x, c0 = (blockIdx.x * 64 + lane) * 4;
     const bool active = c0 < C;
-    const float* xb = x + (int64_t)b * S * C + (active ? c0 : 0);
-    float* dxb = dx + (int64_t)b * S * C + (active ? c0 : 0);
+    const XT* xb = x + (int64_t)b * xbs + (active ? c0 : 0);
+    DT* dxb = dx + (int64_t)b * dxbs + (active ? c0 : 0);
+    if (active) {
+        for (int r = -zlo; r < 0; ++r) st4(dxb + (int64_t)r * C, float4{0.f, 0.f, 0.f, 0.f});
+        for (int r = S; r < S + zhi; ++r) st4(dxb + (int64_t)r * C, float4{0.f, 0.f, 0.f, 0.f});
+    }
     const float* gb = g + (int64_t)b * (T + 1) * C + (active ? c0 : 0);
     float* pab = pa + ((int64_t)blockIdx.x * B + b) * S;
     float* pbb = pb + ((int64_t)blockIdx.x * B + b) * S;
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(64) void cif_bwd_kernel(const float* __restrict__ x
                     gl = gr;
                     gn = active ? *(const float4*)(gb + (int64_t)min(m.right + 1, T) * C) : zero;
                 }
-                if (active) *(float4*)(dxb + (int64_t)s * C) = d;
+                if (active) st4(dxb + (int64_t)s * C, d);
             }
             red[2 * u][lane] = a;
             red[2 * u + 1][lane] = bq;
@@ -369,8 +388,9 @@ __global__ __launch_bounds__(256) void cif_head_fwd_kernel(const CifHead p, floa
 
 // g = dalpha a (1 - a) ; dy[row, c] = g w[c] m2 m1 [y > 0] ; dw_partial[blk][c] = sum over the block's rows of g m2 relu(m1 y) ;
 // db_partial[blk] = sum g     (rows blk * 4 + wave, + 4 gridDim.x, ... ; partials reduced in order by sc_colsum_f32)
+template <typename DT>
 __global__ __launch_bounds__(256) void cif_head_bwd_kernel(const CifHead p, const float* __restrict__ alpha, const float* __restrict__ dalpha,
-                                                           float* __restrict__ dy, int64_t lddy, float* __restrict__ dw_partial,
+                                                           DT* __restrict__ dy, int64_t lddy, float* __restrict__ dw_partial,
                                                            float* __restrict__ db_partial) {
     __shared__ float red[4][1024];
     __shared__ float redb[4];
@@ -384,7 +404,7 @@ __global__ __launch_bounds__(256) void cif_head_bwd_kernel(const CifHead p, cons
         const float g = dalpha[row] * a * (1.f - a);
         db += g;
         const float* yr = p.y + (int64_t)row * p.ldy;
-        float* dr = dy + (int64_t)row * lddy;
+        DT* dr = dy + (int64_t)row * lddy;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = lane * 4 + i * 256;
@@ -399,7 +419,7 @@ __global__ __launch_bounds__(256) void cif_head_bwd_kernel(const CifHead p, cons
                 dw[i][e] += g * m2[e] * h;
                 o[e] = h > 0.f ? g * wv[e] * m2[e] * m1[e] : 0.f;
             }
-            *(f32x4*)(dr + c) = o;
+            st4(dr + c, float4{o[0], o[1], o[2], o[3]});
         }
     }
 #pragma unroll
@@ -413,27 +433,47 @@ __global__ __launch_bounds__(256) void cif_head_bwd_kernel(const CifHead p, cons
 
 }  // namespace
 
+extern "C" int sc_cif_fwd_rows(const void* x, int32_t x_bf16, int64_t xbs, const float* alpha, const float* csum, float* out, int32_t B,
+                               int32_t S, int32_t C, int32_t T, float thr, void* stream) {
+    SC_CHECK(x && alpha && csum && out, "sc_cif_fwd: null pointer");
+    SC_CHECK(B > 0 && S > 0 && S <= MAXS && T >= 0 && C > 0 && C % 4 == 0 && thr > 0.f && xbs >= (int64_t)S * C && xbs % 4 == 0,
+             "sc_cif_fwd: B=%d S=%d (<= 2048) C=%d (C %% 4) T=%d thr=%f", B, S, C, T, (double)thr);
+    SC_CHECK(((uintptr_t)x % (x_bf16 ? 8 : 16)) == 0 && ((uintptr_t)out % 16) == 0, "sc_cif_fwd: alignment");
+    const dim3 grid((C + 255) / 256, B);
+    if (x_bf16) hipLaunchKernelGGL(cif_fwd_kernel<uint16_t>, grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)x, xbs, alpha, csum, out, S, C, T, thr);
+    else hipLaunchKernelGGL(cif_fwd_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)x, xbs, alpha, csum, out, S, C, T, thr);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sc_cif_fwd(const float* x, const float* alpha, const float* csum, float* out, int32_t B, int32_t S, int32_t C, int32_t T,
                           float thr, void* stream) {
-    SC_CHECK(x && alpha && csum && out, "sc_cif_fwd: null pointer");
-    SC_CHECK(B > 0 && S > 0 && S <= MAXS && T >= 0 && C > 0 && C % 4 == 0 && thr > 0.f,
-             "sc_cif_fwd: B=%d S=%d (<= 2048) C=%d (C %% 4) T=%d thr=%f", B, S, C, T, (double)thr);
-    SC_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0, "sc_cif_fwd: alignment");
-    hipLaunchKernelGGL(cif_fwd_kernel, dim3((C + 255) / 256, B), dim3(64), 0, (hipStream_t)stream, x, alpha, csum, out, S, C, T, thr);
+    return sc_cif_fwd_rows(x, 0, (int64_t)S * C, alpha, csum, out, B, S, C, T, thr, stream);
+}
+
+extern "C" int sc_cif_bwd_rows(const void* x, int32_t x_bf16, int64_t xbs, const float* alpha, const float* csum, const float* g, void* dx,
+                               int32_t dx_bf16, int64_t dxbs, int32_t zlo, int32_t zhi, float* pa, float* pb, int32_t B, int32_t S, int32_t C,
+                               int32_t T, float thr, void* stream) {
+    SC_CHECK(x && alpha && csum && g && dx && pa && pb, "sc_cif_bwd: null pointer");
+    SC_CHECK(B > 0 && S > 0 && S <= MAXS && T >= 0 && C > 0 && C % 4 == 0 && thr > 0.f && xbs >= (int64_t)S * C && xbs % 4 == 0 && zlo >= 0 &&
+                 zhi >= 0 && dxbs >= (int64_t)(S + zhi) * C && dxbs % 4 == 0,
+             "sc_cif_bwd: B=%d S=%d (<= 2048) C=%d (C %% 4) T=%d thr=%f", B, S, C, T, (double)thr);
+    SC_CHECK(((uintptr_t)x % (x_bf16 ? 8 : 16)) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)dx % (dx_bf16 ? 8 : 16)) == 0, "sc_cif_bwd: alignment");
+    SC_CHECK((x_bf16 != 0) == (dx_bf16 != 0), "sc_cif_bwd: the gradient leaves in the dtype the frames came in");
+    const dim3 grid((C + 255) / 256, B);
+    if (x_bf16)
+        hipLaunchKernelGGL((cif_bwd_kernel<uint16_t, uint16_t>), grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)x, xbs, alpha, csum, g,
+                           (uint16_t*)dx, dxbs, zlo, zhi, pa, pb, B, S, C, T, thr);
+    else
+        hipLaunchKernelGGL((cif_bwd_kernel<float, float>), grid, dim3(64), 0, (hipStream_t)stream, (const float*)x, xbs, alpha, csum, g, (float*)dx,
+                           dxbs, zlo, zhi, pa, pb, B, S, C, T, thr);
     SC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sc_cif_bwd(const float* x, const float* alpha, const float* csum, const float* g, float* dx, float* pa, float* pb,
                           int32_t B, int32_t S, int32_t C, int32_t T, float thr, void* stream) {
-    SC_CHECK(x && alpha && csum && g && dx && pa && pb, "sc_cif_bwd: null pointer");
-    SC_CHECK(B > 0 && S > 0 && S <= MAXS && T >= 0 && C > 0 && C % 4 == 0 && thr > 0.f,
-             "sc_cif_bwd: B=%d S=%d (<= 2048) C=%d (C %% 4) T=%d thr=%f", B, S, C, T, (double)thr);
-    SC_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)dx % 16) == 0, "sc_cif_bwd: alignment");
-    hipLaunchKernelGGL(cif_bwd_kernel, dim3((C + 255) / 256, B), dim3(64), 0, (hipStream_t)stream, x, alpha, csum, g, dx, pa, pb, B, S, C, T,
-                       thr);
-    SC_LAUNCH_CHECK();
-    return 0;
+    return sc_cif_bwd_rows(x, 0, (int64_t)S * C, alpha, csum, g, dx, 0, (int64_t)S * C, 0, 0, pa, pb, B, S, C, T, thr, stream);
 }
 
 extern "C" int sc_cif_prepare(const float* alpha_raw, int64_t lda, const uint8_t* pad, int64_t ldp, const int64_t* target,
@@ -488,14 +528,56 @@ extern "C" int sc_cif_head_fwd(const float* y, int64_t ldy, const float* w, cons
     return 0;
 }
 
+extern "C" int sc_cif_head_bwd_rows(const float* y, int64_t ldy, const float* w, const float* alpha, const float* dalpha, void* dy,
+                                    int32_t dy_bf16, int64_t lddy, float* dw_partial, float* db_partial, int32_t nblk, int32_t rows, int32_t C,
+                                    float p1, uint32_t seed1, float p2, uint32_t seed2, void* stream) {
+    SC_CHECK(y && w && alpha && dalpha && dy && dw_partial && db_partial && nblk > 0 && rows > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+             "sc_cif_head_bwd: bad args (C=%d)", C);
+    SC_CHECK(ldy % 4 == 0 && lddy % 4 == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)dy % (dy_bf16 ? 8 : 16)) == 0 && ((uintptr_t)w % 16) == 0,
+             "sc_cif_head_bwd: alignment");
+    const CifHead a = cif_head_args(y, ldy, w, nullptr, rows, C, p1, seed1, p2, seed2);
+    if (dy_bf16)
+        hipLaunchKernelGGL(cif_head_bwd_kernel<uint16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a, alpha, dalpha, (uint16_t*)dy, lddy, dw_partial, db_partial);
+    else
+        hipLaunchKernelGGL(cif_head_bwd_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a, alpha, dalpha, (float*)dy, lddy, dw_partial, db_partial);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sc_cif_head_bwd(const float* y, int64_t ldy, const float* w, const float* alpha, const float* dalpha, float* dy, int64_t lddy,
                                float* dw_partial, float* db_partial, int32_t nblk, int32_t rows, int32_t C, float p1, uint32_t seed1, float p2,
                                uint32_t seed2, void* stream) {
-    SC_CHECK(y && w && alpha && dalpha && dy && dw_partial && db_partial && nblk > 0 && rows > 0 && C > 0 && C % 4 == 0 && C <= 1024,
-             "sc_cif_head_bwd: bad args (C=%d)", C);
-    SC_CHECK(ldy % 4 == 0 && lddy % 4 == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)w % 16) == 0, "sc_cif_head_bwd: alignment");
-    const CifHead a = cif_head_args(y, ldy, w, nullptr, rows, C, p1, seed1, p2, seed2);
-    hipLaunchKernelGGL(cif_head_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a, alpha, dalpha, dy, lddy, dw_partial, db_partial);
+    return sc_cif_head_bwd_rows(y, ldy, w, alpha, dalpha, dy, 0, lddy, dw_partial, db_partial, nblk, rows, C, p1, seed1, p2, seed2, stream);
+}
+
+// rows of a [lead + B P + trail, D] bf16 row buffer that are not frames <- 0: the `lead` rows in front, per utterance the rows
+// [0, head) and [stop, P), the `trail` rows behind (the zero padding a k-tap conv GEMM reads in place between utterances)
+__global__ __launch_bounds__(256) void rows_zero_pad_kernel(uint16_t* __restrict__ buf, int lead, int B, int P, int head, int stop, int trail,
+                                                            int D) {
+    const int per = head + (P - stop), nz = lead + B * per + trail;
+    const int cpr = D >> 3;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < (int64_t)nz * cpr; q += (int64_t)gridDim.x * 256) {
+        const int z = (int)(q / cpr), c = (int)(q - (int64_t)z * cpr);
+        int row;
+        if (z < lead) row = z;
+        else if (z < lead + B * per) {
+            const int b = (z - lead) / per, r = (z - lead) - b * per;
+            row = lead + b * P + (r < head ? r : stop + (r - head));
+        } else row = lead + B * P + (z - lead - B * per);
+        *(uint4*)(buf + (int64_t)row * D + c * 8) = make_uint4(0, 0, 0, 0);
+    }
+}
+
+extern "C" int sc_rows_zero_pad_bf16(uint16_t* buf, int32_t lead, int32_t B, int32_t P, int32_t head, int32_t stop, int32_t trail, int32_t D,
+                                     void* stream) {
+    SC_CHECK(buf && lead >= 0 && B >= 0 && trail >= 0 && D > 0 && D % 8 == 0 && (B == 0 || (P > 0 && head >= 0 && head <= stop && stop <= P)),
+             "sc_rows_zero_pad_bf16: bad arguments (B=%d P=%d head=%d stop=%d D=%d)", B, P, head, stop, D);
+    SC_CHECK(((uintptr_t)buf % 16) == 0, "sc_rows_zero_pad_bf16: alignment");
+    const int64_t nz = (int64_t)lead + (int64_t)B * (head + (P - stop)) + trail;
+    if (nz == 0) return 0;
+    const int64_t chunks = nz * (D >> 3);
+    hipLaunchKernelGGL(rows_zero_pad_kernel, dim3((unsigned)((chunks + 255) / 256 < 2048 ? (chunks + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream, buf, lead, B, P, head,
+                       stop, trail, D);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -167,10 +167,13 @@ class KW_CascadedBranchPlus(GeneralBranch):
         self.downsampling = CIF(**cif_cfg)
 
     def downsampling_audio_feat(self, audio_feat, audio_feat_len, audio_feat_pad_mask, global_step: int = 0,
-                                target_len: Optional[torch.Tensor] = None) -> dict:
-        """kw_branches.py:644-699: the CIF target length is used only in training (round(len / 20) if not given)."""
+                                target_len: Optional[torch.Tensor] = None, rows=None) -> dict:
+        """kw_branches.py:644-699: the CIF target length is used only in training (round(len / 20) if not given).  ``rows``: the
+        attention block's output rows (mha_block.BranchRows) instead of ``audio_feat`` - CIF reads them in place."""
         inputs = {"audio_feat": audio_feat, "audio_feat_len": audio_feat_len, "audio_feat_pad_mask": audio_feat_pad_mask,
                   "global_step": global_step}
+        if rows is not None:
+            inputs["audio_feat_rows"] = rows
         host = None
         if not self.training:
             input_target_len = None
@@ -188,11 +191,16 @@ class KW_CascadedBranchPlus(GeneralBranch):
             res["dsample_len_diff"] = (res["dsample_feats_length"] - target_len).abs().float().mean()
         return res
 
-    def _tail(self, output, feats, feat_len, pad_mask, otherInputs):
+    def _rows_path(self, audio_feat: torch.Tensor) -> bool:
+        """train steps hand the attention block's bf16 output rows straight to CIF (no fp32 copy, no padded copies, gradients in
+        the same layout); eval and the module-level API keep the reference's tensors"""
+        return self.training and audio_feat.is_cuda and hasattr(self.self_att, "forward_rows")
+
+    def _tail(self, output, feats, feat_len, pad_mask, otherInputs, rows=None):
         otherInputs = otherInputs or {}
         ds = self.downsampling_audio_feat(audio_feat=feats, audio_feat_len=feat_len, audio_feat_pad_mask=pad_mask,
                                           target_len=otherInputs.get("target_len", None),
-                                          global_step=otherInputs.get("global_step", 0))
+                                          global_step=otherInputs.get("global_step", 0), rows=rows)
         output["dsample_results"] = ds
         vq_results, keywords = self.vq_audio_features(ds["dsample_feats"])
         output["vq_results"] = vq_results
@@ -203,6 +211,9 @@ class KW_CascadedBranchPlus(GeneralBranch):
     def forward(self, audio_feat: torch.Tensor, audio_feat_len: torch.Tensor, otherInputs: dict = {}) -> dict:
         output = defaultdict(lambda: None)
         pad = get_keypadding_mask(audio_feat.shape[1], audio_feat_len.to(audio_feat.device))
+        if self._rows_path(audio_feat):
+            rows, _ = self.self_att.forward_rows(src=audio_feat, key_padding_mask=pad)
+            return self._tail(output, None, audio_feat_len.to(audio_feat.device), pad, otherInputs, rows=rows)
         feats = self.self_att(src=audio_feat, key_padding_mask=pad)
         return self._tail(output, feats, audio_feat_len.to(audio_feat.device), pad, otherInputs)
 
@@ -255,6 +266,10 @@ class KW_HybridBranchPlus(KW_CascadedBranchPlus):
             src._sc_handle = SimpleNamespace(src=buf, inplace_ok=True)
         else:
             src = torch.cat([self.cls.expand(bsz, -1, -1).to(audio_feat.dtype), audio_feat], dim=1)
+        if self._rows_path(audio_feat):
+            rows, cls_rows = self.self_att.forward_rows(src=src, key_padding_mask=pad, n_cls=1)
+            output["parallel_audio_feat"] = linear_f32_autograd(cls_rows, self.parallel_proj.weight, self.parallel_proj.bias)
+            return self._tail(output, None, lens, pad[:, 1:], otherInputs, rows=rows)
         post = self.self_att(src=src, key_padding_mask=pad)
         output["parallel_audio_feat"] = linear_f32_autograd(post[:, :1].reshape(-1, self.audio_dim).float(), self.parallel_proj.weight,
                                                             self.parallel_proj.bias)

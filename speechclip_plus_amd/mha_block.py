@@ -33,6 +33,17 @@ def _roundup(x: int, m: int) -> int:
 
 
 _calls = 0
+ROWS_LEAD, ROWS_TRAIL = 8, 8     # zero rows in front of / behind a row buffer handed to the CIF weight conv (>= its padding / kernel width)
+
+
+class BranchRows:
+    """The attention block's output rows as the CIF module consumes them in place: ``full`` [B, P, D] bf16 (autograd output of
+    MhaNormFn, the middle of ``flat`` [lead + B P + trail, D]); the frames of utterance b are its rows head .. head + S - 1, every
+    other row of ``flat`` is zero."""
+
+    def __init__(self, full, lead, trail, head, S):
+        self.full, self.lead, self.trail, self.head, self.S = full, lead, trail, head, S
+        self.B, self.P, self.D = full.shape
 
 
 def _next_seed() -> int:
@@ -50,11 +61,16 @@ class MhaNormFn(torch.autograd.Function):
     LayerNorm weight / bias [D]; constants: key_padding_mask [B, S] bool (True = padding), H, eps, p_drop (0 in eval)."""
 
     @staticmethod
-    def forward(ctx, x, Wi, bi, Wo, bo, g, beta, kpm, H, eps, p_drop, seed, p_res=0.0, seed_res=0, rows=None, out_dtype=None):
+    def forward(ctx, x, Wi, bi, Wo, bo, g, beta, kpm, H, eps, p_drop, seed, p_res=0.0, seed_res=0, rows=None, out_dtype=None, rows_out=None):
         """``rows`` = (off, S): ``x`` is the encoder's resident bf16 row buffer [B, R, Dm] (R a multiple of 64, at least ``off``
         finite rows behind its end) and the sequence of utterance b is its rows off .. off + S - 1 - the block then reads that buffer
         in place (row pitch R, the rows behind a sequence are masked keys) and returns the gradient in the same layout, so neither a
-        padded copy of the input nor a slice / cast of its gradient is made."""
+        padded copy of the input nor a slice / cast of its gradient is made.
+
+        ``rows_out`` = n_cls (0 / 1): the block's own output rows are handed on as they are - returns the bf16 buffer [B, Sp, Dm]
+        itself (inside a flat buffer with ROWS_LEAD zero rows in front and ROWS_TRAIL behind; the n_cls leading rows of every
+        utterance and the rows from S on zeroed: the zero padding the CIF weight conv reads in place), plus the n_cls CLS rows as
+        fp32 [B, Dm]; the gradient then arrives in that layout too (bf16, zero outside the frames) and is used as it is."""
         dev, bf = x.device, torch.bfloat16
         if rows is None:
             B, S, Dm = x.shape
@@ -105,24 +121,44 @@ class MhaNormFn(torch.autograd.Function):
         # fresh copies: trainable parameters are views into the optimiser's flat buffer (4-byte aligned), the row kernels read
         # gamma / beta with 16-byte loads
         g32, b32 = g.detach().float().clone(), beta.detach().float().clone()
-        out = ops.layernorm_bf16(pre, g32, b32, eps=eps)
+        flat = None
+        if rows_out is None:
+            out = ops.layernorm_bf16(pre, g32, b32, eps=eps)
+        else:
+            flat = torch.empty(ROWS_LEAD + M + ROWS_TRAIL, Dm, device=dev, dtype=bf)
+            out = ops.layernorm_bf16(pre, g32, b32, eps=eps, out=flat[ROWS_LEAD: ROWS_LEAD + M])
         ctx.save_for_backward(xb, Wi_b, Wo_b, qkv, P, Pd if p_drop > 0.0 else None, cx, pre, g32)
-        ctx.meta = (B, S, Sp, D, H, dh, eps, p_drop, seed, x.dtype, Dm, dh_true, p_res, seed_res, rows)
+        ctx.meta = (B, S, Sp, D, H, dh, eps, p_drop, seed, x.dtype, Dm, dh_true, p_res, seed_res, rows, rows_out)
         # transposed bf16 copies for the input-gradient products: per parameter version when the weights are used as they are
         ctx.wT = (ops.derived(Wi, "bf16T", lambda t: t.to(bf).t().contiguous()), ops.derived(Wo, "bf16T", lambda t: t.to(bf).t().contiguous())) \
             if dh == dh_true else None
-        return out.view(B, Sp, Dm)[:, :S].to(x.dtype if out_dtype is None else out_dtype)
+        if rows_out is None:
+            return out.view(B, Sp, Dm)[:, :S].to(x.dtype if out_dtype is None else out_dtype)
+        n_cls = int(rows_out)
+        cls_rows = out.view(B, Sp, Dm)[:, 0].float() if n_cls else None
+        ops.rows_zero_pad(flat, ROWS_LEAD, B, Sp, n_cls, S, ROWS_TRAIL)
+        # (a tensor of its own over the middle of the flat buffer, not an autograd view)
+        full = torch.empty(0, device=dev, dtype=bf).set_(flat.untyped_storage(), ROWS_LEAD * Dm, (B, Sp, Dm), (Sp * Dm, Dm, 1))
+        return (full, cls_rows) if n_cls else full
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dcls=None):
         xb, Wi_b, Wo_b, qkv, P, Pd, cx, pre, g = ctx.saved_tensors
-        B, S, Sp, D, H, dh, eps, p_drop, seed, xdtype, Dm, dh_true, p_res, seed_res, rows = ctx.meta
-        dev, bf = dout.device, torch.bfloat16
+        B, S, Sp, D, H, dh, eps, p_drop, seed, xdtype, Dm, dh_true, p_res, seed_res, rows, rows_out = ctx.meta
+        dev, bf = pre.device, torch.bfloat16
         M = B * Sp
         if Pd is None:
             Pd = P
-        dy = torch.zeros(B, Sp, Dm, device=dev, dtype=bf)
-        dy[:, :S] = dout
+        if rows_out is None:
+            dy = torch.zeros(B, Sp, Dm, device=dev, dtype=bf)
+            dy[:, :S] = dout
+        else:
+            # the consumers (CIF weight head / integrate-and-fire, cif.py) return bf16 rows in the block's own layout, zero outside
+            # the frames; the CLS rows' gradient is added into row 0 of every utterance (this buffer belongs to the backward pass)
+            dy = dout if dout is not None else torch.zeros(B, Sp, Dm, device=dev, dtype=bf)
+            assert dy.dtype == bf and dy.is_contiguous() and tuple(dy.shape) == (B, Sp, Dm)
+            if dcls is not None:
+                dy[:, 0] += dcls.to(bf)
         dy = dy.view(M, Dm)
         # ---- LayerNorm, out_proj
         dpre, dg, dbeta = ops.layernorm_bwd(pre, dy, g, eps, want_param_grads=True)
@@ -183,7 +219,7 @@ class MhaNormFn(torch.autograd.Function):
             gWi = gWi.view(3, H, dh, Dm)[:, :, :dh_true].reshape(3 * Dm, Dm)
             gbi = gbi.view(3, H, dh)[:, :, :dh_true].reshape(3 * Dm)
             gWo = gWo.view(Dm, H, dh)[:, :, :dh_true].reshape(Dm, Dm)
-        return dx, gWi, gbi, gWo, gbo, dg, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, gWi, gbi, gWo, gbo, dg, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def resident_rows(x: torch.Tensor):
@@ -204,9 +240,11 @@ def resident_rows(x: torch.Tensor):
 
 
 def mha_norm(x: torch.Tensor, mha: torch.nn.MultiheadAttention, norm: torch.nn.LayerNorm, key_padding_mask: torch.Tensor,
-             training: bool, p_res: float = 0.0, out_dtype=None) -> torch.Tensor:
+             training: bool, p_res: float = 0.0, out_dtype=None, rows_out=None):
     """``norm(x + dropout_res(MHA(x, x, x, key_padding_mask)))``; ``p_res`` = nn.TransformerEncoderLayer's dropout1 (the bare
-    MultiheadAttentionAndNorm block has none).  An ``x`` that is a view of the encoder's resident output rows is read in place."""
+    MultiheadAttentionAndNorm block has none).  An ``x`` that is a view of the encoder's resident output rows is read in place.
+    ``rows_out`` = n_cls (0 / 1): instead of the [B, S, D] result return (BranchRows, CLS rows fp32 [B, D] or None) - the block's
+    bf16 output rows for a consumer that reads them in place (cif.CIF)."""
     p = float(mha.dropout) if training else 0.0
     p_res = float(p_res) if training else 0.0
     res = resident_rows(x)
@@ -214,9 +252,14 @@ def mha_norm(x: torch.Tensor, mha: torch.nn.MultiheadAttention, norm: torch.nn.L
     if res is not None:
         src, off = res
         x, rows = src, (off, x.shape[1])
-    return MhaNormFn.apply(x, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, norm.weight,
-                           norm.bias, key_padding_mask, mha.num_heads, norm.eps, p, _next_seed() if p > 0.0 else 0,
-                           p_res, _next_seed() if p_res > 0.0 else 0, rows, out_dtype)
+    S = rows[1] if rows is not None else x.shape[1]
+    res = MhaNormFn.apply(x, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, norm.weight,
+                          norm.bias, key_padding_mask, mha.num_heads, norm.eps, p, _next_seed() if p > 0.0 else 0,
+                          p_res, _next_seed() if p_res > 0.0 else 0, rows, out_dtype, rows_out)
+    if rows_out is None:
+        return res
+    full, cls_rows = res if rows_out else (res, None)
+    return BranchRows(full, ROWS_LEAD, ROWS_TRAIL, int(rows_out), S - int(rows_out)), cls_rows
 
 
 class FfnNormFn(torch.autograd.Function):

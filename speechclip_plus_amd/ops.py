@@ -1263,14 +1263,16 @@ def cif_head_fwd(y: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, p1: float
 
 
 def cif_head_bwd(y: torch.Tensor, w: torch.Tensor, alpha: torch.Tensor, dalpha: torch.Tensor, p1: float, seed1: int, p2: float, seed2: int,
-                 nblk: int = 512):
+                 nblk: int = 512, dy_out: Optional[torch.Tensor] = None):
     """-> dy [rows, C], dw [C], db [1]"""
     rows, C = y.shape
-    dy = torch.empty_like(y)
+    dy = torch.empty_like(y) if dy_out is None else dy_out             # dy_out: bf16 [rows, C] rows (what the conv's dgrad GEMM reads)
+    assert dy.dtype in (torch.float32, torch.bfloat16) and dy.stride(1) == 1 and tuple(dy.shape) == (rows, C)
     pw = torch.empty(nblk, C, device=y.device, dtype=torch.float32)
     pb = torch.empty(nblk, device=y.device, dtype=torch.float32)
-    check(lib().sc_cif_head_bwd(_p(y), y.stride(0), _p(w), _p(alpha), _p(dalpha), _p(dy), dy.stride(0), _p(pw), _p(pb), nblk, rows, C, float(p1),
-                                int(seed1) & 0xffffffff, float(p2), int(seed2) & 0xffffffff, _stream()), "sc_cif_head_bwd")
+    check(lib().sc_cif_head_bwd_rows(_p(y), y.stride(0), _p(w), _p(alpha), _p(dalpha), _p(dy), int(dy.dtype == torch.bfloat16), dy.stride(0), _p(pw),
+                                     _p(pb), nblk, rows, C, float(p1), int(seed1) & 0xffffffff, float(p2), int(seed2) & 0xffffffff, _stream()),
+          "sc_cif_head_bwd")
     dw = torch.empty(C, device=y.device, dtype=torch.float32)
     db = torch.empty(1, device=y.device, dtype=torch.float32)
     colsum(pw, C, nblk, C, dw)
@@ -1333,3 +1335,34 @@ def rows_scatter(d: torch.Tensor, row: torch.Tensor, M: int, SEG: int) -> torch.
     dX = torch.empty(M, W, device=d.device, dtype=torch.bfloat16)
     check(lib().sc_rows_scatter_bf16(_p(d), _p(row), _p(dX), M, B, W, SEG, _stream()), "sc_rows_scatter_bf16")
     return dX
+
+
+# ---- CIF on the rows of the attention block in front of it (bf16, the block's pitch; csrc/cif.hip) ------------------------------------
+def cif_fwd_rows(full: torch.Tensor, head: int, S: int, alpha: torch.Tensor, csum: torch.Tensor, T: int, thr: float) -> torch.Tensor:
+    """full [B, P, C] bf16 contiguous, frames of utterance b = its rows head .. head + S - 1 -> out [B, T + 1, C] fp32"""
+    B, P, C = full.shape
+    assert full.dtype == torch.bfloat16 and full.is_contiguous() and head + S <= P
+    assert alpha.dtype == torch.float32 and alpha.is_contiguous() and csum.is_contiguous() and tuple(alpha.shape) == (B, S)
+    out = torch.empty(B, T + 1, C, device=full.device, dtype=torch.float32)
+    x0 = full.view(-1)[head * C:]
+    check(lib().sc_cif_fwd_rows(_p(x0), 1, P * C, _p(alpha), _p(csum), _p(out), B, S, C, T, float(thr), _stream()), "sc_cif_fwd_rows")
+    return out
+
+
+def cif_bwd_rows(full: torch.Tensor, head: int, S: int, alpha: torch.Tensor, csum: torch.Tensor, g: torch.Tensor, T: int, thr: float):
+    """-> (d full [B, P, C] bf16: the frames' gradient, zero in every other row, pa, pb [nblk, B, S])"""
+    B, P, C = full.shape
+    assert g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == (B, T + 1, C)
+    nblk = (C + 255) // 256
+    dfull = torch.empty_like(full)
+    pa = torch.empty(nblk, B, S, device=full.device, dtype=torch.float32)
+    pb = torch.empty(nblk, B, S, device=full.device, dtype=torch.float32)
+    check(lib().sc_cif_bwd_rows(_p(full.view(-1)[head * C:]), 1, P * C, _p(alpha), _p(csum), _p(g), _p(dfull.view(-1)[head * C:]), 1, P * C, head,
+                                P - head - S, _p(pa), _p(pb), B, S, C, T, float(thr), _stream()), "sc_cif_bwd_rows")
+    return dfull, pa, pb
+
+
+def rows_zero_pad(flat: torch.Tensor, lead: int, B: int, P: int, head: int, stop: int, trail: int) -> None:
+    """flat [lead + B P + trail, D] bf16: zero the rows that are not frames (see sc_rows_zero_pad_bf16)"""
+    assert flat.dtype == torch.bfloat16 and flat.is_contiguous() and flat.shape[0] == lead + B * P + trail
+    check(lib().sc_rows_zero_pad_bf16(_p(flat), lead, B, P, head, stop, trail, flat.shape[1], _stream()), "sc_rows_zero_pad_bf16")

@@ -119,5 +119,12 @@ class MultiheadAttentionAndNorm(nn.Module):
         return mha_norm(src, self.multihead_attn_layer, self.attentionBlock_Norm, key_padding_mask, self.training,
                         out_dtype=torch.float32)
 
+    def forward_rows(self, src: torch.Tensor, key_padding_mask: torch.Tensor, n_cls: int = 0):
+        """The same block for a consumer that reads its output rows in place (the CIF module of the cascaded+/hybrid+ branches):
+        -> (mha_block.BranchRows: the bf16 output rows, frames of every utterance behind its ``n_cls`` leading rows; the CLS rows as
+        fp32 [B, D] or None).  Training path only: forward() is the module's public form."""
+        from .mha_block import mha_norm
+        return mha_norm(src, self.multihead_attn_layer, self.attentionBlock_Norm, key_padding_mask, self.training, rows_out=int(n_cls))
+
     def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
         return tuple([src, self.forward(src, key_padding_mask)])

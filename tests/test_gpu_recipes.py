@@ -388,3 +388,38 @@ def test_branch_reads_the_encoder_rows_in_place_with_identical_results(kind):
     assert g0.keys() == g1.keys() and len(g0) > 10
     for n in g0:
         assert torch.equal(g0[n], g1[n]), n
+
+
+@pytest.mark.parametrize("kind", ["hybrid_large", "cascaded_base"])
+def test_cif_reads_the_attention_rows_in_place_like_the_tensor_path(kind):
+    """Train steps hand the attention block's bf16 output rows to CIF in place (mha_block.BranchRows: weight conv as a strided-row GEMM
+    over the buffer, integrate-and-fire on bf16 rows at the block's pitch, gradients returned in that layout).  Against the tensor
+    path of the module-level API (fp32 [B, S, D] between the modules): identical loss and tokens - the forward reads the same values -
+    and gradients that differ only by the bf16 rounding of the two gradient branches before their sum."""
+    model, sd, o_arch, oracle = _make(kind)
+    E = 768 if kind == "hybrid_large" else 512
+    g = torch.Generator().manual_seed(12)
+    lens = [40000, 26000, 33000, 17000, 39000, 22000]
+    B = len(lens)
+    wav = torch.zeros(B, max(lens))
+    for b, l in enumerate(lens):
+        wav[b, :l] = torch.randn(l, generator=g) * 0.5
+    batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens), "image": torch.randn(B, E, generator=g).cuda(),
+             "id": torch.tensor([0, 0, 1, 2, 2, 3]).cuda()}
+    br = model.cascaded_branch
+    results = []
+    for rows_path in (True, False):
+        if not rows_path:
+            br._rows_path = lambda audio_feat: False
+        model.zero_grad(set_to_none=True)
+        losses_, _, others = model(batch)
+        out = model.compute_loss(losses_)
+        out["loss"].backward()
+        results.append((out["loss"].detach().clone(), others["vq_results"]["targets"].clone(),
+                        {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    del br._rows_path
+    (l0, t0, g0), (l1, t1, g1) = results
+    assert torch.equal(l0, l1) and torch.equal(t0, t1)
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        assert rel(g0[n], g1[n]) < 1e-2, (n, rel(g0[n], g1[n]))
