@@ -36,6 +36,16 @@ _calls = 0
 ROWS_LEAD, ROWS_TRAIL = 8, 8     # zero rows in front of / behind a row buffer handed to the CIF weight conv (>= its padding / kernel width)
 
 
+def grad_target(p):
+    """``p.grad`` if a backward may ADD its result into it directly (the optimiser's flat gradient buffer: fp32, dense, p's shape) -
+    the producing kernel's own reduction then accumulates (beta = 1) and the autograd node returns None for that input, which saves
+    the temporary and the AccumulateGrad add launch per parameter.  None (p.grad unset / foreign): return the gradient as usual."""
+    g = getattr(p, "grad", None)
+    if g is None or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
+        return None
+    return g if (g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device) else None
+
+
 class BranchRows:
     """The attention block's output rows as the CIF module consumes them in place: ``full`` [B, P, D] bf16 (autograd output of
     MhaNormFn, the middle of ``flat`` [lead + B P + trail, D]); the frames of utterance b are its rows head .. head + S - 1, every
@@ -128,6 +138,7 @@ class MhaNormFn(torch.autograd.Function):
             flat = torch.empty(ROWS_LEAD + M + ROWS_TRAIL, Dm, device=dev, dtype=bf)
             out = ops.layernorm_bf16(pre, g32, b32, eps=eps, out=flat[ROWS_LEAD: ROWS_LEAD + M])
         ctx.save_for_backward(xb, Wi_b, Wo_b, qkv, P, Pd if p_drop > 0.0 else None, cx, pre, g32)
+        ctx.params = (Wi, bi, Wo, bo, g, beta)
         ctx.meta = (B, S, Sp, D, H, dh, eps, p_drop, seed, x.dtype, Dm, dh_true, p_res, seed_res, rows, rows_out)
         # transposed bf16 copies for the input-gradient products: per parameter version when the weights are used as they are
         ctx.wT = (ops.derived(Wi, "bf16T", lambda t: t.to(bf).t().contiguous()), ops.derived(Wo, "bf16T", lambda t: t.to(bf).t().contiguous())) \
@@ -160,12 +171,21 @@ class MhaNormFn(torch.autograd.Function):
             if dcls is not None:
                 dy[:, 0] += dcls.to(bf)
         dy = dy.view(M, Dm)
+        # parameter gradients go straight into the optimiser's buffers where they exist (grad_target): no temporaries, no add launches
+        tWi, tbi, tWo, tbo, tg, tbeta = (grad_target(p_) if dh == dh_true else None for p_ in ctx.params)
         # ---- LayerNorm, out_proj
-        dpre, dg, dbeta = ops.layernorm_bwd(pre, dy, g, eps, want_param_grads=True)
-        gWo = torch.empty(Dm, D, device=dev, dtype=torch.float32)
-        gbo = torch.empty(Dm, device=dev, dtype=torch.float32)
+        if tg is not None and tbeta is not None:
+            dpre, dg, dbeta = ops.layernorm_bwd(pre, dy, g, eps, acc=(tg, tbeta)), None, None
+        else:
+            dpre, dg, dbeta = ops.layernorm_bwd(pre, dy, g, eps, want_param_grads=True)
         dbr = ops.dropout_bf16(dpre, p_res, seed_res) if p_res > 0.0 else dpre                # the dropped branch's gradient
-        ops.wgrad_bf16(dbr, cx, gWo, gbo, beta=0.0)
+        if tWo is not None and tbo is not None:
+            ops.wgrad_bf16(dbr, cx, tWo, tbo, beta=1.0)
+            gWo = gbo = None
+        else:
+            gWo = torch.empty(Dm, D, device=dev, dtype=torch.float32)
+            gbo = torch.empty(Dm, device=dev, dtype=torch.float32)
+            ops.wgrad_bf16(dbr, cx, gWo, gbo, beta=0.0)
         WiT, WoT = ctx.wT if ctx.wT is not None else (Wi_b.t().contiguous(), Wo_b.t().contiguous())
         dcx = ops.linear_bf16(dbr, WoT)                                                        # [M, D]
         # ---- core: dP = dctx V^T ; dS = P (dP - rowsum(P dP)) scale
@@ -199,9 +219,13 @@ class MhaNormFn(torch.autograd.Function):
             ops.gemm_raw(dST, B * H * Sp, qT, M, dqkv[:, D: 2 * D], 3 * D, Sp, dh, Sp, nb1=B, nb2=H,
                          sA=(H * Sp, Sp), sW=(Sp, dh * M), sC=(Sp * 3 * D, dh))
         # ---- in_proj (+ the residual branch's gradient)
-        gWi = torch.empty(3 * D, Dm, device=dev, dtype=torch.float32)
-        gbi = torch.empty(3 * D, device=dev, dtype=torch.float32)
-        ops.wgrad_bf16(dqkv, xb, gWi, gbi, beta=0.0)
+        if tWi is not None and tbi is not None:
+            ops.wgrad_bf16(dqkv, xb, tWi, tbi, beta=1.0)
+            gWi = gbi = None
+        else:
+            gWi = torch.empty(3 * D, Dm, device=dev, dtype=torch.float32)
+            gbi = torch.empty(3 * D, device=dev, dtype=torch.float32)
+            ops.wgrad_bf16(dqkv, xb, gWi, gbi, beta=0.0)
         if rows is None:
             dx = ops.linear_bf16(dqkv, WiT, residual=dpre)
             dx = dx.view(B, Sp, Dm)[:, :S].to(xdtype)
@@ -215,7 +239,7 @@ class MhaNormFn(torch.autograd.Function):
                 flat[:off].zero_()
             ops.linear_bf16(dqkv, WiT, residual=dpre, out=flat[off:])
             dx = flat[:M].view(B, Sp, Dm)
-        if dh != dh_true:                                   # drop the gradients of the zero padding
+        if dh != dh_true:                                   # drop the gradients of the zero padding (grad_target is off then)
             gWi = gWi.view(3, H, dh, Dm)[:, :, :dh_true].reshape(3 * Dm, Dm)
             gbi = gbi.view(3, H, dh)[:, :, :dh_true].reshape(3 * Dm)
             gWo = gWo.view(Dm, H, dh)[:, :, :dh_true].reshape(Dm, Dm)

@@ -496,15 +496,24 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 own = [conv_out_lengths(max(int(l), 400), a) for l in wav_len]
                 pl.alg_rows_l = [sum(o[i] for o in own) for i in range(len(a.conv_kernels))]
                 pl.alg_attn_flops = 4.0 * D * sum(float(o[-1]) ** 2 for o in own)
-            host = torch.tensor([list(map(int, wav_len)), valid, feat_len], dtype=torch.int64).pin_memory()
-            ints = host.to(self._dev, non_blocking=True)
-            pl.feat_len = ints[2]
+            # ONE pinned buffer, ONE copy: [wav_len i64 | feat_len i64 | valid i32 | feat_len + 1 i32] (the last = the key count of the
+            # parallel head's [CLS ; frames] as the int32 vector its kernels take); the device tensors below are views of it
+            import numpy as np
+            hb = torch.empty(24 * B, dtype=torch.uint8).pin_memory()
+            hv = hb.numpy()
+            hv[: 16 * B].view(np.int64)[:] = np.asarray([list(map(int, wav_len)), feat_len], dtype=np.int64).reshape(-1)
+            hv[16 * B:].view(np.int32)[:] = np.asarray([valid, [f + 1 for f in feat_len]], dtype=np.int32).reshape(-1)
+            db = hb.to(self._dev, non_blocking=True)
+            i64, i32 = db[: 16 * B].view(torch.int64), db[16 * B:].view(torch.int32)
+            pl.feat_len = i64[B:]
             pl.feat_len._sc_host = list(feat_len)       # host twin (length-derived integers are known before any kernel runs)
-            # key count of the parallel head ([CLS ; frames]: feat_len + 1) as the int32 vector its kernels take: uploaded here too, so the
-            # head needs no add / cast launches
-            pl.feat_len._sc_p1_i32 = torch.tensor([f + 1 for f in feat_len], dtype=torch.int32).pin_memory().to(self._dev, non_blocking=True)
-        pl.len_dev.copy_(ints[0])
-        pl.valid.copy_(ints[1])
+            pl.feat_len._sc_p1_i32 = i32[B:]
+            ints = (i64[:B], i32[:B])
+        if _USE_GRAPH:                                   # a captured graph holds the plan's own buffers
+            pl.len_dev.copy_(ints[0])
+            pl.valid.copy_(ints[1])
+        else:
+            pl.len_dev, pl.valid = ints[0], ints[1]
         # The frozen encoder is a fixed sequence of ~130 launches over the plan's resident buffers.  Opt-in (SC_ENCODER_GRAPH=1):
         # after one eager pass (which also sets the kernels' LDS attributes) it is captured into a hipGraph and replayed - one
         # launch instead of ~130.  Measured +-0 on one GPU (the host already runs a full step ahead of the device and the ~3 us
