@@ -490,6 +490,18 @@ int sc_sgemm_f32(const float* A, int64_t sai, int64_t sak, const float* Bm, int6
 int sc_layernorm_bwd_bf16(const sc_bf16* x, int64_t ldx, const sc_bf16* dy, int64_t lddy, const float* gamma, const sc_bf16* dres,
                           int64_t lddres, sc_bf16* dx, int64_t lddx, int64_t rows, int32_t D, float eps, float* dgamma_partial,
                           float* dbeta_partial, int32_t n_partial, void* stream);
+/* the same pass with what the NEXT products of a differentiated layer's backward read (round 4): dx_drop (may be NULL) = F.dropout of the
+ * stored dx with the stateless mask of element row*D + col (drop_p = 0: a plain copy is not written - pass NULL), dsum_partial
+ * [n_partial, D] (may be NULL; needs the parameter partial buffers) = partial column sums of dx_drop's values (of dx when drop_p = 0):
+ * the bias gradient of the residual branch behind this LayerNorm - no dropout launch, no column-sum pass */
+int sc_layernorm_bwd_drop_bf16(const sc_bf16* x, int64_t ldx, const sc_bf16* dy, int64_t lddy, const float* gamma, const sc_bf16* dres,
+                               int64_t lddres, sc_bf16* dx, int64_t lddx, int64_t rows, int32_t D, float eps, float* dgamma_partial,
+                               float* dbeta_partial, int32_t n_partial, sc_bf16* dx_drop, int64_t lddd, float drop_p, uint32_t drop_seed,
+                               float* dsum_partial, void* stream);
+/* out[b*R + t] = (prev ? prev[..] : 0) + bf16(w[0] * dX[b, t + row_off]) for t < T (rows t >= T: prev or 0): the gradient reaching hidden
+ * state n of a differentiated encoder = what came down from layer n + 1 + its share of the weighted sum's gradient dX (fp32 [B, R, D]) */
+int sc_wsum_share_bf16(const float* dX, const float* w, const sc_bf16* prev, sc_bf16* out, int32_t B, int32_t R, int32_t T, int32_t D,
+                       int32_t row_off, void* stream);
 int sc_act_bf16(const sc_bf16* u, const sc_bf16* df, sc_bf16* out, int64_t n, int32_t act, void* stream);
 /*   sc_transpose_bf16 : y[c, r] = x[r, c]  - operands of the weight-gradient GEMMs (dW = dY^T X: the row index becomes the
  *                       contraction dimension of sc_gemm_bf16, split along K over the batch dimension, partials in fp32)

@@ -188,6 +188,9 @@ SIGNATURES = {
                        c_void_p, c_void_p, c_void_p],
     "sc_infonce_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p,
                         c_void_p, c_void_p],
+    "sc_layernorm_bwd_drop_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_float,
+                                   c_void_p, c_void_p, c_int, c_void_p, c_i64, c_float, ctypes.c_uint32, c_void_p, c_void_p],
+    "sc_wsum_share_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "sc_layernorm_bwd_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_float,
                               c_void_p, c_void_p, c_int, c_void_p],
     "sc_conv0_gn_bwd": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

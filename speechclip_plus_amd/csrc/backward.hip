@@ -9,17 +9,22 @@ namespace {
 // Persistent over rows (row = wave_global + k * n_waves) so that each lane can also accumulate its columns' dgamma / dbeta
 // partials in registers; partial[workgroup][D] (the four waves added through LDS) is reduced by the caller (sc_colsum_f32):
 // fixed order, no atomics.
-template <int NCH>
+// EXT (the differentiated HuBERT layers): the row that leaves is also what the NEXT products of the backward read - its dropped copy
+// (the residual branch's F.dropout mask, regenerated: dx_drop, the operand of the branch's input- and weight-gradient GEMMs) and the
+// column sums of that copy (the branch's bias gradient) leave from the same pass: no dropout launch, no column-sum pass over it.
+template <int NCH, bool EXT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                             const uint16_t* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ gamma, const uint16_t* __restrict__ dres,
                                                             int64_t lddres, uint16_t* __restrict__ dx, int64_t lddx, int64_t rows,
                                                             int D, float eps, float* __restrict__ dg_part,
-                                                            float* __restrict__ db_part) {
+                                                            float* __restrict__ db_part, uint16_t* __restrict__ dx_drop, int64_t lddd,
+                                                            uint32_t drop_thr, float drop_scale, uint32_t drop_seed,
+                                                            float* __restrict__ ds_part) {
     const int lane = threadIdx.x & 63;
     const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     const int nchunks = D >> 2;
-    float ag[NCH][4], ab[NCH][4], gm[NCH][4];
+    float ag[NCH][4], ab[NCH][4], gm[NCH][4], as[EXT ? NCH : 1][4];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + i * 64;
@@ -27,6 +32,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
         for (int j = 0; j < 4; ++j) {
             ag[i][j] = 0.f;
             ab[i][j] = 0.f;
+            if (EXT) as[i][j] = 0.f;
             gm[i][j] = ch < nchunks ? gamma[ch * 4 + j] : 0.f;
         }
     }
@@ -92,11 +98,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
                 w.x = pack2bf(o[0], o[1]);
                 w.y = pack2bf(o[2], o[3]);
                 *(uint2*)(dx + row * lddx + ch * 4) = w;
+                if (EXT) {
+                    // the stored bf16 values, dropped with the mask of element row * D + column (sc_keep8: 8 flags per hash word)
+                    float d[4] = {bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y)};
+                    if (drop_thr) {
+                        const uint32_t idx = (uint32_t)row * (uint32_t)D + (uint32_t)(ch * 4);
+                        const uint32_t keep = sc_keep8(idx & ~7u, drop_seed, drop_thr) >> (idx & 4u);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) d[j] = (keep >> j) & 1u ? d[j] * drop_scale : 0.f;
+                    }
+                    uint2 wd;
+                    wd.x = pack2bf(d[0], d[1]);
+                    wd.y = pack2bf(d[2], d[3]);
+                    if (dx_drop) *(uint2*)(dx_drop + row * lddd + ch * 4) = wd;
+                    as[i][0] += bflo(wd.x); as[i][1] += bfhi(wd.x); as[i][2] += bflo(wd.y); as[i][3] += bfhi(wd.y);
+                }
             }
         }
     }
     if (dg_part) {                                   // the four waves' column partials are added through LDS: one row per workgroup
-        __shared__ float red[2][4][NCH * 256];
+        __shared__ float red[EXT ? 3 : 2][4][NCH * 256];
         const int w = threadIdx.x >> 6;
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
@@ -104,12 +125,48 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
             for (int j = 0; j < 4; ++j) {
                 red[0][w][(i * 64 + lane) * 4 + j] = ag[i][j];
                 red[1][w][(i * 64 + lane) * 4 + j] = ab[i][j];
+                if (EXT) red[2][w][(i * 64 + lane) * 4 + j] = as[i][j];
             }
         __syncthreads();
         for (int c = threadIdx.x; c < D; c += 256) {
             dg_part[(int64_t)blockIdx.x * D + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
             db_part[(int64_t)blockIdx.x * D + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+            if (EXT && ds_part) ds_part[(int64_t)blockIdx.x * D + c] = (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]);
         }
+    }
+}
+
+// out[b R + t] = (prev ? prev[b R + t] : 0) + bf16(w[0] * dX[b, t + row_off]) for t < T, prev (or 0) for the padding rows: the gradient
+// that reaches hidden state n of a differentiated encoder = what came down from layer n + 1 plus its share of the weighted sum's
+// gradient (fp32 [B, R, D], frames at row offset row_off) - one pass instead of slice + scale + cast + add.  Rounding as the
+// element-wise formulation had it: the share is rounded to bf16, the sum again.
+__global__ __launch_bounds__(256) void wsum_share_kernel(const float* __restrict__ dX, const float* __restrict__ w,
+                                                         const uint16_t* __restrict__ prev, uint16_t* __restrict__ out, int B, int R, int T,
+                                                         int D, int row_off) {
+    const int64_t per_row = D >> 3, total = (int64_t)B * R * per_row;
+    const float wn = w[0];
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t row = q / per_row;
+        const int c = (int)(q - row * per_row) * 8;
+        const int t = (int)(row % R);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (t < T && t + row_off < R) {
+            const float* gp = dX + (row + row_off) * D + c;
+            const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+            uint4 r;                                                     // the share, rounded to bf16 first
+            r.x = pack2bf(g0[0] * wn, g0[1] * wn); r.y = pack2bf(g0[2] * wn, g0[3] * wn);
+            r.z = pack2bf(g1[0] * wn, g1[1] * wn); r.w = pack2bf(g1[2] * wn, g1[3] * wn);
+            v[0] = bflo(r.x); v[1] = bfhi(r.x); v[2] = bflo(r.y); v[3] = bfhi(r.y);
+            v[4] = bflo(r.z); v[5] = bfhi(r.z); v[6] = bflo(r.w); v[7] = bfhi(r.w);
+        }
+        if (prev) {
+            const uint4 p = *(const uint4*)(prev + row * D + c);
+            v[0] += bflo(p.x); v[1] += bfhi(p.x); v[2] += bflo(p.y); v[3] += bfhi(p.y);
+            v[4] += bflo(p.z); v[5] += bfhi(p.z); v[6] += bflo(p.w); v[7] += bfhi(p.w);
+        }
+        uint4 o;
+        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+        *(uint4*)(out + row * D + c) = o;
     }
 }
 
@@ -192,13 +249,20 @@ extern "C" int sc_dropout_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* out, int6
     return 0;
 }
 
-extern "C" int sc_layernorm_bwd_bf16(const sc_bf16* x, int64_t ldx, const sc_bf16* dy, int64_t lddy, const float* gamma,
-                                     const sc_bf16* dres, int64_t lddres, sc_bf16* dx, int64_t lddx, int64_t rows, int32_t D,
-                                     float eps, float* dgamma_partial, float* dbeta_partial, int32_t n_partial, void* stream) {
+static int layernorm_bwd_launch(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, const float* gamma, const uint16_t* dres,
+                                int64_t lddres, uint16_t* dx, int64_t lddx, int64_t rows, int32_t D, float eps, float* dgamma_partial,
+                                float* dbeta_partial, int32_t n_partial, bool ext, uint16_t* dx_drop, int64_t lddd, float drop_p,
+                                uint32_t drop_seed, float* dsum_partial, void* stream) {
     SC_CHECK(x && dy && gamma && dx, "sc_layernorm_bwd_bf16: null pointer");
     SC_CHECK(rows > 0 && D > 0 && D % 4 == 0 && D <= 1024, "sc_layernorm_bwd_bf16: D=%d must be a multiple of 4, <= 1024", D);
     SC_CHECK(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (dres == nullptr || lddres % 4 == 0), "sc_layernorm_bwd_bf16: leading dims");
     SC_CHECK((dgamma_partial == nullptr) == (dbeta_partial == nullptr), "sc_layernorm_bwd_bf16: both partial buffers or none");
+    if (ext) {
+        SC_CHECK(drop_p >= 0.f && drop_p < 1.f && (dx_drop == nullptr || lddd % 4 == 0) && (dsum_partial == nullptr || dgamma_partial != nullptr) &&
+                     (drop_p == 0.f || (rows * (int64_t)D < ((int64_t)1 << 32) && D % 8 == 0)),
+                 "sc_layernorm_bwd_drop_bf16: p=%f, column sums need the parameter partial buffers, dropout needs rows * D < 2^32 and D %% 8 == 0",
+                 (double)drop_p);
+    }
     // with partial sums the caller's buffers fix the workgroup count (n_partial rows of D floats each)
     int grid;
     if (dgamma_partial) {
@@ -209,15 +273,52 @@ extern "C" int sc_layernorm_bwd_bf16(const sc_bf16* x, int64_t ldx, const sc_bf1
     }
     hipStream_t s = (hipStream_t)stream;
     const int nch = (D / 4 + 63) / 64;
-#define SC_LNB(N) hipLaunchKernelGGL((layernorm_bwd_kernel<N>), dim3(grid), dim3(256), 0, s, x, ldx, dy, lddy, gamma, dres, lddres, dx, \
-                                     lddx, rows, D, eps, dgamma_partial, dbeta_partial)
-    switch (nch) {
-        case 1: SC_LNB(1); break;
-        case 2: SC_LNB(2); break;
-        case 3: SC_LNB(3); break;
-        default: SC_LNB(4); break;
+    const uint32_t thr = ext ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
+    const float scale = ext && drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#define SC_LNB(N, E) hipLaunchKernelGGL((layernorm_bwd_kernel<N, E>), dim3(grid), dim3(256), 0, s, x, ldx, dy, lddy, gamma, dres, lddres, dx, \
+                                        lddx, rows, D, eps, dgamma_partial, dbeta_partial, dx_drop, lddd, thr, scale, drop_seed, dsum_partial)
+    if (ext) {
+        switch (nch) {
+            case 1: SC_LNB(1, true); break;
+            case 2: SC_LNB(2, true); break;
+            case 3: SC_LNB(3, true); break;
+            default: SC_LNB(4, true); break;
+        }
+    } else {
+        switch (nch) {
+            case 1: SC_LNB(1, false); break;
+            case 2: SC_LNB(2, false); break;
+            case 3: SC_LNB(3, false); break;
+            default: SC_LNB(4, false); break;
+        }
     }
 #undef SC_LNB
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_layernorm_bwd_bf16(const sc_bf16* x, int64_t ldx, const sc_bf16* dy, int64_t lddy, const float* gamma,
+                                     const sc_bf16* dres, int64_t lddres, sc_bf16* dx, int64_t lddx, int64_t rows, int32_t D,
+                                     float eps, float* dgamma_partial, float* dbeta_partial, int32_t n_partial, void* stream) {
+    return layernorm_bwd_launch(x, ldx, dy, lddy, gamma, dres, lddres, dx, lddx, rows, D, eps, dgamma_partial, dbeta_partial, n_partial, false,
+                                nullptr, 0, 0.f, 0u, nullptr, stream);
+}
+
+extern "C" int sc_layernorm_bwd_drop_bf16(const sc_bf16* x, int64_t ldx, const sc_bf16* dy, int64_t lddy, const float* gamma,
+                                          const sc_bf16* dres, int64_t lddres, sc_bf16* dx, int64_t lddx, int64_t rows, int32_t D,
+                                          float eps, float* dgamma_partial, float* dbeta_partial, int32_t n_partial, sc_bf16* dx_drop,
+                                          int64_t lddd, float drop_p, uint32_t drop_seed, float* dsum_partial, void* stream) {
+    return layernorm_bwd_launch(x, ldx, dy, lddy, gamma, dres, lddres, dx, lddx, rows, D, eps, dgamma_partial, dbeta_partial, n_partial, true,
+                                dx_drop, lddd, drop_p, drop_seed, dsum_partial, stream);
+}
+
+extern "C" int sc_wsum_share_bf16(const float* dX, const float* w, const sc_bf16* prev, sc_bf16* out, int32_t B, int32_t R, int32_t T, int32_t D,
+                                  int32_t row_off, void* stream) {
+    SC_CHECK(dX && w && out && B > 0 && R > 0 && T >= 0 && T <= R && D > 0 && D % 8 == 0 && row_off >= 0, "sc_wsum_share_bf16: bad arguments");
+    SC_CHECK(((uintptr_t)dX % 16) == 0 && ((uintptr_t)out % 16) == 0 && (prev == nullptr || ((uintptr_t)prev % 16) == 0), "sc_wsum_share_bf16: alignment");
+    const int64_t total = (int64_t)B * R * (D >> 3);
+    hipLaunchKernelGGL(wsum_share_kernel, dim3((unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384)), dim3(256), 0, (hipStream_t)stream, dX, w,
+                       prev, out, B, R, T, D, row_off);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -179,25 +179,27 @@ class TrainableLayers(nn.Module):
         B, R, M, T = pl.B, pl.R, pl.M, pl.T
         D = a.embed_dim
         lo = self.ids[0]
-        dfeat = torch.zeros(B, R, D, device=dX.device, dtype=torch.float32)
-        dfeat[:, :T] = dX[:, 1: T + 1]
-        dfeat = dfeat.view(M, D)
+        dX = dX.float().contiguous()
         ones = torch.ones(D, device=dX.device, dtype=torch.float32) if normalize else None
+
+        def add_share(n: int, d_prev):
+            # d hidden[n] = what came down from the layer above + this state's share of the weighted sum's gradient (frames of dX at
+            # row offset 1), one pass (sc_wsum_share_bf16); with ``normalize`` the share passes the state's non-affine LayerNorm first
+            # and the sum rides on that kernel's residual input
+            if not normalize:
+                return ops.wsum_share(dX, w_soft[n: n + 1], d_prev, B, R, T)
+            g = ops.wsum_share(dX, w_soft[n: n + 1], None, B, R, T)
+            return ops.layernorm_bwd(pl.hidden[n], g, ones, 1e-5, dres=d_prev)
+
         d_out = None
         for i in range(a.layers - 1, lo - 1, -1):
-            g = (dfeat * w_soft[i + 1]).to(torch.bfloat16)                 # d hidden[i + 1] from the weighted sum
-            if normalize:
-                g = ops.layernorm_bwd(pl.hidden[i + 1], g, ones, 1e-5)
-            d_out = g if d_out is None else d_out + g
+            d_out = add_share(i + 1, d_out)
             assert i in pl.train, "unfrozen layers ran without saved activations (forward in eval / no_grad mode?)"
             d_out = self._layer_backward(i, pl, d_out, need_dx=i > lo or self.frontend is not None, train=i in self.ids)
             if self.grad_ready_hook is not None and i in self.ids:
                 self.grad_ready_hook(i)
         if self.frontend is not None:                      # lo == 0: on into the front end with d hidden[0]
-            g = (dfeat * w_soft[0]).to(torch.bfloat16)
-            if normalize:
-                g = ops.layernorm_bwd(pl.hidden[0], g, ones, 1e-5)
-            self.frontend.backward_frontend(pl, d_out + g)
+            self.frontend.backward_frontend(pl, add_share(0, d_out))
 
     def _layer_backward(self, i: int, pl, d_out: torch.Tensor, need_dx: bool, train: bool = True):
         a, c, s = self.arch, self._copies[i], pl.train[i]
@@ -207,36 +209,48 @@ class TrainableLayers(nn.Module):
         pre_ln = a.layer_norm_first
         P = lambda name: _gacc(self.get(i, name))
 
-        def ln_bwd(xin, dy, which, dres=None):                             # LayerNorm backward (+ its parameter gradients)
+        def ln_bwd(xin, dy, which, dres=None, branch=None):                # LayerNorm backward (+ its parameter gradients)
+            # ``branch`` = (linear layer, seed): the output is next read by that layer's residual branch - the same pass also writes
+            # its dropped copy (the branch's F.dropout mask, regenerated) and adds the copy's column sums into the layer's bias gradient
+            # (ops.layernorm_bwd drop / sum_acc): returns (dx, dx_dropped)
             gname = "self_attn_layer_norm" if which == 1 else "final_layer_norm"
-            if not train:
-                return ops.layernorm_bwd(xin, dy, c[f"ln{which}_g"], 1e-5, dres=dres)
-            return ops.layernorm_bwd(xin, dy, c[f"ln{which}_g"], 1e-5, dres=dres, acc=(P(gname + ".weight"), P(gname + ".bias")))
-
-        def wgrad(dy, xin, name):
+            kw = {}
             if train:
-                ops.wgrad_bf16(dy, xin, P(name + ".weight"), P(name + ".bias"))
+                kw["acc"] = (P(gname + ".weight"), P(gname + ".bias"))
+            if branch is None:
+                return ops.layernorm_bwd(xin, dy, c[f"ln{which}_g"], 1e-5, dres=dres, **kw)
+            name, seed = branch
+            if train:
+                kw["sum_acc"] = P(name + ".bias")
+            if p_res > 0.0:
+                return ops.layernorm_bwd(xin, dy, c[f"ln{which}_g"], 1e-5, dres=dres, drop=(p_res, seed), **kw)
+            dx_ = ops.layernorm_bwd(xin, dy, c[f"ln{which}_g"], 1e-5, dres=dres, **kw)
+            return dx_, dx_
+
+        def wgrad(dy, xin, name, bias=True):
+            if train:
+                ops.wgrad_bf16(dy, xin, P(name + ".weight"), P(name + ".bias") if bias else None)
 
         p_res, p_att, sd_a, sd_o, sd_f = s.get("drops", (0.0, 0.0, 0, 0, 0))
         # ---- FFN half
+        # gradient of the dropped branch = the same mask on the sum's gradient; the residual path keeps the un-masked one
         if pre_ln:                                                          # out = pre1 + drop(fc2(gelu(fc1(LN2(pre1)))))
             dffn_out, ffn_in = d_out, s["pre2"]
+            dfc2 = ops.dropout_bf16(dffn_out, p_res, sd_f) if p_res > 0.0 else dffn_out
+            wgrad(dfc2, s["f"], "fc2")
         else:                                                               # out = LN2(pre2), pre2 = x1 + drop(fc2(gelu(fc1(x1))))
-            dffn_out, ffn_in = ln_bwd(s["pre2"], d_out, 2), s["x1"]
-        # gradient of the dropped branch = the same mask on the sum's gradient; the residual path keeps the un-masked one
-        dfc2 = ops.dropout_bf16(dffn_out, p_res, sd_f) if p_res > 0.0 else dffn_out
-        wgrad(dfc2, s["f"], "fc2")
+            (dffn_out, dfc2), ffn_in = ln_bwd(s["pre2"], d_out, 2, branch=("fc2", sd_f)), s["x1"]
+            wgrad(dfc2, s["f"], "fc2", bias=False)
         du = ops.linear_bf16(dfc2, c["fc2_wT"], act=1, aux=s["u"], aux_mode=2)          # (dfc2 W2) * gelu'(u) in the GEMM's epilogue
         wgrad(du, ffn_in, "fc1")
         if pre_ln:
             dx2n = ops.linear_bf16(du, c["fc1_wT"])
-            dpre1 = ln_bwd(s["pre1"], dx2n, 2, dres=d_out)                  # through LN2 + the residual
+            dpre1, dop = ln_bwd(s["pre1"], dx2n, 2, dres=d_out, branch=("self_attn.out_proj", sd_o))      # through LN2 + the residual
         else:
             dx1 = ops.linear_bf16(du, c["fc1_wT"], residual=dffn_out)
-            dpre1 = ln_bwd(s["pre1"], dx1, 1)
+            dpre1, dop = ln_bwd(s["pre1"], dx1, 1, branch=("self_attn.out_proj", sd_o))
         # ---- attention half:  pre1 = x + out_proj(attn(qkv(attn_in)))
-        dop = ops.dropout_bf16(dpre1, p_res, sd_o) if p_res > 0.0 else dpre1
-        wgrad(dop, s["ctx"], "self_attn.out_proj")
+        wgrad(dop, s["ctx"], "self_attn.out_proj", bias=False)
         dctx = ops.linear_bf16(dop, c["o_wT"])
         dqkv = torch.empty(M, 3 * D, device=x.device, dtype=torch.bfloat16)
         qkv = s["qkv"]

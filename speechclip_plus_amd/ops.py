@@ -310,34 +310,56 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
 
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float, dres: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None, want_param_grads: bool = False, acc=None):
+                  out: Optional[torch.Tensor] = None, want_param_grads: bool = False, acc=None, drop=None, sum_acc: Optional[torch.Tensor] = None):
     """dx = LN'(x)(dy) (+ dres) for bf16 rows; with ``want_param_grads`` also returns (dgamma, dbeta) fp32.
     ``acc`` = (dgamma_target, dbeta_target): the parameter gradients are ADDED to these fp32 [D] tensors by the reduction itself (no
-    temporaries, no add launches); returns dx only."""
+    temporaries, no add launches); returns dx only.
+    ``drop`` = (p, seed): also returns F.dropout(dx) with the stateless mask of element row * D + col (the residual branch's operand) -
+    result (dx, dx_dropped); ``sum_acc`` fp32 [D]: the column sums of that dropped copy (of dx without ``drop``) are ADDED to it (the
+    branch's bias gradient; needs ``acc`` / ``want_param_grads``).  One pass (sc_layernorm_bwd_drop_bf16)."""
     want_param_grads = want_param_grads or acc is not None
     rows, D = x.shape
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and gamma.dtype == torch.float32
     if out is None:
         out = torch.empty(rows, D, device=x.device, dtype=torch.bfloat16)
-    dg = db = None
+    dg = db = ds = None
     n_part = 0
     if want_param_grads:
         n_part = min(1024, (rows + 3) // 4)             # one partial row per workgroup (its four waves are added in LDS)
         dg = torch.empty(n_part, D, device=x.device, dtype=torch.float32)
         db = torch.empty(n_part, D, device=x.device, dtype=torch.float32)
-    check(lib().sc_layernorm_bwd_bf16(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(dres), 0 if dres is None else dres.stride(0),
-                                      _p(out), out.stride(0), rows, D, float(eps), _p(dg), _p(db), n_part, _stream()),
-          "sc_layernorm_bwd_bf16")
+    ext = drop is not None or sum_acc is not None
+    out_drop = None
+    if ext:
+        p, seed = drop if drop is not None else (0.0, 0)
+        if p > 0.0:
+            out_drop = torch.empty(rows, D, device=x.device, dtype=torch.bfloat16)
+        if sum_acc is not None:
+            assert want_param_grads, "the column sums ride on the parameter-gradient partials"
+            ds = torch.empty(n_part, D, device=x.device, dtype=torch.float32)
+        check(lib().sc_layernorm_bwd_drop_bf16(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(dres), 0 if dres is None else dres.stride(0),
+                                               _p(out), out.stride(0), rows, D, float(eps), _p(dg), _p(db), n_part, _p(out_drop),
+                                               D if out_drop is not None else 0, float(p), int(seed) & 0xffffffff, _p(ds), _stream()),
+              "sc_layernorm_bwd_drop_bf16")
+        if sum_acc is not None:
+            colsum(ds, D, n_part, D, sum_acc, beta=1.0)
+        if out_drop is None:
+            out_drop = out
+    else:
+        check(lib().sc_layernorm_bwd_bf16(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(dres), 0 if dres is None else dres.stride(0),
+                                          _p(out), out.stride(0), rows, D, float(eps), _p(dg), _p(db), n_part, _stream()),
+              "sc_layernorm_bwd_bf16")
+    res = (out, out_drop) if drop is not None else out
     if not want_param_grads:
-        return out
+        return res
     if acc is not None:
         colsum(dg, D, n_part, D, acc[0], beta=1.0)
         colsum(db, D, n_part, D, acc[1], beta=1.0)
-        return out
+        return res
     g, b = torch.empty(D, device=x.device, dtype=torch.float32), torch.empty(D, device=x.device, dtype=torch.float32)
     colsum(dg, D, n_part, D, g)
     colsum(db, D, n_part, D, b)
-    return out, g, b
+    return (res, g, b) if drop is not None else (out, g, b)
 
 
 def transpose_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None, colsum_partial: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -1366,3 +1388,14 @@ def rows_zero_pad(flat: torch.Tensor, lead: int, B: int, P: int, head: int, stop
     """flat [lead + B P + trail, D] bf16: zero the rows that are not frames (see sc_rows_zero_pad_bf16)"""
     assert flat.dtype == torch.bfloat16 and flat.is_contiguous() and flat.shape[0] == lead + B * P + trail
     check(lib().sc_rows_zero_pad_bf16(_p(flat), lead, B, P, head, stop, trail, flat.shape[1], _stream()), "sc_rows_zero_pad_bf16")
+
+
+def wsum_share(dX: torch.Tensor, w: torch.Tensor, prev: Optional[torch.Tensor], B: int, R: int, T: int, row_off: int = 1) -> torch.Tensor:
+    """[B R, D] bf16 = (prev or 0) + bf16(w * dX[b, t + row_off]) for the frames t < T (sc_wsum_share_bf16): dX fp32 [B, R, D], w a
+    one-element fp32 device tensor (one softmax weight of the weighted sum)"""
+    D = dX.shape[-1]
+    assert dX.dtype == torch.float32 and dX.is_contiguous() and w.dtype == torch.float32 and w.numel() == 1
+    assert prev is None or (prev.dtype == torch.bfloat16 and prev.is_contiguous() and prev.numel() == B * R * D)
+    out = torch.empty(B * R, D, device=dX.device, dtype=torch.bfloat16)
+    check(lib().sc_wsum_share_bf16(_p(dX), _p(w), _p(prev), _p(out), B, R, T, D, row_off, _stream()), "sc_wsum_share_bf16")
+    return out

@@ -1359,3 +1359,44 @@ def test_conv_overlap_add_with_activation_backward(dev):
     u = torch.randn(2 * M, C, generator=g).to(torch.bfloat16).to(dev)
     ref = ops.act_bf16(u, 1, df=ops.conv_overlap_add(dcols, C))
     assert torch.equal(ops.conv_overlap_add(dcols, C, u=u), ref)
+
+
+@pytest.mark.gpu
+def test_layernorm_bwd_with_dropped_copy_and_column_sums(dev):
+    """sc_layernorm_bwd_drop_bf16: the same dx as the plain kernel, its dropped copy bit-identical to sc_dropout_bf16 of that dx (the
+    stateless mask of element row * D + col), and the copy's column sums accumulated into a bias-gradient target (fp32, vs fp64)."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(31)
+    for rows, D, p in ((1000, 768, 0.1), (515, 1024, 0.25), (300, 512, 0.0)):
+        x = bf(torch.randn(rows, D, generator=g)).to(dev)
+        dy = bf(torch.randn(rows, D, generator=g)).to(dev)
+        res = bf(torch.randn(rows, D, generator=g)).to(dev)
+        gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+        ref_dx, ref_g, ref_b = ops.layernorm_bwd(x, dy, gamma, 1e-5, dres=res, want_param_grads=True)
+        acc = (torch.full((D,), 2.0, device=dev), torch.full((D,), -1.0, device=dev))
+        bias = torch.full((D,), 0.5, device=dev)
+        if p > 0:
+            dx, dxd = ops.layernorm_bwd(x, dy, gamma, 1e-5, dres=res, acc=acc, drop=(p, 777), sum_acc=bias)
+            assert torch.equal(dxd, ops.dropout_bf16(dx, p, 777))
+        else:
+            dx = dxd = ops.layernorm_bwd(x, dy, gamma, 1e-5, dres=res, acc=acc, sum_acc=bias)
+        assert torch.equal(dx, ref_dx)
+        assert rel_l2(acc[0] - 2.0, ref_g) < 1e-5 and rel_l2(acc[1] + 1.0, ref_b) < 1e-5
+        assert rel_l2(bias - 0.5, dxd.double().sum(0).float()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_weighted_sum_share_kernel(dev):
+    """sc_wsum_share_bf16 = the element-wise formulation it replaces: slice the frames out of dX, scale by one softmax weight, round to
+    bf16, add to what came down from the layer above (bf16 add), padding rows untouched - bit-identical."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(32)
+    B, R, T, D = 3, 128, 99, 768
+    dX = torch.randn(B, R, D, generator=g).to(dev)
+    w = torch.tensor([0.3, 0.0721, 0.6], device=dev)
+    prev = bf(torch.randn(B * R, D, generator=g)).to(dev)
+    dfeat = torch.zeros(B, R, D, device=dev)
+    dfeat[:, :T] = dX[:, 1: T + 1]
+    share = (dfeat.view(B * R, D) * w[1]).to(torch.bfloat16)
+    assert torch.equal(ops.wsum_share(dX, w[1:2], None, B, R, T), share)
+    assert torch.equal(ops.wsum_share(dX, w[1:2], prev, B, R, T), prev + share)

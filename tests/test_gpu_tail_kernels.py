@@ -342,3 +342,75 @@ def test_prompt_assembly_kernels_match_the_elementwise_formulation():
     dk = ops.prompt_assemble_bwd(dXr, count, B, N, SEG, n_pos)
     live = (torch.arange(N, device=dev).unsqueeze(0) + 1 < torch.clamp(index, max=n_pos).unsqueeze(1)).unsqueeze(-1)
     assert torch.equal(dk, torch.where(live, dXr.view(Bp, SEG, W)[:B, 1: 1 + N].float(), torch.zeros((), device=dev)))
+
+
+@pytest.mark.gpu
+def test_cif_row_kernels_match_the_fp32_tensor_kernels():
+    """sc_cif_fwd_rows / sc_cif_bwd_rows (bf16 rows at the attention block's pitch, frames behind ``head`` leading rows) against
+    sc_cif_fwd / sc_cif_bwd on the fp32 copy of the same frames: identical slots (fp32 accumulation of the same values), gradient =
+    the fp32 one rounded to bf16 in the frames' rows and exact zeros in every other row; sc_rows_zero_pad_bf16 on the way."""
+    from speechclip_plus_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    for B, P, head, S, C, Tc in ((5, 128, 1, 99, 768, 9), (3, 64, 0, 64, 1024, 5), (4, 192, 1, 150, 256, 12)):
+        lead, trail = 8, 8
+        flat = torch.randn(lead + B * P + trail, C, generator=g).to(torch.bfloat16).to(dev)
+        ref = flat.clone()
+        ops.rows_zero_pad(flat, lead, B, P, head, head + S, trail)
+        keep = torch.zeros(lead + B * P + trail, dtype=torch.bool, device=dev)
+        for b in range(B):
+            keep[lead + b * P + head: lead + b * P + head + S] = True
+        assert torch.equal(flat[keep], ref[keep]) and float(flat[~keep].float().abs().max()) == 0.0
+        full = flat[lead: lead + B * P].view(B, P, C)
+        x32 = full[:, head: head + S].float().contiguous()
+        alpha = (torch.rand(B, S, generator=g) * (Tc / S) * 1.6).to(dev)
+        csum = alpha.cumsum(1).contiguous()
+        out = ops.cif_fwd_rows(full, head, S, alpha, csum, Tc, 1.0)
+        assert torch.equal(out, ops.cif_fwd(x32, alpha, csum, Tc, 1.0))
+        gslots = torch.randn(B, Tc + 1, C, generator=g).to(dev)
+        dfull, pa, pb = ops.cif_bwd_rows(full, head, S, alpha, csum, gslots, Tc, 1.0)
+        dx32, pa32, pb32 = ops.cif_bwd(x32, alpha, csum, gslots, Tc, 1.0)
+        assert torch.equal(dfull[:, head: head + S], dx32.to(torch.bfloat16))
+        assert float(dfull[:, :head].float().abs().sum()) == 0.0 and float(dfull[:, head + S:].float().abs().sum()) == 0.0
+        assert torch.equal(pa, pa32) and torch.equal(pb, pb32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("head,k", [(0, 3), (1, 5)])
+def test_cif_weight_head_over_resident_rows_matches_the_padded_copy_path(head, k):
+    """cif._WeightHeadRowsFn (the weight conv as a strided-row GEMM over the attention block's buffer + the head kernel, one autograd
+    node, gradients in the buffer's layout) against the padded-copy formulation (_ConvRowsBf16Fn + _CifHeadFn on the same frames):
+    identical alpha, identical parameter gradients and input gradient (the same GEMMs on the same bf16 values)."""
+    from speechclip_plus_amd import cif, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    B, P, S, C = 4, 128, 90, 256
+    pd = k // 2
+    lead = trail = 8
+    flat = (torch.randn(lead + B * P + trail, C, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    ops.rows_zero_pad(flat, lead, B, P, head, head + S, trail)
+    full = flat[lead: lead + B * P].view(B, P, C)
+    conv_w = (torch.randn(C, C, k, generator=g) * (C * k) ** -0.5).to(dev).requires_grad_()
+    conv_b = (torch.randn(C, generator=g) * 0.1).to(dev).requires_grad_()
+    lin_w = (torch.randn(1, C, generator=g) * C ** -0.5).to(dev).requires_grad_()
+    lin_b = torch.zeros(1, device=dev).requires_grad_()
+    dalpha = torch.randn(B, S, generator=g).to(dev)
+    # rows path
+    flat1 = flat.clone()            # the rows as mha_block hands them over: a tensor of its own over the middle of the flat buffer
+    f1 = torch.empty(0, device=dev, dtype=torch.bfloat16).set_(flat1.untyped_storage(), lead * C, (B, P, C), (P * C, C, 1)).requires_grad_()
+    a1 = cif._WeightHeadRowsFn.apply(f1, conv_w, conv_b, lin_w, lin_b, head, S, pd, 0.0, 0, 0.0, 0)
+    a1.backward(dalpha)
+    got = [t.grad.clone() for t in (f1, conv_w, conv_b, lin_w, lin_b)]
+    for t in (conv_w, conv_b, lin_w, lin_b):
+        t.grad = None
+    # padded-copy path on the same frames
+    x2 = full[:, head: head + S].clone().requires_grad_()
+    y_full = cif._ConvRowsBf16Fn.apply(x2, conv_w, conv_b, pd)
+    a_full = cif._CifHeadFn.apply(y_full.unsqueeze(0), lin_w, lin_b, 0.0, 0, 0.0, 0)
+    a2 = a_full.view(-1)[: B * (S + 2 * pd)].view(B, S + 2 * pd)[:, :S]
+    a2.backward(dalpha)
+    assert torch.equal(a1, a2)
+    assert torch.equal(got[0][:, head: head + S], x2.grad)
+    assert float(got[0][:, :head].float().abs().sum()) == 0.0 and float(got[0][:, head + S:].float().abs().sum()) == 0.0
+    for a, b in zip(got[1:], (conv_w.grad, conv_b.grad, lin_w.grad, lin_b.grad)):
+        assert rel(a, b) < 1e-5, rel(a, b)
