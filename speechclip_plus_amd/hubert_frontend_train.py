@@ -90,6 +90,11 @@ class TrainableFrontend(nn.Module):
             w = self.P(f"feature_extractor.conv_layers.{i}.0.weight").detach()           # [C_out, C_in, k]
             c[f"conv{i}_w"] = bf(w.permute(0, 2, 1).reshape(w.shape[0], -1))               # tap-major [C_out, k C_in]
             c[f"conv{i}_wT"] = bf(w.permute(0, 2, 1).reshape(w.shape[0], -1).t())          # [k C_in, C_out]
+            if a.conv_kernels[i] == 3 and a.conv_strides[i] == 2:
+                # input gradient of an even input row 2 m = window m's tap 0 + window m - 1's tap 2: ONE product over the row pair
+                # [du[m - 1] | du[m]] (K = 2 C_out) against [W_2^T | W_0^T]; odd rows 2 m + 1 take tap 1 of window m (backward_frontend)
+                c[f"conv{i}_wT_even"] = bf(torch.cat([w[:, :, 2].t(), w[:, :, 0].t()], dim=1))       # [C_in, 2 C_out]
+                c[f"conv{i}_wT_odd"] = bf(w[:, :, 1].t())                                          # [C_in, C_out]
             c[f"conv{i}_b"] = f32(self.P(f"feature_extractor.conv_layers.{i}.0.bias")) if a.conv_bias else None
             if a.extractor_mode == "layer_norm":
                 c[f"conv{i}_g"] = f32(self.P(f"feature_extractor.conv_layers.{i}.2.1.weight"))
@@ -235,6 +240,14 @@ class TrainableFrontend(nn.Module):
         # output gradient - the epilogue of the input-gradient GEMM (k = stride: its windows are a reshape) or the overlap-add pass
         # (k = 3, stride 2) - so du of the next iteration arrives ready (no activation-sized pass of its own)
         du_ready = None
+
+        def rows_buf(n: int) -> torch.Tensor:
+            """[n, C] bf16 rows with ONE zero row allocated in front of them: the k = 3 / stride 2 layers read the row pair
+            [du[m - 1] | du[m]] in place, and window -1 does not exist"""
+            buf = torch.empty(1 + n, C, device=dev, dtype=torch.bfloat16)
+            buf[0].zero_()
+            return buf[1:]
+
         for i in range(len(a.conv_kernels) - 1, 0, -1):
             k, s = a.conv_kernels[i], a.conv_strides[i]
             rows = B * pl.R_l[i]
@@ -242,13 +255,13 @@ class TrainableFrontend(nn.Module):
             fuse_below = (not ln_mode) and i >= 2
             if ln_mode:
                 dn = ops.act_bf16(st["n"][i], 1, df=df)
-                du, dg, db = ops.layernorm_bwd(u, dn, c[f"conv{i}_g"], 1e-5, want_param_grads=True)
+                du, dg, db = ops.layernorm_bwd(u, dn, c[f"conv{i}_g"], 1e-5, want_param_grads=True, out=rows_buf(rows))
                 acc(f"feature_extractor.conv_layers.{i}.2.1.weight", dg)
                 acc(f"feature_extractor.conv_layers.{i}.2.1.bias", db)
             elif du_ready is not None:
                 du, du_ready = du_ready, None
             else:
-                du = ops.act_bf16(u, 1, df=df)
+                du = ops.act_bf16(u, 1, df=df, out=rows_buf(rows))
             # weight gradient: dy^T . im2col VIEW of the layer input (rows overlap in memory: lda = s C < K = k C)
             cols = torch.as_strided(pl.conv[i - 1], (rows, k * C), (s * C, 1))
             gw = torch.empty(C, k * C, device=dev, dtype=torch.float32)
@@ -257,20 +270,27 @@ class TrainableFrontend(nn.Module):
             acc(f"feature_extractor.conv_layers.{i}.0.weight", gw.view(C, k, C).permute(0, 2, 1))
             if a.conv_bias:
                 acc(f"feature_extractor.conv_layers.{i}.0.bias", gbias)
-            # input gradient: windows of dcols = du . W back onto the rows they were cut from
+            # input gradient: the windows of du . W back onto the rows they were cut from; the GELU' of the layer below in the epilogue
+            dx = rows_buf(rows * s)
+            kw = dict(act=1, aux_mode=2) if fuse_below else {}
             if k == s:                                                                     # non-overlapping windows: a reshape
-                if fuse_below:
-                    du_ready = ops.linear_bf16(du, c[f"conv{i}_wT"], act=1, aux=st["u"][i - 1].view(rows, k * C), aux_mode=2).view(rows * s, C)
-                else:
-                    df = ops.linear_bf16(du, c[f"conv{i}_wT"]).view(rows * s, C)
+                ops.gemm_raw(du, C, c[f"conv{i}_wT"], C, dx.view(rows, k * C), k * C, rows, k * C, C,
+                             aux=st["u"][i - 1].view(rows, k * C) if fuse_below else None, **kw)
             else:
+                # k = 3, stride 2: row 2 m gets tap 0 of window m and tap 2 of window m - 1, row 2 m + 1 tap 1 of window m - two products
+                # that write the interleaved rows directly (row stride 2 C), the first over the overlapping row pairs of du (lda = C,
+                # K = 2 C: the conv forward's strided-row trick).  No [rows, 3 C] window gradients, no overlap-add pass (round 3 wrote
+                # 3.1 GB of them for conv 1 and read them back).
                 assert k == 3 and s == 2
-                dcols = ops.linear_bf16(du, c[f"conv{i}_wT"])                               # [rows, k C]
-                # tap 2 of window m lands on row 2 (m + 1): one pass, one launch
-                if fuse_below:
-                    du_ready = ops.conv_overlap_add(dcols, C, u=st["u"][i - 1])
-                else:
-                    df = ops.conv_overlap_add(dcols, C)
+                pair = torch.as_strided(du, (rows, 2 * C), (C, 1), du.storage_offset() - C)
+                dx2 = dx.view(rows, 2 * C)
+                ub = st["u"][i - 1].view(rows, 2 * C) if fuse_below else None
+                ops.gemm_raw(pair, C, c[f"conv{i}_wT_even"], 2 * C, dx2[:, :C], 2 * C, rows, C, 2 * C, aux=ub[:, :C] if fuse_below else None, **kw)
+                ops.gemm_raw(du, C, c[f"conv{i}_wT_odd"], C, dx2[:, C:], 2 * C, rows, C, C, aux=ub[:, C:] if fuse_below else None, **kw)
+            if fuse_below:
+                du_ready = dx
+            else:
+                df = dx
         # ---- conv layer 0: parameter gradients only (the input is the waveform)
         T0 = pl.T_l[0]
         if "conv0" in st:
