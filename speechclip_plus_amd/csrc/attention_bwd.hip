@@ -208,14 +208,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bwd_args p) { at
 __global__ __launch_bounds__(256) void attn_bwd_dq_drop_kernel(const bwd_args p) { attn_bwd_dq_body<1>(p); }
 
 // ------------------------------------------------------------------------------------------------------------ dK, dV
+// Round 4 (second half): the four tiles of a query step (Q, dO row-major; Q^T, dO^T) and its 64 lse / delta values arrive by LDS-DMA
+// into the OTHER half of a double buffer while the current step is computed - global_load_lds_dwordx4 for the row-major tiles (the
+// 16-byte chunk swizzle lives in the per-lane source address), global_load_lds_dword for the transposed ones (their swizzle is
+// 8-byte granular: a lane fetches the 4 bytes that belong at its LDS position) - no staging registers (the kernel sits at the
+// 255-register ceiling: 250 / 218 now), one barrier per step instead of two.  Measured (tools/bench_attn_bwd.py, alternating with the
+// synchronous-load version, prep + dq + dk/dv at B = 64 x 10 s): 451-459 vs 463-465 us eval, 517-521 vs 527-534 us with dropout - the
+// kernel was never waiting for its loads much; its time is the VALU work per (query, key) element (exp2, masks, the dropout hash of
+// a key lane, dS) at 2 waves per SIMD.
+constexpr int DKV_TILE = TT * 128;                                   // bytes of one tile image
+constexpr int DKV_LDS = 8 * DKV_TILE + 4 * TT * 4;                    // 2 x (Qs, Os, QTs, OTs) + 2 x (lse, delta)
+
+__device__ __forceinline__ void glds(const void* g, char* lds_wave_base, int bytes16) {
+    if (bytes16)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
 template <int DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
-    __shared__ __attribute__((aligned(16))) char Qs[TT * 128];
-    __shared__ __attribute__((aligned(16))) char Os[TT * 128];
-    __shared__ __attribute__((aligned(16))) char QTs[64 * 128];
-    __shared__ __attribute__((aligned(16))) char OTs[64 * 128];
-    __shared__ __attribute__((aligned(16))) float lse_s[TT], dl_s[TT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Qs = smem;
+    char* const Os = smem + 2 * DKV_TILE;
+    char* const QTs = smem + 4 * DKV_TILE;
+    char* const OTs = smem + 6 * DKV_TILE;
+    float* const lse_s = (float*)(smem + 8 * DKV_TILE);
+    float* const dl_s = lse_s + 2 * TT;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int R = p.R, H = p.H, nkb = R >> 7;
     const int logical = xcd_logical();
     const int kblk = logical % nkb, bh = logical / nkb, h = bh % H, b = bh / H;
@@ -246,43 +267,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
     }
     const bool key_ok = krow < n_valid;
 
-    const uint16_t *qg[2], *og[2], *qtg[2], *otg[2];
-    int r_lds[2], t_lds0[2], t_lds1[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int id = tid + i * 256, row = id >> 3, ch = id & 7;
-        qg[i] = p.q + ((int64_t)b * R + row) * p.ldq + h * 64 + ch * 8;
-        og[i] = p.dout + ((int64_t)b * R + row) * p.lddo + h * 64 + ch * 8;
-        qtg[i] = p.qT + (((int64_t)b * H + h) * 64 + row) * R + ch * 8;
-        otg[i] = p.doT + (((int64_t)b * H + h) * 64 + row) * R + ch * 8;
-        r_lds[i] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
-        t_lds0[i] = row * 128 + (((2 * ch) ^ sc_tr_swizzle(row)) << 3);
-        t_lds1[i] = row * 128 + (((2 * ch + 1) ^ sc_tr_swizzle(row)) << 3);
-    }
+    // DMA sources.  Row-major tiles: wave instruction i (0, 1) of a wave fills tile rows (4 i + wave) 8 .. + 7, lane -> (row, LDS chunk
+    // position); the chunk it fetches is position ^ ((row >> 1) & 7) (row_frag reads the same way).  Transposed tiles: instruction i
+    // (0 .. 7) fills rows 2 (4 i + wave), + 1, lane -> (row, 4-byte position); it fetches half (pos & 1) of 8-byte unit
+    // (pos >> 1) ^ sc_tr_swizzle(row) (tr_frag).
+    const uint16_t* const qb_ = p.q + (int64_t)b * R * p.ldq + h * 64;
+    const uint16_t* const ob_ = p.dout + (int64_t)b * R * p.lddo + h * 64;
+    const uint16_t* const qtb = p.qT + ((int64_t)b * H + h) * 64 * R;
+    const uint16_t* const otb = p.doT + ((int64_t)b * H + h) * 64 * R;
     const float* lse_g = p.lse2 + ((int64_t)b * H + h) * R;
     const float* dl_g = p.delta + ((int64_t)b * H + h) * R;
+    auto issue = [&](int t, int nb) {
+        const int qt0 = t * TT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int blk = i * 4 + wave, row = blk * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            glds(qb_ + (int64_t)(qt0 + row) * p.ldq + c * 8, Qs + nb * DKV_TILE + blk * 1024, 1);
+            glds(ob_ + (int64_t)(qt0 + row) * p.lddo + c * 8, Os + nb * DKV_TILE + blk * 1024, 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int blk = i * 4 + wave, row = blk * 2 + (lane >> 5), pos = lane & 31;
+            const int su = (pos >> 1) ^ sc_tr_swizzle(row);
+            const int64_t off = (int64_t)row * R + qt0 + su * 4 + (pos & 1) * 2;
+            glds(qtb + off, QTs + nb * DKV_TILE + blk * 256, 0);
+            glds(otb + off, OTs + nb * DKV_TILE + blk * 256, 0);
+        }
+        if (wave == 0) glds(lse_g + qt0 + lane, (char*)(lse_s + nb * TT), 0);
+        if (wave == 1) glds(dl_g + qt0 + lane, (char*)(dl_s + nb * TT), 0);
+    };
 
     // queries that can see this key block: all valid ones, or (causal) those from the block's first key on
     const int q_end = p.q_rows;                                        // rows beyond carry dO = 0
     const int t_first = p.causal ? (kblk * 128) / TT : 0;
     const int t_last = (q_end + TT - 1) / TT;                          // exclusive
-    for (int t = t_first; t < t_last; ++t) {
+    int nb = 0;
+    if (t_first < t_last) issue(t_first, 0);
+    for (int t = t_first; t < t_last; ++t, nb ^= 1) {
         const int qt0 = t * TT;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *(uint4*)(Qs + r_lds[i]) = *(const uint4*)(qg[i] + (int64_t)qt0 * p.ldq);
-            *(uint4*)(Os + r_lds[i]) = *(const uint4*)(og[i] + (int64_t)qt0 * p.lddo);
-            const uint4 a = *(const uint4*)(qtg[i] + qt0), o = *(const uint4*)(otg[i] + qt0);
-            *(uint2*)(QTs + t_lds0[i]) = make_uint2(a.x, a.y);
-            *(uint2*)(QTs + t_lds1[i]) = make_uint2(a.z, a.w);
-            *(uint2*)(OTs + t_lds0[i]) = make_uint2(o.x, o.y);
-            *(uint2*)(OTs + t_lds1[i]) = make_uint2(o.z, o.w);
-        }
-        if (tid < TT) {
-            lse_s[tid] = lse_g[qt0 + tid];
-            dl_s[tid] = dl_g[qt0 + tid];
-        }
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this step's tiles have landed (this wave's share) ...
+        __syncthreads();                                               // ... everybody's; and every wave is done with the previous step
+        if (t + 1 < t_last) issue(t + 1, nb ^ 1);
+        const char* Qc = Qs + nb * DKV_TILE;
+        const char* Oc = Os + nb * DKV_TILE;
+        const char* QTc = QTs + nb * DKV_TILE;
+        const char* OTc = OTs + nb * DKV_TILE;
+        const float* lse_c = lse_s + nb * TT;
+        const float* dl_c = dl_s + nb * TT;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             const int qbase = qt0 + qb * 32;
@@ -293,14 +324,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qs, qb, l31, half, ks), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Os, qb, l31, half, ks), vf[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qc, qb, l31, half, ks), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Oc, qb, l31, half, ks), vf[ks], dp, 0, 0, 0);
             }
             f32x16 pr, ds;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ql = qb * 32 + 8 * g + 4 * half;               // local query index of registers 4 g .. 4 g + 3
-                const f32x4 l4 = *(const f32x4*)(lse_s + ql), d4 = *(const f32x4*)(dl_s + ql);
+                const f32x4 l4 = *(const f32x4*)(lse_c + ql), d4 = *(const f32x4*)(dl_c + ql);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e, qidx = qt0 + ql + e;
@@ -323,13 +354,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
             acc_to_frag(ds, df);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                av0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(OTs, qb, s2, 0, l31, half), pf[s2], av0, 0, 0, 0);
-                av1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(OTs, qb, s2, 1, l31, half), pf[s2], av1, 0, 0, 0);
-                ak0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(QTs, qb, s2, 0, l31, half), df[s2], ak0, 0, 0, 0);
-                ak1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(QTs, qb, s2, 1, l31, half), df[s2], ak1, 0, 0, 0);
+                av0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(OTc, qb, s2, 0, l31, half), pf[s2], av0, 0, 0, 0);
+                av1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(OTc, qb, s2, 1, l31, half), pf[s2], av1, 0, 0, 0);
+                ak0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(QTc, qb, s2, 0, l31, half), df[s2], ak0, 0, 0, 0);
+                ak1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(QTc, qb, s2, 1, l31, half), df[s2], ak1, 0, 0, 0);
             }
         }
-        __syncthreads();
     }
     store_T(ak0, ak1, dkp, p.scale);
     store_T(av0, av1, dvp, 1.0f);
@@ -472,8 +502,14 @@ static int attn_bwd_launch(int fused_prep, const sc_bf16* q, int64_t ldq, const 
     if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_dq_drop_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     SC_LAUNCH_CHECK();
-    if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    static sc_lds_attr_once attr0, attr1;
+    if (hipError_t e = drop_p > 0.f ? sc_set_max_lds_once(attr1, attn_bwd_dkv_kernel<1>, DKV_LDS) : sc_set_max_lds_once(attr0, attn_bwd_dkv_kernel<0>, DKV_LDS);
+        e != hipSuccess) {
+        sc_set_error("hipFuncSetAttribute(attn_bwd_dkv): %s", hipGetErrorString(e));
+        return -3;
+    }
+    if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid, dim3(256), DKV_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<0>, grid, dim3(256), DKV_LDS, (hipStream_t)stream, a);
     SC_LAUNCH_CHECK();
     return 0;
 }
