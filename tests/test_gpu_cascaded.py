@@ -186,3 +186,40 @@ def test_clip_text_tower_kernels_match_the_oracle():
     assert rel(kw.grad, kw2.grad) < 4e-2, rel(kw.grad, kw2.grad)
     for b in range(B):                                           # rows beyond the utterance's keywords carry no gradient
         assert float(kw.grad[b, int(n[b]):].abs().sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cascaded", "hybrid"])
+def test_branch_rows_hand_over_falls_back_when_the_buffer_has_no_padding_rows(kind):
+    """CIF reads the attention block's rows in place only when the buffer has zero rows behind every utterance for the weight conv's
+    reach (cif.CIF.rows_usable).  With exactly 64 frames (cascaded: no row to spare; hybrid: CLS + 64 = 65 -> pitch 128, usable) both
+    routes must give the tensor path's results: same keywords / counts, gradients within bf16 rounding."""
+    import cascaded_checks as cc
+    br, clip = cc.build_branch(kind, "cuda")
+    br.train()
+    g = torch.Generator().manual_seed(21)
+    feat0 = torch.randn(3, 64, 64, generator=g)
+    lens = torch.tensor([64, 40, 57])
+    tgt = (lens / 20).round().long()
+    used = []
+    real = br.downsampling.rows_usable
+    br.downsampling.rows_usable = lambda rows: used.append(real(rows)) or used[-1]
+    outs = []
+    for rows_path in (True, False):
+        if not rows_path:
+            br._rows_path = lambda audio_feat: False
+        feat = feat0.clone().cuda().requires_grad_()
+        br.zero_grad(set_to_none=True)
+        out = br(audio_feat=feat, audio_feat_len=lens.cuda(), otherInputs={"global_step": 0, "target_len": tgt.cuda()})
+        (out["cascaded_audio_feat"].float().pow(2).sum() + out["dsample_results"]["quantity_out"].sum()).backward()
+        outs.append((out["keywords"].detach().clone(), out["dsample_results"]["dsample_feats_length"].clone(), feat.grad.clone(),
+                     {n: p.grad.clone() for n, p in br.named_parameters() if p.grad is not None}))
+    del br._rows_path
+    assert used == [kind == "hybrid"]                    # cascaded: 64 frames fill the 64-row pitch -> fallback inside CIF
+    (k0, n0, gx0, gp0), (k1, n1, gx1, gp1) = outs
+    assert torch.equal(n0, n1)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-20))
+    assert rel(k0, k1) < 1e-5 and rel(gx0, gx1) < 2e-2
+    assert gp0.keys() == gp1.keys()
+    for n in gp0:
+        assert rel(gp0[n], gp1[n]) < 2e-2, (n, rel(gp0[n], gp1[n]))
