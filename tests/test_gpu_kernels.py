@@ -1400,3 +1400,34 @@ def test_weighted_sum_share_kernel(dev):
     share = (dfeat.view(B * R, D) * w[1]).to(torch.bfloat16)
     assert torch.equal(ops.wsum_share(dX, w[1:2], None, B, R, T), share)
     assert torch.equal(ops.wsum_share(dX, w[1:2], prev, B, R, T), prev + share)
+
+
+@pytest.mark.gpu
+def test_attention_backward_is_bitwise_repeatable(dev):
+    """The dK / dV kernel stages its tiles by LDS-DMA into a double buffer (one barrier per step): a missed wait or a buffer re-used
+    too early would show as run-to-run differences.  Same inputs, five runs, several shapes incl. dropout and the causal text-tower
+    form: identical bits every time (every gradient element is written once, in a fixed summation order)."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(41)
+    for B, H, R, T, causal, p in ((4, 12, 512, 499, 0, 0.1), (3, 8, 128, 128, 32, 0.0), (2, 12, 384, 300, 0, 0.0), (5, 4, 256, 256, 1, 0.0)):
+        D = 64 * H
+        qkv = bf(torch.randn(B * R, 3 * D, generator=g)).to(dev)
+        dout = bf(torch.randn(B * R, D, generator=g)).to(dev)
+        if T < R:
+            dout.view(B, R, D)[:, T:] = 0
+        valid = torch.full((B,), T if not causal else R, dtype=torch.int32, device=dev)
+        vt = ops.head_transpose(qkv[:, 2 * D:], B, R, H)
+        out = torch.empty(B * R, D, device=dev, dtype=torch.bfloat16)
+        lse2 = torch.empty(B, H, R, device=dev, dtype=torch.float32)
+        ops.attn_fwd(qkv[:, : 2 * D], vt, valid, out, B, R, H, D, 0.125, lse2=lse2, causal=causal, drop_p=p, drop_seed=5)
+        ref = None
+        for _ in range(5):
+            dqkv = torch.full((B * R, 3 * D), 7.0, device=dev, dtype=torch.bfloat16)
+            ops.attn_bwd(qkv[:, :D], qkv[:, D: 2 * D], qkv[:, 2 * D:], out, dout, lse2, valid, dqkv[:, :D], dqkv[:, D: 2 * D], dqkv[:, 2 * D:],
+                         B, R, H, 0.125, causal=causal, q_rows=T if not causal else R, drop_p=p, drop_seed=5)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(dqkv.float()).all())
+            if ref is None:
+                ref = dqkv
+            else:
+                assert torch.equal(dqkv, ref), (B, H, R, T, causal, p)
