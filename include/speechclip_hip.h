@@ -506,6 +506,9 @@ int sc_act_bf16(const sc_bf16* u, const sc_bf16* df, sc_bf16* out, int64_t n, in
 /*   sc_transpose_bf16 : y[c, r] = x[r, c]  - operands of the weight-gradient GEMMs (dW = dY^T X: the row index becomes the
  *                       contraction dimension of sc_gemm_bf16, split along K over the batch dimension, partials in fp32)
  *   sc_colsum_bf16    : partial[blk, c] = sum of the block's rows of x[:, c] in fp32 (bias gradients; reduce with sc_colsum_f32) */
+/*   sc_transpose_batched_bf16 : nbatch equally shaped [rows, cols] matrices, matrix z starting sx / sy elements after matrix z - 1 */
+int sc_transpose_batched_bf16(const sc_bf16* x, int64_t ldx, int64_t sx, sc_bf16* y, int64_t ldy, int64_t sy, int32_t rows, int32_t cols,
+                              int32_t nbatch, void* stream);
 /*   sc_dropout_bf16   : out = dropout(x) (F.dropout semantics, the stateless mask of sc_gemm_args over element row*D + col):
  *                       fairseq's encoder dropout after pos_conv + LayerNorm (speech_encoder_plus.py:41), train mode only */
 int sc_dropout_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* out, int64_t ldo, int64_t rows, int32_t D, float p, uint32_t seed,

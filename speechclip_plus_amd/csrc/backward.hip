@@ -340,9 +340,12 @@ namespace {
 // colpart (optional): colpart[row block][c] = sum of the block's 64 rows of column c in fp32 - the bias gradient's first stage
 // comes for free with the pass that already reads dY.
 __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
-                                                        int64_t ldy, int rows, int cols, float* __restrict__ colpart) {
+                                                        int64_t ldy, int rows, int cols, float* __restrict__ colpart, int64_t sx = 0,
+                                                        int64_t sy = 0) {
     __shared__ uint16_t tile[64][66];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    x += blockIdx.z * sx;                          // batch (blockIdx.z): matrix z starts sx / sy elements after matrix z - 1
+    y += blockIdx.z * sy;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int id = tid + i * 256, row = id >> 3, ch = id & 7;
@@ -458,6 +461,19 @@ extern "C" int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int6
     SC_CHECK(rows % 8 == 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "sc_transpose_bf16: rows, cols and leading dims must be multiples of 8");
     hipLaunchKernelGGL(transpose_kernel, dim3((rows + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols,
                        colsum_partial);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+// nbatch equally shaped matrices at uniform strides in one launch (the transposed bf16 working copies of a trainable encoder's
+// per-layer weights: 4 launches per step instead of 48)
+extern "C" int sc_transpose_batched_bf16(const sc_bf16* x, int64_t ldx, int64_t sx, sc_bf16* y, int64_t ldy, int64_t sy, int32_t rows,
+                                         int32_t cols, int32_t nbatch, void* stream) {
+    SC_CHECK(x && y && rows > 0 && cols > 0 && nbatch > 0 && nbatch <= 65535, "sc_transpose_batched_bf16: bad args");
+    SC_CHECK(rows % 8 == 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && sx % 8 == 0 && sy % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
+                 ((uintptr_t)y % 16) == 0, "sc_transpose_batched_bf16: rows, cols, leading dims and strides must be multiples of 8, operands 16-byte aligned");
+    hipLaunchKernelGGL(transpose_kernel, dim3((rows + 63) / 64, (cols + 63) / 64, nbatch), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows,
+                       cols, (float*)nullptr, sx, sy);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -109,14 +109,42 @@ class TrainableLayers(nn.Module):
                     return mirror[off: off + t.numel()].view(t.shape)
             return bf(t)
 
+        # The trainable layers' matrices sit at ONE stride in the bf16 mirror (every layer registers the same parameters in the same
+        # order): the fused QKV weight of all layers is gathered with three strided copies and every kind of transposed working copy
+        # (QKV, out_proj, fc1, fc2) is ONE batched transpose launch over the layers - 7 launches per step where the per-layer
+        # cat + .t().contiguous() took 60.
+        batched = {}
+        n = len(self.ids)
+        if mirror is not None and n >= 2:
+            offs = {nm: [self.get(i, nm).storage_offset() - lo for i in self.ids] for nm in _PARAMS if nm.endswith("weight") and "layer_norm" not in nm}
+            stride = offs["fc1.weight"][1] - offs["fc1.weight"][0]
+            if stride > 0 and stride % 8 == 0 and all(o[j] == o[0] + j * stride and o[0] % 8 == 0 for o in offs.values() for j in range(n)):
+                D, F = self.arch.embed_dim, self.arch.ffn_dim
+                lay = lambda nm, r, k: torch.as_strided(mirror, (n, r, k), (stride, k, 1), offs[nm][0])
+                qkv = torch.empty(n, 3 * D, D, device=mirror.device, dtype=torch.bfloat16)
+                for k3, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                    qkv[:, k3 * D: (k3 + 1) * D].copy_(lay(f"self_attn.{nm}.weight", D, D))
+                batched["qkv"] = (qkv, ops.transpose_batched_bf16(qkv[0], 3 * D * D, n))
+                for short, nm, r, k in (("o", "self_attn.out_proj.weight", D, D), ("fc1", "fc1.weight", F, D), ("fc2", "fc2.weight", D, F)):
+                    w = lay(nm, r, k)
+                    batched[short] = (w, ops.transpose_batched_bf16(w[0], stride, n))
+
         for i in self.ids + [j for j in self.pass_ids if j not in self._copies]:
             c = {}
-            qkv_b16 = torch.cat([bfp(i, f"self_attn.{n}.weight") for n in ("q_proj", "k_proj", "v_proj")], 0)
-            c["qkv_w"], c["qkv_wT"] = qkv_b16, qkv_b16.t().contiguous()
-            c["qkv_b"] = torch.cat([self.get(i, f"self_attn.{n}.bias").detach() for n in ("q_proj", "k_proj", "v_proj")], 0).contiguous()
+            jb = self.ids.index(i) if (batched and i in self.ids) else None
+            if jb is not None:
+                c["qkv_w"], c["qkv_wT"] = batched["qkv"][0][jb], batched["qkv"][1][jb]
+            else:
+                qkv_b16 = torch.cat([bfp(i, f"self_attn.{n_}.weight") for n_ in ("q_proj", "k_proj", "v_proj")], 0)
+                c["qkv_w"], c["qkv_wT"] = qkv_b16, qkv_b16.t().contiguous()
+            c["qkv_b"] = torch.cat([self.get(i, f"self_attn.{n_}.bias").detach() for n_ in ("q_proj", "k_proj", "v_proj")], 0).contiguous()
             for short, name in (("o", "self_attn.out_proj"), ("fc1", "fc1"), ("fc2", "fc2")):
-                wb = bfp(i, name + ".weight")
-                c[short + "_w"], c[short + "_wT"], c[short + "_b"] = wb, wb.t().contiguous(), self.get(i, name + ".bias").detach()
+                if jb is not None:
+                    c[short + "_w"], c[short + "_wT"] = batched[short][0][jb], batched[short][1][jb]
+                else:
+                    wb = bfp(i, name + ".weight")
+                    c[short + "_w"], c[short + "_wT"] = wb, wb.t().contiguous()
+                c[short + "_b"] = self.get(i, name + ".bias").detach()
             c["ln1_g"], c["ln1_b"] = self.get(i, "self_attn_layer_norm.weight").detach(), self.get(i, "self_attn_layer_norm.bias").detach()
             c["ln2_g"], c["ln2_b"] = self.get(i, "final_layer_norm.weight").detach(), self.get(i, "final_layer_norm.bias").detach()
             self._copies[i] = c

@@ -1399,3 +1399,14 @@ def wsum_share(dX: torch.Tensor, w: torch.Tensor, prev: Optional[torch.Tensor], 
     out = torch.empty(B * R, D, device=dX.device, dtype=torch.bfloat16)
     check(lib().sc_wsum_share_bf16(_p(dX), _p(w), _p(prev), _p(out), B, R, T, D, row_off, _stream()), "sc_wsum_share_bf16")
     return out
+
+
+def transpose_batched_bf16(x0: torch.Tensor, sx: int, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """n equally shaped [rows, cols] bf16 matrices, matrix z = ``sx`` elements after matrix z - 1 (``x0`` = the first, dense rows) ->
+    out [n, cols, rows] (one launch, sc_transpose_batched_bf16)"""
+    rows, cols = x0.shape
+    assert x0.dtype == torch.bfloat16 and x0.stride(1) == 1
+    if out is None:
+        out = torch.empty(n, cols, rows, device=x0.device, dtype=torch.bfloat16)
+    check(lib().sc_transpose_batched_bf16(_p(x0), x0.stride(0), sx, _p(out), rows, cols * rows, rows, cols, n, _stream()), "sc_transpose_batched_bf16")
+    return out
