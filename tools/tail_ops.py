@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which host lines issue the torch (aten) device ops of a cascaded+ / hybrid+ train step: a TorchDispatchMode around one step
 (autograd single-threaded so that the backward's Python runs under it too), grouped by the innermost frame inside the package
-(diagnostics).  usage: tail_ops.py [cascaded_plus|hybrid_plus_large]"""
+(diagnostics).  usage: tail_ops.py [cascaded_plus|hybrid_plus_large|base|trainable]"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,9 @@ from torch.utils._python_dispatch import TorchDispatchMode
 import bench
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cascaded_plus"
-model, trainer, batch, sd, wav_len = bench.make_workload(name, 64, 160000, False, 0, torch.device("cuda:0"))
+trainable = name == "trainable"                     # fully trainable HuBERT-base (bench.py --trainable)
+model, trainer, batch, sd, wav_len = bench.make_workload("base" if trainable else name, 64, 160000, False, 0, torch.device("cuda:0"),
+                                                         trainable=trainable)
 for _ in range(3):
     trainer.step(batch)
 torch.cuda.synchronize()
