@@ -91,7 +91,7 @@ class TrainableLayers(nn.Module):
         bf = lambda t: t.detach().to(torch.bfloat16).contiguous()
         # Trainable parameters managed by optim.FlatAdam are contiguous views of ONE flat fp32 buffer: cast the span they cover in a
         # single launch and hand out views of that bf16 mirror, instead of one cast launch per weight matrix (113 per step)
-        mirror, lo = None, 0
+        mirror, flat32, lo = None, None, 0
         ps = [q for q in self.p.values()]
         if ps and all(q.is_contiguous() and q.dtype == torch.float32 and
                       q.data.untyped_storage().data_ptr() == ps[0].data.untyped_storage().data_ptr() for q in ps):
@@ -99,7 +99,7 @@ class TrainableLayers(nn.Module):
             hi = max(q.storage_offset() + q.numel() for q in ps)
             if hi - lo <= 2 * sum(q.numel() for q in ps):          # a compact span (other modules' parameters may sit in between)
                 flat = torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(ps[0].data.untyped_storage(), lo, (hi - lo,))
-                mirror = flat.to(torch.bfloat16)
+                mirror, flat32 = flat.to(torch.bfloat16), flat
 
         def bfp(i, name):                                          # bf16 working copy of a layer parameter
             t = self.get(i, name)
@@ -128,6 +128,13 @@ class TrainableLayers(nn.Module):
                 for short, nm, r, k in (("o", "self_attn.out_proj.weight", D, D), ("fc1", "fc1.weight", F, D), ("fc2", "fc2.weight", D, F)):
                     w = lay(nm, r, k)
                     batched[short] = (w, ops.transpose_batched_bf16(w[0], stride, n))
+                # the fused QKV bias (fp32, the GEMM's bias operand) of all layers: three strided gathers instead of a cat per layer
+                boffs = [[self.get(i, f"self_attn.{nm}.bias").storage_offset() - lo for i in self.ids] for nm in ("q_proj", "k_proj", "v_proj")]
+                if all(o[j] == o[0] + j * stride for o in boffs for j in range(n)):
+                    qkv_b = torch.empty(n, 3, D, device=mirror.device, dtype=torch.float32)
+                    for k3, o in enumerate(boffs):
+                        qkv_b[:, k3].copy_(torch.as_strided(flat32, (n, D), (stride, 1), o[0]))
+                    batched["qkv_b"] = qkv_b.view(n, 3 * D)
 
         for i in self.ids + [j for j in self.pass_ids if j not in self._copies]:
             c = {}
@@ -137,7 +144,10 @@ class TrainableLayers(nn.Module):
             else:
                 qkv_b16 = torch.cat([bfp(i, f"self_attn.{n_}.weight") for n_ in ("q_proj", "k_proj", "v_proj")], 0)
                 c["qkv_w"], c["qkv_wT"] = qkv_b16, qkv_b16.t().contiguous()
-            c["qkv_b"] = torch.cat([self.get(i, f"self_attn.{n_}.bias").detach() for n_ in ("q_proj", "k_proj", "v_proj")], 0).contiguous()
+            if jb is not None and "qkv_b" in batched:
+                c["qkv_b"] = batched["qkv_b"][jb]
+            else:
+                c["qkv_b"] = torch.cat([self.get(i, f"self_attn.{n_}.bias").detach() for n_ in ("q_proj", "k_proj", "v_proj")], 0).contiguous()
             for short, name in (("o", "self_attn.out_proj"), ("fc1", "fc1"), ("fc2", "fc2")):
                 if jb is not None:
                     c[short + "_w"], c[short + "_wT"] = batched[short][0][jb], batched[short][1][jb]
@@ -290,8 +300,14 @@ class TrainableLayers(nn.Module):
             # the fused QKV product's slice reduction adds each D-row block straight into its projection's gradient
             ops.wgrad_bf16(dqkv, attn_in, [P(f"self_attn.{n}.weight") for n in ("q_proj", "k_proj", "v_proj")], None, beta=1.0)
             ops.colsum_bf16(dqkv, gb)
-            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
-                P(f"self_attn.{n}.bias").add_(gb[j * D: (j + 1) * D])
+            tb = [P(f"self_attn.{n}.bias") for n in ("q_proj", "k_proj", "v_proj")]
+            step = (tb[1].data_ptr() - tb[0].data_ptr()) // 4
+            if step > 0 and tb[2].data_ptr() == tb[0].data_ptr() + 8 * step and all(
+                    t.is_contiguous() and t.untyped_storage().data_ptr() == tb[0].untyped_storage().data_ptr() for t in tb):
+                torch.as_strided(tb[0], (3, D), (step, 1)).add_(gb.view(3, D))      # q / k / v biases sit at one stride in the flat buffer
+            else:
+                for j, t in enumerate(tb):
+                    t.add_(gb[j * D: (j + 1) * D])
         if pre_ln:                       # LN1 sits in front of the attention: its parameters need the gradient even at the lowest layer
             if not (need_dx or train):
                 return None
