@@ -83,7 +83,8 @@ class GeneralBranch(nn.Module):
         """kw_branches.py:143-156.  Exact fp32 on the matrix pipe (linear_fn.LinearF32Fn): the projected keywords are compared
         against the whole vocabulary by an argmax, so their operands are not rounded to bf16."""
         if isinstance(self.linear_proj, nn.Linear):
-            features = linear_f32_autograd(features.float(), self.linear_proj.weight, self.linear_proj.bias)
+            # (train steps: exact forward, gradient products on the bf16 GEMMs - only the forward decides a token)
+            features = linear_f32_autograd(features.float(), self.linear_proj.weight, self.linear_proj.bias, bf16_backward=self.training)
         else:
             features = self.linear_proj(features.float())
         if hasattr(self, "bn_layer"):

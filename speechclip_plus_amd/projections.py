@@ -19,5 +19,6 @@ class MLPLayers(nn.Module):
 
     def forward(self, X):
         for m in self.sequential:
-            X = linear_f32_autograd(X, m.weight, m.bias) if isinstance(m, nn.Linear) else m(X)
+            # exact forward; in train steps the two gradient products of a layer run on the bf16 GEMMs (linear_fn.LinearF32Fn)
+            X = linear_f32_autograd(X, m.weight, m.bias, bf16_backward=self.training) if isinstance(m, nn.Linear) else m(X)
         return X
