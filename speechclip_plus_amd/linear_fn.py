@@ -80,13 +80,19 @@ class LinearF32Fn(torch.autograd.Function):
         dx = gW = gb = None
         if ctx.fast:
             rp = (rows + 63) // 64 * 64
-            dyb = torch.zeros(rp, N, device=dy.device, dtype=torch.bfloat16)
-            dyb[:rows] = dy2
+
+            def rows64(t, width):              # bf16 rows, zero-padded to a multiple of 64 (one cast when nothing is to pad)
+                if rp == rows:
+                    return t.to(torch.bfloat16)
+                b = torch.zeros(rp, width, device=dy.device, dtype=torch.bfloat16)
+                b[:rows] = t
+                return b
+
+            dyb = rows64(dy2, N)
             if ctx.needs_input_grad[0]:
                 dx = ops.linear_bf16(dyb, w.t().to(torch.bfloat16).contiguous())[:rows].to(dtype).reshape(shape)
             if ctx.needs_input_grad[1]:
-                xb = torch.zeros(rp, K, device=dy.device, dtype=torch.bfloat16)
-                xb[:rows] = x2
+                xb = rows64(x2, K)
                 gW = torch.empty(N, K, device=dy.device, dtype=torch.float32)
                 gb = torch.empty(N, device=dy.device, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
                 ops.wgrad_bf16(dyb, xb, gW, gb, beta=0.0)
