@@ -20,6 +20,7 @@
 // fixed summation order.  Query rows >= q_rows carry dO = 0 (the caller's contract: layout padding) and are never visited;
 // padded / future keys get P = 0.
 #include "sc_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -179,12 +180,19 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bwd_args& p) {
                 }
             }
             f32x16 ds;
+            // the key-validity / causal tests only where a key of this block can fail them (wave-uniform, as in the forward kernel):
+            // the last valid block, the blocks on or behind the diagonal, segment-causal packing
+            if (kbase + 32 > n_valid || (p.causal && kbase + 31 > q0) || p.causal > 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kidx = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const bool ok = kidx < n_valid && !(p.causal && kidx > qrow) && !(p.causal > 1 && kidx < (qrow & ~(p.causal - 1)));
-                const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse)) : 0.f;
-                ds[r] = pr * (dp[r] - dl);
+                for (int r = 0; r < 16; ++r) {
+                    const int kidx = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const bool ok = kidx < n_valid && !(p.causal && kidx > qrow) && !(p.causal > 1 && kidx < (qrow & ~(p.causal - 1)));
+                    const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse)) : 0.f;
+                    ds[r] = pr * (dp[r] - dl);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse)) * (dp[r] - dl);
             }
             bf16x8 pf[2];
             acc_to_frag(ds, pf);
@@ -328,47 +336,55 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Oc, qb, l31, half, ks), vf[ks], dp, 0, 0, 0);
             }
             f32x16 pr, ds;
-            if constexpr (DROP) {
-                // The mask of (query, key) comes from hash word (element index >> 1): the two KEY lanes of a pair need the same word for
-                // every one of their 16 queries.  Each lane hashes 8 of them - the even lane registers 0 .. 7, the odd lane 8 .. 15 (16
-                // queries further) - and takes the other 8 from its neighbour (DPP quad_perm [1, 0, 3, 2]): half the hash work.
-                const bool odd = (krow & 1) != 0;
+            // mask tests only where a (query, key) pair of this block can fail them (wave-uniform): a wave with a padded key, the
+            // blocks on or above the diagonal, segment-causal packing
+            const bool masked = key0w + 32 > n_valid || (p.causal && key0w + 31 > qbase) || p.causal > 1;
+            auto elem = [&](auto MASKED) {
+                constexpr bool MK = decltype(MASKED)::value;
+                if constexpr (DROP) {
+                    // The mask of (query, key) comes from hash word (element index >> 1): the two KEY lanes of a pair need the same word
+                    // for every one of their 16 queries.  Each lane hashes 8 of them - the even lane registers 0 .. 7, the odd lane
+                    // 8 .. 15 (16 queries further) - and takes the other 8 from its neighbour (DPP quad_perm [1, 0, 3, 2]).
+                    const bool odd = (krow & 1) != 0;
 #pragma unroll
-                for (int sl = 0; sl < 8; ++sl) {
-                    const int g0 = sl >> 2, e = sl & 3;
-                    const int ql0 = qb * 32 + 8 * g0 + 4 * half, ql1 = ql0 + 16;              // registers sl and sl + 8
-                    const int q0i = qt0 + ql0 + e, q1i = q0i + 16;
-                    const uint32_t myq = (uint32_t)(odd ? q1i : q0i);
-                    const uint32_t mine = sc_hash32(((((uint32_t)((b * H + h) * R) + myq) * (uint32_t)R + (uint32_t)krow) >> 1) ^ p.drop_seed);
-                    const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);
-                    const uint32_t h0 = odd ? other : mine, h1 = odd ? mine : other;
-                    const float l0 = lse_c[ql0 + e], l1 = lse_c[ql1 + e], d0 = dl_c[ql0 + e], d1 = dl_c[ql1 + e];
+                    for (int sl = 0; sl < 8; ++sl) {
+                        const int g0 = sl >> 2, e = sl & 3;
+                        const int ql0 = qb * 32 + 8 * g0 + 4 * half, ql1 = ql0 + 16;              // registers sl and sl + 8
+                        const int q0i = qt0 + ql0 + e, q1i = q0i + 16;
+                        const uint32_t myq = (uint32_t)(odd ? q1i : q0i);
+                        const uint32_t mine = sc_hash32(((((uint32_t)((b * H + h) * R) + myq) * (uint32_t)R + (uint32_t)krow) >> 1) ^ p.drop_seed);
+                        const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);
+                        const uint32_t h0 = odd ? other : mine, h1 = odd ? mine : other;
+                        const float l0 = lse_c[ql0 + e], l1 = lse_c[ql1 + e], d0 = dl_c[ql0 + e], d1 = dl_c[ql1 + e];
 #pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        const int r = sl + 8 * w, qidx = w ? q1i : q0i;
-                        const uint32_t hsh = w ? h1 : h0;
-                        const bool ok = key_ok && !(p.causal && krow > qidx) && !(p.causal > 1 && krow < (qidx & ~(p.causal - 1)));
-                        const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -(w ? l1 : l0))) : 0.f;
-                        const bool keep = (odd ? (hsh >> 16) : (hsh & 0xffffu)) >= drop_thr;
-                        pr[r] = keep ? pv * drop_scale : 0.f;          // P' (dV = P'^T dO)
-                        ds[r] = pv * ((keep ? dp[r] * drop_scale : 0.f) - (w ? d1 : d0));
+                        for (int w = 0; w < 2; ++w) {
+                            const int r = sl + 8 * w, qidx = w ? q1i : q0i;
+                            const uint32_t hsh = w ? h1 : h0;
+                            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -(w ? l1 : l0)));
+                            if (MK && !(key_ok && !(p.causal && krow > qidx) && !(p.causal > 1 && krow < (qidx & ~(p.causal - 1))))) pv = 0.f;
+                            const bool keep = (odd ? (hsh >> 16) : (hsh & 0xffffu)) >= drop_thr;
+                            pr[r] = keep ? pv * drop_scale : 0.f;          // P' (dV = P'^T dO)
+                            ds[r] = pv * ((keep ? dp[r] * drop_scale : 0.f) - (w ? d1 : d0));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ql = qb * 32 + 8 * g + 4 * half;               // local query index of registers 4 g .. 4 g + 3
+                        const f32x4 l4 = *(const f32x4*)(lse_c + ql), d4 = *(const f32x4*)(dl_c + ql);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g + e, qidx = qt0 + ql + e;
+                            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e]));
+                            if (MK && !(key_ok && !(p.causal && krow > qidx) && !(p.causal > 1 && krow < (qidx & ~(p.causal - 1))))) pv = 0.f;
+                            pr[r] = pv;
+                            ds[r] = pv * (dp[r] - d4[e]);
+                        }
                     }
                 }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ql = qb * 32 + 8 * g + 4 * half;               // local query index of registers 4 g .. 4 g + 3
-                    const f32x4 l4 = *(const f32x4*)(lse_c + ql), d4 = *(const f32x4*)(dl_c + ql);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e, qidx = qt0 + ql + e;
-                        const bool ok = key_ok && !(p.causal && krow > qidx) && !(p.causal > 1 && krow < (qidx & ~(p.causal - 1)));
-                        const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e])) : 0.f;
-                        pr[r] = pv;
-                        ds[r] = pv * (dp[r] - d4[e]);
-                    }
-                }
-            }
+            };
+            if (masked) elem(std::true_type{});
+            else elem(std::false_type{});
             bf16x8 pf[2], df[2];
             acc_to_frag(pr, pf);
             acc_to_frag(ds, df);
