@@ -219,21 +219,33 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ u, const float* __rest
 }
 
 // out[j] = beta * out[j] + alpha * sum_i x[i * ld + j]      (bias gradients, split-K slices, LayerNorm parameter partials)
-// Many rows: block = 64 columns x 16 row groups; group g adds rows g, g + 16, ... in order, the group sums are added in order.
+// Many rows: block = CW columns x (1024 / CW) row groups; group g adds rows g, g + G, ... in order (four independent chains, joined in
+// order), the group sums are added in order.  CW = 16 for tall, narrow inputs (the [1024, 768] LayerNorm partials of a differentiated
+// layer: 48 workgroups x 16 rows per thread instead of 12 x 64 - 20 -> 6 us), 64 otherwise.
+template <int CW>
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int64_t ld, int rows, int cols,
                                                       float* __restrict__ out, float alpha, float beta) {
-    __shared__ float part[16][64];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int64_t j = (int64_t)blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (j < cols)
-        for (int r = g; r < rows; r += 16) s += x[(int64_t)r * ld + j];
-    part[g][c] = s;
+    constexpr int G = 1024 / CW;
+    __shared__ float part[G][CW];
+    const int c = threadIdx.x % CW, g = threadIdx.x / CW;
+    const int64_t j = (int64_t)blockIdx.x * CW + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < cols) {
+        int r = g;
+        for (; r + 3 * G < rows; r += 4 * G) {
+            s0 += x[(int64_t)r * ld + j];
+            s1 += x[(int64_t)(r + G) * ld + j];
+            s2 += x[(int64_t)(r + 2 * G) * ld + j];
+            s3 += x[(int64_t)(r + 3 * G) * ld + j];
+        }
+        for (; r < rows; r += G) s0 += x[(int64_t)r * ld + j];
+    }
+    part[g][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && j < cols) {
         float t = part[0][c];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) t += part[k][c];
+#pragma unroll 8
+        for (int k = 1; k < G; ++k) t += part[k][c];
         out[j] = (beta != 0.f ? beta * out[j] : 0.f) + alpha * t;
     }
 }
@@ -341,7 +353,10 @@ extern "C" int sc_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t c
         hipLaunchKernelGGL(colsum_few_rows_kernel, dim3((unsigned)((cols4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, rows,
                            cols4, out, alpha, beta);
     } else {
-        hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, rows, cols, out, alpha, beta);
+        if (rows >= 128 && cols <= 8192)
+            hipLaunchKernelGGL(colsum_kernel<16>, dim3((cols + 15) / 16), dim3(1024), 0, (hipStream_t)stream, x, ld, rows, cols, out, alpha, beta);
+        else
+            hipLaunchKernelGGL(colsum_kernel<64>, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, rows, cols, out, alpha, beta);
     }
     SC_LAUNCH_CHECK();
     return 0;
