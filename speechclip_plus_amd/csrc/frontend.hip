@@ -316,15 +316,16 @@ __global__ __launch_bounds__(256) void conv0_gn_bwd_kernel(const float* __restri
     const int wc = blockIdx.x * 4 + wave;
     const float* x = wav + (int64_t)b * ldw;
     const int c0 = lane * 8;
-    float w[8][10], sc[8], sh[8], acc[8][C0_NS];
+    // channel PAIRS in packed fp32 (v_pk_fma_f32), as the forward kernel: 4 pairs x (10 taps + 12 running sums) per row
+    f32x2 w[4][10], sc[4], sh[4], acc[4][C0_NS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 10; ++j) w[i][j] = w0[(c0 + i) * 10 + j];
-        sc[i] = scale[(int64_t)b * C + c0 + i];
-        sh[i] = shift[(int64_t)b * C + c0 + i];
+        for (int j = 0; j < 10; ++j) w[i][j] = f32x2{w0[(c0 + 2 * i) * 10 + j], w0[(c0 + 2 * i + 1) * 10 + j]};
+        sc[i] = *(const f32x2*)(scale + (int64_t)b * C + c0 + 2 * i);
+        sh[i] = *(const f32x2*)(shift + (int64_t)b * C + c0 + 2 * i);
 #pragma unroll
-        for (int e = 0; e < C0_NS; ++e) acc[i][e] = 0.f;
+        for (int e = 0; e < C0_NS; ++e) acc[i][e] = f32x2{0.f, 0.f};
     }
     const int t_end = min(T0, (wc + 1) * rpw);
     for (int t = wc * rpw; t < t_end; ++t) {
@@ -332,26 +333,29 @@ __global__ __launch_bounds__(256) void conv0_gn_bwd_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];              // wave-uniform address: scalar loads
         const uint4 d = *(const uint4*)(dy + ((int64_t)b * R0 + t) * C + c0);
-        const float g[8] = {bflo(d.x), bfhi(d.x), bflo(d.y), bfhi(d.y), bflo(d.z), bfhi(d.z), bflo(d.w), bfhi(d.w)};
+        const f32x2 g[4] = {f32x2{bflo(d.x), bfhi(d.x)}, f32x2{bflo(d.y), bfhi(d.y)}, f32x2{bflo(d.z), bfhi(d.z)}, f32x2{bflo(d.w), bfhi(d.w)}};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float u = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            f32x2 u = f32x2{0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 10; ++j) u = fmaf(w[i][j], v[j], u);
-            const float n = fmaf(u, sc[i], sh[i]);
-            const float dn = g[i] * gelu_grad_as(n);
+            for (int j = 0; j < 10; ++j) u = __builtin_elementwise_fma(w[i][j], f32x2{v[j], v[j]}, u);
+            const f32x2 n = __builtin_elementwise_fma(u, sc[i], sh[i]);
+            const f32x2 dn = g[i] * gelu_grad_as2(n);
             acc[i][0] += dn;
-            acc[i][1] = fmaf(dn, n, acc[i][1]);
+            acc[i][1] = __builtin_elementwise_fma(dn, n, acc[i][1]);
 #pragma unroll
-            for (int j = 0; j < 10; ++j) acc[i][2 + j] = fmaf(dn, v[j], acc[i][2 + j]);
+            for (int j = 0; j < 10; ++j) acc[i][2 + j] = __builtin_elementwise_fma(dn, f32x2{v[j], v[j]}, acc[i][2 + j]);
         }
     }
     if (wc < nwc) {
         float* pp = partial + (((int64_t)b * nwc + wc) * C + c0) * C0_NS;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < C0_NS; e += 4) *(f32x4*)(pp + i * C0_NS + e) = f32x4{acc[i][e], acc[i][e + 1], acc[i][e + 2], acc[i][e + 3]};
+            for (int e = 0; e < C0_NS; e += 4) {
+                *(f32x4*)(pp + (2 * i) * C0_NS + e) = f32x4{acc[i][e].x, acc[i][e + 1].x, acc[i][e + 2].x, acc[i][e + 3].x};
+                *(f32x4*)(pp + (2 * i + 1) * C0_NS + e) = f32x4{acc[i][e].y, acc[i][e + 1].y, acc[i][e + 2].y, acc[i][e + 3].y};
+            }
     }
 }
 

@@ -117,6 +117,33 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     return __builtin_elementwise_fma(-ah, r, h + ah);
 }
 
+// gelu_grad_as on two elements: the polynomial, squarings and products as packed fp32 ops, rcp / exp per element.  Same operation order
+// as gelu_grad_as => the same bits.
+__device__ __forceinline__ f32x2 gelu_grad_as2(f32x2 x) {
+    f32x2 ax;
+    ax.x = fabsf(x.x); ax.y = fabsf(x.y);
+    const f32x2 z = ax * 0.70710678118654752f;
+    f32x2 p = __builtin_elementwise_fma(f32x2{0.0000430638f, 0.0000430638f}, z, f32x2{0.0002765672f, 0.0002765672f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0001520143f, 0.0001520143f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0092705272f, 0.0092705272f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0422820123f, 0.0422820123f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0705230784f, 0.0705230784f});
+    p = __builtin_elementwise_fma(p, z, f32x2{1.0f, 1.0f});
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    f32x2 he;
+    he.x = 0.5f * __builtin_amdgcn_rcpf(p.x); he.y = 0.5f * __builtin_amdgcn_rcpf(p.y);
+    f32x2 cdf;
+    cdf.x = x.x >= 0.f ? 1.f - he.x : he.x;
+    cdf.y = x.y >= 0.f ? 1.f - he.y : he.y;
+    const f32x2 xx = (x * -0.5f) * x;
+    f32x2 ex;
+    ex.x = __expf(xx.x); ex.y = __expf(xx.y);
+    return __builtin_elementwise_fma(x * 0.3989422804014327f, ex, cdf);
+}
+
 // Stateless dropout masks (train mode): lowbias32 integer hash of (element-pair index ^ seed); the low / high 16 bits decide
 // the even / odd element of the pair: keep iff bits >= thr16 = round(p * 65536).  The same function is evaluated on the host
 // (tests/, numpy uint32) to reconstruct a mask exactly.
