@@ -348,7 +348,8 @@ extern "C" int sc_gelu_f32(const float* u, const float* df, float* out, int64_t 
 extern "C" int sc_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float* out, float alpha, float beta,
                              void* stream) {
     SC_CHECK(x && out && rows > 0 && cols > 0, "sc_colsum_f32: bad args");
-    if (rows <= 16 && cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+    // (up to 32 rows: the 28 split-K slices of a 768 x 768 weight gradient - 16-byte loads, 26.7 -> ~12 us)
+    if (rows <= 32 && cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0) {
         const int64_t cols4 = cols / 4;
         hipLaunchKernelGGL(colsum_few_rows_kernel, dim3((unsigned)((cols4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, rows,
                            cols4, out, alpha, beta);
