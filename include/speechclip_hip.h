@@ -439,7 +439,7 @@ int sc_cif_tail(const float* alpha, const float* csum, int32_t B, int32_t S, int
  *                      set to -inf IN PLACE (the reference's x[:, i] += -inf), idx = first argmax, lse_t = LSE(x / temp),
  *                      lse_1 = LSE(x), ent = - sum p log(p + 1e-9) with p = softmax(x)       (my_vector_quantizer.py:80-116)
  *   sc_vq_perplexity   out2[0] = code_perplexity (histogram of idx), out2[1] = prob_perplexity (column means of softmax(x));
- *                      workspaces: partial [nchunk, V] fp32, hist [V] int32
+ *                      workspaces: partial [nchunk, V] fp32, hist [V + 64] int32 (the last 64 words: per-workgroup entropy partials)
  *   sc_vq_gather_f32   out[n] = table[idx[n]]   (= hard one-hot @ token_embedding)
  *   sc_vq_onehot_f32   dense hard one-hot [Nk, ldo] (module-level subword_prob)
  *   sc_vq_soft_bwd     dx = softmax(x / temp) (t - <softmax, t>) / temp, t = d subword_prob [Nk, ldt]; out bf16 (feeds the bf16

@@ -12,7 +12,7 @@
 //   sc_vq_rowstats        per row: mask columns -> -inf (written back, as the reference's in-place `x[:, i] += -inf`), argmax,
 //                         LSE(x / temp), LSE(x), entropy of softmax(x)
 //   sc_vq_colprob         partial column sums of softmax(x) (prob_perplexity)      grid = column blocks x row chunks, fixed order
-//   sc_vq_perplexity      code_perplexity (histogram of the argmax indices) + prob_perplexity, one workgroup
+//   sc_vq_perplexity      code_perplexity (histogram of the argmax indices) + prob_perplexity: count, per-workgroup entropy sums, final
 //   sc_vq_gather_f32      out[n] = table[idx[n]]    (value of hard @ token_embedding)
 //   sc_vq_onehot_f32      dense subword_prob for the module-level API (hard one-hot; the straight-through term is value-neutral)
 //   sc_vq_soft_bwd        dx = softmax(x / temp) * (t - <softmax, t>) / temp   (t = d subword_prob), bf16 or fp32 out
@@ -23,45 +23,51 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ prep
+// grid (row blocks of 64, column blocks of 64): every workgroup recomputes the norms of its 64 rows (four threads per row, independent
+// 16-byte loads; the rows come out of the L2) and normalises + transposes ONE 64 x 64 tile.  (The first version walked all column
+// tiles of a row block in one workgroup, 16 rows per wave one after the other: 26 workgroups, 67 - 102 us for 3 - 5 MB.)
 __global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ kw, int64_t ldk, int Nk, int Et, float eps,
                                                       float* __restrict__ kwn_T, int64_t ldt, float* __restrict__ rnorm) {
     __shared__ float rn[64];
     __shared__ float tile[64][65];
-    const int n0 = blockIdx.x * 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wave * 16 + r;
+    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    {
+        const int r = threadIdx.x >> 2, q = threadIdx.x & 3, n = n0 + r;
         float ss = 0.f;
-        if (n < Nk)
-            for (int k = lane; k < Et; k += 64) {
-                const float v = kw[(int64_t)n * ldk + k];
-                ss = fmaf(v, v, ss);
+        if (n < Nk) {
+            const float* row = kw + (int64_t)n * ldk;
+            if ((Et & 3) == 0 && (ldk & 3) == 0 && (((uintptr_t)kw) & 15) == 0) {
+                for (int k = q * 4; k < Et; k += 16) {
+                    const f32x4 v = *(const f32x4*)(row + k);
+                    ss = fmaf(v[0], v[0], ss); ss = fmaf(v[1], v[1], ss); ss = fmaf(v[2], v[2], ss); ss = fmaf(v[3], v[3], ss);
+                }
+            } else {
+                for (int k = q; k < Et; k += 4) ss = fmaf(row[k], row[k], ss);
             }
-        ss = wave_sum(ss);
-        if (lane == 0) {
+        }
+        ss += __shfl_xor(ss, 1);
+        ss += __shfl_xor(ss, 2);
+        if (q == 0) {
             const float r_ = (n < Nk) ? 1.f / fmaxf(sqrtf(ss), eps) : 0.f;
-            rn[wave * 16 + r] = r_;
-            if (n < Nk) rnorm[n] = r_;
+            rn[r] = r_;
+            if (n < Nk && blockIdx.y == 0) rnorm[n] = r_;
         }
     }
     __syncthreads();
-    for (int k0 = 0; k0 < Et; k0 += 64) {
 #pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int idx = threadIdx.x + i * 256;
-            const int r = idx >> 6, c = idx & 63;
-            const int n = n0 + r, k = k0 + c;
-            tile[r][c] = (n < Nk && k < Et) ? kw[(int64_t)n * ldk + k] * rn[r] : 0.f;
-        }
-        __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int r = idx >> 6, c = idx & 63;
+        const int n = n0 + r, k = k0 + c;
+        tile[r][c] = (n < Nk && k < Et) ? kw[(int64_t)n * ldk + k] * rn[r] : 0.f;
+    }
+    __syncthreads();
 #pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int idx = threadIdx.x + i * 256;
-            const int c = idx >> 6, r = idx & 63;
-            const int k = k0 + c;
-            if (k < Et) kwn_T[(int64_t)k * ldt + n0 + r] = tile[r][c];
-        }
-        __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int c = idx >> 6, r = idx & 63;
+        const int k = k0 + c;
+        if (k < Et) kwn_T[(int64_t)k * ldt + n0 + r] = tile[r][c];
     }
 }
 
@@ -276,33 +282,35 @@ __global__ __launch_bounds__(256) void vq_rowstats_kernel(float* __restrict__ x,
     }
 }
 
-// partial[chunk][v] = sum over the chunk's rows of exp(x[n, v] - lse_1[n])
+// partial[chunk][v] = sum over the chunk's rows of exp(x[n, v] - lse_1[n]); the blocks of chunk 0 also clear the histogram word of
+// their column (the counting launch comes next)
 __global__ __launch_bounds__(256) void vq_colprob_kernel(const float* __restrict__ x, int64_t ldx, int Nk, int V,
                                                          const float* __restrict__ lse_1, int rows_per_chunk,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, int* __restrict__ hist) {
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int n0 = blockIdx.y * rows_per_chunk;
     const int n1 = min(Nk, n0 + rows_per_chunk);
     if (v >= V) return;
+    if (blockIdx.y == 0) hist[v] = 0;
     float s = 0.f;
     for (int n = n0; n < n1; ++n) s += __expf(x[(int64_t)n * ldx + v] - lse_1[n]);
     partial[(int64_t)blockIdx.y * V + v] = s;
 }
 
-// out[0] = code_perplexity = exp(-sum hp log(hp + 1e-7)), hp = histogram(idx) / Nk
-// out[1] = prob_perplexity = exp(-sum ap log(ap + 1e-7)), ap = sum_chunks partial / Nk
-__global__ __launch_bounds__(1024) void vq_perplexity_kernel(const int64_t* __restrict__ idx, int Nk, int V,
-                                                             const float* __restrict__ partial, int nchunk, int* __restrict__ hist,
-                                                             float* __restrict__ out) {
+__global__ __launch_bounds__(256) void vq_hist_kernel(const int64_t* __restrict__ idx, int Nk, int* __restrict__ hist) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < Nk) atomicAdd(&hist[(int)idx[n]], 1);               // integer atomics: order-independent
+}
+
+// per workgroup w: ent[2 w] = sum over its columns of hp log(hp + 1e-7), ent[2 w + 1] = sum of ap log(ap + 1e-7),
+// hp = histogram(idx) / Nk, ap = sum_chunks partial / Nk   (one workgroup walked all V columns x nchunk partials: 40 - 93 us)
+__global__ __launch_bounds__(1024) void vq_entropy_kernel(int Nk, int V, const float* __restrict__ partial, int nchunk,
+                                                          const int* __restrict__ hist, float* __restrict__ ent) {
     __shared__ float red[16];
-    for (int v = threadIdx.x; v < V; v += 1024) atomicExch(&hist[v], 0);
-    __syncthreads();
-    for (int n = threadIdx.x; n < Nk; n += 1024) atomicAdd(&hist[(int)idx[n]], 1);
-    __syncthreads();
     const float inv = 1.f / (float)Nk;
     float sc = 0.f, sp = 0.f;
-    for (int v = threadIdx.x; v < V; v += 1024) {
-        const float hp = (float)atomicAdd(&hist[v], 0) * inv;
+    for (int v = blockIdx.x * 1024 + threadIdx.x; v < V; v += gridDim.x * 1024) {
+        const float hp = (float)hist[v] * inv;
         sc += hp * __logf(hp + 1e-7f);
         float a = 0.f;
         for (int c = 0; c < nchunk; ++c) a += partial[(int64_t)c * V + v];
@@ -312,6 +320,17 @@ __global__ __launch_bounds__(1024) void vq_perplexity_kernel(const int64_t* __re
     sc = block_sum<16>(sc, red);
     sp = block_sum<16>(sp, red);
     if (threadIdx.x == 0) {
+        ent[2 * blockIdx.x] = sc;
+        ent[2 * blockIdx.x + 1] = sp;
+    }
+}
+
+// out[0] = code_perplexity = exp(-sum hp log(hp + 1e-7)), out[1] = prob_perplexity = exp(-sum ap log(ap + 1e-7)): the workgroups'
+// sums added in order
+__global__ void vq_perplexity_kernel(const float* __restrict__ ent, int nw, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float sc = 0.f, sp = 0.f;
+        for (int w = 0; w < nw; ++w) { sc += ent[2 * w]; sp += ent[2 * w + 1]; }
         out[0] = __expf(-sc);
         out[1] = __expf(-sp);
     }
@@ -378,12 +397,13 @@ __global__ __launch_bounds__(256) void vq_norm_bwd_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------ keyword BatchNorm (kw_bn.py:167-228)
 // nn.BatchNorm1d over the keyword positions: x [N, E] fp32 (N = batch x keyword slots, padded slots included, as the reference's
-// permute(0, 2, 1) view feeds them), statistics per channel.  One workgroup per 32 channels, 1024 threads = 32 row lanes x 32 columns
-// (every load instruction reads whole 128-byte segments; 8 row lanes left each thread a 200-row serial walk per pass: 102 -> ~30 us);
-// two-pass mean / variance, then the normalisation, all out of the L2.  The row lanes are added in fixed order.
-constexpr int BN_RL = 32;                                                         // row lanes
-__device__ __forceinline__ float col_reduce8(float v, float (*red)[33]) {       // sum over the row lanes of a column
-    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+// permute(0, 2, 1) view feeds them), statistics per channel.  One workgroup per BN_CB = 8 channels, 1024 threads = 128 row lanes x 8
+// columns: 64 - 96 workgroups and a 13-row serial walk per pass at N = 1600 (32 channels x 32 row lanes: 16 - 24 workgroups, 50 rows,
+// 30 - 39 us; 8 row lanes: 102 us); two-pass mean / variance, then the normalisation, all out of the L2.  The row lanes are added in
+// fixed order.
+constexpr int BN_CB = 8, BN_RL = 1024 / BN_CB;                                    // channels per workgroup, row lanes
+__device__ __forceinline__ float col_reduce8(float v, float (*red)[BN_CB + 1]) {  // sum over the row lanes of a column
+    const int c = threadIdx.x % BN_CB, r = threadIdx.x / BN_CB;
     __syncthreads();
     red[r][c] = v;
     __syncthreads();
@@ -398,9 +418,9 @@ __global__ __launch_bounds__(1024) void bn_fwd_kernel(const float* __restrict__ 
                                                      float* __restrict__ run_var, int training, float momentum, float eps,
                                                      float* __restrict__ y, int64_t ldy, float* __restrict__ save_mean,
                                                      float* __restrict__ save_rstd) {
-    __shared__ float red[BN_RL][33];
-    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + c;
+    __shared__ float red[BN_RL][BN_CB + 1];
+    const int c = threadIdx.x % BN_CB, r = threadIdx.x / BN_CB;
+    const int e = blockIdx.x * BN_CB + c;
     const bool ok = e < E;
     float mean, rstd;
     if (training) {
@@ -434,9 +454,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_kernel(const float* __restrict__ 
                                                      int N, int E, const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                                      const float* __restrict__ save_rstd, float* __restrict__ dx, int64_t ldd,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float red[BN_RL][33];
-    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + c;
+    __shared__ float red[BN_RL][BN_CB + 1];
+    const int c = threadIdx.x % BN_CB, r = threadIdx.x / BN_CB;
+    const int e = blockIdx.x * BN_CB + c;
     const bool ok = e < E;
     const float mean = ok ? save_mean[e] : 0.f, rstd = ok ? save_rstd[e] : 0.f;
     float sb = 0.f, sg = 0.f;
@@ -466,7 +486,7 @@ extern "C" int sc_vq_prep_f32(const float* kw, int64_t ldk, int32_t Nk, int32_t 
                               void* stream) {
     SC_CHECK(kw && kwn_T && rnorm, "sc_vq_prep_f32: null pointer");
     SC_CHECK(Nk > 0 && Et > 0 && ldt % 64 == 0 && ldt >= Nk, "sc_vq_prep_f32: ldt must be a multiple of 64 >= Nk");
-    hipLaunchKernelGGL(vq_prep_kernel, dim3((unsigned)(ldt / 64)), dim3(256), 0, (hipStream_t)stream, kw, ldk, Nk, Et, eps, kwn_T, ldt, rnorm);
+    hipLaunchKernelGGL(vq_prep_kernel, dim3((unsigned)(ldt / 64), (unsigned)((Et + 63) / 64)), dim3(256), 0, (hipStream_t)stream, kw, ldk, Nk, Et, eps, kwn_T, ldt, rnorm);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -543,9 +563,17 @@ extern "C" int sc_vq_perplexity(const float* x, int64_t ldx, int32_t Nk, int32_t
     SC_CHECK(x && idx && lse_1 && partial && hist && out2, "sc_vq_perplexity: null pointer");
     SC_CHECK(Nk > 0 && V > 0 && nchunk > 0, "sc_vq_perplexity: bad arguments");
     const int rpc = (Nk + nchunk - 1) / nchunk;
-    hipLaunchKernelGGL(vq_colprob_kernel, dim3((V + 255) / 256, nchunk), dim3(256), 0, (hipStream_t)stream, x, ldx, Nk, V, lse_1, rpc, partial);
+    hipStream_t s = (hipStream_t)stream;
+    // hist [V + 64] int32: the 64 words behind the histogram hold the entropy partials of <= 32 workgroups (as floats)
+    float* ent = (float*)(hist + V);
+    const int nw = (V + 1023) / 1024 < 32 ? (V + 1023) / 1024 : 32;
+    hipLaunchKernelGGL(vq_colprob_kernel, dim3((V + 255) / 256, nchunk), dim3(256), 0, s, x, ldx, Nk, V, lse_1, rpc, partial, hist);
     SC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vq_perplexity_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx, Nk, V, partial, nchunk, hist, out2);
+    hipLaunchKernelGGL(vq_hist_kernel, dim3((Nk + 255) / 256), dim3(256), 0, s, idx, Nk, hist);
+    SC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vq_entropy_kernel, dim3(nw), dim3(1024), 0, s, Nk, V, partial, nchunk, (const int*)hist, ent);
+    SC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vq_perplexity_kernel, dim3(1), dim3(64), 0, s, (const float*)ent, nw, out2);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -593,7 +621,7 @@ extern "C" int sc_bn_rows_fwd(const float* x, int64_t ldx, int32_t N, int32_t E,
                               float* save_rstd, void* stream) {
     SC_CHECK(x && gamma && beta && run_mean && run_var && y, "sc_bn_rows_fwd: null pointer");
     SC_CHECK(N > 0 && E > 0 && (!training || (save_mean && save_rstd)), "sc_bn_rows_fwd: bad arguments");
-    hipLaunchKernelGGL(bn_fwd_kernel, dim3((E + 31) / 32), dim3(32 * BN_RL), 0, (hipStream_t)stream, x, ldx, N, E, gamma, beta, run_mean, run_var,
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3((E + BN_CB - 1) / BN_CB), dim3(BN_CB * BN_RL), 0, (hipStream_t)stream, x, ldx, N, E, gamma, beta, run_mean, run_var,
                        training, momentum, eps, y, ldy, save_mean, save_rstd);
     SC_LAUNCH_CHECK();
     return 0;
@@ -604,7 +632,7 @@ extern "C" int sc_bn_rows_bwd(const float* x, int64_t ldx, const float* dy, int6
                               void* stream) {
     SC_CHECK(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta, "sc_bn_rows_bwd: null pointer");
     SC_CHECK(N > 0 && E > 0, "sc_bn_rows_bwd: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3((E + 31) / 32), dim3(32 * BN_RL), 0, (hipStream_t)stream, x, ldx, dy, ldg, N, E, gamma, save_mean,
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3((E + BN_CB - 1) / BN_CB), dim3(BN_CB * BN_RL), 0, (hipStream_t)stream, x, ldx, dy, ldg, N, E, gamma, save_mean,
                        save_rstd, dx, ldd, dgamma, dbeta);
     SC_LAUNCH_CHECK();
     return 0;

@@ -674,7 +674,7 @@ def vq_perplexity(x: torch.Tensor, V: int, idx: torch.Tensor, lse_1: torch.Tenso
     Nk = x.shape[0]
     nchunk = max(1, min(nchunk, Nk))
     partial = torch.empty(nchunk, V, device=x.device, dtype=torch.float32)
-    hist = torch.empty(V, device=x.device, dtype=torch.int32)
+    hist = torch.empty(V + 64, device=x.device, dtype=torch.int32)       # + 64 words: the entropy partials of the workgroups
     out = torch.empty(2, device=x.device, dtype=torch.float32)
     check(lib().sc_vq_perplexity(_p(x), x.stride(0), Nk, V, _p(idx), _p(lse_1), _p(partial), nchunk, _p(hist), _p(out), _stream()),
           "sc_vq_perplexity")
