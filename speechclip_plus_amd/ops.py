@@ -806,7 +806,7 @@ def wav_prep_seg(wav: torch.Tensor, wav_len: torch.Tensor, out_flat: torch.Tenso
 
 def conv0_groupnorm_gelu_seg(wav: torch.Tensor, wav_len: torch.Tensor, wav_flat: torch.Tensor, seg: "RowSegments", samples_per_row: int,
                              w0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, T0: int, out: torch.Tensor, eps: float = 1e-5,
-                             nchunk: int = 32) -> None:
+                             nchunk: int = 8) -> None:
     """conv layer 0 + GroupNorm + GELU on ragged rows.  The GroupNorm statistics run over the PADDED batch length T0 (fairseq feeds the
     zero-padded batch, speech_encoder_plus.py:75) and come straight from the caller's [B, L] batch masked by wav_len; the activation is
     written for the rows of the segment layout only."""
@@ -829,7 +829,7 @@ def conv0_layernorm_gelu_seg(wav_flat: torch.Tensor, seg: "RowSegments", samples
 
 
 def conv0_groupnorm_gelu(wav_pad: torch.Tensor, w0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, T0: int,
-                         R0: int, out: torch.Tensor, eps: float = 1e-5, nchunk: int = 32):
+                         R0: int, out: torch.Tensor, eps: float = 1e-5, nchunk: int = 8):
     """conv layer 0 + GroupNorm(C groups) over t < T0 + GELU -> out[B*R0, C] bf16 (channels-last).  Returns what the backward
     (conv0_groupnorm_gelu_bwd) needs: (scale, shift, Gram statistics, nchunk)."""
     B = wav_pad.shape[0]
