@@ -43,6 +43,24 @@ __device__ __forceinline__ void stage_meta(frame_meta* sm, const float* __restri
 
 constexpr int UNROLL = 8;
 
+// the backward's arithmetic spelled out (no compiler-chosen contraction): the sequential and the parallel kernels, fp32 and bf16 frames,
+// must produce the same bits
+__device__ __forceinline__ float dot4(const float4 v, const float4 g) {
+    return fmaf(v.w, g.w, fmaf(v.z, g.z, fmaf(v.y, g.y, __fmul_rn(v.x, g.x))));
+}
+__device__ __forceinline__ float4 sub4(const float4 a, const float4 b) {
+    return float4{__fsub_rn(a.x, b.x), __fsub_rn(a.y, b.y), __fsub_rn(a.z, b.z), __fsub_rn(a.w, b.w)};
+}
+__device__ __forceinline__ float4 scale4(const float s, const float4 g) {
+    return float4{__fmul_rn(s, g.x), __fmul_rn(s, g.y), __fmul_rn(s, g.z), __fmul_rn(s, g.w)};
+}
+// d + rw gr + thr mid
+__device__ __forceinline__ float4 fire4(const float4 d, const float rw, const float4 gr, const float thr, const float4 mid) {
+    return float4{fmaf(rw, gr.x, fmaf(thr, mid.x, d.x)), fmaf(rw, gr.y, fmaf(thr, mid.y, d.y)), fmaf(rw, gr.z, fmaf(thr, mid.z, d.z)),
+                  fmaf(rw, gr.w, fmaf(thr, mid.w, d.w))};
+}
+
+
 // the frames arrive as fp32 [B, S, C] or as the bf16 rows the attention block's LayerNorm wrote (round 4: row pitch of the block's
 // buffer, no fp32 copy of the activations in between); the gradient leaves the same way
 // A prefetched row stays in registers AS LOADED (float4 / the 8 raw bytes of 4 bf16) and is converted where it is consumed: converting
@@ -95,10 +113,10 @@ __global__ __launch_bounds__(64) void cif_fwd_kernel(const XT* __restrict__ x, i
                 if (m.right != m.left) {
                     if (active) {
                         *(float4*)(ob + (int64_t)m.left * C) = acc;
-                        const float4 w = {thr * v.x, thr * v.y, thr * v.z, thr * v.w};
+                        const float4 w = scale4(thr, v);
                         for (int j = 1; j <= extra; ++j) *(float4*)(ob + (int64_t)(m.left + j) * C) = w;
                     }
-                    acc = float4{m.rw * v.x, m.rw * v.y, m.rw * v.z, m.rw * v.w};
+                    acc = scale4(m.rw, v);
                     cur = m.right;
                 }
             }
@@ -149,8 +167,8 @@ __global__ __launch_bounds__(64) void cif_bwd_kernel(const XT* __restrict__ x, i
                 const frame_meta m = sm[s];
                 const int extra = m.right - m.left - 1;
                 const float4 v = row_f4(xv[u]);
-                float4 d = {m.lw * gl.x, m.lw * gl.y, m.lw * gl.z, m.lw * gl.w};
-                a = v.x * gl.x + v.y * gl.y + v.z * gl.z + v.w * gl.w;
+                float4 d = scale4(m.lw, gl);
+                a = dot4(v, gl);
                 if (m.right != m.left) {
                     const float4 gr = extra == 0 ? gn : (active ? *(const float4*)(gb + (int64_t)m.right * C) : zero);
                     float4 mid = zero;
@@ -158,9 +176,8 @@ __global__ __launch_bounds__(64) void cif_bwd_kernel(const XT* __restrict__ x, i
                         const float4 t = active ? *(const float4*)(gb + (int64_t)(m.left + j) * C) : zero;
                         mid.x += t.x; mid.y += t.y; mid.z += t.z; mid.w += t.w;
                     }
-                    d.x += m.rw * gr.x + thr * mid.x; d.y += m.rw * gr.y + thr * mid.y;
-                    d.z += m.rw * gr.z + thr * mid.z; d.w += m.rw * gr.w + thr * mid.w;
-                    bq = v.x * (gr.x - gl.x) + v.y * (gr.y - gl.y) + v.z * (gr.z - gl.z) + v.w * (gr.w - gl.w);
+                    d = fire4(d, m.rw, gr, thr, mid);
+                    bq = dot4(v, sub4(gr, gl));
                     gl = gr;
                     gn = active ? *(const float4*)(gb + (int64_t)min(m.right + 1, T) * C) : zero;
                 }
@@ -180,6 +197,139 @@ __global__ __launch_bounds__(64) void cif_bwd_kernel(const XT* __restrict__ x, i
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) xv[u] = xn[u];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ the same, parallel over slots / frames
+// The frame walk above is one dependent chain of S frames per wave (~150 ns a frame: 71 us forward, 128 us backward at S = 499 whatever
+// the width).  But an output slot only sums a CONTIGUOUS run of frames - the frame that fired into it (weight rw) and the frames whose
+// left slot it is (weights lw), in frame order - and the backward of a frame only reads the slots it touched.  One wave per (slot,
+// 256-channel block, utterance) forward, one per (8 frames, 256-channel block, utterance) backward: the same operations on the same
+// values in the same order (bitwise the sequential kernels' results), chains of ~S / T frames.
+__device__ __forceinline__ int cif_right(float c, float thr, int T) { return min(max((int)floorf(c / thr), 0), T); }
+
+// first s in [0, S) with right_s >= t, or S (right is non-decreasing): the 64 lanes test 64 candidates at a time
+__device__ __forceinline__ int cif_first_right_ge(const float* __restrict__ cs, int S, float thr, int T, int t, int lane) {
+    int lo = 0, hi = S;                                      // answer in [lo, hi]; hi < S means right_hi >= t is already known
+    while (hi > lo) {
+        const int step = (hi - lo + 63) >> 6;                // lane l tests the LAST index of its sub-range [lo + l step, lo + (l+1) step)
+        const int idx = min(lo + (lane + 1) * step - 1, hi - 1);
+        const unsigned long long m = __ballot(cif_right(cs[idx], thr, T) >= t);
+        if (m == 0ull) return hi;                            // not even hi - 1: nothing in [lo, hi)
+        const int l0 = __ffsll((long long)m) - 1;             // the first sub-range whose end satisfies it holds the answer
+        hi = min(lo + (l0 + 1) * step - 1, hi - 1);
+        lo = lo + l0 * step;
+    }
+    return lo;
+}
+
+template <typename XT>
+__global__ __launch_bounds__(64) void cif_fwd_slot_kernel(const XT* __restrict__ x, int64_t xbs, const float* __restrict__ alpha,
+                                                          const float* __restrict__ csum, float* __restrict__ out, int S, int C, int T,
+                                                          float thr) {
+    const int b = blockIdx.z, t = blockIdx.y, lane = threadIdx.x, c0 = (blockIdx.x * 64 + lane) * 4;
+    const bool active = c0 < C;
+    const XT* xb = x + (int64_t)b * xbs + (active ? c0 : 0);
+    const float* cs = csum + (int64_t)b * S;
+    const float* al = alpha + (int64_t)b * S;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    // f = first frame whose LEFT slot is >= t (left_s = right_{s-1}, left_0 = 0)
+    int f = 0;
+    bool live = true;                                        // does the sequential walk write this slot at all?
+    if (t > 0) {
+        const int a = cif_first_right_ge(cs, S, thr, T, t, lane);        // the frame that fires into / across slot t
+        if (a >= S) {
+            live = false;                                     // behind the last slot: zero
+        } else {
+            f = a + 1;
+            const float ca = cs[a];
+            const int ra = cif_right(ca, thr, T);
+            const float4 v = active ? row_f4(*(const typename RawRow<XT>::type*)(xb + (int64_t)a * C)) : float4{0.f, 0.f, 0.f, 0.f};
+            if (ra == t) {
+                const float rw = ca - (float)ra * thr;        // (fire > 0 here: left_a < t = right_a)
+                acc = scale4(rw, v);
+            } else {                                          // left_a < t < right_a: one of the frame's extra slots
+                if (active) *(float4*)(out + ((int64_t)b * (T + 1) + t) * C + c0) = scale4(thr, v);
+                return;
+            }
+        }
+    }
+    if (live) {
+        int left = f > 0 ? cif_right(cs[f - 1], thr, T) : 0;
+        for (int s2 = f; s2 < S && left == t; ++s2) {
+            const float c = cs[s2];
+            const int right = cif_right(c, thr, T), fire = right - left;
+            const float rw = fire > 0 ? c - (float)right * thr : 0.f;
+            const float lw = al[s2] - rw - (float)max(fire - 1, 0) * thr;
+            if (active) {
+                const float4 v = row_f4(*(const typename RawRow<XT>::type*)(xb + (int64_t)s2 * C));
+                acc.x = fmaf(lw, v.x, acc.x); acc.y = fmaf(lw, v.y, acc.y);
+                acc.z = fmaf(lw, v.z, acc.z); acc.w = fmaf(lw, v.w, acc.w);
+            }
+            left = right;
+        }
+    }
+    if (active) *(float4*)(out + ((int64_t)b * (T + 1) + t) * C + c0) = acc;
+}
+
+template <typename XT, typename DT>
+__global__ __launch_bounds__(64) void cif_bwd_frame_kernel(const XT* __restrict__ x, int64_t xbs, const float* __restrict__ alpha,
+                                                           const float* __restrict__ csum, const float* __restrict__ g,
+                                                           DT* __restrict__ dx, int64_t dxbs, int zlo, int zhi, float* __restrict__ pa,
+                                                           float* __restrict__ pb, int B, int S, int C, int T, float thr) {
+    const int b = blockIdx.z, lane = threadIdx.x, c0 = (blockIdx.x * 64 + lane) * 4, s0 = blockIdx.y * UNROLL;
+    const bool active = c0 < C;
+    const XT* xb = x + (int64_t)b * xbs + (active ? c0 : 0);
+    DT* dxb = dx + (int64_t)b * dxbs + (active ? c0 : 0);
+    const float* gb = g + (int64_t)b * (T + 1) * C + (active ? c0 : 0);
+    const float* cs = csum + (int64_t)b * S;
+    const float* al = alpha + (int64_t)b * S;
+    float* pab = pa + ((int64_t)blockIdx.x * B + b) * S;
+    float* pbb = pb + ((int64_t)blockIdx.x * B + b) * S;
+    const float4 zero = {0.f, 0.f, 0.f, 0.f};
+    __shared__ float red[2 * UNROLL][65];
+    if (active) {                                            // the rows of the buffer that are not frames: first / last block of an utterance
+        if (blockIdx.y == 0)
+            for (int r = -zlo; r < 0; ++r) st4(dxb + (int64_t)r * C, zero);
+        if (s0 + UNROLL >= S)
+            for (int r = S; r < S + zhi; ++r) st4(dxb + (int64_t)r * C, zero);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const int s2 = s0 + u;
+        float a = 0.f, bq = 0.f;
+        if (s2 < S) {
+            const float c = cs[s2];
+            const int right = cif_right(c, thr, T), left = s2 > 0 ? cif_right(cs[s2 - 1], thr, T) : 0, fire = right - left;
+            const float rw = fire > 0 ? c - (float)right * thr : 0.f;
+            const float lw = al[s2] - rw - (float)max(fire - 1, 0) * thr;
+            const int extra = fire - 1;
+            const float4 v = active ? row_f4(*(const typename RawRow<XT>::type*)(xb + (int64_t)s2 * C)) : zero;
+            const float4 gl = active ? *(const float4*)(gb + (int64_t)left * C) : zero;
+            float4 d = scale4(lw, gl);
+            a = dot4(v, gl);
+            if (right != left) {
+                const float4 gr = active ? *(const float4*)(gb + (int64_t)right * C) : zero;
+                float4 mid = zero;
+                for (int j = 1; j <= extra; ++j) {
+                    const float4 tt = active ? *(const float4*)(gb + (int64_t)(left + j) * C) : zero;
+                    mid.x += tt.x; mid.y += tt.y; mid.z += tt.z; mid.w += tt.w;
+                }
+                d = fire4(d, rw, gr, thr, mid);
+                bq = dot4(v, sub4(gr, gl));
+            }
+            if (active) st4(dxb + (int64_t)s2 * C, d);
+        }
+        red[2 * u][lane] = a;
+        red[2 * u + 1][lane] = bq;
+    }
+    __syncthreads();
+    if (lane < 2 * UNROLL) {                     // lane k sums row k over the 64 lanes: fixed order
+        float tsum = 0.f;
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) tsum += red[lane][j];
+        const int s2 = s0 + (lane >> 1);
+        if (s2 < S) ((lane & 1) ? pbb : pab)[s2] = tsum;
     }
 }
 
@@ -446,6 +596,13 @@ extern "C" int sc_cif_fwd_rows(const void* x, int32_t x_bf16, int64_t xbs, const
     SC_CHECK(B > 0 && S > 0 && S <= MAXS && T >= 0 && C > 0 && C % 4 == 0 && thr > 0.f && xbs >= (int64_t)S * C && xbs % 4 == 0,
              "sc_cif_fwd: B=%d S=%d (<= 2048) C=%d (C %% 4) T=%d thr=%f", B, S, C, T, (double)thr);
     SC_CHECK(((uintptr_t)x % (x_bf16 ? 8 : 16)) == 0 && ((uintptr_t)out % 16) == 0, "sc_cif_fwd: alignment");
+    if (!sc_option(6)) {            // one wave per output slot (sc_set_option(6, 1): the sequential frame walk, for A/B)
+        const dim3 grid((C + 255) / 256, T + 1, B);
+        if (x_bf16) hipLaunchKernelGGL(cif_fwd_slot_kernel<uint16_t>, grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)x, xbs, alpha, csum, out, S, C, T, thr);
+        else hipLaunchKernelGGL(cif_fwd_slot_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)x, xbs, alpha, csum, out, S, C, T, thr);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     const dim3 grid((C + 255) / 256, B);
     if (x_bf16) hipLaunchKernelGGL(cif_fwd_kernel<uint16_t>, grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)x, xbs, alpha, csum, out, S, C, T, thr);
     else hipLaunchKernelGGL(cif_fwd_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)x, xbs, alpha, csum, out, S, C, T, thr);
@@ -467,6 +624,17 @@ extern "C" int sc_cif_bwd_rows(const void* x, int32_t x_bf16, int64_t xbs, const
              "sc_cif_bwd: B=%d S=%d (<= 2048) C=%d (C %% 4) T=%d thr=%f", B, S, C, T, (double)thr);
     SC_CHECK(((uintptr_t)x % (x_bf16 ? 8 : 16)) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)dx % (dx_bf16 ? 8 : 16)) == 0, "sc_cif_bwd: alignment");
     SC_CHECK((x_bf16 != 0) == (dx_bf16 != 0), "sc_cif_bwd: the gradient leaves in the dtype the frames came in");
+    if (!sc_option(6)) {            // one wave per 8 frames
+        const dim3 gridf((C + 255) / 256, (S + UNROLL - 1) / UNROLL, B);
+        if (x_bf16)
+            hipLaunchKernelGGL((cif_bwd_frame_kernel<uint16_t, uint16_t>), gridf, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)x, xbs, alpha,
+                               csum, g, (uint16_t*)dx, dxbs, zlo, zhi, pa, pb, B, S, C, T, thr);
+        else
+            hipLaunchKernelGGL((cif_bwd_frame_kernel<float, float>), gridf, dim3(64), 0, (hipStream_t)stream, (const float*)x, xbs, alpha, csum, g,
+                               (float*)dx, dxbs, zlo, zhi, pa, pb, B, S, C, T, thr);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     const dim3 grid((C + 255) / 256, B);
     if (x_bf16)
         hipLaunchKernelGGL((cif_bwd_kernel<uint16_t, uint16_t>), grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)x, xbs, alpha, csum, g,

@@ -376,6 +376,35 @@ def test_cif_row_kernels_match_the_fp32_tensor_kernels():
 
 
 @pytest.mark.gpu
+def test_cif_slot_and_frame_parallel_kernels_equal_the_sequential_walk():
+    """The integrate-and-fire kernels launched per output slot (forward) / per 8 frames (backward) against the one-wave frame walk
+    (tuning switch 6): every bit equal, on weights that fire across several slots at once, run into the slot cap T, never fire at
+    all, and on widths that leave a partial channel block."""
+    from speechclip_plus_amd import ops
+    from speechclip_plus_amd._lib import lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(14)
+    try:
+        for B, S, C, Tc, scale in ((6, 499, 1024, 25, 0.1), (7, 130, 768, 40, 0.5), (3, 50, 256, 8, 2.5), (2, 17, 260, 30, 3.0),
+                                   (4, 70, 512, 6, 0.01), (3, 65, 768, 3, 1.0)):
+            alpha = (torch.rand(B, S, generator=g) * scale).to(dev)
+            alpha[0, S // 2:] = 0.0                                    # an utterance whose second half is padding
+            csum = alpha.cumsum(1).contiguous()
+            x32 = torch.randn(B, S, C, generator=g).to(dev)
+            full = torch.randn(B, S + 13, C, generator=g).to(torch.bfloat16).to(dev)
+            gs = torch.randn(B, Tc + 1, C, generator=g).to(dev)
+            res = []
+            for opt in (1, 0):
+                assert lib().sc_set_option(6, opt) == 0
+                res.append((ops.cif_fwd(x32, alpha, csum, Tc, 1.0),) + tuple(ops.cif_bwd(x32, alpha, csum, gs, Tc, 1.0))
+                           + (ops.cif_fwd_rows(full, 5, S, alpha, csum, Tc, 1.0),) + tuple(ops.cif_bwd_rows(full, 5, S, alpha, csum, gs, Tc, 1.0)))
+            for u, v in zip(*res):
+                assert torch.equal(u, v)
+    finally:
+        lib().sc_set_option(6, 0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("head,k", [(0, 3), (1, 5)])
 def test_cif_weight_head_over_resident_rows_matches_the_padded_copy_path(head, k):
     """cif._WeightHeadRowsFn (the weight conv as a strided-row GEMM over the attention block's buffer + the head kernel, one autograd
