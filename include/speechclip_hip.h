@@ -203,6 +203,15 @@ int sc_attn_bwd_fused_bf16(const sc_bf16* q, int64_t ldq, const sc_bf16* k, int6
                            int64_t lddq, sc_bf16* dk, int64_t lddk, sc_bf16* dv, int64_t lddv, int32_t B, int32_t R,
                            int32_t H, int32_t q_rows, float scale, int32_t causal, float drop_p, uint32_t drop_seed, void* stream);
 int sc_head_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* xT, int32_t B, int32_t R, int32_t H, void* stream);
+/* Causal self-attention of 32-row sequences (the frozen CLIP text tower on keyword prompts of <= 32 tokens: clip_official.py:222-279 ->
+ * CLIP Transformer / nn.MultiheadAttention, head_dim 64), one wave per (sequence, head), no workspaces:
+ *   qkv  [nseq * 32, ld >= 3 heads 64] bf16 rows, Q | K | V side by side, head h at columns h*64.. of each third
+ *   forward   out[nseq * 32, heads 64] = softmax(scale Q K^T | key <= query) V
+ *   backward  dqkv (laid out like qkv) from qkv and dout alone: the probabilities are recomputed, delta = sum_k P dP in fp32
+ * Rows behind a prompt are ordinary causal rows (finite values; zero gradient iff their dout rows are zero). */
+int sc_attn32_fwd_bf16(const sc_bf16* qkv, int64_t ld, sc_bf16* out, int64_t ldo, int32_t nseq, int32_t heads, float scale, void* stream);
+int sc_attn32_bwd_bf16(const sc_bf16* qkv, int64_t ld, const sc_bf16* dout, int64_t ldd, sc_bf16* dqkv, int64_t ldg, int32_t nseq,
+                       int32_t heads, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row LayerNorm, bf16 in/out, fp32 statistics:  y = (x - mean) * rstd * gamma + beta  [-> GELU]

@@ -10,7 +10,7 @@ LIB = os.path.join(CSRC, "libspeechclip_hip.so")
 DIAG_LIB = os.path.join(CSRC, "libspeechclip_hip_diag.so")    # same sources + -DSC_DIAG_BUILD: diagnostic kernels, LayerNorm-folded GEMMs
 DIAG_SOURCES = ["sc_error.cpp", "gemm256_bf16.hip", "attention.hip"]    # the files whose contents depend on SC_DIAG_BUILD
 SOURCES = ["sc_error.cpp", "hubert_layer.cpp", "gemm_bf16.hip", "gemm256_bf16.hip", "attention.hip", "attention_bwd.hip", "rowops.hip", "frontend.hip", "posconv.hip", "posconv_bwd.hip", "clspool.hip",
-           "loss_optim.hip", "headtail.hip", "rowtail.hip", "backward.hip", "softmax.hip", "cif.hip", "vq.hip", "prompt.hip"]
+           "loss_optim.hip", "headtail.hip", "rowtail.hip", "backward.hip", "softmax.hip", "cif.hip", "vq.hip", "prompt.hip", "attn_short.hip"]
 
 
 def _stale(target, deps):

@@ -7,7 +7,9 @@ train step needs the tower's forward and its input gradient but no weight gradie
 only the end-of-text row is read, so ``encode_keywords`` hands over the prompt PREFIX up to the last end-of-text position only
 (2 + the batch's largest keyword count, ~27 tokens for 10 s utterances instead of 77): with SEG < 128 the sequences lie back to
 back, 128 / SEG to an attention block, and the attention kernels mask causally inside aligned segments (``causal = SEG``) - the
-GEMMs, LayerNorms and activations then run on B * SEG dense rows instead of B * 128:
+GEMMs, LayerNorms and activations then run on B * SEG dense rows instead of B * 128.  SEG = 32 (every shipped recipe: 8 keywords)
+has kernels of its own, one wave per (sequence, head), forward 1 launch and backward 1 launch from qkv and d out alone
+(csrc/attn_short.hip) instead of V^T + forward and row sums + dQ + dK/dV on 128-row blocks that are 7/8 mask:
 
     forward   LN -> QKV GEMM -> causal attention (+ LSE) -> out-proj GEMM (+ residual) -> LN -> FC GEMM -> QuickGELU
               -> proj GEMM (+ residual)
@@ -25,6 +27,7 @@ import torch
 from . import ops
 
 BLOCK = 128         # rows of an attention block
+SHORT = 32          # segment length served by the one-wave attention kernels
 
 
 def _segment(T: int) -> int:
@@ -81,19 +84,23 @@ def tower_forward(X: torch.Tensor, weights, heads: int, causal: int):
     valid = _full_blocks(NB, dev)
     scale = (W // heads) ** -0.5
     saved = []
+    short = causal == SHORT                              # one 32-row segment per sequence: the one-wave kernels (csrc/attn_short.hip)
     for w in weights:
         h = ops.layernorm_bf16(X, w.g1, w.be1, eps=w.eps1)
         qkv = ops.linear_bf16(h, w.wqkv, w.bqkv)
-        vt = ops.head_transpose(qkv[:, 2 * W:], NB, BLOCK, heads)
-        att = torch.empty(M, W, device=dev, dtype=torch.bfloat16)
-        lse2 = torch.empty(NB, heads, BLOCK, device=dev, dtype=torch.float32)
-        ops.attn_fwd(qkv[:, : 2 * W], vt, valid, att, NB, BLOCK, heads, W, scale, lse2=lse2, causal=causal)
+        if short:
+            att, lse2 = ops.attn32_fwd(qkv, heads, scale), None
+        else:
+            vt = ops.head_transpose(qkv[:, 2 * W:], NB, BLOCK, heads)
+            att = torch.empty(M, W, device=dev, dtype=torch.bfloat16)
+            lse2 = torch.empty(NB, heads, BLOCK, device=dev, dtype=torch.float32)
+            ops.attn_fwd(qkv[:, : 2 * W], vt, valid, att, NB, BLOCK, heads, W, scale, lse2=lse2, causal=causal)
         X2 = ops.linear_bf16(att, w.wo, w.bo, residual=X)
         h2 = ops.layernorm_bf16(X2, w.g2, w.be2, eps=w.eps2)
         u = torch.empty(M, w.w1.shape[0], device=dev, dtype=torch.bfloat16)
         f = ops.linear_bf16(h2, w.w1, w.b1, act=2, aux=u, aux_mode=1)          # u = fc1 pre-activation (kept), f = QuickGELU(u)
         Xn = ops.linear_bf16(f, w.w2, w.b2, residual=X2)
-        saved.append((X, qkv, att, lse2, X2, u))
+        saved.append((X, qkv, None if short else att, lse2, X2, u))
         X = Xn
     return X, saved
 
@@ -110,9 +117,12 @@ def tower_backward(dX: torch.Tensor, weights, saved, heads: int, causal: int, q_
         dh2 = ops.linear_bf16(du, w.w1T)
         dX2 = ops.layernorm_bwd(X2, dh2, w.g2, w.eps2, dres=dX)
         datt = ops.linear_bf16(dX2, w.woT)
-        dqkv = torch.empty(M, 3 * W, device=dev, dtype=torch.bfloat16)
-        ops.attn_bwd(qkv[:, :W], qkv[:, W: 2 * W], qkv[:, 2 * W:], att, datt, lse2, valid, dqkv[:, :W], dqkv[:, W: 2 * W],
-                     dqkv[:, 2 * W:], NB, BLOCK, heads, scale, causal=causal, q_rows=q_rows)
+        if causal == SHORT:
+            dqkv = ops.attn32_bwd(qkv, datt, heads, scale)
+        else:
+            dqkv = torch.empty(M, 3 * W, device=dev, dtype=torch.bfloat16)
+            ops.attn_bwd(qkv[:, :W], qkv[:, W: 2 * W], qkv[:, 2 * W:], att, datt, lse2, valid, dqkv[:, :W], dqkv[:, W: 2 * W],
+                         dqkv[:, 2 * W:], NB, BLOCK, heads, scale, causal=causal, q_rows=q_rows)
         dh1 = ops.linear_bf16(dqkv, w.wqkvT)
         dX = ops.layernorm_bwd(X, dh1, w.g1, w.eps1, dres=dX2)
     return dX

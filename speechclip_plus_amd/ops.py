@@ -287,6 +287,30 @@ def head_transpose(x: torch.Tensor, B: int, R: int, H: int, out: Optional[torch.
     return out
 
 
+def attn32_fwd(qkv: torch.Tensor, heads: int, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Causal attention of 32-row sequences (sc_attn32_fwd_bf16): qkv [nseq 32, 3 heads 64] bf16 -> [nseq 32, heads 64]"""
+    M, W3 = qkv.shape
+    W = heads * 64
+    assert qkv.dtype == torch.bfloat16 and qkv.stride(1) == 1 and W3 == 3 * W and M % 32 == 0
+    if out is None:
+        out = torch.empty(M, W, device=qkv.device, dtype=torch.bfloat16)
+    assert out.dtype == torch.bfloat16 and out.stride(1) == 1 and tuple(out.shape) == (M, W)
+    check(lib().sc_attn32_fwd_bf16(_p(qkv), qkv.stride(0), _p(out), out.stride(0), M // 32, heads, float(scale), _stream()), "sc_attn32_fwd_bf16")
+    return out
+
+
+def attn32_bwd(qkv: torch.Tensor, dout: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """-> d qkv [nseq 32, 3 heads 64] bf16 (sc_attn32_bwd_bf16: from qkv and d out alone)"""
+    M, W3 = qkv.shape
+    W = heads * 64
+    assert qkv.dtype == torch.bfloat16 and qkv.stride(1) == 1 and W3 == 3 * W and M % 32 == 0
+    assert dout.dtype == torch.bfloat16 and dout.stride(1) == 1 and tuple(dout.shape) == (M, W)
+    dqkv = torch.empty(M, 3 * W, device=qkv.device, dtype=torch.bfloat16)
+    check(lib().sc_attn32_bwd_bf16(_p(qkv), qkv.stride(0), _p(dout), dout.stride(0), _p(dqkv), 3 * W, M // 32, heads, float(scale), _stream()),
+          "sc_attn32_bwd_bf16")
+    return dqkv
+
+
 def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse2: torch.Tensor,
              valid_len: torch.Tensor, dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, B: int, R: int, H: int, scale: float,
              causal: bool = False, kT: Optional[torch.Tensor] = None, q_rows: Optional[int] = None, drop_p: float = 0.0,

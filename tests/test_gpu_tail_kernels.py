@@ -345,6 +345,53 @@ def test_prompt_assembly_kernels_match_the_elementwise_formulation():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nseq,heads", [(64, 8), (5, 12), (1, 4)])
+def test_short_sequence_attention_kernels_vs_fp32(nseq, heads):
+    """sc_attn32_fwd_bf16 / sc_attn32_bwd_bf16 (one wave per (sequence, head) of the text tower's 32-row prompts) against causal
+    softmax attention in fp32 on the same bf16 inputs: output within bf16 rounding of the fp32 result, gradients within 1.5e-2 of
+    their norm (P and dS enter the matrix instructions as bf16), exact zeros where dout is zero for every later query; and against
+    the 128-row flash kernels the tower used before (same inputs, 4 sequences to a block)."""
+    from speechclip_plus_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31 + nseq)
+    W = heads * 64
+    M = nseq * 32
+    qkv = (torch.randn(M, 3 * W, generator=g) * 0.8).to(torch.bfloat16).to(dev)
+    dout = torch.randn(M, W, generator=g).to(torch.bfloat16).to(dev)
+    T = 27
+    dout.view(nseq, 32, W)[:, T:] = 0                                   # scratch rows behind the prompt carry no gradient
+    scale = 64 ** -0.5
+    out = ops.attn32_fwd(qkv, heads, scale)
+    dqkv = ops.attn32_bwd(qkv, dout, heads, scale)
+    x = qkv.float().view(nseq, 32, 3, heads, 64).permute(2, 0, 3, 1, 4).contiguous().requires_grad_()      # [3, nseq, heads, 32, 64]
+    sc = (x[0] @ x[1].transpose(-1, -2)) * scale
+    sc = sc.masked_fill(torch.ones(32, 32, device=dev, dtype=torch.bool).triu(1), float("-inf"))
+    ref = (sc.softmax(-1) @ x[2]).permute(0, 2, 1, 3).reshape(M, W)
+    ref.backward(dout.float())
+    ref = ref.detach()
+    dref = x.grad.permute(1, 3, 0, 2, 4).reshape(M, 3 * W)
+    rel = lambda a, b: float((a.float() - b).norm() / b.norm())
+    assert rel(out, ref) < 6e-3, rel(out, ref)
+    assert float((out.float() - ref).abs().max()) < 3e-2
+    for i, name in enumerate("qkv"):
+        a, b = dqkv[:, i * W: (i + 1) * W], dref[:, i * W: (i + 1) * W]
+        assert rel(a, b) < 1.5e-2, (name, rel(a, b))
+    assert float(dqkv.view(nseq, 32, 3 * W)[:, T:].float().abs().max()) == 0.0
+    if M % 128 == 0:
+        NB = M // 128
+        valid = torch.full((NB,), 128, device=dev, dtype=torch.int32)
+        vt = ops.head_transpose(qkv[:, 2 * W:], NB, 128, heads)
+        att = torch.empty(M, W, device=dev, dtype=torch.bfloat16)
+        lse2 = torch.empty(NB, heads, 128, device=dev, dtype=torch.float32)
+        ops.attn_fwd(qkv[:, : 2 * W], vt, valid, att, NB, 128, heads, W, scale, lse2=lse2, causal=32)
+        assert rel(out, att.float()) < 6e-3
+        d2 = torch.empty_like(dqkv)
+        ops.attn_bwd(qkv[:, :W], qkv[:, W: 2 * W], qkv[:, 2 * W:], att, dout, lse2, valid, d2[:, :W], d2[:, W: 2 * W], d2[:, 2 * W:],
+                     NB, 128, heads, scale, causal=32, q_rows=128)
+        assert rel(dqkv, d2.float()) < 1.5e-2
+
+
+@pytest.mark.gpu
 def test_cif_row_kernels_match_the_fp32_tensor_kernels():
     """sc_cif_fwd_rows / sc_cif_bwd_rows (bf16 rows at the attention block's pitch, frames behind ``head`` leading rows) against
     sc_cif_fwd / sc_cif_bwd on the fp32 copy of the same frames: identical slots (fp32 accumulation of the same values), gradient =
