@@ -519,6 +519,10 @@ int sc_act_bf16(const sc_bf16* u, const sc_bf16* df, sc_bf16* out, int64_t n, in
 /*   sc_transpose_batched_bf16 : nbatch equally shaped [rows, cols] matrices, matrix z starting sx / sy elements after matrix z - 1 */
 int sc_transpose_batched_bf16(const sc_bf16* x, int64_t ldx, int64_t sx, sc_bf16* y, int64_t ldy, int64_t sy, int32_t rows, int32_t cols,
                               int32_t nbatch, void* stream);
+/*   sc_cast_transpose_f32_bf16 : the bf16 working copies of an fp32 [rows, cols] weight in one pass - y = bf16(x) (same layout) and /
+ *   or yT = bf16(x)^T [cols, rows]; either may be NULL.  rows, cols, leading dims multiples of 4. */
+int sc_cast_transpose_f32_bf16(const float* x, int64_t ldx, sc_bf16* y, int64_t ldy, sc_bf16* yT, int64_t ldyT, int32_t rows, int32_t cols,
+                               void* stream);
 /*   sc_dropout_bf16   : out = dropout(x) (F.dropout semantics, the stateless mask of sc_gemm_args over element row*D + col):
  *                       fairseq's encoder dropout after pos_conv + LayerNorm (speech_encoder_plus.py:41), train mode only */
 int sc_dropout_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* out, int64_t ldo, int64_t rows, int32_t D, float p, uint32_t seed,

@@ -203,6 +203,7 @@ SIGNATURES = {
     "sc_transpose_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p],
     "sc_colsum_bf16": [c_void_p, c_i64, c_i64, c_int, c_void_p, c_int, c_void_p],
     "sc_transpose_batched_bf16": [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_void_p],
+    "sc_cast_transpose_f32_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p],
     "sc_dropout_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_float, ctypes.c_uint32, c_void_p],
     "sc_act_bf16": [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p],
     "sc_sgemm_f32_ex": [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int,

@@ -181,6 +181,7 @@ class _WeightHeadRowsFn(torch.autograd.Function):
         alpha = ops.cif_head_fwd(y, w, b, p1, seed1, p2, seed2)
         ctx.save_for_backward(full, conv_w, y, w, alpha)
         ctx.meta = (B, P, C, N, k, pd, head, S, p1, seed1, p2, seed2, lin_w.shape, conv_b is not None)
+        ctx.params = (conv_b, lin_w, lin_b)
         return alpha.view(B, P)[:, :S]
 
     @staticmethod
@@ -194,7 +195,12 @@ class _WeightHeadRowsFn(torch.autograd.Function):
         # d y as bf16 rows, k zero rows in front (the first utterance's left padding) and behind (the last window of the GEMM below)
         dyb = torch.empty(M + 2 * k, N, device=dev, dtype=torch.bfloat16)
         ops.rows_zero_pad(dyb, k, 1, M, 0, M, k)
-        _, dw, db = ops.cif_head_bwd(y, w, alpha, da.view(-1), p1, seed1, p2, seed2, dy_out=dyb[k: k + M])
+        # the head's and the conv bias' gradients are added straight into the optimiser's buffers where they exist (ops.grad_target)
+        conv_b, lin_w, lin_b = ctx.params
+        t_cb, t_lw, t_lb = (ops.grad_target(q) if q is not None else None for q in (conv_b, lin_w, lin_b))
+        direct = t_lw is not None and t_lb is not None and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]
+        _, dw, db = ops.cif_head_bwd(y, w, alpha, da.view(-1), p1, seed1, p2, seed2, dy_out=dyb[k: k + M],
+                                     acc=(t_lw.view(-1), t_lb.view(-1)) if direct else None)
         dfull = gW = gb = None
         if ctx.needs_input_grad[0]:
             # dx[m] = sum_jj dyb_row[m + p + 1 + jj] . W_{k-1-jj}; row m = b P + t is frame t, i.e. row head + t of ``full``
@@ -206,10 +212,13 @@ class _WeightHeadRowsFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             cols = torch.as_strided(full, (M, k * C), (C, 1), full.storage_offset() + (head - pd) * C)       # im2col VIEW: rows overlap
             g2 = torch.empty(N, k * C, device=dev, dtype=torch.float32)
-            gb = torch.empty(N, device=dev, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
+            want_b = has_bias and ctx.needs_input_grad[2]
+            gb = torch.empty(N, device=dev, dtype=torch.float32) if (want_b and t_cb is None) else None
             ops.wgrad_bf16(dyb[k: k + M], cols, g2, gb, beta=0.0)
+            if want_b and t_cb is not None:
+                ops.colsum_bf16(dyb[k: k + M], t_cb, beta=1.0)
             gW = g2.view(N, k, C).permute(0, 2, 1)
-        return dfull, gW, gb, dw.view(wshape), db, None, None, None, None, None, None, None
+        return dfull, gW, gb, None if direct else dw.view(wshape), None if direct else db, None, None, None, None, None, None, None
 
 
 class CIF(nn.Module):

@@ -376,6 +376,39 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restri
     }
 }
 
+// The bf16 working copies of a trainable fp32 weight in one pass: y = bf16(x) [rows, cols] and / or yT = bf16(x)^T [cols, rows]
+// (both GEMM operand layouts of a projection: forward x W^T reads W, the input gradient dy W reads W^T).  Was _to_copy + clone per copy.
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y, int64_t ldy,
+                                                             uint16_t* __restrict__ yT, int64_t ldyT, int rows, int cols) {
+    __shared__ uint16_t tile[64][66];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + i * 256, row = id >> 4, ch = id & 15;           // 16 chunks of 4 floats per tile row
+        uint2 o = make_uint2(0, 0);
+        if (r0 + row < rows && c0 + ch * 4 < cols) {
+            const f32x4 v = *(const f32x4*)(x + (int64_t)(r0 + row) * ldx + c0 + ch * 4);
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            if (y) *(uint2*)(y + (int64_t)(r0 + row) * ldy + c0 + ch * 4) = o;
+        }
+        uint16_t* d = &tile[row][ch * 4];
+        d[0] = o.x & 0xffff; d[1] = o.x >> 16; d[2] = o.y & 0xffff; d[3] = o.y >> 16;
+    }
+    if (!yT) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + i * 256, c = id >> 4, ch = id & 15;
+        if (c0 + c < cols && r0 + ch * 4 < rows) {
+            uint2 o;
+            o.x = tile[ch * 4 + 0][c] | ((uint32_t)tile[ch * 4 + 1][c] << 16);
+            o.y = tile[ch * 4 + 2][c] | ((uint32_t)tile[ch * 4 + 3][c] << 16);
+            *(uint2*)(yT + (int64_t)(c0 + c) * ldyT + r0 + ch * 4) = o;
+        }
+    }
+}
+
 // partial[blk][c] = sum over the block's rows of x[row, c]  (bf16 -> fp32; bias gradients).  A thread owns 8 consecutive columns
 // (one 16-byte load per row); with fewer than 256 column chunks the block walks 256 / chunks rows at a time and adds its row lanes
 // through LDS in fixed order at the end.
@@ -461,6 +494,18 @@ extern "C" int sc_transpose_bf16(const sc_bf16* x, int64_t ldx, sc_bf16* y, int6
     SC_CHECK(rows % 8 == 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "sc_transpose_bf16: rows, cols and leading dims must be multiples of 8");
     hipLaunchKernelGGL(transpose_kernel, dim3((rows + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols,
                        colsum_partial);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_cast_transpose_f32_bf16(const float* x, int64_t ldx, sc_bf16* y, int64_t ldy, sc_bf16* yT, int64_t ldyT, int32_t rows,
+                                          int32_t cols, void* stream) {
+    SC_CHECK(x && (y || yT) && rows > 0 && cols > 0, "sc_cast_transpose_f32_bf16: bad args");
+    SC_CHECK(rows % 4 == 0 && cols % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && (!y || (ldy % 4 == 0 && ((uintptr_t)y % 8) == 0)) &&
+                 (!yT || (ldyT % 4 == 0 && ((uintptr_t)yT % 8) == 0)),
+             "sc_cast_transpose_f32_bf16: rows, cols and leading dims must be multiples of 4, x 16-byte and y / yT 8-byte aligned");
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((rows + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (uint16_t*)y, ldy, (uint16_t*)yT, ldyT, rows, cols);
     SC_LAUNCH_CHECK();
     return 0;
 }

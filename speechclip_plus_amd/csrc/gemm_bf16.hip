@@ -402,7 +402,10 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
             const int64_t tiles64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.nb1 * a.nb2;
             // long-K products with a narrow output (text tower: fc2, the input gradients of fc1 / QKV): 64 x 64 tiles put them on
             // 2-3 times the CUs, each streaming half the A rows: 18.4 -> 13.1 us (2048 x 512 x 2048), 20.2 -> 16.3 (2048 x 768 x 2304)
-            if (a.n_split < 0 && a.K >= 1024 && tiles64 <= 2 * (int64_t)sc_num_cus()) tile = 15;
+            // (the K loop runs at the rate the CU issues its LDS-DMA pieces, ~0.35 us per 16 KiB K-tile whatever the ring depth - an
+            // 8-stage ring changed nothing -, so what helps is more CUs; round 4: also the K = 512 / 768 products with a narrow
+            // output, 8.0 -> 6.6 us at 2048 x 512 x 512, 10.4 -> 9.0 at 2048 x 768 x 768)
+            if (a.n_split < 0 && a.K >= 512 && tiles64 <= 2 * (int64_t)sc_num_cus()) tile = 15;
             else tile = (tiles128 <= 2 * (int64_t)sc_num_cus() && a.n_split < 0) ? 3 : 1;
         }
     }

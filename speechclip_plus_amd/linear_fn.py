@@ -13,6 +13,22 @@ import torch
 from . import ops
 
 
+def _wgrad_into(params, dyb, xb, N, K, want_bias):
+    """dW = dy^T x (+ db = column sums of dy) by ops.wgrad_bf16: added straight into the optimiser's gradient buffers where the
+    parameters have them (ops.grad_target; the node then returns None for them: no temporary, no AccumulateGrad add launch), else
+    into fresh tensors.  -> (gW, gb) to return from backward."""
+    weight, bias = params
+    tW = ops.grad_target(weight) if weight.dim() == 2 else None
+    tb = ops.grad_target(bias) if (want_bias and bias is not None) else None
+    if tW is not None and (tb is not None or not want_bias):
+        ops.wgrad_bf16(dyb, xb, tW, tb, beta=1.0)
+        return None, None
+    gW = torch.empty(N, K, device=dyb.device, dtype=torch.float32)
+    gb = torch.empty(N, device=dyb.device, dtype=torch.float32) if want_bias else None
+    ops.wgrad_bf16(dyb, xb, gW, gb, beta=0.0)
+    return gW, gb
+
+
 class LinearBf16Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -23,11 +39,14 @@ class LinearBf16Fn(torch.autograd.Function):
         rp = (rows + 63) // 64 * 64
         xb = torch.zeros(rp, K, device=x.device, dtype=torch.bfloat16)
         xb[:rows] = x.reshape(rows, K)
-        wb = ops.derived(weight, "bf16", lambda t: t.to(torch.bfloat16).contiguous())     # once per parameter version
+        if weight.dim() == 2:
+            wb, ctx.wT = ops.derived_pair(weight)                                         # once per parameter version, one launch
+        else:
+            wb, ctx.wT = ops.derived(weight, "bf16", lambda t: t.to(torch.bfloat16).contiguous()), None
         y = ops.linear_bf16(xb, wb, None if bias is None else bias.detach().float().contiguous())
         ctx.save_for_backward(xb, wb)
-        ctx.wT = ops.derived(weight, "bf16T", lambda t: t.to(torch.bfloat16).t().contiguous()) if weight.dim() == 2 else None
         ctx.meta = (shape, rows, rp, K, N, x.dtype, bias is not None)
+        ctx.params = (weight, bias)
         return y[:rows].to(x.dtype).reshape(*shape[:-1], N)
 
     @staticmethod
@@ -40,10 +59,7 @@ class LinearBf16Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear_bf16(dyb, ctx.wT if ctx.wT is not None else wb.t().contiguous())[:rows].to(dtype).reshape(shape)
         if ctx.needs_input_grad[1]:
-            gW = torch.empty(N, K, device=dy.device, dtype=torch.float32)
-            if has_bias and ctx.needs_input_grad[2]:
-                gb = torch.empty(N, device=dy.device, dtype=torch.float32)
-            ops.wgrad_bf16(dyb, xb, gW, gb, beta=0.0)
+            gW, gb = _wgrad_into(ctx.params, dyb, xb, N, K, has_bias and ctx.needs_input_grad[2])
         elif has_bias and ctx.needs_input_grad[2]:
             gb = dy.reshape(rows, N).float().sum(0)
         return dx, gW, gb
@@ -68,6 +84,7 @@ class LinearF32Fn(torch.autograd.Function):
         ctx.fast = bool(bf16_backward) and K % 256 == 0 and N % 256 == 0 and rows >= 64
         ctx.save_for_backward(x2, w)
         ctx.meta = (shape, x.dtype, bias is not None)
+        ctx.params = (weight, bias)
         return y.reshape(*shape[:-1], N).to(x.dtype)
 
     @staticmethod
@@ -90,12 +107,9 @@ class LinearF32Fn(torch.autograd.Function):
 
             dyb = rows64(dy2, N)
             if ctx.needs_input_grad[0]:
-                dx = ops.linear_bf16(dyb, w.t().to(torch.bfloat16).contiguous())[:rows].to(dtype).reshape(shape)
+                dx = ops.linear_bf16(dyb, ops.weight_copies(w, "T")[1])[:rows].to(dtype).reshape(shape)
             if ctx.needs_input_grad[1]:
-                xb = rows64(x2, K)
-                gW = torch.empty(N, K, device=dy.device, dtype=torch.float32)
-                gb = torch.empty(N, device=dy.device, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
-                ops.wgrad_bf16(dyb, xb, gW, gb, beta=0.0)
+                gW, gb = _wgrad_into(ctx.params, dyb, rows64(x2, K), N, K, has_bias and ctx.needs_input_grad[2])
             elif has_bias and ctx.needs_input_grad[2]:
                 gb = dy2.sum(0)
             return dx, gW, gb, None

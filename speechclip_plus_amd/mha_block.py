@@ -36,14 +36,7 @@ _calls = 0
 ROWS_LEAD, ROWS_TRAIL = 8, 8     # zero rows in front of / behind a row buffer handed to the CIF weight conv (>= its padding / kernel width)
 
 
-def grad_target(p):
-    """``p.grad`` if a backward may ADD its result into it directly (the optimiser's flat gradient buffer: fp32, dense, p's shape) -
-    the producing kernel's own reduction then accumulates (beta = 1) and the autograd node returns None for that input, which saves
-    the temporary and the AccumulateGrad add launch per parameter.  None (p.grad unset / foreign): return the gradient as usual."""
-    g = getattr(p, "grad", None)
-    if g is None or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
-        return None
-    return g if (g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device) else None
+grad_target = ops.grad_target
 
 
 class BranchRows:
@@ -101,8 +94,9 @@ class MhaNormFn(torch.autograd.Function):
         else:
             xb = torch.as_strided(x.detach(), (M, Dm), (Dm, 1), x.storage_offset() + off * Dm)
         if dh == dh_true:
-            Wi_b = ops.derived(Wi, "bf16", lambda t: t.to(bf).contiguous())
-            Wo_b = ops.derived(Wo, "bf16", lambda t: t.to(bf).contiguous())
+            # bf16 working copy + its transpose (the input-gradient products' operand): one launch per weight and parameter version
+            Wi_b, WiT = ops.derived_pair(Wi)
+            Wo_b, WoT = ops.derived_pair(Wo)
             bi_f = bi.detach().float().contiguous()
         else:
             Wi_b = torch.zeros(3, H, dh, Dm, device=dev, dtype=bf)
@@ -128,9 +122,9 @@ class MhaNormFn(torch.autograd.Function):
         ops.gemm_raw(Pd, Sp, vT, M, cx, D, Sp, dh, Sp, nb1=B, nb2=H,
                      sA=(H * Sp * Sp, Sp * Sp), sW=(Sp, dh * M), sC=(Sp * D, dh))
         pre = ops.linear_bf16(cx, Wo_b, bo.detach().float().contiguous(), residual=xb, drop_p=p_res, drop_seed=seed_res)
-        # fresh copies: trainable parameters are views into the optimiser's flat buffer (4-byte aligned), the row kernels read
-        # gamma / beta with 16-byte loads
-        g32, b32 = g.detach().float().clone(), beta.detach().float().clone()
+        # (the row kernels read gamma / beta with 16-byte loads: FlatAdam lays every parameter out on a 16-byte boundary, anything else
+        # gets a copy)
+        g32, b32 = ops.aligned16(g.detach().float()), ops.aligned16(beta.detach().float())
         flat = None
         if rows_out is None:
             out = ops.layernorm_bf16(pre, g32, b32, eps=eps)
@@ -141,8 +135,7 @@ class MhaNormFn(torch.autograd.Function):
         ctx.params = (Wi, bi, Wo, bo, g, beta)
         ctx.meta = (B, S, Sp, D, H, dh, eps, p_drop, seed, x.dtype, Dm, dh_true, p_res, seed_res, rows, rows_out)
         # transposed bf16 copies for the input-gradient products: per parameter version when the weights are used as they are
-        ctx.wT = (ops.derived(Wi, "bf16T", lambda t: t.to(bf).t().contiguous()), ops.derived(Wo, "bf16T", lambda t: t.to(bf).t().contiguous())) \
-            if dh == dh_true else None
+        ctx.wT = (WiT, WoT) if dh == dh_true else None
         if rows_out is None:
             return out.view(B, Sp, Dm)[:, :S].to(x.dtype if out_dtype is None else out_dtype)
         n_cls = int(rows_out)

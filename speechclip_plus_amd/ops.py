@@ -431,6 +431,37 @@ def derived(param: torch.Tensor, tag: str, fn):
     return val
 
 
+def weight_copies(w: torch.Tensor, want: str = "both"):
+    """bf16 working copies of an fp32 [N, K] weight in ONE launch (sc_cast_transpose_f32_bf16): -> (bf16(w) [N, K], bf16(w)^T [K, N]);
+    ``want`` "plain" / "T" / "both" (the entry not asked for is None).  Falls back to torch for shapes / dtypes the kernel does not take."""
+    w = w.detach()
+    N, K = w.shape
+    if not (w.is_cuda and w.dtype == torch.float32 and w.stride(1) == 1 and w.stride(0) % 4 == 0 and N % 4 == 0 and K % 4 == 0 and w.data_ptr() % 16 == 0):
+        wb = w.to(torch.bfloat16).contiguous()
+        return (wb if want != "T" else None), (wb.t().contiguous() if want != "plain" else None)
+    y = torch.empty(N, K, device=w.device, dtype=torch.bfloat16) if want != "T" else None
+    yT = torch.empty(K, N, device=w.device, dtype=torch.bfloat16) if want != "plain" else None
+    check(lib().sc_cast_transpose_f32_bf16(_p(w), w.stride(0), _p(y), K, _p(yT), N, N, K, _stream()), "sc_cast_transpose_f32_bf16")
+    return y, yT
+
+
+def derived_pair(param: torch.Tensor):
+    """(bf16 copy, transposed bf16 copy) of a trainable 2-D weight, both cached per parameter version (``derived``) and produced by
+    one launch when neither is cached."""
+    pair = derived(param, "bf16_pair", lambda t: weight_copies(t, "both"))
+    return pair
+
+
+def grad_target(p):
+    """``p.grad`` if a backward may ADD its result into it directly (the optimiser's flat gradient buffer: fp32, dense, p's shape) -
+    the producing kernel's own reduction then accumulates (beta = 1) and the autograd node returns None for that input, which saves
+    the temporary and the AccumulateGrad add launch per parameter.  None (p.grad unset / foreign): return the gradient as usual."""
+    g = getattr(p, "grad", None)
+    if g is None or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
+        return None
+    return g if (g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device) else None
+
+
 def invalidate_derived() -> None:
     """Forget every cached derived copy (after writing parameters through ``.data``, which bumps no version counter)."""
     _derived.clear()
@@ -1309,8 +1340,9 @@ def cif_head_fwd(y: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, p1: float
 
 
 def cif_head_bwd(y: torch.Tensor, w: torch.Tensor, alpha: torch.Tensor, dalpha: torch.Tensor, p1: float, seed1: int, p2: float, seed2: int,
-                 nblk: int = 512, dy_out: Optional[torch.Tensor] = None):
-    """-> dy [rows, C], dw [C], db [1]"""
+                 nblk: int = 512, dy_out: Optional[torch.Tensor] = None, acc=None):
+    """-> dy [rows, C], dw [C], db [1]; ``acc`` = (gw, gb) fp32 gradient buffers of C and 1 elements the two reductions ADD into
+    (-> dy, None, None)"""
     rows, C = y.shape
     dy = torch.empty_like(y) if dy_out is None else dy_out             # dy_out: bf16 [rows, C] rows (what the conv's dgrad GEMM reads)
     assert dy.dtype in (torch.float32, torch.bfloat16) and dy.stride(1) == 1 and tuple(dy.shape) == (rows, C)
@@ -1319,6 +1351,11 @@ def cif_head_bwd(y: torch.Tensor, w: torch.Tensor, alpha: torch.Tensor, dalpha: 
     check(lib().sc_cif_head_bwd_rows(_p(y), y.stride(0), _p(w), _p(alpha), _p(dalpha), _p(dy), int(dy.dtype == torch.bfloat16), dy.stride(0), _p(pw),
                                      _p(pb), nblk, rows, C, float(p1), int(seed1) & 0xffffffff, float(p2), int(seed2) & 0xffffffff, _stream()),
           "sc_cif_head_bwd")
+    if acc is not None:
+        assert all(t.dtype == torch.float32 and t.is_contiguous() for t in acc) and acc[0].numel() == C and acc[1].numel() == 1
+        colsum(pw, C, nblk, C, acc[0], beta=1.0)
+        colsum(pb.view(nblk, 1), 1, nblk, 1, acc[1], beta=1.0)
+        return dy, None, None
     dw = torch.empty(C, device=y.device, dtype=torch.float32)
     db = torch.empty(1, device=y.device, dtype=torch.float32)
     colsum(pw, C, nblk, C, dw)

@@ -28,6 +28,7 @@ def noam(step: int, warmup: int = 4000) -> float:
     return n / warmup if step < warmup else (warmup / n) ** 0.5
 
 
+ALIGN = 4            # floats: every parameter of a FlatAdam buffer starts on a 16-byte boundary
 _GENERATION = [0]
 
 
@@ -47,19 +48,25 @@ class FlatAdam:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         assert len(self.params) > 0
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
-        self.n = n
-        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        # every parameter starts on a 16-byte boundary of the flat buffers (the kernels read weights, biases and LayerNorm vectors with
+        # 16-byte loads: without the padding every odd-sized neighbour cost its successors a copy per step); the padding elements
+        # are zero parameters with zero gradients, which Adam leaves at zero
+        self.offsets: List[int] = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.n = sum(p.numel() for p in self.params)                  # parameters managed
+        self.size = n = off                                           # elements of the flat buffers
+        self.flat_p = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             self.flat_p[off: off + k].copy_(p.data.reshape(-1).float())
             p.data = self.flat_p[off: off + k].view_as(p.data)        # parameters now alias the flat buffer
             p.grad = self.flat_g[off: off + k].view_as(p.data)        # autograd accumulates in place
-            off += k
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
@@ -67,24 +74,20 @@ class FlatAdam:
     def span(self, params) -> tuple:
         """(start, end) of the smallest range of the flat buffers covering ``params`` (registered consecutively for one module)."""
         ids = {id(p) for p in params}
-        off, lo, hi = 0, None, None
-        for p in self.params:
-            k = p.numel()
+        lo, hi = None, None
+        for p, off in zip(self.params, self.offsets):
             if id(p) in ids:
                 lo = off if lo is None else lo
-                hi = off + k
-            off += k
+                hi = off + p.numel()
         assert lo is not None, "parameters are not managed by this optimiser"
         return lo, hi
 
     def zero_grad(self) -> None:
         self.flat_g.zero_()
-        off = 0
-        for p in self.params:                                          # re-attach if something replaced .grad
+        for p, off in zip(self.params, self.offsets):                  # re-attach if something replaced .grad
             k = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off: off + k].view_as(p.data)
-            off += k
 
     def step(self, lr: Optional[float] = None) -> None:
         self.step_count += 1
@@ -121,7 +124,7 @@ class FlatAdamOptimizer(torch.optim.Optimizer):
     def state_dict(self):
         sd = super().state_dict()
         sd["flat_adam"] = {"m": self.flat.m.detach().clone(), "v": self.flat.v.detach().clone(),
-                           "step_count": int(self.flat.step_count), "numel": int(self.flat.n)}
+                           "step_count": int(self.flat.step_count), "numel": int(self.flat.size)}
         return sd
 
     def load_state_dict(self, state_dict):
@@ -129,8 +132,8 @@ class FlatAdamOptimizer(torch.optim.Optimizer):
         fa = state_dict.pop("flat_adam", None)
         if fa is None:
             raise KeyError("optimizer state has no 'flat_adam' entry (not saved by FlatAdamOptimizer.state_dict)")
-        if int(fa["numel"]) != self.flat.n:
-            raise ValueError(f"optimizer state holds {int(fa['numel'])} parameters, this optimizer manages {self.flat.n}")
+        if int(fa["numel"]) != self.flat.size:
+            raise ValueError(f"optimizer state holds {int(fa['numel'])} elements, this optimizer's buffers {self.flat.size}")
         super().load_state_dict(state_dict)
         self.flat.m.copy_(fa["m"])
         self.flat.v.copy_(fa["v"])

@@ -140,7 +140,7 @@ class ContrastiveTrainer:
             self.allreduce.wait()
         else:                                          # everything the per-layer collectives have not covered yet
             pos = 0
-            for lo, hi in sorted(self._reduced) + [(self.opt.n, self.opt.n)]:
+            for lo, hi in sorted(self._reduced) + [(self.opt.size, self.opt.size)]:
                 if lo > pos and self._world() > 1:
                     with comm_span("all_reduce", self.opt.flat_g.is_cuda):
                         dist.all_reduce(self.opt.flat_g[pos:lo], op=dist.ReduceOp.SUM, group=self.group)

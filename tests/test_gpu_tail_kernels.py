@@ -392,6 +392,44 @@ def test_short_sequence_attention_kernels_vs_fp32(nseq, heads):
 
 
 @pytest.mark.gpu
+def test_weight_working_copies_in_one_launch_and_aligned_optimiser_layout():
+    """sc_cast_transpose_f32_bf16 = (w.to(bf16), w.to(bf16).t()) exactly, for shapes with partial tiles and strided sources; and
+    FlatAdam places every parameter (odd-sized neighbours included) on a 16-byte boundary, leaves the padding at zero through steps
+    and accumulates a linear layer's weight / bias gradient straight into its buffer (no AccumulateGrad copy: same values)."""
+    from speechclip_plus_amd import ops
+    from speechclip_plus_amd.linear_fn import LinearBf16Fn
+    from speechclip_plus_amd.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    for N, K in ((768, 768), (2304, 768), (100, 36), (4, 260)):
+        w = torch.randn(N, K + 4, generator=g).to(dev)[:, :K]
+        y, yT = ops.weight_copies(w)
+        assert torch.equal(y, w.to(torch.bfloat16)) and torch.equal(yT, w.to(torch.bfloat16).t().contiguous())
+        assert ops.weight_copies(w, "plain")[1] is None and torch.equal(ops.weight_copies(w, "T")[1], yT)
+    lin = torch.nn.Linear(256, 256).to(dev)
+    odd = torch.nn.Parameter(torch.randn(13, generator=g).to(dev))
+    one = torch.nn.Parameter(torch.randn(1, generator=g).to(dev))
+    params = [odd, lin.weight, one, lin.bias]
+    opt = FlatAdam(params, lr=1e-2, weight_decay=0.1, max_grad_norm=1.0)
+    assert all(p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0 for p in params)
+    assert opt.n == 13 + 256 * 256 + 1 + 256 and opt.size == 16 + 256 * 256 + 4 + 256
+    x = torch.randn(128, 256, generator=g).to(dev)
+    ref_w = lin.weight.detach().clone().requires_grad_()
+    ref_b = lin.bias.detach().clone().requires_grad_()
+    (LinearBf16Fn.apply(x, ref_w, ref_b).square().sum() + 0).backward()             # plain tensors: gradients returned
+    for _ in range(2):                                                               # twice: accumulation (beta = 1)
+        (LinearBf16Fn.apply(x, lin.weight, lin.bias).square().sum() + (odd.sum() + one.sum()) * 0.5).backward()
+    assert lin.weight.grad.data_ptr() == opt.flat_g.data_ptr() + 4 * opt.offsets[1]
+    assert torch.allclose(lin.weight.grad, 2 * ref_w.grad, rtol=1e-5, atol=1e-5) and torch.allclose(lin.bias.grad, 2 * ref_b.grad, rtol=1e-5, atol=1e-4)
+    pad = torch.ones(opt.size, dtype=torch.bool, device=dev)
+    for p_, off in zip(opt.params, opt.offsets):
+        pad[off: off + p_.numel()] = False
+    opt.step()
+    opt.zero_grad()
+    assert int(pad.sum()) == 3 + 3 and float(opt.flat_p[pad].abs().sum()) == 0.0 and float(opt.m[pad].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
 def test_cif_row_kernels_match_the_fp32_tensor_kernels():
     """sc_cif_fwd_rows / sc_cif_bwd_rows (bf16 rows at the attention block's pitch, frames behind ``head`` leading rows) against
     sc_cif_fwd / sc_cif_bwd on the fp32 copy of the same frames: identical slots (fp32 accumulation of the same values), gradient =
