@@ -253,3 +253,32 @@ def test_natural_margin_recall_fixture_is_consistent():
     img = torch.from_numpy(fx["image"])
     assert torch.allclose(img.norm(dim=-1), torch.ones(1000), atol=1e-5)
     assert max(summ["largest_fp32_margin_of_an_emulation_flip_in_sigma"]) < 4.0 and summ["fraction_of_queries_within_3_sigma_at_1_5_10"][0] > 0.05
+
+
+def test_flat_optimiser_layout_is_16_byte_aligned():
+    """optim.FlatAdam (host logic only, no kernel): every parameter starts on a 4-float boundary of the flat buffers whatever the
+    sizes in front of it, parameters and gradients alias the buffers, `span` covers consecutive parameters including the padding
+    between them, `n` counts parameters and `size` buffer elements."""
+    import torch
+    from speechclip_plus_amd.optim import ALIGN, FlatAdam
+    shapes = [(13,), (8, 6), (1,), (3, 5, 7), (4,), (2,)]
+    params = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    frozen = torch.nn.Parameter(torch.randn(5), requires_grad=False)
+    vals = [p.detach().clone() for p in params]
+    opt = FlatAdam(params[:3] + [frozen] + params[3:], lr=1e-3)
+    assert ALIGN == 4 and len(opt.params) == len(params) and all(o % ALIGN == 0 for o in opt.offsets)
+    assert opt.n == sum(v.numel() for v in vals) and opt.size == sum((v.numel() + 3) // 4 * 4 for v in vals)
+    for p, v, off in zip(params, vals, opt.offsets):
+        assert torch.equal(p.detach(), v) and p.data_ptr() == opt.flat_p.data_ptr() + 4 * off
+        assert p.grad.data_ptr() == opt.flat_g.data_ptr() + 4 * off and p.grad.shape == p.shape
+    lo, hi = opt.span(params[1:4])
+    assert lo == opt.offsets[1] and hi == opt.offsets[3] + params[3].numel()
+    used = torch.zeros(opt.size, dtype=torch.bool)
+    for p, off in zip(params, opt.offsets):
+        assert not used[off: off + p.numel()].any()
+        used[off: off + p.numel()] = True
+    assert float(opt.flat_p[~used].abs().sum()) == 0.0
+    params[2].grad = None
+    opt.zero_grad()
+    assert params[2].grad.data_ptr() == opt.flat_g.data_ptr() + 4 * opt.offsets[2]
+
