@@ -70,9 +70,15 @@ class _CifFn(torch.autograd.Function):
         if ctx.rows is None:
             dx, pa, pb = ops.cif_bwd(x, alpha, csum, g, Tc, thr)
         else:
-            dx, pa, pb = ops.cif_bwd_rows(x, ctx.rows[0], ctx.rows[1], alpha, csum, g, Tc, thr)
+            sink = st.get("grad_sink")
+            dx, pa, pb = ops.cif_bwd_rows(x, ctx.rows[0], ctx.rows[1], alpha, csum, g, Tc, thr, tail_rows=ctx.rows[0] if sink is not None else 0)
         gq = g_q.float().contiguous() if g_q is not None else None
         da = ops.cif_prepare_bwd(pa, pb, a_clip, pad, ratio, quantity, gq, st["scaled"])
+        if ctx.rows is not None and sink is not None and ctx.needs_input_grad[1]:
+            # the weight head's backward runs after this one (its output alpha is this node's input) and returns the SUM of both
+            # gradients of the block's rows: this share rides in its input-gradient GEMM's residual operand instead of an add launch
+            sink["dfull"] = dx
+            return None, da.to(ctx.dtypes[1]), None, None, None, None
         return dx.to(ctx.dtypes[0]), da.to(ctx.dtypes[1]), None, None, None, None
 
 
@@ -167,7 +173,7 @@ class _WeightHeadRowsFn(torch.autograd.Function):
     No padded copy of the frames, no fp32 copy, no cast or slice of a gradient."""
 
     @staticmethod
-    def forward(ctx, full, conv_w, conv_b, lin_w, lin_b, head, S, pd, p1, seed1, p2, seed2):
+    def forward(ctx, full, conv_w, conv_b, lin_w, lin_b, head, S, pd, p1, seed1, p2, seed2, sink=None):
         B, P, C = full.shape
         N, _, k = conv_w.shape
         M = B * P
@@ -182,6 +188,7 @@ class _WeightHeadRowsFn(torch.autograd.Function):
         ctx.save_for_backward(full, conv_w, y, w, alpha)
         ctx.meta = (B, P, C, N, k, pd, head, S, p1, seed1, p2, seed2, lin_w.shape, conv_b is not None)
         ctx.params = (conv_b, lin_w, lin_b)
+        ctx.sink = sink                        # dict shared with _CifFn: its gradient of ``full`` is handed over here (see its backward)
         return alpha.view(B, P)[:, :S]
 
     @staticmethod
@@ -206,7 +213,12 @@ class _WeightHeadRowsFn(torch.autograd.Function):
             # dx[m] = sum_jj dyb_row[m + p + 1 + jj] . W_{k-1-jj}; row m = b P + t is frame t, i.e. row head + t of ``full``
             wd = ops.derived(conv_w, "conv_rows_T", lambda t: t.flip(2).permute(1, 2, 0).reshape(C, k * N).to(torch.bfloat16))
             flat = torch.empty(M + head, C, device=dev, dtype=torch.bfloat16)
-            ops.gemm_raw(dyb[pd + 1:], N, wd, k * N, flat[head:], C, M, C, k * N)
+            other = ctx.sink.pop("dfull", None) if ctx.sink is not None else None
+            if other is not None:              # integrate-and-fire's share of d full (same layout, ``head`` zero rows behind it)
+                res = torch.as_strided(other, (M, C), (C, 1), other.storage_offset() + head * C)
+                ops.gemm_raw(dyb[pd + 1:], N, wd, k * N, flat[head:], C, M, C, k * N, residual=res, ldr=C)
+            else:
+                ops.gemm_raw(dyb[pd + 1:], N, wd, k * N, flat[head:], C, M, C, k * N)
             ops.rows_zero_pad(flat, 0, B, P, head, head + S, head)
             dfull = flat[:M].view(B, P, C)
         if ctx.needs_input_grad[1]:
@@ -218,7 +230,7 @@ class _WeightHeadRowsFn(torch.autograd.Function):
             if want_b and t_cb is not None:
                 ops.colsum_bf16(dyb[k: k + M], t_cb, beta=1.0)
             gW = g2.view(N, k, C).permute(0, 2, 1)
-        return dfull, gW, gb, None if direct else dw.view(wshape), None if direct else db, None, None, None, None, None, None, None
+        return dfull, gW, gb, None if direct else dw.view(wshape), None if direct else db, None, None, None, None, None, None, None, None
 
 
 class CIF(nn.Module):
@@ -293,10 +305,12 @@ class CIF(nn.Module):
         seed1 = ops.next_mult_seed() if p1 > 0 else 0
         seed2 = ops.next_mult_seed() if p2 > 0 else 0
         last = self.conv[-3]
+        grad_sink = None
         if br is not None:
             # the block's rows read in place: conv GEMM + weight head, forward and backward, in one autograd node
+            grad_sink = {} if (torch.is_grad_enabled() and feats.requires_grad) else None
             alpha_raw = _WeightHeadRowsFn.apply(feats, last.weight, last.bias, lin.weight, lin.bias, br.head, S, last.padding[0], p1, seed1, p2,
-                                                seed2)
+                                                seed2, grad_sink)
         elif self.training and last.stride[0] == 1 and last.kernel_size[0] == 2 * last.padding[0] + 1:
             # training: the last conv layer as a strided-row GEMM over the zero-padded frames; the weight head runs over the GEMM's row
             # layout (pitch S + 2p per utterance, the extra rows are dropped from alpha)
@@ -316,7 +330,7 @@ class CIF(nn.Module):
             T_known = max(min(max(int(t), 1), MAX_FEAT_LEN) for t in target_lengths_host)
         st = {"thr": float(self.cif_threshold), "eps": float(eps), "apply_scaling": scaled, "scaled": scaled, "tail": tail,
               "tail_thr": float(self.tail_handling_firing_threshold), "flags": self.consistency_flags,
-              "T_clip": T_known if T_known is not None else MAX_FEAT_LEN}
+              "T_clip": T_known if T_known is not None else MAX_FEAT_LEN, "grad_sink": grad_sink}
         self.consistency_flags[2:3] += 1
         slots, quantity, feat_lengths = _CifFn.apply(feats, alpha_raw, pad, target, st, (br.head, S) if br is not None else None)
         if T_known is not None:

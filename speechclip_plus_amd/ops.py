@@ -1432,12 +1432,19 @@ def cif_fwd_rows(full: torch.Tensor, head: int, S: int, alpha: torch.Tensor, csu
     return out
 
 
-def cif_bwd_rows(full: torch.Tensor, head: int, S: int, alpha: torch.Tensor, csum: torch.Tensor, g: torch.Tensor, T: int, thr: float):
-    """-> (d full [B, P, C] bf16: the frames' gradient, zero in every other row, pa, pb [nblk, B, S])"""
+def cif_bwd_rows(full: torch.Tensor, head: int, S: int, alpha: torch.Tensor, csum: torch.Tensor, g: torch.Tensor, T: int, thr: float,
+                 tail_rows: int = 0):
+    """-> (d full [B, P, C] bf16: the frames' gradient, zero in every other row, pa, pb [nblk, B, S]); ``tail_rows``: d full is the
+    head of a flat buffer with that many more (zero) rows behind it"""
     B, P, C = full.shape
     assert g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == (B, T + 1, C)
     nblk = (C + 255) // 256
-    dfull = torch.empty_like(full)
+    if tail_rows:
+        flat = torch.empty(B * P + tail_rows, C, device=full.device, dtype=full.dtype)
+        flat[B * P:].zero_()
+        dfull = flat[: B * P].view(B, P, C)
+    else:
+        dfull = torch.empty_like(full)
     pa = torch.empty(nblk, B, S, device=full.device, dtype=torch.float32)
     pb = torch.empty(nblk, B, S, device=full.device, dtype=torch.float32)
     check(lib().sc_cif_bwd_rows(_p(full.view(-1)[head * C:]), 1, P * C, _p(alpha), _p(csum), _p(g), _p(dfull.view(-1)[head * C:]), 1, P * C, head,
