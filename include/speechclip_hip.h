@@ -734,6 +734,9 @@ int sc_prompt_assemble_bwd(const sc_bf16* dX, const int64_t* count, float* dkeyw
                            int32_t SEG, int32_t n_pos, void* stream);
 int sc_rows_gather_bf16(const sc_bf16* X, const int32_t* row, float* out, int32_t B, int32_t W, void* stream);
 int sc_rows_scatter_bf16(const float* d, const int32_t* row, sc_bf16* dX, int32_t M, int32_t B, int32_t W, int32_t SEG, void* stream);
+/* mask[b, k] = (k >= lens[b] + add), k < n, as bytes (1 = padding): get_keypadding_mask (avssl/util/data_utils.py:6-22) and the attention
+ * block's padded-pitch key mask from the lengths in one launch. */
+int sc_len_mask_u8(const int64_t* lens, int32_t add, uint8_t* mask, int32_t B, int32_t n, void* stream);
 
 #ifdef __cplusplus
 }

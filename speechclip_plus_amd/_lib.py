@@ -128,6 +128,7 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int,
                                c_int, c_int, c_float, c_int, c_float, ctypes.c_uint32, c_void_p],
     "sc_head_transpose_bf16": [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p],
+    "sc_len_mask_u8": [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p],
     "sc_attn32_fwd_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_float, c_void_p],
     "sc_attn32_bwd_bf16": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_float, c_void_p],
     "sc_layernorm_bf16": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_float, c_int, c_void_p],

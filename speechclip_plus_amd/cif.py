@@ -346,8 +346,13 @@ class CIF(nn.Module):
             add = torch.zeros(S, dtype=torch.bool, device=feats.device).index_put_((cols[ext],), torch.ones((), dtype=torch.bool,
                                                                                                        device=feats.device))
             fired = fired | add.unsqueeze(0)
-        out_pad = torch.arange(T, device=feats.device).unsqueeze(0) >= feat_lengths.unsqueeze(1)
-        return {"quantity_out": quantity, "orig_alpha": st["a_clip"], "original_length": (~pad).sum(-1).long(),
+        out_pad = ops.len_mask(feat_lengths, T)
+        # frames per utterance: the lengths the mask was built from when it carries them (ops.len_mask), else counted
+        src_lens = getattr(input_dict["audio_feat_pad_mask"], "_sc_lens", None)
+        host = getattr(src_lens[0], "_sc_host", None) if src_lens is not None else None
+        original_length = src_lens[0].long() if (host is not None and src_lens[1] == 0 and len(host) == B and max(host) <= S) \
+            else (~pad).sum(-1).long()
+        return {"quantity_out": quantity, "orig_alpha": st["a_clip"], "original_length": original_length,
                 "target_len": target_lengths, "dsample_feats_pad_mask": out_pad, "dsample_feats": output,
                 "dsample_feats_length": feat_lengths, "alpha": st["alpha"], "fired_marks": fired, "input_feats_pad_mask": pad}
 

@@ -92,6 +92,15 @@ __global__ __launch_bounds__(128) void rows_scatter_kernel(const float* __restri
     }
 }
 
+// mask[b, k] = k >= lens[b] + add (1 = padding), k < n: the key-padding masks of the branch heads (avssl/util/data_utils.py:6-22) from the
+// lengths in one launch (was arange + compare, and ones + copy for the attention block's padded pitch)
+__global__ __launch_bounds__(256) void len_mask_kernel(const int64_t* __restrict__ lens, int add, uint8_t* __restrict__ mask, int B, int n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * n) return;
+    const int b = (int)(i / n), k = (int)(i - (int64_t)b * n);
+    mask[i] = (int64_t)k >= lens[b] + add ? 1 : 0;
+}
+
 }  // namespace
 
 extern "C" int sc_prompt_assemble(const float* keywords, int64_t ldb, const int64_t* count, const float* tok, const float* pos, uint16_t* X,
@@ -131,6 +140,13 @@ extern "C" int sc_rows_scatter_bf16(const float* d, const int32_t* row, uint16_t
     SC_CHECK(d && row && dX && M > 0 && B > 0 && SEG > 0 && W > 0 && W % 8 == 0, "sc_rows_scatter_bf16: bad arguments (M=%d B=%d W=%d SEG=%d)", M, B, W, SEG);
     SC_CHECK(((uintptr_t)d % 16) == 0 && ((uintptr_t)dX % 8) == 0, "sc_rows_scatter_bf16: alignment");
     hipLaunchKernelGGL(rows_scatter_kernel, dim3(M), dim3(128), 0, (hipStream_t)stream, d, row, dX, B, W, SEG);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_len_mask_u8(const int64_t* lens, int32_t add, uint8_t* mask, int32_t B, int32_t n, void* stream) {
+    SC_CHECK(lens && mask && B > 0 && n > 0, "sc_len_mask_u8: bad arguments");
+    hipLaunchKernelGGL(len_mask_kernel, dim3((unsigned)(((int64_t)B * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lens, add, mask, B, n);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -23,9 +23,12 @@ from .vector_quantizers import Kw_BatchNorm_dynamic
 logger = logging.getLogger(__name__)
 
 
-def get_keypadding_mask(max_length: int, data_lens: torch.Tensor) -> torch.Tensor:
-    """avssl/util/data_utils.py:6-22 (True = padding), built on the device of the lengths."""
-    return torch.arange(max_length, device=data_lens.device).unsqueeze(0) >= data_lens.unsqueeze(1)
+def get_keypadding_mask(max_length: int, data_lens: torch.Tensor, add: int = 0) -> torch.Tensor:
+    """avssl/util/data_utils.py:6-22 (True = padding) for the lengths ``data_lens + add``, built on the device of the lengths."""
+    if data_lens.is_cuda and data_lens.dtype == torch.int64 and data_lens.dim() == 1:
+        from . import ops
+        return ops.len_mask(data_lens.contiguous(), max_length, add)     # one launch; carries the lengths (``_sc_lens``)
+    return torch.arange(max_length, device=data_lens.device).unsqueeze(0) >= (data_lens + add).unsqueeze(1)
 
 
 def target_len_host(feat_len_host) -> list:
@@ -125,7 +128,7 @@ class KW_ParallelBranch(GeneralBranch):
         (full-sequence path: stock torch ops)."""
         bsz, T = audio_feat.shape[:2]
         src = torch.cat([self.cls.expand(bsz, -1, -1).to(audio_feat.dtype), audio_feat], dim=1)
-        pad = get_keypadding_mask(T + 1, audio_len.to(audio_feat.device) + 1)
+        pad = get_keypadding_mask(T + 1, audio_len.to(audio_feat.device), add=1)
         return tuple(x[:, 1:, ...] for x in self.self_att.extract_hidden_states(src=src, key_padding_mask=pad))
 
     def forward(self, audio_feat: torch.Tensor, audio_len: Optional[torch.Tensor] = None, otherInputs: dict = None,
@@ -256,7 +259,7 @@ class KW_HybridBranchPlus(KW_CascadedBranchPlus):
         output = defaultdict(lambda: None)
         bsz, T = audio_feat.shape[:2]
         lens = audio_feat_len.to(audio_feat.device)
-        pad = get_keypadding_mask(T + 1, lens + 1)
+        pad = get_keypadding_mask(T + 1, lens, add=1)
         from .mha_block import resident_rows
         res = resident_rows(audio_feat)
         if res is not None and res[1] == 1:
@@ -270,7 +273,10 @@ class KW_HybridBranchPlus(KW_CascadedBranchPlus):
         if self._rows_path(audio_feat):
             rows, cls_rows = self.self_att.forward_rows(src=src, key_padding_mask=pad, n_cls=1)
             output["parallel_audio_feat"] = linear_f32_autograd(cls_rows, self.parallel_proj.weight, self.parallel_proj.bias)
-            return self._tail(output, None, lens, pad[:, 1:], otherInputs, rows=rows)
+            frames_pad = pad[:, 1:]
+            if getattr(pad, "_sc_lens", None) is not None:
+                frames_pad._sc_lens = (lens, 0)           # the frames' mask is the lengths' own mask
+            return self._tail(output, None, lens, frames_pad, otherInputs, rows=rows)
         post = self.self_att(src=src, key_padding_mask=pad)
         output["parallel_audio_feat"] = linear_f32_autograd(post[:, :1].reshape(-1, self.audio_dim).float(), self.parallel_proj.weight,
                                                             self.parallel_proj.bias)

@@ -113,8 +113,12 @@ class MhaNormFn(torch.autograd.Function):
         scores = torch.empty(B, H, Sp, Sp, device=dev, dtype=torch.float32)
         ops.gemm_raw(qkv, 3 * D, qkv[:, D:], 3 * D, scores, Sp, Sp, Sp, dh, out_f32=True, nb1=B, nb2=H,
                      sA=(Sp * 3 * D, dh), sW=(Sp * 3 * D, dh), sC=(H * Sp * Sp, Sp * Sp))
-        key_pad = torch.ones(B, Sp, device=dev, dtype=torch.uint8)
-        key_pad[:, :S] = kpm
+        lens = getattr(kpm, "_sc_lens", None)
+        if lens is not None and tuple(kpm.shape) == (B, S) and int(lens[0].numel()) == B:
+            key_pad = ops.len_mask(lens[0], Sp, lens[1]).view(torch.uint8)       # the same mask at the block's pitch (lens + add <= S)
+        else:
+            key_pad = torch.ones(B, Sp, device=dev, dtype=torch.uint8)
+            key_pad[:, :S] = kpm
         P, Pd = ops.softmax_fwd(scores, key_pad, H * Sp, dh_true ** -0.5, p_drop, seed)          # P un-dropped (softmax backward), Pd dropped
         del scores
         vT = ops.transpose_bf16(qkv[:, 2 * D:])                                               # [D, M]: V^T of every utterance

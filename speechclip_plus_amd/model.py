@@ -271,11 +271,13 @@ class KWClip_GeneralTransformer(nn.Module):
                 assert "text" in batch, f"Text captions are required, {batch.keys()}"
                 target_len = torch.LongTensor([(t.squeeze().tolist().index(49407) - 1) for t in batch["text"]]).to(self._device)
             else:
-                target_len = (audio_feat_len / 20).round().long()
-                lens_host = getattr(audio_feat_len, "_sc_host", None)
-                if lens_host is not None:          # host twin of the targets: the CIF output is sized without a device read
-                    from .kw_branches import target_len_host
-                    target_len._sc_host = target_len_host(lens_host)
+                target_len = getattr(audio_feat_len, "_sc_target20", None)     # uploaded with the batch's other integers (speech_encoder)
+                if target_len is None:
+                    target_len = (audio_feat_len / 20).round().long()
+                    lens_host = getattr(audio_feat_len, "_sc_host", None)
+                    if lens_host is not None:          # host twin of the targets: the CIF output is sized without a device read
+                        from .kw_branches import target_len_host
+                        target_len._sc_host = target_len_host(lens_host)
             otherInputs["target_len"] = target_len
             output = self.cascaded_branch(audio_feat=audio_feat, audio_feat_len=audio_feat_len, otherInputs=otherInputs)
         if self.parallel_branch is not None:

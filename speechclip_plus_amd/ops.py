@@ -452,6 +452,18 @@ def derived_pair(param: torch.Tensor):
     return pair
 
 
+def len_mask(lens: torch.Tensor, n: int, add: int = 0) -> torch.Tensor:
+    """bool [B, n]: True where k >= lens[b] + add (sc_len_mask_u8); the lengths ride along as ``._sc_lens`` = (lens, add) so that a
+    consumer can rebuild the mask at another pitch, or read the lengths back, without a reduction over the mask"""
+    assert lens.dtype == torch.int64 and lens.dim() == 1 and lens.is_contiguous()
+    B = lens.shape[0]
+    m = torch.empty(B, n, device=lens.device, dtype=torch.uint8)
+    check(lib().sc_len_mask_u8(_p(lens), int(add), _p(m), B, int(n), _stream()), "sc_len_mask_u8")
+    m = m.view(torch.bool)
+    m._sc_lens = (lens, int(add))
+    return m
+
+
 def grad_target(p):
     """``p.grad`` if a backward may ADD its result into it directly (the optimiser's flat gradient buffer: fp32, dense, p's shape) -
     the producing kernel's own reduction then accumulates (beta = 1) and the autograd node returns None for that input, which saves

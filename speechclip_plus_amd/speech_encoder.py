@@ -496,18 +496,22 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 own = [conv_out_lengths(max(int(l), 400), a) for l in wav_len]
                 pl.alg_rows_l = [sum(o[i] for o in own) for i in range(len(a.conv_kernels))]
                 pl.alg_attn_flops = 4.0 * D * sum(float(o[-1]) ** 2 for o in own)
-            # ONE pinned buffer, ONE copy: [wav_len i64 | feat_len i64 | valid i32 | feat_len + 1 i32] (the last = the key count of the
-            # parallel head's [CLS ; frames] as the int32 vector its kernels take); the device tensors below are views of it
+            # ONE pinned buffer, ONE copy: [wav_len i64 | feat_len i64 | round(feat_len / 20) i64 | valid i32 | feat_len + 1 i32] (the third =
+            # the keyword-count targets of the cascaded branches, kwClip.py:876; the last = the key count of the parallel head's
+            # [CLS ; frames] as the int32 vector its kernels take); the device tensors below are views of it
             import numpy as np
-            hb = torch.empty(24 * B, dtype=torch.uint8).pin_memory()
+            tgt20 = [int(v) for v in np.round(np.asarray(feat_len, dtype=np.float32) / np.float32(20.0))]      # = kw_branches.target_len_host
+            hb = torch.empty(32 * B, dtype=torch.uint8).pin_memory()
             hv = hb.numpy()
-            hv[: 16 * B].view(np.int64)[:] = np.asarray([list(map(int, wav_len)), feat_len], dtype=np.int64).reshape(-1)
-            hv[16 * B:].view(np.int32)[:] = np.asarray([valid, [f + 1 for f in feat_len]], dtype=np.int32).reshape(-1)
+            hv[: 24 * B].view(np.int64)[:] = np.asarray([list(map(int, wav_len)), feat_len, tgt20], dtype=np.int64).reshape(-1)
+            hv[24 * B:].view(np.int32)[:] = np.asarray([valid, [f + 1 for f in feat_len]], dtype=np.int32).reshape(-1)
             db = hb.to(self._dev, non_blocking=True)
-            i64, i32 = db[: 16 * B].view(torch.int64), db[16 * B:].view(torch.int32)
-            pl.feat_len = i64[B:]
+            i64, i32 = db[: 24 * B].view(torch.int64), db[24 * B:].view(torch.int32)
+            pl.feat_len = i64[B: 2 * B]
             pl.feat_len._sc_host = list(feat_len)       # host twin (length-derived integers are known before any kernel runs)
             pl.feat_len._sc_p1_i32 = i32[B:]
+            pl.feat_len._sc_target20 = i64[2 * B:]      # (feat_len / 20).round().long(), with its own host twin
+            pl.feat_len._sc_target20._sc_host = tgt20
             ints = (i64[:B], i32[:B])
         if _USE_GRAPH:                                   # a captured graph holds the plan's own buffers
             pl.len_dev.copy_(ints[0])
