@@ -66,9 +66,10 @@ class _WeightedSumSrcFn(torch.autograd.Function):
     cascaded+/hybrid+ branches consume ``feat`` with ordinary torch ops, and their gradient arrives here."""
 
     @staticmethod
-    def forward(ctx, weights, hidden, B, R, D, normalize, plan):
+    def forward(ctx, weights, hidden, B, R, D, normalize, plan, w_soft=None):
         ctx.plan, ctx.generation = plan, (plan.generation if plan is not None else None)
-        w_soft = torch.softmax(weights.detach().float(), dim=0).contiguous()
+        if w_soft is None:                   # (forward_padded hands its own softmax of the same weights over)
+            w_soft = torch.softmax(weights.detach().float(), dim=0).contiguous()
         extra = int(getattr(plan, "branch_rows", 0))       # zero rows behind the buffer for a consumer that reads it in place, shifted
         if extra:
             flat = torch.empty((B * R + extra) * D, device=hidden.device, dtype=torch.bfloat16)
@@ -98,7 +99,7 @@ class _WeightedSumSrcFn(torch.autograd.Function):
         if not (g.is_contiguous() and g.dtype in (torch.float32, torch.bfloat16)):      # (bf16 rows as the attention block returns them)
             g = g.float().contiguous()
         return (ops.wsum_bwd_logits(hidden, g, w_soft, B, R, D, 1, normalize=normalize, lazy=ctx.lazy, seg=ctx.seg),
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class WeightedSumLayer(nn.Module):
@@ -118,7 +119,7 @@ class WeightedSumLayer(nn.Module):
 
     def forward_padded(self, hidden: torch.Tensor, B: int, R: int, T: int, D: int, plan=None) -> torch.Tensor:
         w_soft = torch.softmax(self.weights.detach().float(), dim=0).contiguous()
-        src = _WeightedSumSrcFn.apply(self.weights, hidden, B, R, D, self.normalize_features, plan)
+        src = _WeightedSumSrcFn.apply(self.weights, hidden, B, R, D, self.normalize_features, plan, w_soft)
         feat = src[:, 1: T + 1]
         feat._sc_handle = PaddedFeatHandle(src, hidden, self, w_soft, B, R, T, D, self.normalize_features, plan)
         return feat
