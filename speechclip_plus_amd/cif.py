@@ -126,7 +126,7 @@ class _ConvRowsBf16Fn(torch.autograd.Function):
         dev = x.device
         xp = torch.zeros(rows_pad + k, C, device=dev, dtype=torch.bfloat16)
         xp[:rows].view(B, Tp, C)[:, pad: pad + T] = x.detach()
-        wt = ops.derived(weight, "conv_rows", lambda t: t.permute(0, 2, 1).reshape(N, k * C).to(torch.bfloat16))   # [N, k C] tap-major
+        wt = ops.derived(weight, "conv_rows", lambda t: ops.bf16_copy(t.permute(0, 2, 1)).view(N, k * C))   # [N, k C] tap-major
         y = torch.empty(rows_pad, N, device=dev, dtype=torch.float32)
         ops.gemm_raw(xp, C, wt, k * C, y, N, rows_pad, N, k * C, bias=None if bias is None else bias.detach().float().contiguous(),
                      out_f32=True)
@@ -145,7 +145,7 @@ class _ConvRowsBf16Fn(torch.autograd.Function):
         dx = gW = gb = None
         if ctx.needs_input_grad[0]:
             # dx[m] = sum_j dy[m + p - j] W_j = sum_jj dyb_row[m + p + 1 + jj] . W_{k-1-jj}     (dyb rows are shifted by k)
-            wd = ops.derived(weight, "conv_rows_T", lambda t: t.flip(2).permute(1, 2, 0).reshape(C, k * N).to(torch.bfloat16))   # [C, (jj, n)]
+            wd = ops.derived(weight, "conv_rows_T", lambda t: ops.bf16_copy(t.flip(2).permute(1, 2, 0)).view(C, k * N))   # [C, (jj, n)]
             dxf = torch.empty(rows_pad, C, device=dev, dtype=torch.bfloat16)
             ops.gemm_raw(dyb[pad + 1:], N, wd, k * N, dxf, C, rows_pad, C, k * N)
             dx = dxf[:rows].view(B, Tp, C)[:, :T].to(xdtype)
@@ -179,7 +179,7 @@ class _WeightHeadRowsFn(torch.autograd.Function):
         M = B * P
         dev = full.device
         A = torch.as_strided(full.detach(), (M, C), (C, 1), full.storage_offset() + (head - pd) * C)
-        wt = ops.derived(conv_w, "conv_rows", lambda t: t.permute(0, 2, 1).reshape(N, k * C).to(torch.bfloat16))   # [N, k C] tap-major
+        wt = ops.derived(conv_w, "conv_rows", lambda t: ops.bf16_copy(t.permute(0, 2, 1)).view(N, k * C))   # [N, k C] tap-major
         y = torch.empty(M, N, device=dev, dtype=torch.float32)
         ops.gemm_raw(A, C, wt, k * C, y, N, M, N, k * C, bias=None if conv_b is None else conv_b.detach().float().contiguous(), out_f32=True)
         w = ops.aligned16(lin_w.detach().float().reshape(N).contiguous())
@@ -211,7 +211,7 @@ class _WeightHeadRowsFn(torch.autograd.Function):
         dfull = gW = gb = None
         if ctx.needs_input_grad[0]:
             # dx[m] = sum_jj dyb_row[m + p + 1 + jj] . W_{k-1-jj}; row m = b P + t is frame t, i.e. row head + t of ``full``
-            wd = ops.derived(conv_w, "conv_rows_T", lambda t: t.flip(2).permute(1, 2, 0).reshape(C, k * N).to(torch.bfloat16))
+            wd = ops.derived(conv_w, "conv_rows_T", lambda t: ops.bf16_copy(t.flip(2).permute(1, 2, 0)).view(C, k * N))
             flat = torch.empty(M + head, C, device=dev, dtype=torch.bfloat16)
             other = ctx.sink.pop("dfull", None) if ctx.sink is not None else None
             if other is not None:              # integrate-and-fire's share of d full (same layout, ``head`` zero rows behind it)

@@ -84,12 +84,12 @@ class TrainableFrontend(nn.Module):
         if gen == self._gen:
             return
         a, c = self.arch, {}
-        bf = lambda t: t.detach().to(torch.bfloat16).contiguous()
+        bf = ops.bf16_copy          # one copy kernel whatever the view's strides
         f32 = lambda t: ops.aligned16(t.detach().float().contiguous())
         for i in range(1, len(a.conv_kernels)):
             w = self.P(f"feature_extractor.conv_layers.{i}.0.weight").detach()           # [C_out, C_in, k]
-            c[f"conv{i}_w"] = bf(w.permute(0, 2, 1).reshape(w.shape[0], -1))               # tap-major [C_out, k C_in]
-            c[f"conv{i}_wT"] = bf(w.permute(0, 2, 1).reshape(w.shape[0], -1).t())          # [k C_in, C_out]
+            c[f"conv{i}_w"] = bf(w.permute(0, 2, 1)).view(w.shape[0], -1)                  # tap-major [C_out, k C_in]
+            c[f"conv{i}_wT"] = bf(w.permute(2, 1, 0)).view(-1, w.shape[0])                 # its transpose [k C_in, C_out]
             if a.conv_kernels[i] == 3 and a.conv_strides[i] == 2:
                 # input gradient of an even input row 2 m = window m's tap 0 + window m - 1's tap 2: ONE product over the row pair
                 # [du[m - 1] | du[m]] (K = 2 C_out) against [W_2^T | W_0^T]; odd rows 2 m + 1 take tap 1 of window m (backward_frontend)
@@ -101,12 +101,12 @@ class TrainableFrontend(nn.Module):
                 c[f"conv{i}_beta"] = f32(self.P(f"feature_extractor.conv_layers.{i}.2.1.bias"))
         c["ln_feat_g"], c["ln_feat_b"] = f32(self.P("layer_norm.weight")), f32(self.P("layer_norm.bias"))
         pw = self.P("post_extract_proj.weight").detach()
-        c["proj_w"], c["proj_wT"], c["proj_b"] = bf(pw), bf(pw.t()), f32(self.P("post_extract_proj.bias"))
+        (c["proj_w"], c["proj_wT"]), c["proj_b"] = ops.weight_copies(pw), f32(self.P("post_extract_proj.bias"))
         D, G, Kp = a.embed_dim, a.pos_conv_groups, a.pos_conv_kernel
         Dg = D // G
         w = self.pos_weight().detach().reshape(G, Dg, Dg, Kp)                              # [g][co][ci][tap]
-        c["pos_w"] = bf(w.permute(0, 1, 3, 2).reshape(G, Dg, Kp * Dg))                      # forward: [g][co][tap ci]
-        c["pos_w_flip"] = bf(w.flip(3).permute(0, 2, 3, 1).reshape(G, Dg, Kp * Dg))         # dgrad:   [g][ci][tap' co], tap' = K-1-tap
+        c["pos_w"] = bf(w.permute(0, 1, 3, 2)).view(G, Dg, Kp * Dg)                         # forward: [g][co][tap ci]
+        c["pos_w_flip"] = bf(w.flip(3).permute(0, 2, 3, 1)).view(G, Dg, Kp * Dg)            # dgrad:   [g][ci][tap' co], tap' = K-1-tap
         c["pos_b"] = f32(self.P("encoder.pos_conv.0.bias"))
         c["ln_enc_g"], c["ln_enc_b"] = f32(self.P("encoder.layer_norm.weight")), f32(self.P("encoder.layer_norm.bias"))
         self._c, self._gen = c, gen
@@ -188,9 +188,9 @@ class TrainableFrontend(nn.Module):
         if a.layer_norm_first:
             dpre = dh0
         else:
-            dpre, dg, db = ops.layernorm_bwd(st["pre"], dh0, c["ln_enc_g"], 1e-5, want_param_grads=True)
-            acc("encoder.layer_norm.weight", dg)
-            acc("encoder.layer_norm.bias", db)
+            # (the LayerNorm parameter gradients are added by the reduction itself)
+            dpre = ops.layernorm_bwd(st["pre"], dh0, c["ln_enc_g"], 1e-5,
+                                     acc=(self._gacc(self.P("encoder.layer_norm.weight")), self._gacc(self.P("encoder.layer_norm.bias"))))
         # ---- pos_conv:  pre = xz + gelu(u),  u = conv(xz) + b
         G, Kp = a.pos_conv_groups, a.pos_conv_kernel
         Dg, halo = D // G, pl.halo
@@ -230,9 +230,8 @@ class TrainableFrontend(nn.Module):
         # ---- post_extract_proj, feature LayerNorm
         ops.wgrad_bf16(dx_proj, pl.feat_ln, self._gacc(self.P("post_extract_proj.weight")), self._gacc(self.P("post_extract_proj.bias")))
         dfl = ops.linear_bf16(dx_proj, c["proj_wT"])
-        df, dg, db = ops.layernorm_bwd(pl.conv[-1][:M], dfl, c["ln_feat_g"], 1e-5, want_param_grads=True)
-        acc("layer_norm.weight", dg)
-        acc("layer_norm.bias", db)
+        df = ops.layernorm_bwd(pl.conv[-1][:M], dfl, c["ln_feat_g"], 1e-5,
+                               acc=(self._gacc(self.P("layer_norm.weight")), self._gacc(self.P("layer_norm.bias"))))
         fgm = float(getattr(a, "feature_grad_mult", 1.0))
         if fgm != 1.0:                       # fairseq GradMultiply on the extractor's output
             df = (df.float() * fgm).to(torch.bfloat16)

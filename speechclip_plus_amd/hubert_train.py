@@ -88,7 +88,7 @@ class TrainableLayers(nn.Module):
         ver = (param_generation(),) + tuple((p.data_ptr(), p._version) for p in self.p.values())
         if ver == self._versions:
             return
-        bf = lambda t: t.detach().to(torch.bfloat16).contiguous()
+        bf = ops.bf16_copy          # one copy kernel whatever the view's strides
         # Trainable parameters managed by optim.FlatAdam are contiguous views of ONE flat fp32 buffer: cast the span they cover in a
         # single launch and hand out views of that bf16 mirror, instead of one cast launch per weight matrix (113 per step)
         mirror, flat32, lo = None, None, 0

@@ -431,6 +431,14 @@ def derived(param: torch.Tensor, tag: str, fn):
     return val
 
 
+def bf16_copy(t: torch.Tensor) -> torch.Tensor:
+    """contiguous bf16 copy of ``t`` (any float dtype, any strides - a permuted / transposed / flipped view) in ONE copy kernel;
+    ``t.to(bfloat16).contiguous()`` on a strided view is a cast launch plus a layout launch"""
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    out.copy_(t.detach())
+    return out
+
+
 def weight_copies(w: torch.Tensor, want: str = "both"):
     """bf16 working copies of an fp32 [N, K] weight in ONE launch (sc_cast_transpose_f32_bf16): -> (bf16(w) [N, K], bf16(w)^T [K, N]);
     ``want`` "plain" / "T" / "both" (the entry not asked for is None).  Falls back to torch for shapes / dtypes the kernel does not take."""
