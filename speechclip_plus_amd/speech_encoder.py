@@ -142,6 +142,9 @@ _USE_GRAPH = os.environ.get("SC_ENCODER_GRAPH", "0") == "1"      # opt-in: measu
 # (0.6 ms) come back as VALU work in GEMM epilogues that are already issue-bound (+12 us fc1, +19 fc2, +6 QKV, +7 out_proj per
 # launch with all operands prefetched into LDS; +25..45 before that).  DESIGN.md section 7.
 _FUSED_LN = os.environ.get("SC_FUSED_LN", "0") == "1"
+# The frozen encoder of train step N + 1 on a stream of its own, under the branch / head / loss / backward kernels of step N (two
+# alternating sets of resident buffers): see SpeechEncoderPlus._encode_overlapped.  "0" = everything on the caller's stream.
+_ENC_OVERLAP = os.environ.get("SC_ENC_OVERLAP", "0") == "1"
 
 
 def _mix32(x: int) -> int:
@@ -329,7 +332,12 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             from .hubert_frontend_train import TrainableFrontend
             self.frontend = TrainableFrontend(self.arch, state_dict, self._dev)
             self.train_layers.frontend = self.frontend
-        self._plans: Dict[Tuple[int, int, bool], _Plan] = {}
+        self._plans: Dict[Tuple[int, int, bool, int], _Plan] = {}
+        self.enc_overlap = _ENC_OVERLAP
+        self._enc_stream = None           # _encode_overlapped
+        self._prev_entry = None
+        self._parity = 0
+        self._consumer_stream = None
         if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             self.weightedsum_layer = WeightedSumLayer(
                 n_weights=self.upstream_model_hiddenstates_len,
@@ -428,9 +436,9 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # segment layout: the workspaces are views into capacity-sized buffers, so one plan serves every padded length of its 2 s
         # bucket (real batches change their longest utterance all the time); the uniform layout of unfrozen layers is per length
         cap = _roundup(L, self.LENGTH_BUCKET) if seg_mode else L
-        key = (B, cap, seg_mode)
+        key = (B, cap, seg_mode, self._parity)
         if key not in self._plans:
-            if len(self._plans) >= 4:          # keep HBM bounded when lengths vary
+            if len(self._plans) >= (8 if self.enc_overlap else 4):          # keep HBM bounded when lengths vary
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = _Plan(self.arch, B, cap, self._dev, seg_mode=seg_mode)
         pl = self._plans[key]
@@ -439,6 +447,43 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         pl.out_align, pl.branch_rows = (64, 8) if self.branch_inplace else (ops.RowSegments.GRAN, 0)
         if seg_mode:
             pl.set_length(L)
+        return pl
+
+    def _encode_overlapped(self, padded: torch.Tensor, lens, wav) -> _Plan:
+        """The frozen encoder of this step on its own stream.  Nothing in it depends on the previous step (no trainable parameter, no
+        activation), so it may run UNDER the previous step's branch / head / loss / backward kernels, which are launch-sized and leave
+        most of the chip idle (cascaded+: 313 launches, 4.6 ms after a 12.3 ms encoder).  The host enqueues step N's tail, then this
+        encoder for step N + 1; the device runs the two streams side by side:
+          * two alternating plans (resident hidden states / workspaces): step N's backward still reads plan N % 2 (weighted-sum
+            gradient) while the encoder of step N + 1 fills the other one;
+          * the encoder of step N waits for the event recorded on the caller's stream at the ENTRY of step N - 1 (everything enqueued
+            before it - through step N - 2's backward, the last reader of this plan - has finished); encoders run one after the
+            other on the one encoder stream;
+          * the caller's stream waits for the encoder's completion event before the weighted sum.
+        Same kernels on the same values: results are bit-identical to the single-stream schedule."""
+        main = torch.cuda.current_stream()
+        if self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream(device=self._dev)
+        enc = self._enc_stream
+        entry = torch.cuda.Event()
+        entry.record(main)
+        if self._prev_entry is not None:
+            enc.wait_event(self._prev_entry)
+        if not (isinstance(wav, torch.Tensor) and padded.data_ptr() == wav.data_ptr()):
+            enc.wait_event(entry)                       # the padded batch was produced on the caller's stream just now
+        self._prev_entry = entry
+        self._parity ^= 1
+        self._consumer_stream = main
+        try:
+            with torch.cuda.stream(enc):
+                pl = self._encode(padded, lens, False)
+            done = torch.cuda.Event()
+            done.record(enc)
+        finally:
+            self._consumer_stream = None
+        if pl.seg is not None:                          # layout tables uploaded on the encoder's stream, read by the step's kernels too
+            pl.seg._dev.record_stream(main)
+        main.wait_event(done)
         return pl
 
     def segment_pitches(self, T: int, valid: Sequence[int], feat_len: Sequence[int], ragged: bool) -> Tuple[List[int], List[int]]:
@@ -506,6 +551,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             hv[: 24 * B].view(np.int64)[:] = np.asarray([list(map(int, wav_len)), feat_len, tgt20], dtype=np.int64).reshape(-1)
             hv[24 * B:].view(np.int32)[:] = np.asarray([valid, [f + 1 for f in feat_len]], dtype=np.int32).reshape(-1)
             db = hb.to(self._dev, non_blocking=True)
+            if self._consumer_stream is not None:       # allocated on the encoder's stream, read by the step's stream
+                db.record_stream(self._consumer_stream)
             i64, i32 = db[: 24 * B].view(torch.int64), db[24 * B:].view(torch.int32)
             pl.feat_len = i64[B: 2 * B]
             pl.feat_len._sc_host = list(feat_len)       # host twin (length-derived integers are known before any kernel runs)
@@ -824,7 +871,11 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # tensors: holding encoder outputs across calls must be safe), the weighted-sum fast path reads the workspace in place
         want_states = return_hidden_states or (feat_select_idx or self.feat_select_idx) != FEAT_SELECT_IDX_WEIGHTED_SUM_MODE
         # returned hidden states carry every padded row, as the reference's do: that forward runs un-ragged (all B x T frames)
-        pl = self._encode(padded, lens, save, ragged=False if want_states else None)
+        if (self.enc_overlap and self.train_layers is None and self.training and torch.is_grad_enabled() and not want_states
+                and padded.is_cuda and not isinstance(lens, torch.Tensor)):
+            pl = self._encode_overlapped(padded, lens, wav)
+        else:
+            pl = self._encode(padded, lens, save, ragged=False if want_states else None)
         B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
         # (without want_states the tuple is only a placeholder: the weighted sum reads the plan's workspace, raw or not, in place)
         hidden_states = self._materialised_states(pl) if want_states else ((None,) * (self.arch.layers + 1) if pl.seg is not None else tuple(

@@ -304,6 +304,49 @@ def test_trainer_side_stream_schedule_matches_synchronous():
     assert finals[0][0][2] < finals[0][0][0]
 
 
+@pytest.mark.parametrize("kind", ["parallel", "cascaded"])
+def test_encoder_on_its_own_stream_under_the_previous_steps_tail(kind):
+    """speech_encoder._encode_overlapped: the frozen encoder of step N + 1 runs on a stream of its own while step N's branch / head /
+    loss / backward kernels are still in flight, on two alternating sets of resident buffers.  Five steps over DIFFERENT batches (so a
+    stale or prematurely overwritten buffer changes a loss), ragged lengths that change the row layout from step to step: losses,
+    parameters and last gradients must equal the single-stream schedule's bit for bit."""
+    import dataclasses
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    arch = dataclasses.replace(ARCHS["hubert"], layers=2)
+    sd = random_hubert_state_dict(arch, seed=3)
+    g = torch.Generator().manual_seed(23)
+    B = 6
+    lens = [[24000, 17000, 24000, 9000, 20000, 24000], [24000, 24000, 12000, 24000, 8000, 15000], [16000, 24000, 24000, 24000, 11000, 7000],
+            [24000, 17000, 24000, 9000, 20000, 24000], [24000, 6000, 24000, 24000, 24000, 13000]]
+    batches = [{"wav": torch.randn(B, 24000, generator=g).cuda(), "wav_len": torch.tensor(l), "image": torch.randn(B, 512, generator=g).cuda(),
+                "id": torch.arange(B).cuda()} for l in lens]
+    finals = []
+    for overlap in (False, True):
+        torch.manual_seed(3)
+        if kind == "parallel":
+            cfg = base_parallel_config()
+            cfg.audio_encoder.max_audio_len = -1
+            model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch)
+        else:
+            from speechclip_plus_amd import cascaded_plus_base_config
+            cfg = cascaded_plus_base_config()
+            cfg.audio_encoder.max_audio_len = -1
+            cfg.clip.layers = 2
+            model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch)
+        model = set_dropout(model.train(), False)
+        model.audio_encoder.enc_overlap = overlap
+        trainer = ContrastiveTrainer(model)
+        losses = [float(trainer.step(b)) for b in batches]
+        torch.cuda.synchronize()
+        finals.append((losses, trainer.opt.flat_p.clone(), trainer.opt.flat_g.clone()))
+        assert (model.audio_encoder._enc_stream is not None) == overlap
+    assert finals[0][0] == finals[1][0], (finals[0][0], finals[1][0])
+    assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
+    assert len(set(finals[0][0])) == len(batches)
+
+
 def test_accumulate_grad_batches_two_micro_steps_make_one_optimiser_step():
     """trainer.accumulate_grad_batches: 2 (config/speechCLIP+/model_large/coco/spchclip_h+.yaml:138, Lightning semantics): the first
     micro-step only back-propagates loss / 2 (no optimiser step, parameters and global_step unchanged), the second adds its loss / 2
