@@ -93,10 +93,7 @@ _AUX_ON = os.environ.get("SC_HEAD_AUX_STREAM", "1") == "1"
 
 def _aux_stream(dev) -> "torch.cuda.Stream":
     """A second stream for the parameter-only half of the head's backward (it runs beside the weighted-sum sweep)."""
-    st = _aux.get(dev)
-    if st is None:
-        st = _aux[dev] = torch.cuda.Stream(device=dev)
-    return st
+    return ops.shared_stream("head_aux", dev)
 
 
 class ParallelHeadFn(torch.autograd.Function):

@@ -472,6 +472,23 @@ def len_mask(lens: torch.Tensor, n: int, add: int = 0) -> torch.Tensor:
     return m
 
 
+_shared_streams = {}
+
+
+def shared_stream(name: str, device=None) -> "torch.cuda.Stream":
+    """ONE HIP stream per (role, device) and process.  The runtime multiplexes streams onto a handful of hardware queues; two streams
+    that land on the same queue run one after the other.  Roles that are meant to run side by side ("encoder", "optimiser",
+    "allreduce", "head_aux") therefore keep the streams they got first, instead of every model / trainer instance drawing new ones (the
+    fourth model built in one process lost the encoder / tail overlap that way)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (name, idx)
+    st = _shared_streams.get(key)
+    if st is None:
+        st = _shared_streams[key] = torch.cuda.Stream(device=idx)
+    return st
+
+
 def grad_target(p):
     """``p.grad`` if a backward may ADD its result into it directly (the optimiser's flat gradient buffer: fp32, dense, p's shape) -
     the producing kernel's own reduction then accumulates (beta = 1) and the autograd node returns None for that input, which saves

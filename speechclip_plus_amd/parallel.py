@@ -151,7 +151,11 @@ class GradAllReduce:
 
     def __init__(self, flat_grad: torch.Tensor, group: Optional[dist.ProcessGroup] = None):
         self.flat_grad, self.group = flat_grad, group
-        self.stream = torch.cuda.Stream() if flat_grad.is_cuda else None
+        if flat_grad.is_cuda:
+            from .ops import shared_stream
+            self.stream = shared_stream("allreduce", flat_grad.device)
+        else:
+            self.stream = None
         self.work = None
 
     def launch(self) -> None:

@@ -143,8 +143,8 @@ _USE_GRAPH = os.environ.get("SC_ENCODER_GRAPH", "0") == "1"      # opt-in: measu
 # launch with all operands prefetched into LDS; +25..45 before that).  DESIGN.md section 7.
 _FUSED_LN = os.environ.get("SC_FUSED_LN", "0") == "1"
 # The frozen encoder of train step N + 1 on a stream of its own, under the branch / head / loss / backward kernels of step N (two
-# alternating sets of resident buffers): see SpeechEncoderPlus._encode_overlapped.  "0" = everything on the caller's stream.
-_ENC_OVERLAP = os.environ.get("SC_ENC_OVERLAP", "0") == "1"
+# alternating sets of resident buffers): see _encode_overlapped.  SC_ENC_OVERLAP=0: everything on the caller's stream.
+_ENC_OVERLAP = os.environ.get("SC_ENC_OVERLAP", "1") == "1"
 
 
 def _mix32(x: int) -> int:
@@ -463,7 +463,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         Same kernels on the same values: results are bit-identical to the single-stream schedule."""
         main = torch.cuda.current_stream()
         if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream(device=self._dev)
+            self._enc_stream = ops.shared_stream("encoder", self._dev)
         enc = self._enc_stream
         entry = torch.cuda.Event()
         entry.record(main)

@@ -40,7 +40,8 @@ class ContrastiveTrainer:
         self._boundary = self.accum.n == 1          # is the micro-step in flight the one that ends with the optimiser step?
         self.allreduce = GradAllReduce(self.opt.flat_g, group)
         self.replicated = [p for p in model.criterion.parameters() if p.requires_grad]   # evaluated on the full batch by every rank
-        self.side = torch.cuda.Stream() if self.opt.flat_g.is_cuda else None
+        from .ops import shared_stream
+        self.side = shared_stream("optimiser", self.opt.flat_g.device) if self.opt.flat_g.is_cuda else None
         self._pending = False
         self._one = None
         # unfrozen HuBERT layers (hubert_train.py): the slice of the flat gradient buffer that belongs to a layer is all-reduced
