@@ -871,8 +871,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # tensors: holding encoder outputs across calls must be safe), the weighted-sum fast path reads the workspace in place
         want_states = return_hidden_states or (feat_select_idx or self.feat_select_idx) != FEAT_SELECT_IDX_WEIGHTED_SUM_MODE
         # returned hidden states carry every padded row, as the reference's do: that forward runs un-ragged (all B x T frames)
-        if (self.enc_overlap and self.train_layers is None and self.training and torch.is_grad_enabled() and not want_states
-                and padded.is_cuda and not isinstance(lens, torch.Tensor)):
+        if (self.enc_overlap and not _USE_GRAPH and self.train_layers is None and self.training and torch.is_grad_enabled()
+                and not want_states and padded.is_cuda and not isinstance(lens, torch.Tensor)):
             pl = self._encode_overlapped(padded, lens, wav)
         else:
             pl = self._encode(padded, lens, save, ragged=False if want_states else None)
