@@ -338,6 +338,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self._prev_entry = None
         self._parity = 0
         self._consumer_stream = None
+        self._retired = []                # (forward count at eviction, plan): see _plan
+        self._forwards = 0
         if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             self.weightedsum_layer = WeightedSumLayer(
                 n_weights=self.upstream_model_hiddenstates_len,
@@ -439,9 +441,16 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         key = (B, cap, seg_mode, self._parity)
         if key not in self._plans:
             if len(self._plans) >= (8 if self.enc_overlap else 4):          # keep HBM bounded when lengths vary
-                self._plans.pop(next(iter(self._plans)))
+                # least recently used goes.  Its buffers may still be read by kernels in flight on the caller's stream while the
+                # encoder stream would be handed the freed blocks: the plan itself is kept two more forwards (_retired), by when the
+                # encoder's entry-event wait covers every reader
+                self._retired.append((self._forwards, self._plans.pop(next(iter(self._plans)))))
             self._plans[key] = _Plan(self.arch, B, cap, self._dev, seg_mode=seg_mode)
-        pl = self._plans[key]
+        pl = self._plans.pop(key)
+        self._plans[key] = pl                    # most recently used last
+        self._forwards += 1
+        while self._retired and self._retired[0][0] + 3 <= self._forwards:
+            self._retired.pop(0)
         # a cascaded+/hybrid+ attention block reads the encoder's output rows in place (mha_block.resident_rows): output pitch a
         # multiple of 64, a few zero rows behind the buffer
         pl.out_align, pl.branch_rows = (64, 8) if self.branch_inplace else (ops.RowSegments.GRAN, 0)
