@@ -347,6 +347,44 @@ def test_encoder_on_its_own_stream_under_the_previous_steps_tail(kind):
     assert len(set(finals[0][0])) == len(batches)
 
 
+def test_encoder_stream_with_changing_padded_lengths_and_plan_eviction():
+    """The overlapped schedule when the padded length changes from step to step (five 2-second buckets x two alternating plans = 10
+    resident plans against a cache of 8: least-recently-used plans are evicted and released two forwards later) - 14 steps must
+    reproduce the single-stream schedule bit for bit."""
+    import dataclasses
+    from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
+    from speechclip_plus_amd.speech_encoder import ARCHS
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    arch = dataclasses.replace(ARCHS["hubert"], layers=2)
+    sd = random_hubert_state_dict(arch, seed=5)
+    g = torch.Generator().manual_seed(29)
+    B = 4
+    longest = [24000, 50000, 80000, 110000, 150000]
+    batches = []
+    for i in range(14):
+        L = longest[i % 5]
+        lens = torch.randint(L // 3, L + 1, (B,), generator=g)
+        lens[i % B] = L
+        batches.append({"wav": torch.randn(B, L, generator=g).cuda(), "wav_len": lens, "image": torch.randn(B, 512, generator=g).cuda(),
+                        "id": torch.arange(B).cuda()})
+    finals = []
+    for overlap in (False, True):
+        torch.manual_seed(5)
+        cfg = base_parallel_config()
+        cfg.audio_encoder.max_audio_len = -1
+        model = set_dropout(KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch).train(), False)
+        enc = model.audio_encoder
+        enc.enc_overlap = overlap
+        trainer = ContrastiveTrainer(model)
+        losses = [float(trainer.step(b)) for b in batches]
+        torch.cuda.synchronize()
+        finals.append((losses, trainer.opt.flat_p.clone()))
+        if overlap:
+            assert len(enc._plans) == 8 and len(enc._retired) <= 3
+    assert finals[0][0] == finals[1][0], (finals[0][0], finals[1][0])
+    assert torch.equal(finals[0][1], finals[1][1])
+
+
 def test_accumulate_grad_batches_two_micro_steps_make_one_optimiser_step():
     """trainer.accumulate_grad_batches: 2 (config/speechCLIP+/model_large/coco/spchclip_h+.yaml:138, Lightning semantics): the first
     micro-step only back-propagates loss / 2 (no optimiser step, parameters and global_step unchanged), the second adds its loss / 2
