@@ -339,6 +339,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self._parity = 0
         self._consumer_stream = None
         self._retired = []                # (forward count at eviction, plan): see _plan
+        self._switch = None               # _encode_overlapped -> _first_trainable
         self._forwards = 0
         if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             self.weightedsum_layer = WeightedSumLayer(
@@ -458,7 +459,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             pl.set_length(L)
         return pl
 
-    def _encode_overlapped(self, padded: torch.Tensor, lens, wav) -> _Plan:
+    def _encode_overlapped(self, padded: torch.Tensor, lens, wav, save: bool = False) -> _Plan:
         """The frozen encoder of this step on its own stream.  Nothing in it depends on the previous step (no trainable parameter, no
         activation), so it may run UNDER the previous step's branch / head / loss / backward kernels, which are launch-sized and leave
         most of the chip idle (cascaded+: 313 launches, 4.6 ms after a 12.3 ms encoder).  The host enqueues step N's tail, then this
@@ -483,16 +484,30 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self._prev_entry = entry
         self._parity ^= 1
         self._consumer_stream = main
-        try:
-            with torch.cuda.stream(enc):
-                pl = self._encode(padded, lens, False)
+        switched = []
+
+        def switch():               # unfrozen top layers (_first_trainable): the rest of the encoder runs on the caller's stream
             done = torch.cuda.Event()
             done.record(enc)
+            torch.cuda.set_stream(main)
+            main.wait_event(done)
+            if self.before_trainable is not None:
+                self.before_trainable()
+            switched.append(True)
+
+        self._switch = switch if self.train_layers is not None else None
+        try:
+            with torch.cuda.stream(enc):
+                pl = self._encode(padded, lens, save)
+            if not switched:
+                done = torch.cuda.Event()
+                done.record(enc)
+                main.wait_event(done)
         finally:
             self._consumer_stream = None
+            self._switch = None
         if pl.seg is not None:                          # layout tables uploaded on the encoder's stream, read by the step's kernels too
             pl.seg._dev.record_stream(main)
-        main.wait_event(done)
         return pl
 
     def segment_pitches(self, T: int, valid: Sequence[int], feat_len: Sequence[int], ragged: bool) -> Tuple[List[int], List[int]]:
@@ -697,6 +712,15 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                          sBias=(Dg, 0), sR=(Dg, R * D), alg_rows=T)
 
     @torch.no_grad()
+    def _first_trainable(self, tl) -> bool:
+        """In front of the first unfrozen layer: hand over from the encoder stream to the caller's (overlapped schedule: the layers
+        below are frozen and ran a step ahead; from here on the kernels read parameters, so the caller's stream joins the optimiser's
+        first), then rebuild the layers' bf16 working copies."""
+        if self._switch is not None:
+            self._switch()
+        tl.refresh()
+        return True
+
     def _layers(self, pl, w, seeds, sd, p_res, p_att, save, scale, first_hidden_done) -> None:
         a = self.arch
         B, L = pl.B, pl.L
@@ -720,8 +744,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 if p_res > 0:
                     ops.dropout_bf16(pl.hidden[0], p_res, sd(1), out=pl.hidden[0])             # F.dropout after the LN (:42)
             tl = self.train_layers
-            if tl is not None:
-                tl.refresh()
+            refreshed = tl is None
             pl.lazy = None
             if _FUSED_LN and tl is None and self._dev.type == "cuda":
                 self._layers_fused(pl, w, sd, p_res, p_att, scale)
@@ -729,6 +752,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             for i in range(a.layers):
                 x = pl.hidden[i]
                 if tl is not None and (i in tl.ids or i in tl.pass_ids):   # unfrozen (or frozen above an unfrozen one): activations kept
+                    if not refreshed:
+                        refreshed = self._first_trainable(tl)
                     tl.layer_forward(i, x, pl.hidden[i + 1], pl, save,
                                      drops=(p_res, p_att, sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)) if seeds else None)
                     continue
@@ -754,11 +779,12 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 if p_res > 0:
                     ops.dropout_bf16(pl.hidden[0], p_res, sd(1), out=pl.hidden[0])
             tl = self.train_layers
-            if tl is not None:
-                tl.refresh()
+            refreshed = tl is None
             for i in range(a.layers):
                 x = pl.hidden[i]
                 if tl is not None and (i in tl.ids or i in tl.pass_ids):
+                    if not refreshed:
+                        refreshed = self._first_trainable(tl)
                     tl.layer_forward(i, x, pl.hidden[i + 1], pl, save,
                                      drops=(p_res, p_att, sd(3 * i + 2), sd(3 * i + 3), sd(3 * i + 4)) if seeds else None)
                     continue
@@ -872,7 +898,12 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             for b, x in enumerate(wav):
                 padded[b, : lens[b]] = x.to(self._dev, torch.float32)
         save = self.train_layers is not None and self.training and torch.is_grad_enabled()
-        if self.train_layers is not None and self.before_trainable is not None:
+        # the overlapped schedule (see _encode_overlapped): a frozen encoder entirely, unfrozen TOP layers up to the first of them
+        tl = self.train_layers
+        ahead = (self.enc_overlap and not _USE_GRAPH and self.training and torch.is_grad_enabled() and padded.is_cuda
+                 and not isinstance(lens, torch.Tensor)
+                 and (tl is None or (self.frontend is None and save)))
+        if self.train_layers is not None and self.before_trainable is not None and not ahead:
             # unfrozen layers read their parameters (refresh(): bf16 copies; LayerNorm affine and biases alias the masters) inside
             # the encoder: join the optimiser's side stream BEFORE the first kernel, not at the weighted sum
             self.before_trainable()
@@ -880,10 +911,11 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # tensors: holding encoder outputs across calls must be safe), the weighted-sum fast path reads the workspace in place
         want_states = return_hidden_states or (feat_select_idx or self.feat_select_idx) != FEAT_SELECT_IDX_WEIGHTED_SUM_MODE
         # returned hidden states carry every padded row, as the reference's do: that forward runs un-ragged (all B x T frames)
-        if (self.enc_overlap and not _USE_GRAPH and self.train_layers is None and self.training and torch.is_grad_enabled()
-                and not want_states and padded.is_cuda and not isinstance(lens, torch.Tensor)):
-            pl = self._encode_overlapped(padded, lens, wav)
+        if ahead and not want_states:
+            pl = self._encode_overlapped(padded, lens, wav, save)
         else:
+            if ahead and self.train_layers is not None and self.before_trainable is not None:
+                self.before_trainable()
             pl = self._encode(padded, lens, save, ragged=False if want_states else None)
         B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
         # (without want_states the tuple is only a placeholder: the weighted sum reads the plan's workspace, raw or not, in place)

@@ -304,7 +304,7 @@ def test_trainer_side_stream_schedule_matches_synchronous():
     assert finals[0][0][2] < finals[0][0][0]
 
 
-@pytest.mark.parametrize("kind", ["parallel", "cascaded"])
+@pytest.mark.parametrize("kind", ["parallel", "cascaded", "unfrozen_top"])
 def test_encoder_on_its_own_stream_under_the_previous_steps_tail(kind):
     """speech_encoder._encode_overlapped: the frozen encoder of step N + 1 runs on a stream of its own while step N's branch / head /
     loss / backward kernels are still in flight, on two alternating sets of resident buffers.  Five steps over DIFFERENT batches (so a
@@ -314,7 +314,7 @@ def test_encoder_on_its_own_stream_under_the_previous_steps_tail(kind):
     from speechclip_plus_amd import set_dropout, KWClip_GeneralTransformer, base_parallel_config, random_hubert_state_dict
     from speechclip_plus_amd.speech_encoder import ARCHS
     from speechclip_plus_amd.train import ContrastiveTrainer
-    arch = dataclasses.replace(ARCHS["hubert"], layers=2)
+    arch = dataclasses.replace(ARCHS["hubert"], layers=3 if kind == "unfrozen_top" else 2)
     sd = random_hubert_state_dict(arch, seed=3)
     g = torch.Generator().manual_seed(23)
     B = 6
@@ -325,9 +325,13 @@ def test_encoder_on_its_own_stream_under_the_previous_steps_tail(kind):
     finals = []
     for overlap in (False, True):
         torch.manual_seed(3)
-        if kind == "parallel":
+        if kind in ("parallel", "unfrozen_top"):
             cfg = base_parallel_config()
             cfg.audio_encoder.max_audio_len = -1
+            if kind == "unfrozen_top":          # conv stack + layer 0 run ahead on the encoder stream, layers 1-2 wait for the optimiser
+                cfg.audio_encoder.trainable = True
+                cfg.audio_encoder.unfreeze_layers = [1, 2]
+                cfg.audio_encoder.optim.args.lr = 1e-3
             model = KWClip_GeneralTransformer(cfg, device="cuda:0", hubert_state_dict=sd, hubert_arch=arch)
         else:
             from speechclip_plus_amd import cascaded_plus_base_config
