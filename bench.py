@@ -200,7 +200,11 @@ def main():
                        "global_batch": B * world, "per_gpu_batch": B, "audio_samples": L, "frames": T,
                        "parallelism": f"dp{world}", "dropout": ("off (--no-dropout)" if args.no_dropout else
                                    "on, as the reference's train step: HuBERT in train mode (base: input / residual / attention "
-                                   "p=0.1; large: 0) + head p=0.1; masks = stateless hash inside the GEMM / attention kernels")},
+                                   "p=0.1; large: 0) + head p=0.1; masks = stateless hash inside the GEMM / attention kernels"),
+                       "schedule": ("frozen encoder of step N + 1 enqueued on its own HIP stream under step N's head / loss / backward / "
+                                    "optimiser kernels (two alternating sets of resident buffers; every step's full work inside the "
+                                    "timed region; SC_ENC_OVERLAP=0 = one stream)"
+                                    if getattr(model.audio_encoder, "enc_overlap", False) and not args.trainable else "one stream per step")},
             "rccl_ranks": rccl_ranks, "dist_backend": (os.environ.get("SC_DIST_BACKEND", "nccl") if dist is not None else None),
             "collectives": collectives,
             "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,
