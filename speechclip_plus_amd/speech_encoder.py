@@ -459,7 +459,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             pl.set_length(L)
         return pl
 
-    def _encode_overlapped(self, padded: torch.Tensor, lens, wav, save: bool = False) -> _Plan:
+    def _encode_overlapped(self, padded: Optional[torch.Tensor], host_src: Optional[torch.Tensor], lens, wav, save: bool = False) -> _Plan:
         """The frozen encoder of this step on its own stream.  Nothing in it depends on the previous step (no trainable parameter, no
         activation), so it may run UNDER the previous step's branch / head / loss / backward kernels, which are launch-sized and leave
         most of the chip idle (cascaded+: 313 launches, 4.6 ms after a 12.3 ms encoder).  The host enqueues step N's tail, then this
@@ -470,6 +470,13 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             before it - through step N - 2's backward, the last reader of this plan - has finished); encoders run one after the
             other on the one encoder stream;
           * the caller's stream waits for the encoder's completion event before the weighted sum.
+        The INPUT must be ready when the encoder stream gets to it, which may be a step's length before the caller's stream does:
+          * a host batch (``host_src``) is copied to the device here, on the encoder stream (pinned memory: asynchronously) - the way
+            a loop gets both the overlap and its H2D copy off the critical path;
+          * a device batch marked ``wav._sc_ready = True`` (resident data: bench.py's synthetic batch) or ``= torch.cuda.Event`` (a
+            prefetcher's copy-done event) is read as soon as that allows;
+          * any other device tensor may still be the target of work queued on the caller's stream (e.g. the loop's own ``.to(device)``):
+            the encoder stream waits for the caller's stream as of this call - correct, and little overlap.
         Same kernels on the same values: results are bit-identical to the single-stream schedule."""
         main = torch.cuda.current_stream()
         if self._enc_stream is None:
@@ -479,8 +486,12 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         entry.record(main)
         if self._prev_entry is not None:
             enc.wait_event(self._prev_entry)
-        if not (isinstance(wav, torch.Tensor) and padded.data_ptr() == wav.data_ptr()):
-            enc.wait_event(entry)                       # the padded batch was produced on the caller's stream just now
+        if host_src is None:
+            ready = getattr(wav, "_sc_ready", None) if (isinstance(wav, torch.Tensor) and padded.data_ptr() == wav.data_ptr()) else None
+            if isinstance(ready, torch.cuda.Event):
+                enc.wait_event(ready)
+            elif ready is not True:
+                enc.wait_event(entry)                   # whatever produced the batch on the caller's stream comes first
         self._prev_entry = entry
         self._parity ^= 1
         self._consumer_stream = main
@@ -498,6 +509,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self._switch = switch if self.train_layers is not None else None
         try:
             with torch.cuda.stream(enc):
+                if host_src is not None:
+                    padded = host_src.to(self._dev, torch.float32, non_blocking=True).contiguous()
                 pl = self._encode(padded, lens, save)
             if not switched:
                 done = torch.cuda.Event()
@@ -879,8 +892,14 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 else:
                     lens = [wav.shape[1]] * wav.shape[0]
                 L = max(lens)
-            padded = wav[:, :L].to(self._dev, torch.float32).contiguous()
+            host_src = None
+            if not wav.is_cuda and self._dev.type == "cuda":
+                host_src = wav[:, :L]               # copied to the device on the stream the encoder runs on (below)
+                padded = None
+            else:
+                padded = wav[:, :L].to(self._dev, torch.float32).contiguous()
         else:
+            host_src = None
             if isinstance(wav, torch.Tensor):
                 if wav.dim() == 2:
                     if len(wav_len) > 0:
@@ -900,7 +919,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         save = self.train_layers is not None and self.training and torch.is_grad_enabled()
         # the overlapped schedule (see _encode_overlapped): a frozen encoder entirely, unfrozen TOP layers up to the first of them
         tl = self.train_layers
-        ahead = (self.enc_overlap and not _USE_GRAPH and self.training and torch.is_grad_enabled() and padded.is_cuda
+        ahead = (self.enc_overlap and not _USE_GRAPH and self.training and torch.is_grad_enabled() and self._dev.type == "cuda"
                  and not isinstance(lens, torch.Tensor)
                  and (tl is None or (self.frontend is None and save)))
         if self.train_layers is not None and self.before_trainable is not None and not ahead:
@@ -912,10 +931,12 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         want_states = return_hidden_states or (feat_select_idx or self.feat_select_idx) != FEAT_SELECT_IDX_WEIGHTED_SUM_MODE
         # returned hidden states carry every padded row, as the reference's do: that forward runs un-ragged (all B x T frames)
         if ahead and not want_states:
-            pl = self._encode_overlapped(padded, lens, wav, save)
+            pl = self._encode_overlapped(padded, host_src, lens, wav, save)
         else:
             if ahead and self.train_layers is not None and self.before_trainable is not None:
                 self.before_trainable()
+            if padded is None:
+                padded = host_src.to(self._dev, torch.float32).contiguous()
             pl = self._encode(padded, lens, save, ragged=False if want_states else None)
         B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
         # (without want_states the tuple is only a placeholder: the weighted sum reads the plan's workspace, raw or not, in place)

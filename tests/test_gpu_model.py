@@ -322,6 +322,11 @@ def test_encoder_on_its_own_stream_under_the_previous_steps_tail(kind):
             [24000, 17000, 24000, 9000, 20000, 24000], [24000, 6000, 24000, 24000, 24000, 13000]]
     batches = [{"wav": torch.randn(B, 24000, generator=g).cuda(), "wav_len": torch.tensor(l), "image": torch.randn(B, 512, generator=g).cuda(),
                 "id": torch.arange(B).cuda()} for l in lens]
+    torch.cuda.synchronize()
+    for i, b in enumerate(batches):          # resident inputs, marked ready (the encoder stream then runs a step ahead); one batch stays
+        if i != 2:                           # unmarked (waits for the caller's stream) and one arrives as a host tensor (copied by the
+            b["wav"]._sc_ready = True        # encoder stream itself)
+    batches[4]["wav"] = batches[4]["wav"].cpu().pin_memory()
     finals = []
     for overlap in (False, True):
         torch.manual_seed(3)
@@ -371,6 +376,8 @@ def test_encoder_stream_with_changing_padded_lengths_and_plan_eviction():
         lens[i % B] = L
         batches.append({"wav": torch.randn(B, L, generator=g).cuda(), "wav_len": lens, "image": torch.randn(B, 512, generator=g).cuda(),
                         "id": torch.arange(B).cuda()})
+        batches[-1]["wav"]._sc_ready = True
+    torch.cuda.synchronize()
     finals = []
     for overlap in (False, True):
         torch.manual_seed(5)
