@@ -269,6 +269,17 @@ int sc_conv0_stats_len(const float* wav, int64_t ldw, const int64_t* wav_len, in
                        void* stream);
 int sc_conv0_gn_gelu_seg(const float* wav_flat, const sc_segments* seg, int32_t samples_per_row, const float* w0, const float* scale,
                          const float* shift, sc_bf16* out, int32_t C, void* stream);
+/* The in-forward training crop (round 5): avssl/module/speech_encoder_plus.py:548-552 calls random_crop_max_length
+ * (avssl/data/audio_transforms.py:5-23) per utterance on the un-padded list and re-pads (:506-518).  Here the caller's [B, ldw] batch
+ * stays where it is: utterance b is wav[b, wav_off[b] : wav_off[b] + wav_len[b]] (wav_len = the CROPPED lengths, L = their maximum,
+ * wav_off[b] + wav_len[b] <= ldw is the caller's contract), read in place by the two kernels that touch the caller's batch.
+ * wav_off == NULL: the un-cropped entry points above. */
+int sc_wav_prep_crop(const float* wav, int64_t ldw_in, const int64_t* wav_len, const int64_t* wav_off, float* out, int64_t ldw_out,
+                     int32_t B, int32_t L, int32_t normalize, void* stream);
+int sc_wav_prep_seg_crop(const float* wav, int64_t ldw_in, const int64_t* wav_len, const int64_t* wav_off, float* out,
+                         const sc_segments* seg, int32_t samples_per_row, int32_t L, int32_t normalize, void* stream);
+int sc_conv0_stats_len_crop(const float* wav, int64_t ldw, const int64_t* wav_len, const int64_t* wav_off, int32_t B, int32_t T0,
+                            int32_t nchunk, double* partial, void* stream);
 int sc_conv0_ln_gelu_seg(const float* wav_flat, const sc_segments* seg, int32_t samples_per_row, const float* w0, const float* bias,
                          const float* gamma, const float* beta, float eps, sc_bf16* out, int32_t C, void* stream);
 /* "layer_norm" extractor mode (HuBERT-large): conv0 (+bias) -> LayerNorm over the 512 channels -> GELU */

@@ -115,6 +115,9 @@ SIGNATURES = {
                              c_float, c_void_p, c_int, c_float, ctypes.c_uint32, c_void_p],
     "sc_wav_prep_seg": [c_void_p, c_i64, c_void_p, c_void_p, ctypes.POINTER(Segments), c_int, c_int, c_int, c_void_p],
     "sc_conv0_stats_len": [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sc_wav_prep_crop": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p],
+    "sc_wav_prep_seg_crop": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Segments), c_int, c_int, c_int, c_void_p],
+    "sc_conv0_stats_len_crop": [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sc_conv0_gn_gelu_seg": [c_void_p, ctypes.POINTER(Segments), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "sc_conv0_ln_gelu_seg": [c_void_p, ctypes.POINTER(Segments), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p],
     "sc_posconv_prep_seg": [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Segments), c_int, c_int, c_int, c_void_p],

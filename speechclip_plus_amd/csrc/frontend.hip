@@ -17,12 +17,14 @@ namespace {
 // row0 != NULL (ragged rows, sc_segments): utterance b's region is [spr * row0[b], spr * row0[b + 1]) of ONE flat buffer
 __global__ __launch_bounds__(1024) void wav_prep_kernel(const float* __restrict__ wav, int64_t ldw_in,
                                                         const int64_t* __restrict__ wav_len, float* __restrict__ out,
-                                                        int64_t ldw_out, int L, int normalize, const int32_t* __restrict__ row0, int spr) {
+                                                        int64_t ldw_out, int L, int normalize, const int32_t* __restrict__ row0, int spr,
+                                                        const int64_t* __restrict__ wav_off) {
     __shared__ double red[2][16];
     const int b = blockIdx.x;
     int len = (int)wav_len[b];
     len = max(0, min(len, L));
-    const float* x = wav + (int64_t)b * ldw_in;
+    // wav_off != NULL (the in-forward training crop, speech_encoder_plus.py:548-552): utterance b is wav[b, off_b : off_b + len_b]
+    const float* x = wav + (int64_t)b * ldw_in + (wav_off ? wav_off[b] : (int64_t)0);
     float* o = out + (int64_t)b * ldw_out;
     if (row0) {
         const int r0 = row0[b];
@@ -75,14 +77,16 @@ __global__ __launch_bounds__(1024) void wav_prep_kernel(const float* __restrict_
 // partial[(b*nchunk + chunk)*66 + e]: e < 55 Gram (j <= j'), 55..64 sums
 // wav_len != NULL: the caller's un-prepared batch - samples at and past wav_len[b] read as 0 (windows that lie wholly behind the
 // utterance add nothing and are skipped); the sums are those of the zero-padded waveform, term for term
+// wav_off != NULL: utterance b starts at sample wav_off[b] of its row (the in-forward crop)
 __global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ wav, int64_t ldw, int T0,
-                                                          int nchunk, double* __restrict__ partial, const int64_t* __restrict__ wav_len) {
+                                                          int nchunk, double* __restrict__ partial, const int64_t* __restrict__ wav_len,
+                                                          const int64_t* __restrict__ wav_off) {
     __shared__ double red[4][SC_CONV0_NSTAT];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int per = (T0 + nchunk - 1) / nchunk;
     const int len = wav_len ? (int)wav_len[b] : 0x7fffffff;
     const int t_begin = chunk * per, t_end = min(min(T0, t_begin + per), wav_len ? (len + 4) / 5 : 0x7fffffff);
-    const float* x = wav + (int64_t)b * ldw;
+    const float* x = wav + (int64_t)b * ldw + (wav_off ? wav_off[b] : (int64_t)0);
     if (t_begin >= t_end) {                      // a chunk wholly behind the utterance (ragged batches): its sums are zero
         if (threadIdx.x < 65) partial[((int64_t)b * nchunk + chunk) * SC_CONV0_NSTAT + threadIdx.x] = 0.0;
         return;
@@ -506,17 +510,32 @@ extern "C" int sc_wav_prep(const float* wav, int64_t ldw_in, const int64_t* wav_
     SC_CHECK(wav && wav_len && out, "sc_wav_prep: null pointer");
     SC_CHECK(B > 0 && L > 0 && ldw_out >= L && ldw_in >= L, "sc_wav_prep: bad sizes");
     // without normalisation the kernel is a pure copy: spread each utterance over 32 blocks
-    hipLaunchKernelGGL(wav_prep_kernel, dim3(B, normalize ? 4 : 32), dim3(normalize ? 1024 : 256), 0, (hipStream_t)stream, wav, ldw_in, wav_len, out, ldw_out, L, normalize, (const int32_t*)nullptr, 0);
+    hipLaunchKernelGGL(wav_prep_kernel, dim3(B, normalize ? 4 : 32), dim3(normalize ? 1024 : 256), 0, (hipStream_t)stream, wav, ldw_in, wav_len, out, ldw_out, L, normalize, (const int32_t*)nullptr, 0, (const int64_t*)nullptr);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_wav_prep_seg_crop(const float* wav, int64_t ldw_in, const int64_t* wav_len, const int64_t* wav_off, float* out,
+                                    const sc_segments* seg, int32_t samples_per_row, int32_t L, int32_t normalize, void* stream) {
+    SC_CHECK(wav && wav_len && out && seg && seg->row0, "sc_wav_prep_seg: null pointer");
+    SC_CHECK(seg->B > 0 && L > 0 && ldw_in >= L && samples_per_row > 0 && samples_per_row % 5 == 0, "sc_wav_prep_seg: bad sizes");
+    hipLaunchKernelGGL(wav_prep_kernel, dim3(seg->B, normalize ? 4 : 32), dim3(normalize ? 1024 : 256), 0, (hipStream_t)stream, wav, ldw_in, wav_len,
+                       out, (int64_t)0, L, normalize, seg->row0, samples_per_row, wav_off);
     SC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sc_wav_prep_seg(const float* wav, int64_t ldw_in, const int64_t* wav_len, float* out, const sc_segments* seg,
                                int32_t samples_per_row, int32_t L, int32_t normalize, void* stream) {
-    SC_CHECK(wav && wav_len && out && seg && seg->row0, "sc_wav_prep_seg: null pointer");
-    SC_CHECK(seg->B > 0 && L > 0 && ldw_in >= L && samples_per_row > 0 && samples_per_row % 5 == 0, "sc_wav_prep_seg: bad sizes");
-    hipLaunchKernelGGL(wav_prep_kernel, dim3(seg->B, normalize ? 4 : 32), dim3(normalize ? 1024 : 256), 0, (hipStream_t)stream, wav, ldw_in, wav_len,
-                       out, (int64_t)0, L, normalize, seg->row0, samples_per_row);
+    return sc_wav_prep_seg_crop(wav, ldw_in, wav_len, nullptr, out, seg, samples_per_row, L, normalize, stream);
+}
+
+extern "C" int sc_wav_prep_crop(const float* wav, int64_t ldw_in, const int64_t* wav_len, const int64_t* wav_off, float* out,
+                                int64_t ldw_out, int32_t B, int32_t L, int32_t normalize, void* stream) {
+    SC_CHECK(wav && wav_len && out, "sc_wav_prep_crop: null pointer");
+    SC_CHECK(B > 0 && L > 0 && ldw_out >= L && ldw_in >= L, "sc_wav_prep_crop: bad sizes");
+    hipLaunchKernelGGL(wav_prep_kernel, dim3(B, normalize ? 4 : 32), dim3(normalize ? 1024 : 256), 0, (hipStream_t)stream, wav, ldw_in, wav_len, out,
+                       ldw_out, L, normalize, (const int32_t*)nullptr, 0, wav_off);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -525,18 +544,23 @@ extern "C" int sc_conv0_stats(const float* wav, int64_t ldw, int32_t B, int32_t 
                               void* stream) {
     SC_CHECK(wav && partial, "sc_conv0_stats: null pointer");
     SC_CHECK(B > 0 && T0 > 0 && nchunk > 0 && ldw >= 5 * (int64_t)(T0 - 1) + 10, "sc_conv0_stats: bad sizes");
-    hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, wav, ldw, T0, nchunk, partial, (const int64_t*)nullptr);
+    hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, wav, ldw, T0, nchunk, partial, (const int64_t*)nullptr, (const int64_t*)nullptr);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_conv0_stats_len_crop(const float* wav, int64_t ldw, const int64_t* wav_len, const int64_t* wav_off, int32_t B, int32_t T0,
+                                       int32_t nchunk, double* partial, void* stream) {
+    SC_CHECK(wav && wav_len && partial, "sc_conv0_stats_len: null pointer");
+    SC_CHECK(B > 0 && T0 > 0 && nchunk > 0, "sc_conv0_stats_len: bad sizes");
+    hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, wav, ldw, T0, nchunk, partial, wav_len, wav_off);
     SC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sc_conv0_stats_len(const float* wav, int64_t ldw, const int64_t* wav_len, int32_t B, int32_t T0, int32_t nchunk,
                                   double* partial, void* stream) {
-    SC_CHECK(wav && wav_len && partial, "sc_conv0_stats_len: null pointer");
-    SC_CHECK(B > 0 && T0 > 0 && nchunk > 0, "sc_conv0_stats_len: bad sizes");
-    hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, wav, ldw, T0, nchunk, partial, wav_len);
-    SC_LAUNCH_CHECK();
-    return 0;
+    return sc_conv0_stats_len_crop(wav, ldw, wav_len, nullptr, B, T0, nchunk, partial, stream);
 }
 
 extern "C" int sc_conv0_finalize(const double* partial, int32_t nchunk, const float* w0, const float* gamma,

@@ -3,13 +3,63 @@
 
 Semantics kept: a ``wav_len`` key is derived from the un-padded waveforms, ``wav`` is zero-padded to the longest
 utterance of the batch (batch first), other tensors are stacked, non-tensor fields (ids, lengths) become int64 tensors.
+
+Round 5 - the way a batch reaches the device (avssl/model/kwClip.py:145-147 receives what Lightning's transfer produced):
+``transfer_batch_to_device`` is the body of the LightningModule hook of the same name.  It keeps what a plain ``.to(device)`` of
+every tensor loses: the lengths stay readable on the HOST (``wav_len._sc_host`` - the ragged row layout and the crop offsets are
+host decisions, and reading a device tensor back would synchronise every step) and the waveform's H2D copy runs on a copy stream
+of its own with a completion event (``wav._sc_ready``), so the encoder - a step ahead of the caller's stream on the overlapped
+schedule - starts when the DATA is there, not when the caller's stream gets there.  ``collate_general(pin_memory=True)`` builds the
+padded waveform in pinned memory so that copy is asynchronous.
 """
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import torch
 
 
-def collate_general(batch: Sequence[dict]) -> Dict[str, torch.Tensor]:
+def attach_host_lengths(wav_len: torch.Tensor, host: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """``wav_len`` with its host twin attached (a python attribute: it does not survive ``.to()`` - attach it to the tensor the
+    model receives).  ``host`` defaults to the tensor's own values, which must then live on the CPU."""
+    if host is None:
+        if wav_len.is_cuda:
+            raise ValueError("attach_host_lengths: a device tensor needs the host values passed in (reading it back would synchronise)")
+        host = wav_len.tolist()
+    wav_len._sc_host = [int(v) for v in host]
+    return wav_len
+
+
+def transfer_batch_to_device(batch: dict, device, copy_stream: Optional["torch.cuda.Stream"] = None) -> dict:
+    """Body of ``LightningModule.transfer_batch_to_device(batch, device, dataloader_idx)`` for the batch dict of ``collate_general``.
+    Every tensor goes to ``device``; ``wav_len`` keeps a host twin; ``wav`` is copied on ``copy_stream`` (default: the package's
+    shared "h2d" stream) and carries the copy's completion event.  No host synchronisation when ``wav`` is pinned (a pageable
+    waveform is pinned here first: one extra host copy)."""
+    device = torch.device(device)
+    out = {}
+    for k, v in batch.items():
+        if not isinstance(v, torch.Tensor) or v.device == device:
+            out[k] = v
+            continue
+        if k == "wav_len":
+            host = getattr(v, "_sc_host", None) or (v.tolist() if not v.is_cuda else None)
+            d = v.to(device, non_blocking=True)
+            out[k] = attach_host_lengths(d, host) if host is not None else d
+        elif k == "wav" and device.type == "cuda" and not v.is_cuda:
+            from . import ops
+            src = v if v.is_pinned() else v.pin_memory()
+            cs = copy_stream if copy_stream is not None else ops.shared_stream("h2d", device)
+            with torch.cuda.stream(cs):
+                d = src.to(device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(cs)
+            d._sc_ready = ev
+            d._sc_pinned_src = src           # the pinned source stays alive until the consumer drops the batch
+            out[k] = d
+        else:
+            out[k] = v.to(device, non_blocking=True)
+    return out
+
+
+def collate_general(batch: Sequence[dict], pin_memory: bool = False) -> Dict[str, torch.Tensor]:
     if len(batch) == 0:
         raise ValueError("empty batch")
     keys: List[str] = list(batch[0].keys())
@@ -20,7 +70,9 @@ def collate_general(batch: Sequence[dict]) -> Dict[str, torch.Tensor]:
         if isinstance(vals[0], torch.Tensor):
             if k == "wav":
                 L = max(int(v.shape[0]) for v in vals)
-                padded = vals[0].new_zeros((len(vals), L) + tuple(vals[0].shape[1:]))
+                padded = torch.zeros((len(vals), L) + tuple(vals[0].shape[1:]), dtype=vals[0].dtype,
+                                     pin_memory=bool(pin_memory) and torch.cuda.is_available() and not vals[0].is_cuda,
+                                     device=vals[0].device)
                 for i, v in enumerate(vals):
                     padded[i, : v.shape[0]] = v
                 out[k] = padded
@@ -29,5 +81,5 @@ def collate_general(batch: Sequence[dict]) -> Dict[str, torch.Tensor]:
         else:
             out[k] = torch.tensor(vals, dtype=torch.long)
     if derive_len:
-        out["wav_len"] = torch.tensor([int(row["wav"].shape[0]) for row in batch], dtype=torch.long)
+        out["wav_len"] = attach_host_lengths(torch.tensor([int(row["wav"].shape[0]) for row in batch], dtype=torch.long))
     return out

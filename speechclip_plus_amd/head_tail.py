@@ -242,6 +242,8 @@ class ParallelHeadFn(torch.autograd.Function):
             d_ws = ops.wsum_bwd_logits(hd.hidden, dX, hd.w_soft, B, R, D, 1, normalize=hd.normalize, lazy=hd.lazy, seg=hd.seg)
         if hd is not None and hd.layers_bwd is not None:           # unfrozen HuBERT layers: continue the chain below the weighted sum
             hd.layers_bwd(dX, hd.w_soft)
+        if hd is not None:
+            hd.release()                     # nothing after this reads the encoder plan's resident states (speech_encoder._claim)
         if ctx.feat_meta is not None and ctx.needs_input_grad[2]:
             shape, dtype = ctx.feat_meta
             d_feat = dX[:, 1: 1 + shape[1]].to(dtype)

@@ -337,6 +337,12 @@ class KWClip_GeneralTransformer(nn.Module):
         losses_["loss"] = total
         return losses_
 
+    def transfer_batch_to_device(self, batch: dict, device=None, dataloader_idx: int = 0) -> dict:
+        """The LightningModule hook of the same name (what hands kwClip.py:145-147 its device batch): see
+        data.transfer_batch_to_device - host twin of ``wav_len``, the waveform copied on its own stream with a completion event."""
+        from .data import transfer_batch_to_device
+        return transfer_batch_to_device(batch, self._device if device is None else device)
+
     def training_step(self, batch: dict) -> dict:
         losses_, log_metrics = self.forward(batch)[:2]
         return {"loss_feats": losses_, "log_metrics": log_metrics}

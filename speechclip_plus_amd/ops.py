@@ -879,26 +879,40 @@ def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out
     return out
 
 
-def wav_prep(wav: torch.Tensor, wav_len: torch.Tensor, out: torch.Tensor, normalize: bool) -> None:
-    assert wav.dtype == torch.float32 and wav_len.dtype == torch.int64 and out.dtype == torch.float32
-    B, L = wav.shape
-    check(lib().sc_wav_prep(_p(wav), wav.stride(0), _p(wav_len), _p(out), out.stride(0), B, L, int(normalize), _stream()),
-          "sc_wav_prep")
+def _wav_window(wav: torch.Tensor, L: Optional[int], wav_off: Optional[torch.Tensor]) -> int:
+    """host-side shape contract of the kernels that read the caller's [B, ld] batch in place: unit sample stride, a padded length
+    L <= the row width, int64 offsets on the batch's device (their range is the caller's contract: off_b + len_b <= width)"""
+    assert wav.dim() == 2 and wav.stride(1) == 1 and wav.dtype == torch.float32, (wav.shape, wav.stride(), wav.dtype)
+    L = wav.shape[1] if L is None else int(L)
+    assert 0 < L <= wav.shape[1] and (wav.shape[0] == 1 or wav.stride(0) >= wav.shape[1]), (L, wav.shape, wav.stride())
+    if wav_off is not None:
+        assert wav_off.dtype == torch.int64 and wav_off.device == wav.device and wav_off.numel() == wav.shape[0] and wav_off.is_contiguous()
+    return L
+
+
+def wav_prep(wav: torch.Tensor, wav_len: torch.Tensor, out: torch.Tensor, normalize: bool, L: Optional[int] = None,
+             wav_off: Optional[torch.Tensor] = None) -> None:
+    """L / wav_off: the in-forward crop - utterance b is wav[b, off_b : off_b + len_b], padded length L (sc_wav_prep_crop)"""
+    assert wav_len.dtype == torch.int64 and out.dtype == torch.float32
+    L = _wav_window(wav, L, wav_off)
+    check(lib().sc_wav_prep_crop(_p(wav), wav.stride(0), _p(wav_len), _p(wav_off), _p(out), out.stride(0), wav.shape[0], L, int(normalize),
+                                 _stream()), "sc_wav_prep_crop")
 
 
 def wav_prep_seg(wav: torch.Tensor, wav_len: torch.Tensor, out_flat: torch.Tensor, seg: "RowSegments", samples_per_row: int,
-                 normalize: bool) -> None:
-    """waveform into the ragged layout: utterance b at sample samples_per_row * row0[b] of ONE flat fp32 buffer (sc_wav_prep_seg)"""
-    assert wav.dtype == torch.float32 and wav_len.dtype == torch.int64 and out_flat.dtype == torch.float32
+                 normalize: bool, L: Optional[int] = None, wav_off: Optional[torch.Tensor] = None) -> None:
+    """waveform into the ragged layout: utterance b at sample samples_per_row * row0[b] of ONE flat fp32 buffer (sc_wav_prep_seg);
+    L / wav_off as in wav_prep"""
+    assert wav_len.dtype == torch.int64 and out_flat.dtype == torch.float32
     assert out_flat.numel() >= samples_per_row * seg.rows + 16
-    B, L = wav.shape
-    check(lib().sc_wav_prep_seg(_p(wav), wav.stride(0), _p(wav_len), _p(out_flat), seg.ref(), samples_per_row, L, int(normalize), _stream()),
-          "sc_wav_prep_seg")
+    L = _wav_window(wav, L, wav_off)
+    check(lib().sc_wav_prep_seg_crop(_p(wav), wav.stride(0), _p(wav_len), _p(wav_off), _p(out_flat), seg.ref(), samples_per_row, L,
+                                     int(normalize), _stream()), "sc_wav_prep_seg_crop")
 
 
 def conv0_groupnorm_gelu_seg(wav: torch.Tensor, wav_len: torch.Tensor, wav_flat: torch.Tensor, seg: "RowSegments", samples_per_row: int,
                              w0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, T0: int, out: torch.Tensor, eps: float = 1e-5,
-                             nchunk: int = 8) -> None:
+                             nchunk: int = 8, wav_off: Optional[torch.Tensor] = None) -> None:
     """conv layer 0 + GroupNorm + GELU on ragged rows.  The GroupNorm statistics run over the PADDED batch length T0 (fairseq feeds the
     zero-padded batch, speech_encoder_plus.py:75) and come straight from the caller's [B, L] batch masked by wav_len; the activation is
     written for the rows of the segment layout only."""
@@ -907,7 +921,9 @@ def conv0_groupnorm_gelu_seg(wav: torch.Tensor, wav_len: torch.Tensor, wav_flat:
     scale = torch.empty(B, C, device=wav.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
     L = lib()
-    check(L.sc_conv0_stats_len(_p(wav), wav.stride(0), _p(wav_len), B, T0, nchunk, _p(partial), _stream()), "sc_conv0_stats_len")
+    _wav_window(wav, None, wav_off)
+    check(L.sc_conv0_stats_len_crop(_p(wav), wav.stride(0), _p(wav_len), _p(wav_off), B, T0, nchunk, _p(partial), _stream()),
+          "sc_conv0_stats_len_crop")
     check(L.sc_conv0_finalize(_p(partial), nchunk, _p(w0), _p(gamma), _p(beta), B, C, T0, float(eps), _p(scale), _p(shift), _stream()),
           "sc_conv0_finalize")
     check(L.sc_conv0_gn_gelu_seg(_p(wav_flat), seg.ref(), samples_per_row, _p(w0), _p(scale), _p(shift), _p(out), C, _stream()),

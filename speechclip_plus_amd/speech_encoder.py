@@ -88,6 +88,23 @@ def random_crop_max_length(audio: torch.Tensor, max_len: int, orig_len: int = 10
     return audio[offset: offset + max_len]
 
 
+def crop_windows(lens: Sequence[int], max_len: int) -> Tuple[List[int], List[int]]:
+    """The training crop of speech_encoder_plus.py:548-552 as (offset, cropped length) per utterance: the same draws from numpy's global
+    generator, in the same order, as the reference's loop over ``random_crop_max_length`` (audio_transforms.py:5-23) - one
+    ``np.random.randint(len - max_len)`` per utterance longer than ``max_len``, none for the others - so a seeded run crops the same
+    windows.  The samples themselves are never touched on the host: the kernels that read the caller's batch take the offsets."""
+    offs, out = [], []
+    for l in lens:
+        l = int(l)
+        if l <= max_len or max_len < 0:
+            offs.append(0)
+            out.append(l)
+        else:
+            offs.append(int(np.random.randint(l - max_len)))
+            out.append(int(max_len))
+    return offs, out
+
+
 def random_hubert_state_dict(arch: HubertArch, seed: int = 7122) -> Dict[str, torch.Tensor]:
     """Seeded synthetic weights with fairseq key names (fan-in scaled so activations stay O(1))."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -231,6 +248,12 @@ class _Plan:
         self.graph, self.graph_warm = None, 0        # hipGraph of the frozen encoder forward for this geometry
         self.train = {}              # per unfrozen layer: activations kept for the backward (hubert_train.TrainableLayers)
         self.generation = 0          # forwards run on this plan (weighted_sum.PaddedFeatHandle.check_fresh)
+        # overlapped schedule (speech_encoder._claim): a forward that will be differentiated leaves ``grad_pending`` set until its
+        # backward has ENQUEUED its last read of this plan's buffers (weighted-sum / unfrozen-layer backward) and recorded
+        # ``readers_done`` behind it on the stream it ran on
+        self.grad_pending = False
+        self.readers_done = None
+        self.wav_off, self.src_L = None, L
         self.seg = None
         self.bind(None)
 
@@ -251,6 +274,15 @@ class _Plan:
         if self._seg_cache[0] != key:
             self._seg_cache = (key, ops.RowSegments(pitch, keys, device, keys_known=keys_known))
         return self._seg_cache[1]
+
+    def release(self) -> None:
+        """Called by the backward that read this plan's resident buffers last (weighted_sum / head_tail), on the stream it ran on:
+        from the recorded event on, the encoder stream may overwrite them."""
+        if self.hidden.is_cuda:          # (every reader records: with two readers in one backward - hybrid+ - the later event counts)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.readers_done = ev
+        self.grad_pending = False
 
     def bind(self, seg) -> None:
         """Lay the current batch out: ``seg`` = its ops.RowSegments (seg_mode) or None = the uniform B x R rows."""
@@ -340,6 +372,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self._consumer_stream = None
         self._retired = []                # (forward count at eviction, plan): see _plan
         self._switch = None               # _encode_overlapped -> _first_trainable
+        self._ov = None                   # (encoder stream, entry event) while _encode_overlapped runs: see _claim
         self._forwards = 0
         if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             self.weightedsum_layer = WeightedSumLayer(
@@ -411,6 +444,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             w["lazy_gamma"] = f32(torch.stack([torch.ones(a.embed_dim)] + [sd[f"encoder.layers.{i}.final_layer_norm.weight"].float() for i in range(a.layers)]))
             w["lazy_beta"] = f32(torch.stack([torch.zeros(a.embed_dim)] + [sd[f"encoder.layers.{i}.final_layer_norm.bias"].float() for i in range(a.layers)]))
         self._w = w          # frozen device tensors (not nn.Parameters: no grads, no optimizer state)
+        self._weights_dirty = True       # _encode_overlapped: the encoder stream has to see these before its next forward
 
     def trainable_params(self) -> list:
         """speech_encoder_plus.py:478-494.  Frozen encoder: only the weighted-sum weights train; with ``reinit_layers`` the
@@ -459,7 +493,24 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             pl.set_length(L)
         return pl
 
-    def _encode_overlapped(self, padded: Optional[torch.Tensor], host_src: Optional[torch.Tensor], lens, wav, save: bool = False) -> _Plan:
+    def _claim(self, pl: _Plan) -> None:
+        """Before the first write into a plan's resident buffers.  On the overlapped schedule the encoder stream runs ahead of the
+        caller's stream, so 'the previous user of this plan is done' has to be said explicitly: the backward that read the
+        plan last recorded ``readers_done`` (f1 f2 b1 b2 f3: f3 re-uses f1's plan and waits for b1's event, wherever b1 was enqueued);
+        a forward whose backward has NOT been enqueued yet can only be waited for as 'everything on the caller's stream so far' - its
+        late backward then fails the generation check loudly instead of reading overwritten states."""
+        ov = self._ov
+        if ov is not None:
+            enc, entry = ov
+            if pl.grad_pending:
+                enc.wait_event(entry)
+            elif pl.readers_done is not None:
+                enc.wait_event(pl.readers_done)
+        pl.readers_done = None
+        pl.grad_pending = bool(self.training and torch.is_grad_enabled())
+
+    def _encode_overlapped(self, padded: Optional[torch.Tensor], host_src: Optional[torch.Tensor], lens, ready, save: bool = False,
+                           L: Optional[int] = None, off=None) -> _Plan:
         """The frozen encoder of this step on its own stream.  Nothing in it depends on the previous step (no trainable parameter, no
         activation), so it may run UNDER the previous step's branch / head / loss / backward kernels, which are launch-sized and leave
         most of the chip idle (cascaded+: 313 launches, 4.6 ms after a 12.3 ms encoder).  The host enqueues step N's tail, then this
@@ -484,10 +535,14 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         enc = self._enc_stream
         entry = torch.cuda.Event()
         entry.record(main)
-        if self._prev_entry is not None:
+        if self._prev_entry is not None and not self._weights_dirty:
             enc.wait_event(self._prev_entry)
+        else:
+            # first overlapped forward, or weights (re)loaded since the last one: the casts / weight-norm fold / QKV concatenation of
+            # _load_weights were enqueued on the caller's stream and nothing orders them against the encoder stream yet
+            enc.wait_event(entry)
+            self._weights_dirty = False
         if host_src is None:
-            ready = getattr(wav, "_sc_ready", None) if (isinstance(wav, torch.Tensor) and padded.data_ptr() == wav.data_ptr()) else None
             if isinstance(ready, torch.cuda.Event):
                 enc.wait_event(ready)
             elif ready is not True:
@@ -507,11 +562,16 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             switched.append(True)
 
         self._switch = switch if self.train_layers is not None else None
+        self._ov = (enc, entry)
         try:
             with torch.cuda.stream(enc):
                 if host_src is not None:
-                    padded = host_src.to(self._dev, torch.float32, non_blocking=True).contiguous()
-                pl = self._encode(padded, lens, save)
+                    # (a pinned source: asynchronous; a pageable one blocks the HOST until the encoder stream gets to the copy -
+                    # pin it, data.collate_general / transfer_batch_to_device do)
+                    padded = host_src.to(self._dev, torch.float32, non_blocking=True)
+                else:
+                    padded.record_stream(enc)           # the caller's tensor, read on this stream
+                pl = self._encode(padded, lens, save, L=L, off=off)
             if not switched:
                 done = torch.cuda.Event()
                 done.record(enc)
@@ -519,6 +579,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         finally:
             self._consumer_stream = None
             self._switch = None
+            self._ov = None
         if pl.seg is not None:                          # layout tables uploaded on the encoder's stream, read by the step's kernels too
             pl.seg._dev.record_stream(main)
         return pl
@@ -533,12 +594,20 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         return need, [_roundup(n + 1, ops.RowSegments.GRAN) for n in need]
 
     @torch.no_grad()
-    def _encode(self, padded: torch.Tensor, wav_len: List[int], save: bool = False, ragged: Optional[bool] = None) -> _Plan:
-        """customHubertForward + patched extract_features (speech_encoder_plus.py:29-107) on the device."""
+    def _encode(self, padded: torch.Tensor, wav_len: List[int], save: bool = False, ragged: Optional[bool] = None,
+                L: Optional[int] = None, off=None) -> _Plan:
+        """customHubertForward + patched extract_features (speech_encoder_plus.py:29-107) on the device.
+        ``padded``: the caller's [B, >= L] fp32 device batch, read in place (row stride = its own); ``L``: the padded length of the
+        batch the reference would have built (default: the tensor's width); ``off``: per-utterance start samples of the in-forward
+        training crop (host list -> uploaded with the step's other integers, or a device int64 tensor), ``wav_len`` then holds the
+        CROPPED lengths."""
         a, w = self.arch, self._w
-        B, L = padded.shape
+        B = padded.shape[0]
+        L = int(padded.shape[1] if L is None else L)
         pl = self._plan(B, L)
+        self._claim(pl)
         pl.generation += 1
+        pl.src_L = L
         C, D, F, H = a.conv_dim, a.embed_dim, a.ffn_dim, a.heads
         R, M, T = pl.R, pl.M, pl.T
         # every length-derived integer of the step goes up in ONE asynchronous copy from pinned memory BEFORE the kernels are
@@ -564,6 +633,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             pl.feat_len = feat_d
             pl.feat_len._sc_p1_i32 = (feat_d + 1).to(torch.int32)
             ints = (l64, valid_d.to(torch.int32))
+            assert off is None or isinstance(off, torch.Tensor)
+            pl.wav_off = off
         else:
             valid = [min(T, -(-int(l) // chunk)) for l in wav_len]
             feat_len = [min(round(int(l) / self.downsample_rate), T) for l in wav_len]
@@ -581,16 +652,21 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             # ONE pinned buffer, ONE copy: [wav_len i64 | feat_len i64 | round(feat_len / 20) i64 | valid i32 | feat_len + 1 i32] (the third =
             # the keyword-count targets of the cascaded branches, kwClip.py:876; the last = the key count of the parallel head's
             # [CLS ; frames] as the int32 vector its kernels take); the device tensors below are views of it
-            import numpy as np
+            # a fourth int64 row: the crop offsets (zeros without a crop)
             tgt20 = [int(v) for v in np.round(np.asarray(feat_len, dtype=np.float32) / np.float32(20.0))]      # = kw_branches.target_len_host
-            hb = torch.empty(32 * B, dtype=torch.uint8).pin_memory()
+            assert off is None or (not isinstance(off, torch.Tensor) and len(off) == B)
+            # straight from torch's caching pinned-host allocator (no cudaHostAlloc, no pageable staging copy per step; the allocator
+            # keeps the block until the asynchronous copy below has finished, so dropping ``hb`` right away is safe)
+            hb = torch.empty(40 * B, dtype=torch.uint8, pin_memory=self._dev.type == "cuda")
             hv = hb.numpy()
-            hv[: 24 * B].view(np.int64)[:] = np.asarray([list(map(int, wav_len)), feat_len, tgt20], dtype=np.int64).reshape(-1)
-            hv[24 * B:].view(np.int32)[:] = np.asarray([valid, [f + 1 for f in feat_len]], dtype=np.int32).reshape(-1)
+            hv[: 32 * B].view(np.int64)[:] = np.asarray([list(map(int, wav_len)), feat_len, tgt20, list(off) if off is not None else [0] * B],
+                                                        dtype=np.int64).reshape(-1)
+            hv[32 * B:].view(np.int32)[:] = np.asarray([valid, [f + 1 for f in feat_len]], dtype=np.int32).reshape(-1)
             db = hb.to(self._dev, non_blocking=True)
             if self._consumer_stream is not None:       # allocated on the encoder's stream, read by the step's stream
                 db.record_stream(self._consumer_stream)
-            i64, i32 = db[: 24 * B].view(torch.int64), db[24 * B:].view(torch.int32)
+            i64, i32 = db[: 32 * B].view(torch.int64), db[32 * B:].view(torch.int32)
+            pl.wav_off = i64[3 * B: 4 * B] if off is not None else None
             pl.feat_len = i64[B: 2 * B]
             pl.feat_len._sc_host = list(feat_len)       # host twin (length-derived integers are known before any kernel runs)
             pl.feat_len._sc_p1_i32 = i32[B:]
@@ -608,7 +684,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # gaps between kernels are the hardware's dispatch, not the host's), so it stays off by default; not used with
         # unfrozen layers nor while bench.py's per-kernel event timer is attached.
         use_graph = (_USE_GRAPH and self._dev.type == "cuda" and self.train_layers is None and ops._timer is None
-                     and not self._dropout_active() and not pl.seg_mode)
+                     and not self._dropout_active() and not pl.seg_mode and pl.wav_off is None and padded.shape[1] == L)
         if not use_graph:
             self._encode_kernels(pl, padded, save)
             return pl
@@ -658,9 +734,9 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             self._section_ev["start"].record()
         # a1: (optional) utterance layer-norm + zero pad                                (:506-518)
         if pl.seg is not None:
-            ops.wav_prep_seg(padded, len_dev, pl.wav_pad, pl.seg, pl.spr, a.normalize_wav)
+            ops.wav_prep_seg(padded, len_dev, pl.wav_pad, pl.seg, pl.spr, a.normalize_wav, L=pl.src_L, wav_off=pl.wav_off)
         else:
-            ops.wav_prep(padded, len_dev, pl.wav_pad, a.normalize_wav)
+            ops.wav_prep(padded, len_dev, pl.wav_pad, a.normalize_wav, L=pl.src_L, wav_off=pl.wav_off)
         scale = (D // H) ** -0.5
         train_front = self.frontend is not None      # (also in eval: the frozen copies in self._w are the INITIAL weights)
         if train_front:           # fully trainable encoder: the front end keeps its activations (hubert_frontend_train.py)
@@ -686,7 +762,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             if ln_mode:
                 ops.conv0_layernorm_gelu_seg(pl.wav_pad, seg, pl.spr, w["conv0_w"], w["conv0_bias"], w["conv0_ln_g"], w["conv0_ln_b"], pl.conv[0])
             else:
-                ops.conv0_groupnorm_gelu_seg(padded, pl.len_dev, pl.wav_pad, seg, pl.spr, w["conv0_w"], w["gn_g"], w["gn_b"], pl.T_l[0], pl.conv[0])
+                ops.conv0_groupnorm_gelu_seg(padded, pl.len_dev, pl.wav_pad, seg, pl.spr, w["conv0_w"], w["gn_g"], w["gn_b"], pl.T_l[0], pl.conv[0],
+                                             wav_off=pl.wav_off)
         elif ln_mode:       # large: conv (+bias) -> LayerNorm(512) -> GELU after every layer
             ops.conv0_layernorm_gelu(pl.wav_pad, w["conv0_w"], w["conv0_bias"], w["conv0_ln_g"], w["conv0_ln_b"],
                                      pl.R_l[0], pl.conv[0])
@@ -877,38 +954,57 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
 
     def forward(self, wav: Union[torch.Tensor, list], wav_len: Union[torch.Tensor, list] = [],
                 feat_select_idx: Union[str, list] = None, return_hidden_states: bool = False) -> Tuple:
-        # :539-554.  Fast path: an already padded (B, L) device batch that needs no crop goes to the kernels as is
-        # (sc_wav_prep re-applies the zero padding from wav_len); otherwise un-pad / crop / re-pad like the reference.
+        # :539-554.  A padded (B, width) batch - what collate_general builds and Lightning moves - goes to the kernels AS IS, with or
+        # without the training crop: the two kernels that read it (sc_wav_prep*_crop, sc_conv0_stats_len_crop) take the padded length,
+        # the lengths and the crop offsets and read utterance b from wav[b, off_b : off_b + len_b] in place; the reference's un-pad /
+        # crop / re-pad (:539-552, :506-518) never happens as data movement.  A list of waveforms is padded once.
         crop = self.training and self.max_audio_len >= 0
-        if isinstance(wav, torch.Tensor) and wav.dim() == 2 and not (crop and wav.shape[1] > self.max_audio_len):
-            if isinstance(wav_len, torch.Tensor) and wav_len.is_cuda and wav_len.numel() > 0:
-                # device-resident lengths: not read back (no host synchronisation); the batch's second dimension
-                # is then taken as its padded length (what collate_general produces: padded to the longest utterance)
-                lens = getattr(wav_len, "_sc_host", None) or wav_len
-                L = wav.shape[1] if isinstance(lens, torch.Tensor) else max(lens)
+        host_src, off, ready = None, None, None
+        if isinstance(wav, torch.Tensor) and wav.dim() == 1:
+            wav = wav.unsqueeze(0)
+        if isinstance(wav, torch.Tensor) and wav.dim() == 2:
+            ready = getattr(wav, "_sc_ready", None)
+            width = int(wav.shape[1])
+            lens = None
+            if isinstance(wav_len, torch.Tensor) and wav_len.numel() > 0:
+                lens = getattr(wav_len, "_sc_host", None)            # host twin (data.attach_host_lengths / transfer_batch_to_device)
+                if lens is None:
+                    lens = wav_len if wav_len.is_cuda else [int(l) for l in wav_len.tolist()]
+            elif not isinstance(wav_len, torch.Tensor) and len(wav_len) > 0:
+                lens = [int(l) for l in wav_len]
+            if lens is None:
+                lens = [width] * wav.shape[0]
+            if isinstance(lens, torch.Tensor):
+                # lengths on the DEVICE only (Lightning's transferred batch without a host twin): never read back.  The crop is then
+                # drawn on the device from host uniforms (one per utterance: same distribution as the reference's randint, not the
+                # same stream of draws), the rows keep the uniform pitch of the padded length
+                L = width
+                if crop and width > self.max_audio_len:
+                    l64 = lens.to(device=self._dev, dtype=torch.int64).clamp(min=0, max=width)
+                    uh = torch.empty(wav.shape[0], dtype=torch.float64, pin_memory=self._dev.type == "cuda")
+                    uh.numpy()[:] = np.random.random_sample(wav.shape[0])
+                    u = uh.to(self._dev, non_blocking=True)
+                    room = (l64 - self.max_audio_len).clamp(min=0)
+                    off = torch.minimum((u * room.double()).long(), (room - 1).clamp(min=0)).contiguous()
+                    lens = torch.minimum(l64, torch.full_like(l64, self.max_audio_len))
+                    L = self.max_audio_len
             else:
-                if len(wav_len) > 0:
-                    lens = [int(l) for l in (wav_len.tolist() if isinstance(wav_len, torch.Tensor) else wav_len)]
-                else:
-                    lens = [wav.shape[1]] * wav.shape[0]
-                L = max(lens)
-            host_src = None
+                lens = [min(int(l), width) for l in lens]
+                if crop and max(lens) > self.max_audio_len:
+                    off, lens = crop_windows(lens, self.max_audio_len)
+                L = max(max(lens), 1)
             if not wav.is_cuda and self._dev.type == "cuda":
-                host_src = wav[:, :L]               # copied to the device on the stream the encoder runs on (below)
-                padded = None
+                # copied to the device on the stream the encoder runs on; whole rows (a sliced host view would be staged through a
+                # pageable temporary and block), the kernels read the first L samples / the crop windows
+                host_src, padded = (wav if wav.dtype == torch.float32 else wav.float()), None
             else:
-                padded = wav[:, :L].to(self._dev, torch.float32).contiguous()
+                padded = wav.to(self._dev, torch.float32)
+                if padded.stride(1) != 1:
+                    padded = padded.contiguous()
+                if padded.data_ptr() != wav.data_ptr():
+                    ready = None                       # a fresh tensor produced on the caller's stream just now
         else:
-            host_src = None
-            if isinstance(wav, torch.Tensor):
-                if wav.dim() == 2:
-                    if len(wav_len) > 0:
-                        lens = wav_len.tolist() if isinstance(wav_len, torch.Tensor) else list(wav_len)
-                        wav = [wav[b, : lens[b]] for b in range(len(wav))]
-                    else:
-                        wav = [wav[b] for b in range(len(wav))]
-                elif wav.dim() == 1:
-                    wav = [wav]
+            wav = list(wav)
             if crop:                                                                   # :548-552
                 wav = [random_crop_max_length(wav[b], self.max_audio_len, len(wav[b])) for b in range(len(wav))]
             lens = [len(w) for w in wav]
@@ -931,13 +1027,15 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         want_states = return_hidden_states or (feat_select_idx or self.feat_select_idx) != FEAT_SELECT_IDX_WEIGHTED_SUM_MODE
         # returned hidden states carry every padded row, as the reference's do: that forward runs un-ragged (all B x T frames)
         if ahead and not want_states:
-            pl = self._encode_overlapped(padded, host_src, lens, wav, save)
+            pl = self._encode_overlapped(padded, host_src, lens, ready, save, L=L, off=off)
         else:
             if ahead and self.train_layers is not None and self.before_trainable is not None:
                 self.before_trainable()
             if padded is None:
-                padded = host_src.to(self._dev, torch.float32).contiguous()
-            pl = self._encode(padded, lens, save, ragged=False if want_states else None)
+                padded = host_src.to(self._dev, torch.float32, non_blocking=True)
+            elif isinstance(ready, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(ready)         # a prefetcher's copy-done event
+            pl = self._encode(padded, lens, save, ragged=False if want_states else None, L=L, off=off)
         B, R, T, D = pl.B, pl.R, pl.T, self.arch.embed_dim
         # (without want_states the tuple is only a placeholder: the weighted sum reads the plan's workspace, raw or not, in place)
         hidden_states = self._materialised_states(pl) if want_states else ((None,) * (self.arch.layers + 1) if pl.seg is not None else tuple(

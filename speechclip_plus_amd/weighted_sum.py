@@ -34,6 +34,11 @@ class PaddedFeatHandle:
         # of 64, every row finite, and a few zero rows allocated behind the buffer (the cascaded layout starts one row in)
         self.inplace_ok = bool(getattr(plan, "branch_rows", 0)) and R % 64 == 0 and src.dtype == torch.bfloat16
 
+    def release(self) -> None:
+        """the backward has enqueued its last read of the plan's resident buffers (speech_encoder._Plan.release)"""
+        if self.plan is not None:
+            self.plan.release()
+
     def check_fresh(self) -> None:
         if self.plan is not None and self.plan.generation != self.generation:
             raise RuntimeError("the encoder ran another forward with the same batch geometry before this backward: its hidden "
@@ -98,8 +103,10 @@ class _WeightedSumSrcFn(torch.autograd.Function):
                                "hidden states were overwritten): one outstanding forward per (B, L) plan")
         if not (g.is_contiguous() and g.dtype in (torch.float32, torch.bfloat16)):      # (bf16 rows as the attention block returns them)
             g = g.float().contiguous()
-        return (ops.wsum_bwd_logits(hidden, g, w_soft, B, R, D, 1, normalize=normalize, lazy=ctx.lazy, seg=ctx.seg),
-                None, None, None, None, None, None, None)
+        d_w = ops.wsum_bwd_logits(hidden, g, w_soft, B, R, D, 1, normalize=normalize, lazy=ctx.lazy, seg=ctx.seg)
+        if ctx.plan is not None:
+            ctx.plan.release()               # last read of the plan's resident states by this backward (speech_encoder._claim)
+        return (d_w, None, None, None, None, None, None, None)
 
 
 class WeightedSumLayer(nn.Module):

@@ -412,7 +412,35 @@ def make_cascaded():
         init_weight=bn.bn_layer.weight, init_bias=bn.bn_layer.bias)
 
 
+# --------------------------------------------------------------------------- in-forward training crop
+def make_crop():
+    """random_crop_max_length (avssl/data/audio_transforms.py:5-23) driven exactly as speech_encoder_plus.py:548-552 drives it: a
+    loop over the un-padded utterances under one numpy seed per case.  Each "waveform" holds its own sample indices, so what comes
+    back IS the (offset, length) window the reference cut."""
+    at = load_leaf("avssl/data/audio_transforms.py", "ref_audio_transforms")
+    rs = np.random.RandomState(11)
+    cases = {}
+    for ci, (B, max_len) in enumerate([(8, 102400), (64, 102400), (16, 1000), (5, -1), (12, 4000)]):
+        lens = rs.randint(max(1, abs(max_len) // 3), 3 * abs(max_len), size=B)
+        lens[0] = abs(max_len)                       # exactly at the cap: returned whole, NO draw
+        if B > 2:
+            lens[2] = abs(max_len) + 1               # one over: randint(1) == 0, a draw is consumed
+        seed = 1000 + ci
+        np.random.seed(seed)
+        offs, outl = [], []
+        for b in range(B):
+            w = torch.arange(int(lens[b]))
+            o = at.random_crop_max_length(w, max_len, len(w))
+            offs.append(int(o[0]) if len(o) else 0)
+            outl.append(len(o))
+            assert len(o) == 0 or torch.equal(o, torch.arange(int(o[0]), int(o[0]) + len(o)))
+        after = np.random.randint(1 << 30)           # the generator's state behind the loop: the number of draws is pinned too
+        cases[f"c{ci}_lens"], cases[f"c{ci}_meta"] = lens, np.asarray([B, max_len, seed, after])
+        cases[f"c{ci}_off"], cases[f"c{ci}_out"] = np.asarray(offs), np.asarray(outl)
+    npz("crop.npz", n=np.asarray(5), **cases)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["loss", "head", "mha", "loss_variants", "wsum", "masks", "retrieval", "hubert", "cascaded"]
+    todo = sys.argv[1:] or ["loss", "head", "mha", "loss_variants", "wsum", "masks", "retrieval", "hubert", "cascaded", "crop"]
     for what in todo:                       # e.g. `make_golden.py mha loss_variants` regenerates only those fixtures
         globals()["make_" + what]()

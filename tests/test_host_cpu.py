@@ -178,6 +178,34 @@ def test_audio_transform_like_the_reference_test():
     assert torch.equal(random_crop_max_length(short, 1000), short)                    # shorter than the cap: returned as is
 
 
+def test_crop_windows_draw_the_references_windows(golden):
+    """speech_encoder.crop_windows against tests/golden/crop.npz - the windows avssl/data/audio_transforms.py:5-23 cut when driven
+    as speech_encoder_plus.py:548-552 drives it (make_golden.py crop): same offsets, same lengths, the same NUMBER of draws from
+    numpy's global generator (an utterance at or under the cap draws nothing; one sample over the cap draws randint(1))."""
+    from speechclip_plus_amd.speech_encoder import crop_windows
+    fx = golden("crop.npz")
+    for ci in range(int(fx["n"])):
+        B, max_len, seed, after = (int(v) for v in fx[f"c{ci}_meta"])
+        np.random.seed(seed)
+        off, out = crop_windows(fx[f"c{ci}_lens"].tolist(), max_len)
+        assert off == fx[f"c{ci}_off"].tolist() and out == fx[f"c{ci}_out"].tolist(), ci
+        assert int(np.random.randint(1 << 30)) == after, ci
+        assert all(o + n <= l for o, n, l in zip(off, out, fx[f"c{ci}_lens"].tolist()))
+
+
+def test_host_lengths_travel_with_the_batch():
+    """data.collate_general / attach_host_lengths / transfer_batch_to_device (CPU -> CPU here: the device branch is a -m gpu test):
+    the host twin of wav_len is what keeps the ragged layout and the crop free of device read-backs."""
+    from speechclip_plus_amd.data import attach_host_lengths, collate_general, transfer_batch_to_device
+    rows = [{"wav": torch.randn(n), "id": i} for i, n in enumerate([50, 120, 33])]
+    out = collate_general(rows)
+    assert out["wav_len"]._sc_host == [50, 120, 33]
+    moved = transfer_batch_to_device(out, "cpu")
+    assert moved["wav_len"]._sc_host == [50, 120, 33] and moved["wav"] is out["wav"]
+    t = attach_host_lengths(torch.tensor([3, 4]), [3, 4])
+    assert t._sc_host == [3, 4]
+
+
 def test_recall_eval_generators_draw_the_oracles_streams():
     """tools/recall_eval.py (used by bench.py without the oracle) must generate exactly the weights the fixture was made with."""
     import oracle
