@@ -670,7 +670,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             pl.feat_len = i64[B: 2 * B]
             pl.feat_len._sc_host = list(feat_len)       # host twin (length-derived integers are known before any kernel runs)
             pl.feat_len._sc_p1_i32 = i32[B:]
-            pl.feat_len._sc_target20 = i64[2 * B:]      # (feat_len / 20).round().long(), with its own host twin
+            pl.feat_len._sc_target20 = i64[2 * B: 3 * B]      # (feat_len / 20).round().long(), with its own host twin
             pl.feat_len._sc_target20._sc_host = tgt20
             ints = (i64[:B], i32[:B])
         if _USE_GRAPH:                                   # a captured graph holds the plan's own buffers

@@ -93,10 +93,11 @@ def test_in_forward_crop_equals_the_precropped_batch_bit_for_bit(setup, arrives)
             assert moved["wav_len"].is_cuda and moved["wav_len"]._sc_host == LENS
             f, l = enc_c(moved["wav"], moved["wav_len"])
         elif arrives == "device_lengths_only":
+            wd, ld = batch["wav"].cuda(), batch["wav_len"].cuda().clone()
             torch.cuda.synchronize()
             torch.cuda.set_sync_debug_mode("error")
             try:
-                f, l = enc_c(batch["wav"].cuda(), batch["wav_len"].cuda().clone())
+                f, l = enc_c(wd, ld)
             finally:
                 torch.cuda.set_sync_debug_mode("default")
         else:
