@@ -30,32 +30,49 @@ def attach_host_lengths(wav_len: torch.Tensor, host: Optional[Sequence[int]] = N
 
 def transfer_batch_to_device(batch: dict, device, copy_stream: Optional["torch.cuda.Stream"] = None) -> dict:
     """Body of ``LightningModule.transfer_batch_to_device(batch, device, dataloader_idx)`` for the batch dict of ``collate_general``.
-    Every tensor goes to ``device``; ``wav_len`` keeps a host twin; ``wav`` is copied on ``copy_stream`` (default: the package's
-    shared "h2d" stream) and carries the copy's completion event.  No host synchronisation when ``wav`` is pinned (a pageable
-    waveform is pinned here first: one extra host copy)."""
+    Every tensor goes to ``device``; ``wav_len`` keeps a host twin; EVERY host -> device copy runs on ``copy_stream`` (default: the
+    package's shared "h2d" stream) from pinned memory, and one completion event behind them is (a) attached to ``wav`` - the encoder
+    stream waits for it, a step ahead of the caller's stream - and (b) waited for by the caller's stream, which reads the others.
+
+    Why not ``.to(device, non_blocking=True)`` on the caller's stream: measured on MI355X / ROCm 7.2, a 128 KiB copy - even from pinned
+    memory - queued on a stream that holds a step's worth of kernels blocks the HOST for 1.2-1.8 ms per step (a pageable one likewise),
+    on an idle copy stream it returns in 20 us (tools/h2d_probe3.py).  No host synchronisation in here when the batch is pinned
+    (``collate_general(pin_memory=True)`` / a DataLoader with ``pin_memory=True``); pageable tensors are pinned first (a host copy)."""
     device = torch.device(device)
-    out = {}
-    for k, v in batch.items():
-        if not isinstance(v, torch.Tensor) or v.device == device:
-            out[k] = v
-            continue
-        if k == "wav_len":
-            host = getattr(v, "_sc_host", None) or (v.tolist() if not v.is_cuda else None)
-            d = v.to(device, non_blocking=True)
-            out[k] = attach_host_lengths(d, host) if host is not None else d
-        elif k == "wav" and device.type == "cuda" and not v.is_cuda:
-            from . import ops
-            src = v if v.is_pinned() else v.pin_memory()
-            cs = copy_stream if copy_stream is not None else ops.shared_stream("h2d", device)
-            with torch.cuda.stream(cs):
-                d = src.to(device, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(cs)
-            d._sc_ready = ev
-            d._sc_pinned_src = src           # the pinned source stays alive until the consumer drops the batch
+    if device.type != "cuda":
+        out = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        if isinstance(batch.get("wav_len"), torch.Tensor):
+            host = getattr(batch["wav_len"], "_sc_host", None) or (batch["wav_len"].tolist() if not batch["wav_len"].is_cuda else None)
+            if host is not None:
+                attach_host_lengths(out["wav_len"], host)
+        return out
+    from . import ops
+    cs = copy_stream if copy_stream is not None else ops.shared_stream("h2d", device, priority=-1)
+    main = torch.cuda.current_stream(device)
+    out, moved = {}, []
+    with torch.cuda.stream(cs):
+        for k, v in batch.items():
+            if not isinstance(v, torch.Tensor) or v.device == device:
+                out[k] = v
+                continue
+            src = v
+            if not v.is_cuda and not v.is_pinned():
+                src = v.pin_memory()
+            d = src.to(device, non_blocking=True)
+            if k == "wav_len":
+                host = getattr(v, "_sc_host", None) or (v.tolist() if not v.is_cuda else None)
+                if host is not None:
+                    attach_host_lengths(d, host)
             out[k] = d
-        else:
-            out[k] = v.to(device, non_blocking=True)
+            moved.append(d)
+        ev = torch.cuda.Event()
+        ev.record(cs)
+    if moved:
+        main.wait_event(ev)                    # (enqueued behind the previous step's kernels: the copies are long done by then)
+        for d in moved:
+            d.record_stream(main)
+        if isinstance(out.get("wav"), torch.Tensor) and any(d is out["wav"] for d in moved):
+            out["wav"]._sc_ready = ev
     return out
 
 
@@ -63,6 +80,7 @@ def collate_general(batch: Sequence[dict], pin_memory: bool = False) -> Dict[str
     if len(batch) == 0:
         raise ValueError("empty batch")
     keys: List[str] = list(batch[0].keys())
+    pin = lambda t: bool(pin_memory) and torch.cuda.is_available() and (t is None or not t.is_cuda)     # every tensor of the batch
     derive_len = "wav" in keys and isinstance(batch[0]["wav"], torch.Tensor)
     out: Dict[str, torch.Tensor] = {}
     for k in keys:
@@ -70,16 +88,18 @@ def collate_general(batch: Sequence[dict], pin_memory: bool = False) -> Dict[str
         if isinstance(vals[0], torch.Tensor):
             if k == "wav":
                 L = max(int(v.shape[0]) for v in vals)
-                padded = torch.zeros((len(vals), L) + tuple(vals[0].shape[1:]), dtype=vals[0].dtype,
-                                     pin_memory=bool(pin_memory) and torch.cuda.is_available() and not vals[0].is_cuda,
+                padded = torch.zeros((len(vals), L) + tuple(vals[0].shape[1:]), dtype=vals[0].dtype, pin_memory=pin(vals[0]),
                                      device=vals[0].device)
                 for i, v in enumerate(vals):
                     padded[i, : v.shape[0]] = v
                 out[k] = padded
             else:
                 out[k] = torch.stack(vals, dim=0)
+                if pin(out[k]):
+                    out[k] = out[k].pin_memory()
         else:
-            out[k] = torch.tensor(vals, dtype=torch.long)
+            out[k] = torch.tensor(vals, dtype=torch.long, pin_memory=pin(None))
     if derive_len:
-        out["wav_len"] = attach_host_lengths(torch.tensor([int(row["wav"].shape[0]) for row in batch], dtype=torch.long))
+        out["wav_len"] = attach_host_lengths(torch.tensor([int(row["wav"].shape[0]) for row in batch], dtype=torch.long,
+                                                          pin_memory=pin(None)))
     return out

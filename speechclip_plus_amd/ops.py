@@ -475,7 +475,7 @@ def len_mask(lens: torch.Tensor, n: int, add: int = 0) -> torch.Tensor:
 _shared_streams = {}
 
 
-def shared_stream(name: str, device=None) -> "torch.cuda.Stream":
+def shared_stream(name: str, device=None, priority: int = 0) -> "torch.cuda.Stream":
     """ONE HIP stream per (role, device) and process.  The runtime multiplexes streams onto a handful of hardware queues; two streams
     that land on the same queue run one after the other.  Roles that are meant to run side by side ("encoder", "optimiser",
     "allreduce", "head_aux") therefore keep the streams they got first, instead of every model / trainer instance drawing new ones (the
@@ -485,7 +485,10 @@ def shared_stream(name: str, device=None) -> "torch.cuda.Stream":
     key = (name, idx)
     st = _shared_streams.get(key)
     if st is None:
-        st = _shared_streams[key] = torch.cuda.Stream(device=idx)
+        # priority < 0: a high-priority stream gets a hardware queue of its own priority class - not one of the few normal-priority
+        # queues the other roles share (the "h2d" copy stream: queued on the encoder's hardware queue, a batch's copy would start
+        # only when the encoder in front of it has finished)
+        st = _shared_streams[key] = torch.cuda.Stream(device=idx, priority=priority)
     return st
 
 

@@ -564,13 +564,19 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self._switch = switch if self.train_layers is not None else None
         self._ov = (enc, entry)
         try:
-            with torch.cuda.stream(enc):
-                if host_src is not None:
-                    # (a pinned source: asynchronous; a pageable one blocks the HOST until the encoder stream gets to the copy -
-                    # pin it, data.collate_general / transfer_batch_to_device do)
+            if host_src is not None:
+                # a host batch: copied on the high-priority "h2d" stream (a hardware queue of its own: queued on the encoder's, the
+                # copy would only start when the encoder in front of it has finished), the encoder stream waits for its event.  A pinned
+                # source is asynchronous; a pageable one blocks the HOST for the copy - INTEGRATION.md: pin it
+                # (data.collate_general(pin_memory=True) / transfer_batch_to_device do)
+                cs = ops.shared_stream("h2d", self._dev, priority=-1)
+                with torch.cuda.stream(cs):
                     padded = host_src.to(self._dev, torch.float32, non_blocking=True)
-                else:
-                    padded.record_stream(enc)           # the caller's tensor, read on this stream
+                    copied = torch.cuda.Event()
+                    copied.record(cs)
+                enc.wait_event(copied)
+            with torch.cuda.stream(enc):
+                padded.record_stream(enc)               # the caller's tensor / the copy above, read on this stream
                 pl = self._encode(padded, lens, save, L=L, off=off)
             if not switched:
                 done = torch.cuda.Event()
