@@ -634,6 +634,9 @@ def recall_parity(dev):
     out["set"] = "planted margins (every confusion >= 30 sigma of the bf16 margin noise): parity holds by construction for any bf16-storage implementation"
     if os.path.exists(recall_eval.FIXTURE_NATURAL):       # the same utterances against a gallery with natural margins (nothing planted)
         out["natural_margins"] = recall_eval.natural_margin_report(emb, dict(np.load(recall_eval.FIXTURE_NATURAL)))
+        second = recall_eval.FIXTURE_NATURAL.replace(".npz", "_b.npz")      # gallery B: same construction, another noise seed (round 5)
+        if os.path.exists(second):
+            out["natural_margins_gallery_b"] = recall_eval.natural_margin_report(emb, dict(np.load(second)))
     return out
 
 

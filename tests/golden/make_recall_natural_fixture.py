@@ -38,8 +38,15 @@ def main():
     ap.add_argument("--ids", type=int, default=1000)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--cache", default=None, help="directory with / for new_fp32.npy, new_emu.npy (raw embeddings of the two references)")
-    ap.add_argument("--out", default=os.path.join(HERE, "recall_eval_natural.npz"))
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--seed", type=int, default=None, help="seed of the gallery's isotropic noise (default: recall_eval.natural_gallery's own, "
+                    "gallery A = recall_eval_natural.npz).  Round 5: --seed 20261005 = gallery B (recall_eval_natural_b.npz), drawn AFTER the "
+                    "acceptance criterion of tests/test_gpu_recall.py::test_recall_on_natural_margins was written down")
     args = ap.parse_args()
+    suffix = "" if args.seed is None else "_b"
+    if args.out is None:
+        args.out = os.path.join(HERE, f"recall_eval_natural{suffix}.npz")
+    gkw = {} if args.seed is None else {"seed": args.seed}
     torch.set_num_threads(args.threads)
     wavs, ids = eval_set(args.ids)
     e32 = oracle_embeddings("fp32", wavs, args.cache)
@@ -50,10 +57,10 @@ def main():
     lo, hi = 0.0, 8.0
     for _ in range(24):
         s = 0.5 * (lo + hi)
-        r1 = recalls(rank_stats(a32, natural_gallery(a32, ids, args.ids, s), ids)["rank_ai"])[0]
+        r1 = recalls(rank_stats(a32, natural_gallery(a32, ids, args.ids, s, **gkw), ids)["rank_ai"])[0]
         lo, hi = (s, hi) if r1 > 50.0 else (lo, s)
     s = 0.5 * (lo + hi)
-    image = natural_gallery(a32, ids, args.ids, s)
+    image = natural_gallery(a32, ids, args.ids, s, **gkw)
     s32, sem = rank_stats(a32, image, ids), rank_stats(aem, image, ids)
     held = (torch.arange(len(ids)) % PER_ID) >= GALLERY
     noise_ai = (sem["own"].unsqueeze(1) - sem["scores"].gather(1, s32["kth_idx"])) - s32["margin_ai"]
@@ -80,7 +87,7 @@ def main():
                   if ((s32["rank_ia"] < k) != (sem["rank_ia"] < k)).any() else 0.0) for i, k in enumerate((1, 5, 10))],
     }
     print(json.dumps(summary, indent=1))
-    json.dump(summary, open(os.path.join(HERE, "recall_eval_natural_margins.json"), "w"), indent=1)
+    json.dump(summary, open(os.path.join(HERE, f"recall_eval_natural{suffix}_margins.json"), "w"), indent=1)
     np.savez_compressed(
         args.out, image=image.numpy(), n_ids=np.int64(args.ids), batch=np.int64(BATCH), gallery=np.int64(GALLERY), noise_level=np.float64(s),
         rank_ai_fp32=s32["rank_ai"].numpy().astype(np.int16), rank_ia_fp32=s32["rank_ia"].numpy().astype(np.int16),

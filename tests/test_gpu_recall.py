@@ -39,35 +39,53 @@ def hip_emb():
     return model, recall_eval.hip_embeddings(model, 1000, recall_eval.BATCH)
 
 
-def test_recall_on_natural_margins(golden, hip_emb):
+def _same_rate(n_a: int, n_b: int, z: float = 3.0) -> bool:
+    """Two counts of rare events as two draws from Poisson distributions with ONE rate (the conditional test: given n_a + n_b = N,
+    n_a ~ Binomial(N, 1/2), standard deviation sqrt(N) / 2, so |n_a - n_b| = 2 |n_a - N / 2| <= z sqrt(N))."""
+    return abs(n_a - n_b) <= z * (n_a + n_b) ** 0.5
+
+
+@pytest.mark.parametrize("gallery", ["recall_eval_natural.npz", "recall_eval_natural_b.npz"])
+def test_recall_on_natural_margins(golden, hip_emb, gallery):
     """Round 4: the same utterances against a gallery with NATURAL margins - class centre +
     isotropic noise, nothing planted, fp32 recall@1 = 50.02 %, 14.8 % of the rank-1 decisions within 3 sigma of the margin noise that
     bf16 STORAGE alone causes (the bf16-emulated oracle flips 79 / 66 / 61 of the 5000 rank-1 / 5 / 10 decisions against fp32).  On such
-    a set no bf16 implementation can match recall@1 to 0.1; what is required instead:
-      * every decision the HIP model takes differently from the fp32 oracle sits at an fp32 margin below 4 sigma of the emulation's
-        margin noise (the emulation's own flips reach 2.1 sigma) - a flip at a resolvable margin would be a defect;
-      * the HIP model flips no more decisions against the emulated oracle than the emulated oracle flips against fp32, x 1.25
-        (+ 3 for the small image -> audio counts);
-      * the recalls themselves stay within the band those flip counts allow."""
+    a set no bf16 implementation can match recall@1 to 0.1.
+
+    Acceptance criterion, PRE-REGISTERED in round 5.  History, so that nobody has to dig for it: round 4's first
+    bound on the HIP-vs-fp32 flip counts, max(1.25 emu, emu + 3), failed on the GPU at image -> audio @5 (16 flips, emulation 12) and
+    was replaced two minutes later by 1.25 emu + 2 sqrt(emu), a bound fitted to that one observation.  Both are gone.  The model:
+      * a rank decision flips when the implementation's margin noise exceeds the fp32 margin; over thousands of decisions with
+        independent margins the number of flips of ONE bf16-storage implementation against fp32 is Poisson with a rate lambda that
+        depends on the storage format (where values are rounded), not on the summation order;
+      * the bf16-storage-emulated oracle and the HIP model are two such implementations: their flip counts against fp32, n_emu and
+        n_hip, are two draws with one rate.  Whether two Poisson counts share a rate is the conditional binomial test:
+        |n_hip - n_emu| <= z sqrt(n_hip + n_emu); z = 3 (two-sided p = 0.0027 per comparison, 12 comparisons per gallery);
+      * a flip at a RESOLVABLE margin is a defect whatever the counts say: every decision the HIP model takes differently from fp32
+        must sit at an fp32 margin below 4 sigma of the emulation's margin noise (the emulation's own flips reach 2.3 sigma);
+      * against the EMULATED oracle the HIP model differs by summation order only - fewer flips than the emulation has against
+        fp32: n_hip_vs_emu <= n_emu (+ the same z sqrt allowance);
+      * the recalls themselves stay within the band the flip counts allow.
+    Gallery A (recall_eval_natural.npz) is the one round 4 looked at: (16, 12) passes the test with |4| <= 15.9, which is no
+    evidence by itself.  Gallery B (recall_eval_natural_b.npz: the same construction, noise seed 20261005) was generated and this
+    criterion committed BEFORE the HIP model was ever scored on it (git history: the fixture and this text precede the first GPU
+    run).  A future red run is answered in the code or in a written derivation committed before any new bound - not by editing z."""
     import recall_eval
     model, emb = hip_emb
-    fx = golden("recall_eval_natural.npz")
+    fx = golden(gallery)
     r = recall_eval.natural_margin_report(emb, fx)
-    print("natural-margin recall:", r)
+    print("natural-margin recall", gallery, r)
     assert r["queries"] == 5000 and r["images"] == 1000
+    n = {"audio_to_image": 5000, "image_to_audio": 1000}
     for d in ("audio_to_image", "image_to_audio"):
         assert max(r["largest_fp32_margin_of_a_flip_in_sigma"][d]) < 4.0, r["largest_fp32_margin_of_a_flip_in_sigma"]
         for k in range(3):
             emu = r["emulation_flips_vs_fp32"][d][k]
-            mine = r["oracle_bf16emu"]["rank_flips_" + d][k]
-            assert mine <= max(1.25 * emu, emu + 3), (d, k, mine, emu)
-            # against fp32 the HIP model is one more bf16-storage implementation: as many flips as the emulation, up to the counting
-            # noise of two independent draws (2 sqrt(n): the image -> audio counts are 5 .. 12)
-            assert r["oracle_fp32"]["rank_flips_" + d][k] <= 1.25 * emu + 2.0 * emu ** 0.5, (d, k, r["oracle_fp32"], emu)
-    n = {"audio_to_image": 5000, "image_to_audio": 1000}
-    for d in ("audio_to_image", "image_to_audio"):
-        for k in range(3):
-            band = 100.0 * r["oracle_fp32"]["rank_flips_" + d][k] / n[d]
+            vs_fp32 = r["oracle_fp32"]["rank_flips_" + d][k]
+            vs_emu = r["oracle_bf16emu"]["rank_flips_" + d][k]
+            assert _same_rate(vs_fp32, emu), (gallery, d, k, vs_fp32, emu)
+            assert vs_emu <= emu + 3.0 * (vs_emu + emu) ** 0.5, (gallery, d, k, vs_emu, emu)
+            band = 100.0 * vs_fp32 / n[d]
             assert abs(r["hip"][d][k] - r["oracle_fp32"][d][k]) <= band + 1e-9
 
 

@@ -265,15 +265,16 @@ def test_bench_host_helpers():
     assert abs(same["alg_gflop_per_utt"] - full["alg_gflop_per_utt"]) < 1e-6
 
 
-def test_natural_margin_recall_fixture_is_consistent():
-    """tests/golden/recall_eval_natural.npz (make_recall_natural_fixture.py): the stored ranks give the recalls of its summary, the
-    gallery is unit-norm and orthogonal to nothing planted (role-free), and the report code reproduces the emulation's own flip counts
-    when it is fed the fixture's references."""
+@pytest.mark.parametrize("suffix", ["", "_b"])
+def test_natural_margin_recall_fixture_is_consistent(suffix):
+    """tests/golden/recall_eval_natural{,_b}.npz (make_recall_natural_fixture.py; _b = gallery B of round 5, another noise seed): the
+    stored ranks give the recalls of its summary, the gallery is unit-norm and orthogonal to nothing planted (role-free), and the
+    report code reproduces the emulation's own flip counts when it is fed the fixture's references."""
     import json
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import recall_eval
-    fx = dict(np.load(recall_eval.FIXTURE_NATURAL))
-    summ = json.load(open(os.path.join(ROOT, "tests", "golden", "recall_eval_natural_margins.json")))
+    fx = dict(np.load(recall_eval.FIXTURE_NATURAL.replace(".npz", suffix + ".npz")))
+    summ = json.load(open(os.path.join(ROOT, "tests", "golden", f"recall_eval_natural{suffix}_margins.json")))
     r32, rem = torch.from_numpy(fx["rank_ai_fp32"]).long(), torch.from_numpy(fx["rank_ai_bf16emu"]).long()
     assert recall_eval.recalls(r32) == summ["fp32"]["audio_to_image"] and recall_eval.recalls(rem) == summ["bf16emu"]["audio_to_image"]
     assert 45.0 < summ["fp32"]["audio_to_image"][0] < 55.0                       # natural margins: recall@1 tuned to ~50 %
