@@ -423,3 +423,47 @@ def test_cif_reads_the_attention_rows_in_place_like_the_tensor_path(kind):
     assert g0.keys() == g1.keys()
     for n in g0:
         assert rel(g0[n], g1[n]) < 1e-2, (n, rel(g0[n], g1[n]))
+
+
+@pytest.mark.parametrize("kind", ["parallel_base", "cascaded_base"])
+def test_overlapped_schedule_equals_the_one_stream_schedule_at_full_size(kind):
+    """the encoder-under-the-previous-tail schedule at the size it is USED at - B = 64 x 10 s, the real 12-layer
+    encoder (12 ms of kernels on the encoder stream beside ~300 tail launches on the caller's, shared per-stream workspaces, two
+    alternating 7 GB plans), four steps over DIFFERENT ragged batches (the row layout changes every step), every dropout site live
+    (the masks are functions of torch's seed and host-side call counters, so both schedules draw the same ones).  Losses, parameters and
+    the last gradients of ``enc_overlap = True`` must equal ``enc_overlap = False`` bit for bit (the toy-size version of this is
+    tests/test_gpu_model.py::test_encoder_on_its_own_stream_under_the_previous_steps_tail; one train step = kwClip.py:145-193)."""
+    from speechclip_plus_amd import KWClip_GeneralTransformer, base_parallel_config, cascaded_plus_base_config, mha_block, ops
+    from speechclip_plus_amd.train import ContrastiveTrainer
+    B, L = 64, 160000
+    g = torch.Generator().manual_seed(17)
+    batches = []
+    for i in range(4):
+        wav = torch.randn(B, L, generator=g)
+        lens = torch.randint(32000, L + 1, (B,), generator=g)
+        lens[i] = L
+        wav = (wav * (torch.arange(L)[None] < lens[:, None])).cuda()
+        batches.append({"wav": wav, "wav_len": lens, "image": F.normalize(torch.randn(B, 512, generator=g), dim=-1).cuda(),
+                        "id": (torch.arange(B) // 5).cuda()})
+    torch.cuda.synchronize()
+    for b in batches:
+        b["wav"]._sc_ready = True                  # resident inputs: the encoder stream runs a step ahead
+    finals = []
+    for overlap in (False, True):
+        torch.manual_seed(7122)
+        ops._mult_calls[0] = 0
+        mha_block._calls = 0
+        cfg = base_parallel_config() if kind == "parallel_base" else cascaded_plus_base_config()
+        cfg.audio_encoder.max_audio_len = -1
+        model = KWClip_GeneralTransformer(cfg, device="cuda:0").train()
+        model.audio_encoder.enc_overlap = overlap
+        trainer = ContrastiveTrainer(model)
+        losses = [float(trainer.step(b)) for b in batches]
+        torch.cuda.synchronize()
+        assert (model.audio_encoder._enc_stream is not None) == overlap
+        finals.append((losses, trainer.opt.flat_p.clone(), trainer.opt.flat_g.clone()))
+        del trainer, model
+        torch.cuda.empty_cache()
+    assert finals[0][0] == finals[1][0], (finals[0][0], finals[1][0])
+    assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
+    assert all(l == l for l in finals[0][0]) and len(set(finals[0][0])) == len(batches)
