@@ -25,7 +25,10 @@ import os
 import sys
 import time
 
-import torch
+# before the HIP runtime initialises (inherited by the ranks torch.distributed.run starts): see speechclip_plus_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

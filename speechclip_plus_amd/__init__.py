@@ -1,5 +1,14 @@
 """speechclip_plus_amd: MI355X-native contrastive hot path of SpeechCLIP+ (HuBERT encoder -> CLS attention
 pooling head -> speech<->image InfoNCE), behind the reference's module API.  See DESIGN.md."""
+import os as _os
+
+# The step runs on several HIP streams side by side (caller's, "encoder", "optimiser", "head_aux", "h2d", "allreduce" + RCCL's own).
+# The runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue run one after the
+# other: measured on MI355X / ROCm 7.2 with a (one-rank) RCCL world the encoder-under-the-previous-tail overlap disappears at the
+# default (13.34 vs 13.13 ms one-stream) and is back at 8 queues (12.60 ms; without RCCL 12.55 vs 12.61: no cost).  The variable is read
+# when the HIP runtime initialises (first device call, not `import torch`), so it is set here unless the user chose a value.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .config import load_config
 from .model import (Config, KWClip_GeneralTransformer, base_parallel_config, cascaded_plus_base_config,
                     hybrid_plus_large_config, large_parallel_config, set_dropout)
