@@ -258,6 +258,9 @@ def make_workload(kind, B, L, ragged, rank, dev, unfreeze=0, trainable=False, no
     cfg = {"base": base_parallel_config, "large": large_parallel_config, "cascaded_plus": cascaded_plus_base_config,
            "hybrid_plus_large": hybrid_plus_large_config}[kind]()
     E = int(cfg.clip.embed_dim)
+    # every timed "step" here is one optimiser step over B utterances (hybrid+ large's yaml accumulates 2 micro-batches of 128 per
+    # optimiser step: tests/test_gpu_recipes.py::test_hybrid_plus_large_at_the_recipe_batch_of_128_with_accumulation)
+    cfg.trainer.accumulate_grad_batches = 1
     # -1: the batch is given at its length (no second crop inside the model); 102400 (every shipped yaml): the reference's training
     # entry - full utterances in, random 6.4 s crop inside the encoder forward (recipes.train_crop_in_forward)
     cfg.audio_encoder.max_audio_len = max_audio_len

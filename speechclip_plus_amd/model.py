@@ -36,8 +36,10 @@ def _cif_args(d: int) -> dict:
 
 
 def cascaded_plus_base_config(**overrides) -> Config:
-    """config/speechCLIP+/model_base/spchclip_c+.yaml (BASELINE configs[2]) restricted to the keys the path reads."""
+    """config/speechCLIP+/model_base/spchclip_c+.yaml (BASELINE configs[2]) restricted to the keys the path reads
+    (tests/test_host_cpu.py::test_builtin_configs_equal_the_reference_yamls holds every one of them against the yaml)."""
     cfg = base_parallel_config()
+    cfg.audio_encoder.name = "hubert_base"
     ms = cfg.model_settings
     ms.cascaded_objective_weight, ms.parallel_objective_weight = 1.0, 0.0
     ms.cascaded_branch = Config({
@@ -59,8 +61,13 @@ def cascaded_plus_base_config(**overrides) -> Config:
 
 
 def hybrid_plus_large_config(**overrides) -> Config:
-    """config/speechCLIP+/model_large/coco/spchclip_h+.yaml (BASELINE configs[4]) restricted to the keys the path reads."""
+    """config/speechCLIP+/model_large/coco/spchclip_h+.yaml (BASELINE configs[4]) restricted to the keys the path reads.  Unlike the
+    PARALLEL large recipe this yaml has no ``normalize_hiddenstates`` key: the reference default applies (False,
+    speech_encoder_plus.py:350) - round 4 inherited True from large_parallel_config; and the recipe accumulates
+    two micro-batches per optimiser step (``trainer.accumulate_grad_batches: 2``, :138)."""
     cfg = large_parallel_config()
+    cfg.audio_encoder.normalize_hiddenstates = False
+    cfg.trainer.accumulate_grad_batches = 2
     ms = cfg.model_settings
     ms.cascaded_objective_weight, ms.parallel_objective_weight = 1.0, 1.0
     ms.cascaded_branch = Config({
@@ -90,6 +97,7 @@ def large_parallel_config(**overrides) -> Config:
     cfg.clip = Config({"name": "ViT-L/14", "embed_dim": 768})
     cfg.audio_encoder.name = "hubert_large_ll60k"
     cfg.audio_encoder.normalize_hiddenstates = True
+    cfg.cl_loss.args.temperature_trainable = True
     for k, v in overrides.items():
         cfg[k] = v
     return cfg

@@ -499,6 +499,10 @@ def grad_target(p):
     g = getattr(p, "grad", None)
     if g is None or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
         return None
+    # ONLY the optimiser's own flat gradient buffer (optim.FlatAdam tags the views it hands out): adding into any other .grad would
+    # bypass tensor / post-accumulate-grad hooks and write .grad under torch.autograd.grad, which must not touch it
+    if not getattr(g, "_sc_flat", False):
+        return None
     return g if (g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device) else None
 
 

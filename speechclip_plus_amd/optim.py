@@ -67,6 +67,7 @@ class FlatAdam:
             self.flat_p[off: off + k].copy_(p.data.reshape(-1).float())
             p.data = self.flat_p[off: off + k].view_as(p.data)        # parameters now alias the flat buffer
             p.grad = self.flat_g[off: off + k].view_as(p.data)        # autograd accumulates in place
+            p.grad._sc_flat = True                                    # ops.grad_target: kernels may add into THIS buffer directly
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
@@ -88,6 +89,7 @@ class FlatAdam:
             k = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off: off + k].view_as(p.data)
+                p.grad._sc_flat = True
 
     def step(self, lr: Optional[float] = None) -> None:
         self.step_count += 1
@@ -123,8 +125,11 @@ class FlatAdamOptimizer(torch.optim.Optimizer):
     # reference uses, resumes exactly).
     def state_dict(self):
         sd = super().state_dict()
+        # ``offsets`` / ``numels``: where each parameter's moments sit in m / v.  The layout is an implementation detail (round 4 moved
+        # every parameter to a 16-byte boundary), so a checkpoint carries its own and load_state_dict re-packs when they differ
         sd["flat_adam"] = {"m": self.flat.m.detach().clone(), "v": self.flat.v.detach().clone(),
-                           "step_count": int(self.flat.step_count), "numel": int(self.flat.size)}
+                           "step_count": int(self.flat.step_count), "numel": int(self.flat.size),
+                           "offsets": [int(o) for o in self.flat.offsets], "numels": [int(p.numel()) for p in self.flat.params]}
         return sd
 
     def load_state_dict(self, state_dict):
@@ -132,11 +137,29 @@ class FlatAdamOptimizer(torch.optim.Optimizer):
         fa = state_dict.pop("flat_adam", None)
         if fa is None:
             raise KeyError("optimizer state has no 'flat_adam' entry (not saved by FlatAdamOptimizer.state_dict)")
-        if int(fa["numel"]) != self.flat.size:
-            raise ValueError(f"optimizer state holds {int(fa['numel'])} elements, this optimizer's buffers {self.flat.size}")
+        mine = [int(p.numel()) for p in self.flat.params]
+        numels = [int(n) for n in fa["numels"]] if "numels" in fa else None
+        if numels is None and int(fa["numel"]) == sum(mine) and int(fa["numel"]) != self.flat.size:
+            # a checkpoint from before the 16-byte aligned layout (rounds 1-3): parameters back to back, 'numel' = their total
+            numels, offs = mine, [sum(mine[:i]) for i in range(len(mine))]
+        elif numels is not None:
+            offs = [int(o) for o in fa["offsets"]]
+        else:
+            offs = None
+        if numels is not None and numels != mine:
+            raise ValueError(f"optimizer state was saved for parameters of {numels} elements, this optimizer manages {mine}")
+        if numels is None and int(fa["numel"]) != self.flat.size:
+            raise ValueError(f"optimizer state holds {int(fa['numel'])} elements in an unrecorded layout, this optimizer's buffers "
+                             f"{self.flat.size}: re-save it with this version (state_dict now records offsets / numels)")
         super().load_state_dict(state_dict)
-        self.flat.m.copy_(fa["m"])
-        self.flat.v.copy_(fa["v"])
+        if offs is None or offs == [int(o) for o in self.flat.offsets]:
+            self.flat.m.copy_(fa["m"])
+            self.flat.v.copy_(fa["v"])
+        else:                                          # another layout: moments move parameter by parameter (padding stays zero)
+            for buf, src in ((self.flat.m, fa["m"]), (self.flat.v, fa["v"])):
+                buf.zero_()
+                for n, o_src, o_dst in zip(numels, offs, self.flat.offsets):
+                    buf[o_dst: o_dst + n].copy_(src[o_src: o_src + n])
         self.flat.step_count = int(fa["step_count"])
 
 

@@ -92,7 +92,7 @@ def test_plus_recipe_train_step_vs_oracle_at_full_dims(kind):
 
     def run(forced):
         aux = {}
-        feat = oracle.weighted_sum(ws_w, [h.detach() for h in hs], large)
+        feat = oracle.weighted_sum(ws_w, [h.detach() for h in hs], bool(model.audio_encoder.normalize_hiddenstates))
         res = fwd(W, feat, fl, forced_tokens=forced, aux=aux, **kw)
         return res, aux
 
@@ -222,6 +222,7 @@ def test_hybrid_plus_large_full_size_properties():
     torch.manual_seed(7122)
     cfg = hybrid_plus_large_config()
     cfg.audio_encoder.max_audio_len = -1
+    cfg.trainer.accumulate_grad_batches = 1        # (the yaml's 2 is the test below: here one step = one optimiser step)
     model = KWClip_GeneralTransformer(cfg, device="cuda:0").eval()
     assert model.audio_encoder.arch.layers == 24 and model.audio_encoder.arch.embed_dim == 1024
     B, L, E = 64, 160000, int(cfg.clip.embed_dim)

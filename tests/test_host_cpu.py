@@ -248,6 +248,44 @@ audio_encoder: {type: FairseqHubert, name: hubert_large_ll60k, trainable: false,
         assert c.clip.embed_dim in (512, 768)
 
 
+def test_builtin_configs_equal_the_reference_yamls():
+    """every built-in recipe against load_config(<the reference's yaml>) on EVERY key the built-in holds (= the
+    keys the path reads).  A key the yaml does not have must carry the reference's default, listed here with its source.  Runs in
+    the build container only (the yamls do not travel)."""
+    from speechclip_plus_amd import (base_parallel_config, cascaded_plus_base_config, hybrid_plus_large_config, large_parallel_config,
+                                     load_config)
+    ref = "/root/reference/config"
+    if not os.path.isdir(ref):
+        pytest.skip("the reference's yaml recipes exist in the build container only")
+    defaults = {"audio_encoder.normalize_hiddenstates": False,                 # speech_encoder_plus.py:350
+                "model_settings.parallel_branch.need_projection": True,       # the plus yamls do not configure a separate parallel head:
+                "model_settings.parallel_branch.transformer_type": "TransformerEncoder",    # inherited, unused (hybrid's CLS row shares the block)
+                "trainer.accumulate_grad_batches": 1}                         # pytorch_lightning.Trainer default
+
+    def flat(c, pre=""):
+        out = {}
+        for k, v in c.items():
+            if hasattr(v, "items"):
+                out.update(flat(v, pre + k + "."))
+            else:
+                out[pre + k] = v
+        return out
+
+    for builtin, rel in ((base_parallel_config(), "speechCLIP/model_base/spchclp_p.yaml"),
+                         (large_parallel_config(), "speechCLIP/model_large/flickr/spchclp_p.yaml"),
+                         (cascaded_plus_base_config(), "speechCLIP+/model_base/spchclip_c+.yaml"),
+                         (hybrid_plus_large_config(), "speechCLIP+/model_large/coco/spchclip_h+.yaml")):
+        fy = flat(load_config(os.path.join(ref, rel), reference_root="/root/reference", allow_synthetic_vocab=True))
+        for k, v in flat(builtin).items():
+            if isinstance(v, torch.Tensor):                                    # the reduced vocabulary: same size as the yaml's table
+                table = np.load(fy[k]) if isinstance(fy[k], str) else fy[k]
+                assert v.numel() == len(table), (rel, k, v.numel(), len(table))
+            elif k in fy:
+                assert v == fy[k], (rel, k, v, fy[k])
+            else:
+                assert k in defaults and v == defaults[k], (rel, k, v, "not in the yaml and not a documented default")
+
+
 def test_bench_host_helpers():
     """bench.py's host-side accounting: physical cores are counted from /proc/cpuinfo, and the algorithmic flops of a ragged batch
     count every utterance at its own length (padding is not achieved work)."""
@@ -311,3 +349,34 @@ def test_flat_optimiser_layout_is_16_byte_aligned():
     opt.zero_grad()
     assert params[2].grad.data_ptr() == opt.flat_g.data_ptr() + 4 * opt.offsets[2]
 
+    assert all(getattr(p.grad, "_sc_flat", False) for p in params)                    # ops.grad_target adds only into these
+
+
+def test_flat_optimiser_checkpoint_carries_its_layout():
+    """the optimiser state records where every parameter's moments sit (offsets / numels) and load_state_dict re-packs a
+    checkpoint written in another layout - the back-to-back layout of rounds 1-3 ('numel' = the parameters' total, no offsets) and
+    any future one - instead of refusing it; a state for other parameter sizes is still refused."""
+    from speechclip_plus_amd.optim import FlatAdamOptimizer
+    shapes = [(13,), (8, 6), (1,), (3, 5)]
+    mk = lambda: [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+    a = FlatAdamOptimizer(mk(), lr=1e-3)
+    g = torch.Generator().manual_seed(0)
+    a.flat.m.copy_(torch.randn(a.flat.size, generator=g))
+    a.flat.v.copy_(torch.rand(a.flat.size, generator=g))
+    a.flat.step_count = 7
+    sd = a.state_dict()
+    assert sd["flat_adam"]["offsets"] == [int(o) for o in a.flat.offsets] and sd["flat_adam"]["numels"] == [13, 48, 1, 15]
+    b = FlatAdamOptimizer(mk(), lr=1e-3)
+    b.load_state_dict(sd)
+    assert torch.equal(b.flat.m, a.flat.m) and torch.equal(b.flat.v, a.flat.v) and b.flat.step_count == 7
+    # the old layout: moments back to back, no offsets in the entry
+    dense = lambda buf: torch.cat([buf[o: o + n] for o, n in zip(a.flat.offsets, sd["flat_adam"]["numels"])])
+    old = dict(sd)
+    old["flat_adam"] = {"m": dense(a.flat.m), "v": dense(a.flat.v), "step_count": 7, "numel": 77}
+    c = FlatAdamOptimizer(mk(), lr=1e-3)
+    c.load_state_dict(old)
+    for o, n in zip(c.flat.offsets, [13, 48, 1, 15]):
+        assert torch.equal(c.flat.m[o: o + n], a.flat.m[o: o + n]) and torch.equal(c.flat.v[o: o + n], a.flat.v[o: o + n])
+    other = FlatAdamOptimizer([torch.nn.Parameter(torch.zeros(5))], lr=1e-3)
+    with pytest.raises(ValueError):
+        other.load_state_dict(sd)

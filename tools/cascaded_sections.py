@@ -11,6 +11,7 @@ from speechclip_plus_amd.train import ContrastiveTrainer
 name = sys.argv[1] if len(sys.argv) > 1 else "cascaded_plus"
 large = name == "hybrid_plus_large"
 cfg = (hybrid_plus_large_config if large else cascaded_plus_base_config)()
+cfg.trainer.accumulate_grad_batches = 1
 cfg.audio_encoder.max_audio_len = -1
 sd = random_hubert_state_dict(ARCHS["hubert_large_ll60k" if large else "hubert"], seed=7122)
 torch.manual_seed(0)
