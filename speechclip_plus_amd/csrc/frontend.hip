@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
                 f32x2 a = f32x2{0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 10; ++j) a = __builtin_elementwise_fma(w[i][j], f32x2{v[j], v[j]}, a);
-                const f32x2 g = gelu_erf2(__builtin_elementwise_fma(a, sc[i], sh[i]));
+                const f32x2 u_ = __builtin_elementwise_fma(a, sc[i], sh[i]);
+                const f32x2 g = F32OUT ? gelu_erf2(u_) : gelu_bf2(u_);      // (fp32 debug mode: the 3e-7 form)
                 o[2 * i] = g.x;
                 o[2 * i + 1] = g.y;
             }
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; i += 2) {
-            const f32x2 g = gelu_erf2(f32x2{(a[i] - mean) * rstd * gm[i] + bt[i], (a[i + 1] - mean) * rstd * gm[i + 1] + bt[i + 1]});
+            const f32x2 u_ = f32x2{(a[i] - mean) * rstd * gm[i] + bt[i], (a[i + 1] - mean) * rstd * gm[i + 1] + bt[i + 1]};
+            const f32x2 g = F32OUT ? gelu_erf2(u_) : gelu_bf2(u_);
             o[i] = g.x;
             o[i + 1] = g.y;
         }

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
             const int ml = wm * TM + mi * 16 + 4 * (lane >> 4);
             f32x4 v = acc[mi][ni];
             if (p.act == 1 && p.aux_mode == 0) {
-                const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+                const f32x2 g0 = gelu_bf2(f32x2{v[0], v[1]}), g1 = gelu_bf2(f32x2{v[2], v[3]});
                 v = f32x4{g0.x, g0.y, g1.x, g1.y};
             }
             if (transposed) {

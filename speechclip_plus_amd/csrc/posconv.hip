@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void posconv_kernel(const uint16_t* __rest
 #pragma unroll
         for (int ni = 0; ni < FN; ++ni) {
             const f32x4 v = acc[mi][ni];
-            const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+            const f32x2 g0 = gelu_bf2(f32x2{v[0], v[1]}), g1 = gelu_bf2(f32x2{v[2], v[3]});
             float r0 = g0.x, r1 = g0.y, r2 = g1.x, r3 = g1.y;
             if (res) {
                 const uint2 rv = *(const uint2*)(res + o + ni * 16);

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bt[j];
             if (act == 1) {
-                const f32x2 g0 = gelu_erf2(f32x2{o[0], o[1]}), g1 = gelu_erf2(f32x2{o[2], o[3]});
+                const f32x2 g0 = gelu_bf2(f32x2{o[0], o[1]}), g1 = gelu_bf2(f32x2{o[2], o[3]});
                 o[0] = g0.x; o[1] = g0.y; o[2] = g1.x; o[3] = g1.y;
             }
             uint2 w;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const uint16_t* __rest
             if (act == 1) {
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    const f32x2 gg = gelu_erf2(f32x2{o[j], o[j + 1]});
+                    const f32x2 gg = gelu_bf2(f32x2{o[j], o[j + 1]});
                     o[j] = gg.x; o[j + 1] = gg.y;
                 }
             }

@@ -79,9 +79,24 @@ __device__ __forceinline__ float gelu_grad_as(float x) {
     return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
 }
 
+// scalar twin of gelu_bf2 (below): the same operations in the same order => the same bits (the bf16-output sites' erf-GELU)
+__device__ __forceinline__ float gelu_bf(float x) {
+#ifdef SC_GELU_EXACT
+    return gelu_erf(x);
+#else
+#pragma clang fp contract(off)
+    const float t = fminf(x * x, 64.f);
+    float p = fmaf(0.0010142630198970437f, t, -0.10677572339773178f);
+    p = fmaf(p, t, -2.301121234893799f);
+    const float w = p * x;
+    const float d = __builtin_amdgcn_exp2f(w) + 1.0f;
+    return x * __builtin_amdgcn_rcpf(d);
+#endif
+}
+
 // activation codes of sc_act_bf16 / sc_gemm_args.act: 1 = erf-GELU (fairseq FFN), 2 = QuickGELU (CLIP MLP)
 __device__ __forceinline__ float act_fwd(float u, int act) {
-    if (act == 1) return gelu_erf(u);
+    if (act == 1) return gelu_bf(u);
     const float sg = 1.f / (1.f + __expf(-1.702f * u));            // QuickGELU (CLIP): u * sigmoid(1.702 u)
     return u * sg;
 }
@@ -115,6 +130,36 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     r.x = __builtin_amdgcn_rcpf(p.x); r.y = __builtin_amdgcn_rcpf(p.y);
     const f32x2 h = x * 0.5f, ah = ax * 0.5f;
     return __builtin_elementwise_fma(-ah, r, h + ah);
+}
+
+// The erf-GELU of the bf16-OUTPUT sites (GEMM epilogues of FC1 / the conv stack, conv layer 0, pos_conv, LayerNorm + GELU rows), round 5:
+//     gelu(x) ~ x * sigmoid(x (c1 + c3 t + c5 t^2)),  t = min(x^2, 64),  c = (1.59501577, 7.40112920e-2, -7.03033580e-4)
+// - the logistic approximation of the normal CDF with one more odd term, coefficients fitted (minimax on |x Phi(x) - approx| over
+// [-12, 12], tools/fit_gelu.py) - in fp32: |error| <= 2.6e-5 everywhere, relative error <= 1.6e-4 for x >= -1, 5e-4 down to -2, 6e-3
+// down to -3 (where gelu = -4e-3); a bf16 store rounds by up to 3.9e-3 relative, the reference's fp16 store by 4.9e-4.  Why: those
+// epilogues are VALU-bound on the activation (5.5 us of a 25 us FC1 tile period), and this form is 7 packed
+// ops + 2 v_exp + 2 v_rcp per PAIR of elements against 15 packed ops + 2 v_rcp for the 3e-7-accurate A&S 7.1.28 form above, which
+// every fp32 site keeps (the head's row tail, the fp32 debug mode, gelu_grad_as).  The clamp keeps the odd polynomial monotone
+// (its x^5 term would turn it round at |x| = 10.9); beyond it the exponent keeps growing linearly: exp2 -> 0 / inf, rcp -> 1 / 0,
+// i.e. gelu -> x / -0 exactly.  SC_GELU_EXACT (A/B builds): the A&S form everywhere.
+__device__ __forceinline__ f32x2 gelu_bf2(f32x2 x) {
+#ifdef SC_GELU_EXACT
+    return gelu_erf2(x);
+#else
+#pragma clang fp contract(off)
+    f32x2 t = x * x;
+    t.x = fminf(t.x, 64.f); t.y = fminf(t.y, 64.f);
+    // coefficients times -log2(e): the exponent of 2 of exp(-x (c1 + c3 t + c5 t^2))
+    f32x2 p = __builtin_elementwise_fma(f32x2{0.0010142630198970437f, 0.0010142630198970437f}, t, f32x2{-0.10677572339773178f, -0.10677572339773178f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-2.301121234893799f, -2.301121234893799f});
+    const f32x2 w = p * x;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(w.x); e.y = __builtin_amdgcn_exp2f(w.y);
+    const f32x2 d = e + 1.0f;
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+    return x * r;
+#endif
 }
 
 // gelu_grad_as on two elements: the polynomial, squarings and products as packed fp32 ops, rcp / exp per element.  Same operation order
