@@ -9,6 +9,18 @@
 // image as gemm_bf16.hip.  Staging is LDS-DMA (global_load_lds_dwordx4) that stays in flight across barriers:
 // raw s_barrier (no implicit vmcnt(0)), one counted `s_waitcnt vmcnt(NBI)` per K-tile.
 //
+// Round 5: K-tile kt = TWO phases, each [L segment | barrier | C segment: 32 MFMA | barrier]  (in-kernel stamps had the four-phase loop
+// at 2390 cycles per K-tile against the 2048 its MFMAs take: ~43 cycles around each of its 8 barriers):
+//   X  L: read B(n-sub 0) 4 + A(m-sub 0) 8 + B(n-sub 1) 4 x b128 ; DMA A(kt+1) -> other buffer      C: (m0, n0), (m0, n1)
+//   Y  L: read A(m-sub 1) 8 ; DMA B(kt+2) -> this buffer ; s_waitcnt vmcnt(NBI)                     C: (m1, n1), (m1, n0)
+// Phase p spans barrier intervals 2p, 2p+1 for wm = 0 and 2p+1, 2p+2 for wm = 1 (X = 0, Y = 1 of K-tile kt, X = 2 of kt + 1 ...):
+//   WAR  A slot of the other buffer (A(kt-1)): last read in L(Y(kt-1)) - by this group 2 intervals, by the staggered group ONE interval
+//        (and one barrier) before this group's DMA issue in L(X(kt)); B slot (B(kt)): last read in L(X(kt)), re-staged in L(Y(kt)).  A
+//        ds_read issued before the barrier returns the old bytes whatever lands later (LDS requests are served in arrival order, a DMA's
+//        data arrives a memory round trip after its issue);
+//   RAW  A(kt+1) (issued X(kt)) and B(kt+1) (issued Y(kt-1)) are retired by every wave's vmcnt(NBI) in L(Y(kt)) and first read in
+//        L(X(kt+1)), one barrier later for either group.
+// The four-phase form (SC_GEMM_4PHASE, A/B builds) as it was:
 // K-tile kt (buffer par = (kt + base) & 1) = 4 phases, each [L segment | barrier | C segment: 16 MFMA | barrier]:
 //   P0  L: read A(m-sub 0) 8 x b128 + B(n-sub 0) 4 x b128            C: quadrant (m0, n0)
 //   P1  L: read B(n-sub 1) 4 ; DMA A(kt+1) -> other buffer            C: (m0, n1)
@@ -331,6 +343,48 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             const int par = (kt + base) & 1;
             const char* as = smem + par * BUF_BYTES + a_base;
             const char* bs = smem + par * BUF_BYTES + b_base;
+#ifndef SC_GEMM_4PHASE
+            // ---------------- X  (round 5: TWO phases of 32 MFMAs per K-tile instead of four of 16 - half the barriers; same operand
+            // registers, same accumulation order => same bits.  X: L = every fragment of B and A(m-sub 0) + DMA A(kt+1) -> other buffer;
+            // Y: L = A(m-sub 1) + DMA B(kt+2) -> this buffer + the counted wait.  Hazards: header.)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                b0[ni][0] = ld_frag(bs, ni, 0);
+                b0[ni][1] = ld_frag(bs, ni, 1);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                af[mi][0] = ld_frag(as, mi, 0);
+                af[mi][1] = ld_frag(as, mi, 1);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NB1; ++ni) {
+                b1[ni][0] = ld_frag(bs, 2 + ni, 0);
+                b1[ni][1] = ld_frag(bs, 2 + ni, 1);
+            }
+            if (LN != 0 && kt == 0) dma_ln(m0, n0);      // older than every later wait of this K loop: in LDS long before the epilogue
+            if (kt + 1 < nk) dma_A(par ^ 1, koff(kt + 1));
+            SC_BAR();
+            SC_MFMA_QUAD(0, 0, b0);
+            SC_MFMA_QUAD(0, 1, b1);
+            SC_BAR();
+            // ---------------- Y
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                af[mi][0] = ld_frag(as, 4 + mi, 0);
+                af[mi][1] = ld_frag(as, 4 + mi, 1);
+            }
+            if (kt + 2 < nk) {
+                dma_B(par, koff(kt + 2));
+                SC_WAIT_NBI();
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            SC_BAR();
+            SC_MFMA_QUAD(1, 1, b1);
+            SC_MFMA_QUAD(1, 0, b0);
+            SC_BAR();
+#else
             // ---------------- P0
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
@@ -375,6 +429,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             SC_BAR();
             SC_MFMA_QUAD(1, 0, b0);
             SC_BAR();
+#endif
         } while (++kt < nk);
         if (wm == 0) SC_BAR();                       // pairs the staggered group's last barrier
         SC_STAMP(2);
