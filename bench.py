@@ -403,6 +403,10 @@ def run_recipes(args, dev):
         ms = (time.perf_counter() - t0) / 10 * 1e3
         rec = {"ms_per_step": round(ms, 3), "utterances_per_s": round(B / ms * 1e3, 1), "steps": 10, "warmup": 3, "batch": B,
                "seconds": seconds, "loss": round(float(loss.item()), 5)}
+        if not ragged:                                   # whole-step algorithmic flops and their fraction of the dense bf16 peak
+            alg = step_alg_gflop(kind, L, unfreeze=extra.get("unfreeze", 0), trainable=bool(extra.get("trainable")))
+            rec.update(alg)
+            rec["step_frac_of_mfma_bf16_peak"] = round(alg["alg_gflop_per_utt_step"] * B / ms / 1e3 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)
         if extra:
             rec["mode"] = ("top 2 HuBERT layers unfrozen (audio_encoder.trainable + unfreeze_layers [10, 11]): fwd + bwd + Adam" if "unfreeze" in extra
                            else "audio_encoder.trainable: true - the whole HuBERT trains (speech_encoder_plus.py:556-562): fwd + bwd + Adam")
@@ -558,6 +562,50 @@ def forward_summary(fwd_ms, B, L, T, lens=None, conv_ms=None):
                     "frac_transformer_head_only": round(t_rest / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                     "frac_conv_extractor_only": round(conv * B / (conv_ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)})
     return out
+
+
+def step_alg_gflop(kind: str, L: int, unfreeze: int = 0, trainable: bool = False) -> dict:
+    """ALGORITHMIC flops of one TRAIN step per utterance of a recipe (SURVEY 8d conventions: an utterance at its own length, the parallel
+    head as the CLS row only, backward of a trainable block = 2 x its forward, of a frozen block that gradients cross = 1 x, nothing
+    for frozen blocks in front of the first trainable one).  Terms, with T frames, D / F / NL of the encoder, S = T + 1 rows of a
+    branch's attention block, N = round(T / 20) keywords (kwClip.py:876), E_t / V the text width / reduced vocabulary:
+      hubert_fwd   conv stack + projection + pos_conv + NL (linear + attention)                         (forward_summary's formulae)
+      head         parallel: 1.19 (base) / 2.12 (large) GFLOP forward, CLS row only
+      block        MultiheadAttentionAndNorm over S rows: 8 S D^2 + 4 S^2 D
+      cif_conv     Conv1d(D, D, 3) of the CIF weight generator: 6 T D^2
+      kw           keyword projection(s) + cosine against the vocabulary + the embedding product: 2 N (D E_t [+ D D]) + 4 N E_t V
+      text         the frozen CLIP text tower on the causal PREFIX the end-of-text pooling reads (N + 2 of the 77 tokens; the
+                   reference runs all 77): 12 (24 P W^2 + 4 P^2 W)"""
+    large = kind in ("large", "hybrid_plus_large")
+    D, F, NL, W, V = (1024, 4096, 24, 768, 19787) if large else (768, 3072, 12, 512, 8112)
+    t, cin, conv = L, 1, 0.0
+    for k, s_ in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
+        t = (t - k) // s_ + 1
+        conv += 2.0 * t * 512 * cin * k
+        cin = 512
+    T = t
+    layer = T * 2.0 * (4 * D * D + 2 * D * F) + 4.0 * T * T * D
+    front = conv + 2.0 * T * 512 * D + 2.0 * T * D * (D // 16) * 128
+    hubert = front + NL * layer
+    terms = {"hubert_fwd": hubert}
+    if trainable:
+        terms["hubert_bwd"] = 2.0 * hubert
+    elif unfreeze:
+        terms["hubert_bwd_top_layers"] = 2.0 * unfreeze * layer
+    if kind in ("base", "large"):
+        terms["head_fwd_bwd"] = 3.0 * (2.12e9 if large else 1.19e9)
+    else:
+        S, N = T + 1, round(T / 20)
+        block = 8.0 * S * D * D + 4.0 * S * S * D
+        cif = 6.0 * T * D * D
+        kw = 2.0 * N * (D * W + (D * D if large else 0)) + 4.0 * N * W * V
+        P = N + 2
+        text = 12 * (24.0 * P * W * W + 4.0 * P * P * W)
+        terms.update({"branch_block_cif_kw_fwd_bwd": 3.0 * (block + cif + kw), "text_tower_fwd_dgrad": 2.0 * text})
+        if kind == "hybrid_plus_large":
+            terms["parallel_projection_fwd_bwd"] = 3.0 * 2.0 * D * W
+    total = sum(terms.values())
+    return {"alg_gflop_per_utt_step": round(total / 1e9, 1), "terms_gflop": {k: round(v / 1e9, 2) for k, v in terms.items()}}
 
 
 def pmc_traffic(kernel_substr):

@@ -6,12 +6,12 @@ import torch
 from speechclip_plus_amd import ops, _lib
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-B, R, D, F, C = 64, int(sys.argv[3]) if len(sys.argv) > 3 else 504, 768, 3072, 512
+B, R, D, F, C = 64, int(os.environ.get("SC_BENCH_R", "504")), 768, 3072, 512
 M = B * R
 shapes = [("qkv", M, 3 * D, D, None, 0, False), ("oproj", M, D, D, None, 0, True), ("fc1", M, F, D, None, 1, False),
           ("fc2", M, D, F, None, 0, True), ("conv1", B * 32 * R, C, 3 * C, 2 * C, 1, False), ("conv2", B * 16 * R, C, 3 * C, 2 * C, 1, False),
           ("conv3", B * 8 * R, C, 3 * C, 2 * C, 1, False), ("conv5", B * 2 * R, C, 2 * C, 2 * C, 1, False)]
-libs = [(os.path.basename(p), _lib._load(p)) for p in sys.argv[1:3]]
+libs = [(os.path.basename(p), _lib._load(p)) for p in sys.argv[1:] if p.endswith(".so")]
 tot = {n: 0.0 for n, _ in libs}
 for name, m, n, k, lda, act, res in shapes:
     lda = lda or k
@@ -32,7 +32,7 @@ for name, m, n, k, lda, act, res in shapes:
             torch.cuda.synchronize()
             if r > 0:
                 times[nm].append(e0.elapsed_time(e1) / 3)
-    d = (Cm[0].float() - Cm[1].float()).abs()
+    d = (Cm[0].float() - Cm[-1].float()).abs()
     row = {nm: round(sorted(v)[len(v) // 2] * 1e3, 1) for nm, v in times.items()}
     for nm in row:
         tot[nm] += row[nm]
