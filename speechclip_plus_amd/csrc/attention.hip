@@ -45,8 +45,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                                                         float drop_p, uint32_t drop_seed, const int32_t* __restrict__ row0,
                                                         const int32_t* __restrict__ work, int npairs, int rows_total, int max_pitch,
                                                         long long* __restrict__ stamps = nullptr) {
-    __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
-    __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
+    // Round 5: two K and two V^T tile buffers (32 KiB), filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write)
+    // one tile ahead; ONE barrier per tile.  Both images are [64 rows][128 B] with the 16-byte chunk index XOR (row >> 1) & 7 - the
+    // swizzle sits in the DMA's per-lane source address.
+    __shared__ __attribute__((aligned(16))) char KVs[2][2][KT * 128];      // [buffer][K | V^T]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -103,19 +105,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
     }
 
-    // loader mapping: 512 16-B chunks per tile, two per thread
+    // loader mapping: a tile = 8 pieces of 8 rows x 128 B (one LDS-DMA wave instruction each); wave w brings pieces w and w + 4
     const uint16_t* kg[2];
     const uint16_t* vg[2];
-    int k_lds[2], v_lds0[2], v_lds1[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int id = tid + i * 256, row = id >> 3, ch = id & 7;
+        const int row = (wave + 4 * i) * 8 + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
         kg[i] = qk + ((int64_t)r0 + row) * ldqk + D + h * 64 + ch * 8;
         vg[i] = vt + (int64_t)D * r0 + (int64_t)(h * 64 + row) * R + ch * 8;      // V^T of the utterance: [H, 64, pitch] at D * r0
-        k_lds[i] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
-        v_lds0[i] = row * 128 + (((2 * ch) ^ vsw(row)) << 3);
-        v_lds1[i] = row * 128 + (((2 * ch + 1) ^ vsw(row)) << 3);
     }
+    auto stage = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg[i] + (int64_t)t * KT * ldqk),
+                                             (__attribute__((address_space(3))) void*)(&KVs[buf][0][(wave + 4 * i) * 1024]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg[i] + t * KT),
+                                             (__attribute__((address_space(3))) void*)(&KVs[buf][1][(wave + 4 * i) * 1024]), 16, 0, 0);
+        }
+    };
 
     f32x16 o0, o1;
 #pragma unroll
@@ -130,9 +137,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                                    : (uint32_t)(((b * H + h) * R + qrow)) * (uint32_t)R;
     if (causal) n_valid = min(n_valid, qblk * 128 + 128);           // keys beyond the block's last query are all masked
     const int ntiles = (n_valid + KT - 1) / KT;
-    // prefetch registers as named scalars: arrays indexed across the tile loop were being placed in scratch
-    uint4 kreg0 = *(const uint4*)(kg[0]), kreg1 = *(const uint4*)(kg[1]);
-    uint4 vreg0 = *(const uint4*)(vg[0]), vreg1 = *(const uint4*)(vg[1]);
+    stage(0, 0);
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_first = 0;
 #define SC_ST(K)                                         \
     do {                                                 \
@@ -145,37 +150,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     if (STAMP) st_first = st_prev = clock64();
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
-        // write the prefetched tile
-        *(uint4*)(Ks + k_lds[0]) = kreg0;
-        *(uint4*)(Ks + k_lds[1]) = kreg1;
-        *(uint2*)(Vs + v_lds0[0]) = make_uint2(vreg0.x, vreg0.y);
-        *(uint2*)(Vs + v_lds1[0]) = make_uint2(vreg0.z, vreg0.w);
-        *(uint2*)(Vs + v_lds0[1]) = make_uint2(vreg1.x, vreg1.y);
-        *(uint2*)(Vs + v_lds1[1]) = make_uint2(vreg1.z, vreg1.w);
-        __syncthreads();
+        // tile t has been staged one iteration ago (or above); retire this wave's pieces, meet the others', start the next tile
+        const char* Ks = KVs[t & 1][0];
+        const char* Vs = KVs[t & 1][1];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // every wave's pieces of tile t are in; everyone has finished tile t - 1
+        asm volatile("" ::: "memory");
         SC_ST(0);
-        if (t + 1 < ntiles) {
-            kreg0 = *(const uint4*)(kg[0] + (int64_t)(key0 + KT) * ldqk);
-            kreg1 = *(const uint4*)(kg[1] + (int64_t)(key0 + KT) * ldqk);
-            vreg0 = *(const uint4*)(vg[0] + key0 + KT);
-            vreg1 = *(const uint4*)(vg[1] + key0 + KT);
-        }
+        if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);               // into the buffer tile t - 1 was read from
         // Two 32-key blocks per tile, software-pipelined inside the wave: both S^T blocks are issued first, so the
         // matrix pipe works on block 1 while the VALU runs block 0's softmax, and on P.V of block 0 during block 1's.
         const bool blk1 = key0 + 32 < n_valid;                       // wave-uniform
+        // Round 5: the S^T MFMA takes its 32 key rows in a PERMUTED order (bits 2 and 3 of the row index swapped), so accumulator
+        // register r of lane half h is key (r & 7) + 8 h + 16 (r >> 3) of the block: the 8 k-slots a lane half feeds into a P.V MFMA
+        // are 8 CONSECUTIVE keys = ONE 16-byte chunk of a V^T row (was: two 8-byte pieces 16 bytes apart, two ds_read_b64)
+        const int kperm = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | (l31 & 16);
         if (wave_on) {
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = *(const bf16x8*)(Ks + l31 * 128 + (((2 * ks + half) ^ ((l31 >> 1) & 7)) << 4));
+            const bf16x8 kf = *(const bf16x8*)(Ks + kperm * 128 + (((2 * ks + half) ^ ((kperm >> 1) & 7)) << 4));
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s0, 0, 0, 0);
         }
         if (blk1) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int krow = 32 + l31;
+                const int krow = 32 + kperm;
                 const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((2 * ks + half) ^ ((krow >> 1) & 7)) << 4));
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s1, 0, 0, 0);
             }
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
             if (kbase + 32 > n_valid || (causal && kbase + 31 > q0) || causal > 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int kidx = kbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int kidx = kbase + (r & 7) + 8 * half + 16 * (r >> 3);
                     if (kidx >= n_valid || (causal && kidx > qrow) || (causal > 1 && kidx < (qrow & ~(causal - 1)))) sv[r] = -INFINITY;
                 }
             }
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                 // (inline asm: written with vector builtins the compiler folds the sequence back into v_cmp + v_cndmask)
                 const uint32_t t1 = drop_thr - 1u;
                 const uint32_t thr2 = t1 | (t1 << 16), one2 = 0x00010001u;
-                const uint32_t pair0 = ((drop_row + (uint32_t)(kbase + 4 * half)) >> 1);      // drop_row, kbase even
+                const uint32_t pair0 = ((drop_row + (uint32_t)(kbase + 8 * half)) >> 1);      // drop_row, kbase even
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     uint4 w = __builtin_bit_cast(uint4, pf[s2]);
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int r = 8 * s2 + 2 * q;                                         // elements r, r + 1
-                        const uint32_t hsh = sc_hash32((pair0 + (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2))) ^ drop_seed);
+                        const uint32_t hsh = sc_hash32((pair0 + (uint32_t)(q + 8 * s2)) ^ drop_seed);   // keys kbase + 16 s2 + 8 half + 2 q (+ 1)
                         uint32_t x, m;
                         asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(x) : "v"(hsh), "s"(thr2));
                         asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(x), "s"(one2));
@@ -254,15 +256,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         auto pv_block = [&](int kb, const bf16x8 (&pf)[2]) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int u0 = kb * 8 + 4 * s2 + half;
+                const int chunk = kb * 4 + 2 * s2 + half;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     const int vrow = dt * 32 + l31;
-                    const int sw = vsw(vrow);
-                    const uint2 lo = *(const uint2*)(Vs + vrow * 128 + ((u0 ^ sw) << 3));
-                    const uint2 hi = *(const uint2*)(Vs + vrow * 128 + (((u0 + 2) ^ sw) << 3));
-                    const uint4 v4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    const bf16x8 vf = __builtin_bit_cast(bf16x8, v4);
+                    const bf16x8 vf = *(const bf16x8*)(Vs + vrow * 128 + ((chunk ^ ((vrow >> 1) & 7)) << 4));
                     if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o0, 0, 0, 0);
                     else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o1, 0, 0, 0);
                 }
@@ -281,7 +279,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
             SC_ST(5);
         }
         }
-        __syncthreads();
         SC_ST(6);
     }
     if (STAMP && stamps && (blockIdx.x & 31) == 0 && lane == 0) {
