@@ -406,7 +406,7 @@ def run_recipes(args, dev):
         if not ragged:                                   # whole-step algorithmic flops and their fraction of the dense bf16 peak
             alg = step_alg_gflop(kind, L, unfreeze=extra.get("unfreeze", 0), trainable=bool(extra.get("trainable")))
             rec.update(alg)
-            rec["step_frac_of_mfma_bf16_peak"] = round(alg["alg_gflop_per_utt_step"] * B / ms / 1e3 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)
+            rec["step_frac_of_mfma_bf16_peak"] = round(alg["alg_gflop_per_utt_step"] * B / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)      # GFLOP / ms = TFLOP/s
         if extra:
             rec["mode"] = ("top 2 HuBERT layers unfrozen (audio_encoder.trainable + unfreeze_layers [10, 11]): fwd + bwd + Adam" if "unfreeze" in extra
                            else "audio_encoder.trainable: true - the whole HuBERT trains (speech_encoder_plus.py:556-562): fwd + bwd + Adam")
