@@ -79,15 +79,43 @@ __device__ __forceinline__ float gelu_grad_as(float x) {
     return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
 }
 
+#ifndef SC_GELU_TERMS
+#define SC_GELU_TERMS 5          // 3 / 4: the shorter fits measured on the way (A/B builds)
+#endif
+#if SC_GELU_TERMS == 5
+#define SC_GK0 -2.3020437690e+00f
+#define SC_GK1 -1.0522998852e-01f
+#define SC_GK2 3.6205193708e-04f
+#define SC_GK3 8.7909655076e-05f
+#define SC_GK4 -3.2104365226e-06f
+#elif SC_GELU_TERMS == 4
+#define SC_GK0 -2.3016456068e+00f
+#define SC_GK1 -1.0598370216e-01f
+#define SC_GK2 7.3575809569e-04f
+#define SC_GK3 2.4884072148e-05f
+#endif
 // scalar twin of gelu_bf2 (below): the same operations in the same order => the same bits (the bf16-output sites' erf-GELU)
 __device__ __forceinline__ float gelu_bf(float x) {
 #ifdef SC_GELU_EXACT
     return gelu_erf(x);
 #else
 #pragma clang fp contract(off)
+#if SC_GELU_TERMS == 5
+    const float t = fminf(x * x, 36.f);
+    float p = fmaf(SC_GK4, t, SC_GK3);
+    p = fmaf(p, t, SC_GK2);
+    p = fmaf(p, t, SC_GK1);
+    p = fmaf(p, t, SC_GK0);
+#elif SC_GELU_TERMS == 4
+    const float t = fminf(x * x, 36.f);
+    float p = fmaf(SC_GK3, t, SC_GK2);
+    p = fmaf(p, t, SC_GK1);
+    p = fmaf(p, t, SC_GK0);
+#else
     const float t = fminf(x * x, 64.f);
     float p = fmaf(0.0010142630198970437f, t, -0.10677572339773178f);
     p = fmaf(p, t, -2.301121234893799f);
+#endif
     const float w = p * x;
     const float d = __builtin_amdgcn_exp2f(w) + 1.0f;
     return x * __builtin_amdgcn_rcpf(d);
@@ -133,25 +161,39 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 }
 
 // The erf-GELU of the bf16-OUTPUT sites (GEMM epilogues of FC1 / the conv stack, conv layer 0, pos_conv, LayerNorm + GELU rows), round 5:
-//     gelu(x) ~ x * sigmoid(x (c1 + c3 t + c5 t^2)),  t = min(x^2, 64),  c = (1.59501577, 7.40112920e-2, -7.03033580e-4)
-// - the logistic approximation of the normal CDF with one more odd term, coefficients fitted (minimax on |x Phi(x) - approx| over
-// [-12, 12], tools/fit_gelu.py) - in fp32: |error| <= 2.6e-5 everywhere, relative error <= 1.6e-4 for x >= -1, 5e-4 down to -2, 6e-3
-// down to -3 (where gelu = -4e-3); a bf16 store rounds by up to 3.9e-3 relative, the reference's fp16 store by 4.9e-4.  Why: those
-// epilogues are VALU-bound on the activation (5.5 us of a 25 us FC1 tile period), and this form is 7 packed
-// ops + 2 v_exp + 2 v_rcp per PAIR of elements against 15 packed ops + 2 v_rcp for the 3e-7-accurate A&S 7.1.28 form above, which
-// every fp32 site keeps (the head's row tail, the fp32 debug mode, gelu_grad_as).  The clamp keeps the odd polynomial monotone
-// (its x^5 term would turn it round at |x| = 10.9); beyond it the exponent keeps growing linearly: exp2 -> 0 / inf, rcp -> 1 / 0,
-// i.e. gelu -> x / -0 exactly.  SC_GELU_EXACT (A/B builds): the A&S form everywhere.
+//     gelu(x) ~ x * sigmoid(x p(t)),  t = min(x^2, 36),  p = c0 + c1 t + c2 t^2 + c3 t^3 + c4 t^4
+//     c = (1.595655148, 7.293986985e-2, -2.509552794e-4, -6.093432956e-5, 2.225305024e-6)
+// - the logistic approximation of the normal CDF carried to five odd terms, coefficients fitted (iteratively re-weighted least squares
+// on logit(Phi(x)) / x, then minimax on |x Phi(x) - approx| over [-12, 12]: tools/fit_gelu.py) - in fp32: |error| <= 3.1e-6 everywhere,
+// relative error <= 2.0e-5 for x >= -1, 4.8e-4 down to -3; a bf16 store rounds by up to 3.9e-3 relative, the reference's fp16 store by
+// 4.9e-4.  Why: those epilogues are VALU-bound on the activation, and this form is 9 packed ops + 2 v_exp + 2 v_rcp
+// per PAIR of elements against 15 packed ops + 2 v_rcp for the 3e-7-accurate A&S 7.1.28 form above, which every fp32 site keeps (the head's
+// row tail, the fp32 debug mode, gelu_grad_as).  The three-term fit (|error| 2.5e-5) was 0.3 % faster still and moved a train step's loss by
+// 6e-4 - a SYSTEMATIC error through 19 activation sites, unlike rounding noise; with five terms the loss equals the A&S build's to five
+// digits (1.33628).  The clamp keeps the odd polynomial monotone; beyond it the exponent keeps growing linearly: exp2 -> 0 / inf,
+// rcp -> 1 / 0, i.e. gelu -> x / -0 exactly.  SC_GELU_EXACT (A/B builds): the A&S form everywhere.
 __device__ __forceinline__ f32x2 gelu_bf2(f32x2 x) {
 #ifdef SC_GELU_EXACT
     return gelu_erf2(x);
 #else
 #pragma clang fp contract(off)
     f32x2 t = x * x;
+#if SC_GELU_TERMS >= 4
+    t.x = fminf(t.x, 36.f); t.y = fminf(t.y, 36.f);
+#if SC_GELU_TERMS == 5
+    f32x2 p = __builtin_elementwise_fma(f32x2{SC_GK4, SC_GK4}, t, f32x2{SC_GK3, SC_GK3});
+    p = __builtin_elementwise_fma(p, t, f32x2{SC_GK2, SC_GK2});
+#else
+    f32x2 p = __builtin_elementwise_fma(f32x2{SC_GK3, SC_GK3}, t, f32x2{SC_GK2, SC_GK2});
+#endif
+    p = __builtin_elementwise_fma(p, t, f32x2{SC_GK1, SC_GK1});
+    p = __builtin_elementwise_fma(p, t, f32x2{SC_GK0, SC_GK0});
+#else
     t.x = fminf(t.x, 64.f); t.y = fminf(t.y, 64.f);
     // coefficients times -log2(e): the exponent of 2 of exp(-x (c1 + c3 t + c5 t^2))
     f32x2 p = __builtin_elementwise_fma(f32x2{0.0010142630198970437f, 0.0010142630198970437f}, t, f32x2{-0.10677572339773178f, -0.10677572339773178f});
     p = __builtin_elementwise_fma(p, t, f32x2{-2.301121234893799f, -2.301121234893799f});
+#endif
     const f32x2 w = p * x;
     f32x2 e;
     e.x = __builtin_amdgcn_exp2f(w.x); e.y = __builtin_amdgcn_exp2f(w.y);

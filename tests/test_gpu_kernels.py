@@ -1434,12 +1434,12 @@ def test_attention_backward_is_bitwise_repeatable(dev):
 
 
 def test_bf16_site_gelu_against_the_exact_erf_gelu():
-    """csrc/sc_common.h gelu_bf / gelu_bf2 (round 5): the erf-GELU of every bf16-OUTPUT site is x * sigmoid(x (c1 + c3 t + c5 t^2)),
-    t = min(x^2, 64) (fitted: tools/fit_gelu.py), because the FC1 / conv epilogues are VALU-bound on the activation.  Against the exact
-    x Phi(x) (fairseq nn.GELU, torch erf form) on EVERY bf16 input in [-16, 16]: the fp32 error behind the bf16 store is bounded by
-    2.6e-5 absolute - so the stored value is the exact result's bf16 rounding or its neighbour; for x >= -1 the fit's RELATIVE error
-    is <= 1.6e-4 (tools/fit_gelu.py), i.e. the stored value is within one bf16 rounding (<= 2^-8 relative) + 2e-4 of the exact one;
-    the limits hold (gelu = x beyond +9, |gelu| < 1e-10 beyond -9)."""
+    """csrc/sc_common.h gelu_bf / gelu_bf2 (round 5): the erf-GELU of every bf16-OUTPUT site is x * sigmoid(x p(t)), t = min(x^2, 36), p
+    a five-term polynomial (fitted: tools/fit_gelu.py), because the FC1 / conv epilogues are VALU-bound on the activation.  Against the
+    exact x Phi(x) (fairseq nn.GELU, torch erf form) on EVERY bf16 input in [-16, 16]: the fp32 error behind the bf16 store is bounded by
+    3.5e-6 absolute - so the stored value is the exact result's bf16 rounding or, on a rounding boundary, its neighbour; for x >= -1 the
+    fit's RELATIVE error is <= 2.1e-5, i.e. the stored value is within one bf16 rounding (<= 2^-8 relative) + 3e-5 of the exact one; the
+    limits hold (gelu = x beyond +9, |gelu| < 1e-10 beyond -9)."""
     from speechclip_plus_amd import ops
     dev = torch.device("cuda:0")
     bits = torch.arange(0, 1 << 16, dtype=torch.int32)
@@ -1452,13 +1452,13 @@ def test_bf16_site_gelu_against_the_exact_erf_gelu():
     exact = xf * 0.5 * (1.0 + torch.erf(xf / 2.0 ** 0.5))
     ulp = torch.maximum(exact.abs(), torch.tensor(2.0 ** -126, dtype=torch.float64)).log2().floor().exp2() * 2.0 ** -7      # bf16 spacing at the exact value
     err = (y.double() - exact).abs()
-    assert bool((err <= 0.5 * ulp + 2.6e-5).all()), float((err - 0.5 * ulp).max())
+    assert bool((err <= 0.5 * ulp + 3.5e-6).all()), float((err - 0.5 * ulp).max())
     sig = exact.abs() >= 4e-3
     body = (x.float() >= -1.0) & (exact.abs() >= 1e-30)            # (subnormal inputs are flushed: excluded from the RELATIVE bound)
-    assert float((err[body] / exact.abs()[body]).max()) <= 2.0 ** -8 + 2e-4        # one bf16 rounding (half an ulp: 2^-9 .. 2^-8 relative) + the fit
+    assert float((err[body] / exact.abs()[body]).max()) <= 2.0 ** -8 + 3e-5        # one bf16 rounding (half an ulp: 2^-9 .. 2^-8 relative) + the fit
     # the stored value is the exact result's own bf16 rounding for nearly every input, a neighbour otherwise
     same = (y == exact.float().to(torch.bfloat16).float())
-    assert float(same[sig].float().mean()) > 0.93, float(same[sig].float().mean())
+    assert float(same[sig].float().mean()) > 0.995, float(same[sig].float().mean())
     big = x.float() >= 9.0
     assert torch.equal(y[big], x.float()[big])                                      # gelu(x) = x in bf16 beyond the clamp
     neg = x.float() <= -9.0
