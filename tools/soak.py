@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Soak: N train steps of a recipe with fresh random batches of varying length; loss must stay finite, device memory must plateau.
-usage: soak.py [base|cascaded_plus] [steps]"""
+usage: soak.py [base|cascaded_plus] [steps] [--hook]
+--hook: batches arrive as the reference's loop delivers them - data.collate_general(pin_memory=True), then the LightningModule hook
+model.transfer_batch_to_device (copy stream + event + host twin of the lengths)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,7 +22,12 @@ mem, losses = [], []
 for step in range(steps):
     lens = torch.randint(20000, 140000, (B,), generator=g)       # the 6.4 s training crop (max_audio_len) applies
     wav = torch.randn(B, int(lens.max()), generator=g)
-    batch = {"wav": wav.cuda(), "wav_len": lens, "image": torch.randn(B, E, generator=g).cuda(), "id": (torch.arange(B) // 2).cuda()}
+    if "--hook" in sys.argv:
+        from speechclip_plus_amd import data
+        items = [{"wav": wav[b, : int(lens[b])], "image": torch.randn(E, generator=g), "id": torch.tensor(b // 2)} for b in range(B)]
+        batch = model.transfer_batch_to_device(data.collate_general(items, pin_memory=True), torch.device("cuda:0"), 0)
+    else:
+        batch = {"wav": wav.cuda(), "wav_len": lens, "image": torch.randn(B, E, generator=g).cuda(), "id": (torch.arange(B) // 2).cuda()}
     loss = trainer.step(batch)
     if step % 20 == 19 or step == steps - 1:
         torch.cuda.synchronize()
