@@ -250,33 +250,24 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
     if (t_begin >= R0) return;
     const int t_end = min(R0, t_begin + rows_per_block);
     const int c0 = lane * 8;
-    float w[8][10], bs[8], gm[8], bt[8];
+    // Round 5: channel PAIRS in packed fp32 for the taps (v_pk_fma_f32, as conv0_gn_gelu_kernel) and TWO adjacent output rows per wave
+    // iteration (rows t, t + 1 share 5 of their 10 samples; their two statistics reductions interleave) - per element the same
+    // operations in the same order as the one-row scalar form, so the same bits.
+    f32x2 w[4][10], bs[4];
+    float gm[8], bt[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[i][j] = f32x2{w0[(c0 + 2 * i) * 10 + j], w0[(c0 + 2 * i + 1) * 10 + j]};
+        bs[i] = bias ? f32x2{bias[c0 + 2 * i], bias[c0 + 2 * i + 1]} : f32x2{0.f, 0.f};
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int j = 0; j < 10; ++j) w[i][j] = w0[(c0 + i) * 10 + j];
-        bs[i] = bias ? bias[c0 + i] : 0.f;
         gm[i] = gamma[c0 + i];
         bt[i] = beta[c0 + i];
     }
-    for (int t = t_begin + wave; t < t_end; t += 4) {
-        float v[10];
-#pragma unroll
-        for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];
-        float a[8], s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float acc = bs[i];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) acc = fmaf(w[i][j], v[j], acc);
-            a[i] = acc;
-            s += acc;
-        }
-        const float mean = wave_sum(s) * (1.0f / C);
-        float sq = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sq += (a[i] - mean) * (a[i] - mean);
-        const float rstd = rsqrtf(wave_sum(sq) * (1.0f / C) + eps);
+    auto finish = [&](const f32x2 (&a2)[4], float mean, float rstd, int t) {
+        const float a[8] = {a2[0].x, a2[0].y, a2[1].x, a2[1].y, a2[2].x, a2[2].y, a2[3].x, a2[3].y};
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; i += 2) {
@@ -295,6 +286,41 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
             u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
             *(uint4*)(out + (orow + t) * C + c0) = u;
         }
+    };
+    for (int t = t_begin + 2 * wave; t < t_end; t += 8) {
+        const bool two = t + 1 < t_end;                 // wave-uniform
+        float v[15];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];
+#pragma unroll
+        for (int j = 10; j < 15; ++j) v[j] = two ? x[5 * t + j] : 0.f;     // (nothing behind the last row is read)
+        f32x2 a0[4], a1[4];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x2 acc0 = bs[i], acc1 = bs[i];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                acc0 = __builtin_elementwise_fma(w[i][j], f32x2{v[j], v[j]}, acc0);
+                acc1 = __builtin_elementwise_fma(w[i][j], f32x2{v[j + 5], v[j + 5]}, acc1);
+            }
+            a0[i] = acc0;
+            a1[i] = acc1;
+            s0 += acc0.x; s0 += acc0.y;
+            s1 += acc1.x; s1 += acc1.y;
+        }
+        const float mean0 = wave_sum(s0) * (1.0f / C), mean1 = wave_sum(s1) * (1.0f / C);
+        float sq0 = 0.f, sq1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sq0 += (a0[i].x - mean0) * (a0[i].x - mean0);
+            sq0 += (a0[i].y - mean0) * (a0[i].y - mean0);
+            sq1 += (a1[i].x - mean1) * (a1[i].x - mean1);
+            sq1 += (a1[i].y - mean1) * (a1[i].y - mean1);
+        }
+        const float rstd0 = rsqrtf(wave_sum(sq0) * (1.0f / C) + eps), rstd1 = rsqrtf(wave_sum(sq1) * (1.0f / C) + eps);
+        finish(a0, mean0, rstd0, t);
+        if (two) finish(a1, mean1, rstd1, t + 1);
     }
 }
 
