@@ -194,30 +194,47 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
             sc[i] = *(const f32x2*)(scale + (int64_t)b * C + c0 + 2 * i);
             sh[i] = *(const f32x2*)(shift + (int64_t)b * C + c0 + 2 * i);
         }
-        for (int t = t_begin + wave; t < t_end; t += 4) {
-            float v[10];
+#ifndef SC_CONV0_ROWS
+#define SC_CONV0_ROWS 4
+#endif
+        // SC_CONV0_ROWS adjacent rows per wave iteration (round 5: neighbours share 5 of their 10 samples - 25 scalar loads instead of 40 for
+        // four rows, ONE wait for them per iteration, independent chains for the scheduler: 780 -> 694 us at B = 64 x 10 s, 6 / 8 rows are
+        // slower again); per element the same operations in the same order as the one-row form: same bits
+        constexpr int NR = SC_CONV0_ROWS, NV = 5 * NR + 5;
+        auto fetch = [&](int t, float (&v)[NV]) {
 #pragma unroll
-            for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];   // wave-uniform address: broadcast load
-            float o[8];
+            for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];   // wave-uniform address: scalar loads
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x2 a = f32x2{0.f, 0.f};
+            for (int j = 10; j < NV; ++j) v[j] = (t + (j - 5) / 5 < t_end) ? x[5 * t + j] : 0.f;      // (nothing behind the last row is read)
+        };
+        // (fetching the NEXT iteration's samples under this one's arithmetic: 804 us - not kept)
+        for (int t = t_begin + NR * wave; t < t_end; t += 4 * NR) {
+            float v[NV];
+            fetch(t, v);
 #pragma unroll
-                for (int j = 0; j < 10; ++j) a = __builtin_elementwise_fma(w[i][j], f32x2{v[j], v[j]}, a);
-                const f32x2 u_ = __builtin_elementwise_fma(a, sc[i], sh[i]);
-                const f32x2 g = F32OUT ? gelu_erf2(u_) : gelu_bf2(u_);      // (fp32 debug mode: the 3e-7 form)
-                o[2 * i] = g.x;
-                o[2 * i + 1] = g.y;
-            }
-            if constexpr (F32OUT) {
-                float* of = (float*)out_ + (orow + t) * C + c0;
-                *(f32x4*)of = f32x4{o[0], o[1], o[2], o[3]};
-                *(f32x4*)(of + 4) = f32x4{o[4], o[5], o[6], o[7]};
-            } else {
-                uint4 u;
-                u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
-                u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
-                *(uint4*)(out + (orow + t) * C + c0) = u;
+            for (int r = 0; r < NR; ++r) {
+                if (r > 0 && t + r >= t_end) break;                 // wave-uniform
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x2 a = f32x2{0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) a = __builtin_elementwise_fma(w[i][j], f32x2{v[5 * r + j], v[5 * r + j]}, a);
+                    const f32x2 u_ = __builtin_elementwise_fma(a, sc[i], sh[i]);
+                    const f32x2 g = F32OUT ? gelu_erf2(u_) : gelu_bf2(u_);      // (fp32 debug mode: the 3e-7 form)
+                    o[2 * i] = g.x;
+                    o[2 * i + 1] = g.y;
+                }
+                if constexpr (F32OUT) {
+                    float* of = (float*)out_ + (orow + t + r) * C + c0;
+                    *(f32x4*)of = f32x4{o[0], o[1], o[2], o[3]};
+                    *(f32x4*)(of + 4) = f32x4{o[4], o[5], o[6], o[7]};
+                } else {
+                    uint4 u;
+                    u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
+                    u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+                    *(uint4*)(out + (orow + t + r) * C + c0) = u;
+                }
             }
         }
     }
@@ -250,8 +267,8 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
     if (t_begin >= R0) return;
     const int t_end = min(R0, t_begin + rows_per_block);
     const int c0 = lane * 8;
-    // Round 5: channel PAIRS in packed fp32 for the taps (v_pk_fma_f32, as conv0_gn_gelu_kernel) and TWO adjacent output rows per wave
-    // iteration (rows t, t + 1 share 5 of their 10 samples; their two statistics reductions interleave) - per element the same
+    // Round 5: channel PAIRS in packed fp32 for the taps (v_pk_fma_f32, as conv0_gn_gelu_kernel) and SC_CONV0LN_ROWS adjacent output rows per wave
+    // iteration (neighbours share 5 of their 10 samples; their statistics reductions interleave) - per element the same
     // operations in the same order as the one-row scalar form, so the same bits.
     f32x2 w[4][10], bs[4];
     float gm[8], bt[8];
@@ -287,40 +304,48 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
             *(uint4*)(out + (orow + t) * C + c0) = u;
         }
     };
-    for (int t = t_begin + 2 * wave; t < t_end; t += 8) {
-        const bool two = t + 1 < t_end;                 // wave-uniform
-        float v[15];
+#ifndef SC_CONV0LN_ROWS
+#define SC_CONV0LN_ROWS 2
+#endif
+    constexpr int NR = SC_CONV0LN_ROWS, NV = 5 * NR + 5;
+    for (int t = t_begin + NR * wave; t < t_end; t += 4 * NR) {
+        float v[NV];
 #pragma unroll
         for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];
 #pragma unroll
-        for (int j = 10; j < 15; ++j) v[j] = two ? x[5 * t + j] : 0.f;     // (nothing behind the last row is read)
-        f32x2 a0[4], a1[4];
-        float s0 = 0.f, s1 = 0.f;
+        for (int j = 10; j < NV; ++j) v[j] = (t + (j - 5) / 5 < t_end) ? x[5 * t + j] : 0.f;     // (nothing behind the last row is read)
+        f32x2 a[NR][4];
+        float sm[NR], sq[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) sm[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x2 acc0 = bs[i], acc1 = bs[i];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                acc0 = __builtin_elementwise_fma(w[i][j], f32x2{v[j], v[j]}, acc0);
-                acc1 = __builtin_elementwise_fma(w[i][j], f32x2{v[j + 5], v[j + 5]}, acc1);
+            for (int r = 0; r < NR; ++r) {
+                f32x2 acc = bs[i];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) acc = __builtin_elementwise_fma(w[i][j], f32x2{v[5 * r + j], v[5 * r + j]}, acc);
+                a[r][i] = acc;
+                sm[r] += acc.x;
+                sm[r] += acc.y;
             }
-            a0[i] = acc0;
-            a1[i] = acc1;
-            s0 += acc0.x; s0 += acc0.y;
-            s1 += acc1.x; s1 += acc1.y;
         }
-        const float mean0 = wave_sum(s0) * (1.0f / C), mean1 = wave_sum(s1) * (1.0f / C);
-        float sq0 = 0.f, sq1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sq0 += (a0[i].x - mean0) * (a0[i].x - mean0);
-            sq0 += (a0[i].y - mean0) * (a0[i].y - mean0);
-            sq1 += (a1[i].x - mean1) * (a1[i].x - mean1);
-            sq1 += (a1[i].y - mean1) * (a1[i].y - mean1);
+        for (int r = 0; r < NR; ++r) sm[r] = wave_sum(sm[r]) * (1.0f / C);          // mean
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            sq[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sq[r] += (a[r][i].x - sm[r]) * (a[r][i].x - sm[r]);
+                sq[r] += (a[r][i].y - sm[r]) * (a[r][i].y - sm[r]);
+            }
         }
-        const float rstd0 = rsqrtf(wave_sum(sq0) * (1.0f / C) + eps), rstd1 = rsqrtf(wave_sum(sq1) * (1.0f / C) + eps);
-        finish(a0, mean0, rstd0, t);
-        if (two) finish(a1, mean1, rstd1, t + 1);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) sq[r] = rsqrtf(wave_sum(sq[r]) * (1.0f / C) + eps);   // rstd
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (r == 0 || t + r < t_end) finish(a[r], sm[r], sq[r], t + r);
     }
 }
 

@@ -25,5 +25,22 @@ for r in range(6):
         torch.cuda.synchronize()
         if r:
             times[nm].append(e0.elapsed_time(e1) / 3)
-print({nm: round(sorted(v)[len(v) // 2] * 1e3, 1) for nm, v in times.items()}, "us; bitwise equal:",
+print("layer_norm mode", {nm: round(sorted(v)[len(v) // 2] * 1e3, 1) for nm, v in times.items()}, "us; bitwise equal:",
       [bool(torch.equal(outs[0], o)) for o in outs], "finite:", bool(torch.isfinite(outs[-1].float()).all()))
+# GroupNorm mode (HuBERT-base): stats + finalize + main kernel
+T0 = R0
+outs = [torch.zeros(B * R0 + 8, C, device=dev, dtype=torch.bfloat16) for _ in libs]
+times = {nm: [] for nm, _ in libs}
+for r in range(6):
+    for i, (nm, Lb) in enumerate(libs):
+        _lib._LIB = Lb
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            ops.conv0_groupnorm_gelu(wav, w0, g, be, T0, R0, outs[i])
+        e1.record()
+        torch.cuda.synchronize()
+        if r:
+            times[nm].append(e0.elapsed_time(e1) / 3)
+print("group_norm mode (stats + finalize + main)", {nm: round(sorted(v)[len(v) // 2] * 1e3, 1) for nm, v in times.items()}, "us; bitwise equal:",
+      [bool(torch.equal(outs[0], o)) for o in outs])
