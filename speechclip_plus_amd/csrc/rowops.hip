@@ -534,6 +534,39 @@ __global__ __launch_bounds__(256) void wsum_fwd_seg_kernel(const uint16_t* __res
     }
 }
 
+// The same sum for a layer count known at compile time (13 / 25: base / large), one 16-byte chunk per thread (round 5): grid (chunks of an
+// utterance's Rout rows / 256, B) - no 64-bit divisions, no grid-stride loop -, the NLT weights in registers under constant indices (the
+// generic kernel above indexes its weight array with a loop variable: v_movrel sequences), all NLT loads of a chunk in flight before
+// the first multiply-add.  Same additions in the same order: same bits.
+template <int NLT>
+__global__ __launch_bounds__(256) void wsum_fwd_seg_fixed_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w,
+                                                                 uint16_t* __restrict__ out, const int32_t* __restrict__ row0, int Rout,
+                                                                 int D, int row_off, int64_t plane) {
+    const int cpr = D >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Rout * cpr) return;
+    const int b = blockIdx.y;
+    const int s = idx / cpr, cc = idx - s * cpr, t = s - row_off;
+    const int r0 = row0[b], pitch = row0[b + 1] - r0;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t >= 0 && t < pitch) {
+        const uint16_t* src = h + (int64_t)(r0 + t) * D + cc * 8;
+        uint4 u[NLT];
+#pragma unroll
+        for (int n = 0; n < NLT; ++n) u[n] = *(const uint4*)(src + n * plane);
+#pragma unroll
+        for (int n = 0; n < NLT; ++n) {
+            const float wn = w[n];
+            acc[0] += wn * bflo(u[n].x); acc[1] += wn * bfhi(u[n].x); acc[2] += wn * bflo(u[n].y); acc[3] += wn * bfhi(u[n].y);
+            acc[4] += wn * bflo(u[n].z); acc[5] += wn * bfhi(u[n].z); acc[6] += wn * bflo(u[n].w); acc[7] += wn * bfhi(u[n].w);
+        }
+    }
+    uint4 o;
+    o.x = pack2bf(acc[0], acc[1]); o.y = pack2bf(acc[2], acc[3]);
+    o.z = pack2bf(acc[4], acc[5]); o.w = pack2bf(acc[6], acc[7]);
+    *(uint4*)(out + ((int64_t)b * Rout + s) * D + cc * 8) = o;
+}
+
 // as wsum_bwd_kernel, g in the uniform [B, Rout, D] layout, h in the segment layout
 template <typename GT>
 __global__ __launch_bounds__(256) void wsum_bwd_seg_kernel(const uint16_t* __restrict__ h, const GT* __restrict__ g, int NL,
@@ -833,6 +866,13 @@ extern "C" int sc_wsum_fwd_seg(const sc_bf16* h, const float* w, int32_t NL, sc_
         return 0;
     }
     const int64_t total = (int64_t)B * Rout * (D / 8);
+    if ((NL == 13 || NL == 25) && (int64_t)Rout * (D / 8) < (1ll << 30) && B <= 65535 && !sc_option(5)) {      // option 5: A/B switch (tools/)
+        const dim3 g2((unsigned)(((int64_t)Rout * (D / 8) + 255) / 256), (unsigned)B);
+        if (NL == 13) hipLaunchKernelGGL(wsum_fwd_seg_fixed_kernel<13>, g2, dim3(256), 0, s, h, w, out, seg->row0, Rout, D, row_off, plane);
+        else hipLaunchKernelGGL(wsum_fwd_seg_fixed_kernel<25>, g2, dim3(256), 0, s, h, w, out, seg->row0, Rout, D, row_off, plane);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(wsum_fwd_seg_kernel, dim3(grid), dim3(256), 0, s, h, w, NL, out, seg->row0, B, Rout, D, row_off, plane);
     SC_LAUNCH_CHECK();

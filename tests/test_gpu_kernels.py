@@ -286,6 +286,46 @@ def test_weighted_sum_golden(dev, golden):
     np.testing.assert_allclose(layer.weights.grad.cpu().numpy(), fx["dweights"], rtol=0.05, atol=0.02)
 
 
+def test_weighted_sum_over_segments_fixed_layer_count_kernel(dev):
+    """Round 5: sc_wsum_fwd_seg takes a one-chunk-per-thread kernel with the layer count as a compile-time constant for NL = 13 / 25 (base /
+    large).  It must compute what the generic kernel computes (sc_set_option(5, 1) selects the generic one): the same fp32 multiply-adds
+    in the same order - the compiler's contraction choices may differ, so at most one bf16 ulp on a few elements per million - and both
+    within half an ulp + fp32 round-off of the exact sum; every row of the uniform output written, zeros outside the utterances."""
+    from speechclip_plus_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(12)
+    B, T, D, R, off = 6, 77, 768, 80, 1
+    for NL in (13, 25, 7):                       # 7: no fixed instance, both calls take the generic kernel
+        lens = [T, 5, 40, 77, 1, 63]
+        pitch = [(l + 1 + 7) // 8 * 8 for l in lens]
+        seg = ops.RowSegments(pitch, lens, dev)
+        h = bf(torch.randn(NL, seg.rows, D, generator=g)).to(dev)
+        w = torch.softmax(torch.randn(NL, generator=g), 0).to(dev)
+        outs = []
+        try:
+            for opt in (0, 1):
+                _lib.lib().sc_set_option(5, opt)
+                out = torch.full((B, R, D), 7.0, device=dev, dtype=torch.bfloat16)
+                ops.wsum_fwd(h, w, out, B, R, D, off, seg=seg)
+                outs.append(out.float())
+        finally:
+            _lib.lib().sc_set_option(5, 0)
+        ref = torch.zeros(B, R, D, device=dev, dtype=torch.float64)
+        r0 = 0
+        for b in range(B):
+            n = min(pitch[b], R - off)
+            ref[b, off: off + n] = (w.view(-1, 1, 1).double() * h[:, r0: r0 + n].double()).sum(0)
+            r0 += pitch[b]
+        ulp = torch.clamp(ref.abs(), min=2.0 ** -126).log2().floor().exp2() * 2.0 ** -7          # one bf16 ulp at the value
+        for o in outs:
+            assert bool(((o.double() - ref).abs() <= 0.5 * ulp + 1e-5).all()), NL
+            assert float(o[:, :off].abs().max()) == 0.0
+        d = (outs[0] - outs[1]).abs().double()
+        assert bool((d <= ulp).all()) and float((d > 0).double().mean()) < 1e-3, (NL, float(d.max()))
+        if NL == 7:
+            assert torch.equal(outs[0], outs[1])
+
+
 def test_weighted_sum_normalized(dev, golden):
     """normalize_features=True (HuBERT-large recipes): forward against the reference leaf (wsum.npz out_norm), weight
     gradient against fp32 torch autograd on the same bf16-rounded inputs; also at D = 1024."""
