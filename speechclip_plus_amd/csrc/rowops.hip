@@ -610,6 +610,50 @@ __global__ __launch_bounds__(256) void wsum_bwd_seg_kernel(const uint16_t* __res
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// wsum_bwd_seg_kernel for a layer count known at compile time (round 5): the same elements per thread in the same order (grid-stride over the
+// 16-byte chunks of the uniform gradient), but 32-bit index arithmetic (the generic kernel spends two 64-bit divisions per chunk), every load of a
+// chunk in flight before the first use, and NLT - 1 wavefront reductions instead of 32.
+template <int NLT, typename GT>
+__global__ __launch_bounds__(256) void wsum_bwd_seg_fixed_kernel(const uint16_t* __restrict__ h, const GT* __restrict__ g,
+                                                                 float* __restrict__ dw_partial, const int32_t* __restrict__ row0, int B, int Rout,
+                                                                 int D, int row_off, int64_t plane) {
+    __shared__ float red[4][32];
+    const uint32_t cpr = (uint32_t)D >> 3, total = (uint32_t)B * (uint32_t)Rout * cpr, step = gridDim.x * 256u;
+    float acc[NLT - 1];
+#pragma unroll
+    for (int n = 0; n < NLT - 1; ++n) acc[n] = 0.f;
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < total; q += step) {
+        const uint32_t orow = q / cpr, cc = q - orow * cpr;
+        const uint32_t b = orow / (uint32_t)Rout;
+        const int t = (int)(orow - b * (uint32_t)Rout) - row_off;
+        const int r0 = row0[b], pitch = row0[b + 1] - r0;
+        if (t < 0 || t >= pitch) continue;
+        f32x4 g0, g1;
+        load_g8(g + (int64_t)orow * D + cc * 8, g0, g1);
+        const uint16_t* src = h + (int64_t)(r0 + t) * D + cc * 8;
+        const uint4 r = *(const uint4*)(src + (int64_t)(NLT - 1) * plane);
+        uint4 u[NLT - 1];
+#pragma unroll
+        for (int n = 0; n < NLT - 1; ++n) u[n] = *(const uint4*)(src + n * plane);
+#pragma unroll
+        for (int n = 0; n < NLT - 1; ++n)
+            acc[n] += g0[0] * (bflo(u[n].x) - bflo(r.x)) + g0[1] * (bfhi(u[n].x) - bfhi(r.x)) + g0[2] * (bflo(u[n].y) - bflo(r.y)) +
+                      g0[3] * (bfhi(u[n].y) - bfhi(r.y)) + g1[0] * (bflo(u[n].z) - bflo(r.z)) + g1[1] * (bfhi(u[n].z) - bfhi(r.z)) +
+                      g1[2] * (bflo(u[n].w) - bflo(r.w)) + g1[3] * (bfhi(u[n].w) - bfhi(r.w));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < NLT - 1; ++n) {
+        const float sn = wave_sum(acc[n]);
+        if (lane == 0) red[wave][n] = sn;
+    }
+    if (lane == 0) red[wave][NLT - 1] = 0.f;          // the last layer's entry: zero (everything is relative to it)
+    __syncthreads();
+    if (threadIdx.x < NLT)
+        dw_partial[(int64_t)blockIdx.x * NLT + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 template <int NE>
 __global__ __launch_bounds__(256) void wsum_norm_fwd_seg_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w, int NL,
                                                                 uint16_t* __restrict__ out, const int32_t* __restrict__ row0, int B, int Rout,
@@ -898,6 +942,17 @@ extern "C" int sc_wsum_bwd_seg(const sc_bf16* h, const void* gv, int32_t NL, flo
         } else {
             if (g16) hipLaunchKernelGGL((wsum_norm_bwd_seg_kernel<2, uint16_t>), dim3(nblk), dim3(256), 0, s, h, gh, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
             else hipLaunchKernelGGL((wsum_norm_bwd_seg_kernel<2, float>), dim3(nblk), dim3(256), 0, s, h, g, NL, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+        }
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
+    if ((NL == 13 || NL == 25) && (int64_t)B * Rout * (D / 8) < (1ll << 31) && !sc_option(5)) {      // option 5: A/B switch (tools/)
+        if (NL == 13) {
+            if (g16) hipLaunchKernelGGL((wsum_bwd_seg_fixed_kernel<13, uint16_t>), dim3(nblk), dim3(256), 0, s, h, gh, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+            else hipLaunchKernelGGL((wsum_bwd_seg_fixed_kernel<13, float>), dim3(nblk), dim3(256), 0, s, h, g, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+        } else {
+            if (g16) hipLaunchKernelGGL((wsum_bwd_seg_fixed_kernel<25, uint16_t>), dim3(nblk), dim3(256), 0, s, h, gh, dw_partial, seg->row0, B, Rout, D, row_off, plane);
+            else hipLaunchKernelGGL((wsum_bwd_seg_fixed_kernel<25, float>), dim3(nblk), dim3(256), 0, s, h, g, dw_partial, seg->row0, B, Rout, D, row_off, plane);
         }
         SC_LAUNCH_CHECK();
         return 0;

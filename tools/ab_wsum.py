@@ -41,4 +41,23 @@ for NL, ragged in ((13, False), (13, True), (25, False)):
     print("NL", NL, "ragged", ragged, "rows", seg.rows, res, "us; bitwise equal:", bool(torch.equal(outs[0], outs[1])), "differing elements",
           int((d > 0).sum()), "of", d.numel(), "max", float(d.max()), "| error vs fp64 sum: generic", float((outs[0].float() - ref).abs().max()),
           "fixed", float((outs[1].float() - ref).abs().max()))
+    # backward: gradient of the weight logits from g [B, R, D] (fp32 and bf16)
+    for gdt in (torch.float32, torch.bfloat16):
+        gg = torch.randn(B, R, D, device=dev).to(gdt)
+        res, outs = {}, []
+        for opt in (1, 0, 1, 0):
+            _lib.lib().sc_set_option(5, opt)
+            for _ in range(3):
+                o = ops.wsum_bwd_logits(h, gg, w, B, R, D, 1, seg=seg)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                o = ops.wsum_bwd_logits(h, gg, w, B, R, D, 1, seg=seg)
+            e1.record()
+            torch.cuda.synchronize()
+            res.setdefault("generic" if opt else "fixed", []).append(round(e0.elapsed_time(e1) * 100, 1))
+            outs.append(o)
+        print("   backward, g", str(gdt).split(".")[-1], res, "us (two launches); max rel diff", float(((outs[0] - outs[1]).abs() / outs[0].abs().clamp(min=1e-6)).max()),
+              "equal", bool(torch.equal(outs[0], outs[1])))
 _lib.lib().sc_set_option(5, 0)
