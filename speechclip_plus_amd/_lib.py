@@ -4,6 +4,7 @@ There is NO fallback: if the library is missing or a symbol cannot be resolved t
 every op in ``speechclip_plus_amd.ops`` fails loudly.  Build with ``python -m speechclip_plus_amd.build``
 (or ``__graft_entry__.build()``).
 """
+import contextlib
 import ctypes
 import os
 
@@ -239,8 +240,10 @@ SIGNATURES = {
 }
 
 DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libspeechclip_hip_diag.so")
+GELU_EXACT_LIB_PATH = os.path.join(_HERE, "csrc", "libspeechclip_hip_gelu_exact.so")   # checker build (build.py), tests only
 _LIB = None
 _DIAG = None
+_VARIANTS = {}
 
 
 def lib() -> ctypes.CDLL:
@@ -249,6 +252,20 @@ def lib() -> ctypes.CDLL:
     if _LIB is None:
         _LIB = _load(LIB_PATH)
     return _LIB
+
+
+@contextlib.contextmanager
+def using_library(path: str):
+    """Tests / A-B tools only: route every op through another build of the SAME ABI (e.g. GELU_EXACT_LIB_PATH) inside the block, in one
+    process, so two builds see identical inputs.  The libraries hold no state the ops share (weight copies live in torch tensors)."""
+    global _LIB
+    if path not in _VARIANTS:
+        _VARIANTS[path] = _load(path)
+    prev, _LIB = lib(), _VARIANTS[path]
+    try:
+        yield _LIB
+    finally:
+        _LIB = prev
 
 
 def diag_lib() -> ctypes.CDLL:

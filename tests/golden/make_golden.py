@@ -16,6 +16,8 @@ Fixtures:
   wsum.npz         WeightedSumLayer (avssl/module/weighted_sum.py)
   masks.npz        get_keypadding_mask (avssl/util/data_utils.py) + the three length rules
   retrieval.npz    mutualRetrieval (avssl/module/retrieval.py)
+  clip_text_w64.npz transformers.CLIPTextModelWithProjection (independent implementation, local config): the
+                   cross-check of the openai/CLIP text tower restated in oracle/cascaded_ref.py
   hubert_small.npz transformers.HubertModel (independent implementation, local config) outputs for a
                    tiny HuBERT: the only available cross-check at the fairseq boundary
 """
@@ -412,6 +414,77 @@ def make_cascaded():
         init_weight=bn.bn_layer.weight, init_bias=bn.bn_layer.bias)
 
 
+# --------------------------------------------------------------------------- CLIP text tower (HF cross-check)
+def make_clip_text():
+    """openai/CLIP is absent offline (requirements.txt:4), so the text tower every cascaded+/hybrid+ embedding flows through
+    (clip_official.py:222-279) is cross-checked the way HuBERT is: against transformers' INDEPENDENT implementation built from a
+    local config.  The HF model runs (a) its own forward on plain token ids and (b) its encoder on hand-spliced embeddings with
+    an explicit additive causal mask (what encode_keywords feeds the tower: sot, n keyword vectors, eot, token 0 ...); weights are
+    stored under openai/CLIP's names so the oracle reads them as it reads the reference's state dict."""
+    for name, seed, Wd, heads, E in [("clip_text_w64", 41, 64, 4, 24), ("clip_text_w128", 42, 128, 2, 32)]:
+        _clip_text_case(name, seed, Wd, heads, E)
+
+
+def _clip_text_case(name, seed, Wd, heads, E):
+    """w64: head_dim 16; w128: head_dim 64 = what the HIP tower is built for (the -m gpu test runs on this one)."""
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    torch.manual_seed(seed)
+    layers, V, S = 2, 100, 77
+    sot, eot = V - 2, V - 1
+    cfg = CLIPTextConfig(vocab_size=V, hidden_size=Wd, intermediate_size=4 * Wd, projection_dim=E, num_hidden_layers=layers,
+                         num_attention_heads=heads, max_position_embeddings=S, hidden_act="quick_gelu", bos_token_id=sot,
+                         eos_token_id=eot, pad_token_id=0, attention_dropout=0.0)
+    cfg._attn_implementation = "eager"
+    hf = CLIPTextModelWithProjection(cfg).eval()
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if "norm" in n or n.endswith("bias"):
+                p.add_(0.1 * torch.randn_like(p))
+            elif "embedding" in n or "projection" in n:
+                p.copy_(torch.randn_like(p) * (0.3 if "token" in n else 0.1))
+    sd = hf.state_dict()
+    P = "clip.model."
+    W = {P + "token_embedding.weight": sd["text_model.embeddings.token_embedding.weight"],
+         P + "positional_embedding": sd["text_model.embeddings.position_embedding.weight"],
+         P + "ln_final.weight": sd["text_model.final_layer_norm.weight"], P + "ln_final.bias": sd["text_model.final_layer_norm.bias"],
+         P + "text_projection": sd["text_projection.weight"].t().contiguous()}
+    for i in range(layers):
+        a, b = f"text_model.encoder.layers.{i}.", f"{P}transformer.resblocks.{i}."
+        W[b + "attn.in_proj_weight"] = torch.cat([sd[a + f"self_attn.{n}_proj.weight"] for n in "qkv"])
+        W[b + "attn.in_proj_bias"] = torch.cat([sd[a + f"self_attn.{n}_proj.bias"] for n in "qkv"])
+        for src, dst in [("self_attn.out_proj", "attn.out_proj"), ("layer_norm1", "ln_1"), ("layer_norm2", "ln_2"),
+                         ("mlp.fc1", "mlp.c_fc"), ("mlp.fc2", "mlp.c_proj")]:
+            W[b + dst + ".weight"], W[b + dst + ".bias"] = sd[a + src + ".weight"], sd[a + src + ".bias"]
+    # (a) plain token ids through HF's own forward (its embeddings, its causal mask, its EOS pooling, its projection)
+    n_kw = torch.tensor([3, 1, 75, 10, 8])
+    B = len(n_kw)
+    ids = torch.zeros(B, S, dtype=torch.long)
+    ids[:, 0] = sot
+    tok = torch.randint(4, V - 2, (B, 75))
+    for b in range(B):
+        ids[b, 1: 1 + n_kw[b]] = tok[b, : n_kw[b]]
+        ids[b, 1 + n_kw[b]] = eot
+    with torch.no_grad():
+        out_ids = hf(input_ids=ids)
+    # (b) spliced continuous keyword vectors through HF's encoder layers
+    kw = (torch.randn(B, 75, Wd) * 0.3).requires_grad_(True)
+    emb = sd["text_model.embeddings.token_embedding.weight"]
+    rows = []
+    for b in range(B):
+        n = int(n_kw[b])
+        rows.append(torch.cat([emb[sot][None], kw[b, :n], emb[eot][None], emb[0].expand(S - 2 - n, Wd)]))
+    x = torch.stack(rows) + sd["text_model.embeddings.position_embedding.weight"]
+    causal = torch.full((S, S), float("-inf")).triu_(1)[None, None].expand(B, 1, S, S)
+    h = hf.text_model.encoder(inputs_embeds=x, attention_mask=causal).last_hidden_state
+    last = hf.text_model.final_layer_norm(h)
+    out_kw = hf.text_projection(last[torch.arange(B), n_kw + 1])
+    gout = torch.randn_like(out_kw)
+    (out_kw * gout).sum().backward()
+    npz(name + ".npz", ids=ids, tok=tok, n_kw=n_kw, out_ids=out_ids.text_embeds, last_hidden_ids=out_ids.last_hidden_state,
+        kw=kw, tower_out_kw=h.detach(), out_kw=out_kw, gout=gout, g_kw=kw.grad, heads=np.int64(heads), sot=np.int64(sot),
+        eot=np.int64(eot), **{"W_" + k: v for k, v in W.items()})
+
+
 # --------------------------------------------------------------------------- in-forward training crop
 def make_crop():
     """random_crop_max_length (avssl/data/audio_transforms.py:5-23) driven exactly as speech_encoder_plus.py:548-552 drives it: a
@@ -441,6 +514,6 @@ def make_crop():
 
 
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["loss", "head", "mha", "loss_variants", "wsum", "masks", "retrieval", "hubert", "cascaded", "crop"]
+    todo = sys.argv[1:] or ["loss", "head", "mha", "loss_variants", "wsum", "masks", "retrieval", "hubert", "cascaded", "crop", "clip_text"]
     for what in todo:                       # e.g. `make_golden.py mha loss_variants` regenerates only those fixtures
         globals()["make_" + what]()

@@ -189,6 +189,49 @@ def test_clip_text_tower_kernels_match_the_oracle():
 
 
 @pytest.mark.gpu
+def test_clip_text_tower_vs_hf_fixture(golden):
+    """The product's frozen text tower (clip_text.ClipModel.encode_keywords -> clip_text_hip.KeywordTowerFn / TextTowerFn) against
+    the fixture transformers' independent CLIPTextModelWithProjection produced (tests/golden/make_golden.py make_clip_text, width
+    128 / 2 heads = head_dim 64, 2 layers): plain token ids, spliced keyword vectors with per-sample counts from 1 to 75 (segments
+    of 128 rows), the input gradient through the frozen tower, and the tower's 77 output rows.  Tolerances: bf16 storage between
+    kernels, fp32 accumulate - rel-L2 2e-2 on outputs, 4e-2 on the gradient (the bounds the oracle comparison uses)."""
+    import numpy as np
+    from conftest import weights_from
+    from speechclip_plus_amd import clip_text
+    fx = golden("clip_text_w128.npz")
+    W = {k[len("clip.model."):]: v for k, v in weights_from(fx).items()}
+    V = W["token_embedding.weight"].shape[0]
+    clip_text.CLIP_TEXT_ARCHS["hf-fixture-w128"] = dict(width=128, heads=int(fx["heads"]), layers=2, embed_dim=W["text_projection"].shape[1])
+    try:
+        ids = torch.cat([torch.arange(V - 2), torch.tensor([clip_text.SOT_TOKEN, clip_text.EOT_TOKEN])])
+        clip = clip_text.ClipModel("hf-fixture-w128", device="cuda:0", reduce_subword_embbedding=ids).eval()
+    finally:
+        del clip_text.CLIP_TEXT_ARCHS["hf-fixture-w128"]
+    assert (clip.startOfTxt_reduced, clip.endOfTxt_reduced) == (int(fx["sot"]), int(fx["eot"]))
+    clip.model.load_state_dict({k: v for k, v in W.items()}, strict=True)
+    rel = lambda a, b: float((a.detach().cpu().float() - torch.from_numpy(b)).norm() / torch.from_numpy(b).norm())
+    n_kw = torch.from_numpy(fx["n_kw"]).cuda()
+    emb = clip.model.token_embedding.weight
+    out = clip.encode_keywords(emb[torch.from_numpy(fx["tok"]).cuda()], n_kw)
+    assert rel(out, fx["out_ids"]) < 2e-2, rel(out, fx["out_ids"])
+    kw = torch.from_numpy(fx["kw"]).cuda().requires_grad_()
+    out = clip.encode_keywords(kw, n_kw)
+    assert rel(out, fx["out_kw"]) < 2e-2, rel(out, fx["out_kw"])
+    out.backward(torch.from_numpy(fx["gout"]).cuda())
+    assert rel(kw.grad, fx["g_kw"]) < 4e-2, rel(kw.grad, fx["g_kw"])
+    for b, n in enumerate(fx["n_kw"].tolist()):
+        assert float(kw.grad[b, n:].abs().sum()) == 0
+    # the transformer alone on the full 77-token prompt
+    x = emb[0].detach().expand(len(n_kw), 77, -1).clone()
+    x[:, 0] = emb[int(fx["sot"])]
+    for b, n in enumerate(fx["n_kw"].tolist()):
+        x[b, 1: 1 + n] = kw.detach()[b, :n]
+        x[b, 1 + n] = emb[int(fx["eot"])]
+    h = clip._transformer(x + clip.model.positional_embedding)
+    assert rel(h, fx["tower_out_kw"]) < 2e-2, rel(h, fx["tower_out_kw"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["cascaded", "hybrid"])
 def test_branch_rows_hand_over_falls_back_when_the_buffer_has_no_padding_rows(kind):
     """CIF reads the attention block's rows in place only when the buffer has zero rows behind every utterance for the weight conv's

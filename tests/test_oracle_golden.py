@@ -201,6 +201,33 @@ def test_hubert_vs_hf(golden, name):
     assert feat_len.tolist() == feat_len_rule(lens, Tn)
 
 
+@pytest.mark.parametrize("name", ["clip_text_w64", "clip_text_w128"])
+def test_clip_text_tower_vs_hf(golden, name):
+    """oracle.clip_text_transformer / clip_encode_keywords (the restatement of openai/CLIP's text tower as clip_official.py:222-279
+    drives it) against transformers' independent CLIPTextModelWithProjection (tests/golden/make_golden.py make_clip_text): plain
+    token ids, spliced continuous keyword vectors, and the gradient that flows back through the frozen tower."""
+    fx = golden(name + ".npz")
+    W = weights_from(fx)
+    heads, sot, eot = int(fx["heads"]), int(fx["sot"]), int(fx["eot"])
+    n_kw = T(fx["n_kw"])
+    emb = W["clip.model.token_embedding.weight"]
+    out = oracle.clip_encode_keywords(W, "clip.model.", emb[T(fx["tok"])], n_kw, heads, sot, eot)
+    np.testing.assert_allclose(out.numpy(), fx["out_ids"], rtol=1e-4, atol=2e-5)
+    kw = T(fx["kw"]).clone().requires_grad_(True)
+    out = oracle.clip_encode_keywords(W, "clip.model.", kw, n_kw, heads, sot, eot)
+    np.testing.assert_allclose(out.detach().numpy(), fx["out_kw"], rtol=1e-4, atol=2e-5)
+    (out * T(fx["gout"])).sum().backward()
+    np.testing.assert_allclose(kw.grad.numpy(), fx["g_kw"], rtol=1e-3, atol=2e-6)
+    # the tower alone (before ln_final / pooling), every one of the 77 rows
+    x = emb[0].expand(len(n_kw), 77, -1).clone()
+    x[:, 0] = emb[sot]
+    for b, n in enumerate(n_kw.tolist()):
+        x[b, 1: 1 + n] = T(fx["kw"])[b, :n]
+        x[b, 1 + n] = emb[eot]
+    h = oracle.clip_text_transformer(W, "clip.model.", x + W["clip.model.positional_embedding"], heads)
+    np.testing.assert_allclose(h.numpy(), fx["tower_out_kw"], rtol=1e-4, atol=5e-5)
+
+
 def test_head_train_mode_dropout_sites_vs_torch_layer():
     """Train mode of the oracle head (drop hook) against torch's own nn.TransformerEncoderLayer - the module the reference
     instantiates (avssl/module/kw_modules/TransformerModels.py:62-73) - in train mode, with its three nn.Dropout modules
