@@ -224,7 +224,8 @@ def main():
                        "schedule": ("frozen encoder of step N + 1 enqueued on its own HIP stream under step N's head / loss / backward / "
                                     "optimiser kernels (two alternating sets of resident buffers; every step's full work inside the "
                                     "timed region; SC_ENC_OVERLAP=0 = one stream)"
-                                    if getattr(model.audio_encoder, "enc_overlap", False) and not args.trainable else "one stream per step")},
+                                    if getattr(model.audio_encoder, "enc_overlap", False) and not args.trainable else "one stream per step"),
+                       "hw_queues": __import__("speechclip_plus_amd").hw_queue_status()},
             "rccl_ranks": rccl_ranks, "dist_backend": (os.environ.get("SC_DIST_BACKEND", "nccl") if dist is not None else None),
             "collectives": collectives,
             "loss": round(loss_val, 5), "roofline": roof, "kernels": extra, "cpu_baseline": cpu,

@@ -25,7 +25,7 @@ Pinning status (see DESIGN.md "Oracle"):
 from .lengths import (conv_out_lengths, fairseq_valid_frames, feat_len_rule,
                       get_keypadding_mask)
 from .hubert_ref import (HubertArch, hubert_forward, init_hubert_weights, speech_encoder_forward, bf16_store,
-                         bf16_weights)
+                         bf16_weights, SitedStore)
 from .head_ref import (weighted_sum, parallel_branch_forward, init_parallel_branch_weights,
                        transformer_encoder_forward, mha_and_norm_forward)
 from .loss_ref import masked_contrastive_loss

@@ -131,6 +131,27 @@ def _keep(t):
     return t
 
 
+def _site(store, name: str):
+    """The rounding applied at storage site class ``name``: identity without a store; the store itself for a plain callable
+    (bf16_store: every site); for a ``SitedStore`` only the classes it lists (tools/storage_ablation.py: which site moves recall)."""
+    if store is None:
+        return _keep
+    if isinstance(store, SitedStore):
+        return store.fn if name in store.sites else _keep
+    return store
+
+
+class SitedStore:
+    """bf16 rounding at a SUBSET of the storage site classes: "conv" (conv stack outputs), "ln" (every LayerNorm output incl. the feature
+    and encoder LayerNorms), "proj" (post_extract_proj output), "residual" (the pos_conv sum and both residual sums of every layer), "qkv",
+    "p" (un-normalised attention probabilities in front of P.V), "ctx" (attention context), "ffn_act" (GELU(fc1))."""
+    ALL = ("conv", "ln", "proj", "residual", "qkv", "p", "ctx", "ffn_act")
+
+    def __init__(self, sites, fn=bf16_store):
+        assert set(sites) <= set(self.ALL), sites
+        self.sites, self.fn = frozenset(sites), fn
+
+
 def fold_weight_norm(weight_g: torch.Tensor, weight_v: torch.Tensor) -> torch.Tensor:
     """nn.utils.weight_norm(conv, dim=2): w = g * v / ||v|| with the norm over dims (0, 1)."""
     n = weight_v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
@@ -152,7 +173,7 @@ def preprocess_input(wavs: Sequence[torch.Tensor], normalize: bool):
 
 def conv_feature_extractor(W, arch: HubertArch, x: torch.Tensor, collect: Optional[list] = None, store=None) -> torch.Tensor:
     """fairseq ConvFeatureExtractionModel.forward: (B, L) -> (B, C, T)."""
-    st = store or _keep
+    st = _site(store, "conv")
     x = x.unsqueeze(1)
     for i, (k, s) in enumerate(zip(arch.conv_kernels, arch.conv_strides)):
         w = W[f"feature_extractor.conv_layers.{i}.0.weight"]
@@ -188,7 +209,7 @@ def self_attention(W, p: str, x: torch.Tensor, key_padding_mask: Optional[torch.
     probabilities (B, H, T, T), fairseq's dropout_module(attn_weights)."""
     B, T, D = x.shape
     dh = D // heads
-    st = store or _keep
+    st, st_p, st_ctx = _site(store, "qkv"), _site(store, "p"), _site(store, "ctx")
     # fairseq scales q before the product; dh^-0.5 = 1/8 is a power of two, so scaling the stored (bf16) q commutes with the rounding
     q = st(F.linear(x, W[p + "q_proj.weight"], W[p + "q_proj.bias"])) * dh ** -0.5
     k = st(F.linear(x, W[p + "k_proj.weight"], W[p + "k_proj.bias"]))
@@ -207,8 +228,8 @@ def self_attention(W, p: str, x: torch.Tensor, key_padding_mask: Optional[torch.
     else:               # flash form: un-normalised probabilities rounded in front of P.V, fp32 row sum, one division at the end
         assert drop is None
         e = torch.exp(s.float() - s.float().amax(dim=-1, keepdim=True))
-        o = (st(e) @ v) / e.sum(dim=-1, keepdim=True)
-    o = st(o.transpose(1, 2).reshape(B, T, D))
+        o = (st_p(e) @ v) / e.sum(dim=-1, keepdim=True)
+    o = st_ctx(o.transpose(1, 2).reshape(B, T, D))
     return F.linear(o, W[p + "out_proj.weight"], W[p + "out_proj.bias"])
 
 
@@ -223,13 +244,13 @@ def encoder_layer(W, arch: HubertArch, i: int, x: torch.Tensor, kpm: Optional[to
     d1 = (lambda t: drop("dropout1", i, t)) if drop is not None else (lambda t: t)
     d3 = (lambda t: drop("dropout3", i, t)) if drop is not None else (lambda t: t)
 
-    st = store or _keep
+    st, st_ln, st_act = _site(store, "residual"), _site(store, "ln"), _site(store, "ffn_act")
 
     def ln(name, t):
-        return st(F.layer_norm(t, (D,), W[p + name + ".weight"], W[p + name + ".bias"], 1e-5))
+        return st_ln(F.layer_norm(t, (D,), W[p + name + ".weight"], W[p + name + ".bias"], 1e-5))
 
     def ffn(t):
-        return F.linear(st(F.gelu(F.linear(t, W[p + "fc1.weight"], W[p + "fc1.bias"]))), W[p + "fc2.weight"], W[p + "fc2.bias"])
+        return F.linear(st_act(F.gelu(F.linear(t, W[p + "fc1.weight"], W[p + "fc1.bias"]))), W[p + "fc2.weight"], W[p + "fc2.bias"])
 
     if not arch.layer_norm_first:
         x = ln("self_attn_layer_norm", st(x + d1(self_attention(W, p + "self_attn.", x, kpm, arch.heads, d_att, store))))
@@ -250,17 +271,17 @@ def hubert_forward(W, arch: HubertArch, padded_wav: torch.Tensor, wav_padding_ma
     LayerNorm, :42) and the per-layer sites of encoder_layer; the caller supplies the masks (the oracle has no RNG of its own).
 
     Returns layer_results = [encoder input, out_1 .. out_NL], each (B, T, D)."""
-    st = store or _keep
+    st, st_ln, st_proj = _site(store, "residual"), _site(store, "ln"), _site(store, "proj")
     conv_outs = [] if debug is not None else None
     feats = conv_feature_extractor(W, arch, padded_wav, conv_outs, store)   # :75
     fgm = getattr(arch, "feature_grad_mult", 1.0)
     if fgm != 1.0 and feats.requires_grad:                                   # fairseq HubertModel.forward: GradMultiply.apply(features,
         feats = feats * fgm + feats.detach() * (1.0 - fgm)                   # feature_grad_mult): identity forward, scaled backward
     feats = feats.transpose(1, 2)                                            # :77
-    feats = st(F.layer_norm(feats, (arch.conv_dim,), W["layer_norm.weight"], W["layer_norm.bias"], 1e-5))  # :78
+    feats = st_ln(F.layer_norm(feats, (arch.conv_dim,), W["layer_norm.weight"], W["layer_norm.bias"], 1e-5))  # :78
     T = feats.shape[1]
     pm = forward_padding_mask(T, wav_padding_mask) if wav_padding_mask is not None else None        # :81-82
-    x = st(F.linear(feats, W["post_extract_proj.weight"], W["post_extract_proj.bias"]))             # :84-85
+    x = st_proj(F.linear(feats, W["post_extract_proj.weight"], W["post_extract_proj.bias"]))        # :84-85
     if debug is not None:
         debug["conv"] = conv_outs
         debug["proj"] = x.clone()
@@ -278,7 +299,7 @@ def hubert_forward(W, arch: HubertArch, padded_wav: torch.Tensor, wav_padding_ma
     xc = F.gelu(xc).transpose(1, 2)                                          # :35-36
     x = st(x + xc)                                                           # :37
     if not arch.layer_norm_first:
-        x = st(F.layer_norm(x, (arch.embed_dim,), W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], 1e-5))  # :39-40
+        x = st_ln(F.layer_norm(x, (arch.embed_dim,), W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], 1e-5))  # :39-40
     if drop is not None:
         x = drop("encoder", -1, x)                                           # :42
     layer_results = [x]                                                      # :47

@@ -15,6 +15,7 @@ padded waveform in pinned memory so that copy is asynchronous.
 from typing import Dict, List, Optional, Sequence
 
 import torch
+import torch.utils.data
 
 
 def attach_host_lengths(wav_len: torch.Tensor, host: Optional[Sequence[int]] = None) -> torch.Tensor:
@@ -39,6 +40,8 @@ def transfer_batch_to_device(batch: dict, device, copy_stream: Optional["torch.c
     on an idle copy stream it returns in 20 us (tools/h2d_probe3.py).  No host synchronisation in here when the batch is pinned
     (``collate_general(pin_memory=True)`` / a DataLoader with ``pin_memory=True``); pageable tensors are pinned first (a host copy)."""
     device = torch.device(device)
+    if device.type == "cuda" and device.index is None:        # torch.device("cuda") != cuda:0: compare (and skip) on the resolved index
+        device = torch.device("cuda", torch.cuda.current_device())
     if device.type != "cuda":
         out = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
         if isinstance(batch.get("wav_len"), torch.Tensor):
@@ -55,16 +58,18 @@ def transfer_batch_to_device(batch: dict, device, copy_stream: Optional["torch.c
             if not isinstance(v, torch.Tensor) or v.device == device:
                 out[k] = v
                 continue
-            src = v
-            if not v.is_cuda and not v.is_pinned():
-                src = v.pin_memory()
+            if v.is_cuda:                      # device -> device (another GPU): ordered on the CALLER's stream like any torch op - its
+                with torch.cuda.stream(main):  # producer may still be queued there, and the copy-stream event must not stand in for it
+                    out[k] = v.to(device, non_blocking=True)
+                if k == "wav_len" and getattr(v, "_sc_host", None) is not None:
+                    attach_host_lengths(out[k], v._sc_host)
+                continue
+            src = v if v.is_pinned() else v.pin_memory()
             d = src.to(device, non_blocking=True)
             if k == "wav_len":
-                host = getattr(v, "_sc_host", None) or (v.tolist() if not v.is_cuda else None)
-                if host is not None:
-                    attach_host_lengths(d, host)
+                attach_host_lengths(d, getattr(v, "_sc_host", None) or v.tolist())
             out[k] = d
-            moved.append(d)
+            moved.append(d)                    # host -> device copies only: these are what the event stands for
         ev = torch.cuda.Event()
         ev.record(cs)
     if moved:
@@ -80,7 +85,11 @@ def collate_general(batch: Sequence[dict], pin_memory: bool = False) -> Dict[str
     if len(batch) == 0:
         raise ValueError("empty batch")
     keys: List[str] = list(batch[0].keys())
-    pin = lambda t: bool(pin_memory) and torch.cuda.is_available() and (t is None or not t.is_cuda)     # every tensor of the batch
+    # pin_memory inside a DataLoader WORKER (collate_fn runs there when num_workers > 0, as in the reference's loaders) would initialise
+    # CUDA in a forked process ("Cannot re-initialize CUDA in forked subprocess") or create a GPU context per worker, and pinned-ness
+    # does not survive the worker -> main hand-over anyway: there, leave it to DataLoader(pin_memory=True) + transfer_batch_to_device
+    in_worker = torch.utils.data.get_worker_info() is not None
+    pin = lambda t: bool(pin_memory) and not in_worker and torch.cuda.is_available() and (t is None or not t.is_cuda)     # every tensor
     derive_len = "wav" in keys and isinstance(batch[0]["wav"], torch.Tensor)
     out: Dict[str, torch.Tensor] = {}
     for k in keys:

@@ -485,6 +485,8 @@ def shared_stream(name: str, device=None, priority: int = 0) -> "torch.cuda.Stre
     key = (name, idx)
     st = _shared_streams.get(key)
     if st is None:
+        from . import warn_if_hw_queues_short
+        warn_if_hw_queues_short()               # the first side stream of the process: say so once if the hardware queues cannot carry it
         # priority < 0: a high-priority stream gets a hardware queue of its own priority class - not one of the few normal-priority
         # queues the other roles share (the "h2d" copy stream: queued on the encoder's hardware queue, a batch's copy would start
         # only when the encoder in front of it has finished)

@@ -1005,8 +1005,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 host_src, padded = (wav if wav.dtype == torch.float32 else wav.float()), None
             else:
                 padded = wav.to(self._dev, torch.float32)
-                if padded.stride(1) != 1:
-                    padded = padded.contiguous()
+                if padded.stride(1) != 1 or (padded.shape[0] > 1 and padded.stride(0) < padded.shape[1]):
+                    padded = padded.contiguous()           # also overlapping / zero row strides (wav.expand(B, L), as_strided views)
                 if padded.data_ptr() != wav.data_ptr():
                     ready = None                       # a fresh tensor produced on the caller's stream just now
         else:

@@ -751,6 +751,39 @@ def test_layernorm_bwd_and_act(dev):
         assert rel_l2(ops.act_bf16(u, act, df=df), ur.grad) < 4e-3
 
 
+def test_gelu_fit_vs_exact_build_elementwise(dev):
+    """The shipped erf-GELU of the bf16-output sites (five-term logistic fit, csrc/sc_common.h gelu_bf / gelu_bf2) against the exact-GELU
+    checker build (libspeechclip_hip_gelu_exact.so: A&S 7.1.28, 3e-7) on IDENTICAL inputs in one process, element by element - the
+    high-power half of the paired activation check (ADVICE r05; the model-level half is test_gpu_model.py::test_large_parallel_train_step).
+    4.2 M inputs ~ N(0, 1.5): the two bf16 outputs may differ only where the fit's error (<= 3.1e-6 absolute, <= 2e-5 relative for
+    x >= -1, tools/fit_gelu.py) crosses a rounding boundary.  Criteria fixed before the first run:
+      every difference <= one bf16 ulp (2^-7 relative) or 8e-6 absolute; at most 3 % of the elements differ;
+      |mean signed difference| <= 4e-6 (rounding is unbiased over the inputs, so the mean difference IS the fit's mean error) -
+      a systematic activation error of the size the rejected three-term fit had (2.5e-5) fails this by a factor of six.
+    Both the row kernel (sc_act_bf16) and the FC1-shaped GEMM epilogue (gemm256 tile family, gelu_bf2)."""
+    from speechclip_plus_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(123)
+    u = bf(torch.randn(2048, 2048, generator=g) * 1.5).to(dev)
+    x = bf(torch.randn(2048, 768, generator=g)).to(dev)
+    w = bf(torch.randn(3072, 768, generator=g) * 768 ** -0.5 * 1.5).to(dev)
+    b = (torch.randn(3072, generator=g) * 0.05).to(dev)
+    ship = (ops.act_bf16(u, 1).float(), ops.linear_bf16(x, w, b, act=1).float())
+    with _lib.using_library(_lib.GELU_EXACT_LIB_PATH):
+        exact = (ops.act_bf16(u, 1).float(), ops.linear_bf16(x, w, b, act=1).float())
+    plain = ops.linear_bf16(x, w, b).float()                     # the same GEMM without the activation: identical in both builds
+    with _lib.using_library(_lib.GELU_EXACT_LIB_PATH):
+        assert torch.equal(plain, ops.linear_bf16(x, w, b).float())
+    for name, ys, ye in (("sc_act_bf16", ship[0], exact[0]), ("gemm epilogue", ship[1], exact[1])):
+        d = ys - ye
+        frac = float((d != 0).float().mean())
+        worst = float((d.abs() - torch.maximum(ye.abs() * 2.0 ** -7, torch.full_like(ye, 8e-6))).max())
+        mean = float(d.double().mean())
+        print("%s: %.3f %% of %d elements differ, mean signed difference %.2e, worst excess over one ulp %.1e" % (name, 100 * frac, d.numel(), mean, worst))
+        assert torch.isfinite(ys).all()
+        assert worst <= 0 and frac <= 0.03 and abs(mean) <= 4e-6, (name, worst, frac, mean)
+
+
 def test_transpose_and_weight_gradient(dev):
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(13)

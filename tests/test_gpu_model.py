@@ -265,11 +265,11 @@ def test_large_parallel_train_step():
         wavs, img, ids, batch = _large_parallel_data(seed)
         ship = _product_step(model, batch)
         with torch.no_grad():
-            hs_ship = [h.float().cpu() for h in enc([w.cuda() for w in wavs])[0]["hidden_states"]]
+            hs_ship = [h.float().cpu() for h in enc([w.cuda() for w in wavs], return_hidden_states=True)[2]]
         with _lib.using_library(_lib.GELU_EXACT_LIB_PATH):
             exact = _product_step(model, batch)
             with torch.no_grad():
-                hs_exact = [h.float().cpu() for h in enc([w.cuda() for w in wavs])[0]["hidden_states"]]
+                hs_exact = [h.float().cpu() for h in enc([w.cuda() for w in wavs], return_hidden_states=True)[2]]
         ctrl = _oracle_step(oracle, sd, o_arch, head_W, ws_w, wavs, img, ids, normalize=True, control=True)
         fp32 = _oracle_step(oracle, sd, o_arch, head_W, ws_w, wavs, img, ids, normalize=True)
         r = {"seed": seed, "ship": _step_errors(ship, ctrl), "exact": _step_errors(exact, ctrl), "ship_fp32": _step_errors(ship, fp32),

@@ -380,3 +380,36 @@ def test_flat_optimiser_checkpoint_carries_its_layout():
     other = FlatAdamOptimizer([torch.nn.Parameter(torch.zeros(5))], lr=1e-3)
     with pytest.raises(ValueError):
         other.load_state_dict(sd)
+
+
+def test_hw_queue_status_and_warning(monkeypatch):
+    """The overlapped schedule needs GPU_MAX_HW_QUEUES = 8 when the HIP runtime initialises: the package sets it at
+    import, reports what is effective and warns ONCE where the first side stream is created if the process had the GPU up before."""
+    import warnings
+    import speechclip_plus_amd as pkg
+    st = pkg.hw_queue_status()
+    assert st["wanted"] == 8 and st["hip_initialised_before_import"] is False and st["ok"] == (st["effective"] >= 8)
+    monkeypatch.setattr(pkg, "_HIP_UP_AT_IMPORT", True)
+    monkeypatch.setattr(pkg, "_HWQ_AT_IMPORT", None)
+    monkeypatch.setattr(pkg, "_hwq_warned", False)
+    st = pkg.hw_queue_status()
+    assert st == {"effective": 4, "wanted": 8, "ok": False, "hip_initialised_before_import": True,
+                  "source": "HIP was initialised before speechclip_plus_amd was imported"}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        pkg.warn_if_hw_queues_short()
+        pkg.warn_if_hw_queues_short()
+    assert len(w) == 1 and "GPU_MAX_HW_QUEUES" in str(w[0].message) and "13.3 ms" in str(w[0].message)
+    monkeypatch.setattr(pkg, "_HWQ_AT_IMPORT", "8")            # the user exported it before touching the GPU: fine
+    assert pkg.hw_queue_status()["ok"]
+
+
+def test_collate_general_does_not_pin_inside_a_dataloader_worker(monkeypatch):
+    """collate_fn runs in forked workers when num_workers > 0; pinning there would initialise CUDA per worker."""
+    import torch.utils.data
+    from speechclip_plus_amd import data
+    rows = [{"wav": torch.randn(100 + 10 * i), "id": i} for i in range(3)]
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.utils.data, "get_worker_info", lambda: object())
+    out = data.collate_general(rows, pin_memory=True)            # would try to pin (and fail without a GPU) outside the guard
+    assert not out["wav"].is_pinned() and out["wav_len"]._sc_host == [100, 110, 120]
