@@ -15,9 +15,9 @@
 //   Y  L: read A(m-sub 1) 8 ; DMA B(kt+2) -> this buffer ; s_waitcnt vmcnt(NBI)                     C: (m1, n1), (m1, n0)
 // Phase p spans barrier intervals 2p, 2p+1 for wm = 0 and 2p+1, 2p+2 for wm = 1 (X = 0, Y = 1 of K-tile kt, X = 2 of kt + 1 ...):
 //   WAR  A slot of the other buffer (A(kt-1)): last read in L(Y(kt-1)) - by this group 2 intervals, by the staggered group ONE interval
-//        (and one barrier) before this group's DMA issue in L(X(kt)); B slot (B(kt)): last read in L(X(kt)), re-staged in L(Y(kt)).  A
-//        ds_read issued before the barrier returns the old bytes whatever lands later (LDS requests are served in arrival order, a DMA's
-//        data arrives a memory round trip after its issue);
+//        (and one barrier) before this group's DMA issue in L(X(kt)); B slot (B(kt)): last read in L(X(kt)), re-staged in L(Y(kt)).
+//        Round 6: the barrier that closes an L segment is entered behind s_waitcnt lgkmcnt(0) (SC_BAR_L), so those reads have RETURNED
+//        before any wave passes it - the order is a counter's, not LDS arrival order plus a DMA's memory round trip;
 //   RAW  A(kt+1) (issued X(kt)) and B(kt+1) (issued Y(kt-1)) are retired by every wave's vmcnt(NBI) in L(Y(kt)) and first read in
 //        L(X(kt+1)), one barrier later for either group.
 // The four-phase form (SC_GEMM_4PHASE, A/B builds) as it was:
@@ -66,6 +66,21 @@ constexpr int SC_STAT_STRIDE = 8;                // strips per row in a statisti
         asm volatile("" ::: "memory");         \
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
+
+// The barrier that closes an L segment of the two-phase K loop (round 6): every ds_read of the segment has RETURNED
+// (s_waitcnt lgkmcnt(0)) before the wave enters the barrier, so the other wave group's LDS-DMA into the slot those reads came from -
+// issued one barrier interval later - is ordered behind them by a counter, not by "a DMA takes a memory round trip to arrive".  The
+// MFMAs behind the barrier need the fragments anyway.  Measured on the step's eight GEMM shapes, same box, alternating rounds
+// (tools/ab_gemm_libs.py): 3016 us with the wait vs 3026 us without, bit-identical outputs.  SC_GEMM_NO_LGKM_BAR: the round-5 form (A/B).
+#ifndef SC_GEMM_NO_LGKM_BAR
+#define SC_BAR_L()                                              \
+    do {                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        SC_BAR();                                               \
+    } while (0)
+#else
+#define SC_BAR_L() SC_BAR()
+#endif
 
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             }
             if (LN != 0 && kt == 0) dma_ln(m0, n0);      // older than every later wait of this K loop: in LDS long before the epilogue
             if (kt + 1 < nk) dma_A(par ^ 1, koff(kt + 1));
-            SC_BAR();
+            SC_BAR_L();
             SC_MFMA_QUAD(0, 0, b0);
             SC_MFMA_QUAD(0, 1, b1);
             SC_BAR();
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const sc_gemm_args p) {
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            SC_BAR();
+            SC_BAR_L();
             SC_MFMA_QUAD(1, 1, b1);
             SC_MFMA_QUAD(1, 0, b0);
             SC_BAR();
