@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 
     const int qrow = q0 + l31;                                       // this lane's query
     // attention-probability dropout (fairseq attention_dropout, train mode): P' = mask . P / (1 - p) with the row sum taken
-    // over the un-masked P; element (b, h, q, k) -> sc_hash32 lane as in sc_common.h
-    const uint32_t drop_thr = DROP ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
+    // over the un-masked P; element (b, h, q, k) -> byte of sc_hash32(quad) as in sc_common.h (sc_drop8_*)
+    const uint32_t drop_thr = DROP ? sc_drop8_thr(drop_p) : 0u;        // 8-bit fields: one hash word per four probabilities (sc_common.h)
     const uint32_t drop_row = row0 ? (uint32_t)(h * rows_total + r0 + qrow) * (uint32_t)max_pitch
                                    : (uint32_t)(((b * H + h) * R + qrow)) * (uint32_t)R;
     if (causal) n_valid = min(n_valid, qblk * 128 + 128);           // keys beyond the block's last query are all masked
@@ -227,27 +227,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[s2][j] = (__bf16)pv[8 * s2 + j];
             if (DROP) {
-                // the keep test runs on both 16-bit halves of a hash word at once and lands as an AND mask on the packed bf16 pair
-                // (same mask bits as sc_keep8: keep iff the element's 16-bit field >= thr):  x = sat(h - (thr - 1)) is 0 exactly for
-                // the dropped fields; min(x, 1) * 0xffff widens that to the lane mask.  Four packed integer ops per PAIR and no
-                // compare -> VCC -> select chain (that chain, not the hash, was two thirds of the dropout cost).
+                // Round 6: one hash word per FOUR probabilities (sc_common.h sc_drop8_*): a lane's 8 consecutive keys of a register group
+                // are two quads = two words.  Bytes 0 / 2 of a word (quad positions 0, 1) are tested as one packed 16-bit pair, bytes
+                // 1 / 3 (positions 2, 3) as the next: field - thr8 is negative exactly for the dropped fields, its sign smeared over the
+                // half-word is the AND-NOT mask on the packed bf16 pair.  Four packed integer ops per PAIR, no compare -> VCC -> select.
                 // (inline asm: written with vector builtins the compiler folds the sequence back into v_cmp + v_cndmask)
-                const uint32_t t1 = drop_thr - 1u;
-                const uint32_t thr2 = t1 | (t1 << 16), one2 = 0x00010001u;
-                const uint32_t pair0 = ((drop_row + (uint32_t)(kbase + 8 * half)) >> 1);      // drop_row, kbase even
+                const uint32_t thr2 = drop_thr | (drop_thr << 16), sh2 = 0x000f000fu, eight2 = 0x00080008u;
+                const uint32_t quad0 = (drop_row + (uint32_t)(kbase + 8 * half)) >> 2;        // drop_row, kbase multiples of 8
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     uint4 w = __builtin_bit_cast(uint4, pf[s2]);
                     uint32_t* wp = (uint32_t*)&w;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = 8 * s2 + 2 * q;                                         // elements r, r + 1
-                        const uint32_t hsh = sc_hash32((pair0 + (uint32_t)(q + 8 * s2)) ^ drop_seed);   // keys kbase + 16 s2 + 8 half + 2 q (+ 1)
-                        uint32_t x, m;
-                        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(x) : "v"(hsh), "s"(thr2));
-                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(x), "s"(one2));
-                        asm("v_pk_sub_u16 %0, 0, %1" : "=v"(m) : "v"(m));                      // 0 - {0, 1} = {0, 0xffff}
-                        wp[q] &= m;
+                    for (int qd = 0; qd < 2; ++qd) {                                           // keys kbase + 16 s2 + 8 half + 4 qd .. + 3
+                        const uint32_t hsh = sc_hash32((quad0 + (uint32_t)(4 * s2 + qd)) ^ drop_seed);
+                        uint32_t f1, d0, d1, m0, m1;
+                        const uint32_t f0 = hsh & 0x00ff00ffu;                                 // (byte 0, byte 2): positions 0, 1
+                        asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(f1) : "s"(eight2), "v"(hsh)); // (byte 1, byte 3): positions 2, 3
+                        asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d0) : "v"(f0), "s"(thr2));
+                        asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d1) : "v"(f1), "s"(thr2));
+                        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m0) : "s"(sh2), "v"(d0));     // 0xffff where dropped
+                        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m1) : "s"(sh2), "v"(d1));
+                        asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(wp[2 * qd]) : "v"(m0), "v"(wp[2 * qd]));           // ~m & w
+                        asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(wp[2 * qd + 1]) : "v"(m1), "v"(wp[2 * qd + 1]));
                     }
                     pf[s2] = __builtin_bit_cast(bf16x8, w);
                 }
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 
     const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
-    const float inv = DROP ? 1.0f / (l_tot * (1.0f - drop_p)) : 1.0f / l_tot;
+    const float inv = DROP ? sc_drop8_scale(drop_thr) / l_tot : 1.0f / l_tot;
     if (qrow >= R) return;                                          // lanes past the pitch: the next utterance's rows
     if (lse2 && half == 0)
         lse2[row0 ? (int64_t)h * rows_total + r0 + qrow : ((int64_t)b * H + h) * R + qrow] = m_run * c + __builtin_amdgcn_logf(l_tot);   // log2 domain

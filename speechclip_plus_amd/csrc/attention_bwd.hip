@@ -90,8 +90,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bwd_args& p) {
     const int q0 = qblk * 128 + wave * 32, qrow = q0 + l31;
     int n_valid = max(1, min(p.valid_len[b], R));
     if (p.causal) n_valid = min(n_valid, qblk * 128 + 128);
-    const uint32_t drop_thr = DROP ? (uint32_t)(p.drop_p * 65536.f + 0.5f) : 0u;
-    const float drop_scale = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t drop_thr = DROP ? sc_drop8_thr(p.drop_p) : 0u;       // the forward's 8-bit fields, one hash word per four keys (sc_common.h)
+    const float drop_scale = DROP ? sc_drop8_scale(drop_thr) : 1.f;
     const uint32_t drop_row = (uint32_t)((b * H + h) * R + qrow) * (uint32_t)R;       // element (b, h, q, k) -> drop_row + k
 
     bf16x8 qf[4], dof[4];
@@ -170,13 +170,13 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bwd_args& p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kb, l31, half, ks), qf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kb, l31, half, ks), dof[ks], dp, 0, 0, 0);
             }
-            if (DROP) {                                                // dP = keep . dP' / (1 - p): the forward's mask (pairs along k)
+            if (DROP) {                                                // dP = keep . dP' / (1 - p): the forward's mask (quads along k)
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const uint32_t kidx = (uint32_t)(kbase + (r & 3) + 8 * (r >> 2) + 4 * half);
-                    const uint32_t hsh = sc_hash32(((drop_row + kidx) >> 1) ^ p.drop_seed);
-                    dp[r] = (hsh & 0xffffu) < drop_thr ? 0.f : dp[r] * drop_scale;
-                    dp[r + 1] = (hsh >> 16) < drop_thr ? 0.f : dp[r + 1] * drop_scale;
+                for (int r = 0; r < 16; r += 4) {                      // registers r .. r + 3 = four consecutive keys = one hash word
+                    const uint32_t kidx = (uint32_t)(kbase + 8 * (r >> 2) + 4 * half);
+                    const uint32_t hsh = sc_hash32(((drop_row + kidx) >> 2) ^ p.drop_seed);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dp[r + i] = sc_drop8_keep(hsh, i, drop_thr) ? dp[r + i] * drop_scale : 0.f;
                 }
             }
             f32x16 ds;
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
     const int kblk = logical % nkb, bh = logical / nkb, h = bh % H, b = bh / H;
     const int key0w = kblk * 128 + wave * 32, krow = key0w + l31;
     const int n_valid = max(1, min(p.valid_len[b], R));
-    const uint32_t drop_thr = DROP ? (uint32_t)(p.drop_p * 65536.f + 0.5f) : 0u;
-    const float drop_scale = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t drop_thr = DROP ? sc_drop8_thr(p.drop_p) : 0u;       // the forward's 8-bit fields, one hash word per four keys (sc_common.h)
+    const float drop_scale = DROP ? sc_drop8_scale(drop_thr) : 1.f;
     uint16_t* dkp = p.dk + ((int64_t)b * R + krow) * p.lddk + h * 64 + 4 * half;
     uint16_t* dvp = p.dv + ((int64_t)b * R + krow) * p.lddv + h * 64 + 4 * half;
 
@@ -342,27 +342,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bwd_args p) {
             auto elem = [&](auto MASKED) {
                 constexpr bool MK = decltype(MASKED)::value;
                 if constexpr (DROP) {
-                    // The mask of (query, key) comes from hash word (element index >> 1): the two KEY lanes of a pair need the same word
-                    // for every one of their 16 queries.  Each lane hashes 8 of them - the even lane registers 0 .. 7, the odd lane
-                    // 8 .. 15 (16 queries further) - and takes the other 8 from its neighbour (DPP quad_perm [1, 0, 3, 2]).
-                    const bool odd = (krow & 1) != 0;
+                    // The mask of (query, key) comes from hash word (element index >> 2): the FOUR key lanes of a quad need the same word for
+                    // every one of their 16 queries.  Lane j of the quad hashes the words of registers j, j + 4, j + 8, j + 12 and every
+                    // register's word is then broadcast from its lane (DPP quad_perm [j, j, j, j]); the lane's own byte of a word is
+                    // position krow & 3 (sc_common.h sc_drop8_*).
+                    const uint32_t pos_sh = sc_drop8_shift((uint32_t)krow & 3u);
+                    uint32_t mine[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {                      // register 4 k + (krow & 3): its query, see the register map below
+                        const uint32_t myq = (uint32_t)(qt0 + qb * 32 + 8 * (k & 1) + 4 * half + (krow & 3) + 16 * (k >> 1));
+                        mine[k] = sc_hash32((((((uint32_t)((b * H + h) * R) + myq) * (uint32_t)R + (uint32_t)krow)) >> 2) ^ p.drop_seed);
+                    }
 #pragma unroll
                     for (int sl = 0; sl < 8; ++sl) {
                         const int g0 = sl >> 2, e = sl & 3;
                         const int ql0 = qb * 32 + 8 * g0 + 4 * half, ql1 = ql0 + 16;              // registers sl and sl + 8
                         const int q0i = qt0 + ql0 + e, q1i = q0i + 16;
-                        const uint32_t myq = (uint32_t)(odd ? q1i : q0i);
-                        const uint32_t mine = sc_hash32(((((uint32_t)((b * H + h) * R) + myq) * (uint32_t)R + (uint32_t)krow) >> 1) ^ p.drop_seed);
-                        const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);
-                        const uint32_t h0 = odd ? other : mine, h1 = odd ? mine : other;
                         const float l0 = lse_c[ql0 + e], l1 = lse_c[ql1 + e], d0 = dl_c[ql0 + e], d1 = dl_c[ql1 + e];
 #pragma unroll
                         for (int w = 0; w < 2; ++w) {
                             const int r = sl + 8 * w, qidx = w ? q1i : q0i;
-                            const uint32_t hsh = w ? h1 : h0;
+                            // register r = 4 (r >> 2) + (r & 3): hashed by quad lane r & 3 as its word number r >> 2
+                            constexpr int QP[4] = {0x00, 0x55, 0xAA, 0xFF};
+                            uint32_t hsh;
+                            switch (r & 3) {
+                                case 0: hsh = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine[r >> 2], QP[0], 0xF, 0xF, true); break;
+                                case 1: hsh = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine[r >> 2], QP[1], 0xF, 0xF, true); break;
+                                case 2: hsh = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine[r >> 2], QP[2], 0xF, 0xF, true); break;
+                                default: hsh = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine[r >> 2], QP[3], 0xF, 0xF, true); break;
+                            }
                             float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -(w ? l1 : l0)));
                             if (MK && !(key_ok && !(p.causal && krow > qidx) && !(p.causal > 1 && krow < (qidx & ~(p.causal - 1))))) pv = 0.f;
-                            const bool keep = (odd ? (hsh >> 16) : (hsh & 0xffffu)) >= drop_thr;
+                            const bool keep = ((hsh >> pos_sh) & 0xffu) >= drop_thr;
                             pr[r] = keep ? pv * drop_scale : 0.f;          // P' (dV = P'^T dO)
                             ds[r] = pv * ((keep ? dp[r] * drop_scale : 0.f) - (w ? d1 : d0));
                         }

@@ -254,6 +254,17 @@ __device__ __forceinline__ uint32_t sc_keep8(uint32_t idx, uint32_t seed, uint32
     return m;
 }
 
+// Attention-PROBABILITY dropout (round 6; the other dropout sites keep the 16-bit pair fields above): ONE hash word per FOUR consecutive
+// keys of a query.  Element e = (probability row) * pitch + key; word = sc_hash32((e >> 2) ^ seed); position i = e & 3 of the quad reads
+// BYTE (i & 1) * 2 + (i >> 1) of the word (0, 2, 1, 3: the forward kernel tests the even bytes of a word as one packed pair and the odd
+// bytes as the next); keep iff byte >= thr8 = round(p * 256).  The rate actually applied is thr8 / 256 (p = 0.1 -> 26 / 256 = 0.1016)
+// and the kept probabilities are scaled by 256 / (256 - thr8), so the expectation is exact.  Why: the hash was ~40 % of the train-mode
+// attention kernel's VALU work with one word per two probabilities.  Host twin: tests/test_gpu_kernels.py _keep_mask8.
+__device__ __forceinline__ uint32_t sc_drop8_thr(float p) { return (uint32_t)(p * 256.f + 0.5f); }
+__device__ __forceinline__ float sc_drop8_scale(uint32_t thr8) { return 256.f / (float)(256u - thr8); }
+__device__ __forceinline__ uint32_t sc_drop8_shift(uint32_t pos) { return 8u * ((pos & 1u) * 2u + (pos >> 1)); }      // bit offset of position pos
+__device__ __forceinline__ bool sc_drop8_keep(uint32_t word, uint32_t pos, uint32_t thr8) { return ((word >> sc_drop8_shift(pos)) & 0xffu) >= thr8; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

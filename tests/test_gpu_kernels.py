@@ -914,6 +914,17 @@ def _keep_mask(idx, seed, p):
     return bits >= np.uint32(int(p * 65536 + 0.5))
 
 
+def _keep_mask8(idx, seed, p):
+    """Attention-probability dropout (csrc/sc_common.h sc_drop8_*): one hash word per four consecutive elements, position i of the quad
+    reads byte (0, 2, 1, 3)[i]; keep iff byte >= round(256 p) -> (bool keep mask, the rate actually applied = round(256 p) / 256)."""
+    import numpy as np
+    h = _hash32_np((idx >> 2).astype(np.uint32) ^ np.uint32(seed))
+    pos = (idx & 3).astype(np.uint32)
+    shift = np.uint32(8) * ((pos & np.uint32(1)) * np.uint32(2) + (pos >> np.uint32(1)))
+    thr8 = int(p * 256 + 0.5)
+    return ((h >> shift) & np.uint32(0xff)) >= np.uint32(thr8), thr8 / 256.0
+
+
 def test_dropout_masks_gemm_rows_attention(dev):
     import numpy as np
     from speechclip_plus_amd import _lib
@@ -951,8 +962,10 @@ def test_dropout_masks_gemm_rows_attention(dev):
     s = (qf @ kf.transpose(-1, -2)) * 64 ** -0.5
     key_ok = torch.arange(R, device=dev)[None, :] < vl[:, None]
     P = torch.softmax(s.masked_fill(~key_ok[:, None, None, :], float("-inf")), dim=-1)
-    keep = torch.from_numpy(_keep_mask(np.arange(B * H * R * R, dtype=np.int64), seed, p)).view(B, H, R, R).to(dev)
-    ref = ((P * keep / (1 - p)) @ vf).transpose(1, 2).reshape(B * R, D)
+    keep, p_att = _keep_mask8(np.arange(B * H * R * R, dtype=np.int64), seed, p)
+    keep = torch.from_numpy(keep).view(B, H, R, R).to(dev)
+    assert p_att == 0.25 and abs(float(keep.float().mean()) - (1 - p_att)) < 0.005
+    ref = ((P * keep / (1 - p_att)) @ vf).transpose(1, 2).reshape(B * R, D)
     rows_ok = key_ok.reshape(B * R)
     assert rel_l2(out[rows_ok], ref[rows_ok]) < 1.2e-2
     # backward through the dropped probabilities: the DROP variants of the dq / dkv kernels regenerate the same mask
@@ -960,7 +973,7 @@ def test_dropout_masks_gemm_rows_attention(dev):
     ops.attn_fwd(qkv[:, : 2 * D], vt, vl, out, B, R, H, D, 64 ** -0.5, lse2=lse2, drop_p=p, drop_seed=seed)
     qa, ka, va = (t.detach().clone().requires_grad_() for t in (qf, kf, vf))
     Pa = torch.softmax(((qa @ ka.transpose(-1, -2)) * 64 ** -0.5).masked_fill(~key_ok[:, None, None, :], float("-inf")), dim=-1)
-    oa = ((Pa * keep / (1 - p)) @ va).transpose(1, 2).reshape(B * R, D)
+    oa = ((Pa * keep / (1 - p_att)) @ va).transpose(1, 2).reshape(B * R, D)
     dout = bf(torch.randn(B * R, D, generator=g)).to(dev)
     dout[~rows_ok] = 0
     oa.backward(dout.float())

@@ -1060,7 +1060,7 @@ def _encoder_mask_hook(seed_of, B, T, D, H, R, p=0.1, seg=False):
     speech_encoder._encode_kernels: 0 input, 1 encoder, 3 i + 2 attention, 3 i + 3 out_proj, 3 i + 4 fc2 of layer i).
     ``seg``: the frozen encoder's segment layout with every utterance at pitch R (an un-ragged forward): the attention kernel then
     numbers a probability ((h rows + row0[b] + q) max_pitch + k), sc_attn_fwd_seg_bf16."""
-    from test_gpu_kernels import _keep_mask
+    from test_gpu_kernels import _keep_mask, _keep_mask8
     site_of = {"input": lambda i: 0, "encoder": lambda i: 1, "attn": lambda i: 3 * i + 2, "dropout1": lambda i: 3 * i + 3,
                "dropout3": lambda i: 3 * i + 4}
     b_, t_, d_ = np.meshgrid(np.arange(B), np.arange(T), np.arange(D), indexing="ij")
@@ -1071,7 +1071,10 @@ def _encoder_mask_hook(seed_of, B, T, D, H, R, p=0.1, seg=False):
         att_idx = (((hh * (B * R) + bb * R + qq)) * R + kk).astype(np.int64)
 
     def drop(site, layer, t):
-        keep = _keep_mask(att_idx if site == "attn" else row_idx, seed_of(site_of[site](layer)), p)
+        if site == "attn":               # probabilities: one hash word per four keys, 8-bit fields, applied rate round(256 p) / 256
+            keep, p_att = _keep_mask8(att_idx, seed_of(site_of[site](layer)), p)
+            return t * torch.from_numpy(keep).float() / (1.0 - p_att)
+        keep = _keep_mask(row_idx, seed_of(site_of[site](layer)), p)
         return t * torch.from_numpy(keep).float() / (1.0 - p)
 
     return drop
