@@ -13,9 +13,10 @@ shapes = [("qkv", M, 3 * D, D, None, 0, False), ("oproj", M, D, D, None, 0, True
           ("conv3", B * 8 * R, C, 3 * C, 2 * C, 1, False), ("conv5", B * 2 * R, C, 2 * C, 2 * C, 1, False)]
 libs = [(os.path.basename(p), _lib._load(p)) for p in sys.argv[1:] if p.endswith(".so")]
 tot = {n: 0.0 for n, _ in libs}
-for nm, L in libs:                      # "<name>_off<K>.so": that copy runs with sc_set_option(K, 1)
+for nm, L in libs:                      # "<name>_off<K>[_<K2>...].so": that copy runs with sc_set_option(K, 1) (and K2 ...)
     if "_off" in nm:
-        L.sc_set_option(int((nm.split("_off")[1].split(".")[0]) or 4), 1)
+        for key in (nm.split("_off")[1].split(".")[0] or "4").split("_"):
+            L.sc_set_option(int(key), 1)
 for name, m, n, k, lda, act, res in shapes:
     lda = lda or k
     A = torch.randn(m * lda + k + 64, device=dev).to(torch.bfloat16) if lda != k else torch.randn(m, k, device=dev).to(torch.bfloat16)

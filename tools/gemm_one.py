@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speechclip_plus_amd import ops
 name, tile, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 10
-B, R, D, F, C = 64, 512, 768, 3072, 512
+for key in sys.argv[4:]:                      # tuning switches: sc_set_option(key, 1)
+    from speechclip_plus_amd import _lib
+    _lib.lib().sc_set_option(int(key), 1)
+B, R, D, F, C = 64, int(os.environ.get("SC_BENCH_R", "512")), 768, 3072, 512
 M = B * R
 shapes = {"qkv": (M, 3 * D, D, D, 0, False), "oproj": (M, D, D, D, 0, True), "fc1": (M, F, D, D, 1, False),
           "fc2": (M, D, F, F, 0, True), "conv1": (B * 32 * R, C, 3 * C, 2 * C, 1, False),
