@@ -106,20 +106,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     }
 
     // loader mapping: a tile = 8 pieces of 8 rows x 128 B (one LDS-DMA wave instruction each); wave w brings pieces w and w + 4
-    const uint16_t* kg[2];
-    const uint16_t* vg[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave + 4 * i) * 8 + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
-        kg[i] = qk + ((int64_t)r0 + row) * ldqk + D + h * 64 + ch * 8;
-        vg[i] = vt + (int64_t)D * r0 + (int64_t)(h * 64 + row) * R + ch * 8;      // V^T of the utterance: [H, 64, pitch] at D * r0
-    }
+    // Round 6: a source address = wave-uniform 64-bit base (SGPRs: utterance, head, piece, tile) + ONE 32-bit per-lane byte offset for
+    // the K pieces and one for the V^T pieces (row inside the piece and swizzled chunk: (row >> 1) & 7 does not depend on the piece):
+    // global_load_lds_dwordx4 v, s[base] - 2 address VGPRs instead of four 64-bit pointers and no 64-bit vector adds per tile
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int srow = lane >> 3, sch = (lane & 7) ^ ((wave_u * 4 + (lane >> 4)) & 7);
+    const uint32_t k_lane = (uint32_t)(srow * (int)ldqk + sch * 8) * 2u;            // bytes
+    const uint32_t v_lane = (uint32_t)(srow * R + sch * 8) * 2u;
+    const char* k_base = (const char*)(qk + ((int64_t)r0 + wave_u * 8) * ldqk + D + h * 64);
+    const char* v_base = (const char*)(vt + (int64_t)D * r0 + (int64_t)(h * 64 + wave_u * 8) * R);   // V^T of the utterance: [H, 64, pitch] at D * r0
     auto stage = [&](int t, int buf) {
+        uint32_t kl = k_lane, vl = v_lane;           // opaque: keeps base + lane offset from being re-associated into 64-bit vector pointers
+        asm volatile("" : "+v"(kl), "+v"(vl));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg[i] + (int64_t)t * KT * ldqk),
+            const char* kb = k_base + ((int64_t)t * KT + 32 * i) * ldqk * 2;
+            const char* vb = v_base + ((int64_t)32 * i * R + t * KT) * 2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + kl),
                                              (__attribute__((address_space(3))) void*)(&KVs[buf][0][(wave + 4 * i) * 1024]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg[i] + t * KT),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + vl),
                                              (__attribute__((address_space(3))) void*)(&KVs[buf][1][(wave + 4 * i) * 1024]), 16, 0, 0);
         }
     };
