@@ -46,9 +46,9 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="SURVEY 8d's variable-length run: utterance lengths U{32000 .. --seconds * 16000} "
                     "(seeded) instead of all-equal; algorithmic flops then count every utterance at ITS OWN length (padding is not work)")
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances in the CPU-baseline sample: BASELINE configs[0] = batch 8 (0 = skip)")
-    ap.add_argument("--cpu-iters", type=int, default=3, help="timed CPU iterations per thread setting (after 1 warm-up)")
-    ap.add_argument("--cpu-full", action="store_true", help="the CPU baseline exactly as SURVEY 8d states it: 3 warm-up + 10 timed "
-                    "iterations, all host cores and 8 threads (several minutes; the default run is a bounded sample of the same workload)")
+    ap.add_argument("--cpu-iters", type=int, default=10, help="timed CPU iterations (after 3 warm-up): SURVEY 8d's 3 + 10")
+    ap.add_argument("--cpu-full", action="store_true", help="also time the CPU baseline at torch's default thread count and at 8 threads "
+                    "(several minutes more; the default is SURVEY 8d's 3 + 10 at 32 threads, the fastest setting on every host measured)")
     ap.add_argument("--no-recall", action="store_true", help="skip the recall@k parity field (5000-utterance synthetic eval set)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="deterministic train step: every dropout site off (A/B only; the "
@@ -63,6 +63,10 @@ def main():
                          "hybrid_plus_large = configs[4] recipe on one GPU")
     ap.add_argument("--no-recipes", action="store_true", help="skip the `recipes` object of the default N = 1 run (BASELINE configs[2] "
                     "cascaded+ base and configs[4] hybrid+ large on one GPU, the ragged batch and the 6.4 s training crop: 10 steps each)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic counters of the default N = 1 run (two short child "
+                    "runs of this script's train step under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`, started before this process "
+                    "touches the GPU); roofline.traffic then falls back to the newest committed profiles/*_traffic.json")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # the counter passes' target: warm-up + K steps, no output
     ap.add_argument("--rehearse-launch", action="store_true", help="launch plumbing only, no GPU: the ranks rendezvous, issue the "
                     "step's two collectives (packed all-gather, flat all-reduce) on CPU tensors and rank 0 prints the JSON line "
                     "with value null (tests/test_dp_gloo.py runs this with SC_DIST_BACKEND=gloo)")
@@ -75,6 +79,14 @@ def main():
         return rehearse_launch(args, world)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    default_run = (world == 1 and args.model == "base" and not args.ragged and not args.unfreeze and not args.trainable
+                   and not args.no_dropout and abs(args.seconds - 10.0) < 1e-9 and args.batch == 64)
+    live_traffic = rccl_rehearsal = None
+    if default_run and not args.no_recipes and not args.pmc_child and os.environ.get("SC_FORCE_COLLECTIVES", "0") != "1":
+        # child processes, run to completion BEFORE this process makes its first GPU call
+        if not args.no_pmc:
+            live_traffic = live_pmc_traffic()
+        rccl_rehearsal = rccl_one_rank_rehearsal(args)
     if world > 1 or os.environ.get("SC_FORCE_COLLECTIVES", "0") == "1":   # the latter: one-rank RCCL rehearsal (parallel.dp_world)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -108,6 +120,11 @@ def main():
 
     for _ in range(args.warmup):
         trainer.step(batch)
+    if args.pmc_child:                              # target of the counter passes (live_pmc_traffic): K more steps and out
+        for _ in range(args.steps):
+            trainer.step(batch)
+        torch.cuda.synchronize()
+        return
     # ---- timed region: exactly K steps, un-instrumented (timing events would put a marker packet between
     # back-to-back kernels and cost ~20 % of the step) ------------------------------------------------------
     sync()
@@ -181,7 +198,10 @@ def main():
                     "launches_per_step": dom["launches"] // args.steps,
                     "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                     "alg_gflop_per_launch": round(dom["work"] / dom["launches"] / 1e9, 3)}
-            roof.update(pmc_traffic("gemm256_kernel<0," if dom_name == "gemm_bf16_256x256" else "gemm_bf16_kernel<128, 128>"))
+            ksub = "gemm256_kernel<0," if dom_name == "gemm_bf16_256x256" else "gemm_bf16_kernel<128, 128>"
+            roof.update(traffic_from_live(live_traffic, ksub) or pmc_traffic(ksub))
+            if isinstance(live_traffic, str):
+                roof["traffic_live_skipped"] = live_traffic
             if dom_name == "gemm_bf16_256x256" and world == 1:
                 roof["k_loop"] = k_loop_clock(dev)
             for k, v in summ.items():
@@ -234,12 +254,11 @@ def main():
                                                                                     conv_train_ms),
             "recall": recall,
         }
-        default_run = (world == 1 and args.model == "base" and not args.ragged and not args.unfreeze and not args.trainable
-                       and not args.no_dropout and abs(args.seconds - 10.0) < 1e-9)
         if default_run and not args.no_recipes:
             del trainer, model, batch
             torch.cuda.empty_cache()
             result["recipes"] = run_recipes(args, dev)
+            result["recipes"]["rccl_one_rank_rehearsal"] = rccl_rehearsal
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
@@ -609,10 +628,95 @@ def step_alg_gflop(kind: str, L: int, unfreeze: int = 0, trainable: bool = False
     return {"alg_gflop_per_utt_step": round(total / 1e9, 1), "terms_gflop": {k: round(v / 1e9, 2) for k, v in terms.items()}}
 
 
+def rccl_one_rank_rehearsal(args):
+    """The only part of SURVEY 8(e) a one-GPU box can watch: the headline step with a ONE-rank RCCL process group
+    (SC_FORCE_COLLECTIVES=1: parallel.dp_world() = 1 but the packed all-gather with autograd, the side-stream flat all-reduce and the
+    join are issued for real), as a child run of this script that finishes before this process touches the GPU.  -> the child's
+    ms_per_step (overlapped and one-stream schedules), its `collectives` object (all_gather_us / all_reduce_us / join_wait_us under the
+    overlapped encoder) and the hardware-queue setting, or {"skipped": why}."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SC_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--cpu-utts", "0", "--no-recall", "--no-recipes",
+           "--no-pmc", "--no-kernel-timer", "--batch", str(args.batch), "--seconds", str(args.seconds)]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        line = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"skipped": f"child exit {r.returncode}: " + r.stderr.decode(errors="replace")[-300:]}
+        d = json.loads(line[-1])
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"skipped": f"{type(e).__name__}: {e}"[:300]}
+    return {"what": "headline train step in a child process with a one-rank RCCL group (SC_FORCE_COLLECTIVES=1): every collective of the "
+                    "N > 1 step is issued; 10 timed steps after 3 warm-up",
+            "ms_per_step": d.get("ms_per_step"), "one_stream_ms_per_step": d.get("one_stream_ms_per_step"),
+            "rccl_ranks": d.get("rccl_ranks"), "collectives": d.get("collectives"), "hw_queues": d.get("config", {}).get("hw_queues")}
+
+
+def live_pmc_traffic():
+    """HBM-side bytes per kernel launch of THIS run's train step, from hardware counters collected now: two child runs of this script
+    (`--pmc-child`: 2 warm-up + 3 train steps, nothing else) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` - separate passes,
+    `--kernel-trace` only beside them, exactly the recipe of MI355X_MICROARCH.md (units KiB; gfx950 reports half of a wide streaming
+    read, hence FETCH x 2; WRITE exact) - started BEFORE this process makes its first GPU call (a child that profiles is an ordinary child
+    process, not an exec of a GPU-initialised one).  -> {kernel name: {"fetch_kib": [...], "write_kib": [...]}} or a string saying why not."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return "this process is itself being profiled"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="sc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "c", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "3", "--warmup", "2"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            files = glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv")
+            if r.returncode != 0 or not files:
+                return f"rocprofv3 --pmc {counter}: exit {r.returncode}, {len(files)} csv; " + r.stderr.decode(errors="replace")[-200:]
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter:
+                    out.setdefault(row["Kernel_Name"], {"fetch_kib": [], "write_kib": []})[key].append(float(row["Counter_Value"]))
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return f"counter pass failed: {type(e).__name__}: {e}"[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def traffic_from_live(live, kernel_substr):
+    """roofline.traffic fields from live_pmc_traffic()'s table: the average over every launch of every instantiation of the dominant
+    kernel in the child runs' train steps (the first launch of each instantiation, which fills the caches and loads the code, dropped)."""
+    if not isinstance(live, dict):
+        return None
+    tot_f = tot_w = n = 0
+    for name, v in live.items():
+        if kernel_substr in name and len(v["fetch_kib"]) == len(v["write_kib"]) and len(v["fetch_kib"]) > 1:
+            tot_f += sum(v["fetch_kib"][1:])
+            tot_w += sum(v["write_kib"][1:])
+            n += len(v["fetch_kib"]) - 1
+    if n == 0:
+        return None
+    return {"traffic": round((2.0 * tot_f + tot_w) * 1024.0 / n), "traffic_unit": "bytes/launch (PMC, avg over launches of all instantiations)",
+            "traffic_source": f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this bench.py invocation ({n} launches; FETCH x 2 gfx950 correction)",
+            "traffic_fetch_bytes": round(2.0 * tot_f * 1024.0 / n), "traffic_write_bytes": round(tot_w * 1024.0 / n)}
+
+
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this same command
-    (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH x2 gfx950 correction; tools/summarize_pmc.py).  bench.py
-    cannot collect hardware counters itself, so it reports the newest profiles/*_traffic.json (or null)."""
+    """Fallback of traffic_from_live (no rocprofv3, a nested profiler, --no-pmc): HBM bytes per launch of the dominant kernel from the
+    newest committed rocprofv3 PMC summary of this same command (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH x2 gfx950
+    correction; tools/summarize_pmc.py), reported only while the kernel source it was measured on is the tree's."""
     import glob
     import re
 
@@ -635,7 +739,7 @@ def pmc_traffic(kernel_substr):
     n = sum(v["launches_sampled"] for v in hits)
     avg = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hits) / n
     return {"traffic": round(avg), "traffic_unit": "bytes/launch (PMC, avg over launches of all instantiations)",
-            "traffic_source": os.path.relpath(files[-1], ROOT)}
+            "traffic_source": os.path.relpath(files[-1], ROOT) + f" (stored profile; kernel source sha256 {src[:12]} = this tree's)"}
 
 
 def k_loop_clock(dev):
@@ -717,12 +821,11 @@ def physical_cores():
 
 def cpu_baseline(sd, model, n_utts, L, iters, full=False):
     """The oracle (kind "port": torch-CPU fp32 restatement of the reference maths) on the host cores, BASELINE configs[0]:
-    Parallel SpeechCLIP base, batch 8 (the reference's CPU-runnable case), same utterance length as the GPU workload.  Forward
-    (frozen HuBERT under no_grad + weighted sum + parallel head + loss) and forward + backward are timed separately inside each
-    iteration, at up to three thread settings: all host threads torch picks, 32 and 8 (torch's CPU kernels scale negatively past a few
-    dozen threads on a 128-thread host, so the default is not the fastest); ``value`` / ``cores`` are the FASTEST setting's.
-    Default: 1 warm-up + ``iters`` timed iterations per setting (a bounded sample: the step is deterministic in cost);
-    ``full`` = SURVEY 8d's 3 warm-up + 10 timed."""
+    Parallel SpeechCLIP base, batch 8 (the reference's CPU-runnable case), same utterance length as the GPU workload, SURVEY 8d's
+    protocol: 3 warm-up + 10 timed train steps.  Forward (frozen HuBERT under no_grad + weighted sum + parallel head + loss) and
+    forward + backward are timed separately inside each iteration.  Threads: min(32, torch's default) - torch's CPU kernels scale
+    negatively past a few dozen threads (a 128-thread host: 0.83 utt/s at 128 threads, 3.5 at 32, 3.1 at 8; rounds 3-5), so the
+    default no longer spends time on the slow settings; ``full`` adds torch's default count and 8 for the record."""
     import oracle
     torch.manual_seed(0)
     head_W = {k: v.detach().cpu().float().clone().requires_grad_(True) for k, v in model.parallel_branch.state_dict().items()}
@@ -731,7 +834,7 @@ def cpu_baseline(sd, model, n_utts, L, iters, full=False):
     img = torch.nn.functional.normalize(torch.randn(n_utts, 512), dim=-1)
     ids = torch.arange(n_utts) // 5
     arch = oracle.HubertArch.base()
-    warm, timed = (3, 10) if full else (1, iters)
+    warm, timed = 3, iters
 
     def step():
         t0 = time.perf_counter()
@@ -746,7 +849,7 @@ def cpu_baseline(sd, model, n_utts, L, iters, full=False):
 
     default_threads = torch.get_num_threads()
     runs = {}
-    for threads in (default_threads, 32, 8):
+    for threads in ((min(32, default_threads), default_threads, 8) if full else (min(32, default_threads),)):
         if threads in runs or threads > default_threads:
             continue
         torch.set_num_threads(threads)
@@ -760,9 +863,8 @@ def cpu_baseline(sd, model, n_utts, L, iters, full=False):
     torch.set_num_threads(default_threads)
     best = max(runs.values(), key=lambda r: r["train_step_utt_per_s"])
     return {"value": best["train_step_utt_per_s"], "unit": "utterances/s", "cores": best["threads"], "kind": "port",
-            "sample": ("SURVEY 8d protocol, " if full else "bounded sample (the driver's time limit; --cpu-full runs SURVEY 8d's 3 + 10): ") +
-                      f"BASELINE configs[0]: batch {n_utts} x {L} samples, {warm} warm-up + {timed} timed train steps per thread "
-                      f"setting, torch fp32 on {os.cpu_count()} logical CPUs ({physical_cores()} physical cores)",
+            "sample": f"SURVEY 8d protocol: BASELINE configs[0], batch {n_utts} x {L} samples, {warm} warm-up + {timed} timed train steps at "
+                      f"{best['threads']} threads, torch fp32 on {os.cpu_count()} logical CPUs ({physical_cores()} physical cores)",
             "host": {"logical_cpus": os.cpu_count(), "physical_cores": physical_cores(), "torch_default_threads": default_threads},
             "s_per_step": best["forward_backward_s"], "forward_utt_per_s": best["forward_utt_per_s"],
             "by_threads": list(runs.values())}
