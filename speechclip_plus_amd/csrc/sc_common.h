@@ -30,8 +30,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     __bf16 b = (__bf16)f;   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
     return __builtin_bit_cast(uint16_t, b);
 }
+// Round 6: the pair goes through a 2-vector conversion = ONE v_cvt_pk_bf16_f32 lo, hi.  The former (uint32_t)f2bf(lo) | f2bf(hi) << 16
+// compiled to two single-input conversions + v_lshlrev + v_or_b32_sdwa - four VALU instructions per pair in every VALU-bound epilogue
+// (GEMM tiles, conv layer 0, LayerNorm rows).  Same rounding (nearest-even), same bits.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bflo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
