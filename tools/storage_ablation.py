@@ -6,7 +6,9 @@ the 5000-utterance eval set, exactly like the HIP path; on the natural-margin ga
 This tool switches the rounding on for ONE site class at a time (oracle.SitedStore) and tables, per class, against the fp32 oracle:
   mean embedding distance, its part common to all utterances, the per-utterance rest, and the rank flips on gallery A
   (tests/golden/recall_eval_natural.npz) and gallery B (recall_eval_natural_b.npz), audio -> image and image -> audio.
-Configs: fp32 | all (= the emulation) | weights | conv | ln | proj | residual | qkv | p | ctx | ffn_act | wsum, and any "+"-joined set.
+Configs: fp32 | all (= the emulation) | weights | conv | ln | proj | residual | qkv | p | ctx | ffn_act | wsum, and any "+"-joined set;
+weight GROUPS (round 6, after "weights" turned out to carry 0.0052 of the 0.0057): w_conv (conv layers 1-6) | w_proj (post_extract_proj,
+pos_conv) | w_attn (q / k / v / out projections) | w_ffn (fc1, fc2) | w_lo (encoder layers 0-5) | w_hi (layers 6-11).
 
     python tools/storage_ablation.py --cache /tmp/ablation --threads 6 [--configs weights conv ...] [--out profiles/r06_storage_ablation.json]
 
@@ -28,6 +30,10 @@ sys.path.insert(0, HERE)
 from recall_eval import BATCH, WS_WEIGHTS, embed_all, eval_set, head_weights, hubert_weights, rank_stats, recalls  # noqa: E402
 
 SITES = ("conv", "ln", "proj", "residual", "qkv", "p", "ctx", "ffn_act")
+_layer = lambda k: int(k.split(".")[2]) if k.startswith("encoder.layers.") else -1
+WGROUPS = {"w_conv": lambda k: k.startswith("feature_extractor."), "w_proj": lambda k: k.startswith(("post_extract_proj.", "encoder.pos_conv.")),
+           "w_attn": lambda k: ".self_attn." in k, "w_ffn": lambda k: ".fc1." in k or ".fc2." in k,
+           "w_lo": lambda k: 0 <= _layer(k) <= 5, "w_hi": lambda k: _layer(k) >= 6}
 DEFAULT = ["fp32", "all", "weights", "conv", "ln", "proj", "residual", "qkv", "p", "ctx", "ffn_act", "wsum"]
 
 
@@ -37,10 +43,13 @@ def embeddings(config: str, wavs, cache: str) -> torch.Tensor:
     if os.path.exists(path):
         return torch.from_numpy(np.load(path))
     on = set(SITES) | {"weights", "wsum"} if config == "all" else set() if config == "fp32" else set(config.split("+"))
-    assert on <= set(SITES) | {"weights", "wsum"}, on
+    assert on <= set(SITES) | {"weights", "wsum"} | set(WGROUPS), on
     Wh, Whead, arch = hubert_weights(), head_weights(), oracle.HubertArch.base()
     if "weights" in on:
         Wh = oracle.bf16_weights(Wh)
+    for grp in on & set(WGROUPS):            # the bf16 rounding on ONE group of GEMM weights
+        rounded = oracle.bf16_weights(Wh)
+        Wh = {k: (rounded[k] if WGROUPS[grp](k) else v) for k, v in Wh.items()}
     sites = on & set(SITES)
     store = oracle.SitedStore(sites) if sites else None
     t0, done = time.time(), [0]
