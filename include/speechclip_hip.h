@@ -468,6 +468,12 @@ int sc_cif_tail(const float* alpha, const float* csum, int32_t B, int32_t S, int
  *   sc_vq_norm_bwd_f32 gradient through x / max(|x|, eps)
  * ---------------------------------------------------------------------------------------------- */
 int sc_vq_prep_f32(const float* kw, int64_t ldk, int32_t Nk, int32_t Et, float eps, float* kwn_T, int64_t ldt, float* rnorm, void* stream);
+/* round 6: x[r, :] * row_scale[r] (row_scale NULL: 1) as three bf16 addends x1 + x2 + x3 (24 significant bits), laid out as the six
+ * K-blocks of a product to fp32 accuracy on the bf16 matrix pipe - side 0: [x1 | x1 | x2 | x1 | x3 | x2], side 1: [x1 | x2 | x1 | x3 | x1 | x2];
+ * sc_gemm_bf16 (out_f32) over K = 6 Ep on a side-0 and a side-1 operand then sums the products (1,1) (1,2) (2,1) (1,3) (3,1) (2,2), each exact
+ * in fp32.  out [Rp][6 Ep] bf16, zero outside [R, E].  Used for the cosine scores the keyword argmax is taken over (was sc_sgemm_mfma_f32). */
+int sc_split3_bf16(const float* x, int64_t ldx, const float* row_scale, int32_t R, int32_t E, sc_bf16* out, int32_t Rp, int32_t Ep,
+                   int32_t side, void* stream);
 int sc_sgemm_mfma_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc,
                       int32_t M, int32_t N, int32_t K, const float* bias, void* stream);
 int sc_sgemm_mfma_f32_split(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, int32_t b_kmajor, float* C,

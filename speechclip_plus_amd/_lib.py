@@ -173,6 +173,7 @@ SIGNATURES = {
     "sc_sgemm_mfma_f32": [c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p],
     "sc_sgemm_mfma_f32_split": [c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "sc_sgemm_mfma_slices": [c_int, c_int, c_int],
+    "sc_split3_bf16": [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "sc_vq_rowstats": [c_void_p, c_i64, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_void_p],
     "sc_vq_perplexity": [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p],

@@ -71,6 +71,40 @@ __global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------ three-way bf16 split (round 6)
+// x (times an optional per-row scale) = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 significant bits in
+// three bf16 values.  A product of two such numbers to fp32 accuracy is the six bf16 x bf16 products (1,1) (1,2) (2,1) (1,3) (3,1) (2,2) -
+// each EXACT in fp32 (8 x 8 significant bits) - summed in fp32; the dropped terms are below 2^-24 of the product.  Laid out as six
+// K-blocks, side 0 = [x1 | x1 | x2 | x1 | x3 | x2], side 1 = [x1 | x2 | x1 | x3 | x1 | x2], the whole sum is ONE bf16 GEMM with K = 6 Ep
+// on the bf16 matrix pipe (2.5 PF) instead of an fp32 GEMM on the fp32 pipe (157 TF): the cosine scores of the keyword quantiser.
+// out [Rp][6 Ep] bf16; rows >= R and columns >= E of every block are written as zeros.  One thread = 4 consecutive columns of a row.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ row_scale, int R, int E,
+                                                     uint16_t* __restrict__ out, int Rp, int Ep, int side) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int q4 = Ep >> 2;
+    if (idx >= (int64_t)Rp * q4) return;
+    const int r = (int)(idx / q4), c = (int)(idx % q4) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+        const float s = row_scale ? row_scale[r] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c + j < E) v[j] = x[(int64_t)r * ldx + c + j] * s;
+    }
+    uint2 part[3];
+    float res[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const uint32_t lo = pack2bf(res[0], res[1]), hi = pack2bf(res[2], res[3]);
+        part[t] = make_uint2(lo, hi);
+        res[0] -= bflo(lo); res[1] -= bfhi(lo); res[2] -= bflo(hi); res[3] -= bfhi(hi);      // exact: the difference of a value and its rounding
+    }
+    uint16_t* o = out + (int64_t)r * 6 * Ep + c;
+    const int pat0[6] = {0, 0, 1, 0, 2, 1}, pat1[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+    for (int b = 0; b < 6; ++b) *(uint2*)(o + (int64_t)b * Ep) = part[side ? pat1[b] : pat0[b]];
+}
+
 // ------------------------------------------------------------------------------------------ fp32 MFMA GEMM
 // C[m, n] = sum_k A(m, k) B(n, k) (+ bias[n]).  Each operand is either ROW-major ([rows][K], the nn.Linear layout) or K-major ([K][rows]);
 // any M, N, K (16-byte loads when base and leading dimension are 16-byte multiples, element loads otherwise).
@@ -487,6 +521,17 @@ extern "C" int sc_vq_prep_f32(const float* kw, int64_t ldk, int32_t Nk, int32_t 
     SC_CHECK(kw && kwn_T && rnorm, "sc_vq_prep_f32: null pointer");
     SC_CHECK(Nk > 0 && Et > 0 && ldt % 64 == 0 && ldt >= Nk, "sc_vq_prep_f32: ldt must be a multiple of 64 >= Nk");
     hipLaunchKernelGGL(vq_prep_kernel, dim3((unsigned)(ldt / 64), (unsigned)((Et + 63) / 64)), dim3(256), 0, (hipStream_t)stream, kw, ldk, Nk, Et, eps, kwn_T, ldt, rnorm);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_split3_bf16(const float* x, int64_t ldx, const float* row_scale, int32_t R, int32_t E, sc_bf16* out, int32_t Rp, int32_t Ep,
+                              int32_t side, void* stream) {
+    SC_CHECK(x && out, "sc_split3_bf16: null pointer");
+    SC_CHECK(R > 0 && E > 0 && Rp >= R && Ep >= E && Ep % 4 == 0 && (side == 0 || side == 1) && ((uintptr_t)out % 8) == 0,
+             "sc_split3_bf16: R=%d E=%d Rp=%d Ep=%d (Ep %% 4 == 0, out 8-byte aligned) side=%d", R, E, Rp, Ep, side);
+    const int64_t n = (int64_t)Rp * (Ep / 4);
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, row_scale, R, E, out, Rp, Ep, side);
     SC_LAUNCH_CHECK();
     return 0;
 }

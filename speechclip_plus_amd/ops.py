@@ -726,6 +726,28 @@ def vq_prep(kw: torch.Tensor, eps: float = 1e-8):
     return kwn_T, rnorm
 
 
+def split3_bf16(x: torch.Tensor, side: int, row_scale: Optional[torch.Tensor] = None, rows_pad: int = 128, cols_pad: int = 64) -> torch.Tensor:
+    """x [R, E] fp32 (* row_scale [R]) -> its three-way bf16 split as the six K-blocks of an fp32-accurate product on the bf16 matrix
+    pipe (sc_split3_bf16): [Rp, 6 Ep] bf16, Rp / Ep = R / E rounded up to ``rows_pad`` / ``cols_pad``; side 0 and side 1 pair up."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and side in (0, 1)
+    R, E = x.shape
+    Rp, Ep = -(-R // rows_pad) * rows_pad, -(-E // cols_pad) * cols_pad
+    out = torch.empty(Rp, 6 * Ep, device=x.device, dtype=torch.bfloat16)
+    check(lib().sc_split3_bf16(_p(x), x.stride(0), _p(row_scale), R, E, _p(out), Rp, Ep, side, _stream()), "sc_split3_bf16")
+    return out
+
+
+def cosine_scores_split(kw: torch.Tensor, rnorm: torch.Tensor, table_split: torch.Tensor, Vp: int) -> torch.Tensor:
+    """cos [Nkp, Vp] fp32 = (kw * rnorm) . table_n^T to fp32 accuracy: ONE bf16 GEMM over the six K-blocks of the three-way splits
+    (``table_split`` = split3_bf16(normalised table, side 1), rows padded to Vp)."""
+    A = split3_bf16(kw, 0, row_scale=rnorm)
+    K6 = A.shape[1]
+    assert table_split.shape == (Vp, K6), (table_split.shape, Vp, K6)
+    cos = torch.empty(A.shape[0], Vp, device=kw.device, dtype=torch.float32)
+    gemm_raw(A, K6, table_split, K6, cos, Vp, A.shape[0], Vp, K6, out_f32=True)
+    return cos
+
+
 def sgemm_mfma(A: torch.Tensor, Bm: torch.Tensor, a_kmajor: bool = False, b_kmajor: bool = False, bias: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C [M, N] = A . B^T (+ bias) in exact fp32 on the matrix pipe.  A: [M, K] (or [K, M] with a_kmajor), B: [N, K] (nn.Linear

@@ -34,6 +34,8 @@ logger = logging.getLogger(__name__)
 __all__ = ["SimpleVectorQuantizer", "Kw_BatchNorm_dynamic", "VocabTables"]
 
 SPECIAL_TOKENS = (0, 2, 3)        # my_vector_quantizer.py:64 default prob_msk
+# the cosine scores on the fp32 matrix pipe (sc_sgemm_mfma_f32, rounds 2-5) instead of the three-way bf16 split product: A/B and tests
+EXACT_FP32_SCORES = False
 
 
 def _roundup(x: int, m: int) -> int:
@@ -41,8 +43,9 @@ def _roundup(x: int, m: int) -> int:
 
 
 class VocabTables:
-    """Derived copies of the frozen token table, built once per table version: the normalised table K-major in fp32 (score GEMM),
-    the table in bf16 (``g . table^T``) and the normalised table K-major in bf16 (``dx . normalised table``)."""
+    """Derived copies of the frozen token table, built once per table version: the normalised table K-major in fp32 (the exact-fp32
+    score GEMM of the debug / A-B path), its three-way bf16 split (the score GEMM of the product path), the table in bf16
+    (``g . table^T``) and the normalised table K-major in bf16 (``dx . normalised table``)."""
 
     def __init__(self, weight: torch.Tensor):
         w = weight.detach().float().contiguous()
@@ -56,6 +59,10 @@ class VocabTables:
         self.table_bf16 = torch.zeros(self.Vp, self.Etp, device=w.device, dtype=torch.bfloat16)
         self.table_bf16[:V, :Et] = w
         self.norm_T_bf16 = self.norm_T.to(torch.bfloat16)
+        # round 6: the normalised table as three bf16 addends in the six-K-block layout (ops.split3_bf16): the cosine scores are then ONE
+        # bf16 GEMM with fp32-accurate results (every bf16 x bf16 product is exact in fp32) instead of an fp32 GEMM on the fp32 matrix pipe
+        self.norm_split = ops.split3_bf16(wn.contiguous(), 1, rows_pad=128)
+        assert self.norm_split.shape[0] == self.Vp
         units = self.Vp // 64
         self.splits = max(s for s in range(1, 17) if units % s == 0)                # equal vocabulary slices, multiples of 64
 
@@ -87,7 +94,10 @@ class _KeywordVQFn(torch.autograd.Function):
         Nk, Et = kw.shape
         kw = kw.detach().float().contiguous()
         kwn_T, rnorm = ops.vq_prep(kw)
-        cos = ops.sgemm_mfma(kwn_T, tb.norm_T, a_kmajor=True, b_kmajor=True)                                   # [Nkp, Vp] fp32
+        if EXACT_FP32_SCORES:
+            cos = ops.sgemm_mfma(kwn_T, tb.norm_T, a_kmajor=True, b_kmajor=True)                               # [Nkp, Vp] fp32
+        else:
+            cos = ops.cosine_scores_split(kw, rnorm, tb.norm_split, tb.Vp)                                     # [Nkp, Vp] fp32, fp32-accurate
         idx, lse_t, lse_1, ent = ops.vq_rowstats(cos[:Nk], tb.V, temp, SPECIAL_TOKENS)
         ppl = ops.vq_perplexity(cos[:Nk], tb.V, idx, lse_1)
         out = ops.vq_gather(tb.table, idx)

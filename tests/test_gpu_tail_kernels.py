@@ -72,6 +72,41 @@ def _vq_reference(kw, table, temp, training):
     return prob @ table, k, ent, code_ppl, prob_ppl, x
 
 
+@pytest.mark.parametrize("Nk,V,Et", [(512, 8112, 512), (512, 19787, 768), (37, 205, 48)])
+def test_cosine_scores_as_one_bf16_gemm_over_three_way_splits_vs_fp64(Nk, V, Et):
+    """Round 6: the keyword quantiser's cosine scores = ONE bf16 GEMM over the six K-blocks of the operands' three-way bf16 splits
+    (sc_split3_bf16 + sc_gemm_bf16).  Every bf16 x bf16 product is exact in fp32, the six blocks carry the product to 2^-24, so the
+    result must sit as close to the fp64 product as the exact-fp32 MFMA GEMM it replaces does (criterion fixed before the first run:
+    max |error| <= 2 x the fp32 GEMM's own max error + 1e-7, and the split is a lossless decomposition to 2^-22 relative)."""
+    from speechclip_plus_amd import ops
+    g = torch.Generator().manual_seed(V + Et)
+    table = torch.randn(V, Et, generator=g) * 0.02
+    kw = torch.randn(Nk, Et, generator=g) * 3.0
+    wn = table / table.norm(dim=-1, keepdim=True).clamp_min(1e-8)
+    kw_d, wn_d = kw.cuda(), wn.cuda().contiguous()
+    kwn_T, rnorm = ops.vq_prep(kw_d)
+    Vp = (V + 127) // 128 * 128
+    split_tab = ops.split3_bf16(wn_d, 1, rows_pad=128)
+    # the decomposition itself: blocks 0, 1, 3 of a side-1 row are x1, x2, x3
+    Ep = split_tab.shape[1] // 6
+    parts = split_tab[:V].view(V, 6, Ep)[:, [0, 1, 3], :Et].double().sum(1)
+    assert float((parts - wn_d.double()).abs().max()) <= 2.0 ** -22 * float(wn_d.abs().max())
+    assert float(split_tab[V:].float().abs().max() if Vp > V else 0.0) == 0.0
+    cos_split = ops.cosine_scores_split(kw_d, rnorm, split_tab, Vp)[:Nk, :V].double().cpu()
+    norm_T = torch.zeros(Et, Vp, device="cuda")
+    norm_T[:, :V] = wn_d.t()
+    cos_fp32 = ops.sgemm_mfma(kwn_T, norm_T, a_kmajor=True, b_kmajor=True)[:Nk, :V].double().cpu()
+    kwn = (kw_d * rnorm[:, None]).double().cpu()              # the fp32 normalised keywords both paths start from
+    ref = kwn @ wn.double().t()
+    e_split, e_fp32 = float((cos_split - ref).abs().max()), float((cos_fp32 - ref).abs().max())
+    print(f"max |error| vs fp64: split-bf16 GEMM {e_split:.3e}, exact-fp32 MFMA GEMM {e_fp32:.3e}")
+    assert e_split <= 2.0 * e_fp32 + 1e-7, (e_split, e_fp32)
+    # the decisions: identical argmax wherever the fp64 margin of the two best scores exceeds 1e-6
+    top2 = ref.topk(2, dim=-1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-6
+    assert torch.equal(cos_split.argmax(-1)[safe], ref.argmax(-1)[safe]) and float(safe.float().mean()) > 0.99
+
+
 @pytest.mark.parametrize("Nk,V,Et", [(300, 1000, 64), (1600, 8112, 512), (37, 205, 48)])
 def test_fused_keyword_vq_vs_fp64(Nk, V, Et):
     """SimpleVectorQuantizer.quantize_keywords (cosine in exact fp32 MFMA -> mask -> argmax -> gather; straight-through backward)
