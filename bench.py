@@ -653,7 +653,7 @@ def rccl_one_rank_rehearsal(args):
         return {"skipped": f"{type(e).__name__}: {e}"[:300]}
     return {"what": "headline train step in a child process with a one-rank RCCL group (SC_FORCE_COLLECTIVES=1): every collective of the "
                     "N > 1 step is issued; 10 timed steps after 3 warm-up",
-            "ms_per_step": d.get("ms_per_step"), "one_stream_ms_per_step": d.get("one_stream_ms_per_step"),
+            "ms_per_step": d.get("ms_per_step"),
             "rccl_ranks": d.get("rccl_ranks"), "collectives": d.get("collectives"), "hw_queues": d.get("config", {}).get("hw_queues")}
 
 
