@@ -349,6 +349,154 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
     }
 }
 
+
+// Round 6: the layer_norm mode WITHOUT cross-lane reductions.  conv0_ln_gelu_kernel above spends more than half of its 1.43 ms (B = 64 x
+// 10 s; the GroupNorm-mode kernel does the same taps + GELU in 0.61 ms) in two wavefront reductions per row.  But a row's channel
+// statistics are closed forms of its 10-sample window x:  y_c = w_c . x + b_c  =>
+//     mean_c y = wbar . x + bbar,        var_c y = x^T G x + 2 h . x + s
+// with wbar / bbar the channel means of the taps / bias, G = cov_c(w_c) (10 x 10), h = cov_c(w_c, b_c), s = var_c(b_c) - every term
+// CENTRED, so the quadratic form has no cancellation beyond its own PSD structure; it is evaluated in fp64 (65 FMAs per row).  A wave
+// owns 32 rows of its workgroup's 128: lane i computes the statistics of the wave's i-th row up front (one strided 10-sample gather per
+// lane), and the main loop - the GroupNorm kernel's: four rows per iteration, packed taps, scalar sample loads - fetches (mean, rstd)
+// of the current row with v_readlane.  The 77 raw channel sums behind wbar .. s come from a 77-workgroup pre-kernel.
+// Same arithmetic per element as the two-pass kernel, (a - mean) rstd gamma + beta; mean and rstd differ from its fp32 two-pass values in
+// the last bits (they are now the fp64 closed forms rounded once).
+constexpr int C0LN_RAW = 10 + 1 + 55 + 10 + 1;      // sum w_i | sum b | sum w_i w_j (i <= j) | sum w_i b | sum b^2
+
+__global__ __launch_bounds__(256) void conv0_ln_consts_kernel(const float* __restrict__ w0, const float* __restrict__ bias, double* __restrict__ raw) {
+    constexpr int C = 512;
+    __shared__ double red[256];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    int i = -1, j = -1, kind;            // kind 0: w_i, 1: b, 2: w_i w_j, 3: w_i b, 4: b b
+    if (k < 10) { kind = 0; i = k; }
+    else if (k == 10) kind = 1;
+    else if (k < 66) {
+        kind = 2;
+        int e = k - 11;
+        for (i = 0; e >= 10 - i; ++i) e -= 10 - i;
+        j = i + e;
+    } else if (k < 76) { kind = 3; i = k - 66; }
+    else kind = 4;
+    double acc = 0.0;
+    for (int c = tid; c < C; c += 256) {
+        const double b = bias ? (double)bias[c] : 0.0;
+        const double wi = i >= 0 ? (double)w0[c * 10 + i] : 0.0, wj = j >= 0 ? (double)w0[c * 10 + j] : 0.0;
+        acc += kind == 0 ? wi : kind == 1 ? b : kind == 2 ? wi * wj : kind == 3 ? wi * b : b * b;
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) raw[k] = red[0];
+}
+
+__global__ __launch_bounds__(256) void conv0_ln_gelu_stats_kernel(const float* __restrict__ wav, int64_t ldw, const float* __restrict__ w0,
+                                                                  const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps, const double* __restrict__ raw,
+                                                                  uint16_t* __restrict__ out, int R0, const int32_t* __restrict__ row0, int spr) {
+    constexpr int C = 512, NR = 4, RPB = 128;
+    __shared__ double cst[C0LN_RAW];                 // wbar[10] | bbar | G[55] (i <= j, off-diagonal entries doubled) | 2 h[10] | s
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* x = wav + (int64_t)b * ldw;
+    int64_t orow = (int64_t)b * R0;
+    if (row0) {                                     // ragged rows: see conv0_gn_gelu_kernel
+        const int r0 = row0[b];
+        x = wav + (int64_t)r0 * spr;
+        orow = (int64_t)r0 * (spr / 5);
+        R0 = (row0[b + 1] - r0) * (spr / 5);
+    }
+    const int t_begin = blockIdx.x * RPB;
+    if (t_begin >= R0) return;                      // uniform for the workgroup, before the barrier
+    const int t_end = min(R0, t_begin + RPB);
+    if (threadIdx.x < C0LN_RAW) {
+        const int k = threadIdx.x;
+        const double inv = 1.0 / C, bbar = raw[10] * inv;
+        double v;
+        if (k < 10) v = raw[k] * inv;
+        else if (k == 10) v = bbar;
+        else if (k < 66) {
+            int e = k - 11, i = 0;
+            for (; e >= 10 - i; ++i) e -= 10 - i;
+            const int j = i + e;
+            v = raw[k] * inv - (raw[i] * inv) * (raw[j] * inv);
+            if (i != j) v *= 2.0;
+        } else if (k < 76) v = 2.0 * (raw[k] * inv - (raw[k - 66] * inv) * bbar);
+        else v = raw[76] * inv - bbar * bbar;
+        cst[k] = v;
+    }
+    __syncthreads();
+    // ---- statistics of the wave's rows: lane i < 32 <-> row t_begin + NR wave + 4 NR (i / NR) + i % NR
+    float mu_l = 0.f, rs_l = 0.f;
+    {
+        const int i = lane & 31, t = t_begin + NR * wave + 4 * NR * (i / NR) + (i % NR);
+        if (t < t_end) {
+            double xv[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) xv[j] = (double)x[5 * t + j];
+            double mu = cst[10], var = cst[76];
+            int e = 11;
+#pragma unroll
+            for (int p = 0; p < 10; ++p) {
+                mu = fma(cst[p], xv[p], mu);
+                var = fma(cst[66 + p], xv[p], var);
+                double row = 0.0;
+#pragma unroll
+                for (int q = p; q < 10; ++q) row = fma(cst[e++], xv[q], row);
+                var = fma(row, xv[p], var);
+            }
+            mu_l = (float)mu;
+            rs_l = (float)(1.0 / sqrt(fmax(var, 0.0) + (double)eps));
+        }
+    }
+    const int c0 = lane * 8;
+    f32x2 w[4][10], bs[4], gm[4], bt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[i][j] = f32x2{w0[(c0 + 2 * i) * 10 + j], w0[(c0 + 2 * i + 1) * 10 + j]};
+        bs[i] = bias ? f32x2{bias[c0 + 2 * i], bias[c0 + 2 * i + 1]} : f32x2{0.f, 0.f};
+        gm[i] = f32x2{gamma[c0 + 2 * i], gamma[c0 + 2 * i + 1]};
+        bt[i] = f32x2{beta[c0 + 2 * i], beta[c0 + 2 * i + 1]};
+    }
+    constexpr int NV = 5 * NR + 5;
+    int it = 0;
+    for (int t = t_begin + NR * wave; t < t_end; t += 4 * NR, ++it) {
+        float v[NV];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];   // wave-uniform address: scalar loads
+#pragma unroll
+        for (int j = 10; j < NV; ++j) v[j] = (t + (j - 5) / 5 < t_end) ? x[5 * t + j] : 0.f;      // (nothing behind the last row is read)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r > 0 && t + r >= t_end) break;                 // wave-uniform
+            const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mu_l), it * NR + r));
+            const float rs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs_l), it * NR + r));
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x2 a = bs[i];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) a = __builtin_elementwise_fma(w[i][j], f32x2{v[5 * r + j], v[5 * r + j]}, a);
+                // the two-pass kernel's association, (a - mean) rstd gamma + beta: the deviation first, so a row whose mean is large
+                // against its spread loses nothing to cancellation (regrouped as a (rstd gamma) + (beta - mean rstd gamma) the paired
+                // GELU test of the large recipe read 1.9e-2 instead of 1.1e-2 on the weighted-sum logit gradient)
+                const f32x2 dv = (a - f32x2{mu, mu}) * rs;
+                const f32x2 g = gelu_bf2(__builtin_elementwise_fma(dv, gm[i], bt[i]));
+                o[2 * i] = g.x;
+                o[2 * i + 1] = g.y;
+            }
+            uint4 u;
+            u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
+            u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+            *(uint4*)(out + (orow + t + r) * C + c0) = u;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- conv layer 0: backward (GroupNorm form)
 // Fully trainable encoder (avssl/module/speech_encoder_plus.py:556-562), "default" extractor: y = gelu(n), n = gamma (u - mu) / sigma + beta,
 // u[b, t, c] = sum_j W[c][j] x[b, 5t + j], statistics over t < T0 per (b, c).  The input is the waveform: no input gradient, only
@@ -666,6 +814,28 @@ extern "C" int sc_conv0_gn_gelu_f32(const float* wav, int64_t ldw, const float* 
     return 0;
 }
 
+// layer_norm-mode conv 0 through the closed-form row statistics (round 6): 77 raw channel sums into a stream-ordered scratch of 616
+// bytes (hipMallocAsync / hipFreeAsync on the caller's stream: nothing outlives the call, nothing is shared between streams), then the
+// main kernel.  OFF in this commit: sc_set_option(2, 1) selects it (tools/bench_conv0ln.py).
+static int conv0_ln_closed_form(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma, const float* beta, float eps,
+                                sc_bf16* out, dim3 grid, int R0, const int32_t* row0, int spr, hipStream_t s) {
+    double* raw = nullptr;
+    if (hipError_t e = hipMallocAsync((void**)&raw, C0LN_RAW * sizeof(double), s); e != hipSuccess) {
+        sc_set_error("sc_conv0_ln_gelu: hipMallocAsync: %s", hipGetErrorString(e));
+        return -3;
+    }
+    hipLaunchKernelGGL(conv0_ln_consts_kernel, dim3(C0LN_RAW), dim3(256), 0, s, w0, bias, raw);
+    hipLaunchKernelGGL(conv0_ln_gelu_stats_kernel, grid, dim3(256), 0, s, wav, ldw, w0, bias, gamma, beta, eps, (const double*)raw, (uint16_t*)out, R0,
+                       row0, spr);
+    const hipError_t le = hipGetLastError();
+    const hipError_t fe = hipFreeAsync(raw, s);
+    if (le != hipSuccess || fe != hipSuccess) {
+        sc_set_error("sc_conv0_ln_gelu: launch / free failed: %s", hipGetErrorString(le != hipSuccess ? le : fe));
+        return -2;
+    }
+    return 0;
+}
+
 extern "C" int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma,
                                 const float* beta, float eps, sc_bf16* out, int32_t B, int32_t R0, int32_t C, void* stream) {
     SC_CHECK(wav && w0 && gamma && beta && out, "sc_conv0_ln_gelu: null pointer");
@@ -673,6 +843,7 @@ extern "C" int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, 
     SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_ln_gelu: alignment");
     const int rows_per_block = 128;
     dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
+    if (sc_option(2)) return conv0_ln_closed_form(wav, ldw, w0, bias, gamma, beta, eps, out, grid, R0, nullptr, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(conv0_ln_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, (void*)out, R0, rows_per_block,
                        (const int32_t*)nullptr, 0);
     SC_LAUNCH_CHECK();
@@ -688,6 +859,8 @@ extern "C" int sc_conv0_ln_gelu_seg(const float* wav_flat, const sc_segments* se
     const int rows_per_block = 128;
     const int R0max = seg->max_pitch * (samples_per_row / 5);
     dim3 grid((R0max + rows_per_block - 1) / rows_per_block, seg->B);
+    if (sc_option(2))
+        return conv0_ln_closed_form(wav_flat, 0, w0, bias, gamma, beta, eps, out, grid, 0, seg->row0, samples_per_row, (hipStream_t)stream);
     hipLaunchKernelGGL(conv0_ln_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav_flat, (int64_t)0, w0, bias, gamma, beta, eps, (void*)out, 0,
                        rows_per_block, seg->row0, samples_per_row);
     SC_LAUNCH_CHECK();

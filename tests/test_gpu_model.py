@@ -227,7 +227,9 @@ LP_HIDDEN = 2e-2           # hidden states, rel-L2 per layer vs control (SURVEY 
 # computed by the two oracles on the CPU inside the test:
 LP_WSUM_RMS = 1.0          # rms over the seeds of e(HIP, control) <= R: the kernels add no more than the storage format does
 LP_WSUM_MAX = 3.0          # every seed: e(HIP, control) <= 3 R
-LP_PAIR_RMS = 1.0          # shipped five-term GELU build vs exact-GELU build: rms e(shipped, exact) <= R, every seed <= 3 R
+LP_PAIR_RMS = 2.0 ** 0.5    # shipped five-term GELU build vs exact-GELU build: rms e(shipped, exact) <= sqrt(2) R (derivation: doc-string,
+                           # "Paired activation check"; rounds 6a's value 1.0 was the EXPECTED value of the statistic for two equally good
+                           # builds with independent noise, i.e. a coin flip), every seed <= 3 R
 LP_PAIR_LOSS = 1e-3        # |loss(shipped) - loss(exact build)| per seed; the MEAN over the seeds <= 3e-4 (the rejected three-term fit moved the
                            # loss by 6e-4 systematically)
 LP_PAIR_T = 3.0            # paired t statistic of e(shipped, control) - e(exact, control) over the seeds
@@ -254,7 +256,20 @@ def test_large_parallel_train_step():
     Paired activation check.  Both builds run the same seeds; a SYSTEMATIC activation error shows as (a) the builds'
     gradients apart by more than the storage noise (LP_PAIR_RMS), (b) a loss offset common to the seeds (mean <= 3e-4), (c) the shipped
     build systematically farther from the control (paired t <= 3), (d) hidden states apart by more than the tolerance.  Element level,
-    high power: tests/test_gpu_kernels.py::test_gelu_fit_vs_exact_build_elementwise."""
+    high power: tests/test_gpu_kernels.py::test_gelu_fit_vs_exact_build_elementwise.
+
+    LP_PAIR_RMS, derived (round 6, committed with the two-pass conv-0 kernel as the default, on which the statistic reads 1.11e-2 and
+    passes the old and the new value alike).  g_ship - g_exact = (g_ship - g_ctrl) - (g_exact - g_ctrl).  Each bracket is bounded in rms by
+    LP_WSUM_RMS R = R.  The two builds share their inputs but NOT their rounding decisions: one bf16 value that rounds the other way in a
+    conv or FFN activation re-draws the noise of everything behind it, so the brackets are at most partially correlated, and for
+    uncorrelated brackets rms e(shipped, exact) = sqrt(e_ship^2 + e_exact^2) <= sqrt(2) R.  The first version of this test asked <= 1.0 R,
+    which with the measured e_ship = 1.2e-2, e_exact = 1.0 .. 1.2e-2, R = 1.62e-2 is the statistic's own expected value
+    sqrt(1.2^2 + 1.1^2) = 1.63e-2 - a coin flip.  Evidence that the statistic is a noise realisation and not a property of the GELU fit:
+    three conv-0 kernels of the layer_norm extractor that are equally accurate against fp64 (tools/bench_conv0ln.py: max error 1.56e-2,
+    rel-L2 1.66e-3 each; they differ from one another in 2e-5 of the bf16 values, BOTH builds of a pair using the same one) read 1.11e-2
+    (two-pass wave reductions), 1.63e-2 (closed-form statistics, the two-pass kernel's association), 1.87e-2 (closed form, regrouped
+    affine).  A systematic activation bias b adds as sqrt(noise^2 + b^2) and is still caught at b ~ R; (b), (c), (d) and the element-level
+    test keep their bounds."""
     import oracle
     from speechclip_plus_amd import _lib
     model, sd, o_arch, head_W = _large_parallel_model()
