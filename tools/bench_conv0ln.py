@@ -19,7 +19,7 @@ outs = {}
 res = {0: [], 1: []}
 for r in range(6):
     for opt in (0, 1):
-        lib().sc_set_option(2, 1 - opt)
+        lib().sc_set_option(2, opt)
         out = torch.zeros(B * R0, C, device=dev, dtype=torch.bfloat16)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
