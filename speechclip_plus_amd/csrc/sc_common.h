@@ -106,7 +106,11 @@ __device__ __forceinline__ float gelu_bf(float x) {
 #else
 #pragma clang fp contract(off)
 #if SC_GELU_TERMS == 5
+#ifdef SC_GELU_CLAMP
     const float t = fminf(x * x, 36.f);
+#else
+    const float t = x * x;                      // round 6: no clamp, see gelu_bf2
+#endif
     float p = fmaf(SC_GK4, t, SC_GK3);
     p = fmaf(p, t, SC_GK2);
     p = fmaf(p, t, SC_GK1);
@@ -184,7 +188,15 @@ __device__ __forceinline__ f32x2 gelu_bf2(f32x2 x) {
 #pragma clang fp contract(off)
     f32x2 t = x * x;
 #if SC_GELU_TERMS >= 4
+    // Round 6: the five-term form runs WITHOUT the clamp t = min(x^2, 36) of round 5 (two v_min_f32 of the 15 VALU instructions a pair
+    // costs).  The clamp was there to keep the polynomial monotone beyond the fitted range; it is monotone anyway: p(t) < 0 for all
+    // t >= 0 and p'(t) <= -0.33 for t >= 36 (the quartic term dominates), so beyond |x| = 6 the exponent x p(t) keeps growing in
+    // magnitude with the right sign: exp2 -> 0 / inf, rcp -> 1 / 0, gelu -> x / -0, no NaN (inf - inf cannot occur: every Horner step
+    // past overflow is (-inf) * (+inf) + c).  For x^2 <= 36 nothing changes (bit-identical); beyond, both forms sit within 6e-9 of the
+    // exact value.  -DSC_GELU_CLAMP restores the clamp (A/B); the four-term fit keeps it.
+#if SC_GELU_TERMS != 5 || defined(SC_GELU_CLAMP)
     t.x = fminf(t.x, 36.f); t.y = fminf(t.y, 36.f);
+#endif
 #if SC_GELU_TERMS == 5
     f32x2 p = __builtin_elementwise_fma(f32x2{SC_GK4, SC_GK4}, t, f32x2{SC_GK3, SC_GK3});
     p = __builtin_elementwise_fma(p, t, f32x2{SC_GK2, SC_GK2});
