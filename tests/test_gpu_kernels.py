@@ -1520,8 +1520,8 @@ def test_attention_backward_is_bitwise_repeatable(dev):
 
 
 def test_bf16_site_gelu_against_the_exact_erf_gelu():
-    """csrc/sc_common.h gelu_bf / gelu_bf2 (round 5): the erf-GELU of every bf16-OUTPUT site is x * sigmoid(x p(t)), t = min(x^2, 36), p
-    a five-term polynomial (fitted: tools/fit_gelu.py), because the FC1 / conv epilogues are VALU-bound on the activation.  Against the
+    """csrc/sc_common.h gelu_bf / gelu_bf2 (round 5): the erf-GELU of every bf16-OUTPUT site is x * sigmoid(x p(t)), t = x^2 (round 5 clamped t at 36; round 6 dropped the
+    clamp - p is negative and monotone beyond the fitted range, the bounds below are unchanged), p a five-term polynomial (fitted: tools/fit_gelu.py), because the FC1 / conv epilogues are VALU-bound on the activation.  Against the
     exact x Phi(x) (fairseq nn.GELU, torch erf form) on EVERY bf16 input in [-16, 16]: the fp32 error behind the bf16 store is bounded by
     3.5e-6 absolute - so the stored value is the exact result's bf16 rounding or, on a rounding boundary, its neighbour; for x >= -1 the
     fit's RELATIVE error is <= 2.1e-5, i.e. the stored value is within one bf16 rounding (<= 2^-8 relative) + 3e-5 of the exact one; the
