@@ -816,13 +816,14 @@ extern "C" int sc_conv0_gn_gelu_f32(const float* wav, int64_t ldw, const float* 
 
 // layer_norm-mode conv 0 through the closed-form row statistics (round 6): 77 raw channel sums into a stream-ordered scratch of 616
 // bytes (hipMallocAsync / hipFreeAsync on the caller's stream: nothing outlives the call, nothing is shared between streams), then the
-// main kernel.  sc_set_option(2, 1): the two-pass reduction kernel, for A/B (tools/bench_conv0ln.py).
+// main kernel.  sc_set_option(2, 1): the two-pass reduction kernel, for A/B (tools/bench_conv0ln.py).  Returns 1 (caller falls back to
+// the two-pass kernel) when the runtime has no stream-ordered allocator.
 static int conv0_ln_closed_form(const float* wav, int64_t ldw, const float* w0, const float* bias, const float* gamma, const float* beta, float eps,
                                 sc_bf16* out, dim3 grid, int R0, const int32_t* row0, int spr, hipStream_t s) {
     double* raw = nullptr;
-    if (hipError_t e = hipMallocAsync((void**)&raw, C0LN_RAW * sizeof(double), s); e != hipSuccess) {
-        sc_set_error("sc_conv0_ln_gelu: hipMallocAsync: %s", hipGetErrorString(e));
-        return -3;
+    if (hipMallocAsync((void**)&raw, C0LN_RAW * sizeof(double), s) != hipSuccess) {
+        (void)hipGetLastError();                    // no stream-ordered allocator on this runtime / device: the two-pass kernel needs no scratch
+        return 1;
     }
     hipLaunchKernelGGL(conv0_ln_consts_kernel, dim3(C0LN_RAW), dim3(256), 0, s, w0, bias, raw);
     hipLaunchKernelGGL(conv0_ln_gelu_stats_kernel, grid, dim3(256), 0, s, wav, ldw, w0, bias, gamma, beta, eps, (const double*)raw, (uint16_t*)out, R0,
@@ -843,7 +844,10 @@ extern "C" int sc_conv0_ln_gelu(const float* wav, int64_t ldw, const float* w0, 
     SC_CHECK(((uintptr_t)out % 16) == 0, "sc_conv0_ln_gelu: alignment");
     const int rows_per_block = 128;
     dim3 grid((R0 + rows_per_block - 1) / rows_per_block, B);
-    if (!sc_option(2)) return conv0_ln_closed_form(wav, ldw, w0, bias, gamma, beta, eps, out, grid, R0, nullptr, 0, (hipStream_t)stream);
+    if (!sc_option(2)) {
+        const int rc = conv0_ln_closed_form(wav, ldw, w0, bias, gamma, beta, eps, out, grid, R0, nullptr, 0, (hipStream_t)stream);
+        if (rc <= 0) return rc;
+    }
     hipLaunchKernelGGL(conv0_ln_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, ldw, w0, bias, gamma, beta, eps, (void*)out, R0, rows_per_block,
                        (const int32_t*)nullptr, 0);
     SC_LAUNCH_CHECK();
@@ -859,8 +863,10 @@ extern "C" int sc_conv0_ln_gelu_seg(const float* wav_flat, const sc_segments* se
     const int rows_per_block = 128;
     const int R0max = seg->max_pitch * (samples_per_row / 5);
     dim3 grid((R0max + rows_per_block - 1) / rows_per_block, seg->B);
-    if (!sc_option(2))
-        return conv0_ln_closed_form(wav_flat, 0, w0, bias, gamma, beta, eps, out, grid, 0, seg->row0, samples_per_row, (hipStream_t)stream);
+    if (!sc_option(2)) {
+        const int rc = conv0_ln_closed_form(wav_flat, 0, w0, bias, gamma, beta, eps, out, grid, 0, seg->row0, samples_per_row, (hipStream_t)stream);
+        if (rc <= 0) return rc;
+    }
     hipLaunchKernelGGL(conv0_ln_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav_flat, (int64_t)0, w0, bias, gamma, beta, eps, (void*)out, 0,
                        rows_per_block, seg->row0, samples_per_row);
     SC_LAUNCH_CHECK();
