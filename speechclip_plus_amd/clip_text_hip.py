@@ -12,7 +12,8 @@ has kernels of its own, one wave per (sequence, head), forward 1 launch and back
 (csrc/attn_short.hip) instead of V^T + forward and row sums + dQ + dK/dV on 128-row blocks that are 7/8 mask:
 
     forward   LN -> QKV GEMM -> causal attention (+ LSE) -> out-proj GEMM (+ residual) -> LN -> FC GEMM -> QuickGELU
-              -> proj GEMM (+ residual)
+              -> proj GEMM (+ residual)        (SC_TOWER_FOLD_LN=1: both LayerNorms in the prologue of the GEMM behind them, 5 launches
+              per layer - measured slower, see FOLD_LN)
     backward  dgrad GEMMs against transposed weight copies, QuickGELU' , LayerNorm backward fused with the residual add,
               attention backward (csrc/attention_bwd.hip)
 
@@ -26,6 +27,12 @@ import torch
 
 from . import ops
 
+import os as _os
+# LayerNorm in the prologue of the tower's QKV / fc GEMMs (round 6: built, parity-green - closer to fp64 than LayerNorm + GEMM, one bf16
+# rounding less - and SLOWER: every one of a row tile's 24-48 column workgroups re-reads and re-reduces the tile's rows before its
+# K loop; same-box alternating runs: cascaded+ 14.76 -> 14.97 ms per step (one stream 16.1 -> 16.45), hybrid+ large 31.85 -> 32.35).
+# Opt-in: SC_TOWER_FOLD_LN=1; the default keeps the LayerNorm launches.
+FOLD_LN = _os.environ.get("SC_TOWER_FOLD_LN", "0") == "1"
 BLOCK = 128         # rows of an attention block
 SHORT = 32          # segment length served by the one-wave attention kernels
 
@@ -38,7 +45,8 @@ def _segment(T: int) -> int:
 
 
 class _LayerW:
-    __slots__ = ("wqkv", "bqkv", "wqkvT", "wo", "bo", "woT", "w1", "b1", "w1T", "w2", "b2", "w2T", "g1", "be1", "g2", "be2", "eps1", "eps2")
+    __slots__ = ("wqkv", "bqkv", "wqkvT", "wo", "bo", "woT", "w1", "b1", "w1T", "w2", "b2", "w2T", "g1", "be1", "g2", "be2", "eps1", "eps2",
+                 "wqkv_ln", "sqkv", "cqkv", "w1_ln", "s1", "c1")
 
 
 def prepare_weights(transformer, device) -> List[_LayerW]:
@@ -54,6 +62,11 @@ def prepare_weights(transformer, device) -> List[_LayerW]:
         w.w2, w.b2, w.w2T = bf(blk.mlp.c_proj.weight), f32(blk.mlp.c_proj.bias), bf(blk.mlp.c_proj.weight.t())
         w.g1, w.be1, w.eps1 = f32(blk.ln_1.weight), f32(blk.ln_1.bias), blk.ln_1.eps
         w.g2, w.be2, w.eps2 = f32(blk.ln_2.weight), f32(blk.ln_2.bias), blk.ln_2.eps
+        # round 6: ln_1 / ln_2 folded into the QKV / fc GEMMs (LayerNorm in the GEMM's prologue: ops.fold_layernorm, csrc/gemm_bf16.hip) -
+        # the forward runs 5 launches per layer instead of 7; the backward keeps the unfolded weights (it differentiates through the
+        # LayerNorm from the saved raw rows)
+        w.wqkv_ln, w.sqkv, w.cqkv = ops.fold_layernorm(blk.attn.in_proj_weight.to(device), blk.attn.in_proj_bias.to(device), w.g1, w.be1)
+        w.w1_ln, w.s1, w.c1 = ops.fold_layernorm(blk.mlp.c_fc.weight.to(device), blk.mlp.c_fc.bias.to(device), w.g2, w.be2)
         out.append(w)
     return out
 
@@ -85,9 +98,13 @@ def tower_forward(X: torch.Tensor, weights, heads: int, causal: int):
     scale = (W // heads) ** -0.5
     saved = []
     short = causal == SHORT                              # one 32-row segment per sequence: the one-wave kernels (csrc/attn_short.hip)
+    fold = FOLD_LN and W <= 1024
     for w in weights:
-        h = ops.layernorm_bf16(X, w.g1, w.be1, eps=w.eps1)
-        qkv = ops.linear_bf16(h, w.wqkv, w.bqkv)
+        if fold:
+            qkv = ops.linear_bf16(X, w.wqkv_ln, w.cqkv, ln_colsum=w.sqkv, ln_eps=w.eps1)          # LN1 in the GEMM's prologue
+        else:
+            h = ops.layernorm_bf16(X, w.g1, w.be1, eps=w.eps1)
+            qkv = ops.linear_bf16(h, w.wqkv, w.bqkv)
         if short:
             att, lse2 = ops.attn32_fwd(qkv, heads, scale), None
         else:
@@ -96,9 +113,12 @@ def tower_forward(X: torch.Tensor, weights, heads: int, causal: int):
             lse2 = torch.empty(NB, heads, BLOCK, device=dev, dtype=torch.float32)
             ops.attn_fwd(qkv[:, : 2 * W], vt, valid, att, NB, BLOCK, heads, W, scale, lse2=lse2, causal=causal)
         X2 = ops.linear_bf16(att, w.wo, w.bo, residual=X)
-        h2 = ops.layernorm_bf16(X2, w.g2, w.be2, eps=w.eps2)
         u = torch.empty(M, w.w1.shape[0], device=dev, dtype=torch.bfloat16)
-        f = ops.linear_bf16(h2, w.w1, w.b1, act=2, aux=u, aux_mode=1)          # u = fc1 pre-activation (kept), f = QuickGELU(u)
+        if fold:
+            f = ops.linear_bf16(X2, w.w1_ln, w.c1, act=2, aux=u, aux_mode=1, ln_colsum=w.s1, ln_eps=w.eps2)      # LN2 in the prologue
+        else:
+            h2 = ops.layernorm_bf16(X2, w.g2, w.be2, eps=w.eps2)
+            f = ops.linear_bf16(h2, w.w1, w.b1, act=2, aux=u, aux_mode=1)          # u = fc1 pre-activation (kept), f = QuickGELU(u)
         Xn = ops.linear_bf16(f, w.w2, w.b2, residual=X2)
         saved.append((X, qkv, None if short else att, lse2, X2, u))
         X = Xn

@@ -30,7 +30,8 @@ struct GemmCfg {
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     static constexpr int STAGE_BYTES = NS * (A_BYTES + B_BYTES);
     static constexpr int EPI_BYTES = BM * BN * 4;
-    static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+    static constexpr int RING_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+    static constexpr int LDS_BYTES = RING_BYTES + BM * 8;       // + (mean, rstd) of the tile's rows: the LayerNorm-prologue mode
 };
 
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
@@ -118,16 +119,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
         for (int kk = 0; kk < 2; ++kk) b_off[ni][kk] = row * ROWB + (((kk * 4 + (lane >> 4)) ^ ((row >> 1) & 7)) << 4);
     }
 
-    // accumulators start from the bias (same summation order as gemm256_bf16.hip: the tile variants agree bitwise)
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int ni = 0; ni < FN; ++ni) {
-        const int n = n0 + wn * TN + ni * 16 + (lane & 15);
-        const float bv = (bias && n < p.N) ? bias[n] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < FM; ++mi) acc[mi][ni] = f32x4{bv, bv, bv, bv};
-    }
-
     const int nk = p.K / BK;
     // K-tile order of conv-shaped problems (sc_gemm_args.tap_c, see gemm256_bf16.hip): the same order in every kernel, so the
     // result does not depend on which tile family the dispatcher picks for a given row count
@@ -137,6 +128,73 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
         const int c = kt / 3, j = kt - 3 * c;
         return (j == 0 ? 0 : (3 - j) * tap_c) + c * BK;
     };
+    // the first NS - 1 K-tiles go into flight here, ahead of the optional statistics prologue
+    if constexpr (NS == 2) {
+        stage(0, 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NS - 1; ++j)
+            if (j < nk) stage(j, koff(j));
+    }
+
+    // ---- LayerNorm in the PROLOGUE (round 6; the text tower's LN -> QKV and LN -> fc1 pairs: K = the model width, so a tile holds whole
+    // rows of A).  ln_colsum given WITHOUT ln_stats: A holds RAW rows, W = W0 diag(gamma) folded by the caller, and
+    //     C = rstd_m (A W^T - mean_m ln_colsum) + bias,   ln_colsum[n] = sum_k W[n, k],  bias[n] = sum_k beta[k] W0[n, k] + bias0[n]
+    // (the LN = 1 consumer of gemm256_bf16.hip), with mean_m / rstd_m computed HERE: every workgroup reads its BM rows once more (two
+    // passes in registers, half a wave per row as layernorm16_kernel; they come out of the L2 - the DMA of K-tile 0 is already in
+    // flight) instead of a LayerNorm launch writing and this kernel re-reading a normalised copy.
+    const bool ln_self = p.ln_colsum != nullptr && p.ln_stats == nullptr;
+    float* const row_stat = (float*)(smem + Cfg::RING_BYTES);          // [BM][2]
+    if (ln_self) {
+        const int l = tid & 31, hw = tid >> 5;
+        const int nch = p.K >> 3;                                        // 16-byte chunks per row (K <= 1024: at most 4 per lane)
+        for (int r = hw; r < BM; r += 8) {
+            const uint16_t* xr = A + (int64_t)min(m0 + r, p.M - 1) * p.lda;
+            float v[4][8];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = l + i * 32;
+                if (ch < nch) {
+                    const uint4 u = *(const uint4*)(xr + ch * 8);
+                    v[i][0] = bflo(u.x); v[i][1] = bfhi(u.x); v[i][2] = bflo(u.y); v[i][3] = bfhi(u.y);
+                    v[i][4] = bflo(u.z); v[i][5] = bfhi(u.z); v[i][6] = bflo(u.w); v[i][7] = bfhi(u.w);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum += v[i][j];
+                }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum / (float)p.K;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (l + i * 32 < nch) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float d = v[i][j] - mean;
+                        sq = fmaf(d, d, sq);
+                    }
+                }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            if (l == 0) {
+                row_stat[2 * r] = mean;
+                row_stat[2 * r + 1] = rsqrtf(sq / (float)p.K + p.ln_eps);
+            }
+        }
+        // (visible to the epilogue: the K loop below has at least one workgroup barrier)
+    }
+    // accumulators start from the bias (same summation order as gemm256_bf16.hip: the tile variants agree bitwise)
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int ni = 0; ni < FN; ++ni) {
+        const int n = n0 + wn * TN + ni * 16 + (lane & 15);
+        const float bv = (bias && n < p.N && !ln_self) ? bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) acc[mi][ni] = f32x4{bv, bv, bv, bv};
+    }
+
     auto mma_tile = [&](int buf) {
         const char* as = As + buf * Cfg::A_BYTES;
         const char* bs = Bs + buf * Cfg::B_BYTES;
@@ -155,7 +213,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
         }
     };
     if constexpr (NS == 2) {
-        stage(0, 0);
         __syncthreads();   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
@@ -168,9 +225,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
         // wave), barrier (every wave's share has landed, and every wave is done with tile kt - 1), re-stage tile kt - 1's buffer
         // with tile kt + NS - 1, multiply.
         constexpr int IPW = A_INST + B_INST;                  // LDS-DMA instructions per wave and stage
-#pragma unroll
-        for (int j = 0; j < NS - 1; ++j)
-            if (j < nk) stage(j, koff(j));
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -197,6 +251,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const sc_gemm_args p) {
         for (int mi = 0; mi < FM; ++mi) {
             const int ml = wm * TM + mi * 16 + 4 * (lane >> 4);
             f32x4 v = acc[mi][ni];
+            if (ln_self) {                                  // y = rstd_m (acc - mean_m s_n) + c_n
+                const float sn = n < p.N ? p.ln_colsum[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x2 st = *(const f32x2*)(row_stat + 2 * (ml + r));
+                    v[r] = fmaf(st.y, fmaf(-st.x, sn, v[r]), bv);
+                }
+            }
             if (p.act == 1 && p.aux_mode == 0) {
                 const f32x2 g0 = gelu_bf2(f32x2{v[0], v[1]}), g1 = gelu_bf2(f32x2{v[2], v[3]});
                 v = f32x4{g0.x, g0.y, g1.x, g1.y};
@@ -371,6 +433,14 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
         SC_CHECK(a.act == 0 || a.act == 1, "sc_gemm_bf16: act=%d (2 = QuickGELU needs aux_mode)", a.act);
     }
     const bool ln = a.ln_stats || a.stats_out || a.res_stats;
+    const bool ln_self = a.ln_colsum && !a.ln_stats;            // LayerNorm in the prologue of the 128- / 64-row tiles (gemm_bf16_kernel)
+    if (ln_self) {
+        SC_CHECK(!a.stats_out && !a.res_stats && a.K <= 1024 && a.ln_eps > 0.f && a.tap_c == 0 && !a.tn && a.n_split < 0 && a.lda >= a.K &&
+                     ((uintptr_t)a.ln_colsum % 4) == 0,
+                 "sc_gemm_bf16: LayerNorm prologue (ln_colsum without ln_stats) needs K <= 1024, ln_eps, plain rows and no transposed store (K=%d)", a.K);
+        SC_CHECK(a.tile == 0 || a.tile == 1 || a.tile == 3 || a.tile == 13 || a.tile == 14 || a.tile == 15,
+                 "sc_gemm_bf16: the LayerNorm prologue is built into the 128- and 64-row tiles (tile=%d)", a.tile);
+    }
     if (ln) {
         // LayerNorm folded into the GEMMs: built into the 256-row tile family only (csrc/gemm256_bf16.hip)
         SC_CHECK(a.tile == 0 || a.tile == 2 || a.tile == 7 || a.tile == 8, "sc_gemm_bf16: LayerNorm folding needs the 256-row tile family");
@@ -394,7 +464,7 @@ extern "C" int sc_gemm_bf16(const sc_gemm_args* args, void* stream) {
     if (tile == 0) {
         const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.nb1 * a.nb2;
         if (a.N <= 64 && a.n_split < 0) tile = 3;            // narrow outputs (grouped pos_conv, N = 48)
-        else if ((!a.aux_mode || (a.act == 1 && !a.residual)) && a.M >= 512 && a.N >= 192 && tiles256 >= 192 && (a.n_split < 0 || a.n_split % 64 == 0)) tile = 2;
+        else if (!ln_self && (!a.aux_mode || (a.act == 1 && !a.residual)) && a.M >= 512 && a.N >= 192 && tiles256 >= 192 && (a.n_split < 0 || a.n_split % 64 == 0)) tile = 2;
         else {
             // small problems (the text tower's 2048 packed rows): 128 x 64 tiles give twice the workgroups, 10-20 % faster up to two
             // waves of 128 x 128 tiles per CU (tools/bench_small_gemm.py)

@@ -176,6 +176,11 @@ def gemm_raw(A: torch.Tensor, lda: int, W: torch.Tensor, ldw: int, C: torch.Tens
         assert M == seg.rows
         a.seg_chunk = _p(seg.chunk)
     strips = 0
+    if ln_colsum is not None and ln_stats is None and stats_out is None:
+        # LayerNorm in the GEMM's prologue (128- / 64-row tiles, round 6): A holds raw rows, W = W0 diag(gamma), bias = c_n, the row
+        # statistics are computed by the kernel (csrc/gemm_bf16.hip: ln_self)
+        assert ln_colsum.dtype == torch.float32 and ln_colsum.is_contiguous() and ln_colsum.numel() == N and ln_eps > 0.0 and K <= 1024
+        a.ln_colsum, a.ln_eps = _p(ln_colsum), float(ln_eps)
     if ln_stats is not None or stats_out is not None:
         for t in (ln_stats, ln_colsum, res_stats, res_gamma, res_beta, stats_out):
             assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
@@ -242,9 +247,11 @@ def gemm_stats_strips(M: int, N: int) -> int:
 def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, act: int = 0, out_f32: bool = False,
                 alg_rows: Optional[int] = None, tile: int = 0, drop_p: float = 0.0, drop_seed: int = 0,
-                aux: Optional[torch.Tensor] = None, aux_mode: int = 0) -> torch.Tensor:
+                aux: Optional[torch.Tensor] = None, aux_mode: int = 0, ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = 0.0) -> torch.Tensor:
     """y[M, N] = epi(x[M, K] . w[N, K]^T) for contiguous 2-D operands.  ``aux`` / ``aux_mode`` (small problems, 128-row tiles):
-    1 = also store the pre-activation into ``aux`` and return act(it); 2 = return (x . w^T) * act'(aux)."""
+    1 = also store the pre-activation into ``aux`` and return act(it); 2 = return (x . w^T) * act'(aux).
+    ``ln_colsum`` / ``ln_eps``: y = epi(LayerNorm(x) . w0^T) with the LayerNorm in the GEMM's prologue - ``w`` = w0 diag(gamma),
+    ``ln_colsum[n]`` = sum_k w[n, k], ``bias[n]`` = sum_k beta[k] w0[n, k] + bias0[n] (``fold_layernorm``); K <= 1024."""
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
@@ -252,8 +259,20 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         out = torch.empty(M, N, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     gemm_raw(x, x.stride(0), w, w.stride(0), out, out.stride(0), M, N, K, bias=bias, residual=residual,
              ldr=residual.stride(0) if residual is not None else 0, act=act, out_f32=out_f32, alg_rows=alg_rows, tile=tile,
-             drop_p=drop_p, drop_seed=drop_seed, aux=aux, aux_mode=aux_mode)
+             drop_p=drop_p, drop_seed=drop_seed, aux=aux, aux_mode=aux_mode, ln_colsum=ln_colsum, ln_eps=ln_eps)
     return out
+
+
+def fold_layernorm(w0: torch.Tensor, bias0: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """(w, ln_colsum, bias) for linear_bf16(..., ln_colsum=...): LayerNorm(x) w0^T + bias0 = rstd (x w^T - mean ln_colsum) + bias with
+    w = bf16(w0 diag(gamma)), ln_colsum = the row sums of the bf16 values the kernel multiplies, bias = bias0 + w0 beta (fp32)."""
+    w0f = w0.detach().float()
+    w = (w0f * gamma.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+    colsum = w.float().sum(dim=1).contiguous()
+    c = w0f @ beta.detach().float()
+    if bias0 is not None:
+        c = c + bias0.detach().float()
+    return w, colsum, c.contiguous()
 
 
 def attn_fwd(qk: torch.Tensor, vt: torch.Tensor, valid_len: torch.Tensor, out: torch.Tensor, B: int, R: int, H: int,

@@ -1549,3 +1549,41 @@ def test_bf16_site_gelu_against_the_exact_erf_gelu():
     assert torch.equal(y[big], x.float()[big])                                      # gelu(x) = x in bf16 beyond the clamp
     neg = x.float() <= -9.0
     assert float(y[neg].abs().max()) < 1e-10                                        # ... and 0 on the other side (exact: -1e-18 at x = -9)
+
+
+@pytest.mark.parametrize("M,N,K,act_aux", [(2048, 1536, 512, False), (2048, 2048, 512, True), (2048, 2304, 768, False), (200, 3072, 768, True), (96, 192, 1024, False)])
+def test_gemm_layernorm_prologue_against_layernorm_then_gemm(M, N, K, act_aux):
+    """Round 6: LayerNorm in the prologue of the 128- / 64-row GEMM tiles (the text tower's LN -> QKV / LN -> fc pairs; csrc/gemm_bf16.hip
+    ln_self, ops.fold_layernorm): y = rstd (x W'^T - mean colsum) + c against the two-launch sequence LayerNorm kernel -> GEMM and against
+    fp64.  Criterion fixed before the first run: the fused result's error against fp64 is at most 1.5 x the two-launch sequence's
+    (both are bf16-storage noise: the sequence rounds the normalised rows to bf16, the fused form rounds W diag(gamma)) + 1e-4 of the
+    output's rms, and the two agree to 1.5e-2 rel-L2; with the QuickGELU dual store both outputs (u and act(u)) are checked."""
+    from speechclip_plus_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 1.5 + torch.randn(M, 1, generator=g) * 0.7).to(torch.bfloat16)      # rows with a mean
+    w0 = torch.randn(N, K, generator=g) * K ** -0.5
+    b0 = torch.randn(N, generator=g) * 0.1
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    xd, w0d, b0d, gd, bd = x.cuda(), w0.cuda(), b0.cuda(), gamma.cuda(), beta.cuda()
+    w_ln, colsum, c = ops.fold_layernorm(w0d, b0d, gd, bd)
+    h = ops.layernorm_bf16(xd, gd, bd, eps=1e-5)
+    w_b = w0d.to(torch.bfloat16).contiguous()
+    ref = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5) @ w0.double().t() + b0.double()
+    rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())
+    if act_aux:
+        u1 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        u2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        f1 = ops.linear_bf16(xd, w_ln, c, act=2, aux=u1, aux_mode=1, ln_colsum=colsum, ln_eps=1e-5)
+        f2 = ops.linear_bf16(h, w_b, b0d, act=2, aux=u2, aux_mode=1)
+        ref_f = ref * torch.sigmoid(1.702 * ref)
+        pairs = ((u1, u2, ref), (f1, f2, ref_f))
+    else:
+        y1 = ops.linear_bf16(xd, w_ln, c, ln_colsum=colsum, ln_eps=1e-5)
+        y2 = ops.linear_bf16(h, w_b, b0d)
+        pairs = ((y1, y2, ref),)
+    for fused, seq, r in pairs:
+        e1, e2 = rel(fused, r), rel(seq, r)
+        print(f"M {M} N {N} K {K}: fused vs fp64 {e1:.3e}, LayerNorm + GEMM vs fp64 {e2:.3e}, fused vs sequence {rel(fused, seq.double().cpu()):.3e}")
+        assert torch.isfinite(fused.float()).all()
+        assert e1 <= 1.5 * e2 + 1e-4, (e1, e2)
+        assert rel(fused, seq.double().cpu()) <= 1.5e-2
