@@ -301,6 +301,17 @@ def test_bench_host_helpers():
     assert ragged["alg_gflop_per_utt"] < 0.55 * full["alg_gflop_per_utt"]      # shorter utterances count less than linearly (attention ~ T^2)
     same = bench.forward_summary(12.0, 64, 160000, 499, lens=[160000] * 64)
     assert abs(same["alg_gflop_per_utt"] - full["alg_gflop_per_utt"]) < 1e-6
+    # round 6: roofline.traffic from the counter passes of the same invocation - KiB per launch, FETCH x 2 (gfx950), the first launch
+    # of every instantiation dropped, every instantiation of the dominant kernel pooled; anything unusable -> None (stored-profile fallback)
+    live = {"void gemm256_kernel<0, 256, 1, 0, 0, 0>(sc_gemm_args)": {"fetch_kib": [9e9, 100.0, 300.0], "write_kib": [9e9, 50.0, 70.0]},
+            "void gemm256_kernel<0, 192, 0, 1, 1, 0>(sc_gemm_args)": {"fetch_kib": [9e9, 200.0], "write_kib": [9e9, 60.0]},
+            "void gemm256_kernel<4, 256, 0, 0, 0, 0>(sc_gemm_args)": {"fetch_kib": [1.0, 1.0], "write_kib": [1.0, 1.0]},
+            "attn_fwd_kernel<1, 0>": {"fetch_kib": [5.0, 5.0], "write_kib": [5.0, 5.0]}}
+    t = bench.traffic_from_live(live, "gemm256_kernel<0,")
+    assert t["traffic"] == round((2.0 * 600.0 + 180.0) * 1024.0 / 3) and t["traffic_fetch_bytes"] == round(2.0 * 600.0 * 1024.0 / 3)
+    assert t["traffic_write_bytes"] == round(180.0 * 1024.0 / 3) and t["traffic_source"].startswith("live:")
+    assert bench.traffic_from_live("rocprofv3 not found", "gemm256_kernel<0,") is None
+    assert bench.traffic_from_live({"gemm256_kernel<0, x>": {"fetch_kib": [1.0], "write_kib": [1.0, 2.0]}}, "gemm256_kernel<0,") is None
 
 
 @pytest.mark.parametrize("suffix", ["", "_b"])
