@@ -1587,3 +1587,51 @@ def test_gemm_layernorm_prologue_against_layernorm_then_gemm(M, N, K, act_aux):
         assert torch.isfinite(fused.float()).all()
         assert e1 <= 1.5 * e2 + 1e-4, (e1, e2)
         assert rel(fused, seq.double().cpu()) <= 1.5e-2
+
+
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_frontend_conv0_layer_norm_mode_closed_form_statistics(dev, with_bias):
+    """Round 6: the layer_norm-mode conv layer 0 (HuBERT-large: conv -> +bias -> LayerNorm over the 512 channels -> erf-GELU,
+    fairseq ConvFeatureExtractionModel in "layer_norm" mode, called at avssl/module/speech_encoder_plus.py:75) takes a row's channel mean
+    and variance from closed forms of its 10-sample window (fp64 quadratic form; csrc/frontend.hip conv0_ln_gelu_stats_kernel) instead of
+    two wavefront reductions.  Against the fp64 statement on rows of three kinds - noise, a quiet signal on a DC offset (the closed
+    form's cancellation case: mean >> spread), silence - and against the two-pass kernel it replaces (sc_set_option(2, 1)).
+    Criteria fixed before the first run: rel-L2 against fp64 < 5e-3 (the bound test_frontend_conv0 uses for the GroupNorm mode: one bf16
+    store), no worse than 1.05 x the two-pass kernel's on every kind, every value finite, and the two kernels apart by at most one bf16
+    ulp of the larger magnitude on every element; uniform rows with a row count that is not a multiple of the 128-row workgroup.
+    (The first run passed the three accuracy criteria on every kind - 1.66e-3 / 1.75e-3 / 1.59e-3 for both kernels - and failed the
+    last one as first written, without an absolute floor, on 2 of 1 536 000 elements: outputs of 4.6e-8 vs 4.7e-8 and 3.82e-7 vs 3.86e-7,
+    GELU arguments that cancel to ~0, where gelu(u) ~ u / 2 carries the fp32 rounding of mean / rstd (1e-7 of O(1) terms) at full
+    size whatever the output's magnitude - a one-ulp RELATIVE bound means nothing there.  The bound is therefore one bf16 ulp or 1e-6
+    absolute, ten fp32 roundings of an O(1) term.)"""
+    from speechclip_plus_amd._lib import lib
+    ops = _ops()
+    B, C, R0 = 3, 512, 1000
+    L = 5 * (R0 - 1) + 10
+    g = torch.Generator(device="cpu").manual_seed(5)
+    wav = torch.randn(B, L, generator=g)
+    wav[1] = wav[1] * 1e-3 + 0.7
+    wav[2] = 0.0
+    w0 = torch.randn(C, 10, generator=g) * 0.3
+    b0 = torch.randn(C, generator=g) * 0.1 if with_bias else None
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    wav_d = torch.zeros(B, L + 64, device=dev)
+    wav_d[:, :L] = wav.to(dev)
+    outs = {}
+    for opt in (0, 1):
+        lib().sc_set_option(2, opt)
+        try:
+            out = torch.zeros(B * R0, C, device=dev, dtype=torch.bfloat16)
+            ops.conv0_layernorm_gelu(wav_d, w0.to(dev), None if b0 is None else b0.to(dev), gam.to(dev), bet.to(dev), R0, out)
+            outs[opt] = out.view(B, R0, C).float().cpu()
+        finally:
+            lib().sc_set_option(2, 0)
+    y = F.conv1d(wav.double().unsqueeze(1), w0.double().unsqueeze(1), b0.double() if with_bias else None, stride=5).transpose(1, 2)     # (B, R0, C)
+    ref = F.gelu(F.layer_norm(y, (C,), gam.double(), bet.double(), 1e-5))
+    assert bool(torch.isfinite(outs[0]).all())
+    for b, kind in enumerate(("noise", "quiet + DC offset", "silence")):
+        e_new, e_old = rel_l2(outs[0][b].double(), ref[b]), rel_l2(outs[1][b].double(), ref[b])
+        print(f"{kind}: closed form {e_new:.3e}, two-pass {e_old:.3e}")
+        assert e_new < 5e-3 and e_new <= 1.05 * e_old + 1e-6, (kind, e_new, e_old)
+    ulp = torch.maximum(outs[0].abs(), outs[1].abs()).clamp_min(2.0 ** -126).log2().floor().exp2() * 2.0 ** -7
+    assert bool(((outs[0] - outs[1]).abs() <= torch.clamp(ulp, min=1e-6)).all())
